@@ -1,0 +1,11 @@
+"""gftorf_amd -- MI355X-native differentiable ToF Gaussian rasterizer.
+
+Drop-in for the reference's ``diff_gaussian_rasterization_w_tof`` extension
+(brownvc/gftorf, submodules/diff-gaussian-rasterization-w-tof): same Python
+operator API, hand-written gfx950 HIP kernels behind a C ABI
+(include/gftorf_rast.h).  See DESIGN.md.
+"""
+from .api import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians,  # noqa: F401
+                  _RasterizeGaussians)
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]

@@ -1,0 +1,154 @@
+"""ctypes binding of libgftorf_rast.so (include/gftorf_rast.h).
+
+The product path has no CPU fallback: if the HIP library is missing this module
+raises, it never routes anywhere else.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
+ABI_VERSION = 1
+ACC_STRIDE = 20
+
+_lib = None
+
+_fp = C.c_void_p  # every tensor pointer travels as void*
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("M_p", C.c_int32),
+        ("W", C.c_int32), ("H", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("near_n", C.c_float), ("far_n", C.c_float), ("depth_range", C.c_float),
+        ("phase_offset", C.c_float), ("dc_offset", C.c_float),
+        ("use_view_dependent_phase", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("bg_stride_c", C.c_int64), ("bg_stride_y", C.c_int64), ("bg_stride_x", C.c_int64),
+    ]
+
+
+FORWARD_FIELDS = [
+    "bg", "means3D", "colors_precomp", "phasors_precomp", "opacities", "scales", "rotations",
+    "cov3D_precomp", "viewmatrix", "projmatrix", "campos", "shs", "shs_p",
+    "geom", "img", "binning",
+    "out_color", "out_phasor", "out_depth", "out_normal", "out_acc", "out_entropy",
+    "out_depth_distortion", "out_amp_distortion", "pixels", "out_distribution", "radii",
+]
+
+BACKWARD_FIELDS = [
+    "bg", "means3D", "radii", "scales", "rotations", "cov3D_precomp", "viewmatrix", "projmatrix",
+    "campos", "shs", "shs_p",
+    "dL_dout_color", "dL_dout_phasor", "dL_dout_depth", "dL_dout_acc", "dL_dout_depth_distortion",
+    "geom", "img", "binning", "acc",
+    "dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dcov3D", "dL_dsh", "dL_dsh_p",
+    "dL_dscales", "dL_drotations", "dL_dphase_offset", "dL_ddc_offset",
+]
+
+LAYOUT_FIELDS = [
+    "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_offsets", "geom_clamped",
+    "geom_scan_tmp", "geom_total",
+    "img_pix_state", "img_ranges", "img_tile_max", "img_total",
+    "bin_keys_unsorted", "bin_keys", "bin_vals_unsorted", "bin_point_list", "bin_sort_tmp", "bin_total",
+]
+
+PROFILE_FIELDS = ["preprocess_fwd_ms", "scan_ms", "duplicate_ms", "sort_ms", "ranges_ms",
+                  "render_fwd_ms", "render_bwd_ms", "preprocess_bwd_ms", "memset_ms"]
+
+
+class ForwardIO(C.Structure):
+    _fields_ = [(n, _fp) for n in FORWARD_FIELDS]
+
+
+class BackwardIO(C.Structure):
+    _fields_ = [(n, _fp) for n in BACKWARD_FIELDS]
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in LAYOUT_FIELDS]
+
+
+class Profile(C.Structure):
+    _fields_ = [(n, C.c_double) for n in PROFILE_FIELDS] + [("forward_calls", C.c_int64),
+                                                           ("backward_calls", C.c_int64)]
+
+
+EXPORTS = [
+    "gft_abi_version", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes",
+    "gft_get_layout", "gft_forward_preprocess", "gft_forward_render", "gft_backward",
+    "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
+]
+
+
+def load():
+    """dlopen libgftorf_rast.so and declare prototypes.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "gftorf_amd: %s is missing. Build it with `python -m gftorf_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback for the rasterizer." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.gft_abi_version.restype = C.c_int
+    if lib.gft_abi_version() != ABI_VERSION:
+        raise RuntimeError("gftorf_amd: libgftorf_rast.so ABI %d != expected %d, rebuild"
+                           % (lib.gft_abi_version(), ABI_VERSION))
+    lib.gft_last_error.restype = C.c_char_p
+    lib.gft_geom_bytes.restype = C.c_size_t
+    lib.gft_geom_bytes.argtypes = [C.c_int32]
+    lib.gft_image_bytes.restype = C.c_size_t
+    lib.gft_image_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.gft_binning_bytes.restype = C.c_size_t
+    lib.gft_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    lib.gft_get_layout.restype = C.c_int
+    lib.gft_get_layout.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(Layout)]
+    lib.gft_forward_preprocess.restype = C.c_int
+    lib.gft_forward_preprocess.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO),
+                                           C.POINTER(C.c_int64)]
+    lib.gft_forward_render.restype = C.c_int
+    lib.gft_forward_render.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64]
+    lib.gft_backward.restype = C.c_int
+    lib.gft_backward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(BackwardIO), C.c_int64]
+    lib.gft_mark_visible.restype = C.c_int
+    lib.gft_mark_visible.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_float, C.c_float, C.c_void_p]
+    lib.gft_profile_enable.restype = C.c_int
+    lib.gft_profile_enable.argtypes = [C.c_int]
+    lib.gft_profile_reset.restype = C.c_int
+    lib.gft_profile_read.restype = C.c_int
+    lib.gft_profile_read.argtypes = [C.POINTER(Profile)]
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().gft_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(last_error())
+
+
+def get_layout(P, W, H, R=0):
+    L = Layout()
+    check(load().gft_get_layout(P, W, H, R, C.byref(L)))
+    return L
+
+
+def profile_enable(on=True):
+    load().gft_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    load().gft_profile_reset()
+
+
+def profile_read():
+    p = Profile()
+    check(load().gft_profile_read(C.byref(p)))
+    d = {n: getattr(p, n) for n in PROFILE_FIELDS}
+    d["forward_calls"] = p.forward_calls
+    d["backward_calls"] = p.backward_calls
+    return d

@@ -1,0 +1,370 @@
+"""Operator API of the MI355X ToF Gaussian rasterizer.
+
+Host-side mirror of the reference's
+``submodules/diff-gaussian-rasterization-w-tof/diff_gaussian_rasterization_w_tof/__init__.py``
+(same names, argument meaning, return arity and error behaviour) so that
+``gaussian_renderer/__init__.py`` and ``train.py`` run unchanged:
+
+  * ``GaussianRasterizationSettings``  -- reference __init__.py:22-40
+  * ``GaussianRasterizer``             -- reference __init__.py:208-269
+  * ``_RasterizeGaussians`` (autograd) -- reference __init__.py:69-206
+
+The native work is done by libgftorf_rast.so (hand-written gfx950 HIP kernels)
+through the C ABI in include/gftorf_rast.h.  PyTorch is used for device memory,
+streams and autograd plumbing only.  There is no CPU path: tensors must live on
+a HIP device and the library must be built, otherwise this raises.
+"""
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    near_n: Optional[float] = 0.01
+    far_n: Optional[float] = 100.0
+    depth_range: Optional[float] = 100.0
+    use_view_dependent_phase: Optional[bool] = False
+    optimize_phase_offset: Optional[bool] = False
+    optimize_dc_offset: Optional[bool] = False
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
+def _present(t):
+    """The reference marks an absent tensor by an empty one (``torch.Tensor([])``)."""
+    return t is not None and isinstance(t, torch.Tensor) and t.numel() != 0
+
+
+def _f32(t, dev, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))
+    if t.device != dev:
+        raise RuntimeError("%s is on %s, expected %s" % (name, t.device, dev))
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _scalar(x):
+    """phase_offset / dc_offset arrive as a Python float or a 1-element tensor
+    (reference __init__.py:111-112; gaussian_renderer/__init__.py:126-127)."""
+    if isinstance(x, torch.Tensor):
+        return float(x.detach().reshape(-1)[0].item())
+    return float(x)
+
+
+def _bg_strides(bg, H, W, dev):
+    """Background as [7,H,W] element strides.  The reference reads
+    bg[c*H*W + pix] for c < 7 on every call (forward.cu:644,649) after
+    ``.contiguous()``; an expanded constant background (train.py:127) is
+    consumed through its zero strides instead of being materialised."""
+    if bg.dtype != torch.float32 or bg.device != dev:
+        raise RuntimeError("bg must be a float32 tensor on %s" % (dev,))
+    if bg.dim() == 3 and tuple(bg.shape) == (7, H, W):
+        return bg, bg.stride(0), bg.stride(1), bg.stride(2)
+    if bg.numel() == 7 * H * W:
+        bg = bg.contiguous()
+        return bg, H * W, W, 1
+    if bg.numel() == 7:
+        bg = bg.contiguous().reshape(7)
+        return bg, 1, 0, 0
+    raise RuntimeError(
+        "bg must hold 7*H*W floats ([7,H,W], may be an expanded view) or 7 floats; got shape %s. "
+        "The ToF rasterizer blends 7 phasor planes against bg planes 0..6 on every call."
+        % (tuple(bg.shape),))
+
+
+def _make_config(s, P, M, M_p, H, W, phase_offset, dc_offset, bgs):
+    c = _lib.Config()
+    c.P, c.D, c.M, c.M_p, c.W, c.H = P, int(s.sh_degree), M, M_p, W, H
+    c.tanfovx, c.tanfovy = float(s.tanfovx), float(s.tanfovy)
+    c.scale_modifier = float(s.scale_modifier)
+    c.near_n, c.far_n, c.depth_range = float(s.near_n), float(s.far_n), float(s.depth_range)
+    c.phase_offset, c.dc_offset = phase_offset, dc_offset
+    c.use_view_dependent_phase = int(bool(s.use_view_dependent_phase))
+    c.prefiltered = int(bool(s.prefiltered))
+    c.debug = int(bool(s.debug))
+    c.bg_stride_c, c.bg_stride_y, c.bg_stride_x = bgs
+    return c
+
+
+def rasterize_gaussians(means3D, means2D, sh, sh_p, colors_precomp, phasors_precomp, opacities,
+                        scales, rotations, cov3Ds_precomp, phase_offset, dc_offset, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, sh_p, colors_precomp, phasors_precomp,
+                                     opacities, scales, rotations, cov3Ds_precomp, phase_offset,
+                                     dc_offset, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, sh_p, colors_precomp, phasors_precomp, opacities,
+                scales, rotations, cov3Ds_precomp, phase_offset, dc_offset, raster_settings):
+        s = raster_settings
+        lib = _lib.load()
+        if means3D.dim() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError("gftorf_amd: the rasterizer runs on a HIP device only (means3D is on %s); "
+                               "there is no CPU path" % (dev,))
+        P = means3D.size(0)
+        H, W = int(s.image_height), int(s.image_width)
+
+        ph_off = _scalar(phase_offset)
+        dc_off = _scalar(dc_offset)
+
+        g = lambda t, n: _f32(t, dev, n) if _present(t) else None
+        means3D_c = _f32(means3D, dev, "means3D") if P else means3D
+        sh_c, sh_p_c = g(sh, "shs"), g(sh_p, "shs_p")
+        colors_c, phasors_c = g(colors_precomp, "colors_precomp"), g(phasors_precomp, "phasors_precomp")
+        opac_c = g(opacities, "opacities")
+        scales_c, rot_c, cov_c = g(scales, "scales"), g(rotations, "rotations"), g(cov3Ds_precomp, "cov3D_precomp")
+        view_c = _f32(s.viewmatrix, dev, "viewmatrix")
+        proj_c = _f32(s.projmatrix, dev, "projmatrix")
+        campos_c = _f32(s.campos, dev, "campos")
+        bg_c, bsc, bsy, bsx = _bg_strides(s.bg, H, W, dev)
+        M = sh_c.size(1) if sh_c is not None else 0
+        M_p = sh_p_c.size(1) if sh_p_c is not None else 0
+
+        if s.debug:
+            cpu_args = cpu_deep_copy_tuple((s.bg, means3D, colors_precomp, phasors_precomp, opacities, scales,
+                                            rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix, s.projmatrix,
+                                            s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, sh_p,
+                                            s.sh_degree, s.campos, s.prefiltered, s.debug, s.near_n, s.far_n,
+                                            s.depth_range, s.use_view_dependent_phase, ph_off, dc_off))
+
+        f32 = dict(device=dev, dtype=torch.float32)
+        planes = torch.empty((21, H, W), **f32)
+        color, phasor, depth = planes[0:3], planes[3:10], planes[10:11]
+        normal, acc, entropy = planes[11:14], planes[14:15], planes[15:16]
+        depth_distortion, amp_distortion, distribution = planes[16:17], planes[17:18], planes[18:21]
+        radii = torch.empty((P,), device=dev, dtype=torch.int32)
+        pixels = torch.empty((P, 1), **f32)
+        geom = torch.empty((lib.gft_geom_bytes(P),), device=dev, dtype=torch.uint8)
+        img = torch.empty((lib.gft_image_bytes(W, H),), device=dev, dtype=torch.uint8)
+
+        cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx))
+        io = _lib.ForwardIO()
+        io.bg, io.means3D = _ptr(bg_c), _ptr(means3D_c) if P else None
+        io.colors_precomp, io.phasors_precomp, io.opacities = _ptr(colors_c), _ptr(phasors_c), _ptr(opac_c)
+        io.scales, io.rotations, io.cov3D_precomp = _ptr(scales_c), _ptr(rot_c), _ptr(cov_c)
+        io.viewmatrix, io.projmatrix, io.campos = _ptr(view_c), _ptr(proj_c), _ptr(campos_c)
+        io.shs, io.shs_p = _ptr(sh_c), _ptr(sh_p_c)
+        io.geom, io.img, io.binning = _ptr(geom), _ptr(img), None
+        io.out_color, io.out_phasor, io.out_depth = color.data_ptr(), phasor.data_ptr(), depth.data_ptr()
+        io.out_normal, io.out_acc, io.out_entropy = normal.data_ptr(), acc.data_ptr(), entropy.data_ptr()
+        io.out_depth_distortion, io.out_amp_distortion = depth_distortion.data_ptr(), amp_distortion.data_ptr()
+        io.out_distribution = distribution.data_ptr()
+        io.pixels, io.radii = _ptr(pixels) if P else None, _ptr(radii) if P else None
+
+        R = 0
+        if P == 0:
+            # the reference skips every kernel and returns its zero-filled outputs
+            # (rasterize_points.cu:104)
+            planes.zero_()
+            binning = torch.empty((0,), device=dev, dtype=torch.uint8)
+        else:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            num_rendered = C.c_int64(0)
+            try:
+                with torch.cuda.device(dev):
+                    _lib.check(lib.gft_forward_preprocess(stream, C.byref(cfg), C.byref(io), C.byref(num_rendered)))
+                    R = int(num_rendered.value)
+                    # sized after the one blocking read, like the reference's resize callback
+                    # (rasterize_points.cu:27-33, rasterizer_impl.cu:311-315)
+                    binning = torch.empty((lib.gft_binning_bytes(R, W, H),), device=dev, dtype=torch.uint8)
+                    io.binning = binning.data_ptr()
+                    _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), R))
+            except Exception as ex:
+                if s.debug:
+                    torch.save(cpu_args, "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+
+        ctx.raster_settings = s
+        ctx.num_rendered = R
+        ctx.scalars = (ph_off, dc_off)
+        ctx.bg = (bg_c, bsc, bsy, bsx)
+        ctx.consts = (view_c, proj_c, campos_c)
+        ctx.present = (sh_c is not None, sh_p_c is not None, colors_c is not None, phasors_c is not None,
+                       scales_c is not None, cov_c is not None)
+        ctx.in_shapes = (opacities.shape, phase_offset.shape if isinstance(phase_offset, torch.Tensor) else None,
+                         dc_offset.shape if isinstance(dc_offset, torch.Tensor) else None)
+        ctx.set_materialize_grads(False)
+        dummy = means3D_c.new_empty(0)
+        ctx.save_for_backward(means3D_c,
+                              sh_c if sh_c is not None else dummy, sh_p_c if sh_p_c is not None else dummy,
+                              scales_c if scales_c is not None else dummy, rot_c if rot_c is not None else dummy,
+                              cov_c if cov_c is not None else dummy, radii, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return (color, phasor, depth, normal, acc, entropy, depth_distortion, amp_distortion, pixels,
+                distribution, radii)
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_out_phasor, grad_out_depth, grad_out_normal, grad_out_acc,
+                 grad_entropy, grad_depth_distortion, grad_amp_distortion, grad_pixels, grad_distribution, _):
+        s = ctx.raster_settings
+        lib = _lib.load()
+        means3D, sh, sh_p, scales, rotations, cov3D, radii, geom, binning, img = ctx.saved_tensors
+        has_sh, has_sh_p, has_colors, has_phasors, has_scales, has_cov = ctx.present
+        dev = means3D.device
+        P = means3D.size(0)
+        H, W = int(s.image_height), int(s.image_width)
+        ph_off, dc_off = ctx.scalars
+        bg_c, bsc, bsy, bsx = ctx.bg
+        view_c, proj_c, campos_c = ctx.consts
+        M = sh.size(1) if has_sh else 0
+        M_p = sh_p.size(1) if has_sh_p else 0
+
+        def gr(t, c, name):
+            # gradients of normal / entropy / amp_distortion / pixels / distribution are
+            # accepted and ignored, as in the reference kernels (backward.cu:609-630)
+            if t is None:
+                return None
+            if tuple(t.shape) != (c, H, W):
+                raise RuntimeError("grad of %s has shape %s, expected %s" % (name, tuple(t.shape), (c, H, W)))
+            return _f32(t, dev, "grad_" + name)
+
+        g_color, g_phasor = gr(grad_out_color, 3, "color"), gr(grad_out_phasor, 7, "phasor")
+        g_depth, g_acc = gr(grad_out_depth, 1, "depth"), gr(grad_out_acc, 1, "acc")
+        g_dd = gr(grad_depth_distortion, 1, "depth_distortion")
+
+        f32 = dict(device=dev, dtype=torch.float32)
+        grad_means3D = torch.empty((P, 3), **f32)
+        grad_means2D = torch.empty((P, 3), **f32)
+        grad_opacities = torch.empty((P, 1), **f32)
+        grad_colors = torch.empty((P, 3), **f32) if has_colors else None
+        grad_cov3D = torch.empty((P, 6), **f32) if has_cov else None
+        grad_sh = torch.empty((P, M, 3), **f32) if has_sh else None
+        grad_sh_p = torch.empty((P, M_p, 2), **f32) if has_sh_p else None
+        grad_scales = torch.empty((P, 3), **f32) if has_scales else None
+        grad_rotations = torch.empty((P, 4), **f32) if has_scales else None
+        grad_offsets = torch.empty((2,), **f32)
+        acc = torch.empty((P, _lib.ACC_STRIDE), **f32)
+
+        cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx))
+        io = _lib.BackwardIO()
+        io.bg, io.means3D, io.radii = _ptr(bg_c), _ptr(means3D) if P else None, _ptr(radii) if P else None
+        io.scales = _ptr(scales) if has_scales else None
+        io.rotations = _ptr(rotations) if has_scales else None
+        io.cov3D_precomp = _ptr(cov3D) if has_cov else None
+        io.viewmatrix, io.projmatrix, io.campos = _ptr(view_c), _ptr(proj_c), _ptr(campos_c)
+        io.shs = _ptr(sh) if has_sh else None
+        io.shs_p = _ptr(sh_p) if has_sh_p else None
+        io.dL_dout_color, io.dL_dout_phasor = _ptr(g_color), _ptr(g_phasor)
+        io.dL_dout_depth, io.dL_dout_acc, io.dL_dout_depth_distortion = _ptr(g_depth), _ptr(g_acc), _ptr(g_dd)
+        io.geom, io.img, io.binning = _ptr(geom), _ptr(img), _ptr(binning)
+        io.acc = _ptr(acc) if P else None
+        io.dL_dmeans3D, io.dL_dmeans2D = _ptr(grad_means3D) if P else None, _ptr(grad_means2D) if P else None
+        io.dL_dcolors, io.dL_dopacity, io.dL_dcov3D = _ptr(grad_colors), _ptr(grad_opacities) if P else None, _ptr(grad_cov3D)
+        io.dL_dsh, io.dL_dsh_p = _ptr(grad_sh), _ptr(grad_sh_p)
+        io.dL_dscales, io.dL_drotations = _ptr(grad_scales), _ptr(grad_rotations)
+        io.dL_dphase_offset = grad_offsets.data_ptr()
+        io.dL_ddc_offset = grad_offsets.data_ptr() + 4
+
+        if s.debug:
+            cpu_args = cpu_deep_copy_tuple((s.bg, means3D, radii, scales, rotations, s.scale_modifier, cov3D,
+                                            s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color,
+                                            grad_out_phasor, grad_out_depth, grad_out_acc, grad_depth_distortion,
+                                            sh, sh_p, s.sh_degree, s.campos, geom, ctx.num_rendered, binning, img,
+                                            s.debug, s.near_n, s.far_n, s.depth_range, s.use_view_dependent_phase,
+                                            ph_off, dc_off))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        try:
+            with torch.cuda.device(dev):
+                _lib.check(lib.gft_backward(stream, C.byref(cfg), C.byref(io), ctx.num_rendered))
+        except Exception as ex:
+            if s.debug:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+            raise ex
+
+        op_shape, ph_shape, dc_shape = ctx.in_shapes
+        grad_phase = grad_dc = None
+        if s.optimize_phase_offset and ph_shape is not None:
+            grad_phase = grad_offsets[0:1].reshape(ph_shape)
+        if s.optimize_dc_offset and dc_shape is not None:
+            grad_dc = grad_offsets[1:2].reshape(dc_shape)
+        # input order of forward(); the reference has no backward for phasors_precomp
+        return (grad_means3D, grad_means2D, grad_sh, grad_sh_p, grad_colors, None,
+                grad_opacities.reshape(op_shape), grad_scales, grad_rotations, grad_cov3D,
+                grad_phase, grad_dc, None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """bool[P]: near_n <= view-space z <= far_n (reference rasterizer_impl.cu:54-68)."""
+        with torch.no_grad():
+            s = self.raster_settings
+            lib = _lib.load()
+            if positions.device.type != "cuda":
+                raise RuntimeError("gftorf_amd: markVisible needs HIP tensors; there is no CPU path")
+            dev = positions.device
+            pos = _f32(positions, dev, "positions")
+            P = pos.size(0)
+            visible = torch.zeros((P,), device=dev, dtype=torch.bool)
+            if P:
+                view = _f32(s.viewmatrix, dev, "viewmatrix")
+                proj = _f32(s.projmatrix, dev, "projmatrix")
+                with torch.cuda.device(dev):
+                    _lib.check(lib.gft_mark_visible(torch.cuda.current_stream(dev).cuda_stream, P, pos.data_ptr(),
+                                                    view.data_ptr(), proj.data_ptr(), float(s.near_n),
+                                                    float(s.far_n), visible.data_ptr()))
+        return visible
+
+    def forward(self, means3D, means2D, opacities, shs=None, shs_p=None, colors_precomp=None,
+                phasors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+                phase_offset=0.0, dc_offset=0.0):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if shs_p is None:
+            shs_p = torch.Tensor([])
+        if phasors_precomp is None:
+            phasors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+
+        return rasterize_gaussians(means3D, means2D, shs, shs_p, colors_precomp, phasors_precomp, opacities,
+                                   scales, rotations, cov3D_precomp, phase_offset, dc_offset, raster_settings)

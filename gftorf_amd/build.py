@@ -1,0 +1,77 @@
+"""In-tree build of libgftorf_rast.so (hipcc, gfx950 only).
+
+``python -m gftorf_amd.build`` or ``__graft_entry__.build()``.  hipcc
+cross-compiles without a GPU; the resulting .so sits next to this file so it
+travels with the repository snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
+LIB = os.path.join(HERE, "libgftorf_rast.so")
+SOURCES = ["gft_api.hip", "k_preprocess.hip", "k_binning.hip", "k_render.hip"]
+ARCH = "gfx950"
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libgftorf_rast.so cannot be built")
+
+
+def flags():
+    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, save_temps=False):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, "gft_internal.h"), os.path.join(ROOT, "include", "gftorf_rast.h"),
+               os.path.abspath(__file__)]
+    cc = hipcc()
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + headers):
+            cmd = [cc] + flags() + ["-c", s, "-o", o]
+            if save_temps:
+                cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        logs = list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    if jobs or force or _stale(LIB, objs):
+        run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB, logs
+
+
+if __name__ == "__main__":
+    lib, logs = build(force="--force" in sys.argv, verbose=True, save_temps="--save-temps" in sys.argv)
+    for l in logs:
+        if l.strip():
+            print(l)
+    print("built", lib)

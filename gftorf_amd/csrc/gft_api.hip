@@ -1,0 +1,370 @@
+// gft_api.hip -- C ABI of libgftorf_rast.so (include/gftorf_rast.h): scratch layout,
+// stage sequencing, stream handling, error strings, per-stage HIP-event timing.
+// No torch headers; stateless between calls except for the opt-in profiler.
+#include "gft_internal.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+
+// ---- errors ---------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int gft_fail(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+extern "C" const char* gft_last_error(void) { return g_err; }
+extern "C" int gft_abi_version(void) { return GFT_ABI_VERSION; }
+
+// ---- layout ------------------------------------------------------------------
+static inline size_t align_up(size_t x) { return (x + GFT_ALIGN - 1) & ~(size_t)(GFT_ALIGN - 1); }
+
+void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* L)
+{
+    memset(L, 0, sizeof(*L));
+    const size_t p = (size_t)(P > 0 ? P : 0);
+    size_t o = 0;
+    L->geom_rec_a = o;    o = align_up(o + p * 32);
+    L->geom_rec_b = o;    o = align_up(o + p * 48);
+    L->geom_depth = o;    o = align_up(o + p * 4);
+    L->geom_tiles = o;    o = align_up(o + p * 4);
+    L->geom_offsets = o;  o = align_up(o + p * 4);
+    L->geom_clamped = o;  o = align_up(o + p);
+    const size_t nblocks = (p + GFT_BLOCK - 1) / GFT_BLOCK;
+    L->geom_scan_tmp = o; o = align_up(o + (GFT_SCAN_BLOCKS + nblocks + 1) * 4);
+    L->geom_total = o;
+
+    const size_t n = (size_t)W * (size_t)H;
+    const size_t T = (size_t)((W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((H + GFT_TILE_Y - 1) / GFT_TILE_Y);
+    o = 0;
+    L->img_pix_state = o; o = align_up(o + n * 16);
+    L->img_ranges = o;    o = align_up(o + T * 8);
+    L->img_tile_max = o;  o = align_up(o + T * 4);
+    L->img_total = o;
+
+    const size_t r = (size_t)(R > 0 ? R : 0);
+    o = 0;
+    L->bin_keys_unsorted = o; o = align_up(o + r * 8);
+    L->bin_keys = o;          o = align_up(o + r * 8);
+    L->bin_vals_unsorted = o; o = align_up(o + r * 4);
+    L->bin_point_list = o;    o = align_up(o + r * 4);
+    L->bin_sort_tmp = o;      o = align_up(o + gft_sort_tmp_bytes(R));
+    L->bin_total = o + GFT_ALIGN;
+}
+
+GeomView gft_geom_view(void* base, const gft_layout& L)
+{
+    char* b = (char*)base;
+    GeomView g;
+    g.rec_a = (float4*)(b + L.geom_rec_a);
+    g.rec_b = (float4*)(b + L.geom_rec_b);
+    g.depth = (float*)(b + L.geom_depth);
+    g.tiles = (uint32_t*)(b + L.geom_tiles);
+    g.offsets = (uint32_t*)(b + L.geom_offsets);
+    g.clamped = (uint8_t*)(b + L.geom_clamped);
+    g.scan_tmp = (uint32_t*)(b + L.geom_scan_tmp);
+    return g;
+}
+
+ImgView gft_img_view(void* base, const gft_layout& L)
+{
+    char* b = (char*)base;
+    ImgView v;
+    v.pix_state = (float4*)(b + L.img_pix_state);
+    v.ranges = (uint2*)(b + L.img_ranges);
+    v.tile_max = (uint32_t*)(b + L.img_tile_max);
+    return v;
+}
+
+BinView gft_bin_view(void* base, const gft_layout& L)
+{
+    char* b = (char*)base;
+    BinView v;
+    v.keys_unsorted = (uint64_t*)(b + L.bin_keys_unsorted);
+    v.keys = (uint64_t*)(b + L.bin_keys);
+    v.vals_unsorted = (uint32_t*)(b + L.bin_vals_unsorted);
+    v.point_list = (uint32_t*)(b + L.bin_point_list);
+    v.sort_tmp = (void*)(b + L.bin_sort_tmp);
+    v.sort_tmp_bytes = L.bin_total - GFT_ALIGN - L.bin_sort_tmp;
+    return v;
+}
+
+extern "C" size_t gft_geom_bytes(int32_t P)
+{
+    gft_layout L;
+    gft_compute_layout(P, 16, 16, 0, &L);
+    return L.geom_total + GFT_ALIGN;
+}
+
+extern "C" size_t gft_image_bytes(int32_t W, int32_t H)
+{
+    gft_layout L;
+    gft_compute_layout(0, W, H, 0, &L);
+    return L.img_total + GFT_ALIGN;
+}
+
+extern "C" size_t gft_binning_bytes(int64_t R, int32_t W, int32_t H)
+{
+    gft_layout L;
+    gft_compute_layout(0, W, H, R, &L);
+    return L.bin_total;
+}
+
+extern "C" int gft_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* out)
+{
+    if (!out) return gft_fail("gft_get_layout: out is NULL");
+    gft_compute_layout(P, W, H, R, out);
+    return 0;
+}
+
+// ---- profiler -----------------------------------------------------------------
+enum Stage { ST_PRE_FWD, ST_SCAN, ST_DUP, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_RENDER_BWD, ST_PRE_BWD, ST_MEMSET, ST_COUNT };
+
+struct Profiler {
+    std::mutex mu;
+    bool on = false;
+    struct Rec { int stage; hipEvent_t a, b; };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[ST_COUNT] = {0};
+    int64_t fwd = 0, bwd = 0;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    void drain()
+    {
+        for (auto& r : pending) {
+            float t = 0.f;
+            if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms[r.stage] += t;
+            pool.push_back(r.a);
+            pool.push_back(r.b);
+        }
+        pending.clear();
+    }
+};
+static Profiler g_prof;
+
+struct StageTimer {
+    hipStream_t s; int stage; hipEvent_t a = nullptr, b = nullptr; bool on;
+    StageTimer(hipStream_t s_, int st) : s(s_), stage(st), on(g_prof.on)
+    {
+        if (on) {
+            std::lock_guard<std::mutex> lk(g_prof.mu);
+            a = g_prof.get(); b = g_prof.get();
+            if (a && b) (void)hipEventRecord(a, s); else on = false;
+        }
+    }
+    ~StageTimer()
+    {
+        if (on) {
+            (void)hipEventRecord(b, s);
+            std::lock_guard<std::mutex> lk(g_prof.mu);
+            g_prof.pending.push_back({stage, a, b});
+        }
+    }
+};
+
+extern "C" int gft_profile_enable(int on) { std::lock_guard<std::mutex> lk(g_prof.mu); g_prof.on = on != 0; return 0; }
+
+extern "C" int gft_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.drain();
+    memset(g_prof.ms, 0, sizeof(g_prof.ms));
+    g_prof.fwd = g_prof.bwd = 0;
+    return 0;
+}
+
+extern "C" int gft_profile_read(gft_profile* out)
+{
+    if (!out) return gft_fail("gft_profile_read: out is NULL");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.drain();
+    out->preprocess_fwd_ms = g_prof.ms[ST_PRE_FWD];
+    out->scan_ms = g_prof.ms[ST_SCAN];
+    out->duplicate_ms = g_prof.ms[ST_DUP];
+    out->sort_ms = g_prof.ms[ST_SORT];
+    out->ranges_ms = g_prof.ms[ST_RANGES];
+    out->render_fwd_ms = g_prof.ms[ST_RENDER_FWD];
+    out->render_bwd_ms = g_prof.ms[ST_RENDER_BWD];
+    out->preprocess_bwd_ms = g_prof.ms[ST_PRE_BWD];
+    out->memset_ms = g_prof.ms[ST_MEMSET];
+    out->forward_calls = g_prof.fwd;
+    out->backward_calls = g_prof.bwd;
+    return 0;
+}
+
+// ---- helpers -----------------------------------------------------------------
+#define GFT_STAGE(stream, cfg, name, call)                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) return gft_fail("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+        if ((cfg)->debug) {                                                                  \
+            e_ = hipStreamSynchronize(stream);                                               \
+            if (e_ != hipSuccess) return gft_fail("%s: %s", name, hipGetErrorString(e_));    \
+        }                                                                                    \
+    } while (0)
+
+static int check_config(const gft_config* c)
+{
+    if (!c) return gft_fail("config is NULL");
+    if (c->P < 0 || c->W <= 0 || c->H <= 0) return gft_fail("bad sizes P=%d W=%d H=%d", c->P, c->W, c->H);
+    if (c->D < 0 || c->D > 3) return gft_fail("sh_degree %d not in 0..3", c->D);
+    const int need = (c->D + 1) * (c->D + 1);
+    if (c->M != 0 && c->M < need) return gft_fail("shs holds %d coefficients, sh_degree %d needs %d", c->M, c->D, need);
+    if (c->M_p != 0 && c->M_p < need) return gft_fail("shs_p holds %d coefficients, sh_degree %d needs %d", c->M_p, c->D, need);
+    return 0;
+}
+
+// ---- forward, stage 1 -----------------------------------------------------------
+extern "C" int gft_forward_preprocess(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
+                                      int64_t* num_rendered)
+{
+    if (check_config(cfg)) return 1;
+    if (!io || !num_rendered) return gft_fail("gft_forward_preprocess: NULL argument");
+    *num_rendered = 0;
+    if (cfg->P == 0) return 0;
+    if (!io->means3D || !io->opacities || !io->viewmatrix || !io->projmatrix || !io->campos || !io->geom ||
+        !io->radii || !io->pixels)
+        return gft_fail("gft_forward_preprocess: required pointer is NULL");
+    if ((io->shs == nullptr) == (io->colors_precomp == nullptr))
+        return gft_fail("Please provide excatly one of either SHs or precomputed colors!");
+    if ((io->scales == nullptr || io->rotations == nullptr) == (io->cov3D_precomp == nullptr))
+        return gft_fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if ((io->shs != nullptr) != (cfg->M > 0) || (io->shs_p != nullptr) != (cfg->M_p > 0))
+        return gft_fail("M / M_p do not match the presence of shs / shs_p");
+    hipStream_t s = (hipStream_t)hip_stream;
+    gft_layout L;
+    gft_compute_layout(cfg->P, cfg->W, cfg->H, 0, &L);
+    GeomView g = gft_geom_view(io->geom, L);
+
+    GFT_CHECK_HIP(hipMemsetAsync(g.scan_tmp, 0, 2 * sizeof(uint32_t), s));
+    {
+        StageTimer t(s, ST_PRE_FWD);
+        GFT_STAGE(s, cfg, "preprocess_fwd", gft_launch_preprocess_fwd(s, *cfg, *io, g));
+    }
+    {
+        StageTimer t(s, ST_SCAN);
+        GFT_STAGE(s, cfg, "scan", gft_launch_scan(s, cfg->P, g));
+    }
+    // the one blocking read of the forward (reference rasterizer_impl.cu:311)
+    uint32_t host[2] = {0, 0};
+    GFT_CHECK_HIP(hipMemcpyAsync(host, g.scan_tmp, sizeof(host), hipMemcpyDeviceToHost, s));
+    GFT_CHECK_HIP(hipStreamSynchronize(s));
+    if (host[GFT_SCAN_FLAGS] & 1u)
+        return gft_fail("Point is filtered although prefiltered is set. This shouldn't happen!");
+    *num_rendered = (int64_t)host[GFT_SCAN_TOTAL];
+    return 0;
+}
+
+// ---- forward, stage 2 -----------------------------------------------------------
+extern "C" int gft_forward_render(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
+                                  int64_t num_rendered)
+{
+    if (check_config(cfg)) return 1;
+    if (!io) return gft_fail("gft_forward_render: io is NULL");
+    if (!io->img || !io->bg || !io->out_color || !io->out_phasor || !io->out_depth || !io->out_normal ||
+        !io->out_acc || !io->out_entropy || !io->out_depth_distortion || !io->out_amp_distortion ||
+        !io->out_distribution)
+        return gft_fail("gft_forward_render: required pointer is NULL");
+    if (num_rendered > 0 && !io->binning) return gft_fail("gft_forward_render: binning buffer is NULL");
+    if (cfg->P > 0 && (!io->geom || !io->radii || !io->pixels)) return gft_fail("gft_forward_render: geom/radii/pixels NULL");
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int64_t R = cfg->P == 0 ? 0 : num_rendered;
+    gft_layout L;
+    gft_compute_layout(cfg->P, cfg->W, cfg->H, R, &L);
+    GeomView g = gft_geom_view(io->geom, L);
+    ImgView im = gft_img_view(io->img, L);
+    BinView b = gft_bin_view(io->binning, L);
+    const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    const int T = gx * gy;
+
+    if (R > 0) {
+        {
+            StageTimer t(s, ST_DUP);
+            GFT_STAGE(s, cfg, "duplicate_with_keys", gft_launch_duplicate(s, *cfg, g, io->radii, b));
+        }
+        {
+            StageTimer t(s, ST_SORT);
+            GFT_STAGE(s, cfg, "sort", gft_launch_sort(s, R, 32 + (int)gft_higher_msb((uint32_t)T), b));
+        }
+    }
+    {
+        StageTimer t(s, ST_RANGES);
+        GFT_STAGE(s, cfg, "tile_ranges", gft_launch_ranges(s, R, T, b, im));
+    }
+    {
+        StageTimer t(s, ST_RENDER_FWD);
+        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b));
+    }
+    if (g_prof.on) { std::lock_guard<std::mutex> lk(g_prof.mu); g_prof.fwd++; }
+    return 0;
+}
+
+// ---- backward -----------------------------------------------------------------
+extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_backward_io* io, int64_t num_rendered)
+{
+    if (check_config(cfg)) return 1;
+    if (!io) return gft_fail("gft_backward: io is NULL");
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (io->dL_dphase_offset) GFT_CHECK_HIP(hipMemsetAsync(io->dL_dphase_offset, 0, sizeof(float), s));
+    if (io->dL_ddc_offset) GFT_CHECK_HIP(hipMemsetAsync(io->dL_ddc_offset, 0, sizeof(float), s));
+    if (cfg->P == 0) return 0;
+    if (!io->means3D || !io->radii || !io->viewmatrix || !io->projmatrix || !io->campos || !io->geom || !io->img ||
+        !io->bg || !io->acc || !io->dL_dmeans3D || !io->dL_dmeans2D || !io->dL_dopacity || !io->dL_dphase_offset ||
+        !io->dL_ddc_offset)
+        return gft_fail("gft_backward: required pointer is NULL");
+    if (num_rendered > 0 && !io->binning) return gft_fail("gft_backward: binning buffer is NULL");
+    if ((io->shs != nullptr) != (cfg->M > 0) || (io->shs_p != nullptr) != (cfg->M_p > 0))
+        return gft_fail("M / M_p do not match the presence of shs / shs_p");
+    if (io->shs && !io->dL_dsh) return gft_fail("gft_backward: dL_dsh is NULL");
+    if (io->shs_p && !io->dL_dsh_p) return gft_fail("gft_backward: dL_dsh_p is NULL");
+    if ((io->scales == nullptr || io->rotations == nullptr) == (io->cov3D_precomp == nullptr))
+        return gft_fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (io->scales && (!io->dL_dscales || !io->dL_drotations)) return gft_fail("gft_backward: dL_dscales/dL_drotations NULL");
+
+    gft_layout L;
+    gft_compute_layout(cfg->P, cfg->W, cfg->H, num_rendered, &L);
+    GeomView g = gft_geom_view(const_cast<void*>(io->geom), L);
+    ImgView im = gft_img_view(const_cast<void*>(io->img), L);
+    BinView b = gft_bin_view(const_cast<void*>(io->binning), L);
+
+    {
+        StageTimer t(s, ST_MEMSET);
+        GFT_CHECK_HIP(hipMemsetAsync(io->acc, 0, (size_t)cfg->P * GFT_ACC_STRIDE * sizeof(float), s));
+    }
+    if (num_rendered > 0) {
+        StageTimer t(s, ST_RENDER_BWD);
+        GFT_STAGE(s, cfg, "render_bwd", gft_launch_render_bwd(s, *cfg, *io, g, im, b));
+    }
+    {
+        StageTimer t(s, ST_PRE_BWD);
+        GFT_STAGE(s, cfg, "preprocess_bwd", gft_launch_preprocess_bwd(s, *cfg, *io, g));
+    }
+    if (g_prof.on) { std::lock_guard<std::mutex> lk(g_prof.mu); g_prof.bwd++; }
+    return 0;
+}
+
+extern "C" int gft_mark_visible(void* hip_stream, int32_t P, const float* means3D, const float* viewmatrix,
+                                const float* projmatrix, float near_n, float far_n, uint8_t* present)
+{
+    (void)projmatrix;  // the reference passes it but only tests view-space z (auxiliary.h:167-169)
+    if (P < 0) return gft_fail("gft_mark_visible: P < 0");
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present) return gft_fail("gft_mark_visible: NULL pointer");
+    hipError_t e = gft_launch_mark_visible((hipStream_t)hip_stream, P, means3D, viewmatrix, near_n, far_n, present);
+    if (e != hipSuccess) return gft_fail("mark_visible: %s", hipGetErrorString(e));
+    return 0;
+}

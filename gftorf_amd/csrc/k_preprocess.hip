@@ -1,0 +1,687 @@
+// k_preprocess.hip -- per-Gaussian stages (gfx950).
+//
+//  k_preprocess_fwd : cull, project, cov3D/cov2D, conic, radius, tile rect,
+//                     SH -> RGB, SH_p -> (phase, amplitude), ToF phasor[7]
+//                     (reference K1, RAST/cuda_rasterizer/forward.cu:251-419)
+//                     + per-block sums of tiles_touched for the scan.
+//  k_preprocess_bwd : conic -> cov2D -> cov3D/mean chain, projection chain, SH
+//                     and SH_p chains, ToF-phasor chain, distance chain,
+//                     cov3D -> scale/rotation (reference K8 + K9 fused,
+//                     backward.cu:265-395 and :467-606).
+//
+// Memory-bound: one lane per Gaussian, records packed as 16-byte vectors.
+// Floating-point contraction is disabled in this file so that the integer
+// decisions derived here (radius, tile rectangle, sort-key depth bits) are the
+// same on the device as in the fp32 CPU oracle: "bit-exact tile/key indexing".
+#include "gft_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ const float SH_C0 = 0.28209479177387814f;
+__device__ const float SH_C1 = 0.4886025119029199f;
+__device__ const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                   -1.0925484305920792f, 0.5462742152960396f};
+__device__ const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                   0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                   -0.5900435899266435f};
+
+struct Mat16 { float m[16]; };
+
+__device__ __forceinline__ Mat16 load_mat(const float* __restrict__ p)
+{
+    Mat16 r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.m[i] = p[i];
+    return r;
+}
+
+// intermediate values of the EWA projection shared by forward and backward
+struct Ewa {
+    float t0, t1, t2;      // view-space mean with the frustum clamp applied to x,y
+    float txtz, tytz;      // unclamped ratios
+    float T00, T01, T02;   // T[0][r]
+    float T10, T11, T12;   // T[1][r]
+    float a, b, c;         // cov2D[0][0], [0][1], [1][1] before the +0.3 low-pass
+};
+
+// cov3D: 6 unique entries of Sigma = (S R)^T (S R) in the reference's GLM order
+__device__ __forceinline__ void cov3d_from_scale_rot(float sx, float sy, float sz, float4 q, float* cov)
+{
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    // M[c][k] = s_k * R[c][k]
+    const float M00 = sx * (1.f - 2.f * (y * y + z * z)), M01 = sy * (2.f * (x * y - r * z)), M02 = sz * (2.f * (x * z + r * y));
+    const float M10 = sx * (2.f * (x * y + r * z)), M11 = sy * (1.f - 2.f * (x * x + z * z)), M12 = sz * (2.f * (y * z - r * x));
+    const float M20 = sx * (2.f * (x * z - r * y)), M21 = sy * (2.f * (y * z + r * x)), M22 = sz * (1.f - 2.f * (x * x + y * y));
+    cov[0] = M00 * M00 + M01 * M01 + M02 * M02;
+    cov[1] = M10 * M00 + M11 * M01 + M12 * M02;
+    cov[2] = M20 * M00 + M21 * M01 + M22 * M02;
+    cov[3] = M10 * M10 + M11 * M11 + M12 * M12;
+    cov[4] = M20 * M10 + M21 * M11 + M22 * M12;
+    cov[5] = M20 * M20 + M21 * M21 + M22 * M22;
+}
+
+__device__ __forceinline__ Ewa ewa_project(float px, float py, float pz, const Mat16& V, float fx, float fy,
+                                           float tanx, float tany, const float* cov)
+{
+    Ewa e;
+    e.t0 = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
+    e.t1 = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
+    e.t2 = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
+    const float limx = 1.3f * tanx, limy = 1.3f * tany;
+    e.txtz = e.t0 / e.t2;
+    e.tytz = e.t1 / e.t2;
+    e.t0 = fminf(limx, fmaxf(-limx, e.txtz)) * e.t2;
+    e.t1 = fminf(limy, fmaxf(-limy, e.tytz)) * e.t2;
+    const float J00 = fx / e.t2, J02 = -(fx * e.t0) / (e.t2 * e.t2);
+    const float J11 = fy / e.t2, J12 = -(fy * e.t1) / (e.t2 * e.t2);
+    // T = W * J with W[0][r] = (v0,v4,v8), W[1][r] = (v1,v5,v9), W[2][r] = (v2,v6,v10)
+    e.T00 = V.m[0] * J00 + V.m[2] * J02;
+    e.T01 = V.m[4] * J00 + V.m[6] * J02;
+    e.T02 = V.m[8] * J00 + V.m[10] * J02;
+    e.T10 = V.m[1] * J11 + V.m[2] * J12;
+    e.T11 = V.m[5] * J11 + V.m[6] * J12;
+    e.T12 = V.m[9] * J11 + V.m[10] * J12;
+    // X = T^T * Vrk^T ; cov = X * T  (Vrk[i][j] symmetric: c0 c1 c2 / c1 c3 c4 / c2 c4 c5)
+    const float X00 = e.T00 * cov[0] + e.T01 * cov[1] + e.T02 * cov[2];
+    const float X10 = e.T00 * cov[1] + e.T01 * cov[3] + e.T02 * cov[4];
+    const float X20 = e.T00 * cov[2] + e.T01 * cov[4] + e.T02 * cov[5];
+    const float X01 = e.T10 * cov[0] + e.T11 * cov[1] + e.T12 * cov[2];
+    const float X11 = e.T10 * cov[1] + e.T11 * cov[3] + e.T12 * cov[4];
+    const float X21 = e.T10 * cov[2] + e.T11 * cov[4] + e.T12 * cov[5];
+    e.a = X00 * e.T00 + X10 * e.T01 + X20 * e.T02;
+    e.b = X01 * e.T00 + X11 * e.T01 + X21 * e.T02;
+    e.c = X01 * e.T10 + X11 * e.T11 + X21 * e.T12;
+    return e;
+}
+
+// SH basis evaluation: result[c] = sum_k basis_k(dir) * sh[k*NC + c]
+template <int NC>
+__device__ __forceinline__ void sh_eval(int deg, float x, float y, float z, const float* __restrict__ sh, float* res)
+{
+#pragma unroll
+    for (int c = 0; c < NC; c++) res[c] = SH_C0 * sh[c];
+    if (deg > 0) {
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            res[c] = res[c] - SH_C1 * y * sh[1 * NC + c] + SH_C1 * z * sh[2 * NC + c] - SH_C1 * x * sh[3 * NC + c];
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                res[c] = res[c] + SH_C2[0] * xy * sh[4 * NC + c] + SH_C2[1] * yz * sh[5 * NC + c] +
+                         SH_C2[2] * (2.0f * zz - xx - yy) * sh[6 * NC + c] + SH_C2[3] * xz * sh[7 * NC + c] +
+                         SH_C2[4] * (xx - yy) * sh[8 * NC + c];
+            if (deg > 2) {
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    res[c] = res[c] + SH_C3[0] * y * (3.0f * xx - yy) * sh[9 * NC + c] +
+                             SH_C3[1] * xy * z * sh[10 * NC + c] +
+                             SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[11 * NC + c] +
+                             SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[12 * NC + c] +
+                             SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[13 * NC + c] +
+                             SH_C3[5] * z * (xx - yy) * sh[14 * NC + c] +
+                             SH_C3[6] * x * (xx - 3.0f * yy) * sh[15 * NC + c];
+            }
+        }
+    }
+}
+
+// SH backward: writes dL_dsh[k*NC+c] for the active coefficients, zero for the
+// inactive ones up to M, and returns the gradient w.r.t. the unit direction.
+template <int NC>
+__device__ __forceinline__ void sh_backward(int deg, int M, float x, float y, float z, const float* __restrict__ sh,
+                                            const float* dres, float* __restrict__ dsh, float* ddir)
+{
+    float ddx[NC], ddy[NC], ddz[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        ddx[c] = 0.f; ddy[c] = 0.f; ddz[c] = 0.f;
+        dsh[c] = SH_C0 * dres[c];
+    }
+    int written = 1;
+    if (deg > 0) {
+        const float d1 = -SH_C1 * y, d2 = SH_C1 * z, d3 = -SH_C1 * x;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            dsh[1 * NC + c] = d1 * dres[c];
+            dsh[2 * NC + c] = d2 * dres[c];
+            dsh[3 * NC + c] = d3 * dres[c];
+            ddx[c] = -SH_C1 * sh[3 * NC + c];
+            ddy[c] = -SH_C1 * sh[1 * NC + c];
+            ddz[c] = SH_C1 * sh[2 * NC + c];
+        }
+        written = 4;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            const float d4 = SH_C2[0] * xy, d5 = SH_C2[1] * yz, d6 = SH_C2[2] * (2.f * zz - xx - yy);
+            const float d7 = SH_C2[3] * xz, d8 = SH_C2[4] * (xx - yy);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const float* s = sh + c;
+                dsh[4 * NC + c] = d4 * dres[c];
+                dsh[5 * NC + c] = d5 * dres[c];
+                dsh[6 * NC + c] = d6 * dres[c];
+                dsh[7 * NC + c] = d7 * dres[c];
+                dsh[8 * NC + c] = d8 * dres[c];
+                ddx[c] += SH_C2[0] * y * s[4 * NC] + SH_C2[2] * 2.f * -x * s[6 * NC] + SH_C2[3] * z * s[7 * NC] +
+                          SH_C2[4] * 2.f * x * s[8 * NC];
+                ddy[c] += SH_C2[0] * x * s[4 * NC] + SH_C2[1] * z * s[5 * NC] + SH_C2[2] * 2.f * -y * s[6 * NC] +
+                          SH_C2[4] * 2.f * -y * s[8 * NC];
+                ddz[c] += SH_C2[1] * y * s[5 * NC] + SH_C2[2] * 2.f * 2.f * z * s[6 * NC] + SH_C2[3] * x * s[7 * NC];
+            }
+            written = 9;
+            if (deg > 2) {
+                const float d9 = SH_C3[0] * y * (3.f * xx - yy);
+                const float d10 = SH_C3[1] * xy * z;
+                const float d11 = SH_C3[2] * y * (4.f * zz - xx - yy);
+                const float d12 = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                const float d13 = SH_C3[4] * x * (4.f * zz - xx - yy);
+                const float d14 = SH_C3[5] * z * (xx - yy);
+                const float d15 = SH_C3[6] * x * (xx - 3.f * yy);
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const float* s = sh + c;
+                    dsh[9 * NC + c] = d9 * dres[c];
+                    dsh[10 * NC + c] = d10 * dres[c];
+                    dsh[11 * NC + c] = d11 * dres[c];
+                    dsh[12 * NC + c] = d12 * dres[c];
+                    dsh[13 * NC + c] = d13 * dres[c];
+                    dsh[14 * NC + c] = d14 * dres[c];
+                    dsh[15 * NC + c] = d15 * dres[c];
+                    ddx[c] += (SH_C3[0] * s[9 * NC] * 3.f * 2.f * xy + SH_C3[1] * s[10 * NC] * yz +
+                               SH_C3[2] * s[11 * NC] * -2.f * xy + SH_C3[3] * s[12 * NC] * -3.f * 2.f * xz +
+                               SH_C3[4] * s[13 * NC] * (-3.f * xx + 4.f * zz - yy) + SH_C3[5] * s[14 * NC] * 2.f * xz +
+                               SH_C3[6] * s[15 * NC] * 3.f * (xx - yy));
+                    ddy[c] += (SH_C3[0] * s[9 * NC] * 3.f * (xx - yy) + SH_C3[1] * s[10 * NC] * xz +
+                               SH_C3[2] * s[11 * NC] * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * s[12 * NC] * -3.f * 2.f * yz +
+                               SH_C3[4] * s[13 * NC] * -2.f * xy + SH_C3[5] * s[14 * NC] * -2.f * yz +
+                               SH_C3[6] * s[15 * NC] * -3.f * 2.f * xy);
+                    ddz[c] += (SH_C3[1] * s[10 * NC] * xy + SH_C3[2] * s[11 * NC] * 4.f * 2.f * yz +
+                               SH_C3[3] * s[12 * NC] * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * s[13 * NC] * 4.f * 2.f * xz +
+                               SH_C3[5] * s[14 * NC] * (xx - yy));
+                }
+                written = 16;
+            }
+        }
+    }
+    for (int k = written * NC; k < M * NC; k++) dsh[k] = 0.f;
+    float sx = ddx[0] * dres[0], sy = ddy[0] * dres[0], sz = ddz[0] * dres[0];
+#pragma unroll
+    for (int c = 1; c < NC; c++) {
+        sx = sx + ddx[c] * dres[c];
+        sy = sy + ddy[c] * dres[c];
+        sz = sz + ddz[c] * dres[c];
+    }
+    ddir[0] = sx; ddir[1] = sy; ddir[2] = sz;
+}
+
+// d normalize(v) / dv applied to dv (reference auxiliary.h:110-120)
+__device__ __forceinline__ void dnorm_dv(float vx, float vy, float vz, const float* dv, float* o)
+{
+    const float sum2 = vx * vx + vy * vy + vz * vz;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    o[0] = ((+sum2 - vx * vx) * dv[0] - vy * vx * dv[1] - vz * vx * dv[2]) * invsum32;
+    o[1] = (-vx * vy * dv[0] + (sum2 - vy * vy) * dv[1] - vz * vy * dv[2]) * invsum32;
+    o[2] = (-vx * vz * dv[0] - vy * vz * dv[1] + (sum2 - vz * vz) * dv[2]) * invsum32;
+}
+
+struct PreFwdArgs {
+    gft_config c;
+    gft_forward_io io;
+    GeomView g;
+    float focal_x, focal_y, dist2phase;
+    int gx, gy;
+};
+
+__global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
+{
+    const int idx = blockIdx.x * GFT_BLOCK + threadIdx.x;
+    const int P = a.c.P;
+    uint32_t tiles = 0;
+
+    if (idx < P) {
+        int radius = 0;
+        const float px = a.io.means3D[3 * idx], py = a.io.means3D[3 * idx + 1], pz = a.io.means3D[3 * idx + 2];
+        const Mat16 V = load_mat(a.io.viewmatrix);
+        const float vz = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
+        if (vz < a.c.near_n || vz > a.c.far_n) {
+            if (a.c.prefiltered) atomicOr(&a.g.scan_tmp[GFT_SCAN_FLAGS], 1u);
+        } else {
+            const float vx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
+            const float vy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
+            const Mat16 PV = load_mat(a.io.projmatrix);
+            const float hx = PV.m[0] * px + PV.m[4] * py + PV.m[8] * pz + PV.m[12];
+            const float hy = PV.m[1] * px + PV.m[5] * py + PV.m[9] * pz + PV.m[13];
+            const float hw = PV.m[3] * px + PV.m[7] * py + PV.m[11] * pz + PV.m[15];
+            const float p_w = 1.0f / (hw + 0.0000001f);
+            const float ndc_x = hx * p_w, ndc_y = hy * p_w;
+
+            float cov[6];
+            if (a.io.cov3D_precomp != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) cov[i] = a.io.cov3D_precomp[6 * idx + i];
+            } else {
+                const float mod = a.c.scale_modifier;
+                const float4 q = reinterpret_cast<const float4*>(a.io.rotations)[idx];
+                cov3d_from_scale_rot(mod * a.io.scales[3 * idx], mod * a.io.scales[3 * idx + 1],
+                                     mod * a.io.scales[3 * idx + 2], q, cov);
+            }
+            const Ewa e = ewa_project(px, py, pz, V, a.focal_x, a.focal_y, a.c.tanfovx, a.c.tanfovy, cov);
+            const float ca = e.a + 0.3f, cb = e.b, cc = e.c + 0.3f;
+            const float det = ca * cc - cb * cb;
+            if (det != 0.0f) {
+                const float det_inv = 1.f / det;
+                const float conx = cc * det_inv, cony = -cb * det_inv, conz = ca * det_inv;
+                const float mid = 0.5f * (ca + cc);
+                const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+                // ndc2Pix is evaluated in double in the reference (auxiliary.h:44-47)
+                const float pix_x = (float)(((ndc_x + 1.0) * a.c.W - 1.0) * 0.5);
+                const float pix_y = (float)(((ndc_y + 1.0) * a.c.H - 1.0) * 0.5);
+                int x0, y0, x1, y1;
+                gft_get_rect(pix_x, pix_y, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
+                const uint32_t area = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
+                if (area != 0) {
+                    const float3 cam = make_float3(a.io.campos[0], a.io.campos[1], a.io.campos[2]);
+                    const float dox = px - cam.x, doy = py - cam.y, doz = pz - cam.z;
+                    const float dlen = sqrtf(dox * dox + doy * doy + doz * doz);
+                    const float dx = dox / dlen, dy = doy / dlen, dz = doz / dlen;
+
+                    float rgb[3] = {0.f, 0.f, 0.f};
+                    uint32_t clamp_bits = 0;
+                    if (a.io.colors_precomp != nullptr) {
+                        rgb[0] = a.io.colors_precomp[3 * idx];
+                        rgb[1] = a.io.colors_precomp[3 * idx + 1];
+                        rgb[2] = a.io.colors_precomp[3 * idx + 2];
+                    }
+                    if (a.io.shs != nullptr) {
+                        float res[3];
+                        sh_eval<3>(a.c.D, dx, dy, dz, a.io.shs + (size_t)idx * a.c.M * 3, res);
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            res[c] += 0.5f;
+                            if (res[c] < 0) clamp_bits |= (1u << c);
+                            rgb[c] = fmaxf(res[c], 0.0f);
+                        }
+                    }
+
+                    const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+                    const float dist_ndc = a.c.far_n / (a.c.far_n - a.c.near_n) * (1 - a.c.near_n / dist);
+                    const float factor = 1.0f / (dist * dist);
+
+                    // ToF phasor; undefined in the reference when neither input is given -> zeros
+                    float ph[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    float phase_sh = 0.f, amplitude = 0.f;
+                    bool have_phasor = false;
+                    float phase = 0.f;
+                    if (a.io.phasors_precomp != nullptr) {
+                        phase = dist * a.dist2phase;
+                        phase_sh = a.io.phasors_precomp[2 * idx];
+                        amplitude = a.io.phasors_precomp[2 * idx + 1];
+                        if (a.c.use_view_dependent_phase) phase += phase_sh;
+                        have_phasor = true;
+                    }
+                    if (a.io.shs_p != nullptr) {
+                        float res[2];
+                        const float* sp = a.io.shs_p + (size_t)idx * a.c.M_p * 2;
+                        sh_eval<2>(a.c.D, dx, dy, dz, sp, res);
+                        res[0] += 0.5f;
+                        res[1] += 0.5f;
+                        res[0] = res[0] - 0.5f - SH_C0 * sp[0];
+                        if (res[1] < 0) {
+                            clamp_bits |= 8u;
+                            res[1] = 0.0f;
+                        }
+                        phase_sh = res[0];
+                        amplitude = res[1];
+                        phase = dist * a.dist2phase + a.c.phase_offset;
+                        if (a.c.use_view_dependent_phase) phase += phase_sh;
+                        have_phasor = true;
+                    }
+                    if (have_phasor) {
+                        const float cp = cosf(phase), sn = sinf(phase), dc = a.c.dc_offset;
+                        ph[0] = cp * amplitude * factor;
+                        ph[1] = sn * amplitude * factor;
+                        ph[2] = amplitude * factor;
+                        ph[3] = (cp + dc) * amplitude * factor;
+                        ph[4] = (-cp + dc) * amplitude * factor;
+                        ph[5] = (sn + dc) * amplitude * factor;
+                        ph[6] = (-sn + dc) * amplitude * factor;
+                    }
+
+                    a.g.rec_a[2 * idx] = make_float4(pix_x, pix_y, conx, cony);
+                    a.g.rec_a[2 * idx + 1] = make_float4(conz, a.io.opacities[idx], dist_ndc, dist);
+                    a.g.rec_b[3 * idx] = make_float4(rgb[0], rgb[1], rgb[2], ph[0]);
+                    a.g.rec_b[3 * idx + 1] = make_float4(ph[1], ph[2], ph[3], ph[4]);
+                    a.g.rec_b[3 * idx + 2] = make_float4(ph[5], ph[6], phase_sh, amplitude);
+                    a.g.depth[idx] = vz;
+                    a.g.clamped[idx] = (uint8_t)clamp_bits;
+                    radius = (int)my_radius;
+                    tiles = area;
+                }
+            }
+        }
+        a.io.radii[idx] = radius;
+        a.io.pixels[idx] = 0.0f;
+        a.g.tiles[idx] = tiles;
+    }
+
+    // per-block sum of tiles_touched -> first level of the scan
+    __shared__ uint32_t wsum[GFT_BLOCK / 64];
+    const uint32_t s = gft_wave_sum_u32_to_lane63(tiles);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) a.g.scan_tmp[GFT_SCAN_BLOCKS + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ---------------------------------------------------------------------------
+struct PreBwdArgs {
+    gft_config c;
+    gft_backward_io io;
+    GeomView g;
+    float focal_x, focal_y, dist2phase;
+};
+
+__global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
+{
+    const int idx = blockIdx.x * GFT_BLOCK + threadIdx.x;
+    const int P = a.c.P;
+    const int M = a.c.M, M_p = a.c.M_p;
+    float sum_phase = 0.f, sum_dc = 0.f;
+
+    if (idx < P) {
+        const bool visible = a.io.radii[idx] > 0;
+        float dmean[3] = {0.f, 0.f, 0.f};
+        float dmean2d[2] = {0.f, 0.f};
+        float dopac = 0.f;
+        float dcolor[3] = {0.f, 0.f, 0.f};
+        float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float dscale[3] = {0.f, 0.f, 0.f};
+        float drot[4] = {0.f, 0.f, 0.f, 0.f};
+        float* dsh = a.io.shs ? a.io.dL_dsh + (size_t)idx * M * 3 : nullptr;
+        float* dsh_p = a.io.shs_p ? a.io.dL_dsh_p + (size_t)idx * M_p * 2 : nullptr;
+
+        if (visible) {
+            // accumulators written by the render backward
+            const float4* ap = reinterpret_cast<const float4*>(a.io.acc + (size_t)idx * GFT_ACC_STRIDE);
+            const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
+            dmean2d[0] = a0.x; dmean2d[1] = a0.y;
+            const float dconx = a0.z, dcony = a0.w, dconw = a1.x;
+            dopac = a1.y;
+            dcolor[0] = a1.z; dcolor[1] = a1.w; dcolor[2] = a2.x;
+            const float dph[7] = {a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+            const float ddist_in = a4.x, dndc_in = a4.y;
+
+            const float px = a.io.means3D[3 * idx], py = a.io.means3D[3 * idx + 1], pz = a.io.means3D[3 * idx + 2];
+            const Mat16 V = load_mat(a.io.viewmatrix);
+            const Mat16 PV = load_mat(a.io.projmatrix);
+
+            // ---- conic -> cov2D -> cov3D, mean (reference K8) ----
+            float cov[6];
+            float sxs = 0.f, sys = 0.f, szs = 0.f;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.io.cov3D_precomp != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) cov[i] = a.io.cov3D_precomp[6 * idx + i];
+            } else {
+                const float mod = a.c.scale_modifier;
+                q = reinterpret_cast<const float4*>(a.io.rotations)[idx];
+                sxs = mod * a.io.scales[3 * idx];
+                sys = mod * a.io.scales[3 * idx + 1];
+                szs = mod * a.io.scales[3 * idx + 2];
+                cov3d_from_scale_rot(sxs, sys, szs, q, cov);
+            }
+            {
+                const float h_x = a.focal_x, h_y = a.focal_y;
+                const Ewa e = ewa_project(px, py, pz, V, h_x, h_y, a.c.tanfovx, a.c.tanfovy, cov);
+                const float limx = 1.3f * a.c.tanfovx, limy = 1.3f * a.c.tanfovy;
+                const float x_grad_mul = (e.txtz < -limx || e.txtz > limx) ? 0.f : 1.f;
+                const float y_grad_mul = (e.tytz < -limy || e.tytz > limy) ? 0.f : 1.f;
+                const float ca = e.a + 0.3f, cb = e.b, cc = e.c + 0.3f;
+                const float denom = ca * cc - cb * cb;
+                float dL_da = 0, dL_db = 0, dL_dc = 0;
+                const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+                if (denom2inv != 0) {
+                    dL_da = denom2inv * (-cc * cc * dconx + 2 * cb * cc * dcony + (denom - ca * cc) * dconw);
+                    dL_dc = denom2inv * (-ca * ca * dconw + 2 * ca * cb * dcony + (denom - ca * cc) * dconx);
+                    dL_db = denom2inv * 2 * (cb * cc * dconx - (denom + 2 * cb * cb) * dcony + ca * cb * dconw);
+                    dcov[0] = (e.T00 * e.T00 * dL_da + e.T00 * e.T10 * dL_db + e.T10 * e.T10 * dL_dc);
+                    dcov[3] = (e.T01 * e.T01 * dL_da + e.T01 * e.T11 * dL_db + e.T11 * e.T11 * dL_dc);
+                    dcov[5] = (e.T02 * e.T02 * dL_da + e.T02 * e.T12 * dL_db + e.T12 * e.T12 * dL_dc);
+                    dcov[1] = 2 * e.T00 * e.T01 * dL_da + (e.T00 * e.T11 + e.T01 * e.T10) * dL_db + 2 * e.T10 * e.T11 * dL_dc;
+                    dcov[2] = 2 * e.T00 * e.T02 * dL_da + (e.T00 * e.T12 + e.T02 * e.T10) * dL_db + 2 * e.T10 * e.T12 * dL_dc;
+                    dcov[4] = 2 * e.T02 * e.T01 * dL_da + (e.T01 * e.T12 + e.T02 * e.T11) * dL_db + 2 * e.T11 * e.T12 * dL_dc;
+                }
+                // dL/dT (rows 0,1); Vrk[i][j] symmetric
+                const float v00 = cov[0], v01 = cov[1], v02 = cov[2], v11 = cov[3], v12 = cov[4], v22 = cov[5];
+                const float dT00 = 2 * (e.T00 * v00 + e.T01 * v01 + e.T02 * v02) * dL_da + (e.T10 * v00 + e.T11 * v01 + e.T12 * v02) * dL_db;
+                const float dT01 = 2 * (e.T00 * v01 + e.T01 * v11 + e.T02 * v12) * dL_da + (e.T10 * v01 + e.T11 * v11 + e.T12 * v12) * dL_db;
+                const float dT02 = 2 * (e.T00 * v02 + e.T01 * v12 + e.T02 * v22) * dL_da + (e.T10 * v02 + e.T11 * v12 + e.T12 * v22) * dL_db;
+                const float dT10 = 2 * (e.T10 * v00 + e.T11 * v01 + e.T12 * v02) * dL_dc + (e.T00 * v00 + e.T01 * v01 + e.T02 * v02) * dL_db;
+                const float dT11 = 2 * (e.T10 * v01 + e.T11 * v11 + e.T12 * v12) * dL_dc + (e.T00 * v01 + e.T01 * v11 + e.T02 * v12) * dL_db;
+                const float dT12 = 2 * (e.T10 * v02 + e.T11 * v12 + e.T12 * v22) * dL_dc + (e.T00 * v02 + e.T01 * v12 + e.T02 * v22) * dL_db;
+                // W[0][r] = (v0,v4,v8), W[1][r] = (v1,v5,v9), W[2][r] = (v2,v6,v10)
+                const float dJ00 = V.m[0] * dT00 + V.m[4] * dT01 + V.m[8] * dT02;
+                const float dJ02 = V.m[2] * dT00 + V.m[6] * dT01 + V.m[10] * dT02;
+                const float dJ11 = V.m[1] * dT10 + V.m[5] * dT11 + V.m[9] * dT12;
+                const float dJ12 = V.m[2] * dT10 + V.m[6] * dT11 + V.m[10] * dT12;
+                const float tz = 1.f / e.t2, tz2 = tz * tz, tz3 = tz2 * tz;
+                const float dtx = x_grad_mul * -h_x * tz2 * dJ02;
+                const float dty = y_grad_mul * -h_y * tz2 * dJ12;
+                const float dtz = -h_x * tz2 * dJ00 - h_y * tz2 * dJ11 + (2 * h_x * e.t0) * tz3 * dJ02 + (2 * h_y * e.t1) * tz3 * dJ12;
+                dmean[0] = V.m[0] * dtx + V.m[1] * dty + V.m[2] * dtz;
+                dmean[1] = V.m[4] * dtx + V.m[5] * dty + V.m[6] * dtz;
+                dmean[2] = V.m[8] * dtx + V.m[9] * dty + V.m[10] * dtz;
+            }
+
+            // ---- screen-space mean -> 3D mean (reference K9, :498-519) ----
+            const float hw = PV.m[3] * px + PV.m[7] * py + PV.m[11] * pz + PV.m[15];
+            const float m_w = 1.0f / (hw + 0.0000001f);
+            const float mvx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
+            const float mvy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
+            const float mvz = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
+            {
+                const float mul1 = (PV.m[0] * px + PV.m[4] * py + PV.m[8] * pz + PV.m[12]) * m_w * m_w;
+                const float mul2 = (PV.m[1] * px + PV.m[5] * py + PV.m[9] * pz + PV.m[13]) * m_w * m_w;
+                const float gx2 = dmean2d[0], gy2 = dmean2d[1];
+                dmean[0] += (PV.m[0] * m_w - PV.m[3] * mul1) * gx2 + (PV.m[1] * m_w - PV.m[3] * mul2) * gy2;
+                dmean[1] += (PV.m[4] * m_w - PV.m[7] * mul1) * gx2 + (PV.m[5] * m_w - PV.m[7] * mul2) * gy2;
+                dmean[2] += (PV.m[8] * m_w - PV.m[11] * mul1) * gx2 + (PV.m[9] * m_w - PV.m[11] * mul2) * gy2;
+            }
+
+            const float dox = px - a.io.campos[0], doy = py - a.io.campos[1], doz = pz - a.io.campos[2];
+            const float dlen = sqrtf(dox * dox + doy * doy + doz * doz);
+            const float dx = dox / dlen, dy = doy / dlen, dz = doz / dlen;
+            const uint32_t clamp_bits = a.g.clamped[idx];
+
+            // ---- colour SH (reference backward.cu:20-139) ----
+            if (a.io.shs != nullptr) {
+                float dres[3], ddir[3], dm[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) dres[c] = dcolor[c] * (((clamp_bits >> c) & 1u) ? 0.f : 1.f);
+                sh_backward<3>(a.c.D, M, dx, dy, dz, a.io.shs + (size_t)idx * M * 3, dres, dsh, ddir);
+                dnorm_dv(dox, doy, doz, ddir, dm);
+                dmean[0] += dm[0]; dmean[1] += dm[1]; dmean[2] += dm[2];
+            }
+
+            // ---- ToF phasor chain (reference backward.cu:527-587) ----
+            const float4 b2 = a.g.rec_b[3 * idx + 2];
+            const float dist = a.g.rec_a[2 * idx + 1].w;
+            if (a.io.shs_p != nullptr) {
+                float phase = dist * a.dist2phase + a.c.phase_offset;
+                if (a.c.use_view_dependent_phase) phase += b2.z;
+                const float amplitude = b2.w;
+                const float factor = 1.0f / (dist * dist);
+                const float dR = dph[0], dI = dph[1], dA = dph[2], dq1 = dph[3], dq2 = dph[4], dq3 = dph[5], dq4 = dph[6];
+                const float sin_p = sinf(phase), cos_p = cosf(phase), dc = a.c.dc_offset;
+                const float S = (dR * -sin_p + dI * cos_p + dq1 * -sin_p + dq2 * sin_p + dq3 * cos_p + dq4 * -cos_p);
+                float dCW[2] = {0.f, 0.f};
+                if (a.c.use_view_dependent_phase) dCW[0] = S * amplitude * factor;
+                sum_phase = S * amplitude * factor;
+                dCW[1] = (dR * cos_p + dI * sin_p + dA + dq1 * (cos_p + dc) + dq2 * (-cos_p + dc) +
+                          dq3 * (sin_p + dc) + dq4 * (-sin_p + dc)) * factor;
+                sum_dc = (dq1 + dq2 + dq3 + dq4) * amplitude * factor;
+                const float coeff = S * a.dist2phase * amplitude * factor / dist +
+                                    (dR * -cos_p + dI * -sin_p - dA + dq1 * -(cos_p + dc) + dq2 * (cos_p - dc) +
+                                     dq3 * -(sin_p + dc) + dq4 * (sin_p - dc)) * 2.0f * amplitude * factor * factor;
+                const float dxv = mvx * coeff, dyv = mvy * coeff, dzv = mvz * coeff;
+                dmean[0] += dxv * V.m[0] + dyv * V.m[1] + dzv * V.m[2];
+                dmean[1] += dxv * V.m[4] + dyv * V.m[5] + dzv * V.m[6];
+                dmean[2] += dxv * V.m[8] + dyv * V.m[9] + dzv * V.m[10];
+
+                float dres[2], ddir[3], dm[3];
+                dres[0] = dCW[0];
+                dres[1] = dCW[1] * ((clamp_bits & 8u) ? 0.f : 1.f);
+                sh_backward<2>(a.c.D, M_p, dx, dy, dz, a.io.shs_p + (size_t)idx * M_p * 2, dres, dsh_p, ddir);
+                dnorm_dv(dox, doy, doz, ddir, dm);
+                dmean[0] += dm[0]; dmean[1] += dm[1]; dmean[2] += dm[2];
+            }
+
+            // ---- distance chain (reference backward.cu:589-601) ----
+            {
+                const float dndc_ddist = (a.c.far_n * a.c.near_n) / ((a.c.far_n - a.c.near_n) * dist * dist);
+                const float ddist = dndc_in * dndc_ddist + ddist_in;
+                const float dxv = ddist * mvx / dist, dyv = ddist * mvy / dist, dzv = ddist * mvz / dist;
+                dmean[0] += dxv * V.m[0] + dyv * V.m[1] + dzv * V.m[2];
+                dmean[1] += dxv * V.m[4] + dyv * V.m[5] + dzv * V.m[6];
+                dmean[2] += dxv * V.m[8] + dyv * V.m[9] + dzv * V.m[10];
+            }
+
+            // ---- cov3D -> scale, rotation (reference backward.cu:399-462) ----
+            if (a.io.scales != nullptr) {
+                const float r = q.x, x = q.y, y = q.z, z = q.w;
+                // R[c][k] (GLM columns) and M[c][k] = s_k R[c][k]
+                const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
+                const float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
+                const float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
+                const float s[3] = {sxs, sys, szs};
+                const float Rm[3][3] = {{R00, R01, R02}, {R10, R11, R12}, {R20, R21, R22}};
+                // dL_dSigma columns
+                const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                        {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                        {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+                // dL_dM = (2 M) * dL_dSigma ; dMt[i][j] = dL_dM[j][i]
+                float dMt[3][3];
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++) {
+                        const float m0 = 2.0f * (s[rr] * Rm[0][rr]), m1 = 2.0f * (s[rr] * Rm[1][rr]), m2 = 2.0f * (s[rr] * Rm[2][rr]);
+                        dMt[rr][c] = m0 * dS[c][0] + m1 * dS[c][1] + m2 * dS[c][2];
+                    }
+                // Rt[i][j] = R[j][i]; dscale_i = dot(Rt[i], dMt[i])
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    dscale[i] = Rm[0][i] * dMt[i][0] + Rm[1][i] * dMt[i][1] + Rm[2][i] * dMt[i][2];
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) dMt[i][j] *= s[i];
+                drot[0] = 2 * z * (dMt[0][1] - dMt[1][0]) + 2 * y * (dMt[2][0] - dMt[0][2]) + 2 * x * (dMt[1][2] - dMt[2][1]);
+                drot[1] = 2 * y * (dMt[1][0] + dMt[0][1]) + 2 * z * (dMt[2][0] + dMt[0][2]) + 2 * r * (dMt[1][2] - dMt[2][1]) - 4 * x * (dMt[2][2] + dMt[1][1]);
+                drot[2] = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) - 4 * y * (dMt[2][2] + dMt[0][0]);
+                drot[3] = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) - 4 * z * (dMt[1][1] + dMt[0][0]);
+                // reference applies scale_modifier inside s but returns dL/dscale without it
+                // (backward.cu:443-446 dot(Rt, dL_dMt) before the s multiply): keep as is.
+            }
+        } else {
+            // culled: every returned gradient row is zero
+            if (dsh) for (int k = 0; k < M * 3; k++) dsh[k] = 0.f;
+            if (dsh_p) for (int k = 0; k < M_p * 2; k++) dsh_p[k] = 0.f;
+        }
+
+        a.io.dL_dmeans3D[3 * idx] = dmean[0];
+        a.io.dL_dmeans3D[3 * idx + 1] = dmean[1];
+        a.io.dL_dmeans3D[3 * idx + 2] = dmean[2];
+        a.io.dL_dmeans2D[3 * idx] = dmean2d[0];
+        a.io.dL_dmeans2D[3 * idx + 1] = dmean2d[1];
+        a.io.dL_dmeans2D[3 * idx + 2] = 0.f;
+        a.io.dL_dopacity[idx] = dopac;
+        if (a.io.dL_dcolors) {
+            a.io.dL_dcolors[3 * idx] = dcolor[0];
+            a.io.dL_dcolors[3 * idx + 1] = dcolor[1];
+            a.io.dL_dcolors[3 * idx + 2] = dcolor[2];
+        }
+        if (a.io.dL_dcov3D) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) a.io.dL_dcov3D[6 * idx + i] = dcov[i];
+        }
+        if (a.io.scales != nullptr) {
+            a.io.dL_dscales[3 * idx] = dscale[0];
+            a.io.dL_dscales[3 * idx + 1] = dscale[1];
+            a.io.dL_dscales[3 * idx + 2] = dscale[2];
+            reinterpret_cast<float4*>(a.io.dL_drotations)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+        }
+    }
+
+    // phase/dc offset gradients: one atomic per workgroup instead of one per Gaussian
+    __shared__ float wsum[2][GFT_BLOCK / 64];
+    const float sp = gft_wave_sum_to_lane63(sum_phase);
+    const float sd = gft_wave_sum_to_lane63(sum_dc);
+    if ((threadIdx.x & 63) == 63) {
+        wsum[0][threadIdx.x >> 6] = sp;
+        wsum[1][threadIdx.x >> 6] = sd;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && a.io.shs_p != nullptr) {
+        const float tp = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+        const float td = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+        if (tp != 0.f) atomicAdd(a.io.dL_dphase_offset, tp);
+        if (td != 0.f) atomicAdd(a.io.dL_ddc_offset, td);
+    }
+}
+
+__global__ __launch_bounds__(GFT_BLOCK) void k_mark_visible(int P, const float* __restrict__ means3D,
+                                                            const float* __restrict__ view, float near_n,
+                                                            float far_n, uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * GFT_BLOCK + threadIdx.x;
+    if (idx >= P) return;
+    const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+    const float vz = view[2] * px + view[6] * py + view[10] * pz + view[14];
+    present[idx] = (vz < near_n || vz > far_n) ? 0 : 1;
+}
+
+}  // namespace
+
+hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g)
+{
+    PreFwdArgs a;
+    a.c = c;
+    a.io = io;
+    a.g = g;
+    // reference rasterizer_impl.cu:249-250, forward.cu:752
+    a.focal_y = c.H / (2.0f * c.tanfovy);
+    a.focal_x = c.W / (2.0f * c.tanfovx);
+    a.dist2phase = 4.0f * 3.14159265358979323846f / c.depth_range;
+    a.gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X;
+    a.gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    const int blocks = (c.P + GFT_BLOCK - 1) / GFT_BLOCK;
+    hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(GFT_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io, const GeomView& g)
+{
+    PreBwdArgs a;
+    a.c = c;
+    a.io = io;
+    a.g = g;
+    a.focal_y = c.H / (2.0f * c.tanfovy);
+    a.focal_x = c.W / (2.0f * c.tanfovx);
+    a.dist2phase = 4.0f * 3.14159265358979323846f / c.depth_range;
+    const int blocks = (c.P + GFT_BLOCK - 1) / GFT_BLOCK;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(GFT_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t gft_launch_mark_visible(hipStream_t s, int32_t P, const float* means3D, const float* view,
+                                   float near_n, float far_n, uint8_t* present)
+{
+    const int blocks = (P + GFT_BLOCK - 1) / GFT_BLOCK;
+    hipLaunchKernelGGL(k_mark_visible, dim3(blocks), dim3(GFT_BLOCK), 0, s, P, means3D, view, near_n, far_n, present);
+    return hipGetLastError();
+}

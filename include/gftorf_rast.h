@@ -1,0 +1,217 @@
+/*
+ * gftorf_rast.h -- C ABI of libgftorf_rast.so: the MI355X (gfx950) differentiable
+ * ToF Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the reference's native extension
+ * `diff_gaussian_rasterization_w_tof._C` (RAST/ext.cpp:15-19, where RAST/ =
+ * submodules/diff-gaussian-rasterization-w-tof/ of brownvc/gftorf):
+ *
+ *   _C.rasterize_gaussians           (RAST/rasterize_points.cu:42-165)
+ *        -> gft_forward_preprocess() + gft_forward_render()
+ *   _C.rasterize_gaussians_backward  (RAST/rasterize_points.cu:167-281)
+ *        -> gft_backward()
+ *   _C.mark_visible                  (RAST/rasterize_points.cu:283-304)
+ *        -> gft_mark_visible()
+ *
+ * Plain pointers and sizes only, no torch types.  All pointers are DEVICE
+ * pointers unless a comment says "host".  The library keeps no state between
+ * calls: the caller owns every buffer, including the three scratch buffers
+ * (reference: geomBuffer / binningBuffer / imgBuffer, RAST/rasterize_points.cu:
+ * 94-101), which must survive from forward to backward.  A NULL input pointer
+ * means "tensor absent" (reference: `.data<float>()` of an empty tensor is
+ * nullptr and is tested at RAST/cuda_rasterizer/forward.cu:310,346,353,365,389).
+ * Every entry point returns 0 on success, non-zero on error; the message is
+ * available from gft_last_error() (thread local).
+ */
+#ifndef GFTORF_RAST_H
+#define GFTORF_RAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFT_ABI_VERSION 1
+
+/* compile-time constants of the reference (RAST/cuda_rasterizer/config.h:15-23) */
+#define GFT_NUM_CHANNELS 3
+#define GFT_NUM_CHANNELS_PHASOR 7
+#define GFT_NUM_CHANNELS_CWTOF 2
+#define GFT_TILE_X 16
+#define GFT_TILE_Y 16
+/* floats per Gaussian in the backward accumulator table (18 used + 2 pad) */
+#define GFT_ACC_STRIDE 20
+
+/* Scalar arguments of one rasterizer call: the non-tensor fields of
+ * GaussianRasterizationSettings (RAST/diff_gaussian_rasterization_w_tof/
+ * __init__.py:22-40) plus the sizes RasterizeGaussiansCUDA derives
+ * (RAST/rasterize_points.cu:73-75,106-122). */
+typedef struct gft_config {
+    int32_t P;       /* number of Gaussians */
+    int32_t D;       /* active SH degree (0..3) */
+    int32_t M;       /* colour SH coefficients per Gaussian in memory (0 = shs absent) */
+    int32_t M_p;     /* phasor SH coefficients per Gaussian in memory (0 = shs_p absent) */
+    int32_t W, H;    /* image size */
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    float near_n, far_n;
+    float depth_range;
+    float phase_offset, dc_offset;
+    int32_t use_view_dependent_phase;
+    int32_t prefiltered;
+    int32_t debug;   /* synchronise + check after every stage (reference CHECK_CUDA) */
+    /* background [7,H,W] addressed as bg[c*sc + y*sy + x*sx] (element strides), so
+     * the reference's expanded constant background (train.py:127) needs no copy */
+    int64_t bg_stride_c, bg_stride_y, bg_stride_x;
+} gft_config;
+
+/* Tensors of the forward call (argument order of RAST/rasterize_points.cu:42-67). */
+typedef struct gft_forward_io {
+    /* inputs */
+    const float* bg;               /* [7,H,W] via strides in gft_config */
+    const float* means3D;          /* [P,3] */
+    const float* colors_precomp;   /* [P,3] or NULL */
+    const float* phasors_precomp;  /* [P,2] or NULL */
+    const float* opacities;        /* [P] */
+    const float* scales;           /* [P,3] or NULL */
+    const float* rotations;        /* [P,4] (r,x,y,z) or NULL */
+    const float* cov3D_precomp;    /* [P,6] or NULL */
+    const float* viewmatrix;       /* 16 floats, transposed storage */
+    const float* projmatrix;       /* 16 floats, transposed storage (full projection) */
+    const float* campos;           /* 3 floats */
+    const float* shs;              /* [P,M,3] or NULL */
+    const float* shs_p;            /* [P,M_p,2] or NULL */
+    /* scratch, caller-owned, sizes from gft_geom_bytes / gft_image_bytes /
+     * gft_binning_bytes; contents are the forward->backward hand-off */
+    void* geom;
+    void* img;
+    void* binning;                 /* may be NULL for gft_forward_preprocess */
+    /* outputs (all written in full by the library; no pre-zeroing needed) */
+    float* out_color;              /* [3,H,W] */
+    float* out_phasor;             /* [7,H,W] */
+    float* out_depth;              /* [1,H,W] */
+    float* out_normal;             /* [3,H,W] always 0 (reference never writes it) */
+    float* out_acc;                /* [1,H,W] */
+    float* out_entropy;            /* [1,H,W] always 0 */
+    float* out_depth_distortion;   /* [1,H,W] */
+    float* out_amp_distortion;     /* [1,H,W] always 0 */
+    float* pixels;                 /* [P,1] contributing-pixel count per Gaussian */
+    float* out_distribution;       /* [3,H,W] first-hit (alpha, dist, amplitude/d^2) */
+    int32_t* radii;                /* [P] */
+} gft_forward_io;
+
+/* Tensors of the backward call (RAST/rasterize_points.cu:167-198). */
+typedef struct gft_backward_io {
+    /* forward inputs again */
+    const float* bg;
+    const float* means3D;
+    const int32_t* radii;
+    const float* scales;
+    const float* rotations;
+    const float* cov3D_precomp;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* campos;
+    const float* shs;
+    const float* shs_p;
+    /* upstream gradients, contiguous [C,H,W]; NULL = all zeros.  Gradients of
+     * normal / entropy / amp_distortion / pixels / distribution are accepted by
+     * the reference and ignored by its kernels, so they are not part of the ABI */
+    const float* dL_dout_color;              /* [3,H,W] */
+    const float* dL_dout_phasor;             /* [7,H,W] */
+    const float* dL_dout_depth;              /* [1,H,W] */
+    const float* dL_dout_acc;                /* [1,H,W] */
+    const float* dL_dout_depth_distortion;   /* [1,H,W] */
+    /* forward scratch */
+    const void* geom;
+    const void* img;
+    const void* binning;
+    /* backward scratch: [P, GFT_ACC_STRIDE] floats, zeroed by the library */
+    float* acc;
+    /* outputs, written in full (zeros for culled Gaussians); NULL = not wanted */
+    float* dL_dmeans3D;     /* [P,3] */
+    float* dL_dmeans2D;     /* [P,3] (x,y in NDC-derivative units, z = 0) */
+    float* dL_dcolors;      /* [P,3]  grad of colors_precomp, may be NULL */
+    float* dL_dopacity;     /* [P,1] */
+    float* dL_dcov3D;       /* [P,6]  grad of cov3D_precomp, may be NULL */
+    float* dL_dsh;          /* [P,M,3]   required iff shs   != NULL */
+    float* dL_dsh_p;        /* [P,M_p,2] required iff shs_p != NULL */
+    float* dL_dscales;      /* [P,3]  required iff scales != NULL */
+    float* dL_drotations;   /* [P,4]  required iff scales != NULL */
+    float* dL_dphase_offset;/* [1] (zeroed + accumulated by the library) */
+    float* dL_ddc_offset;   /* [1] */
+} gft_backward_io;
+
+/* Byte offsets of the sub-arrays inside the scratch buffers (the forward <->
+ * backward layout contract; reference: GeometryState/ImageState/BinningState::
+ * fromChunk, RAST/cuda_rasterizer/rasterizer_impl.cu:161-211).  Exposed so
+ * tests can inspect intermediate state stage by stage. */
+typedef struct gft_layout {
+    /* geom */
+    size_t geom_rec_a;        /* float[P][8]  {x,y, conic a,b,c, opacity, dist_ndc, dist} */
+    size_t geom_rec_b;        /* float[P][12] {r,g,b, phasor[7], phase_sh, amplitude} */
+    size_t geom_depth;        /* float[P]     view-space z (sort key bits) */
+    size_t geom_tiles;        /* uint32[P]    tiles touched */
+    size_t geom_offsets;      /* uint32[P]    inclusive scan of tiles */
+    size_t geom_clamped;      /* uint8[P]     bit0..2 rgb clamped, bit3 amplitude clamped */
+    size_t geom_scan_tmp;
+    size_t geom_total;
+    /* img */
+    size_t img_pix_state;     /* float[N][4]  {final_T, n_contrib(bits), w_z, w_z2} */
+    size_t img_ranges;        /* uint32[T][2] */
+    size_t img_tile_max;      /* uint32[T]    max n_contrib over the tile */
+    size_t img_total;
+    /* binning */
+    size_t bin_keys_unsorted; /* uint64[R] */
+    size_t bin_keys;          /* uint64[R] sorted */
+    size_t bin_vals_unsorted; /* uint32[R] */
+    size_t bin_point_list;    /* uint32[R] sorted Gaussian ids */
+    size_t bin_sort_tmp;
+    size_t bin_total;
+} gft_layout;
+
+/* per-stage GPU time in milliseconds, accumulated while profiling is enabled */
+typedef struct gft_profile {
+    double preprocess_fwd_ms, scan_ms, duplicate_ms, sort_ms, ranges_ms, render_fwd_ms;
+    double render_bwd_ms, preprocess_bwd_ms, memset_ms;
+    int64_t forward_calls, backward_calls;
+} gft_profile;
+
+int gft_abi_version(void);
+const char* gft_last_error(void);   /* host string, thread local */
+
+size_t gft_geom_bytes(int32_t P);
+size_t gft_image_bytes(int32_t W, int32_t H);
+size_t gft_binning_bytes(int64_t R, int32_t W, int32_t H);
+int gft_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* out /*host*/);
+
+/* Stage 1 of the forward: preprocess (reference K1) + inclusive scan, then one
+ * blocking read of the number of (Gaussian, tile) instances, exactly where the
+ * reference blocks (RAST/cuda_rasterizer/rasterizer_impl.cu:311).
+ * *num_rendered (host) receives R; the caller then sizes `binning`. */
+int gft_forward_preprocess(void* hip_stream, const gft_config* cfg,
+                           const gft_forward_io* io, int64_t* num_rendered /*host*/);
+
+/* Stage 2 of the forward: duplicate-with-keys, sort, tile ranges, per-tile blend. */
+int gft_forward_render(void* hip_stream, const gft_config* cfg,
+                       const gft_forward_io* io, int64_t num_rendered);
+
+int gft_backward(void* hip_stream, const gft_config* cfg,
+                 const gft_backward_io* io, int64_t num_rendered);
+
+int gft_mark_visible(void* hip_stream, int32_t P, const float* means3D,
+                     const float* viewmatrix, const float* projmatrix,
+                     float near_n, float far_n, uint8_t* present);
+
+/* HIP-event timing of every stage on the stream it is launched on (bench.py
+ * roofline leg).  Enabling it adds two event records per stage. */
+int gft_profile_enable(int on);
+int gft_profile_reset(void);
+int gft_profile_read(gft_profile* out /*host*/);   /* synchronises pending events */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,328 @@
+"""GPU parity: HIP path (public API -> C ABI -> gfx950 kernels) vs the CPU oracle on
+identical seeded inputs.  Integer/index stages bit-exact, fp32 stages within the
+tolerances written below (north star: rendered L1 < 1e-5, bit-exact tile/key
+indexing)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+# fp32 tolerances (relative to the max-norm of the reference tensor)
+IMG_L1 = 1e-5          # north star: mean abs error of rendered images
+IMG_MAX = 2e-4         # max-norm, allows a handful of borderline alpha/termination flips
+GRAD_RTOL = 3e-4       # gradients: fp32 atomics/reduction order + T recovered by division
+
+
+# ---------------------------------------------------------------------------
+def raw_forward(scene, dev, inputs=None):
+    """Drive the C ABI directly so the scratch buffers can be inspected."""
+    from gftorf_amd import _lib
+    lib = _lib.load()
+    g = dict(scene["gaussians"])
+    if inputs:
+        g.update(inputs)
+    cfgd, cam = scene["cfg"], scene["cam"]
+    P, W, H = g["means3D"].shape[0], cfgd["W"], cfgd["H"]
+    t = lambda a: None if a is None else torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+    T = {k: t(v) for k, v in g.items()}
+    view, proj, campos, bg = t(cam["viewmatrix"]), t(cam["projmatrix"]), t(cam["campos"]), t(scene["bg"])
+    c = _lib.Config()
+    c.P, c.D, c.W, c.H = P, cfgd["D"], W, H
+    c.M = g["shs"].shape[1] if g.get("shs") is not None else 0
+    c.M_p = g["shs_p"].shape[1] if g.get("shs_p") is not None else 0
+    c.tanfovx, c.tanfovy, c.scale_modifier = cam["tanfovx"], cam["tanfovy"], 1.0
+    c.near_n, c.far_n, c.depth_range = cam["znear"], cam["zfar"], scene["depth_range"]
+    c.phase_offset, c.dc_offset = scene["phase_offset"], scene["dc_offset"]
+    c.use_view_dependent_phase = int(scene["use_view_dependent_phase"])
+    c.bg_stride_c, c.bg_stride_y, c.bg_stride_x = H * W, W, 1
+    planes = torch.full((21, H, W), float("nan"), device=dev)
+    radii = torch.full((P,), -7, device=dev, dtype=torch.int32)
+    pixels = torch.full((P, 1), float("nan"), device=dev)
+    geom = torch.zeros(lib.gft_geom_bytes(P), device=dev, dtype=torch.uint8)
+    img = torch.zeros(lib.gft_image_bytes(W, H), device=dev, dtype=torch.uint8)
+    io = _lib.ForwardIO()
+    p = lambda x: None if x is None else x.data_ptr()
+    io.bg, io.means3D, io.opacities = p(bg), p(T["means3D"]), p(T["opacities"])
+    io.colors_precomp, io.phasors_precomp = p(T.get("colors_precomp")), p(T.get("phasors_precomp"))
+    io.scales, io.rotations, io.cov3D_precomp = p(T.get("scales")), p(T.get("rotations")), p(T.get("cov3D_precomp"))
+    io.viewmatrix, io.projmatrix, io.campos = p(view), p(proj), p(campos)
+    io.shs, io.shs_p = p(T.get("shs")), p(T.get("shs_p"))
+    io.geom, io.img = p(geom), p(img)
+    sl = [0, 3, 10, 11, 14, 15, 16, 17, 18, 21]
+    names = ["out_color", "out_phasor", "out_depth", "out_normal", "out_acc", "out_entropy",
+             "out_depth_distortion", "out_amp_distortion", "out_distribution"]
+    for n, a in zip(names, sl[:-1]):
+        setattr(io, n, planes[a].data_ptr())
+    io.pixels, io.radii = p(pixels), p(radii)
+    R = C.c_int64(0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.gft_forward_preprocess(stream, C.byref(c), C.byref(io), C.byref(R)))
+    R = int(R.value)
+    binning = torch.zeros(lib.gft_binning_bytes(R, W, H), device=dev, dtype=torch.uint8)
+    io.binning = p(binning)
+    _lib.check(lib.gft_forward_render(stream, C.byref(c), C.byref(io), R))
+    torch.cuda.synchronize()
+    L = _lib.get_layout(P, W, H, R)
+    keep = (T, view, proj, campos, bg)
+
+    def view_of(buf, off, count, dtype):
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return buf[off:off + nbytes].view(dtype).cpu().numpy()
+
+    Tn = ((W + 15) // 16) * ((H + 15) // 16)
+    st = dict(
+        R=R, radii=radii.cpu().numpy(), pixels=pixels.cpu().numpy(), planes=planes.cpu().numpy(),
+        rec_a=view_of(geom, L.geom_rec_a, P * 8, torch.float32).reshape(P, 8),
+        rec_b=view_of(geom, L.geom_rec_b, P * 12, torch.float32).reshape(P, 12),
+        depth=view_of(geom, L.geom_depth, P, torch.float32),
+        tiles=view_of(geom, L.geom_tiles, P, torch.int32).astype(np.uint32),
+        offsets=view_of(geom, L.geom_offsets, P, torch.int32).astype(np.uint32),
+        clamped=view_of(geom, L.geom_clamped, P, torch.uint8),
+        pix_state=view_of(img, L.img_pix_state, W * H * 4, torch.float32).reshape(H * W, 4),
+        ranges=view_of(img, L.img_ranges, Tn * 2, torch.int32).astype(np.uint32).reshape(Tn, 2),
+        tile_max=view_of(img, L.img_tile_max, Tn, torch.int32).astype(np.uint32),
+        keys=view_of(binning, L.bin_keys, R, torch.int64).astype(np.uint64) if R else np.zeros(0, np.uint64),
+        point_list=view_of(binning, L.bin_point_list, R, torch.int32).astype(np.uint32) if R else np.zeros(0, np.uint32),
+    )
+    del keep
+    return st
+
+
+SCENES = {
+    "base": dict(),
+    "odd_size": dict(W=50, H=37, P=300),
+    "deep_lists": dict(P=1500, W=48, H=32, scale_lo=0.03, scale_hi=0.2),   # > 256 splats per tile
+    "wide_spread": dict(spread=1.7, P=500),                               # frustum clamp of t.x/t.z
+    "identity_cam": dict(w2c=None),
+    "tiny_splats": dict(scale_lo=0.001, scale_hi=0.004, P=600),
+    "opaque_early_exit": dict(P=2500, W=64, H=48, scale_lo=0.05, scale_hi=0.25, opacity=0.95),  # T < 1e-4 termination
+}
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_preprocess_and_binning_bit_exact(name, oracle, gpu):
+    scene = Hh.small_scene(**SCENES[name])
+    f, _ = Hh.run_oracle(oracle, scene, backward=False)
+    st = raw_forward(scene, gpu)
+    og = f.geom
+    vis = og["radii"] > 0
+    # integer decisions
+    np.testing.assert_array_equal(st["radii"], og["radii"])
+    np.testing.assert_array_equal(st["tiles"], og["tiles_touched"])
+    np.testing.assert_array_equal(st["offsets"], f.offsets)
+    assert st["R"] == f.num_rendered
+    # IEEE-exact float stages (contraction disabled on both sides)
+    np.testing.assert_array_equal(st["rec_a"][vis, 0:2], og["means2D"][vis])
+    np.testing.assert_array_equal(st["depth"][vis].view(np.uint32), og["depths"][vis].view(np.uint32))
+    np.testing.assert_array_equal(st["rec_a"][vis, 2:4], og["conic_opacity"][vis, 0:2])
+    np.testing.assert_array_equal(st["rec_a"][vis, 4:6], og["conic_opacity"][vis, 2:4])
+    np.testing.assert_array_equal(st["rec_a"][vis, 6], og["dists_ndc"][vis])
+    np.testing.assert_array_equal(st["rec_a"][vis, 7], og["dists"][vis])
+    np.testing.assert_array_equal(st["rec_b"][vis, 0:3], og["rgb"][vis])
+    cl = og["clamped"][vis, 0] | (og["clamped"][vis, 1] << 1) | (og["clamped"][vis, 2] << 2) | (og["clamped_p"][vis] << 3)
+    np.testing.assert_array_equal(st["clamped"][vis], cl)
+    # transcendental stage (sinf/cosf differ by ulps between glibc and the device library)
+    Hh.assert_close("phasor7", og["phasor7"][vis], st["rec_b"][vis, 3:10], rtol_max=2e-6, atol=1e-9)
+    Hh.assert_close("phase_amp", og["phase_amp"][vis], st["rec_b"][vis, 10:12], rtol_max=1e-6, atol=1e-9)
+    # keys / sorted list / ranges: bit-identical
+    np.testing.assert_array_equal(st["keys"], f.keys_sorted)
+    np.testing.assert_array_equal(st["point_list"], f.point_list)
+    np.testing.assert_array_equal(st["ranges"], f.ranges)
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_forward_backward_vs_oracle(name, oracle, gpu):
+    scene = Hh.small_scene(**SCENES[name])
+    f, b = Hh.run_oracle(oracle, scene)
+    out, grads, _ = Hh.run_gpu(scene, gpu, optimize_offsets=True)
+    check_outputs(f, out)
+    check_grads(b, grads, scene)
+
+
+def check_outputs(f, out):
+    for k in ["color", "phasor", "depth", "acc", "depth_distortion", "distribution"]:
+        l1 = np.abs(out[k].astype(np.float64) - f[k]).mean()
+        scale = max(1.0, np.abs(f[k]).max())
+        assert l1 < IMG_L1 * scale, "%s: L1 %.3g" % (k, l1)
+        Hh.assert_close(k, f[k], out[k], rtol_max=IMG_MAX, atol=1e-6, frac_bad=1e-3)
+    for k in ["normal", "entropy", "amp_distortion"]:
+        assert not out[k].any(), k
+    np.testing.assert_array_equal(out["radii"], f.radii)
+    # integer-valued counters: exact unless an alpha sits on the 1/255 or T=1e-4 edge
+    mism = (out["pixels"] != f.pixels).mean() if f.pixels.size else 0.0
+    assert mism <= 2e-3, "pixels mismatch fraction %.3g" % mism
+    assert abs(out["pixels"].sum() - f.pixels.sum()) <= 1e-4 * max(1.0, f.pixels.sum())
+
+
+def check_grads(b, grads, scene, rtol=GRAD_RTOL):
+    g = scene["gaussians"]
+    Hh.assert_close("dL_dmeans3D", b["dL_dmeans3D"], grads["means3D"], rtol_max=rtol)
+    Hh.assert_close("dL_dmeans2D", b["dL_dmeans2D"], grads["means2D"], rtol_max=rtol)
+    Hh.assert_close("dL_dopacity", b["dL_dopacity"].reshape(g["opacities"].shape), grads["opacities"], rtol_max=rtol)
+    if g.get("shs") is not None:
+        Hh.assert_close("dL_dsh", b["dL_dsh"], grads["shs"], rtol_max=rtol)
+    if g.get("shs_p") is not None:
+        Hh.assert_close("dL_dsh_p", b["dL_dsh_p"], grads["shs_p"], rtol_max=rtol)
+        if "phase_offset" in grads:
+            Hh.assert_close("dL_dphase_offset", b["dL_dphase_offset"], grads["phase_offset"], rtol_max=rtol, atol=1e-5)
+            Hh.assert_close("dL_ddc_offset", b["dL_ddc_offset"], grads["dc_offset"], rtol_max=rtol, atol=1e-5)
+    if g.get("scales") is not None:
+        Hh.assert_close("dL_dscales", b["dL_dscales"], grads["scales"], rtol_max=rtol)
+        Hh.assert_close("dL_drotations", b["dL_drotations"], grads["rotations"], rtol_max=rtol)
+    if g.get("colors_precomp") is not None:
+        Hh.assert_close("dL_dcolors", b["dL_dcolors"], grads["colors_precomp"], rtol_max=rtol)
+    if g.get("cov3D_precomp") is not None:
+        Hh.assert_close("dL_dcov3D", b["dL_dcov3D"], grads["cov3D_precomp"], rtol_max=rtol)
+
+
+# ---- operator variants (argument patterns of gaussian_renderer/__init__.py) -----
+@pytest.mark.parametrize("D,M", [(0, 16), (1, 16), (2, 16), (3, 16), (0, 1), (1, 4), (2, 9)])
+def test_sh_degrees(D, M, oracle, gpu):
+    scene = Hh.small_scene(D=D, sh_coeffs=M, P=250)
+    f, b = Hh.run_oracle(oracle, scene)
+    out, grads, _ = Hh.run_gpu(scene, gpu, optimize_offsets=True)
+    check_outputs(f, out)
+    check_grads(b, grads, scene)
+    if M > (D + 1) ** 2:   # inactive coefficients receive exact zeros
+        assert not grads["shs"][:, (D + 1) ** 2:, :].any()
+        assert not grads["shs_p"][:, (D + 1) ** 2:, :].any()
+
+
+def test_colors_precomp_and_no_tof(oracle, gpu):
+    """render_flow pattern (gaussian_renderer/__init__.py:194-202): precomputed colours,
+    no shs_p / phasors -> phasor planes are background only."""
+    scene = Hh.small_scene(P=300, tof=False)
+    rng = np.random.default_rng(5)
+    inputs = dict(shs=None, colors_precomp=rng.random((300, 3)).astype(np.float32))
+    f, b = Hh.run_oracle(oracle, scene, inputs=inputs)
+    out, grads, _ = Hh.run_gpu(scene, gpu, inputs=inputs)
+    # the reference leaves real_img_amp uninitialised here; both sides define it as zero
+    for k in ["color", "depth", "acc", "depth_distortion"]:
+        Hh.assert_close(k, f[k], out[k], rtol_max=IMG_MAX, atol=1e-6, frac_bad=1e-3)
+    s2 = dict(scene)
+    s2["gaussians"] = dict(scene["gaussians"], **inputs)
+    check_grads(b, grads, s2)
+
+
+def test_cov3d_precomp(oracle, gpu):
+    scene = Hh.small_scene(P=300)
+    f0, _ = Hh.run_oracle(oracle, scene, backward=False)
+    inputs = dict(scales=None, rotations=None, cov3D_precomp=f0.geom["cov3D"].copy())
+    # culled rows were never written by the oracle: give them a valid covariance
+    inputs["cov3D_precomp"][f0.radii <= 0] = np.array([1e-4, 0, 0, 1e-4, 0, 1e-4], np.float32)
+    f, b = Hh.run_oracle(oracle, scene, inputs=inputs)
+    out, grads, _ = Hh.run_gpu(scene, gpu, inputs=inputs, optimize_offsets=True)
+    check_outputs(f, out)
+    s2 = dict(scene)
+    s2["gaussians"] = dict(scene["gaussians"], **inputs)
+    check_grads(b, grads, s2)
+
+
+def test_phasors_precomp(oracle, gpu):
+    scene = Hh.small_scene(P=300)
+    rng = np.random.default_rng(9)
+    pp = np.stack([rng.uniform(-0.5, 0.5, 300), rng.uniform(0.05, 0.5, 300)], 1).astype(np.float32)
+    inputs = dict(shs_p=None, phasors_precomp=pp)
+    f, b = Hh.run_oracle(oracle, scene, inputs=inputs)
+    out, grads, _ = Hh.run_gpu(scene, gpu, inputs=inputs)
+    check_outputs(f, out)
+
+
+@pytest.mark.parametrize("vdp", [False, True])
+def test_view_dependent_phase_flag(vdp, oracle, gpu):
+    scene = Hh.small_scene(P=300)
+    scene["use_view_dependent_phase"] = vdp
+    f, b = Hh.run_oracle(oracle, scene)
+    out, grads, _ = Hh.run_gpu(scene, gpu, optimize_offsets=True)
+    check_outputs(f, out)
+    check_grads(b, grads, scene)
+
+
+def test_expanded_background_and_float_offsets(oracle, gpu):
+    """train.py:127 builds bg as a 7-vector .view(7,1,1).expand(7,H,W): consumed via strides."""
+    scene = Hh.small_scene(P=300)
+    W, H = scene["cfg"]["W"], scene["cfg"]["H"]
+    vec = np.array([0.2, -0.4, 0.6, 0.1, -0.3, 0.5, -0.7], np.float32)
+    scene["bg"] = np.ascontiguousarray(np.broadcast_to(vec[:, None, None], (7, H, W)))
+    f, b = Hh.run_oracle(oracle, scene)
+    bg_t = torch.tensor(vec, device=gpu).view(7, 1, 1).expand(7, H, W)
+    assert not bg_t.is_contiguous()
+    out, grads, _ = Hh.run_gpu(scene, gpu, bg=bg_t)
+    check_outputs(f, out)
+    check_grads(b, grads, scene)
+
+
+def test_edge_cases(oracle, gpu):
+    from gftorf_amd import GaussianRasterizer
+    scene = Hh.small_scene(P=64)
+    # all culled (behind the far plane): background only, zero gradients
+    far = dict(scene)
+    far["gaussians"] = dict(scene["gaussians"])
+    far["gaussians"]["means3D"] = scene["gaussians"]["means3D"] + np.array([0, 0, 100], np.float32)
+    f, b = Hh.run_oracle(oracle, far)
+    out, grads, _ = Hh.run_gpu(far, gpu)
+    assert f.num_rendered == 0 and not out["radii"].any()
+    np.testing.assert_allclose(out["color"], scene["bg"][:3], rtol=0, atol=0)
+    np.testing.assert_allclose(out["phasor"], scene["bg"][:7], rtol=0, atol=0)
+    for k in ["means3D", "shs", "shs_p", "scales", "rotations", "opacities", "means2D"]:
+        assert not grads[k].any(), k
+    # P == 0: the reference returns zero images (rasterize_points.cu:104)
+    empty = dict(scene)
+    empty["gaussians"] = {k: (v[:0] if v is not None else None) for k, v in scene["gaussians"].items()}
+    out, grads, _ = Hh.run_gpu(empty, gpu)
+    assert out["color"].shape == (3, scene["cfg"]["H"], scene["cfg"]["W"]) and not out["color"].any()
+    assert out["radii"].shape == (0,) and grads["means3D"].shape == (0, 3)
+    # single Gaussian
+    one = dict(scene)
+    one["gaussians"] = {k: (v[:1] if v is not None else None) for k, v in scene["gaussians"].items()}
+    f, b = Hh.run_oracle(oracle, one)
+    out, grads, _ = Hh.run_gpu(one, gpu)
+    check_outputs(f, out)
+    check_grads(b, grads, one)
+    # argument validation mirrors the reference messages
+    st = Hh.gpu_settings(scene, gpu)
+    r = GaussianRasterizer(st)
+    m = torch.zeros(4, 3, device=gpu)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(means3D=m, means2D=m, opacities=m[:, :1], scales=m, rotations=torch.zeros(4, 4, device=gpu))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+        r(means3D=m, means2D=m, opacities=m[:, :1], shs=torch.zeros(4, 16, 3, device=gpu))
+    vis = r.markVisible(torch.tensor(scene["gaussians"]["means3D"], device=gpu))
+    ref = oracle.mark_visible(scene["gaussians"]["means3D"], scene["cam"]["viewmatrix"],
+                              scene["cam"]["projmatrix"], scene["cam"]["znear"], scene["cam"]["zfar"])
+    np.testing.assert_array_equal(vis.cpu().numpy(), ref)
+
+
+def test_two_calls_accumulate_on_shared_means2d(oracle, gpu):
+    """gaussian_renderer/__init__.py:107-128 calls the rasterizer twice on the same
+    screenspace_points: gradients accumulate; eval runs under no_grad."""
+    from gftorf_amd import GaussianRasterizer
+    scene = Hh.small_scene(P=200)
+    st = Hh.gpu_settings(scene, gpu)
+    g = {k: torch.tensor(v, device=gpu, requires_grad=True) for k, v in scene["gaussians"].items()}
+    m2d = torch.zeros(200, 3, device=gpu, requires_grad=True)
+    r = GaussianRasterizer(st)
+    kw = dict(means3D=g["means3D"], means2D=m2d, opacities=g["opacities"], shs=g["shs"], shs_p=g["shs_p"],
+              scales=g["scales"], rotations=g["rotations"], phase_offset=0.1, dc_offset=0.05)
+    o1 = r(**kw)
+    o2 = r(**kw)
+    (o1[0].sum() + o2[1].sum()).backward()
+    a = m2d.grad.clone()
+    m2d.grad = None
+    for v in g.values():
+        v.grad = None
+    o1 = r(**kw)
+    o1[0].sum().backward()
+    b1 = m2d.grad.clone()
+    m2d.grad = None
+    o2 = r(**kw)
+    o2[1].sum().backward()
+    torch.testing.assert_close(a, b1 + m2d.grad, rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        o3 = r(**kw)
+    torch.testing.assert_close(o3[0], o1[0].detach(), rtol=0, atol=0)
