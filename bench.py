@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X ToF Gaussian rasterizer.
+
+Metric (BASELINE.json): train iters/sec of the rasterizer forward+backward, plus
+Mpix/s, at 1 M Gaussians @ 640x480, ToF view (SH colour + SH phasor, degree 3).
+One "step" = one forward + one backward of the hot path through the public
+operator API (GaussianRasterizer -> autograd -> C ABI -> gfx950 kernels) on one
+synthetic frame whose inputs are already resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload metric|C2|C5|tiny]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run ... bench.py
+--gpus N ...`: one rank per GPU, each rank renders its own frame (frames are
+independent units: weak scaling, no data-path collective).  Rank 0 prints ONE JSON
+line.  Also in the line: `roofline` for the dominant kernel (HIP events on the
+launch stream, algorithmic bytes of SURVEY.md 8(d)) and `cpu_baseline` (the CPU
+oracle timed on this box's host cores; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+
+WORKLOADS = {
+    "metric": dict(P=1_000_000, W=640, H=480, D=3, sh_coeffs=16, tof=True,
+                   label="1M Gaussians, 640x480, SH deg 3, RGB+ToF phasor, forward+backward"),
+    "C2": dict(P=500_000, W=640, H=480, D=3, sh_coeffs=16, tof=True,
+               label="500k Gaussians, 640x480, SH deg 3, RGB+ToF phasor, forward+backward"),
+    "C5": dict(P=5_000_000, W=1920, H=1080, D=3, sh_coeffs=16, tof=True,
+               label="5M Gaussians, 1920x1080, SH deg 3, RGB+ToF phasor, forward+backward"),
+    "tiny": dict(P=20_000, W=256, H=256, D=3, sh_coeffs=16, tof=True,
+                 label="20k Gaussians, 256x256 (plumbing check only)"),
+}
+
+
+# ---------------------------------------------------------------------------
+# distributed plumbing (device agnostic; exercised on CPU/gloo by tests/test_dist_gloo.py)
+# ---------------------------------------------------------------------------
+def dist_env():
+    return dict(rank=int(os.environ.get("RANK", "0")), local_rank=int(os.environ.get("LOCAL_RANK", "0")),
+                world=int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def frame_of_rank(rank, step=0, world=1):
+    """Frames (views / time steps) are the independent units of this path: rank r owns
+    frame step*world + r.  The bench re-renders the rank's frame every step."""
+    return step * world + rank
+
+
+def timed_steps(step_fn, steps, warmup, sync_fn, dist=None):
+    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device
+    synchronisation on both sides.  Returns the elapsed seconds, MAX over ranks."""
+    import torch
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    if dist is not None:
+        dist.barrier()
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    if dist is not None:
+        dist.barrier()
+    sync_fn()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+# ---------------------------------------------------------------------------
+# algorithmic bytes; P_vis = radii > 0, R = tile instances, N = pixels
+# ---------------------------------------------------------------------------
+def algorithmic_bytes(P, P_vis, R, N, T):
+    P_cull = P - P_vis
+    per_kernel = {
+        "preprocess_fwd": 484 * P_vis + 48 * P_cull,
+        "scan": 8 * P,
+        "duplicate": 20 * P_vis + 12 * R,
+        "sort": 24 * R,
+        "ranges": 8 * R + 8 * T,
+        "render_fwd": 76 * R + 128 * N,
+        "render_bwd": 148 * R + 96 * N,
+        "preprocess_bwd": 928 * P_vis + 384 * P_cull,
+        "memset": 76 * P,
+    }
+    whole = 1516 * P_vis + 432 * P_cull + 268 * R + 224 * N
+    return per_kernel, whole
+
+
+def build_scene(workload, rank, world):
+    from gftorf_amd import synth
+    cfg = dict(WORKLOADS[workload])
+    frame = frame_of_rank(rank, 0, world)
+    # one frame per rank: same Gaussian population, its own view (small arc) -- the
+    # per-frame deform offsets of the reference's dynamic scenes are out of scope here
+    w2c = synth.look_at_w2c(yaw=0.02 * frame, pitch=-0.01 * frame, t=(0.01 * frame, 0.0, 0.0))
+    scene = synth.make_scene(cfg, seed=1234, w2c=w2c)
+    scene["label"] = cfg["label"]
+    return scene
+
+
+def gpu_step_fn(scene, dev):
+    import numpy as np
+    import torch
+    from gftorf_amd import GaussianRasterizationSettings, GaussianRasterizer
+    cam, cfg, g = scene["cam"], scene["cfg"], scene["gaussians"]
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
+    settings = GaussianRasterizationSettings(
+        image_height=cfg["H"], image_width=cfg["W"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+        bg=t(scene["bg"]), scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]),
+        projmatrix=t(cam["projmatrix"]), sh_degree=cfg["D"], campos=t(cam["campos"]), prefiltered=False,
+        debug=False, near_n=cam["znear"], far_n=cam["zfar"], depth_range=scene["depth_range"],
+        use_view_dependent_phase=scene["use_view_dependent_phase"])
+    rast = GaussianRasterizer(settings)
+    leaf = {k: t(v).requires_grad_(True) for k, v in g.items() if v is not None}
+    means2D = torch.zeros((cfg["P"], 3), device=dev, requires_grad=True)
+    gr = {k: t(v) for k, v in scene["grads"].items()}
+    state = {}
+
+    def step():
+        for v in leaf.values():
+            v.grad = None
+        means2D.grad = None
+        outs = rast(means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"], shs=leaf["shs"],
+                    shs_p=leaf.get("shs_p"), scales=leaf["scales"], rotations=leaf["rotations"],
+                    phase_offset=scene["phase_offset"], dc_offset=scene["dc_offset"])
+        color, phasor, depth, _, acc, _, dd = outs[:7]
+        # fixed random upstream gradients: every differentiable output is exercised
+        torch.autograd.backward([color, phasor, depth, acc, dd],
+                                [gr["color"], gr["phasor"], gr["depth"], gr["acc"], gr["depth_distortion"]])
+        state["radii"] = outs[10]
+        state["pixels"] = outs[8]
+
+    return step, state, leaf
+
+
+def cpu_baseline(scene, budget_s=20.0, max_iters=5):
+    """The CPU oracle (a port of the reference algorithm; the reference itself has no CPU
+    rasterizer) timed on this host: full forward+backward of the same frame."""
+    from oracle import oracle
+    import helpers as Hh
+    oracle.build()
+    oracle.lib()
+    t_all = []
+    t_start = time.perf_counter()
+    Hh.run_oracle(oracle, scene)  # warm-up (page faults, thread pool)
+    warm = time.perf_counter() - t_start
+    while len(t_all) < max_iters and (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        Hh.run_oracle(oracle, scene)
+        t_all.append(time.perf_counter() - t0)
+    if not t_all:
+        t_all = [warm]
+    t_all.sort()
+    med = t_all[len(t_all) // 2]
+    return dict(value=1.0 / med, unit="it/s", cores=oracle.num_threads(), kind="port",
+                sample="%d full forward+backward iterations of the same frame (median %.3f s)" % (len(t_all), med))
+
+
+def load_traffic(kernel, workload):
+    """HBM bytes per launch from a committed rocprofv3 --pmc pass, if one exists."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d.get(workload, {}).get(kernel)
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="metric", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    env = dist_env()
+    world = max(env["world"], 1)
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the rasterizer has no CPU path)")
+    from gftorf_amd import _lib
+    _lib.load()
+    torch.cuda.set_device(env["local_rank"])
+    dev = torch.device("cuda", env["local_rank"])
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=dev)
+        dist = dist_mod
+
+    scene = build_scene(args.workload, env["rank"], world)
+    step, state, _ = gpu_step_fn(scene, dev)
+    sync = torch.cuda.synchronize
+
+    elapsed = timed_steps(step, args.steps, args.warmup, sync, dist)
+
+    # ---- roofline leg: the same K steps again with per-stage HIP events on the launch stream
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    for _ in range(args.steps):
+        step()
+    sync()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+
+    cfg = scene["cfg"]
+    P, W, H = cfg["P"], cfg["W"], cfg["H"]
+    N = W * H
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    radii = state["radii"]
+    P_vis = int((radii > 0).sum().item())
+    from gftorf_amd import api
+    R = int(api.last_call_stats["num_rendered"])
+
+    if env["rank"] == 0:
+        per_kernel, whole = algorithmic_bytes(P, P_vis, R, N, T)
+        calls = max(prof["forward_calls"], 1)
+        stage_ms = {k[:-3]: prof[k] / calls for k in prof if k.endswith("_ms")}
+        dom = max(stage_ms, key=lambda k: stage_ms[k])
+        dom_ms = stage_ms[dom]
+        achieved = per_kernel[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        out = {
+            "metric": "train iters/sec (fwd+bwd raster) + Mpix/s, 1M Gaussians @ 640x480 ToF",
+            "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": scene["label"], "P": P, "W": W, "H": H, "sh_degree": cfg["D"],
+                       "P_visible": P_vis, "num_rendered": R, "frames_per_step": world,
+                       "parallelism": "frame-sharded x%d (no data-path collective)" % world},
+            "mpix_per_s": value * N / 1e6,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom, args.workload),
+                         "algorithmic_bytes_per_launch": per_kernel[dom], "avg_launch_ms": dom_ms},
+            "path_roofline": {"algorithmic_bytes_per_step": whole,
+                              "achieved_GBs": whole / (ms_per_step * 1e-3) / 1e9,
+                              "frac": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "gpu_ms_sum_of_stages": sum(stage_ms.values())},
+            "stage_ms": stage_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, budget_s=args.cpu_budget)
+            out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

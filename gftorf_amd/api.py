@@ -44,6 +44,10 @@ class GaussianRasterizationSettings(NamedTuple):
     optimize_dc_offset: Optional[bool] = False
 
 
+# (Gaussian, tile) instance count of the most recent forward (diagnostics / bench)
+last_call_stats = {"num_rendered": 0}
+
+
 def cpu_deep_copy_tuple(input_tuple):
     return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
 
@@ -206,6 +210,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         ctx.raster_settings = s
         ctx.num_rendered = R
+        last_call_stats["num_rendered"] = R
         ctx.scalars = (ph_off, dc_off)
         ctx.bg = (bg_c, bsc, bsy, bsx)
         ctx.consts = (view_c, proj_c, campos_c)
