@@ -89,14 +89,14 @@ def algorithmic_bytes(P, P_vis, R, N, T):
     P_cull = P - P_vis
     per_kernel = {
         "preprocess_fwd": 484 * P_vis + 48 * P_cull,
-        "scan": 8 * P,
+        "scan": 8 * P_vis,
         "duplicate": 20 * P_vis + 12 * R,
         "sort": 24 * R,
-        "ranges": 8 * R + 8 * T,
+        "ranges": 8 * R,
         "render_fwd": 76 * R + 128 * N,
         "render_bwd": 148 * R + 96 * N,
         "preprocess_bwd": 928 * P_vis + 384 * P_cull,
-        "memset": 76 * P,
+        "memset": 76 * P_vis,
     }
     whole = 1516 * P_vis + 432 * P_cull + 268 * R + 224 * N
     return per_kernel, whole
