@@ -3,8 +3,12 @@
 // One 256-thread workgroup (4 waves) per 16x16 tile; each wave owns an 8x8 pixel
 // quadrant so that a splat's footprint is wave-coherent.  The tile's depth-sorted
 // splat list is staged through LDS in batches of 256 packed records (80 B per
-// splat: rec_a 32 B + rec_b 48 B, gathered with 16-byte loads); the inner loop
-// reads them back as LDS broadcasts.
+// splat: rec_a 32 B + rec_b 48 B, gathered with 16-byte loads).  While staging,
+// every splat's alpha >= 1/255 ellipse is bounded by a box and tested against the
+// four quadrants; the four ballots per staging wave give each wave a 256-bit mask
+// of the splats that can reach it, walked with scalar bit scans, so a wave only
+// touches splats that may contribute to its quadrant and reads their records as
+// LDS broadcasts.
 //
 // forward  (reference K6, RAST/cuda_rasterizer/forward.cu:424-676): front-to-back
 //   blend of colour(3, w = a*T), ToF phasor(7, w = a*T^2), distance, accumulation,
@@ -13,14 +17,18 @@
 //   per (pixel, splat).
 // backward (reference K7, backward.cu:609-889): back-to-front, starting at the
 //   tile's deepest contributor (stored by the forward) instead of the list end.
-//   The 18 per-(pixel, splat) float atomics of the reference become: DPP wave
-//   reduction -> ds_add_f32 into a per-batch LDS table -> one coalesced global
+//   The 18 per-(pixel, splat) float atomics of the reference become: a
+//   v_permlane32_swap / v_permlane16_swap / DPP reduction tree (18 values -> 5
+//   registers), 5 ds_add_f32 into a per-batch LDS table, and one coalesced global
 //   atomic burst per (tile, splat).
 #include "gft_internal.h"
 
 namespace {
 
 #define GFT_BATCH 256
+#define ACC_LDS_STRIDE 20
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int tile_of_block(int b, int T)
 {
@@ -28,6 +36,63 @@ __device__ __forceinline__ int tile_of_block(int b, int T)
     // run of tiles so neighbouring tiles (which share splats) share an L2
     const int chunk = (T + 7) >> 3;
     return (b & 7) * chunk + (b >> 3);
+}
+
+// exp(x) for x <= 0 through the hardware exp2: |rel err| < 1e-6 on the range that
+// can pass the 1/255 alpha threshold; forward and backward use the same function.
+__device__ __forceinline__ float gft_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+__device__ __forceinline__ uint64_t uniform_mask(const uint64_t* p)
+{
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(v.x), hi = __builtin_amdgcn_readfirstlane(v.y);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Stage splat `id` into LDS slot `slot` and return its quadrant-reach bits.
+__device__ __forceinline__ uint32_t stage_splat(uint32_t id, int slot, const float4* __restrict__ rec_a,
+                                                const float4* __restrict__ rec_b, float4* sA, float4* sB,
+                                                float tile_x0, float tile_y0)
+{
+    const float4 a0 = rec_a[2 * id], a1 = rec_a[2 * id + 1];
+    sA[2 * slot] = a0;
+    sA[2 * slot + 1] = a1;
+    sB[3 * slot] = rec_b[3 * id];
+    sB[3 * slot + 1] = rec_b[3 * id + 1];
+    sB[3 * slot + 2] = rec_b[3 * id + 2];
+    // alpha = min(0.99, o*exp(power)) >= 1/255  <=>  power >= -tau, tau = ln(255 o):
+    // the pixels that can blend this splat lie in the ellipse q(d) <= 2 tau, whose bounding
+    // box has half extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy) with cov = conic^-1.
+    const float ca = a0.z, cb = a0.w, cc = a1.x, op = a1.y;
+    const float det = ca * cc - cb * cb;
+    const float tau = __logf(255.0f * op);
+    uint32_t bits = 0xfu;
+    if (!(tau > 0.0f)) {
+        bits = 0;                       // opacity <= 1/255: can never pass the alpha test
+    } else if (det > 0.0f && ca > 0.0f && cc > 0.0f) {
+        const float inv = 2.0f * tau / det;
+        const float ex = sqrtf(inv * cc) * 1.0005f + 0.02f;   // margins keep the box conservative
+        const float ey = sqrtf(inv * ca) * 1.0005f + 0.02f;
+        const float lx = a0.x - ex - tile_x0, hx = a0.x + ex - tile_x0;
+        const float ly = a0.y - ey - tile_y0, hy = a0.y + ey - tile_y0;
+        const bool x_lo = hx >= 0.0f && lx <= 7.0f, x_hi = hx >= 8.0f && lx <= 15.0f;
+        const bool y_lo = hy >= 0.0f && ly <= 7.0f, y_hi = hy >= 8.0f && ly <= 15.0f;
+        bits = (x_lo && y_lo ? 1u : 0u) | (x_hi && y_lo ? 2u : 0u) | (x_lo && y_hi ? 4u : 0u) | (x_hi && y_hi ? 8u : 0u);
+    }
+    return bits;
+}
+
+// masks[q*4 + w] = ballot over staging wave w of "splat reaches quadrant q"
+__device__ __forceinline__ void publish_masks(uint32_t bits, int wave, int lane, uint64_t* sMask)
+{
+    const unsigned long long m0 = __ballot(bits & 1u), m1 = __ballot(bits & 2u);
+    const unsigned long long m2 = __ballot(bits & 4u), m3 = __ballot(bits & 8u);
+    if (lane == 0) {
+        sMask[0 * 4 + wave] = m0;
+        sMask[1 * 4 + wave] = m1;
+        sMask[2 * 4 + wave] = m2;
+        sMask[3 * 4 + wave] = m3;
+    }
 }
 
 struct RenderFwdArgs {
@@ -51,6 +116,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_render_fwd(RenderFwdArgs a)
     __shared__ float4 sB[GFT_BATCH * 3];
     __shared__ uint32_t sId[GFT_BATCH];
     __shared__ uint32_t sCnt[GFT_BATCH];
+    __shared__ uint64_t sMask[16];
     __shared__ uint32_t sMax;
 
     const int tile = tile_of_block(blockIdx.x, a.T);
@@ -61,6 +127,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_render_fwd(RenderFwdArgs a)
     const int py = ty * GFT_TILE_Y + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
+    const float tile_x0 = (float)(tx * GFT_TILE_X), tile_y0 = (float)(ty * GFT_TILE_Y);
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
     const int rounds = (total + GFT_BATCH - 1) / GFT_BATCH;
@@ -80,52 +147,64 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_render_fwd(RenderFwdArgs a)
         // all pixels of the tile finished -> the rest of the list is never used
         if (__syncthreads_and(done)) break;
         const int n = min(GFT_BATCH, todo);
+        uint32_t bits = 0;
         if (tid < n) {
             const uint32_t id = a.point_list[range.x + i * GFT_BATCH + tid];
             sId[tid] = id;
             sCnt[tid] = 0;
-            sA[2 * tid] = a.rec_a[2 * id];
-            sA[2 * tid + 1] = a.rec_a[2 * id + 1];
-            sB[3 * tid] = a.rec_b[3 * id];
-            sB[3 * tid + 1] = a.rec_b[3 * id + 1];
-            sB[3 * tid + 2] = a.rec_b[3 * id + 2];
+            bits = stage_splat(id, tid, a.rec_a, a.rec_b, sA, sB, tile_x0, tile_y0);
         }
+        publish_masks(bits, wave, lane, sMask);
         __syncthreads();
 
-        for (int j = 0; !done && j < n; j++) {
-            const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
-            const float dx = a0.x - pxf, dy = a0.y - pyf;
-            const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-            if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, a1.y * expf(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T * (1 - alpha);
-            if (test_T < 0.0001f) {
-                done = true;
-                continue;
+        bool wave_live = __ballot(!done) != 0ull;
+        for (int s = 0; s < 4 && wave_live; s++) {
+            uint64_t m = uniform_mask(&sMask[wave * 4 + s]);
+            while (m) {
+                const int j = s * 64 + (int)__builtin_ctzll(m);
+                m &= m - 1;
+                bool contrib = false;
+                if (!done) {
+                    const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
+                    const float dx = a0.x - pxf, dy = a0.y - pyf;
+                    const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+                    const float alpha = fminf(0.99f, a1.y * gft_exp(power));
+                    if (!(power > 0.0f) && !(alpha < 1.0f / 255.0f)) {
+                        const float test_T = T * (1 - alpha);
+                        if (test_T < 0.0001f) {
+                            done = true;
+                        } else {
+                            contrib = true;
+                            const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
+                            const float w = alpha * T;
+                            const float w_p = alpha * T * T;
+                            C0 += b0.x * w; C1 += b0.y * w; C2 += b0.z * w;
+                            P0 += b0.w * w_p; P1 += b1.x * w_p; P2 += b1.y * w_p; P3 += b1.z * w_p;
+                            P4 += b1.w * w_p; P5 += b2.x * w_p; P6 += b2.y * w_p;
+                            const float dist = a1.w;
+                            Dd += dist * w;
+                            if (first) {
+                                WD0 = alpha; WD1 = dist; WD2 = b1.y;
+                                first = false;
+                            }
+                            const float z = a1.z;
+                            DD += w * (z * z * A - 2.0f * z * DD_D + DD_D2);
+                            DD_D += w * z;
+                            DD_D2 += w * z * z;
+                            A += alpha * T;
+                            T = test_T;
+                            last_contributor = (uint32_t)(i * GFT_BATCH + j + 1);
+                        }
+                    }
+                }
+                // pixels[id] += 1 for every contributing pixel: wave popcount -> LDS
+                const unsigned long long cm = __ballot(contrib);
+                if (cm != 0ull && lane == 0) atomicAdd(&sCnt[j], (uint32_t)__popcll(cm));
+                if (__ballot(!done) == 0ull) {
+                    wave_live = false;
+                    break;
+                }
             }
-            const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
-            const float w = alpha * T;
-            const float w_p = alpha * T * T;
-            C0 += b0.x * w; C1 += b0.y * w; C2 += b0.z * w;
-            P0 += b0.w * w_p; P1 += b1.x * w_p; P2 += b1.y * w_p; P3 += b1.z * w_p;
-            P4 += b1.w * w_p; P5 += b2.x * w_p; P6 += b2.y * w_p;
-            const float dist = a1.w;
-            Dd += dist * w;
-            if (first) {
-                WD0 = alpha; WD1 = dist; WD2 = b1.y;
-                first = false;
-            }
-            const float z = a1.z;
-            DD += w * (z * z * A - 2.0f * z * DD_D + DD_D2);
-            DD_D += w * z;
-            DD_D2 += w * z * z;
-            A += alpha * T;
-            T = test_T;
-            last_contributor = (uint32_t)(i * GFT_BATCH + j + 1);
-            // pixels[id] += 1 for every contributing pixel: wave popcount -> LDS
-            const unsigned long long m = __ballot(1);
-            if (lane == (int)__ffsll((long long)m) - 1) atomicAdd(&sCnt[j], (uint32_t)__popcll(m));
         }
         __syncthreads();
         if (tid < n) {
@@ -185,7 +264,51 @@ struct RenderBwdArgs {
     float* acc;   // [P][GFT_ACC_STRIDE]
 };
 
-#define ACC_LDS_STRIDE 20
+__device__ __forceinline__ float swap32_add(float x, float y)
+{
+    // lanes 0-31: x[l] + x[l+32]; lanes 32-63: y[l-32] + y[l]
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+__device__ __forceinline__ float swap16_add(float x, float y)
+{
+    // row0: x.r0 + x.r1; row1: y.r0 + y.r1; row2: x.r2 + x.r3; row3: y.r2 + y.r3
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+__device__ __forceinline__ float row_sum_to_lane15(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), GFT_DPP_ROW_SHR(1), 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), GFT_DPP_ROW_SHR(2), 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), GFT_DPP_ROW_SHR(4), 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), GFT_DPP_ROW_SHR(8), 0xf, 0xf, false));
+    return v;
+}
+
+// Sum 18 per-lane values over the 64 lanes of the wave and add the 18 totals to
+// row[0..17] in LDS.  Halving tree: 18 -> 9 registers (lane halves), 9 -> 5 (16-lane
+// rows), then a 4-step DPP scan inside each row; lanes 15/31/47/63 own the totals.
+__device__ __forceinline__ void wave_reduce18_add(const float* v, float* row, int lane)
+{
+    float s[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) s[i] = swap32_add(v[i], v[i + 9]);      // lo half: value i, hi half: value i+9
+    float t[5];
+#pragma unroll
+    for (int i = 0; i < 4; i++) t[i] = swap16_add(s[i], s[i + 4]);      // rows: i, i+4, i+9, i+13
+    t[4] = swap16_add(s[8], s[8]);                                      // rows 0,1: value 8; rows 2,3: value 17
+#pragma unroll
+    for (int i = 0; i < 5; i++) t[i] = row_sum_to_lane15(t[i]);
+    if ((lane & 15) == 15) {
+        const int r = lane >> 4;
+        const int off = (r & 1) * 4 + (r >> 1) * 9;
+#pragma unroll
+        for (int i = 0; i < 4; i++) atomicAdd(&row[i + off], t[i]);
+        if (!(r & 1)) atomicAdd(&row[8 + (r >> 1) * 9], t[4]);
+    }
+}
 
 __global__ __launch_bounds__(GFT_BLOCK) void k_render_bwd(RenderBwdArgs a)
 {
@@ -194,6 +317,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_render_bwd(RenderBwdArgs a)
     __shared__ uint32_t sId[GFT_BATCH];
     __shared__ float sAcc[GFT_BATCH * ACC_LDS_STRIDE];
     __shared__ uint32_t sTouched[GFT_BATCH];
+    __shared__ uint64_t sMask[16];
 
     const int tile = tile_of_block(blockIdx.x, a.T);
     if (tile >= a.T) return;
@@ -205,6 +329,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_render_bwd(RenderBwdArgs a)
     const int py = ty * GFT_TILE_Y + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
+    const float tile_x0 = (float)(tx * GFT_TILE_X), tile_y0 = (float)(ty * GFT_TILE_Y);
     const uint32_t r0 = a.ranges[tile].x;
     const size_t HW = (size_t)a.H * a.W;
     const size_t pix = inside ? (size_t)a.W * py + px : 0;
@@ -235,6 +360,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_render_bwd(RenderBwdArgs a)
         bg_dot_p += b4 * gp4; bg_dot_p += b5 * gp5; bg_dot_p += b6 * gp6;
     }
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+    const float one_m_Tf = 1 - T_final;
 
     float T = T_final;
     float ar0 = 0, ar1 = 0, ar2 = 0;                                    // accum_rec colour
@@ -249,16 +375,14 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_render_bwd(RenderBwdArgs a)
         const int hi = tmax - i * GFT_BATCH;       // list indices [hi-n, hi) in descending order
         const int n = min(GFT_BATCH, hi);
         __syncthreads();                           // previous batch's flush has read LDS
+        uint32_t bits = 0;
         if (tid < n) {
             const uint32_t id = a.point_list[r0 + (uint32_t)(hi - 1 - tid)];
             sId[tid] = id;
             sTouched[tid] = 0;
-            sA[2 * tid] = a.rec_a[2 * id];
-            sA[2 * tid + 1] = a.rec_a[2 * id + 1];
-            sB[3 * tid] = a.rec_b[3 * id];
-            sB[3 * tid + 1] = a.rec_b[3 * id + 1];
-            sB[3 * tid + 2] = a.rec_b[3 * id + 2];
+            bits = stage_splat(id, tid, a.rec_a, a.rec_b, sA, sB, tile_x0, tile_y0);
         }
+        publish_masks(bits, wave, lane, sMask);
         {
             float4* z = reinterpret_cast<float4*>(sAcc) + tid * (ACC_LDS_STRIDE / 4);
 #pragma unroll
@@ -266,98 +390,99 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_render_bwd(RenderBwdArgs a)
         }
         __syncthreads();
 
-        for (int j = 0; j < n; j++) {
-            const int c = hi - 1 - j;               // list position of this splat
-            const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
-            const float dx = a0.x - pxf, dy = a0.y - pyf;
-            const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-            const float G = expf(power);
-            const float alpha = fminf(0.99f, a1.y * G);
-            const bool contrib = (c < n_contrib) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (__ballot(contrib) == 0ull) continue;   // wave-uniform skip
+        for (int s = 0; s < 4; s++) {
+            uint64_t m = uniform_mask(&sMask[wave * 4 + s]);
+            while (m) {
+                const int j = s * 64 + (int)__builtin_ctzll(m);
+                m &= m - 1;
+                const int c = hi - 1 - j;               // list position of this splat
+                const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
+                const float dx = a0.x - pxf, dy = a0.y - pyf;
+                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+                const float G = gft_exp(power);
+                const float alpha = fminf(0.99f, a1.y * G);
+                const bool contrib = (c < n_contrib) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__ballot(contrib) == 0ull) continue;   // wave-uniform skip
 
-            float v[GFT_NUM_ACC];
+                float v[GFT_NUM_ACC];
 #pragma unroll
-            for (int k = 0; k < GFT_NUM_ACC; k++) v[k] = 0.f;
-            if (contrib) {
-                const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
-                T = T / (1.f - alpha);
-                const float wc = alpha * T;          // dchannel_dcolor == dchannel_ddepth
-                const float wp = alpha * T * T;      // dchannel_dphasor
-                const float one_m_la = 1.f - last_alpha;
-                float dL_dalpha = 0.f;
+                for (int k = 0; k < GFT_NUM_ACC; k++) v[k] = 0.f;
+                if (contrib) {
+                    const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
+                    const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                    T = T * rcp_1ma;
+                    const float wc = alpha * T;          // dchannel_dcolor == dchannel_ddepth
+                    const float wp = wc * T;             // dchannel_dphasor = alpha*T*T
+                    const float one_m_la = 1.f - last_alpha;
+                    float dL_dalpha = 0.f;
 
-                // colour
-                float dac = 0.f;
-                ar0 = last_alpha * lc0 + one_m_la * ar0; lc0 = b0.x; dac += (b0.x - ar0) * gc0; v[6] = wc * gc0;
-                ar1 = last_alpha * lc1 + one_m_la * ar1; lc1 = b0.y; dac += (b0.y - ar1) * gc1; v[7] = wc * gc1;
-                ar2 = last_alpha * lc2 + one_m_la * ar2; lc2 = b0.z; dac += (b0.z - ar2) * gc2; v[8] = wc * gc2;
-                dac *= T;
+                    // colour
+                    float dac = 0.f;
+                    ar0 = last_alpha * lc0 + one_m_la * ar0; lc0 = b0.x; dac += (b0.x - ar0) * gc0; v[6] = wc * gc0;
+                    ar1 = last_alpha * lc1 + one_m_la * ar1; lc1 = b0.y; dac += (b0.y - ar1) * gc1; v[7] = wc * gc1;
+                    ar2 = last_alpha * lc2 + one_m_la * ar2; lc2 = b0.z; dac += (b0.z - ar2) * gc2; v[8] = wc * gc2;
+                    dac *= T;
 
-                // ToF phasor (weight alpha*T^2)
-                float dap = 0.f;
-                const float one_m_la2 = one_m_la * one_m_la;
-                const float two_1ma = 2.f * (1.f - alpha);
-                ap0 = last_alpha * lp0 + one_m_la2 * ap0; lp0 = b0.w; dap += (b0.w - two_1ma * ap0) * gp0; v[9] = wp * gp0;
-                ap1 = last_alpha * lp1 + one_m_la2 * ap1; lp1 = b1.x; dap += (b1.x - two_1ma * ap1) * gp1; v[10] = wp * gp1;
-                ap2 = last_alpha * lp2 + one_m_la2 * ap2; lp2 = b1.y; dap += (b1.y - two_1ma * ap2) * gp2; v[11] = wp * gp2;
-                ap3 = last_alpha * lp3 + one_m_la2 * ap3; lp3 = b1.z; dap += (b1.z - two_1ma * ap3) * gp3; v[12] = wp * gp3;
-                ap4 = last_alpha * lp4 + one_m_la2 * ap4; lp4 = b1.w; dap += (b1.w - two_1ma * ap4) * gp4; v[13] = wp * gp4;
-                ap5 = last_alpha * lp5 + one_m_la2 * ap5; lp5 = b2.x; dap += (b2.x - two_1ma * ap5) * gp5; v[14] = wp * gp5;
-                ap6 = last_alpha * lp6 + one_m_la2 * ap6; lp6 = b2.y; dap += (b2.y - two_1ma * ap6) * gp6; v[15] = wp * gp6;
-                dap *= T * T;
+                    // ToF phasor (weight alpha*T^2)
+                    float dap = 0.f;
+                    const float one_m_la2 = one_m_la * one_m_la;
+                    const float two_1ma = 2.f * (1.f - alpha);
+                    ap0 = last_alpha * lp0 + one_m_la2 * ap0; lp0 = b0.w; dap += (b0.w - two_1ma * ap0) * gp0; v[9] = wp * gp0;
+                    ap1 = last_alpha * lp1 + one_m_la2 * ap1; lp1 = b1.x; dap += (b1.x - two_1ma * ap1) * gp1; v[10] = wp * gp1;
+                    ap2 = last_alpha * lp2 + one_m_la2 * ap2; lp2 = b1.y; dap += (b1.y - two_1ma * ap2) * gp2; v[11] = wp * gp2;
+                    ap3 = last_alpha * lp3 + one_m_la2 * ap3; lp3 = b1.z; dap += (b1.z - two_1ma * ap3) * gp3; v[12] = wp * gp3;
+                    ap4 = last_alpha * lp4 + one_m_la2 * ap4; lp4 = b1.w; dap += (b1.w - two_1ma * ap4) * gp4; v[13] = wp * gp4;
+                    ap5 = last_alpha * lp5 + one_m_la2 * ap5; lp5 = b2.x; dap += (b2.x - two_1ma * ap5) * gp5; v[14] = wp * gp5;
+                    ap6 = last_alpha * lp6 + one_m_la2 * ap6; lp6 = b2.y; dap += (b2.y - two_1ma * ap6) * gp6; v[15] = wp * gp6;
+                    dap *= T * T;
 
-                // distance
-                const float dist = a1.w;
-                ar_d = last_alpha * last_dist + one_m_la * ar_d;
-                last_dist = dist;
-                float dad = (dist - ar_d) * gd;
-                v[16] = wc * gd;
-                dad *= T;
+                    // distance
+                    const float dist = a1.w;
+                    ar_d = last_alpha * last_dist + one_m_la * ar_d;
+                    last_dist = dist;
+                    float dad = (dist - ar_d) * gd;
+                    v[16] = wc * gd;
+                    dad *= T;
 
-                // accumulation
-                ar_a = last_alpha + one_m_la * ar_a;
-                float daa = (1.f - ar_a) * ga;
-                daa *= T;
+                    // accumulation
+                    ar_a = last_alpha + one_m_la * ar_a;
+                    float daa = (1.f - ar_a) * ga;
+                    daa *= T;
 
-                // depth distortion
-                const float z = a1.z;
-                const float dL_dw = gdd * (z * z * (1 - T_final) - 2.0f * z * wz_tot + wz2_tot);
-                ar_dd = last_alpha * last_dL_dw + one_m_la * ar_dd;
-                last_dL_dw = dL_dw;
-                float dadd = dL_dw - ar_dd;
-                v[17] = gdd * 2.0f * alpha * T * (z * (1 - T_final) - wz_tot);
-                dadd *= T;
+                    // depth distortion
+                    const float z = a1.z;
+                    const float dL_dw = gdd * (z * z * one_m_Tf - 2.0f * z * wz_tot + wz2_tot);
+                    ar_dd = last_alpha * last_dL_dw + one_m_la * ar_dd;
+                    last_dL_dw = dL_dw;
+                    float dadd = dL_dw - ar_dd;
+                    v[17] = gdd * 2.0f * wc * (z * one_m_Tf - wz_tot);
+                    dadd *= T;
 
-                last_alpha = alpha;
+                    last_alpha = alpha;
 
-                const float bgf = -T_final / (1.f - alpha);
-                dL_dalpha += bgf * bg_dot;
-                dap += bgf * bg_dot_p;
-                dL_dalpha += dac;
-                dL_dalpha += dap;
-                dL_dalpha += dad;
-                dL_dalpha += daa;
-                dL_dalpha += dadd;
+                    const float bgf = -T_final * rcp_1ma;
+                    dL_dalpha += bgf * bg_dot;
+                    dap += bgf * bg_dot_p;
+                    dL_dalpha += dac;
+                    dL_dalpha += dap;
+                    dL_dalpha += dad;
+                    dL_dalpha += daa;
+                    dL_dalpha += dadd;
 
-                const float dL_dG = a1.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * a0.z - gdy * a0.w;
-                const float dG_ddely = -gdy * a1.x - gdx * a0.w;
-                v[0] = dL_dG * dG_ddelx * ddelx_dx;
-                v[1] = dL_dG * dG_ddely * ddely_dy;
-                v[2] = -0.5f * gdx * dx * dL_dG;
-                v[3] = -0.5f * gdx * dy * dL_dG;
-                v[4] = -0.5f * gdy * dy * dL_dG;
-                v[5] = G * dL_dalpha;
-            }
-            // 64 pixels -> one partial per value; lane 63 owns the LDS update
-#pragma unroll
-            for (int k = 0; k < GFT_NUM_ACC; k++) v[k] = gft_wave_sum_to_lane63(v[k]);
-            if (lane == 63) {
-                sTouched[j] = 1;
-#pragma unroll
-                for (int k = 0; k < GFT_NUM_ACC; k++) atomicAdd(&sAcc[j * ACC_LDS_STRIDE + k], v[k]);
+                    const float dL_dG = a1.y * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * a0.z - gdy * a0.w;
+                    const float dG_ddely = -gdy * a1.x - gdx * a0.w;
+                    v[0] = dL_dG * dG_ddelx * ddelx_dx;
+                    v[1] = dL_dG * dG_ddely * ddely_dy;
+                    v[2] = -0.5f * gdx * dx * dL_dG;
+                    v[3] = -0.5f * gdx * dy * dL_dG;
+                    v[4] = -0.5f * gdy * dy * dL_dG;
+                    v[5] = G * dL_dalpha;
+                }
+                // 64 pixels -> one partial per value, accumulated in the batch's LDS table
+                wave_reduce18_add(v, &sAcc[j * ACC_LDS_STRIDE], lane);
+                if (lane == 0) sTouched[j] = 1;
             }
         }
         __syncthreads();
