@@ -89,10 +89,9 @@ def algorithmic_bytes(P, P_vis, R, N, T):
     P_cull = P - P_vis
     per_kernel = {
         "preprocess_fwd": 484 * P_vis + 48 * P_cull,
-        "scan": 8 * P_vis,
-        "duplicate": 20 * P_vis + 12 * R,
-        "sort": 24 * R,
-        "ranges": 8 * R,
+        "tile_count": 8 * P_vis + 8 * R,        # reference scan (K2) + tile ranges (K5)
+        "tile_scatter": 20 * P_vis + 12 * R,    # reference duplicateWithKeys (K3)
+        "tile_sort": 24 * R,                    # reference key sort (K4), one read + one write of a pair
         "render_fwd": 76 * R + 128 * N,
         "render_bwd": 148 * R + 96 * N,
         "preprocess_bwd": 928 * P_vis + 384 * P_cull,

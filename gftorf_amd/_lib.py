@@ -46,13 +46,13 @@ BACKWARD_FIELDS = [
 ]
 
 LAYOUT_FIELDS = [
-    "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_offsets", "geom_clamped",
-    "geom_scan_tmp", "geom_total",
-    "img_pix_state", "img_ranges", "img_tile_max", "img_total",
-    "bin_keys_unsorted", "bin_keys", "bin_vals_unsorted", "bin_point_list", "bin_sort_tmp", "bin_total",
+    "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_rect", "geom_clamped",
+    "geom_ctrl", "geom_total",
+    "img_pix_state", "img_ranges", "img_tile_max", "img_tile_cnt", "img_tile_cursor", "img_total",
+    "bin_keys", "bin_point_list", "bin_total",
 ]
 
-PROFILE_FIELDS = ["preprocess_fwd_ms", "scan_ms", "duplicate_ms", "sort_ms", "ranges_ms",
+PROFILE_FIELDS = ["preprocess_fwd_ms", "tile_count_ms", "tile_scatter_ms", "tile_sort_ms",
                   "render_fwd_ms", "render_bwd_ms", "preprocess_bwd_ms", "memset_ms"]
 
 

@@ -36,27 +36,25 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->geom_rec_b = o;    o = align_up(o + p * 48);
     L->geom_depth = o;    o = align_up(o + p * 4);
     L->geom_tiles = o;    o = align_up(o + p * 4);
-    L->geom_offsets = o;  o = align_up(o + p * 4);
+    L->geom_rect = o;     o = align_up(o + p * 8);
     L->geom_clamped = o;  o = align_up(o + p);
-    const size_t nblocks = (p + GFT_BLOCK - 1) / GFT_BLOCK;
-    L->geom_scan_tmp = o; o = align_up(o + (GFT_SCAN_BLOCKS + nblocks + 1) * 4);
+    L->geom_ctrl = o;     o = align_up(o + GFT_CTRL_WORDS * 4);
     L->geom_total = o;
 
     const size_t n = (size_t)W * (size_t)H;
     const size_t T = (size_t)((W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((H + GFT_TILE_Y - 1) / GFT_TILE_Y);
     o = 0;
-    L->img_pix_state = o; o = align_up(o + n * 16);
-    L->img_ranges = o;    o = align_up(o + T * 8);
-    L->img_tile_max = o;  o = align_up(o + T * 4);
+    L->img_pix_state = o;   o = align_up(o + n * 16);
+    L->img_ranges = o;      o = align_up(o + T * 8);
+    L->img_tile_max = o;    o = align_up(o + T * 4);
+    L->img_tile_cnt = o;    o = align_up(o + T * 4);
+    L->img_tile_cursor = o; o = align_up(o + T * 4);
     L->img_total = o;
 
     const size_t r = (size_t)(R > 0 ? R : 0);
     o = 0;
-    L->bin_keys_unsorted = o; o = align_up(o + r * 8);
-    L->bin_keys = o;          o = align_up(o + r * 8);
-    L->bin_vals_unsorted = o; o = align_up(o + r * 4);
-    L->bin_point_list = o;    o = align_up(o + r * 4);
-    L->bin_sort_tmp = o;      o = align_up(o + gft_sort_tmp_bytes(R));
+    L->bin_keys = o;        o = align_up(o + r * 8);
+    L->bin_point_list = o;  o = align_up(o + r * 4);
     L->bin_total = o + GFT_ALIGN;
 }
 
@@ -68,9 +66,9 @@ GeomView gft_geom_view(void* base, const gft_layout& L)
     g.rec_b = (float4*)(b + L.geom_rec_b);
     g.depth = (float*)(b + L.geom_depth);
     g.tiles = (uint32_t*)(b + L.geom_tiles);
-    g.offsets = (uint32_t*)(b + L.geom_offsets);
+    g.rect = (ushort4*)(b + L.geom_rect);
     g.clamped = (uint8_t*)(b + L.geom_clamped);
-    g.scan_tmp = (uint32_t*)(b + L.geom_scan_tmp);
+    g.ctrl = (uint32_t*)(b + L.geom_ctrl);
     return g;
 }
 
@@ -81,6 +79,8 @@ ImgView gft_img_view(void* base, const gft_layout& L)
     v.pix_state = (float4*)(b + L.img_pix_state);
     v.ranges = (uint2*)(b + L.img_ranges);
     v.tile_max = (uint32_t*)(b + L.img_tile_max);
+    v.tile_cnt = (uint32_t*)(b + L.img_tile_cnt);
+    v.tile_cursor = (uint32_t*)(b + L.img_tile_cursor);
     return v;
 }
 
@@ -88,12 +88,8 @@ BinView gft_bin_view(void* base, const gft_layout& L)
 {
     char* b = (char*)base;
     BinView v;
-    v.keys_unsorted = (uint64_t*)(b + L.bin_keys_unsorted);
     v.keys = (uint64_t*)(b + L.bin_keys);
-    v.vals_unsorted = (uint32_t*)(b + L.bin_vals_unsorted);
     v.point_list = (uint32_t*)(b + L.bin_point_list);
-    v.sort_tmp = (void*)(b + L.bin_sort_tmp);
-    v.sort_tmp_bytes = L.bin_total - GFT_ALIGN - L.bin_sort_tmp;
     return v;
 }
 
@@ -126,7 +122,7 @@ extern "C" int gft_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_la
 }
 
 // ---- profiler -----------------------------------------------------------------
-enum Stage { ST_PRE_FWD, ST_SCAN, ST_DUP, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_RENDER_BWD, ST_PRE_BWD, ST_MEMSET, ST_COUNT };
+enum Stage { ST_PRE_FWD, ST_TILE_COUNT, ST_TILE_SCATTER, ST_TILE_SORT, ST_RENDER_FWD, ST_RENDER_BWD, ST_PRE_BWD, ST_MEMSET, ST_COUNT };
 
 struct Profiler {
     std::mutex mu;
@@ -193,10 +189,9 @@ extern "C" int gft_profile_read(gft_profile* out)
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.drain();
     out->preprocess_fwd_ms = g_prof.ms[ST_PRE_FWD];
-    out->scan_ms = g_prof.ms[ST_SCAN];
-    out->duplicate_ms = g_prof.ms[ST_DUP];
-    out->sort_ms = g_prof.ms[ST_SORT];
-    out->ranges_ms = g_prof.ms[ST_RANGES];
+    out->tile_count_ms = g_prof.ms[ST_TILE_COUNT];
+    out->tile_scatter_ms = g_prof.ms[ST_TILE_SCATTER];
+    out->tile_sort_ms = g_prof.ms[ST_TILE_SORT];
     out->render_fwd_ms = g_prof.ms[ST_RENDER_FWD];
     out->render_bwd_ms = g_prof.ms[ST_RENDER_BWD];
     out->preprocess_bwd_ms = g_prof.ms[ST_PRE_BWD];
@@ -245,27 +240,29 @@ extern "C" int gft_forward_preprocess(void* hip_stream, const gft_config* cfg, c
         return gft_fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
     if ((io->shs != nullptr) != (cfg->M > 0) || (io->shs_p != nullptr) != (cfg->M_p > 0))
         return gft_fail("M / M_p do not match the presence of shs / shs_p");
+    if (!io->img) return gft_fail("gft_forward_preprocess: img buffer is NULL");
     hipStream_t s = (hipStream_t)hip_stream;
     gft_layout L;
     gft_compute_layout(cfg->P, cfg->W, cfg->H, 0, &L);
     GeomView g = gft_geom_view(io->geom, L);
+    ImgView im = gft_img_view(io->img, L);
 
-    GFT_CHECK_HIP(hipMemsetAsync(g.scan_tmp, 0, 2 * sizeof(uint32_t), s));
+    GFT_CHECK_HIP(hipMemsetAsync(g.ctrl, 0, GFT_CTRL_WORDS * sizeof(uint32_t), s));
     {
         StageTimer t(s, ST_PRE_FWD);
         GFT_STAGE(s, cfg, "preprocess_fwd", gft_launch_preprocess_fwd(s, *cfg, *io, g));
     }
     {
-        StageTimer t(s, ST_SCAN);
-        GFT_STAGE(s, cfg, "scan", gft_launch_scan(s, cfg->P, g));
+        StageTimer t(s, ST_TILE_COUNT);
+        GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im));
     }
     // the one blocking read of the forward (reference rasterizer_impl.cu:311)
-    uint32_t host[2] = {0, 0};
-    GFT_CHECK_HIP(hipMemcpyAsync(host, g.scan_tmp, sizeof(host), hipMemcpyDeviceToHost, s));
+    uint32_t host[GFT_CTRL_WORDS] = {0};
+    GFT_CHECK_HIP(hipMemcpyAsync(host, g.ctrl, sizeof(host), hipMemcpyDeviceToHost, s));
     GFT_CHECK_HIP(hipStreamSynchronize(s));
-    if (host[GFT_SCAN_FLAGS] & 1u)
+    if (host[GFT_CTRL_FLAGS] & 1u)
         return gft_fail("Point is filtered although prefiltered is set. This shouldn't happen!");
-    *num_rendered = (int64_t)host[GFT_SCAN_TOTAL];
+    *num_rendered = (int64_t)host[GFT_CTRL_TOTAL];
     return 0;
 }
 
@@ -288,22 +285,15 @@ extern "C" int gft_forward_render(void* hip_stream, const gft_config* cfg, const
     GeomView g = gft_geom_view(io->geom, L);
     ImgView im = gft_img_view(io->img, L);
     BinView b = gft_bin_view(io->binning, L);
-    const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
-    const int T = gx * gy;
-
     if (R > 0) {
         {
-            StageTimer t(s, ST_DUP);
-            GFT_STAGE(s, cfg, "duplicate_with_keys", gft_launch_duplicate(s, *cfg, g, io->radii, b));
+            StageTimer t(s, ST_TILE_SCATTER);
+            GFT_STAGE(s, cfg, "tile_scatter", gft_launch_tile_scatter(s, *cfg, g, im, b));
         }
         {
-            StageTimer t(s, ST_SORT);
-            GFT_STAGE(s, cfg, "sort", gft_launch_sort(s, R, 32 + (int)gft_higher_msb((uint32_t)T), b));
+            StageTimer t(s, ST_TILE_SORT);
+            GFT_STAGE(s, cfg, "tile_sort", gft_launch_tile_sort(s, *cfg, im, b));
         }
-    }
-    {
-        StageTimer t(s, ST_RANGES);
-        GFT_STAGE(s, cfg, "tile_ranges", gft_launch_ranges(s, R, T, b, im));
     }
     {
         StageTimer t(s, ST_RENDER_FWD);

@@ -15,37 +15,34 @@ struct GeomView {
     float4* rec_b;      // [P][3]  {r,g,b,p0} {p1,p2,p3,p4} {p5,p6,phase_sh,amp}
     float* depth;       // [P]
     uint32_t* tiles;    // [P]
-    uint32_t* offsets;  // [P] inclusive
+    ushort4* rect;      // [P] tile rectangle {x0,y0,x1,y1}; all zero when culled
     uint8_t* clamped;   // [P]
-    uint32_t* scan_tmp; // block sums + total + flags
+    uint32_t* ctrl;     // [8]
 };
 
 struct ImgView {
-    float4* pix_state;  // [N] {final_T, n_contrib bits, w_z, w_z2}
-    uint2* ranges;      // [T]
-    uint32_t* tile_max; // [T]
+    float4* pix_state;    // [N] {final_T, n_contrib bits, w_z, w_z2}
+    uint2* ranges;        // [T]
+    uint32_t* tile_max;   // [T]
+    uint32_t* tile_cnt;   // [T]
+    uint32_t* tile_cursor;// [T]
 };
 
 struct BinView {
-    uint64_t* keys_unsorted;
-    uint64_t* keys;
-    uint32_t* vals_unsorted;
-    uint32_t* point_list;
-    void* sort_tmp;
-    size_t sort_tmp_bytes;
+    uint64_t* keys;        // [R] (depth bits << 32 | id), grouped by tile
+    uint32_t* point_list;  // [R]
 };
 
-// scan_tmp layout (uint32): [0] = R (total), [1] = flags (bit0: prefiltered
-// point culled), [2..] = per-block sums / scanned block offsets
-#define GFT_SCAN_TOTAL 0
-#define GFT_SCAN_FLAGS 1
-#define GFT_SCAN_BLOCKS 2
+// ctrl words (uint32)
+#define GFT_CTRL_TOTAL 0     // R = number of (Gaussian, tile) instances
+#define GFT_CTRL_FLAGS 1     // bit0: prefiltered point culled
+#define GFT_CTRL_MAXCNT 2    // longest tile list
+#define GFT_CTRL_WORDS 8
 
 void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* L);
 GeomView gft_geom_view(void* base, const gft_layout& L);
 ImgView gft_img_view(void* base, const gft_layout& L);
 BinView gft_bin_view(void* base, const gft_layout& L);
-size_t gft_sort_tmp_bytes(int64_t R);
 
 int gft_fail(const char* fmt, ...);
 #define GFT_CHECK_HIP(expr)                                                          \
@@ -59,11 +56,11 @@ int gft_fail(const char* fmt, ...);
 // ---- stage launchers (each enqueues on `s`, returns hipError_t) -----------
 hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
                                      const GeomView& g);
-hipError_t gft_launch_scan(hipStream_t s, int32_t P, const GeomView& g);
-hipError_t gft_launch_duplicate(hipStream_t s, const gft_config& c, const GeomView& g,
-                                const int32_t* radii, const BinView& b);
-hipError_t gft_launch_sort(hipStream_t s, int64_t R, int end_bit, const BinView& b);
-hipError_t gft_launch_ranges(hipStream_t s, int64_t R, int T, const BinView& b, const ImgView& im);
+hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im);
+hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
+                                   const BinView& b);
+hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, const ImgView& im,
+                                const BinView& b);
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b);
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
@@ -73,8 +70,6 @@ hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const g
 hipError_t gft_launch_mark_visible(hipStream_t s, int32_t P, const float* means3D,
                                    const float* view, float near_n, float far_n, uint8_t* present);
 
-// reference rasterizer_impl.cu:35-50 (bit count of the tile id in the sort key)
-uint32_t gft_higher_msb(uint32_t n);
 
 // ---- device helpers ---------------------------------------------------------
 #define GFT_DPP_ROW_SHR(n) (0x110 + (n))

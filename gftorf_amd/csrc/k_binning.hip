@@ -1,29 +1,80 @@
-// k_binning.hip -- instance binning (gfx950): scan of tiles_touched, duplicate-with-
-// keys, key sort, per-tile ranges.  Integer/byte work, HBM-bound; results are
-// bit-identical to the reference's CUB pipeline (RAST/cuda_rasterizer/
-// rasterizer_impl.cu:307-348): keys = (tile << 32) | float_bits(view z), stable
-// order, ranges[tile] = [first, last+1).
+// k_binning.hip -- instance binning (gfx950): per-tile counting, scatter of
+// (depth, id) keys into tile segments, per-tile sort in LDS.
+//
+// The reference duplicates every Gaussian into (tile << 32 | depth bits) keys and runs
+// one global 64-bit radix sort over all R instances (RAST/cuda_rasterizer/
+// rasterizer_impl.cu:72-140,307-348: ~6 passes x 24 B x R of HBM traffic).  The
+// result it needs is only: for every tile, the ids of the Gaussians whose rectangle
+// covers it, ascending by (depth bits, id) -- that is what a stable sort of keys
+// emitted in id order produces.  MI355X form (integer work, HBM-bound, no global sort):
+//
+//   k_tile_count   : LDS histogram of tile hits per 4096-Gaussian block, one global
+//                    atomic per (block, tile)                           [8 B/Gaussian]
+//   k_tile_scan    : exclusive scan over tiles -> ranges[tile] = [first,last), R, max
+//   k_tile_scatter : each block reserves one chunk per tile with a single global atomic
+//                    and writes its (depth bits << 32 | id) keys there   [8 B/instance]
+//   k_tile_sort    : one workgroup per tile: bitonic sort of the tile's keys in LDS
+//                    (all comparators ascending, so the power-of-two padding never
+//                    moves), writes the id list               [8 B read + 4 B written]
+//
+// The order inside a tile segment after the scatter is arbitrary (atomic cursors); the
+// sort makes the final lists deterministic and bit-identical to the reference's.
 #include "gft_internal.h"
-
-#include <cstring>
-#include <rocprim/rocprim.hpp>
 
 namespace {
 
-// ---- scan: level 2 (block sums -> exclusive block offsets + total) ---------
-// One workgroup; nblocks <= a few thousand (P / 256).
-__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ scan_tmp, int nblocks)
+#define BIN_ITEMS 16                       // Gaussians per thread in count / scatter
+#define BIN_CHUNK (GFT_BLOCK * BIN_ITEMS)   // 4096 Gaussians per workgroup
+#define BIN_LDS_MAX_TILES 16384            // LDS histogram limit (2 x 64 KB in the scatter)
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(GFT_BLOCK) void k_tile_count(int P, int gx, int T, const ushort4* __restrict__ rect,
+                                                          uint32_t* __restrict__ tile_cnt)
+{
+    extern __shared__ uint32_t hist[];
+    const int tid = threadIdx.x;
+    if (USE_LDS) {
+        for (int i = tid; i < T; i += GFT_BLOCK) hist[i] = 0;
+        __syncthreads();
+    }
+    const int base = blockIdx.x * BIN_CHUNK;
+#pragma unroll 4
+    for (int k = 0; k < BIN_ITEMS; k++) {
+        const int idx = base + k * GFT_BLOCK + tid;
+        if (idx < P) {
+            const ushort4 r = rect[idx];
+            for (int y = r.y; y < r.w; y++)
+                for (int x = r.x; x < r.z; x++) {
+                    if (USE_LDS) atomicAdd(&hist[y * gx + x], 1u);
+                    else atomicAdd(&tile_cnt[y * gx + x], 1u);
+                }
+        }
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        for (int i = tid; i < T; i += GFT_BLOCK) {
+            const uint32_t h = hist[i];
+            if (h) atomicAdd(&tile_cnt[i], h);
+        }
+    }
+}
+
+// One workgroup: ranges = exclusive scan of tile_cnt; totals into ctrl; cursors zeroed.
+__global__ __launch_bounds__(1024) void k_tile_scan(int T, const uint32_t* __restrict__ tile_cnt,
+                                                    uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
+                                                    uint32_t* __restrict__ ctrl)
 {
     __shared__ uint32_t wtot[16];
+    __shared__ uint32_t wmax[16];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    uint32_t* sums = scan_tmp + GFT_SCAN_BLOCKS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < nblocks; base += 1024) {
+    uint32_t vmax = 0;
+    for (int base = 0; base < T; base += 1024) {
         const int i = base + threadIdx.x;
-        const uint32_t v = (i < nblocks) ? sums[i] : 0u;
-        // inclusive scan inside the wave (Hillis-Steele over shuffles)
+        const uint32_t v = (i < T) ? tile_cnt[i] : 0u;
+        vmax = max(vmax, v);
         uint32_t x = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -35,143 +86,217 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
         uint32_t woff = 0;
         for (int w = 0; w < wave; w++) woff += wtot[w];
         const uint32_t carry = carry_s;
-        if (i < nblocks) sums[i] = carry + woff + x - v;  // exclusive offset of block i
+        if (i < T) {
+            const uint32_t first = carry + woff + x - v;
+            ranges[i] = v ? make_uint2(first, first + v) : make_uint2(0u, 0u);   // untouched tiles: (0,0) like the reference
+            cursor[i] = 0;
+        }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + woff + x;
         __syncthreads();
     }
-    if (threadIdx.x == 0) scan_tmp[GFT_SCAN_TOTAL] = carry_s;
-}
-
-// ---- scan: level 3 (inclusive offsets per Gaussian) -------------------------
-__global__ __launch_bounds__(GFT_BLOCK) void k_scan_final(int P, const uint32_t* __restrict__ tiles,
-                                                          const uint32_t* __restrict__ scan_tmp,
-                                                          uint32_t* __restrict__ offsets)
-{
-    __shared__ uint32_t wtot[GFT_BLOCK / 64];
-    const int idx = blockIdx.x * GFT_BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t v = (idx < P) ? tiles[idx] : 0u;
-    uint32_t x = v;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    if (lane == 63) wtot[wave] = x;
+    for (int d = 32; d > 0; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
+    if (lane == 0) wmax[wave] = vmax;
     __syncthreads();
-    uint32_t woff = scan_tmp[GFT_SCAN_BLOCKS + blockIdx.x];
-    for (int w = 0; w < wave; w++) woff += wtot[w];
-    if (idx < P) offsets[idx] = woff + x;
-}
-
-// ---- duplicate with keys (reference K3) ---------------------------------------
-__global__ __launch_bounds__(GFT_BLOCK) void k_duplicate(int P, int gx, int gy, const float4* __restrict__ rec_a,
-                                                         const float* __restrict__ depth,
-                                                         const uint32_t* __restrict__ offsets,
-                                                         const uint32_t* __restrict__ tiles,
-                                                         const int32_t* __restrict__ radii,
-                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
-{
-    const int idx = blockIdx.x * GFT_BLOCK + threadIdx.x;
-    if (idx >= P) return;
-    const int radius = radii[idx];
-    if (radius > 0) {
-        uint32_t off = offsets[idx] - tiles[idx];
-        const float4 a0 = rec_a[2 * idx];
-        int x0, y0, x1, y1;
-        gft_get_rect(a0.x, a0.y, radius, gx, gy, x0, y0, x1, y1);
-        const uint64_t dbits = (uint64_t)__float_as_uint(depth[idx]);
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) {
-                keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
-                vals[off] = (uint32_t)idx;
-                off++;
-            }
+    if (threadIdx.x == 0) {
+        uint32_t m = 0;
+        for (int w = 0; w < 16; w++) m = max(m, wmax[w]);
+        ctrl[GFT_CTRL_TOTAL] = carry_s;
+        ctrl[GFT_CTRL_MAXCNT] = m;
     }
 }
 
-// ---- tile ranges (reference K5) -------------------------------------------------
-__global__ __launch_bounds__(GFT_BLOCK) void k_tile_ranges(uint32_t R, const uint64_t* __restrict__ keys,
-                                                           uint2* __restrict__ ranges)
+template <bool USE_LDS>
+__global__ __launch_bounds__(GFT_BLOCK) void k_tile_scatter(int P, int gx, int T, const ushort4* __restrict__ rect,
+                                                            const float* __restrict__ depth,
+                                                            const uint2* __restrict__ ranges,
+                                                            uint32_t* __restrict__ cursor,
+                                                            uint64_t* __restrict__ keys)
 {
-    const uint32_t idx = blockIdx.x * GFT_BLOCK + threadIdx.x;
-    if (idx >= R) return;
-    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
-    if (idx == 0)
-        ranges[cur].x = 0;
-    else {
-        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
-        if (cur != prev) {
-            ranges[prev].y = idx;
-            ranges[cur].x = idx;
+    extern __shared__ uint32_t sh[];
+    uint32_t* cnt = sh;          // [T] instances of this block per tile, then running slot
+    uint32_t* first = sh + T;    // [T] global position of this block's chunk in the tile segment
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * BIN_CHUNK;
+    if (USE_LDS) {
+        for (int i = tid; i < T; i += GFT_BLOCK) cnt[i] = 0;
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < BIN_ITEMS; k++) {
+            const int idx = base + k * GFT_BLOCK + tid;
+            if (idx < P) {
+                const ushort4 r = rect[idx];
+                for (int y = r.y; y < r.w; y++)
+                    for (int x = r.x; x < r.z; x++) atomicAdd(&cnt[y * gx + x], 1u);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < T; i += GFT_BLOCK) {
+            const uint32_t c = cnt[i];
+            if (c) {
+                first[i] = ranges[i].x + atomicAdd(&cursor[i], c);
+                cnt[i] = 0;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll 2
+    for (int k = 0; k < BIN_ITEMS; k++) {
+        const int idx = base + k * GFT_BLOCK + tid;
+        if (idx < P) {
+            const ushort4 r = rect[idx];
+            if (r.z > r.x && r.w > r.y) {
+                const uint64_t key = ((uint64_t)__float_as_uint(depth[idx]) << 32) | (uint32_t)idx;
+                for (int y = r.y; y < r.w; y++)
+                    for (int x = r.x; x < r.z; x++) {
+                        const int t = y * gx + x;
+                        uint32_t pos;
+                        if (USE_LDS) pos = first[t] + atomicAdd(&cnt[t], 1u);
+                        else pos = ranges[t].x + atomicAdd(&cursor[t], 1u);
+                        keys[pos] = key;
+                    }
+            }
         }
     }
-    if (idx == R - 1) ranges[cur].y = R;
+}
+
+// Bitonic network with ascending comparators only: merge step k starts with the
+// mirror stage (i <-> i ^ (k-1)), then half-cleaners at distances k/4 .. 1.
+// Elements at positions >= n are +inf by construction and never move.
+template <typename Ld, typename St, typename Sync>
+__device__ __forceinline__ void bitonic_ascending(uint32_t n, uint32_t npad, int tid, Ld ld, St st, Sync sync)
+{
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        const uint32_t half = k >> 1;
+        for (uint32_t c = tid; c < (npad >> 1); c += GFT_BLOCK) {
+            const uint32_t blk = c / half, off = c - blk * half;
+            const uint32_t i = blk * k + off, l = blk * k + (k - 1 - off);
+            if (l < n) {
+                const uint64_t a = ld(i), b = ld(l);
+                if (a > b) { st(i, b); st(l, a); }
+            }
+        }
+        sync();
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            for (uint32_t c = tid; c < (npad >> 1); c += GFT_BLOCK) {
+                const uint32_t i = ((c & ~(j - 1)) << 1) | (c & (j - 1)), l = i + j;
+                if (l < n) {
+                    const uint64_t a = ld(i), b = ld(l);
+                    if (a > b) { st(i, b); st(l, a); }
+                }
+            }
+            sync();
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t next_pow2(uint32_t n)
+{
+    uint32_t p = 2;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// Sort class: tiles with lo < n <= hi.  In-LDS version.
+__global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_lds(const uint2* __restrict__ ranges,
+                                                             const uint64_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ point_list, uint32_t lo,
+                                                             uint32_t hi)
+{
+    extern __shared__ uint64_t sk[];
+    const uint2 r = ranges[blockIdx.x];
+    const uint32_t n = r.y - r.x;
+    if (n <= lo || n > hi) return;
+    const int tid = threadIdx.x;
+    if (n == 1) {
+        if (tid == 0) point_list[r.x] = (uint32_t)keys[r.x];
+        return;
+    }
+    const uint32_t npad = next_pow2(n);
+    for (uint32_t i = tid; i < n; i += GFT_BLOCK) sk[i] = keys[r.x + i];
+    __syncthreads();
+    bitonic_ascending(n, npad, tid, [&](uint32_t i) { return sk[i]; }, [&](uint32_t i, uint64_t v) { sk[i] = v; },
+                      [] { __syncthreads(); });
+    for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[i];
+}
+
+// Fallback for tile lists that do not fit LDS: same network on the key segment in global
+// memory (in place), one workgroup per tile.
+__global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_global(const uint2* __restrict__ ranges, uint64_t* keys,
+                                                                uint32_t* __restrict__ point_list, uint32_t lo)
+{
+    const uint2 r = ranges[blockIdx.x];
+    const uint32_t n = r.y - r.x;
+    if (n <= lo) return;
+    const int tid = threadIdx.x;
+    uint64_t* seg = keys + r.x;
+    const uint32_t npad = next_pow2(n);
+    bitonic_ascending(n, npad, tid, [&](uint32_t i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
+                      [&](uint32_t i, uint64_t v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
+                      [] { __threadfence_block(); __syncthreads(); });
+    for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)seg[i];
 }
 
 }  // namespace
 
-uint32_t gft_higher_msb(uint32_t n)
-{
-    // smallest b with (n >> b) == 0, found by bisection from bit 16 (matches the
-    // reference getHigherMsb for every n, incl. powers of two)
-    uint32_t msb = 16, step = 16;
-    while (step > 1) {
-        step >>= 1;
-        msb = (n >> msb) ? msb + step : msb - step;
-    }
-    if (n >> msb) msb++;
-    return msb;
-}
+#define SORT_LDS_SMALL 4096u      // 32 KB of LDS
+#define SORT_LDS_LARGE 16384u     // 128 KB of LDS
 
-size_t gft_sort_tmp_bytes(int64_t R)
+hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im)
 {
-    if (R <= 0) return 0;
-    size_t bytes = 0;
-    uint64_t* k = nullptr;
-    uint32_t* v = nullptr;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)R, 0u, 64u, (hipStream_t)0);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        bytes = (size_t)R * 12 + (4u << 20);  // no device visible (size query on a CPU-only host)
-    }
-    return bytes;
-}
-
-hipError_t gft_launch_scan(hipStream_t s, int32_t P, const GeomView& g)
-{
-    const int blocks = (P + GFT_BLOCK - 1) / GFT_BLOCK;
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, g.scan_tmp, blocks);
-    hipLaunchKernelGGL(k_scan_final, dim3(blocks), dim3(GFT_BLOCK), 0, s, P, g.tiles, g.scan_tmp, g.offsets);
-    return hipGetLastError();
-}
-
-hipError_t gft_launch_duplicate(hipStream_t s, const gft_config& c, const GeomView& g, const int32_t* radii,
-                                const BinView& b)
-{
-    const int blocks = (c.P + GFT_BLOCK - 1) / GFT_BLOCK;
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
-    hipLaunchKernelGGL(k_duplicate, dim3(blocks), dim3(GFT_BLOCK), 0, s, c.P, gx, gy, g.rec_a, g.depth, g.offsets,
-                       g.tiles, radii, b.keys_unsorted, b.vals_unsorted);
+    const int T = gx * gy;
+    hipError_t e = hipMemsetAsync(im.tile_cnt, 0, (size_t)T * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
+    if (T <= BIN_LDS_MAX_TILES)
+        hipLaunchKernelGGL(k_tile_count<true>, dim3(blocks), dim3(GFT_BLOCK), (size_t)T * 4, s, c.P, gx, T, g.rect, im.tile_cnt);
+    else
+        hipLaunchKernelGGL(k_tile_count<false>, dim3(blocks), dim3(GFT_BLOCK), 0, s, c.P, gx, T, g.rect, im.tile_cnt);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, im.tile_cnt, im.ranges, im.tile_cursor, g.ctrl);
     return hipGetLastError();
 }
 
-hipError_t gft_launch_sort(hipStream_t s, int64_t R, int end_bit, const BinView& b)
+hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
+                                   const BinView& b)
 {
-    if (R <= 0) return hipSuccess;
-    size_t bytes = b.sort_tmp_bytes;
-    return rocprim::radix_sort_pairs(b.sort_tmp, bytes, b.keys_unsorted, b.keys, b.vals_unsorted, b.point_list,
-                                     (size_t)R, 0u, (unsigned)end_bit, s);
+    const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    const int T = gx * gy;
+    const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
+    if (T <= BIN_LDS_MAX_TILES) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_scatter<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BIN_LDS_MAX_TILES * 4);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_tile_scatter<true>, dim3(blocks), dim3(GFT_BLOCK), (size_t)T * 8, s, c.P, gx, T, g.rect,
+                           g.depth, im.ranges, im.tile_cursor, b.keys);
+    } else {
+        hipLaunchKernelGGL(k_tile_scatter<false>, dim3(blocks), dim3(GFT_BLOCK), 0, s, c.P, gx, T, g.rect, g.depth,
+                           im.ranges, im.tile_cursor, b.keys);
+    }
+    return hipGetLastError();
 }
 
-hipError_t gft_launch_ranges(hipStream_t s, int64_t R, int T, const BinView& b, const ImgView& im)
+hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b)
 {
-    hipError_t e = hipMemsetAsync(im.ranges, 0, (size_t)T * sizeof(uint2), s);
-    if (e != hipSuccess) return e;
-    if (R > 0) {
-        const int blocks = (int)((R + GFT_BLOCK - 1) / GFT_BLOCK);
-        hipLaunchKernelGGL(k_tile_ranges, dim3(blocks), dim3(GFT_BLOCK), 0, s, (uint32_t)R, b.keys, im.ranges);
+    const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    const int T = gx * gy;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort_lds),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_LARGE * 8);
+        attr_set = true;
     }
+    // Three size classes, always launched (a workgroup whose tile is in another class exits at
+    // once): that keeps the host from having to read the longest list length back.
+    hipLaunchKernelGGL(k_tile_sort_lds, dim3(T), dim3(GFT_BLOCK), (size_t)SORT_LDS_SMALL * 8, s, im.ranges, b.keys,
+                       b.point_list, 0u, SORT_LDS_SMALL);
+    hipLaunchKernelGGL(k_tile_sort_lds, dim3(T), dim3(GFT_BLOCK), (size_t)SORT_LDS_LARGE * 8, s, im.ranges, b.keys,
+                       b.point_list, SORT_LDS_SMALL, SORT_LDS_LARGE);
+    hipLaunchKernelGGL(k_tile_sort_global, dim3(T), dim3(GFT_BLOCK), 0, s, im.ranges, b.keys, b.point_list,
+                       SORT_LDS_LARGE);
     return hipGetLastError();
 }

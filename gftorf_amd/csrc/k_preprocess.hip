@@ -3,7 +3,6 @@
 //  k_preprocess_fwd : cull, project, cov3D/cov2D, conic, radius, tile rect,
 //                     SH -> RGB, SH_p -> (phase, amplitude), ToF phasor[7]
 //                     (reference K1, RAST/cuda_rasterizer/forward.cu:251-419)
-//                     + per-block sums of tiles_touched for the scan.
 //  k_preprocess_bwd : conic -> cov2D -> cov3D/mean chain, projection chain, SH
 //                     and SH_p chains, ToF-phasor chain, distance chain,
 //                     cov3D -> scale/rotation (reference K8 + K9 fused,
@@ -239,15 +238,15 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
 {
     const int idx = blockIdx.x * GFT_BLOCK + threadIdx.x;
     const int P = a.c.P;
-    uint32_t tiles = 0;
-
     if (idx < P) {
+        uint32_t tiles = 0;
         int radius = 0;
+        ushort4 rect = make_ushort4(0, 0, 0, 0);
         const float px = a.io.means3D[3 * idx], py = a.io.means3D[3 * idx + 1], pz = a.io.means3D[3 * idx + 2];
         const Mat16 V = load_mat(a.io.viewmatrix);
         const float vz = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
         if (vz < a.c.near_n || vz > a.c.far_n) {
-            if (a.c.prefiltered) atomicOr(&a.g.scan_tmp[GFT_SCAN_FLAGS], 1u);
+            if (a.c.prefiltered) atomicOr(&a.g.ctrl[GFT_CTRL_FLAGS], 1u);
         } else {
             const float vx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
             const float vy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
@@ -361,20 +360,15 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                     a.g.clamped[idx] = (uint8_t)clamp_bits;
                     radius = (int)my_radius;
                     tiles = area;
+                    rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
                 }
             }
         }
         a.io.radii[idx] = radius;
         a.io.pixels[idx] = 0.0f;
         a.g.tiles[idx] = tiles;
+        a.g.rect[idx] = rect;
     }
-
-    // per-block sum of tiles_touched -> first level of the scan
-    __shared__ uint32_t wsum[GFT_BLOCK / 64];
-    const uint32_t s = gft_wave_sum_u32_to_lane63(tiles);
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) a.g.scan_tmp[GFT_SCAN_BLOCKS + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // ---------------------------------------------------------------------------

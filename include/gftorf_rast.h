@@ -154,27 +154,26 @@ typedef struct gft_layout {
     size_t geom_rec_b;        /* float[P][12] {r,g,b, phasor[7], phase_sh, amplitude} */
     size_t geom_depth;        /* float[P]     view-space z (sort key bits) */
     size_t geom_tiles;        /* uint32[P]    tiles touched */
-    size_t geom_offsets;      /* uint32[P]    inclusive scan of tiles */
+    size_t geom_rect;         /* uint16[P][4] tile rectangle {x0,y0,x1,y1} (all 0 when culled) */
     size_t geom_clamped;      /* uint8[P]     bit0..2 rgb clamped, bit3 amplitude clamped */
-    size_t geom_scan_tmp;
+    size_t geom_ctrl;         /* uint32[8]    {R, flags, max tile list length, ...} */
     size_t geom_total;
     /* img */
     size_t img_pix_state;     /* float[N][4]  {final_T, n_contrib(bits), w_z, w_z2} */
-    size_t img_ranges;        /* uint32[T][2] */
+    size_t img_ranges;        /* uint32[T][2] [first,last) of the tile's list */
     size_t img_tile_max;      /* uint32[T]    max n_contrib over the tile */
+    size_t img_tile_cnt;      /* uint32[T]    instances per tile */
+    size_t img_tile_cursor;   /* uint32[T]    scatter cursors */
     size_t img_total;
     /* binning */
-    size_t bin_keys_unsorted; /* uint64[R] */
-    size_t bin_keys;          /* uint64[R] sorted */
-    size_t bin_vals_unsorted; /* uint32[R] */
-    size_t bin_point_list;    /* uint32[R] sorted Gaussian ids */
-    size_t bin_sort_tmp;
+    size_t bin_keys;          /* uint64[R]    (depth bits << 32 | Gaussian id), grouped by tile, unsorted */
+    size_t bin_point_list;    /* uint32[R]    Gaussian ids, per tile ascending (depth bits, id) */
     size_t bin_total;
 } gft_layout;
 
 /* per-stage GPU time in milliseconds, accumulated while profiling is enabled */
 typedef struct gft_profile {
-    double preprocess_fwd_ms, scan_ms, duplicate_ms, sort_ms, ranges_ms, render_fwd_ms;
+    double preprocess_fwd_ms, tile_count_ms, tile_scatter_ms, tile_sort_ms, render_fwd_ms;
     double render_bwd_ms, preprocess_bwd_ms, memset_ms;
     int64_t forward_calls, backward_calls;
 } gft_profile;

@@ -73,7 +73,7 @@ def test_size_queries_and_layout_need_no_gpu(lib):
     L = _lib.get_layout(1000, 640, 480, 5000)
     offs = [getattr(L, n) for n in _lib.LAYOUT_FIELDS]
     assert all(o % 256 == 0 for o in offs)
-    assert L.geom_rec_b >= 32 * 1000 and L.bin_keys >= 8 * 5000 and L.bin_total >= 24 * 5000
+    assert L.geom_rec_b >= 32 * 1000 and L.bin_point_list >= 8 * 5000 and L.bin_total >= 12 * 5000
     assert lib.gft_binning_bytes(0, 640, 480) >= 0
 
 

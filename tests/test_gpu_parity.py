@@ -81,12 +81,13 @@ def raw_forward(scene, dev, inputs=None):
         rec_b=view_of(geom, L.geom_rec_b, P * 12, torch.float32).reshape(P, 12),
         depth=view_of(geom, L.geom_depth, P, torch.float32),
         tiles=view_of(geom, L.geom_tiles, P, torch.int32).astype(np.uint32),
-        offsets=view_of(geom, L.geom_offsets, P, torch.int32).astype(np.uint32),
+        rect=view_of(geom, L.geom_rect, P * 4, torch.int16).astype(np.uint16).reshape(P, 4),
         clamped=view_of(geom, L.geom_clamped, P, torch.uint8),
+        ctrl=view_of(geom, L.geom_ctrl, 8, torch.int32).astype(np.uint32),
         pix_state=view_of(img, L.img_pix_state, W * H * 4, torch.float32).reshape(H * W, 4),
         ranges=view_of(img, L.img_ranges, Tn * 2, torch.int32).astype(np.uint32).reshape(Tn, 2),
         tile_max=view_of(img, L.img_tile_max, Tn, torch.int32).astype(np.uint32),
-        keys=view_of(binning, L.bin_keys, R, torch.int64).astype(np.uint64) if R else np.zeros(0, np.uint64),
+        tile_cnt=view_of(img, L.img_tile_cnt, Tn, torch.int32).astype(np.uint32),
         point_list=view_of(binning, L.bin_point_list, R, torch.int32).astype(np.uint32) if R else np.zeros(0, np.uint32),
     )
     del keep
@@ -101,6 +102,8 @@ SCENES = {
     "identity_cam": dict(w2c=None),
     "tiny_splats": dict(scale_lo=0.001, scale_hi=0.004, P=600),
     "opaque_early_exit": dict(P=2500, W=64, H=48, scale_lo=0.05, scale_hi=0.25, opacity=0.95),  # T < 1e-4 termination
+    "long_lists_lds128k": dict(P=9000, W=32, H=32, scale_lo=0.05, scale_hi=0.3),    # 4096 < tile list <= 16384
+    "long_lists_global": dict(P=24000, W=32, H=16, scale_lo=0.05, scale_hi=0.3),    # tile list > 16384: global-memory sort
 }
 
 
@@ -114,8 +117,14 @@ def test_preprocess_and_binning_bit_exact(name, oracle, gpu):
     # integer decisions
     np.testing.assert_array_equal(st["radii"], og["radii"])
     np.testing.assert_array_equal(st["tiles"], og["tiles_touched"])
-    np.testing.assert_array_equal(st["offsets"], f.offsets)
-    assert st["R"] == f.num_rendered
+    assert st["R"] == f.num_rendered == int(st["ctrl"][0])
+    lens = f.ranges[:, 1] - f.ranges[:, 0]
+    np.testing.assert_array_equal(st["tile_cnt"], lens)
+    assert int(st["ctrl"][2]) == int(lens.max())
+    W, H = scene["cfg"]["W"], scene["cfg"]["H"]
+    np.testing.assert_array_equal(
+        (st["rect"][:, 2].astype(np.int64) - st["rect"][:, 0]) * (st["rect"][:, 3].astype(np.int64) - st["rect"][:, 1]),
+        og["tiles_touched"])
     # IEEE-exact float stages (contraction disabled on both sides)
     np.testing.assert_array_equal(st["rec_a"][vis, 0:2], og["means2D"][vis])
     np.testing.assert_array_equal(st["depth"][vis].view(np.uint32), og["depths"][vis].view(np.uint32))
@@ -129,10 +138,12 @@ def test_preprocess_and_binning_bit_exact(name, oracle, gpu):
     # transcendental stage (sinf/cosf differ by ulps between glibc and the device library)
     Hh.assert_close("phasor7", og["phasor7"][vis], st["rec_b"][vis, 3:10], rtol_max=2e-6, atol=1e-9)
     Hh.assert_close("phase_amp", og["phase_amp"][vis], st["rec_b"][vis, 10:12], rtol_max=1e-6, atol=1e-9)
-    # keys / sorted list / ranges: bit-identical
-    np.testing.assert_array_equal(st["keys"], f.keys_sorted)
+    # sorted list / ranges: bit-identical; the reference's 64-bit keys follow from them
     np.testing.assert_array_equal(st["point_list"], f.point_list)
     np.testing.assert_array_equal(st["ranges"], f.ranges)
+    tile_of = np.repeat(np.arange(lens.size, dtype=np.uint64), lens)
+    keys = (tile_of << np.uint64(32)) | st["depth"][st["point_list"]].view(np.uint32).astype(np.uint64)
+    np.testing.assert_array_equal(keys, f.keys_sorted)
 
 
 @pytest.mark.parametrize("name", list(SCENES))
