@@ -74,7 +74,7 @@ class Profile(C.Structure):
 
 
 EXPORTS = [
-    "gft_abi_version", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes",
+    "gft_abi_version", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes", "gft_acc_bytes",
     "gft_get_layout", "gft_forward_preprocess", "gft_forward_render", "gft_backward",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
 ]
@@ -101,6 +101,8 @@ def load():
     lib.gft_image_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.gft_binning_bytes.restype = C.c_size_t
     lib.gft_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    lib.gft_acc_bytes.restype = C.c_size_t
+    lib.gft_acc_bytes.argtypes = [C.c_int32]
     lib.gft_get_layout.restype = C.c_int
     lib.gft_get_layout.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(Layout)]
     lib.gft_forward_preprocess.restype = C.c_int

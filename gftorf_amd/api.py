@@ -268,7 +268,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_scales = torch.empty((P, 3), **f32) if has_scales else None
         grad_rotations = torch.empty((P, 4), **f32) if has_scales else None
         grad_offsets = torch.empty((2,), **f32)
-        acc = torch.empty((P, _lib.ACC_STRIDE), **f32)
+        acc = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32)
 
         cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx))
         io = _lib.BackwardIO()

@@ -114,6 +114,12 @@ extern "C" size_t gft_binning_bytes(int64_t R, int32_t W, int32_t H)
     return L.bin_total;
 }
 
+extern "C" size_t gft_acc_bytes(int32_t P)
+{
+    const size_t p = (size_t)(P > 0 ? P : 0);
+    return (p * GFT_ACC_STRIDE + 2 * ((p + 63) / 64) + 64) * sizeof(float);
+}
+
 extern "C" int gft_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* out)
 {
     if (!out) return gft_fail("gft_get_layout: out is NULL");

@@ -198,21 +198,141 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t n)
     return p;
 }
 
-// Sort class: tiles with lo < n <= hi.  In-LDS version.
-__global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_lds(const uint2* __restrict__ ranges,
-                                                             const uint64_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ point_list, uint32_t lo,
-                                                             uint32_t hi)
+// ---- register-blocked bitonic sort (lists of 1025..4096 keys) -------------------
+// Standard bitonic network on npad = 256 << LOG_E keys (+inf padded).  A thread owns
+// E = 2^LOG_E keys in registers; which keys depends on the layout b: the thread's register
+// index supplies key-index bits [b, b+LOG_E), the thread id supplies the rest.  All stages
+// whose distance bit falls inside [b, b+LOG_E) are compare-exchanges between registers; the
+// keys travel through LDS only when the layout changes (about 20 round trips instead of 78
+// LDS stages for 4096 keys).  LDS slot of key i is i + (i >> 5) (bank spreading).
+__device__ __forceinline__ uint32_t sort_slot(uint32_t i) { return i + (i >> 5); }
+
+template <int LOG_E>
+__device__ __forceinline__ uint32_t key_index(int t, int r, int b)
 {
-    extern __shared__ uint64_t sk[];
+    return ((uint32_t)(t >> b) << (b + LOG_E)) | ((uint32_t)r << b) | ((uint32_t)t & ((1u << b) - 1u));
+}
+
+template <int LOG_E>
+__device__ __forceinline__ void regs_from_lds(uint64_t* v, const uint64_t* sk, int t, int b)
+{
+#pragma unroll
+    for (int r = 0; r < (1 << LOG_E); r++) v[r] = sk[sort_slot(key_index<LOG_E>(t, r, b))];
+}
+
+template <int LOG_E>
+__device__ __forceinline__ void regs_to_lds(const uint64_t* v, uint64_t* sk, int t, int b)
+{
+#pragma unroll
+    for (int r = 0; r < (1 << LOG_E); r++) sk[sort_slot(key_index<LOG_E>(t, r, b))] = v[r];
+}
+
+// one bitonic stage between registers: distance bit S (register-index bit), merge bit m
+template <int LOG_E, int S>
+__device__ __forceinline__ void reg_stage(uint64_t* v, int t, int b, int m, int LG)
+{
+#pragma unroll
+    for (int r = 0; r < (1 << LOG_E); r++) {
+        if (r & (1 << S)) continue;
+        const int r2 = r | (1 << S);
+        const uint32_t i = key_index<LOG_E>(t, r, b);
+        const bool up = (m >= LG) || (((i >> m) & 1u) == 0u);
+        const uint64_t x = v[r], y = v[r2];
+        const bool sw = (x > y) == up;
+        v[r] = sw ? y : x;
+        v[r2] = sw ? x : y;
+    }
+}
+
+template <int LOG_E>
+__device__ __forceinline__ void reg_stage_dyn(uint64_t* v, int s_local, int t, int b, int m, int LG)
+{
+    switch (s_local) {
+    case 0: reg_stage<LOG_E, 0>(v, t, b, m, LG); break;
+    case 1: reg_stage<LOG_E, 1>(v, t, b, m, LG); break;
+    case 2: reg_stage<LOG_E, 2>(v, t, b, m, LG); break;
+    default:
+        if (LOG_E > 3) reg_stage<LOG_E, (LOG_E > 3 ? 3 : 0)>(v, t, b, m, LG);
+        break;
+    }
+}
+
+template <int LOG_E>
+__device__ __forceinline__ void bitonic_blocked(uint64_t* sk, int tid)
+{
+    constexpr int E = 1 << LOG_E;
+    constexpr int LG = 8 + LOG_E;          // log2(npad), 256 threads
+    uint64_t v[E];
+    int b = 0;                             // current layout (compile-time after unrolling)
+    regs_from_lds<LOG_E>(v, sk, tid, 0);
+    // the whole schedule is unrolled: every layout, distance and register pair is a constant,
+    // which keeps the E keys in registers
+#pragma unroll
+    for (int m = 1; m <= LG; m++) {        // merge size 2^m
+#pragma unroll
+        for (int s = m - 1; s >= 0; s--) { // distance bit
+            // layout that holds bit s: chunks of LOG_E bits from the bottom, top chunk clipped
+            int nb = (s / LOG_E) * LOG_E;
+            if (nb > LG - LOG_E) nb = LG - LOG_E;
+            if (nb != b) {
+                __syncthreads();
+                regs_to_lds<LOG_E>(v, sk, tid, b);
+                __syncthreads();
+                b = nb;
+                regs_from_lds<LOG_E>(v, sk, tid, b);
+            }
+            reg_stage_dyn<LOG_E>(v, s - b, tid, b, m, LG);
+        }
+    }
+    // b == 0 here (the last stages of every merge are in the natural layout)
+    __syncthreads();
+    regs_to_lds<LOG_E>(v, sk, tid, 0);
+    __syncthreads();
+}
+
+// Sort class A: tile lists of up to 4096 keys, 33.8 KB of LDS.
+__global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_small(const uint2* __restrict__ ranges,
+                                                               const uint64_t* __restrict__ keys,
+                                                               uint32_t* __restrict__ point_list)
+{
+    __shared__ uint64_t sk[4096 + 128];
     const uint2 r = ranges[blockIdx.x];
     const uint32_t n = r.y - r.x;
-    if (n <= lo || n > hi) return;
+    if (n == 0 || n > 4096u) return;
     const int tid = threadIdx.x;
     if (n == 1) {
         if (tid == 0) point_list[r.x] = (uint32_t)keys[r.x];
         return;
     }
+    if (n <= 1024u) {
+        const uint32_t npad = next_pow2(n);
+        for (uint32_t i = tid; i < n; i += GFT_BLOCK) sk[i] = keys[r.x + i];
+        __syncthreads();
+        bitonic_ascending(n, npad, tid, [&](uint32_t i) { return sk[i]; }, [&](uint32_t i, uint64_t v) { sk[i] = v; },
+                          [] { __syncthreads(); });
+        for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[i];
+        return;
+    }
+    const uint32_t npad = n <= 2048u ? 2048u : 4096u;
+    for (uint32_t i = tid; i < npad; i += GFT_BLOCK) sk[sort_slot(i)] = i < n ? keys[r.x + i] : ~0ull;
+    __syncthreads();
+    if (npad == 2048u) bitonic_blocked<3>(sk, tid);
+    else bitonic_blocked<4>(sk, tid);
+    for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[sort_slot(i)];
+}
+
+// Sort class B: tile lists of 4097..16384 keys, 128 KB of dynamic LDS (rare).
+__global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_lds(const uint2* __restrict__ ranges,
+                                                             const uint64_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ point_list, uint32_t lo,
+                                                             uint32_t hi)
+{
+    extern __shared__ uint64_t sk_dyn[];
+    uint64_t* sk = sk_dyn;
+    const uint2 r = ranges[blockIdx.x];
+    const uint32_t n = r.y - r.x;
+    if (n <= lo || n > hi) return;
+    const int tid = threadIdx.x;
     const uint32_t npad = next_pow2(n);
     for (uint32_t i = tid; i < n; i += GFT_BLOCK) sk[i] = keys[r.x + i];
     __syncthreads();
@@ -292,8 +412,7 @@ hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, const ImgVie
     }
     // Three size classes, always launched (a workgroup whose tile is in another class exits at
     // once): that keeps the host from having to read the longest list length back.
-    hipLaunchKernelGGL(k_tile_sort_lds, dim3(T), dim3(GFT_BLOCK), (size_t)SORT_LDS_SMALL * 8, s, im.ranges, b.keys,
-                       b.point_list, 0u, SORT_LDS_SMALL);
+    hipLaunchKernelGGL(k_tile_sort_small, dim3(T), dim3(GFT_BLOCK), 0, s, im.ranges, b.keys, b.point_list);
     hipLaunchKernelGGL(k_tile_sort_lds, dim3(T), dim3(GFT_BLOCK), (size_t)SORT_LDS_LARGE * 8, s, im.ranges, b.keys,
                        b.point_list, SORT_LDS_SMALL, SORT_LDS_LARGE);
     hipLaunchKernelGGL(k_tile_sort_global, dim3(T), dim3(GFT_BLOCK), 0, s, im.ranges, b.keys, b.point_list,

@@ -129,9 +129,11 @@ __device__ __forceinline__ void sh_eval(int deg, float x, float y, float z, cons
 
 // SH backward: writes dL_dsh[k*NC+c] for the active coefficients, zero for the
 // inactive ones up to M, and returns the gradient w.r.t. the unit direction.
+// `sh` and `dsh` may be the same array (every coefficient is read before its slot is
+// overwritten), which lets the staged path work in place on one register row.
 template <int NC>
-__device__ __forceinline__ void sh_backward(int deg, int M, float x, float y, float z, const float* __restrict__ sh,
-                                            const float* dres, float* __restrict__ dsh, float* ddir)
+__device__ __forceinline__ void sh_backward(int deg, int M, float x, float y, float z, const float* sh,
+                                            const float* dres, float* dsh, float* ddir)
 {
     float ddx[NC], ddy[NC], ddz[NC];
 #pragma unroll
@@ -144,12 +146,13 @@ __device__ __forceinline__ void sh_backward(int deg, int M, float x, float y, fl
         const float d1 = -SH_C1 * y, d2 = SH_C1 * z, d3 = -SH_C1 * x;
 #pragma unroll
         for (int c = 0; c < NC; c++) {
+            const float s1 = sh[1 * NC + c], s2 = sh[2 * NC + c], s3 = sh[3 * NC + c];
+            ddx[c] = -SH_C1 * s3;
+            ddy[c] = -SH_C1 * s1;
+            ddz[c] = SH_C1 * s2;
             dsh[1 * NC + c] = d1 * dres[c];
             dsh[2 * NC + c] = d2 * dres[c];
             dsh[3 * NC + c] = d3 * dres[c];
-            ddx[c] = -SH_C1 * sh[3 * NC + c];
-            ddy[c] = -SH_C1 * sh[1 * NC + c];
-            ddz[c] = SH_C1 * sh[2 * NC + c];
         }
         written = 4;
         if (deg > 1) {
@@ -158,17 +161,16 @@ __device__ __forceinline__ void sh_backward(int deg, int M, float x, float y, fl
             const float d7 = SH_C2[3] * xz, d8 = SH_C2[4] * (xx - yy);
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                const float* s = sh + c;
+                const float s4 = sh[4 * NC + c], s5 = sh[5 * NC + c], s6 = sh[6 * NC + c], s7 = sh[7 * NC + c],
+                            s8 = sh[8 * NC + c];
+                ddx[c] += SH_C2[0] * y * s4 + SH_C2[2] * 2.f * -x * s6 + SH_C2[3] * z * s7 + SH_C2[4] * 2.f * x * s8;
+                ddy[c] += SH_C2[0] * x * s4 + SH_C2[1] * z * s5 + SH_C2[2] * 2.f * -y * s6 + SH_C2[4] * 2.f * -y * s8;
+                ddz[c] += SH_C2[1] * y * s5 + SH_C2[2] * 2.f * 2.f * z * s6 + SH_C2[3] * x * s7;
                 dsh[4 * NC + c] = d4 * dres[c];
                 dsh[5 * NC + c] = d5 * dres[c];
                 dsh[6 * NC + c] = d6 * dres[c];
                 dsh[7 * NC + c] = d7 * dres[c];
                 dsh[8 * NC + c] = d8 * dres[c];
-                ddx[c] += SH_C2[0] * y * s[4 * NC] + SH_C2[2] * 2.f * -x * s[6 * NC] + SH_C2[3] * z * s[7 * NC] +
-                          SH_C2[4] * 2.f * x * s[8 * NC];
-                ddy[c] += SH_C2[0] * x * s[4 * NC] + SH_C2[1] * z * s[5 * NC] + SH_C2[2] * 2.f * -y * s[6 * NC] +
-                          SH_C2[4] * 2.f * -y * s[8 * NC];
-                ddz[c] += SH_C2[1] * y * s[5 * NC] + SH_C2[2] * 2.f * 2.f * z * s[6 * NC] + SH_C2[3] * x * s[7 * NC];
             }
             written = 9;
             if (deg > 2) {
@@ -181,7 +183,20 @@ __device__ __forceinline__ void sh_backward(int deg, int M, float x, float y, fl
                 const float d15 = SH_C3[6] * x * (xx - 3.f * yy);
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    const float* s = sh + c;
+                    const float s9 = sh[9 * NC + c], s10 = sh[10 * NC + c], s11 = sh[11 * NC + c],
+                                s12 = sh[12 * NC + c], s13 = sh[13 * NC + c], s14 = sh[14 * NC + c],
+                                s15 = sh[15 * NC + c];
+                    ddx[c] += (SH_C3[0] * s9 * 3.f * 2.f * xy + SH_C3[1] * s10 * yz +
+                               SH_C3[2] * s11 * -2.f * xy + SH_C3[3] * s12 * -3.f * 2.f * xz +
+                               SH_C3[4] * s13 * (-3.f * xx + 4.f * zz - yy) + SH_C3[5] * s14 * 2.f * xz +
+                               SH_C3[6] * s15 * 3.f * (xx - yy));
+                    ddy[c] += (SH_C3[0] * s9 * 3.f * (xx - yy) + SH_C3[1] * s10 * xz +
+                               SH_C3[2] * s11 * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * s12 * -3.f * 2.f * yz +
+                               SH_C3[4] * s13 * -2.f * xy + SH_C3[5] * s14 * -2.f * yz +
+                               SH_C3[6] * s15 * -3.f * 2.f * xy);
+                    ddz[c] += (SH_C3[1] * s10 * xy + SH_C3[2] * s11 * 4.f * 2.f * yz +
+                               SH_C3[3] * s12 * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * s13 * 4.f * 2.f * xz +
+                               SH_C3[5] * s14 * (xx - yy));
                     dsh[9 * NC + c] = d9 * dres[c];
                     dsh[10 * NC + c] = d10 * dres[c];
                     dsh[11 * NC + c] = d11 * dres[c];
@@ -189,23 +204,15 @@ __device__ __forceinline__ void sh_backward(int deg, int M, float x, float y, fl
                     dsh[13 * NC + c] = d13 * dres[c];
                     dsh[14 * NC + c] = d14 * dres[c];
                     dsh[15 * NC + c] = d15 * dres[c];
-                    ddx[c] += (SH_C3[0] * s[9 * NC] * 3.f * 2.f * xy + SH_C3[1] * s[10 * NC] * yz +
-                               SH_C3[2] * s[11 * NC] * -2.f * xy + SH_C3[3] * s[12 * NC] * -3.f * 2.f * xz +
-                               SH_C3[4] * s[13 * NC] * (-3.f * xx + 4.f * zz - yy) + SH_C3[5] * s[14 * NC] * 2.f * xz +
-                               SH_C3[6] * s[15 * NC] * 3.f * (xx - yy));
-                    ddy[c] += (SH_C3[0] * s[9 * NC] * 3.f * (xx - yy) + SH_C3[1] * s[10 * NC] * xz +
-                               SH_C3[2] * s[11 * NC] * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * s[12 * NC] * -3.f * 2.f * yz +
-                               SH_C3[4] * s[13 * NC] * -2.f * xy + SH_C3[5] * s[14 * NC] * -2.f * yz +
-                               SH_C3[6] * s[15 * NC] * -3.f * 2.f * xy);
-                    ddz[c] += (SH_C3[1] * s[10 * NC] * xy + SH_C3[2] * s[11 * NC] * 4.f * 2.f * yz +
-                               SH_C3[3] * s[12 * NC] * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * s[13 * NC] * 4.f * 2.f * xz +
-                               SH_C3[5] * s[14 * NC] * (xx - yy));
                 }
                 written = 16;
             }
         }
     }
-    for (int k = written * NC; k < M * NC; k++) dsh[k] = 0.f;
+    // inactive coefficients: constant trip count keeps register-resident rows out of scratch
+#pragma unroll
+    for (int k = NC; k < 16 * NC; k++)
+        if (k >= written * NC && k < M * NC) dsh[k] = 0.f;
     float sx = ddx[0] * dres[0], sy = ddy[0] * dres[0], sz = ddz[0] * dres[0];
 #pragma unroll
     for (int c = 1; c < NC; c++) {
@@ -214,6 +221,57 @@ __device__ __forceinline__ void sh_backward(int deg, int M, float x, float y, fl
         sz = sz + ddz[c] * dres[c];
     }
     ddir[0] = sx; ddir[1] = sy; ddir[2] = sz;
+}
+
+// ---- coalesced SH rows through LDS ---------------------------------------------
+// A wave owns 64 consecutive Gaussians whose SH rows form one contiguous block of
+// 64*M*NC floats: moved as 16-byte vectors with consecutive lanes on consecutive
+// addresses (the per-lane row walk of the straightforward kernel touches 64 cache
+// lines per load instruction).  Used when M == 16 (rows are whole float4s).
+#define SH_ROW_F4 12     // 16 coefficients x 3 channels
+#define SHP_ROW_F4 8     // 16 coefficients x 2 channels
+
+template <int ROW_F4>
+__device__ __forceinline__ void wave_rows_to_lds(float4* dst, const float4* __restrict__ src, size_t first_gaussian,
+                                                 size_t P, int lane)
+{
+    const size_t lim = P * ROW_F4;
+    const size_t g0 = first_gaussian * ROW_F4;
+#pragma unroll
+    for (int q = 0; q < ROW_F4; q++) {
+        const size_t i = g0 + (size_t)(q * 64 + lane);
+        if (i < lim) dst[q * 64 + lane] = src[i];
+    }
+}
+
+template <int ROW_F4>
+__device__ __forceinline__ void wave_rows_from_lds(float4* __restrict__ dst, const float4* src, size_t first_gaussian,
+                                                   size_t P, int lane)
+{
+    const size_t lim = P * ROW_F4;
+    const size_t g0 = first_gaussian * ROW_F4;
+#pragma unroll
+    for (int q = 0; q < ROW_F4; q++) {
+        const size_t i = g0 + (size_t)(q * 64 + lane);
+        if (i < lim) dst[i] = src[q * 64 + lane];
+    }
+}
+
+template <int ROW_F4>
+__device__ __forceinline__ void lds_row_load(float* v, const float4* row)
+{
+#pragma unroll
+    for (int q = 0; q < ROW_F4; q++) {
+        const float4 t = row[q];
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+}
+
+template <int ROW_F4>
+__device__ __forceinline__ void lds_row_store(float4* row, const float* v)
+{
+#pragma unroll
+    for (int q = 0; q < ROW_F4; q++) row[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
 // d normalize(v) / dv applied to dv (reference auxiliary.h:110-120)
@@ -226,18 +284,33 @@ __device__ __forceinline__ void dnorm_dv(float vx, float vy, float vz, const flo
     o[2] = (-vx * vz * dv[0] - vy * vz * dv[1] + (sum2 - vz * vz) * dv[2]) * invsum32;
 }
 
+// One wave per workgroup: the SH rows of a wave go through a private LDS region, barriers are
+// wave-local, and occupancy is not quantised by a 4-wave LDS footprint.
+#define PRE_BLOCK 64
+
 struct PreFwdArgs {
     gft_config c;
     gft_forward_io io;
     GeomView g;
     float focal_x, focal_y, dist2phase;
     int gx, gy;
+    int stage_sh, stage_shp;   // SH rows staged through LDS (M == 16)
 };
 
-__global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
 {
-    const int idx = blockIdx.x * GFT_BLOCK + threadIdx.x;
+    extern __shared__ float4 lds_rows[];
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const int P = a.c.P;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4* sh_l = lds_rows + wave * ((a.stage_sh ? 64 * SH_ROW_F4 : 0) + (a.stage_shp ? 64 * SHP_ROW_F4 : 0));
+    float4* shp_l = sh_l + (a.stage_sh ? 64 * SH_ROW_F4 : 0);
+    if (a.stage_sh | a.stage_shp) {
+        const size_t g0 = (size_t)blockIdx.x * PRE_BLOCK + (size_t)wave * 64;
+        if (a.stage_sh) wave_rows_to_lds<SH_ROW_F4>(sh_l, reinterpret_cast<const float4*>(a.io.shs), g0, (size_t)P, lane);
+        if (a.stage_shp) wave_rows_to_lds<SHP_ROW_F4>(shp_l, reinterpret_cast<const float4*>(a.io.shs_p), g0, (size_t)P, lane);
+        __syncthreads();
+    }
     if (idx < P) {
         uint32_t tiles = 0;
         int radius = 0;
@@ -298,7 +371,13 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                     }
                     if (a.io.shs != nullptr) {
                         float res[3];
-                        sh_eval<3>(a.c.D, dx, dy, dz, a.io.shs + (size_t)idx * a.c.M * 3, res);
+                        if (a.stage_sh) {
+                            float v[4 * SH_ROW_F4];
+                            lds_row_load<SH_ROW_F4>(v, sh_l + lane * SH_ROW_F4);
+                            sh_eval<3>(a.c.D, dx, dy, dz, v, res);
+                        } else {
+                            sh_eval<3>(a.c.D, dx, dy, dz, a.io.shs + (size_t)idx * a.c.M * 3, res);
+                        }
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
                             res[c] += 0.5f;
@@ -325,11 +404,20 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                     }
                     if (a.io.shs_p != nullptr) {
                         float res[2];
-                        const float* sp = a.io.shs_p + (size_t)idx * a.c.M_p * 2;
-                        sh_eval<2>(a.c.D, dx, dy, dz, sp, res);
+                        float sp0;
+                        if (a.stage_shp) {
+                            float v[4 * SHP_ROW_F4];
+                            lds_row_load<SHP_ROW_F4>(v, shp_l + lane * SHP_ROW_F4);
+                            sh_eval<2>(a.c.D, dx, dy, dz, v, res);
+                            sp0 = v[0];
+                        } else {
+                            const float* sp = a.io.shs_p + (size_t)idx * a.c.M_p * 2;
+                            sh_eval<2>(a.c.D, dx, dy, dz, sp, res);
+                            sp0 = sp[0];
+                        }
                         res[0] += 0.5f;
                         res[1] += 0.5f;
-                        res[0] = res[0] - 0.5f - SH_C0 * sp[0];
+                        res[0] = res[0] - 0.5f - SH_C0 * sp0;
                         if (res[1] < 0) {
                             clamp_bits |= 8u;
                             res[1] = 0.0f;
@@ -377,14 +465,25 @@ struct PreBwdArgs {
     gft_backward_io io;
     GeomView g;
     float focal_x, focal_y, dist2phase;
+    int stage_sh, stage_shp;
 };
 
-__global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
 {
-    const int idx = blockIdx.x * GFT_BLOCK + threadIdx.x;
+    extern __shared__ float4 lds_rows[];
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const int P = a.c.P;
     const int M = a.c.M, M_p = a.c.M_p;
     float sum_phase = 0.f, sum_dc = 0.f;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4* sh_l = lds_rows + wave * ((a.stage_sh ? 64 * SH_ROW_F4 : 0) + (a.stage_shp ? 64 * SHP_ROW_F4 : 0));
+    float4* shp_l = sh_l + (a.stage_sh ? 64 * SH_ROW_F4 : 0);
+    const size_t g0 = (size_t)blockIdx.x * PRE_BLOCK + (size_t)wave * 64;
+    if (a.stage_sh | a.stage_shp) {
+        if (a.stage_sh) wave_rows_to_lds<SH_ROW_F4>(sh_l, reinterpret_cast<const float4*>(a.io.shs), g0, (size_t)P, lane);
+        if (a.stage_shp) wave_rows_to_lds<SHP_ROW_F4>(shp_l, reinterpret_cast<const float4*>(a.io.shs_p), g0, (size_t)P, lane);
+        __syncthreads();
+    }
 
     if (idx < P) {
         const bool visible = a.io.radii[idx] > 0;
@@ -395,8 +494,8 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
         float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float dscale[3] = {0.f, 0.f, 0.f};
         float drot[4] = {0.f, 0.f, 0.f, 0.f};
-        float* dsh = a.io.shs ? a.io.dL_dsh + (size_t)idx * M * 3 : nullptr;
-        float* dsh_p = a.io.shs_p ? a.io.dL_dsh_p + (size_t)idx * M_p * 2 : nullptr;
+        float* dsh = (a.io.shs && !a.stage_sh) ? a.io.dL_dsh + (size_t)idx * M * 3 : nullptr;
+        float* dsh_p = (a.io.shs_p && !a.stage_shp) ? a.io.dL_dsh_p + (size_t)idx * M_p * 2 : nullptr;
 
         if (visible) {
             // accumulators written by the render backward
@@ -496,7 +595,14 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
                 float dres[3], ddir[3], dm[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) dres[c] = dcolor[c] * (((clamp_bits >> c) & 1u) ? 0.f : 1.f);
-                sh_backward<3>(a.c.D, M, dx, dy, dz, a.io.shs + (size_t)idx * M * 3, dres, dsh, ddir);
+                if (a.stage_sh) {
+                    float v[4 * SH_ROW_F4];
+                    lds_row_load<SH_ROW_F4>(v, sh_l + lane * SH_ROW_F4);
+                    sh_backward<3>(a.c.D, M, dx, dy, dz, v, dres, v, ddir);     // in place
+                    lds_row_store<SH_ROW_F4>(sh_l + lane * SH_ROW_F4, v);
+                } else {
+                    sh_backward<3>(a.c.D, M, dx, dy, dz, a.io.shs + (size_t)idx * M * 3, dres, dsh, ddir);
+                }
                 dnorm_dv(dox, doy, doz, ddir, dm);
                 dmean[0] += dm[0]; dmean[1] += dm[1]; dmean[2] += dm[2];
             }
@@ -529,7 +635,14 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
                 float dres[2], ddir[3], dm[3];
                 dres[0] = dCW[0];
                 dres[1] = dCW[1] * ((clamp_bits & 8u) ? 0.f : 1.f);
-                sh_backward<2>(a.c.D, M_p, dx, dy, dz, a.io.shs_p + (size_t)idx * M_p * 2, dres, dsh_p, ddir);
+                if (a.stage_shp) {
+                    float v[4 * SHP_ROW_F4];
+                    lds_row_load<SHP_ROW_F4>(v, shp_l + lane * SHP_ROW_F4);
+                    sh_backward<2>(a.c.D, M_p, dx, dy, dz, v, dres, v, ddir);   // in place
+                    lds_row_store<SHP_ROW_F4>(shp_l + lane * SHP_ROW_F4, v);
+                } else {
+                    sh_backward<2>(a.c.D, M_p, dx, dy, dz, a.io.shs_p + (size_t)idx * M_p * 2, dres, dsh_p, ddir);
+                }
                 dnorm_dv(dox, doy, doz, ddir, dm);
                 dmean[0] += dm[0]; dmean[1] += dm[1]; dmean[2] += dm[2];
             }
@@ -585,6 +698,14 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
             // culled: every returned gradient row is zero
             if (dsh) for (int k = 0; k < M * 3; k++) dsh[k] = 0.f;
             if (dsh_p) for (int k = 0; k < M_p * 2; k++) dsh_p[k] = 0.f;
+            if (a.stage_sh) {
+#pragma unroll
+                for (int q = 0; q < SH_ROW_F4; q++) sh_l[lane * SH_ROW_F4 + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (a.stage_shp) {
+#pragma unroll
+                for (int q = 0; q < SHP_ROW_F4; q++) shp_l[lane * SHP_ROW_F4 + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
 
         a.io.dL_dmeans3D[3 * idx] = dmean[0];
@@ -611,20 +732,49 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
         }
     }
 
-    // phase/dc offset gradients: one atomic per workgroup instead of one per Gaussian
-    __shared__ float wsum[2][GFT_BLOCK / 64];
+    // SH gradient rows leave through LDS as coalesced 16-byte stores
+    if (a.stage_sh | a.stage_shp) {
+        __syncthreads();
+        if (a.stage_sh) wave_rows_from_lds<SH_ROW_F4>(reinterpret_cast<float4*>(a.io.dL_dsh), sh_l, g0, (size_t)P, lane);
+        if (a.stage_shp) wave_rows_from_lds<SHP_ROW_F4>(reinterpret_cast<float4*>(a.io.dL_dsh_p), shp_l, g0, (size_t)P, lane);
+    }
+
+    // phase/dc offset gradients (the reference issues two same-address atomics per Gaussian,
+    // backward.cu:556-567): wave sum -> the two pad columns of the accumulator row of the
+    // workgroup's first Gaussian -> fixed-order reduction in k_offset_reduce (deterministic).
+    // (partials live in the tail of the acc scratch, two floats per workgroup)
     const float sp = gft_wave_sum_to_lane63(sum_phase);
     const float sd = gft_wave_sum_to_lane63(sum_dc);
-    if ((threadIdx.x & 63) == 63) {
-        wsum[0][threadIdx.x >> 6] = sp;
-        wsum[1][threadIdx.x >> 6] = sd;
+    if (threadIdx.x == PRE_BLOCK - 1 && a.io.shs_p != nullptr) {
+        float* part = a.io.acc + (size_t)P * GFT_ACC_STRIDE + 2 * (size_t)blockIdx.x;
+        part[0] = sp;
+        part[1] = sd;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_offset_reduce(int nblocks, const float2* __restrict__ part,
+                                                        float* __restrict__ out_phase, float* __restrict__ out_dc)
+{
+    __shared__ float s0[1024], s1[1024];
+    float p = 0.f, d = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 1024) {
+        const float2 v = part[i];
+        p += v.x;
+        d += v.y;
+    }
+    s0[threadIdx.x] = p;
+    s1[threadIdx.x] = d;
     __syncthreads();
-    if (threadIdx.x == 0 && a.io.shs_p != nullptr) {
-        const float tp = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
-        const float td = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
-        if (tp != 0.f) atomicAdd(a.io.dL_dphase_offset, tp);
-        if (td != 0.f) atomicAdd(a.io.dL_ddc_offset, td);
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s0[threadIdx.x] += s0[threadIdx.x + w];
+            s1[threadIdx.x] += s1[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *out_phase = s0[0];
+        *out_dc = s1[0];
     }
 }
 
@@ -653,8 +803,19 @@ hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const g
     a.dist2phase = 4.0f * 3.14159265358979323846f / c.depth_range;
     a.gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X;
     a.gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
-    const int blocks = (c.P + GFT_BLOCK - 1) / GFT_BLOCK;
-    hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(GFT_BLOCK), 0, s, a);
+    a.stage_sh = (io.shs != nullptr && c.M == 16) ? 1 : 0;
+    a.stage_shp = (io.shs_p != nullptr && c.M_p == 16) ? 1 : 0;
+    const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_F4 : 0) + (a.stage_shp ? SHP_ROW_F4 : 0));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess_fwd),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 16 * (SH_ROW_F4 + SHP_ROW_F4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess_bwd),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 16 * (SH_ROW_F4 + SHP_ROW_F4));
+        attr_set = true;
+    }
+    const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;
+    hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
     return hipGetLastError();
 }
 
@@ -667,8 +828,14 @@ hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const g
     a.focal_y = c.H / (2.0f * c.tanfovy);
     a.focal_x = c.W / (2.0f * c.tanfovx);
     a.dist2phase = 4.0f * 3.14159265358979323846f / c.depth_range;
-    const int blocks = (c.P + GFT_BLOCK - 1) / GFT_BLOCK;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(GFT_BLOCK), 0, s, a);
+    a.stage_sh = (io.shs != nullptr && c.M == 16) ? 1 : 0;
+    a.stage_shp = (io.shs_p != nullptr && c.M_p == 16) ? 1 : 0;
+    const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_F4 : 0) + (a.stage_shp ? SHP_ROW_F4 : 0));
+    const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
+    if (io.shs_p != nullptr)
+        hipLaunchKernelGGL(k_offset_reduce, dim3(1), dim3(1024), 0, s, blocks,
+                           reinterpret_cast<const float2*>(io.acc + (size_t)c.P * GFT_ACC_STRIDE), io.dL_dphase_offset, io.dL_ddc_offset);
     return hipGetLastError();
 }
 

@@ -128,7 +128,8 @@ typedef struct gft_backward_io {
     const void* geom;
     const void* img;
     const void* binning;
-    /* backward scratch: [P, GFT_ACC_STRIDE] floats, zeroed by the library */
+    /* backward scratch of gft_acc_bytes(P) bytes: [P, GFT_ACC_STRIDE] floats (zeroed by the
+     * library) followed by two partial sums per 64-Gaussian block */
     float* acc;
     /* outputs, written in full (zeros for culled Gaussians); NULL = not wanted */
     float* dL_dmeans3D;     /* [P,3] */
@@ -184,6 +185,7 @@ const char* gft_last_error(void);   /* host string, thread local */
 size_t gft_geom_bytes(int32_t P);
 size_t gft_image_bytes(int32_t W, int32_t H);
 size_t gft_binning_bytes(int64_t R, int32_t W, int32_t H);
+size_t gft_acc_bytes(int32_t P);
 int gft_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* out /*host*/);
 
 /* Stage 1 of the forward: preprocess (reference K1) + inclusive scan, then one
