@@ -27,8 +27,9 @@ def hipcc():
 
 
 def flags():
+    extra = os.environ.get("GFT_EXTRA_FLAGS", "").split()   # tuning experiments only
     return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"] + extra
 
 
 def _stale(target, deps):

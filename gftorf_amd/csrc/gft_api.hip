@@ -46,7 +46,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     o = 0;
     L->img_pix_state = o;   o = align_up(o + n * 16);
     L->img_ranges = o;      o = align_up(o + T * 8);
-    L->img_tile_max = o;    o = align_up(o + T * 4);
+    L->img_tile_max = o;    o = align_up(o + T * 4 * 4);   // one entry per 8x8 quadrant
     L->img_tile_cnt = o;    o = align_up(o + T * 4);
     L->img_tile_cursor = o; o = align_up(o + T * 4);
     L->img_total = o;

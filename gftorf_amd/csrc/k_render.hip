@@ -1,40 +1,41 @@
 // k_render.hip -- per-tile alpha blending, forward and backward (gfx950, wave64).
 //
-// One 256-thread workgroup (4 waves) per 16x16 tile; each wave owns an 8x8 pixel
-// quadrant so that a splat's footprint is wave-coherent.  The tile's depth-sorted
-// splat list is staged through LDS in batches of 256 packed records (80 B per
-// splat: rec_a 32 B + rec_b 48 B, gathered with 16-byte loads).  While staging,
-// every splat's alpha >= 1/255 ellipse is bounded by a box and tested against the
-// four quadrants; the four ballots per staging wave give each wave a 256-bit mask
-// of the splats that can reach it, walked with scalar bit scans, so a wave only
-// touches splats that may contribute to its quadrant and reads their records as
-// LDS broadcasts.
+// Work unit = one wavefront = one 8x8 pixel quadrant of a 16x16 tile (64-thread
+// workgroups, 4 per tile).  A quadrant walks its tile's depth-sorted splat list on its
+// own: no workgroup barriers, it stops as soon as ITS 64 pixels are saturated, and the
+// backward starts at ITS deepest contributor.  The four quadrants of a tile get
+// consecutive unit ids inside one XCD's run of units, so their (identical) list reads
+// hit the same L2.
+//
+// The list is staged through LDS in batches of 64 packed records (80 B per splat:
+// rec_a 32 B + rec_b 48 B, gathered with 16-byte loads, one splat per lane).  While
+// staging, the splat's alpha >= 1/255 ellipse is bounded by a box and tested against the
+// quadrant; one ballot gives the 64-bit mask of splats that can reach it, walked with
+// scalar bit scans, and their records are read back as LDS broadcasts.
 //
 // forward  (reference K6, RAST/cuda_rasterizer/forward.cu:424-676): front-to-back
 //   blend of colour(3, w = a*T), ToF phasor(7, w = a*T^2), distance, accumulation,
-//   depth distortion and the first-hit triple.  The per-Gaussian `pixels` counter
-//   is reduced wave -> LDS -> one global atomic per (tile, splat) instead of one
-//   per (pixel, splat).
-// backward (reference K7, backward.cu:609-889): back-to-front, starting at the
-//   tile's deepest contributor (stored by the forward) instead of the list end.
-//   The 18 per-(pixel, splat) float atomics of the reference become: a
-//   v_permlane32_swap / v_permlane16_swap / DPP reduction tree (18 values -> 5
-//   registers), 5 ds_add_f32 into a per-batch LDS table, and one coalesced global
-//   atomic burst per (tile, splat).
+//   depth distortion and the first-hit triple.  The per-Gaussian `pixels` counter is a
+//   wave popcount -> LDS -> one global atomic per (quadrant, splat).
+// backward (reference K7, backward.cu:609-889): back-to-front.  The 18 per-(pixel,
+//   splat) float atomics of the reference become a v_permlane32_swap /
+//   v_permlane16_swap / DPP reduction tree (18 values -> 5 registers), 5 plain LDS
+//   stores (each splat is visited once per batch by its only wave), and one 72-byte
+//   global atomic burst per (quadrant, splat) that received a contribution.
 #include "gft_internal.h"
 
 namespace {
 
-#define GFT_BATCH 256
+#define RB 64                // splats per staged batch = lanes per wave
 #define ACC_LDS_STRIDE 20
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ int tile_of_block(int b, int T)
+// unit v = 4*tile + quadrant; workgroups are dealt round-robin over the 8 XCDs, so give
+// every XCD one contiguous run of units
+__device__ __forceinline__ int unit_of_block(int b, int V)
 {
-    // blocks are dealt round-robin over the 8 XCDs: give every XCD one contiguous
-    // run of tiles so neighbouring tiles (which share splats) share an L2
-    const int chunk = (T + 7) >> 3;
+    const int chunk = (V + 7) >> 3;
     return (b & 7) * chunk + (b >> 3);
 }
 
@@ -42,17 +43,17 @@ __device__ __forceinline__ int tile_of_block(int b, int T)
 // can pass the 1/255 alpha threshold; forward and backward use the same function.
 __device__ __forceinline__ float gft_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
-__device__ __forceinline__ uint64_t uniform_mask(const uint64_t* p)
+__device__ __forceinline__ uint64_t to_sgpr(unsigned long long m)
 {
-    const uint2 v = *reinterpret_cast<const uint2*>(p);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane(v.x), hi = __builtin_amdgcn_readfirstlane(v.y);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)m), hi = __builtin_amdgcn_readfirstlane((uint32_t)(m >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
 
-// Stage splat `id` into LDS slot `slot` and return its quadrant-reach bits.
-__device__ __forceinline__ uint32_t stage_splat(uint32_t id, int slot, const float4* __restrict__ rec_a,
-                                                const float4* __restrict__ rec_b, float4* sA, float4* sB,
-                                                float tile_x0, float tile_y0)
+// Stage splat `id` into LDS slot `slot`; returns whether it can reach the quadrant whose
+// first pixel is (qx0, qy0).
+__device__ __forceinline__ bool stage_splat(uint32_t id, int slot, const float4* __restrict__ rec_a,
+                                            const float4* __restrict__ rec_b, float4* sA, float4* sB,
+                                            float qx0, float qy0)
 {
     const float4 a0 = rec_a[2 * id], a1 = rec_a[2 * id + 1];
     sA[2 * slot] = a0;
@@ -66,33 +67,14 @@ __device__ __forceinline__ uint32_t stage_splat(uint32_t id, int slot, const flo
     const float ca = a0.z, cb = a0.w, cc = a1.x, op = a1.y;
     const float det = ca * cc - cb * cb;
     const float tau = __logf(255.0f * op);
-    uint32_t bits = 0xfu;
-    if (!(tau > 0.0f)) {
-        bits = 0;                       // opacity <= 1/255: can never pass the alpha test
-    } else if (det > 0.0f && ca > 0.0f && cc > 0.0f) {
-        const float inv = 2.0f * tau / det;
-        const float ex = sqrtf(inv * cc) * 1.0005f + 0.02f;   // margins keep the box conservative
-        const float ey = sqrtf(inv * ca) * 1.0005f + 0.02f;
-        const float lx = a0.x - ex - tile_x0, hx = a0.x + ex - tile_x0;
-        const float ly = a0.y - ey - tile_y0, hy = a0.y + ey - tile_y0;
-        const bool x_lo = hx >= 0.0f && lx <= 7.0f, x_hi = hx >= 8.0f && lx <= 15.0f;
-        const bool y_lo = hy >= 0.0f && ly <= 7.0f, y_hi = hy >= 8.0f && ly <= 15.0f;
-        bits = (x_lo && y_lo ? 1u : 0u) | (x_hi && y_lo ? 2u : 0u) | (x_lo && y_hi ? 4u : 0u) | (x_hi && y_hi ? 8u : 0u);
-    }
-    return bits;
-}
-
-// masks[q*4 + w] = ballot over staging wave w of "splat reaches quadrant q"
-__device__ __forceinline__ void publish_masks(uint32_t bits, int wave, int lane, uint64_t* sMask)
-{
-    const unsigned long long m0 = __ballot(bits & 1u), m1 = __ballot(bits & 2u);
-    const unsigned long long m2 = __ballot(bits & 4u), m3 = __ballot(bits & 8u);
-    if (lane == 0) {
-        sMask[0 * 4 + wave] = m0;
-        sMask[1 * 4 + wave] = m1;
-        sMask[2 * 4 + wave] = m2;
-        sMask[3 * 4 + wave] = m3;
-    }
+    if (!(tau > 0.0f)) return false;            // opacity <= 1/255: can never pass the alpha test
+    if (!(det > 0.0f && ca > 0.0f && cc > 0.0f)) return true;   // degenerate conic: let the pixel test decide
+    const float inv = 2.0f * tau / det;
+    const float ex = sqrtf(inv * cc) * 1.0005f + 0.02f;        // margins keep the box conservative
+    const float ey = sqrtf(inv * ca) * 1.0005f + 0.02f;
+    const float lx = a0.x - ex - qx0, hx = a0.x + ex - qx0;
+    const float ly = a0.y - ey - qy0, hy = a0.y + ey - qy0;
+    return hx >= 0.0f && lx <= 7.0f && hy >= 0.0f && ly <= 7.0f;
 }
 
 struct RenderFwdArgs {
@@ -104,34 +86,31 @@ struct RenderFwdArgs {
     const float* __restrict__ bg;
     int64_t bsc, bsy, bsx;
     float4* __restrict__ pix_state;
-    uint32_t* __restrict__ tile_max;
+    uint32_t* __restrict__ quad_max;
     float* out_color; float* out_phasor; float* out_depth; float* out_normal; float* out_acc;
     float* out_entropy; float* out_dd; float* out_ad; float* out_distribution;
     float* pixels;
 };
 
-__global__ __launch_bounds__(GFT_BLOCK) void k_render_fwd(RenderFwdArgs a)
+__global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
 {
-    __shared__ float4 sA[GFT_BATCH * 2];
-    __shared__ float4 sB[GFT_BATCH * 3];
-    __shared__ uint32_t sId[GFT_BATCH];
-    __shared__ uint32_t sCnt[GFT_BATCH];
-    __shared__ uint64_t sMask[16];
-    __shared__ uint32_t sMax;
+    __shared__ float4 sA[RB * 2];
+    __shared__ float4 sB[RB * 3];
+    __shared__ uint32_t sId[RB];
+    __shared__ uint32_t sCnt[RB];
 
-    const int tile = tile_of_block(blockIdx.x, a.T);
-    if (tile >= a.T) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int V = a.T * 4;
+    const int v = unit_of_block(blockIdx.x, V);
+    if (v >= V) return;
+    const int tile = v >> 2, quad = v & 3;
+    const int lane = threadIdx.x;
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const int px = tx * GFT_TILE_X + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * GFT_TILE_Y + (wave >> 1) * 8 + (lane >> 3);
+    const int qx0 = tx * GFT_TILE_X + (quad & 1) * 8, qy0 = ty * GFT_TILE_Y + (quad >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float tile_x0 = (float)(tx * GFT_TILE_X), tile_y0 = (float)(ty * GFT_TILE_Y);
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
-    const int rounds = (total + GFT_BATCH - 1) / GFT_BATCH;
-    if (tid == 0) sMax = 0;
 
     bool done = !inside;
     float T = 1.0f;
@@ -142,74 +121,67 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_render_fwd(RenderFwdArgs a)
     float WD0 = 0, WD1 = 0, WD2 = 0;
     bool first = true;
 
-    int todo = total;
-    for (int i = 0; i < rounds; i++, todo -= GFT_BATCH) {
-        // all pixels of the tile finished -> the rest of the list is never used
-        if (__syncthreads_and(done)) break;
-        const int n = min(GFT_BATCH, todo);
-        uint32_t bits = 0;
-        if (tid < n) {
-            const uint32_t id = a.point_list[range.x + i * GFT_BATCH + tid];
-            sId[tid] = id;
-            sCnt[tid] = 0;
-            bits = stage_splat(id, tid, a.rec_a, a.rec_b, sA, sB, tile_x0, tile_y0);
+    for (int base = 0; base < total; base += RB) {
+        // all 64 pixels finished -> the rest of the list is never used
+        if (__ballot(!done) == 0ull) break;
+        const int n = min(RB, total - base);
+        bool reach = false;
+        __syncthreads();                         // previous batch's count flush has read LDS
+        if (lane < n) {
+            const uint32_t id = a.point_list[range.x + base + lane];
+            sId[lane] = id;
+            sCnt[lane] = 0;
+            reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, (float)qx0, (float)qy0);
         }
-        publish_masks(bits, wave, lane, sMask);
+        uint64_t m = to_sgpr(__ballot(reach));
         __syncthreads();
 
-        bool wave_live = __ballot(!done) != 0ull;
-        for (int s = 0; s < 4 && wave_live; s++) {
-            uint64_t m = uniform_mask(&sMask[wave * 4 + s]);
-            while (m) {
-                const int j = s * 64 + (int)__builtin_ctzll(m);
-                m &= m - 1;
-                bool contrib = false;
-                if (!done) {
-                    const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
-                    const float dx = a0.x - pxf, dy = a0.y - pyf;
-                    const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-                    const float alpha = fminf(0.99f, a1.y * gft_exp(power));
-                    if (!(power > 0.0f) && !(alpha < 1.0f / 255.0f)) {
-                        const float test_T = T * (1 - alpha);
-                        if (test_T < 0.0001f) {
-                            done = true;
-                        } else {
-                            contrib = true;
-                            const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
-                            const float w = alpha * T;
-                            const float w_p = alpha * T * T;
-                            C0 += b0.x * w; C1 += b0.y * w; C2 += b0.z * w;
-                            P0 += b0.w * w_p; P1 += b1.x * w_p; P2 += b1.y * w_p; P3 += b1.z * w_p;
-                            P4 += b1.w * w_p; P5 += b2.x * w_p; P6 += b2.y * w_p;
-                            const float dist = a1.w;
-                            Dd += dist * w;
-                            if (first) {
-                                WD0 = alpha; WD1 = dist; WD2 = b1.y;
-                                first = false;
-                            }
-                            const float z = a1.z;
-                            DD += w * (z * z * A - 2.0f * z * DD_D + DD_D2);
-                            DD_D += w * z;
-                            DD_D2 += w * z * z;
-                            A += alpha * T;
-                            T = test_T;
-                            last_contributor = (uint32_t)(i * GFT_BATCH + j + 1);
+        while (m) {
+            const int j = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            bool contrib = false;
+            if (!done) {
+                const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
+                const float dx = a0.x - pxf, dy = a0.y - pyf;
+                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+                const float alpha = fminf(0.99f, a1.y * gft_exp(power));
+                if (!(power > 0.0f) && !(alpha < 1.0f / 255.0f)) {
+                    const float test_T = T * (1 - alpha);
+                    if (test_T < 0.0001f) {
+                        done = true;
+                    } else {
+                        contrib = true;
+                        const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
+                        const float w = alpha * T;
+                        const float w_p = alpha * T * T;
+                        C0 += b0.x * w; C1 += b0.y * w; C2 += b0.z * w;
+                        P0 += b0.w * w_p; P1 += b1.x * w_p; P2 += b1.y * w_p; P3 += b1.z * w_p;
+                        P4 += b1.w * w_p; P5 += b2.x * w_p; P6 += b2.y * w_p;
+                        const float dist = a1.w;
+                        Dd += dist * w;
+                        if (first) {
+                            WD0 = alpha; WD1 = dist; WD2 = b1.y;
+                            first = false;
                         }
+                        const float z = a1.z;
+                        DD += w * (z * z * A - 2.0f * z * DD_D + DD_D2);
+                        DD_D += w * z;
+                        DD_D2 += w * z * z;
+                        A += alpha * T;
+                        T = test_T;
+                        last_contributor = (uint32_t)(base + j + 1);
                     }
                 }
-                // pixels[id] += 1 for every contributing pixel: wave popcount -> LDS
-                const unsigned long long cm = __ballot(contrib);
-                if (cm != 0ull && lane == 0) atomicAdd(&sCnt[j], (uint32_t)__popcll(cm));
-                if (__ballot(!done) == 0ull) {
-                    wave_live = false;
-                    break;
-                }
             }
+            // pixels[id] += 1 for every contributing pixel: wave popcount -> LDS
+            const unsigned long long cm = __ballot(contrib);
+            if (cm != 0ull && lane == 0) sCnt[j] = (uint32_t)__popcll(cm);
+            if (__ballot(!done) == 0ull) break;
         }
         __syncthreads();
-        if (tid < n) {
-            const uint32_t cnt = sCnt[tid];
-            if (cnt) atomicAdd(&a.pixels[sId[tid]], (float)cnt);
+        if (lane < n) {
+            const uint32_t cnt = sCnt[lane];
+            if (cnt) atomicAdd(&a.pixels[sId[lane]], (float)cnt);
         }
     }
 
@@ -242,10 +214,11 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_render_fwd(RenderFwdArgs a)
         a.out_entropy[pix] = 0.f;
         a.out_ad[pix] = 0.f;
     }
-    // deepest contributor of the tile: where the backward starts
-    if (last_contributor) atomicMax(&sMax, last_contributor);
-    __syncthreads();
-    if (tid == 0) a.tile_max[tile] = sMax;
+    // deepest contributor of the quadrant: where its backward starts
+    uint32_t mx = last_contributor;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (lane == 0) a.quad_max[v] = mx;
 }
 
 // ---------------------------------------------------------------------------
@@ -258,7 +231,7 @@ struct RenderBwdArgs {
     const float* __restrict__ bg;
     int64_t bsc, bsy, bsx;
     const float4* __restrict__ pix_state;
-    const uint32_t* __restrict__ tile_max;
+    const uint32_t* __restrict__ quad_max;
     const float* __restrict__ g_color; const float* __restrict__ g_phasor; const float* __restrict__ g_depth;
     const float* __restrict__ g_acc; const float* __restrict__ g_dd;
     float* acc;   // [P][GFT_ACC_STRIDE]
@@ -287,10 +260,10 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
     return v;
 }
 
-// Sum 18 per-lane values over the 64 lanes of the wave and add the 18 totals to
+// Sum 18 per-lane values over the 64 lanes of the wave and store the 18 totals to
 // row[0..17] in LDS.  Halving tree: 18 -> 9 registers (lane halves), 9 -> 5 (16-lane
 // rows), then a 4-step DPP scan inside each row; lanes 15/31/47/63 own the totals.
-__device__ __forceinline__ void wave_reduce18_add(const float* v, float* row, int lane)
+__device__ __forceinline__ void wave_reduce18_store(const float* v, float* row, int lane)
 {
     float s[9];
 #pragma unroll
@@ -305,31 +278,30 @@ __device__ __forceinline__ void wave_reduce18_add(const float* v, float* row, in
         const int r = lane >> 4;
         const int off = (r & 1) * 4 + (r >> 1) * 9;
 #pragma unroll
-        for (int i = 0; i < 4; i++) atomicAdd(&row[i + off], t[i]);
-        if (!(r & 1)) atomicAdd(&row[8 + (r >> 1) * 9], t[4]);
+        for (int i = 0; i < 4; i++) row[i + off] = t[i];
+        if (!(r & 1)) row[8 + (r >> 1) * 9] = t[4];
     }
 }
 
-__global__ __launch_bounds__(GFT_BLOCK) void k_render_bwd(RenderBwdArgs a)
+__global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
 {
-    __shared__ float4 sA[GFT_BATCH * 2];
-    __shared__ float4 sB[GFT_BATCH * 3];
-    __shared__ uint32_t sId[GFT_BATCH];
-    __shared__ float sAcc[GFT_BATCH * ACC_LDS_STRIDE];
-    __shared__ uint32_t sTouched[GFT_BATCH];
-    __shared__ uint64_t sMask[16];
+    __shared__ float4 sA[RB * 2];
+    __shared__ float4 sB[RB * 3];
+    __shared__ uint32_t sId[RB];
+    __shared__ float sAcc[RB * ACC_LDS_STRIDE];
 
-    const int tile = tile_of_block(blockIdx.x, a.T);
-    if (tile >= a.T) return;
-    const int tmax = (int)a.tile_max[tile];
+    const int V = a.T * 4;
+    const int v_unit = unit_of_block(blockIdx.x, V);
+    if (v_unit >= V) return;
+    const int tmax = (int)a.quad_max[v_unit];
     if (tmax == 0) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile = v_unit >> 2, quad = v_unit & 3;
+    const int lane = threadIdx.x;
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const int px = tx * GFT_TILE_X + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * GFT_TILE_Y + (wave >> 1) * 8 + (lane >> 3);
+    const int qx0 = tx * GFT_TILE_X + (quad & 1) * 8, qy0 = ty * GFT_TILE_Y + (quad >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float tile_x0 = (float)(tx * GFT_TILE_X), tile_y0 = (float)(ty * GFT_TILE_Y);
     const uint32_t r0 = a.ranges[tile].x;
     const size_t HW = (size_t)a.H * a.W;
     const size_t pix = inside ? (size_t)a.W * py + px : 0;
@@ -360,141 +332,107 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_render_bwd(RenderBwdArgs a)
         bg_dot_p += b4 * gp4; bg_dot_p += b5 * gp5; bg_dot_p += b6 * gp6;
     }
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
-    const float one_m_Tf = 1 - T_final;
+    // depth-distortion weight gradient dL_dw(z) = gdd*(z^2 (1-Tf) - 2 z wz + wz2) = (A2 z + B2) z + C2
+    const float A2 = gdd * (1 - T_final), B2 = -2.0f * gdd * wz_tot, C2 = gdd * wz2_tot;
+    const float bg_sum = bg_dot + bg_dot_p;
 
+    // Back-to-front recurrences.  The reference keeps one "accumulated behind" value per
+    // channel (accum_rec[3], accum_rec_p[7], _d, _a, _dd; backward.cu:776-833); only their
+    // gradient-weighted sums enter dL_dalpha and all channels of a group share one linear
+    // recurrence, so two scalars per group are enough:
+    //   S1 <- la*L1 + (1-la)  *S1,  L1 = sum_k c_k g_k + dist*g_d + g_a + dL_dw   (colour, dist, acc, dd)
+    //   Sp <- la*Lp + (1-la)^2*Sp,  Lp = sum_k p_k gp_k                           (ToF phasor)
     float T = T_final;
-    float ar0 = 0, ar1 = 0, ar2 = 0;                                    // accum_rec colour
-    float ap0 = 0, ap1 = 0, ap2 = 0, ap3 = 0, ap4 = 0, ap5 = 0, ap6 = 0;  // accum_rec phasor
-    float ar_d = 0, ar_a = 0, ar_dd = 0;
-    float last_alpha = 0;
-    float lc0 = 0, lc1 = 0, lc2 = 0, lp0 = 0, lp1 = 0, lp2 = 0, lp3 = 0, lp4 = 0, lp5 = 0, lp6 = 0;
-    float last_dist = 0, last_dL_dw = 0;
+    float S1 = 0.f, L1 = 0.f, Sp = 0.f, Lp = 0.f, last_alpha = 0.f;
 
-    const int rounds = (tmax + GFT_BATCH - 1) / GFT_BATCH;
-    for (int i = 0; i < rounds; i++) {
-        const int hi = tmax - i * GFT_BATCH;       // list indices [hi-n, hi) in descending order
-        const int n = min(GFT_BATCH, hi);
+    for (int hi = tmax; hi > 0; hi -= RB) {        // list indices [hi-n, hi), descending
+        const int n = min(RB, hi);
+        bool reach = false;
         __syncthreads();                           // previous batch's flush has read LDS
-        uint32_t bits = 0;
-        if (tid < n) {
-            const uint32_t id = a.point_list[r0 + (uint32_t)(hi - 1 - tid)];
-            sId[tid] = id;
-            sTouched[tid] = 0;
-            bits = stage_splat(id, tid, a.rec_a, a.rec_b, sA, sB, tile_x0, tile_y0);
+        if (lane < n) {
+            const uint32_t id = a.point_list[r0 + (uint32_t)(hi - 1 - lane)];
+            sId[lane] = id;
+            reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, (float)qx0, (float)qy0);
         }
-        publish_masks(bits, wave, lane, sMask);
-        {
-            float4* z = reinterpret_cast<float4*>(sAcc) + tid * (ACC_LDS_STRIDE / 4);
-#pragma unroll
-            for (int k = 0; k < ACC_LDS_STRIDE / 4; k++) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        uint64_t m = to_sgpr(__ballot(reach));
+        uint64_t touched = 0;
         __syncthreads();
 
-        for (int s = 0; s < 4; s++) {
-            uint64_t m = uniform_mask(&sMask[wave * 4 + s]);
-            while (m) {
-                const int j = s * 64 + (int)__builtin_ctzll(m);
-                m &= m - 1;
-                const int c = hi - 1 - j;               // list position of this splat
-                const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
-                const float dx = a0.x - pxf, dy = a0.y - pyf;
-                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-                const float G = gft_exp(power);
-                const float alpha = fminf(0.99f, a1.y * G);
-                const bool contrib = (c < n_contrib) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (__ballot(contrib) == 0ull) continue;   // wave-uniform skip
+        while (m) {
+            const int j = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            const int c = hi - 1 - j;               // list position of this splat
+            const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
+            const float dx = a0.x - pxf, dy = a0.y - pyf;
+            const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+            const float G = gft_exp(power);
+            const float alpha = fminf(0.99f, a1.y * G);
+            const bool contrib = (c < n_contrib) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (__ballot(contrib) == 0ull) continue;   // wave-uniform skip
 
-                float v[GFT_NUM_ACC];
+            float v[GFT_NUM_ACC];
 #pragma unroll
-                for (int k = 0; k < GFT_NUM_ACC; k++) v[k] = 0.f;
-                if (contrib) {
-                    const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
-                    const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                    T = T * rcp_1ma;
-                    const float wc = alpha * T;          // dchannel_dcolor == dchannel_ddepth
-                    const float wp = wc * T;             // dchannel_dphasor = alpha*T*T
-                    const float one_m_la = 1.f - last_alpha;
-                    float dL_dalpha = 0.f;
+            for (int k = 0; k < GFT_NUM_ACC; k++) v[k] = 0.f;
+            if (contrib) {
+                const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
+                const float one_m_a = 1.f - alpha;
+                const float rcp_1ma = __builtin_amdgcn_rcpf(one_m_a);
+                T = T * rcp_1ma;
+                const float wc = alpha * T;          // dchannel_dcolor == dchannel_ddepth
+                const float wp = wc * T;             // dchannel_dphasor = alpha*T*T
+                const float one_m_la = 1.f - last_alpha;
+                const float dist = a1.w, z = a1.z;
+                const float t2 = fmaf(A2, z, B2);    // A2 z + B2
+                const float dL_dw = fmaf(t2, z, C2);
 
-                    // colour
-                    float dac = 0.f;
-                    ar0 = last_alpha * lc0 + one_m_la * ar0; lc0 = b0.x; dac += (b0.x - ar0) * gc0; v[6] = wc * gc0;
-                    ar1 = last_alpha * lc1 + one_m_la * ar1; lc1 = b0.y; dac += (b0.y - ar1) * gc1; v[7] = wc * gc1;
-                    ar2 = last_alpha * lc2 + one_m_la * ar2; lc2 = b0.z; dac += (b0.z - ar2) * gc2; v[8] = wc * gc2;
-                    dac *= T;
+                float D1 = b0.x * gc0;
+                D1 = fmaf(b0.y, gc1, D1); D1 = fmaf(b0.z, gc2, D1); D1 = fmaf(dist, gd, D1);
+                D1 += ga + dL_dw;
+                S1 = fmaf(last_alpha, L1, one_m_la * S1);
+                L1 = D1;
 
-                    // ToF phasor (weight alpha*T^2)
-                    float dap = 0.f;
-                    const float one_m_la2 = one_m_la * one_m_la;
-                    const float two_1ma = 2.f * (1.f - alpha);
-                    ap0 = last_alpha * lp0 + one_m_la2 * ap0; lp0 = b0.w; dap += (b0.w - two_1ma * ap0) * gp0; v[9] = wp * gp0;
-                    ap1 = last_alpha * lp1 + one_m_la2 * ap1; lp1 = b1.x; dap += (b1.x - two_1ma * ap1) * gp1; v[10] = wp * gp1;
-                    ap2 = last_alpha * lp2 + one_m_la2 * ap2; lp2 = b1.y; dap += (b1.y - two_1ma * ap2) * gp2; v[11] = wp * gp2;
-                    ap3 = last_alpha * lp3 + one_m_la2 * ap3; lp3 = b1.z; dap += (b1.z - two_1ma * ap3) * gp3; v[12] = wp * gp3;
-                    ap4 = last_alpha * lp4 + one_m_la2 * ap4; lp4 = b1.w; dap += (b1.w - two_1ma * ap4) * gp4; v[13] = wp * gp4;
-                    ap5 = last_alpha * lp5 + one_m_la2 * ap5; lp5 = b2.x; dap += (b2.x - two_1ma * ap5) * gp5; v[14] = wp * gp5;
-                    ap6 = last_alpha * lp6 + one_m_la2 * ap6; lp6 = b2.y; dap += (b2.y - two_1ma * ap6) * gp6; v[15] = wp * gp6;
-                    dap *= T * T;
+                float Dp = b0.w * gp0;
+                Dp = fmaf(b1.x, gp1, Dp); Dp = fmaf(b1.y, gp2, Dp); Dp = fmaf(b1.z, gp3, Dp);
+                Dp = fmaf(b1.w, gp4, Dp); Dp = fmaf(b2.x, gp5, Dp); Dp = fmaf(b2.y, gp6, Dp);
+                Sp = fmaf(last_alpha, Lp, one_m_la * one_m_la * Sp);
+                Lp = Dp;
+                last_alpha = alpha;
 
-                    // distance
-                    const float dist = a1.w;
-                    ar_d = last_alpha * last_dist + one_m_la * ar_d;
-                    last_dist = dist;
-                    float dad = (dist - ar_d) * gd;
-                    v[16] = wc * gd;
-                    dad *= T;
+                // alpha also scales what is left for the background (reference :850-858)
+                const float bgf = -T_final * rcp_1ma;
+                const float dL_dalpha = fmaf(D1 - S1, T, fmaf(fmaf(-2.f * one_m_a, Sp, Dp), T * T, bgf * bg_sum));
 
-                    // accumulation
-                    ar_a = last_alpha + one_m_la * ar_a;
-                    float daa = (1.f - ar_a) * ga;
-                    daa *= T;
+                v[6] = wc * gc0; v[7] = wc * gc1; v[8] = wc * gc2;
+                v[9] = wp * gp0; v[10] = wp * gp1; v[11] = wp * gp2; v[12] = wp * gp3;
+                v[13] = wp * gp4; v[14] = wp * gp5; v[15] = wp * gp6;
+                v[16] = wc * gd;
+                v[17] = wc * (t2 + A2 * z);           // gdd*2*alpha*T*(z(1-Tf) - wz)
 
-                    // depth distortion
-                    const float z = a1.z;
-                    const float dL_dw = gdd * (z * z * one_m_Tf - 2.0f * z * wz_tot + wz2_tot);
-                    ar_dd = last_alpha * last_dL_dw + one_m_la * ar_dd;
-                    last_dL_dw = dL_dw;
-                    float dadd = dL_dw - ar_dd;
-                    v[17] = gdd * 2.0f * wc * (z * one_m_Tf - wz_tot);
-                    dadd *= T;
-
-                    last_alpha = alpha;
-
-                    const float bgf = -T_final * rcp_1ma;
-                    dL_dalpha += bgf * bg_dot;
-                    dap += bgf * bg_dot_p;
-                    dL_dalpha += dac;
-                    dL_dalpha += dap;
-                    dL_dalpha += dad;
-                    dL_dalpha += daa;
-                    dL_dalpha += dadd;
-
-                    const float dL_dG = a1.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * a0.z - gdy * a0.w;
-                    const float dG_ddely = -gdy * a1.x - gdx * a0.w;
-                    v[0] = dL_dG * dG_ddelx * ddelx_dx;
-                    v[1] = dL_dG * dG_ddely * ddely_dy;
-                    v[2] = -0.5f * gdx * dx * dL_dG;
-                    v[3] = -0.5f * gdx * dy * dL_dG;
-                    v[4] = -0.5f * gdy * dy * dL_dG;
-                    v[5] = G * dL_dalpha;
-                }
-                // 64 pixels -> one partial per value, accumulated in the batch's LDS table
-                wave_reduce18_add(v, &sAcc[j * ACC_LDS_STRIDE], lane);
-                if (lane == 0) sTouched[j] = 1;
+                const float dL_dG = a1.y * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * a0.z - gdy * a0.w;
+                const float dG_ddely = -gdy * a1.x - gdx * a0.w;
+                v[0] = dL_dG * dG_ddelx * ddelx_dx;
+                v[1] = dL_dG * dG_ddely * ddely_dy;
+                const float h = -0.5f * dL_dG;
+                v[2] = h * gdx * dx;
+                v[3] = h * gdx * dy;
+                v[4] = h * gdy * dy;
+                v[5] = G * dL_dalpha;
             }
+            // 64 pixels -> one partial per value, parked in the batch's LDS table
+            wave_reduce18_store(v, &sAcc[j * ACC_LDS_STRIDE], lane);
+            touched |= 1ull << j;
         }
         __syncthreads();
 
-        // flush: 32 lanes per splat row, 18 of them active -> contiguous 72-byte bursts
-        const int k = tid & 31;
-        if (k < GFT_NUM_ACC) {
-            for (int g = tid >> 5; g < n; g += GFT_BLOCK / 32) {
-                if (sTouched[g]) {
-                    const float val = sAcc[g * ACC_LDS_STRIDE + k];
-                    if (val != 0.f) atomicAdd(&a.acc[(size_t)sId[g] * GFT_ACC_STRIDE + k], val);
-                }
+        // flush: one 72-byte burst of float atomics per splat that received a contribution
+        while (touched) {
+            const int j = (int)__builtin_ctzll(touched);
+            touched &= touched - 1;
+            if (lane < GFT_NUM_ACC) {
+                const float val = sAcc[j * ACC_LDS_STRIDE + lane];
+                if (val != 0.f) atomicAdd(&a.acc[(size_t)sId[j] * GFT_ACC_STRIDE + lane], val);
             }
         }
     }
@@ -512,13 +450,13 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     a.T = a.gx * gy;
     a.ranges = im.ranges; a.point_list = b.point_list; a.rec_a = g.rec_a; a.rec_b = g.rec_b;
     a.bg = io.bg; a.bsc = c.bg_stride_c; a.bsy = c.bg_stride_y; a.bsx = c.bg_stride_x;
-    a.pix_state = im.pix_state; a.tile_max = im.tile_max;
+    a.pix_state = im.pix_state; a.quad_max = im.tile_max;
     a.out_color = io.out_color; a.out_phasor = io.out_phasor; a.out_depth = io.out_depth;
     a.out_normal = io.out_normal; a.out_acc = io.out_acc; a.out_entropy = io.out_entropy;
     a.out_dd = io.out_depth_distortion; a.out_ad = io.out_amp_distortion;
     a.out_distribution = io.out_distribution; a.pixels = io.pixels;
-    const int blocks = 8 * ((a.T + 7) / 8);
-    hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(GFT_BLOCK), 0, s, a);
+    const int blocks = 8 * ((a.T * 4 + 7) / 8);
+    hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
@@ -532,11 +470,11 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     a.T = a.gx * gy;
     a.ranges = im.ranges; a.point_list = b.point_list; a.rec_a = g.rec_a; a.rec_b = g.rec_b;
     a.bg = io.bg; a.bsc = c.bg_stride_c; a.bsy = c.bg_stride_y; a.bsx = c.bg_stride_x;
-    a.pix_state = im.pix_state; a.tile_max = im.tile_max;
+    a.pix_state = im.pix_state; a.quad_max = im.tile_max;
     a.g_color = io.dL_dout_color; a.g_phasor = io.dL_dout_phasor; a.g_depth = io.dL_dout_depth;
     a.g_acc = io.dL_dout_acc; a.g_dd = io.dL_dout_depth_distortion;
     a.acc = io.acc;
-    const int blocks = 8 * ((a.T + 7) / 8);
-    hipLaunchKernelGGL(k_render_bwd, dim3(blocks), dim3(GFT_BLOCK), 0, s, a);
+    const int blocks = 8 * ((a.T * 4 + 7) / 8);
+    hipLaunchKernelGGL(k_render_bwd, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }

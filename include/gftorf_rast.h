@@ -162,7 +162,7 @@ typedef struct gft_layout {
     /* img */
     size_t img_pix_state;     /* float[N][4]  {final_T, n_contrib(bits), w_z, w_z2} */
     size_t img_ranges;        /* uint32[T][2] [first,last) of the tile's list */
-    size_t img_tile_max;      /* uint32[T]    max n_contrib over the tile */
+    size_t img_tile_max;      /* uint32[T][4] max n_contrib over each 8x8 quadrant of the tile */
     size_t img_tile_cnt;      /* uint32[T]    instances per tile */
     size_t img_tile_cursor;   /* uint32[T]    scatter cursors */
     size_t img_total;

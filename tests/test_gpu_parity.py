@@ -86,7 +86,7 @@ def raw_forward(scene, dev, inputs=None):
         ctrl=view_of(geom, L.geom_ctrl, 8, torch.int32).astype(np.uint32),
         pix_state=view_of(img, L.img_pix_state, W * H * 4, torch.float32).reshape(H * W, 4),
         ranges=view_of(img, L.img_ranges, Tn * 2, torch.int32).astype(np.uint32).reshape(Tn, 2),
-        tile_max=view_of(img, L.img_tile_max, Tn, torch.int32).astype(np.uint32),
+        tile_max=view_of(img, L.img_tile_max, Tn * 4, torch.int32).astype(np.uint32).reshape(Tn, 4),
         tile_cnt=view_of(img, L.img_tile_cnt, Tn, torch.int32).astype(np.uint32),
         point_list=view_of(binning, L.bin_point_list, R, torch.int32).astype(np.uint32) if R else np.zeros(0, np.uint32),
     )
