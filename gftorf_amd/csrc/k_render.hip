@@ -260,6 +260,24 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
     return v;
 }
 
+// Inclusive scan inside every 16-lane row of five registers at once (lane 15/31/47/63 end up
+// with the row totals).  One v_add_f32_dpp per step and register; the five chains are
+// interleaved so consecutive DPP reads of a register are four instructions apart (the
+// VALU-write -> DPP-read hazard needs two wait states, covered by the leading s_nop for the
+// first step).
+__device__ __forceinline__ void row_scan5(float& t0, float& t1, float& t2, float& t3, float& t4)
+{
+#define GFT_DPP_STEP(N)                                                                    \
+    "v_add_f32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %1, %1, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %3, %3, %3 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %4, %4, %4 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 1\n\t" GFT_DPP_STEP(1) GFT_DPP_STEP(2) GFT_DPP_STEP(4) GFT_DPP_STEP(8) "s_nop 1"
+                 : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4));
+#undef GFT_DPP_STEP
+}
+
 // Sum 18 per-lane values over the 64 lanes of the wave and store the 18 totals to
 // row[0..17] in LDS.  Halving tree: 18 -> 9 registers (lane halves), 9 -> 5 (16-lane
 // rows), then a 4-step DPP scan inside each row; lanes 15/31/47/63 own the totals.
@@ -272,8 +290,7 @@ __device__ __forceinline__ void wave_reduce18_store(const float* v, float* row, 
 #pragma unroll
     for (int i = 0; i < 4; i++) t[i] = swap16_add(s[i], s[i + 4]);      // rows: i, i+4, i+9, i+13
     t[4] = swap16_add(s[8], s[8]);                                      // rows 0,1: value 8; rows 2,3: value 17
-#pragma unroll
-    for (int i = 0; i < 5; i++) t[i] = row_sum_to_lane15(t[i]);
+    row_scan5(t[0], t[1], t[2], t[3], t[4]);
     if ((lane & 15) == 15) {
         const int r = lane >> 4;
         const int off = (r & 1) * 4 + (r >> 1) * 9;
@@ -370,15 +387,18 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
             const bool contrib = (c < n_contrib) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
             if (__ballot(contrib) == 0ull) continue;   // wave-uniform skip
 
+            // Every lane runs the same arithmetic; lanes that do not blend this splat use
+            // alpha = G = 0, which leaves T unchanged (rcp(1) == 1) and makes all 18 partials
+            // exactly zero; only the five recurrence registers need a select.
             float v[GFT_NUM_ACC];
-#pragma unroll
-            for (int k = 0; k < GFT_NUM_ACC; k++) v[k] = 0.f;
-            if (contrib) {
+            {
                 const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
-                const float one_m_a = 1.f - alpha;
+                const float al = contrib ? alpha : 0.f;
+                const float Gm = contrib ? G : 0.f;
+                const float one_m_a = 1.f - al;
                 const float rcp_1ma = __builtin_amdgcn_rcpf(one_m_a);
                 T = T * rcp_1ma;
-                const float wc = alpha * T;          // dchannel_dcolor == dchannel_ddepth
+                const float wc = al * T;             // dchannel_dcolor == dchannel_ddepth
                 const float wp = wc * T;             // dchannel_dphasor = alpha*T*T
                 const float one_m_la = 1.f - last_alpha;
                 const float dist = a1.w, z = a1.z;
@@ -388,19 +408,22 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
                 float D1 = b0.x * gc0;
                 D1 = fmaf(b0.y, gc1, D1); D1 = fmaf(b0.z, gc2, D1); D1 = fmaf(dist, gd, D1);
                 D1 += ga + dL_dw;
-                S1 = fmaf(last_alpha, L1, one_m_la * S1);
-                L1 = D1;
+                const float S1n = fmaf(last_alpha, L1, one_m_la * S1);
 
                 float Dp = b0.w * gp0;
                 Dp = fmaf(b1.x, gp1, Dp); Dp = fmaf(b1.y, gp2, Dp); Dp = fmaf(b1.z, gp3, Dp);
                 Dp = fmaf(b1.w, gp4, Dp); Dp = fmaf(b2.x, gp5, Dp); Dp = fmaf(b2.y, gp6, Dp);
-                Sp = fmaf(last_alpha, Lp, one_m_la * one_m_la * Sp);
-                Lp = Dp;
-                last_alpha = alpha;
+                const float Spn = fmaf(last_alpha, Lp, one_m_la * one_m_la * Sp);
 
                 // alpha also scales what is left for the background (reference :850-858)
                 const float bgf = -T_final * rcp_1ma;
-                const float dL_dalpha = fmaf(D1 - S1, T, fmaf(fmaf(-2.f * one_m_a, Sp, Dp), T * T, bgf * bg_sum));
+                const float dL_dalpha = fmaf(D1 - S1n, T, fmaf(fmaf(-2.f * one_m_a, Spn, Dp), T * T, bgf * bg_sum));
+
+                S1 = contrib ? S1n : S1;
+                L1 = contrib ? D1 : L1;
+                Sp = contrib ? Spn : Sp;
+                Lp = contrib ? Dp : Lp;
+                last_alpha = contrib ? alpha : last_alpha;
 
                 v[6] = wc * gc0; v[7] = wc * gc1; v[8] = wc * gc2;
                 v[9] = wp * gp0; v[10] = wp * gp1; v[11] = wp * gp2; v[12] = wp * gp3;
@@ -409,7 +432,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
                 v[17] = wc * (t2 + A2 * z);           // gdd*2*alpha*T*(z(1-Tf) - wz)
 
                 const float dL_dG = a1.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
+                const float gdx = Gm * dx, gdy = Gm * dy;
                 const float dG_ddelx = -gdx * a0.z - gdy * a0.w;
                 const float dG_ddely = -gdy * a1.x - gdx * a0.w;
                 v[0] = dL_dG * dG_ddelx * ddelx_dx;
@@ -418,7 +441,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
                 v[2] = h * gdx * dx;
                 v[3] = h * gdx * dy;
                 v[4] = h * gdy * dy;
-                v[5] = G * dL_dalpha;
+                v[5] = Gm * dL_dalpha;
             }
             // 64 pixels -> one partial per value, parked in the batch's LDS table
             wave_reduce18_store(v, &sAcc[j * ACC_LDS_STRIDE], lane);
