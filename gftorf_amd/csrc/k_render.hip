@@ -119,7 +119,6 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     float P0 = 0, P1 = 0, P2 = 0, P3 = 0, P4 = 0, P5 = 0, P6 = 0;
     float Dd = 0, A = 0, DD = 0, DD_D = 0, DD_D2 = 0;
     float WD0 = 0, WD1 = 0, WD2 = 0;
-    bool first = true;
 
     for (int base = 0; base < total; base += RB) {
         // all 64 pixels finished -> the rest of the list is never used
@@ -139,44 +138,44 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
         while (m) {
             const int j = (int)__builtin_ctzll(m);
             m &= m - 1;
-            bool contrib = false;
-            if (!done) {
-                const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
-                const float dx = a0.x - pxf, dy = a0.y - pyf;
-                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-                const float alpha = fminf(0.99f, a1.y * gft_exp(power));
-                if (!(power > 0.0f) && !(alpha < 1.0f / 255.0f)) {
-                    const float test_T = T * (1 - alpha);
-                    if (test_T < 0.0001f) {
-                        done = true;
-                    } else {
-                        contrib = true;
-                        const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
-                        const float w = alpha * T;
-                        const float w_p = alpha * T * T;
-                        C0 += b0.x * w; C1 += b0.y * w; C2 += b0.z * w;
-                        P0 += b0.w * w_p; P1 += b1.x * w_p; P2 += b1.y * w_p; P3 += b1.z * w_p;
-                        P4 += b1.w * w_p; P5 += b2.x * w_p; P6 += b2.y * w_p;
-                        const float dist = a1.w;
-                        Dd += dist * w;
-                        if (first) {
-                            WD0 = alpha; WD1 = dist; WD2 = b1.y;
-                            first = false;
-                        }
-                        const float z = a1.z;
-                        DD += w * (z * z * A - 2.0f * z * DD_D + DD_D2);
-                        DD_D += w * z;
-                        DD_D2 += w * z * z;
-                        A += alpha * T;
-                        T = test_T;
-                        last_contributor = (uint32_t)(base + j + 1);
-                    }
-                }
-            }
-            // pixels[id] += 1 for every contributing pixel: wave popcount -> LDS
+            const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
+            const float dx = a0.x - pxf, dy = a0.y - pyf;
+            const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+            const float alpha = fminf(0.99f, a1.y * gft_exp(power));
+            const bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (__ballot(valid) == 0ull) continue;          // wave-uniform skip
+            const float test_T = T * (1 - alpha);
+            const bool term = valid && test_T < 0.0001f;    // this pixel is saturated: splat not blended
+            const bool contrib = valid && !term;
+            done = done || term;
             const unsigned long long cm = __ballot(contrib);
-            if (cm != 0ull && lane == 0) sCnt[j] = (uint32_t)__popcll(cm);
-            if (__ballot(!done) == 0ull) break;
+            if (cm != 0ull) {
+                // Branch-free blend: lanes that do not take this splat use alpha = 0, which adds
+                // exact zeros and leaves T unchanged.
+                const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
+                const float al = contrib ? alpha : 0.f;
+                const float w = al * T;
+                const float w_p = w * T;
+                C0 += b0.x * w; C1 += b0.y * w; C2 += b0.z * w;
+                P0 += b0.w * w_p; P1 += b1.x * w_p; P2 += b1.y * w_p; P3 += b1.z * w_p;
+                P4 += b1.w * w_p; P5 += b2.x * w_p; P6 += b2.y * w_p;
+                const float dist = a1.w;
+                Dd += dist * w;
+                const bool is_first = contrib && last_contributor == 0u;
+                WD0 = is_first ? alpha : WD0;
+                WD1 = is_first ? dist : WD1;
+                WD2 = is_first ? b1.y : WD2;
+                const float z = a1.z;
+                DD += w * (z * z * A - 2.0f * z * DD_D + DD_D2);
+                DD_D += w * z;
+                DD_D2 += w * z * z;
+                A += w;
+                T = T * (1 - al);
+                last_contributor = contrib ? (uint32_t)(base + j + 1) : last_contributor;
+                // pixels[id] += 1 for every contributing pixel: wave popcount -> LDS
+                if (lane == 0) sCnt[j] = (uint32_t)__popcll(cm);
+            }
+            if (__ballot(term) != 0ull && __ballot(!done) == 0ull) break;
         }
         __syncthreads();
         if (lane < n) {
