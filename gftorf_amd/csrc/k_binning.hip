@@ -23,24 +23,25 @@
 
 namespace {
 
-#define BIN_ITEMS 16                       // Gaussians per thread in count / scatter
-#define BIN_CHUNK (GFT_BLOCK * BIN_ITEMS)   // 4096 Gaussians per workgroup
+#define BIN_THREADS 1024                    // 16 waves per workgroup keep one CU busy on its own
+#define BIN_ITEMS 4                         // Gaussians per thread in count / scatter
+#define BIN_CHUNK (BIN_THREADS * BIN_ITEMS)  // 4096 Gaussians per workgroup
 #define BIN_LDS_MAX_TILES 16384            // LDS histogram limit (2 x 64 KB in the scatter)
 
 template <bool USE_LDS>
-__global__ __launch_bounds__(GFT_BLOCK) void k_tile_count(int P, int gx, int T, const ushort4* __restrict__ rect,
+__global__ __launch_bounds__(BIN_THREADS) void k_tile_count(int P, int gx, int T, const ushort4* __restrict__ rect,
                                                           uint32_t* __restrict__ tile_cnt)
 {
     extern __shared__ uint32_t hist[];
     const int tid = threadIdx.x;
     if (USE_LDS) {
-        for (int i = tid; i < T; i += GFT_BLOCK) hist[i] = 0;
+        for (int i = tid; i < T; i += BIN_THREADS) hist[i] = 0;
         __syncthreads();
     }
     const int base = blockIdx.x * BIN_CHUNK;
 #pragma unroll 4
     for (int k = 0; k < BIN_ITEMS; k++) {
-        const int idx = base + k * GFT_BLOCK + tid;
+        const int idx = base + k * BIN_THREADS + tid;
         if (idx < P) {
             const ushort4 r = rect[idx];
             for (int y = r.y; y < r.w; y++)
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_count(int P, int gx, int T, 
     }
     if (USE_LDS) {
         __syncthreads();
-        for (int i = tid; i < T; i += GFT_BLOCK) {
+        for (int i = tid; i < T; i += BIN_THREADS) {
             const uint32_t h = hist[i];
             if (h) atomicAdd(&tile_cnt[i], h);
         }
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int T, const uint32_t* __res
 }
 
 template <bool USE_LDS>
-__global__ __launch_bounds__(GFT_BLOCK) void k_tile_scatter(int P, int gx, int T, const ushort4* __restrict__ rect,
+__global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int T, const ushort4* __restrict__ rect,
                                                             const float* __restrict__ depth,
                                                             const uint2* __restrict__ ranges,
                                                             uint32_t* __restrict__ cursor,
@@ -120,11 +121,11 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_scatter(int P, int gx, int T
     const int tid = threadIdx.x;
     const int base = blockIdx.x * BIN_CHUNK;
     if (USE_LDS) {
-        for (int i = tid; i < T; i += GFT_BLOCK) cnt[i] = 0;
+        for (int i = tid; i < T; i += BIN_THREADS) cnt[i] = 0;
         __syncthreads();
 #pragma unroll 4
         for (int k = 0; k < BIN_ITEMS; k++) {
-            const int idx = base + k * GFT_BLOCK + tid;
+            const int idx = base + k * BIN_THREADS + tid;
             if (idx < P) {
                 const ushort4 r = rect[idx];
                 for (int y = r.y; y < r.w; y++)
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_scatter(int P, int gx, int T
             }
         }
         __syncthreads();
-        for (int i = tid; i < T; i += GFT_BLOCK) {
+        for (int i = tid; i < T; i += BIN_THREADS) {
             const uint32_t c = cnt[i];
             if (c) {
                 first[i] = ranges[i].x + atomicAdd(&cursor[i], c);
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_scatter(int P, int gx, int T
     }
 #pragma unroll 2
     for (int k = 0; k < BIN_ITEMS; k++) {
-        const int idx = base + k * GFT_BLOCK + tid;
+        const int idx = base + k * BIN_THREADS + tid;
         if (idx < P) {
             const ushort4 r = rect[idx];
             if (r.z > r.x && r.w > r.y) {
@@ -371,9 +372,9 @@ hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomV
     if (e != hipSuccess) return e;
     const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
     if (T <= BIN_LDS_MAX_TILES)
-        hipLaunchKernelGGL(k_tile_count<true>, dim3(blocks), dim3(GFT_BLOCK), (size_t)T * 4, s, c.P, gx, T, g.rect, im.tile_cnt);
+        hipLaunchKernelGGL(k_tile_count<true>, dim3(blocks), dim3(BIN_THREADS), (size_t)T * 4, s, c.P, gx, T, g.rect, im.tile_cnt);
     else
-        hipLaunchKernelGGL(k_tile_count<false>, dim3(blocks), dim3(GFT_BLOCK), 0, s, c.P, gx, T, g.rect, im.tile_cnt);
+        hipLaunchKernelGGL(k_tile_count<false>, dim3(blocks), dim3(BIN_THREADS), 0, s, c.P, gx, T, g.rect, im.tile_cnt);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, im.tile_cnt, im.ranges, im.tile_cursor, g.ctrl);
     return hipGetLastError();
 }
@@ -391,10 +392,10 @@ hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const Geo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BIN_LDS_MAX_TILES * 4);
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_tile_scatter<true>, dim3(blocks), dim3(GFT_BLOCK), (size_t)T * 8, s, c.P, gx, T, g.rect,
+        hipLaunchKernelGGL(k_tile_scatter<true>, dim3(blocks), dim3(BIN_THREADS), (size_t)T * 8, s, c.P, gx, T, g.rect,
                            g.depth, im.ranges, im.tile_cursor, b.keys);
     } else {
-        hipLaunchKernelGGL(k_tile_scatter<false>, dim3(blocks), dim3(GFT_BLOCK), 0, s, c.P, gx, T, g.rect, g.depth,
+        hipLaunchKernelGGL(k_tile_scatter<false>, dim3(blocks), dim3(BIN_THREADS), 0, s, c.P, gx, T, g.rect, g.depth,
                            im.ranges, im.tile_cursor, b.keys);
     }
     return hipGetLastError();

@@ -805,6 +805,10 @@ hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const g
     a.gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     a.stage_sh = (io.shs != nullptr && c.M == 16) ? 1 : 0;
     a.stage_shp = (io.shs_p != nullptr && c.M_p == 16) ? 1 : 0;
+    // Measured on MI355X (1 M Gaussians): staging the forward's SH rows through LDS costs more
+    // in occupancy than the strided reads cost in TA cycles (0.155 vs 0.128 ms); the backward,
+    // which also writes 320 B of SH gradients per Gaussian, gains from it (0.32 -> 0.245 ms).
+    a.stage_sh = a.stage_shp = 0;
     const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_F4 : 0) + (a.stage_shp ? SHP_ROW_F4 : 0));
     static bool attr_set = false;
     if (!attr_set) {
