@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
 ABI_VERSION = 1
-ACC_STRIDE = 20
+ACC_STRIDE = 16
 
 _lib = None
 

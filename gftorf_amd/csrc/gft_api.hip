@@ -33,7 +33,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     const size_t p = (size_t)(P > 0 ? P : 0);
     size_t o = 0;
     L->geom_rec_a = o;    o = align_up(o + p * 32);
-    L->geom_rec_b = o;    o = align_up(o + p * 48);
+    L->geom_rec_b = o;    o = align_up(o + p * 32);
     L->geom_depth = o;    o = align_up(o + p * 4);
     L->geom_tiles = o;    o = align_up(o + p * 4);
     L->geom_rect = o;     o = align_up(o + p * 8);

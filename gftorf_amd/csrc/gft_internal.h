@@ -7,12 +7,12 @@
 
 #define GFT_ALIGN 256
 #define GFT_BLOCK 256            // threads per workgroup = one 16x16 tile = 4 waves
-#define GFT_NUM_ACC 18           // accumulators actually used per Gaussian
+#define GFT_NUM_ACC 15           // accumulators actually used per Gaussian
 
 // ---- scratch views -------------------------------------------------------
 struct GeomView {
     float4* rec_a;      // [P][2]  {x,y,ca,cb} {cc,opacity,dist_ndc,dist}
-    float4* rec_b;      // [P][3]  {r,g,b,p0} {p1,p2,p3,p4} {p5,p6,phase_sh,amp}
+    float4* rec_b;      // [P][2]  {r,g,b,R} {I,Am,phase_sh,amp}
     float* depth;       // [P]
     uint32_t* tiles;    // [P]
     ushort4* rect;      // [P] tile rectangle {x0,y0,x1,y1}; all zero when culled

@@ -391,7 +391,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                     const float factor = 1.0f / (dist * dist);
 
                     // ToF phasor; undefined in the reference when neither input is given -> zeros
-                    float ph[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    // The seven ToF planes are linear in three per-splat values (reference
+                    // forward.cu:399-406): R = cos(phi) A/d^2, I = sin(phi) A/d^2, Am = A/d^2;
+                    // planes 3..6 are (+-R + dc Am), (+-I + dc Am) and are formed by the render kernels.
+                    float ph[3] = {0.f, 0.f, 0.f};
                     float phase_sh = 0.f, amplitude = 0.f;
                     bool have_phasor = false;
                     float phase = 0.f;
@@ -429,21 +432,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                         have_phasor = true;
                     }
                     if (have_phasor) {
-                        const float cp = cosf(phase), sn = sinf(phase), dc = a.c.dc_offset;
+                        const float cp = cosf(phase), sn = sinf(phase);
                         ph[0] = cp * amplitude * factor;
                         ph[1] = sn * amplitude * factor;
                         ph[2] = amplitude * factor;
-                        ph[3] = (cp + dc) * amplitude * factor;
-                        ph[4] = (-cp + dc) * amplitude * factor;
-                        ph[5] = (sn + dc) * amplitude * factor;
-                        ph[6] = (-sn + dc) * amplitude * factor;
                     }
 
                     a.g.rec_a[2 * idx] = make_float4(pix_x, pix_y, conx, cony);
                     a.g.rec_a[2 * idx + 1] = make_float4(conz, a.io.opacities[idx], dist_ndc, dist);
-                    a.g.rec_b[3 * idx] = make_float4(rgb[0], rgb[1], rgb[2], ph[0]);
-                    a.g.rec_b[3 * idx + 1] = make_float4(ph[1], ph[2], ph[3], ph[4]);
-                    a.g.rec_b[3 * idx + 2] = make_float4(ph[5], ph[6], phase_sh, amplitude);
+                    a.g.rec_b[2 * idx] = make_float4(rgb[0], rgb[1], rgb[2], ph[0]);
+                    a.g.rec_b[2 * idx + 1] = make_float4(ph[1], ph[2], phase_sh, amplitude);
                     a.g.depth[idx] = vz;
                     a.g.clamped[idx] = (uint8_t)clamp_bits;
                     radius = (int)my_radius;
@@ -500,13 +498,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
         if (visible) {
             // accumulators written by the render backward
             const float4* ap = reinterpret_cast<const float4*>(a.io.acc + (size_t)idx * GFT_ACC_STRIDE);
-            const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
+            // row = {dmean2D.xy, dconic.xyw, dopacity, dcolor[3], XR, XI, X2, XQ, ddist, dndc}
+            const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
             dmean2d[0] = a0.x; dmean2d[1] = a0.y;
             const float dconx = a0.z, dcony = a0.w, dconw = a1.x;
             dopac = a1.y;
             dcolor[0] = a1.z; dcolor[1] = a1.w; dcolor[2] = a2.x;
-            const float dph[7] = {a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
-            const float ddist_in = a4.x, dndc_in = a4.y;
+            // phasor-plane gradients arrive already folded onto the (R, I, Am) basis:
+            // XR = sum w_p (g0+g3-g4), XI = sum w_p (g1+g5-g6), X2 = sum w_p g2, XQ = sum w_p (g3+g4+g5+g6)
+            const float XR = a2.y, XI = a2.z, X2 = a2.w, XQ = a3.x;
+            const float ddist_in = a3.y, dndc_in = a3.z;
 
             const float px = a.io.means3D[3 * idx], py = a.io.means3D[3 * idx + 1], pz = a.io.means3D[3 * idx + 2];
             const Mat16 V = load_mat(a.io.viewmatrix);
@@ -608,25 +609,24 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
             }
 
             // ---- ToF phasor chain (reference backward.cu:527-587) ----
-            const float4 b2 = a.g.rec_b[3 * idx + 2];
+            const float4 b2 = a.g.rec_b[2 * idx + 1];     // {I, Am, phase_sh, amplitude}
             const float dist = a.g.rec_a[2 * idx + 1].w;
             if (a.io.shs_p != nullptr) {
                 float phase = dist * a.dist2phase + a.c.phase_offset;
                 if (a.c.use_view_dependent_phase) phase += b2.z;
                 const float amplitude = b2.w;
                 const float factor = 1.0f / (dist * dist);
-                const float dR = dph[0], dI = dph[1], dA = dph[2], dq1 = dph[3], dq2 = dph[4], dq3 = dph[5], dq4 = dph[6];
                 const float sin_p = sinf(phase), cos_p = cosf(phase), dc = a.c.dc_offset;
-                const float S = (dR * -sin_p + dI * cos_p + dq1 * -sin_p + dq2 * sin_p + dq3 * cos_p + dq4 * -cos_p);
+                // reference backward.cu:551-577 with dL_dR + dL_dq1 - dL_dq2 = XR etc.
+                const float XA = X2 + dc * XQ;
+                const float S = cos_p * XI - sin_p * XR;
+                const float Camp = cos_p * XR + sin_p * XI + XA;
                 float dCW[2] = {0.f, 0.f};
                 if (a.c.use_view_dependent_phase) dCW[0] = S * amplitude * factor;
                 sum_phase = S * amplitude * factor;
-                dCW[1] = (dR * cos_p + dI * sin_p + dA + dq1 * (cos_p + dc) + dq2 * (-cos_p + dc) +
-                          dq3 * (sin_p + dc) + dq4 * (-sin_p + dc)) * factor;
-                sum_dc = (dq1 + dq2 + dq3 + dq4) * amplitude * factor;
-                const float coeff = S * a.dist2phase * amplitude * factor / dist +
-                                    (dR * -cos_p + dI * -sin_p - dA + dq1 * -(cos_p + dc) + dq2 * (cos_p - dc) +
-                                     dq3 * -(sin_p + dc) + dq4 * (sin_p - dc)) * 2.0f * amplitude * factor * factor;
+                dCW[1] = Camp * factor;
+                sum_dc = XQ * amplitude * factor;
+                const float coeff = S * a.dist2phase * amplitude * factor / dist - Camp * 2.0f * amplitude * factor * factor;
                 const float dxv = mvx * coeff, dyv = mvy * coeff, dzv = mvz * coeff;
                 dmean[0] += dxv * V.m[0] + dyv * V.m[1] + dzv * V.m[2];
                 dmean[1] += dxv * V.m[4] + dyv * V.m[5] + dzv * V.m[6];

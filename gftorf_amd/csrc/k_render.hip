@@ -7,8 +7,8 @@
 // consecutive unit ids inside one XCD's run of units, so their (identical) list reads
 // hit the same L2.
 //
-// The list is staged through LDS in batches of 64 packed records (80 B per splat:
-// rec_a 32 B + rec_b 48 B, gathered with 16-byte loads, one splat per lane).  While
+// The list is staged through LDS in batches of 64 packed records (64 B per splat:
+// rec_a 32 B + rec_b 32 B, gathered with 16-byte loads, one splat per lane).  While
 // staging, the splat's alpha >= 1/255 ellipse is bounded by a box and tested against the
 // quadrant; one ballot gives the 64-bit mask of splats that can reach it, walked with
 // scalar bit scans, and their records are read back as LDS broadcasts.
@@ -18,16 +18,17 @@
 //   depth distortion and the first-hit triple.  The per-Gaussian `pixels` counter is a
 //   wave popcount -> LDS -> one global atomic per (quadrant, splat).
 // backward (reference K7, backward.cu:609-889): back-to-front.  The 18 per-(pixel,
-//   splat) float atomics of the reference become a v_permlane32_swap /
-//   v_permlane16_swap / DPP reduction tree (18 values -> 5 registers), 5 plain LDS
-//   stores (each splat is visited once per batch by its only wave), and one 72-byte
-//   global atomic burst per (quadrant, splat) that received a contribution.
+//   splat) float atomics of the reference become 15 sums (the 7 phasor planes are linear in
+//   3 per-splat values), a v_permlane32_swap / v_permlane16_swap / DPP reduction tree
+//   (15 values -> 4 registers), one 16-byte LDS store per row of lanes (each splat is visited
+//   once per batch by its only wave), and one 64-byte-row global atomic burst per
+//   (quadrant, splat) that received a contribution.
 #include "gft_internal.h"
 
 namespace {
 
 #define RB 64                // splats per staged batch = lanes per wave
-#define ACC_LDS_STRIDE 20
+#define ACC_LDS_STRIDE 16
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -58,9 +59,8 @@ __device__ __forceinline__ bool stage_splat(uint32_t id, int slot, const float4*
     const float4 a0 = rec_a[2 * id], a1 = rec_a[2 * id + 1];
     sA[2 * slot] = a0;
     sA[2 * slot + 1] = a1;
-    sB[3 * slot] = rec_b[3 * id];
-    sB[3 * slot + 1] = rec_b[3 * id + 1];
-    sB[3 * slot + 2] = rec_b[3 * id + 2];
+    sB[2 * slot] = rec_b[2 * id];
+    sB[2 * slot + 1] = rec_b[2 * id + 1];
     // alpha = min(0.99, o*exp(power)) >= 1/255  <=>  power >= -tau, tau = ln(255 o):
     // the pixels that can blend this splat lie in the ellipse q(d) <= 2 tau, whose bounding
     // box has half extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy) with cov = conic^-1.
@@ -85,6 +85,7 @@ struct RenderFwdArgs {
     const float4* __restrict__ rec_b;
     const float* __restrict__ bg;
     int64_t bsc, bsy, bsx;
+    float dc_offset;
     float4* __restrict__ pix_state;
     uint32_t* __restrict__ quad_max;
     float* out_color; float* out_phasor; float* out_depth; float* out_normal; float* out_acc;
@@ -95,7 +96,7 @@ struct RenderFwdArgs {
 __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
 {
     __shared__ float4 sA[RB * 2];
-    __shared__ float4 sB[RB * 3];
+    __shared__ float4 sB[RB * 2];
     __shared__ uint32_t sId[RB];
     __shared__ uint32_t sCnt[RB];
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     float T = 1.0f;
     uint32_t last_contributor = 0;
     float C0 = 0, C1 = 0, C2 = 0;
-    float P0 = 0, P1 = 0, P2 = 0, P3 = 0, P4 = 0, P5 = 0, P6 = 0;
+    float PR = 0, PI = 0, PA = 0;     // ToF phasor on its (R, I, Am) basis
     float Dd = 0, A = 0, DD = 0, DD_D = 0, DD_D2 = 0;
     float WD0 = 0, WD1 = 0, WD2 = 0;
 
@@ -152,13 +153,12 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
             if (cm != 0ull) {
                 // Branch-free blend: lanes that do not take this splat use alpha = 0, which adds
                 // exact zeros and leaves T unchanged.
-                const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
+                const float4 b0 = sB[2 * j], b1 = sB[2 * j + 1];
                 const float al = contrib ? alpha : 0.f;
                 const float w = al * T;
                 const float w_p = w * T;
                 C0 += b0.x * w; C1 += b0.y * w; C2 += b0.z * w;
-                P0 += b0.w * w_p; P1 += b1.x * w_p; P2 += b1.y * w_p; P3 += b1.z * w_p;
-                P4 += b1.w * w_p; P5 += b2.x * w_p; P6 += b2.y * w_p;
+                PR += b0.w * w_p; PI += b1.x * w_p; PA += b1.y * w_p;
                 const float dist = a1.w;
                 Dd += dist * w;
                 const bool is_first = contrib && last_contributor == 0u;
@@ -195,13 +195,15 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
         a.out_color[HW + pix] = C1 + T * g1;
         a.out_color[2 * HW + pix] = C2 + T * g2;
         // phasor planes share background planes 0..6, weighted by T (not T^2)
-        a.out_phasor[pix] = P0 + T * g0;
-        a.out_phasor[HW + pix] = P1 + T * g1;
-        a.out_phasor[2 * HW + pix] = P2 + T * g2;
-        a.out_phasor[3 * HW + pix] = P3 + T * g3;
-        a.out_phasor[4 * HW + pix] = P4 + T * g4;
-        a.out_phasor[5 * HW + pix] = P5 + T * g5;
-        a.out_phasor[6 * HW + pix] = P6 + T * g6;
+        // planes 3..6 = (+-cos + dc, +-sin + dc) A/d^2 blended = +-PR + dc PA, +-PI + dc PA
+        const float dcA = a.dc_offset * PA;
+        a.out_phasor[pix] = PR + T * g0;
+        a.out_phasor[HW + pix] = PI + T * g1;
+        a.out_phasor[2 * HW + pix] = PA + T * g2;
+        a.out_phasor[3 * HW + pix] = (PR + dcA) + T * g3;
+        a.out_phasor[4 * HW + pix] = (dcA - PR) + T * g4;
+        a.out_phasor[5 * HW + pix] = (PI + dcA) + T * g5;
+        a.out_phasor[6 * HW + pix] = (dcA - PI) + T * g6;
         a.out_depth[pix] = Dd;
         a.out_acc[pix] = A;
         a.out_dd[pix] = DD;
@@ -229,6 +231,7 @@ struct RenderBwdArgs {
     const float4* __restrict__ rec_b;
     const float* __restrict__ bg;
     int64_t bsc, bsy, bsx;
+    float dc_offset;
     const float4* __restrict__ pix_state;
     const uint32_t* __restrict__ quad_max;
     const float* __restrict__ g_color; const float* __restrict__ g_phasor; const float* __restrict__ g_depth;
@@ -259,50 +262,47 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
     return v;
 }
 
-// Inclusive scan inside every 16-lane row of five registers at once (lane 15/31/47/63 end up
-// with the row totals).  One v_add_f32_dpp per step and register; the five chains are
-// interleaved so consecutive DPP reads of a register are four instructions apart (the
+// Inclusive scan inside every 16-lane row of four registers at once (lane 15/31/47/63 end up
+// with the row totals).  One v_add_f32_dpp per step and register; the four chains are
+// interleaved so consecutive DPP reads of a register are three instructions apart (the
 // VALU-write -> DPP-read hazard needs two wait states, covered by the leading s_nop for the
 // first step).
-__device__ __forceinline__ void row_scan5(float& t0, float& t1, float& t2, float& t3, float& t4)
+__device__ __forceinline__ void row_scan4(float& t0, float& t1, float& t2, float& t3)
 {
 #define GFT_DPP_STEP(N)                                                                    \
     "v_add_f32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
     "v_add_f32_dpp %1, %1, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
     "v_add_f32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-    "v_add_f32_dpp %3, %3, %3 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-    "v_add_f32_dpp %4, %4, %4 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    "v_add_f32_dpp %3, %3, %3 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     asm volatile("s_nop 1\n\t" GFT_DPP_STEP(1) GFT_DPP_STEP(2) GFT_DPP_STEP(4) GFT_DPP_STEP(8) "s_nop 1"
-                 : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4));
+                 : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
 #undef GFT_DPP_STEP
 }
 
-// Sum 18 per-lane values over the 64 lanes of the wave and store the 18 totals to
-// row[0..17] in LDS.  Halving tree: 18 -> 9 registers (lane halves), 9 -> 5 (16-lane
-// rows), then a 4-step DPP scan inside each row; lanes 15/31/47/63 own the totals.
-__device__ __forceinline__ void wave_reduce18_store(const float* v, float* row, int lane)
+// Sum 15 per-lane values over the 64 lanes of the wave and store the totals to row[0..14]
+// (row[15] receives a duplicate) in LDS.  Halving tree: 15 -> 8 registers (lane halves:
+// value i | value i+8), 8 -> 4 (16-lane rows: values i, i+4, i+8, i+12), then a 4-step DPP
+// scan inside each row; lane 15 + 16 r owns values 4 r' .. with one 16-byte LDS store.
+__device__ __forceinline__ void wave_reduce15_store(const float* v, float* row, int lane)
 {
-    float s[9];
+    float s[8];
 #pragma unroll
-    for (int i = 0; i < 9; i++) s[i] = swap32_add(v[i], v[i + 9]);      // lo half: value i, hi half: value i+9
-    float t[5];
+    for (int i = 0; i < 7; i++) s[i] = swap32_add(v[i], v[i + 8]);      // lo half: value i, hi half: value i+8
+    s[7] = swap32_add(v[7], v[7]);                                      // both halves: value 7
+    float t[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) t[i] = swap16_add(s[i], s[i + 4]);      // rows: i, i+4, i+9, i+13
-    t[4] = swap16_add(s[8], s[8]);                                      // rows 0,1: value 8; rows 2,3: value 17
-    row_scan5(t[0], t[1], t[2], t[3], t[4]);
+    for (int i = 0; i < 4; i++) t[i] = swap16_add(s[i], s[i + 4]);      // rows: i, i+4, i+8, i+12 (i = 3: 3,7,11,7)
+    row_scan4(t[0], t[1], t[2], t[3]);
     if ((lane & 15) == 15) {
-        const int r = lane >> 4;
-        const int off = (r & 1) * 4 + (r >> 1) * 9;
-#pragma unroll
-        for (int i = 0; i < 4; i++) row[i + off] = t[i];
-        if (!(r & 1)) row[8 + (r >> 1) * 9] = t[4];
+        const int r = lane >> 4;                                        // row r holds values r*4 + i in t[i]
+        *reinterpret_cast<float4*>(row + 4 * r) = make_float4(t[0], t[1], t[2], t[3]);
     }
 }
 
 __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
 {
     __shared__ float4 sA[RB * 2];
-    __shared__ float4 sB[RB * 3];
+    __shared__ float4 sB[RB * 2];
     __shared__ uint32_t sId[RB];
     __shared__ float sAcc[RB * ACC_LDS_STRIDE];
 
@@ -351,6 +351,10 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     // depth-distortion weight gradient dL_dw(z) = gdd*(z^2 (1-Tf) - 2 z wz + wz2) = (A2 z + B2) z + C2
     const float A2 = gdd * (1 - T_final), B2 = -2.0f * gdd * wz_tot, C2 = gdd * wz2_tot;
     const float bg_sum = bg_dot + bg_dot_p;
+    // upstream phasor gradients folded onto the per-splat basis (R, I, Am):
+    // sum_k p_k g_k = R*GR + I*GI + Am*GA; K9 needs sum w_p*{GR, GI, g2, GQ}
+    const float GR = gp0 + gp3 - gp4, GI = gp1 + gp5 - gp6, GQ = (gp3 + gp4) + (gp5 + gp6);
+    const float GA = gp2 + a.dc_offset * GQ;
 
     // Back-to-front recurrences.  The reference keeps one "accumulated behind" value per
     // channel (accum_rec[3], accum_rec_p[7], _d, _a, _dd; backward.cu:776-833); only their
@@ -387,11 +391,11 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
             if (__ballot(contrib) == 0ull) continue;   // wave-uniform skip
 
             // Every lane runs the same arithmetic; lanes that do not blend this splat use
-            // alpha = G = 0, which leaves T unchanged (rcp(1) == 1) and makes all 18 partials
+            // alpha = G = 0, which leaves T unchanged (rcp(1) == 1) and makes all 15 partials
             // exactly zero; only the five recurrence registers need a select.
             float v[GFT_NUM_ACC];
             {
-                const float4 b0 = sB[3 * j], b1 = sB[3 * j + 1], b2 = sB[3 * j + 2];
+                const float4 b0 = sB[2 * j], b1 = sB[2 * j + 1];
                 const float al = contrib ? alpha : 0.f;
                 const float Gm = contrib ? G : 0.f;
                 const float one_m_a = 1.f - al;
@@ -409,9 +413,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
                 D1 += ga + dL_dw;
                 const float S1n = fmaf(last_alpha, L1, one_m_la * S1);
 
-                float Dp = b0.w * gp0;
-                Dp = fmaf(b1.x, gp1, Dp); Dp = fmaf(b1.y, gp2, Dp); Dp = fmaf(b1.z, gp3, Dp);
-                Dp = fmaf(b1.w, gp4, Dp); Dp = fmaf(b2.x, gp5, Dp); Dp = fmaf(b2.y, gp6, Dp);
+                float Dp = b0.w * GR;
+                Dp = fmaf(b1.x, GI, Dp); Dp = fmaf(b1.y, GA, Dp);
                 const float Spn = fmaf(last_alpha, Lp, one_m_la * one_m_la * Sp);
 
                 // alpha also scales what is left for the background (reference :850-858)
@@ -425,10 +428,9 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
                 last_alpha = contrib ? alpha : last_alpha;
 
                 v[6] = wc * gc0; v[7] = wc * gc1; v[8] = wc * gc2;
-                v[9] = wp * gp0; v[10] = wp * gp1; v[11] = wp * gp2; v[12] = wp * gp3;
-                v[13] = wp * gp4; v[14] = wp * gp5; v[15] = wp * gp6;
-                v[16] = wc * gd;
-                v[17] = wc * (t2 + A2 * z);           // gdd*2*alpha*T*(z(1-Tf) - wz)
+                v[9] = wp * GR; v[10] = wp * GI; v[11] = wp * gp2; v[12] = wp * GQ;
+                v[13] = wc * gd;
+                v[14] = wc * (t2 + A2 * z);           // gdd*2*alpha*T*(z(1-Tf) - wz)
 
                 const float dL_dG = a1.y * dL_dalpha;
                 const float gdx = Gm * dx, gdy = Gm * dy;
@@ -443,12 +445,12 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
                 v[5] = Gm * dL_dalpha;
             }
             // 64 pixels -> one partial per value, parked in the batch's LDS table
-            wave_reduce18_store(v, &sAcc[j * ACC_LDS_STRIDE], lane);
+            wave_reduce15_store(v, &sAcc[j * ACC_LDS_STRIDE], lane);
             touched |= 1ull << j;
         }
         __syncthreads();
 
-        // flush: one 72-byte burst of float atomics per splat that received a contribution
+        // flush: one 60-byte burst of float atomics (a single 64-byte row) per splat that received a contribution
         while (touched) {
             const int j = (int)__builtin_ctzll(touched);
             touched &= touched - 1;
@@ -472,6 +474,7 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     a.T = a.gx * gy;
     a.ranges = im.ranges; a.point_list = b.point_list; a.rec_a = g.rec_a; a.rec_b = g.rec_b;
     a.bg = io.bg; a.bsc = c.bg_stride_c; a.bsy = c.bg_stride_y; a.bsx = c.bg_stride_x;
+    a.dc_offset = c.dc_offset;
     a.pix_state = im.pix_state; a.quad_max = im.tile_max;
     a.out_color = io.out_color; a.out_phasor = io.out_phasor; a.out_depth = io.out_depth;
     a.out_normal = io.out_normal; a.out_acc = io.out_acc; a.out_entropy = io.out_entropy;
@@ -492,6 +495,7 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     a.T = a.gx * gy;
     a.ranges = im.ranges; a.point_list = b.point_list; a.rec_a = g.rec_a; a.rec_b = g.rec_b;
     a.bg = io.bg; a.bsc = c.bg_stride_c; a.bsy = c.bg_stride_y; a.bsx = c.bg_stride_x;
+    a.dc_offset = c.dc_offset;
     a.pix_state = im.pix_state; a.quad_max = im.tile_max;
     a.g_color = io.dL_dout_color; a.g_phasor = io.dL_dout_phasor; a.g_depth = io.dL_dout_depth;
     a.g_acc = io.dL_dout_acc; a.g_dd = io.dL_dout_depth_distortion;

@@ -41,8 +41,8 @@ extern "C" {
 #define GFT_NUM_CHANNELS_CWTOF 2
 #define GFT_TILE_X 16
 #define GFT_TILE_Y 16
-/* floats per Gaussian in the backward accumulator table (18 used + 2 pad) */
-#define GFT_ACC_STRIDE 20
+/* floats per Gaussian in the backward accumulator table (15 used + 1 pad = one 64-byte row) */
+#define GFT_ACC_STRIDE 16
 
 /* Scalar arguments of one rasterizer call: the non-tensor fields of
  * GaussianRasterizationSettings (RAST/diff_gaussian_rasterization_w_tof/
@@ -152,7 +152,7 @@ typedef struct gft_backward_io {
 typedef struct gft_layout {
     /* geom */
     size_t geom_rec_a;        /* float[P][8]  {x,y, conic a,b,c, opacity, dist_ndc, dist} */
-    size_t geom_rec_b;        /* float[P][12] {r,g,b, phasor[7], phase_sh, amplitude} */
+    size_t geom_rec_b;        /* float[P][8]  {r,g,b, R,I,Am (ToF phasor basis: cos,sin,1 times A/d^2), phase_sh, amplitude} */
     size_t geom_depth;        /* float[P]     view-space z (sort key bits) */
     size_t geom_tiles;        /* uint32[P]    tiles touched */
     size_t geom_rect;         /* uint16[P][4] tile rectangle {x0,y0,x1,y1} (all 0 when culled) */

@@ -78,7 +78,7 @@ def raw_forward(scene, dev, inputs=None):
     st = dict(
         R=R, radii=radii.cpu().numpy(), pixels=pixels.cpu().numpy(), planes=planes.cpu().numpy(),
         rec_a=view_of(geom, L.geom_rec_a, P * 8, torch.float32).reshape(P, 8),
-        rec_b=view_of(geom, L.geom_rec_b, P * 12, torch.float32).reshape(P, 12),
+        rec_b=view_of(geom, L.geom_rec_b, P * 8, torch.float32).reshape(P, 8),
         depth=view_of(geom, L.geom_depth, P, torch.float32),
         tiles=view_of(geom, L.geom_tiles, P, torch.int32).astype(np.uint32),
         rect=view_of(geom, L.geom_rect, P * 4, torch.int16).astype(np.uint16).reshape(P, 4),
@@ -136,8 +136,13 @@ def test_preprocess_and_binning_bit_exact(name, oracle, gpu):
     cl = og["clamped"][vis, 0] | (og["clamped"][vis, 1] << 1) | (og["clamped"][vis, 2] << 2) | (og["clamped_p"][vis] << 3)
     np.testing.assert_array_equal(st["clamped"][vis], cl)
     # transcendental stage (sinf/cosf differ by ulps between glibc and the device library)
-    Hh.assert_close("phasor7", og["phasor7"][vis], st["rec_b"][vis, 3:10], rtol_max=2e-6, atol=1e-9)
-    Hh.assert_close("phase_amp", og["phase_amp"][vis], st["rec_b"][vis, 10:12], rtol_max=1e-6, atol=1e-9)
+    # device keeps the phasor on its (R, I, Am) basis; planes 3..6 are +-R + dc*Am, +-I + dc*Am
+    Hh.assert_close("phasor RIA", og["phasor7"][vis, 0:3], st["rec_b"][vis, 3:6], rtol_max=2e-6, atol=1e-9)
+    dc = scene["dc_offset"]
+    R_, I_, A_ = st["rec_b"][vis, 3], st["rec_b"][vis, 4], st["rec_b"][vis, 5]
+    quad = np.stack([R_ + dc * A_, -R_ + dc * A_, I_ + dc * A_, -I_ + dc * A_], 1)
+    Hh.assert_close("phasor quads", og["phasor7"][vis, 3:7], quad, rtol_max=3e-6, atol=1e-9)
+    Hh.assert_close("phase_amp", og["phase_amp"][vis], st["rec_b"][vis, 6:8], rtol_max=1e-6, atol=1e-9)
     # sorted list / ranges: bit-identical; the reference's 64-bit keys follow from them
     np.testing.assert_array_equal(st["point_list"], f.point_list)
     np.testing.assert_array_equal(st["ranges"], f.ranges)
