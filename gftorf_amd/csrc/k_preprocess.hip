@@ -230,6 +230,19 @@ __device__ __forceinline__ void sh_backward(int deg, int M, float x, float y, fl
 // lines per load instruction).  Used when M == 16 (rows are whole float4s).
 #define SH_ROW_F4 12     // 16 coefficients x 3 channels
 #define SHP_ROW_F4 8     // 16 coefficients x 2 channels
+// LDS rows are padded by one float4 (odd stride in 16-byte slots): the per-lane ds_read/write_b128
+// row walks are then conflict free (12- and 8-slot strides gave 4- and 8-way conflicts, measured
+// 39 M of 50 M LDS cycles in the backward).
+#define SH_ROW_PAD (SH_ROW_F4 + 1)
+#define SHP_ROW_PAD (SHP_ROW_F4 + 1)
+
+template <int ROW_F4>
+__device__ __forceinline__ int padded_slot(int e)
+{
+    // element e of the wave's linear block -> slot in the padded LDS image
+    const int row = ROW_F4 == 12 ? (e * 43691) >> 19 : e >> 3;     // e / 12 for e < 768, e / 8
+    return row * (ROW_F4 + 1) + (e - row * ROW_F4);
+}
 
 template <int ROW_F4>
 __device__ __forceinline__ void wave_rows_to_lds(float4* dst, const float4* __restrict__ src, size_t first_gaussian,
@@ -240,7 +253,7 @@ __device__ __forceinline__ void wave_rows_to_lds(float4* dst, const float4* __re
 #pragma unroll
     for (int q = 0; q < ROW_F4; q++) {
         const size_t i = g0 + (size_t)(q * 64 + lane);
-        if (i < lim) dst[q * 64 + lane] = src[i];
+        if (i < lim) dst[padded_slot<ROW_F4>(q * 64 + lane)] = src[i];
     }
 }
 
@@ -253,7 +266,7 @@ __device__ __forceinline__ void wave_rows_from_lds(float4* __restrict__ dst, con
 #pragma unroll
     for (int q = 0; q < ROW_F4; q++) {
         const size_t i = g0 + (size_t)(q * 64 + lane);
-        if (i < lim) dst[i] = src[q * 64 + lane];
+        if (i < lim) dst[i] = src[padded_slot<ROW_F4>(q * 64 + lane)];
     }
 }
 
@@ -303,8 +316,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const int P = a.c.P;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float4* sh_l = lds_rows + wave * ((a.stage_sh ? 64 * SH_ROW_F4 : 0) + (a.stage_shp ? 64 * SHP_ROW_F4 : 0));
-    float4* shp_l = sh_l + (a.stage_sh ? 64 * SH_ROW_F4 : 0);
+    float4* sh_l = lds_rows + wave * ((a.stage_sh ? 64 * SH_ROW_PAD : 0) + (a.stage_shp ? 64 * SHP_ROW_PAD : 0));
+    float4* shp_l = sh_l + (a.stage_sh ? 64 * SH_ROW_PAD : 0);
     if (a.stage_sh | a.stage_shp) {
         const size_t g0 = (size_t)blockIdx.x * PRE_BLOCK + (size_t)wave * 64;
         if (a.stage_sh) wave_rows_to_lds<SH_ROW_F4>(sh_l, reinterpret_cast<const float4*>(a.io.shs), g0, (size_t)P, lane);
@@ -373,7 +386,17 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                         float res[3];
                         if (a.stage_sh) {
                             float v[4 * SH_ROW_F4];
-                            lds_row_load<SH_ROW_F4>(v, sh_l + lane * SH_ROW_F4);
+                            lds_row_load<SH_ROW_F4>(v, sh_l + lane * SH_ROW_PAD);
+                            sh_eval<3>(a.c.D, dx, dy, dz, v, res);
+                        } else if (a.c.M == 16) {
+                            // whole 192-byte row as twelve 16-byte loads (4x fewer TA requests than dwords)
+                            float v[4 * SH_ROW_F4];
+                            const float4* r4 = reinterpret_cast<const float4*>(a.io.shs) + (size_t)idx * SH_ROW_F4;
+#pragma unroll
+                            for (int q = 0; q < SH_ROW_F4; q++) {
+                                const float4 t = r4[q];
+                                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+                            }
                             sh_eval<3>(a.c.D, dx, dy, dz, v, res);
                         } else {
                             sh_eval<3>(a.c.D, dx, dy, dz, a.io.shs + (size_t)idx * a.c.M * 3, res);
@@ -410,7 +433,17 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                         float sp0;
                         if (a.stage_shp) {
                             float v[4 * SHP_ROW_F4];
-                            lds_row_load<SHP_ROW_F4>(v, shp_l + lane * SHP_ROW_F4);
+                            lds_row_load<SHP_ROW_F4>(v, shp_l + lane * SHP_ROW_PAD);
+                            sh_eval<2>(a.c.D, dx, dy, dz, v, res);
+                            sp0 = v[0];
+                        } else if (a.c.M_p == 16) {
+                            float v[4 * SHP_ROW_F4];
+                            const float4* r4 = reinterpret_cast<const float4*>(a.io.shs_p) + (size_t)idx * SHP_ROW_F4;
+#pragma unroll
+                            for (int q = 0; q < SHP_ROW_F4; q++) {
+                                const float4 t = r4[q];
+                                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+                            }
                             sh_eval<2>(a.c.D, dx, dy, dz, v, res);
                             sp0 = v[0];
                         } else {
@@ -474,8 +507,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
     const int M = a.c.M, M_p = a.c.M_p;
     float sum_phase = 0.f, sum_dc = 0.f;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float4* sh_l = lds_rows + wave * ((a.stage_sh ? 64 * SH_ROW_F4 : 0) + (a.stage_shp ? 64 * SHP_ROW_F4 : 0));
-    float4* shp_l = sh_l + (a.stage_sh ? 64 * SH_ROW_F4 : 0);
+    float4* sh_l = lds_rows + wave * ((a.stage_sh ? 64 * SH_ROW_PAD : 0) + (a.stage_shp ? 64 * SHP_ROW_PAD : 0));
+    float4* shp_l = sh_l + (a.stage_sh ? 64 * SH_ROW_PAD : 0);
     const size_t g0 = (size_t)blockIdx.x * PRE_BLOCK + (size_t)wave * 64;
     if (a.stage_sh | a.stage_shp) {
         if (a.stage_sh) wave_rows_to_lds<SH_ROW_F4>(sh_l, reinterpret_cast<const float4*>(a.io.shs), g0, (size_t)P, lane);
@@ -598,9 +631,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
                 for (int c = 0; c < 3; c++) dres[c] = dcolor[c] * (((clamp_bits >> c) & 1u) ? 0.f : 1.f);
                 if (a.stage_sh) {
                     float v[4 * SH_ROW_F4];
-                    lds_row_load<SH_ROW_F4>(v, sh_l + lane * SH_ROW_F4);
+                    lds_row_load<SH_ROW_F4>(v, sh_l + lane * SH_ROW_PAD);
                     sh_backward<3>(a.c.D, M, dx, dy, dz, v, dres, v, ddir);     // in place
-                    lds_row_store<SH_ROW_F4>(sh_l + lane * SH_ROW_F4, v);
+                    lds_row_store<SH_ROW_F4>(sh_l + lane * SH_ROW_PAD, v);
                 } else {
                     sh_backward<3>(a.c.D, M, dx, dy, dz, a.io.shs + (size_t)idx * M * 3, dres, dsh, ddir);
                 }
@@ -637,9 +670,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
                 dres[1] = dCW[1] * ((clamp_bits & 8u) ? 0.f : 1.f);
                 if (a.stage_shp) {
                     float v[4 * SHP_ROW_F4];
-                    lds_row_load<SHP_ROW_F4>(v, shp_l + lane * SHP_ROW_F4);
+                    lds_row_load<SHP_ROW_F4>(v, shp_l + lane * SHP_ROW_PAD);
                     sh_backward<2>(a.c.D, M_p, dx, dy, dz, v, dres, v, ddir);   // in place
-                    lds_row_store<SHP_ROW_F4>(shp_l + lane * SHP_ROW_F4, v);
+                    lds_row_store<SHP_ROW_F4>(shp_l + lane * SHP_ROW_PAD, v);
                 } else {
                     sh_backward<2>(a.c.D, M_p, dx, dy, dz, a.io.shs_p + (size_t)idx * M_p * 2, dres, dsh_p, ddir);
                 }
@@ -700,11 +733,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
             if (dsh_p) for (int k = 0; k < M_p * 2; k++) dsh_p[k] = 0.f;
             if (a.stage_sh) {
 #pragma unroll
-                for (int q = 0; q < SH_ROW_F4; q++) sh_l[lane * SH_ROW_F4 + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < SH_ROW_F4; q++) sh_l[lane * SH_ROW_PAD + q] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if (a.stage_shp) {
 #pragma unroll
-                for (int q = 0; q < SHP_ROW_F4; q++) shp_l[lane * SHP_ROW_F4 + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < SHP_ROW_F4; q++) shp_l[lane * SHP_ROW_PAD + q] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 
@@ -809,13 +842,13 @@ hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const g
     // in occupancy than the strided reads cost in TA cycles (0.155 vs 0.128 ms); the backward,
     // which also writes 320 B of SH gradients per Gaussian, gains from it (0.32 -> 0.245 ms).
     a.stage_sh = a.stage_shp = 0;
-    const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_F4 : 0) + (a.stage_shp ? SHP_ROW_F4 : 0));
+    const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_PAD : 0) + (a.stage_shp ? SHP_ROW_PAD : 0));
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess_fwd),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 16 * (SH_ROW_F4 + SHP_ROW_F4));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 16 * (SH_ROW_PAD + SHP_ROW_PAD));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess_bwd),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 16 * (SH_ROW_F4 + SHP_ROW_F4));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 16 * (SH_ROW_PAD + SHP_ROW_PAD));
         attr_set = true;
     }
     const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;
@@ -834,7 +867,7 @@ hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const g
     a.dist2phase = 4.0f * 3.14159265358979323846f / c.depth_range;
     a.stage_sh = (io.shs != nullptr && c.M == 16) ? 1 : 0;
     a.stage_shp = (io.shs_p != nullptr && c.M_p == 16) ? 1 : 0;
-    const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_F4 : 0) + (a.stage_shp ? SHP_ROW_F4 : 0));
+    const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_PAD : 0) + (a.stage_shp ? SHP_ROW_PAD : 0));
     const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
     if (io.shs_p != nullptr)
