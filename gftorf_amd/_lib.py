@@ -48,7 +48,7 @@ BACKWARD_FIELDS = [
 LAYOUT_FIELDS = [
     "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_rect", "geom_clamped",
     "geom_ctrl", "geom_total",
-    "img_pix_state", "img_ranges", "img_tile_max", "img_tile_cnt", "img_tile_cursor", "img_total",
+    "img_pix_state", "img_ranges", "img_tile_max", "img_tile_cnt", "img_tile_cursor", "img_tile_order", "img_total",
     "bin_keys", "bin_point_list", "bin_total",
 ]
 

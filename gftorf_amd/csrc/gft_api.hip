@@ -49,6 +49,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->img_tile_max = o;    o = align_up(o + T * 4 * 4);   // one entry per 8x8 quadrant
     L->img_tile_cnt = o;    o = align_up(o + T * 4);
     L->img_tile_cursor = o; o = align_up(o + T * 4);
+    L->img_tile_order = o;  o = align_up(o + T * 4);
     L->img_total = o;
 
     const size_t r = (size_t)(R > 0 ? R : 0);
@@ -81,6 +82,7 @@ ImgView gft_img_view(void* base, const gft_layout& L)
     v.tile_max = (uint32_t*)(b + L.img_tile_max);
     v.tile_cnt = (uint32_t*)(b + L.img_tile_cnt);
     v.tile_cursor = (uint32_t*)(b + L.img_tile_cursor);
+    v.tile_order = (uint32_t*)(b + L.img_tile_order);
     return v;
 }
 

@@ -26,6 +26,7 @@ struct ImgView {
     uint32_t* tile_max;   // [T]
     uint32_t* tile_cnt;   // [T]
     uint32_t* tile_cursor;// [T]
+    uint32_t* tile_order; // [T] tiles by backward weight, heaviest first (written by the backward)
 };
 
 struct BinView {

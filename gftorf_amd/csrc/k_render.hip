@@ -234,6 +234,7 @@ struct RenderBwdArgs {
     float dc_offset;
     const float4* __restrict__ pix_state;
     const uint32_t* __restrict__ quad_max;
+    const uint32_t* __restrict__ order;     // tiles, heaviest first
     const float* __restrict__ g_color; const float* __restrict__ g_phasor; const float* __restrict__ g_depth;
     const float* __restrict__ g_acc; const float* __restrict__ g_dd;
     float* acc;   // [P][GFT_ACC_STRIDE]
@@ -299,6 +300,47 @@ __device__ __forceinline__ void wave_reduce15_store(const float* v, float* row, 
     }
 }
 
+// Heavy-first launch order for the backward: the work of a quadrant is proportional to its
+// deepest contributor (known from the forward) and varies by an order of magnitude, so tiles
+// are bucket-sorted by that weight (64 buckets, descending) and dealt to the XCDs round-robin;
+// the hardware dispatcher then fills free wave slots with the longest remaining units first.
+// One workgroup; the order inside a bucket is arbitrary and only affects scheduling.
+__global__ __launch_bounds__(1024) void k_tile_order(int T, const uint32_t* __restrict__ quad_max,
+                                                     uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_max;
+    __shared__ uint32_t cnt[64], base[64];
+    const int tid = threadIdx.x;
+    if (tid == 0) s_max = 0;
+    if (tid < 64) cnt[tid] = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    for (int t = tid; t < T; t += 1024) {
+        const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
+        m = max(m, max(max(q.x, q.y), max(q.z, q.w)));
+    }
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const uint32_t wmax = s_max + 1;
+    for (int t = tid; t < T; t += 1024) {
+        const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
+        const uint32_t w = max(max(q.x, q.y), max(q.z, q.w));
+        atomicAdd(&cnt[63 - (w * 64u) / wmax], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int b = 0; b < 64; b++) { base[b] = acc; acc += cnt[b]; cnt[b] = 0; }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+        const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
+        const uint32_t w = max(max(q.x, q.y), max(q.z, q.w));
+        const uint32_t b = 63 - (w * 64u) / wmax;
+        order[base[b] + atomicAdd(&cnt[b], 1u)] = (uint32_t)t;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
 {
     __shared__ float4 sA[RB * 2];
@@ -306,9 +348,12 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     __shared__ uint32_t sId[RB];
     __shared__ float sAcc[RB * ACC_LDS_STRIDE];
 
-    const int V = a.T * 4;
-    const int v_unit = unit_of_block(blockIdx.x, V);
-    if (v_unit >= V) return;
+    // block b runs on XCD b & 7; slot b >> 3 of that XCD takes quadrant (slot & 3) of the tile of
+    // weight rank 8 * (slot >> 2) + xcd: heavy tiles first, a tile's quadrants on one XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int rank = 8 * (slot >> 2) + xcd;
+    if (rank >= a.T) return;
+    const int v_unit = (int)a.order[rank] * 4 + (slot & 3);
     const int tmax = (int)a.quad_max[v_unit];
     if (tmax == 0) return;
     const int tile = v_unit >> 2, quad = v_unit & 3;
@@ -500,7 +545,9 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     a.g_color = io.dL_dout_color; a.g_phasor = io.dL_dout_phasor; a.g_depth = io.dL_dout_depth;
     a.g_acc = io.dL_dout_acc; a.g_dd = io.dL_dout_depth_distortion;
     a.acc = io.acc;
-    const int blocks = 8 * ((a.T * 4 + 7) / 8);
+    a.order = im.tile_order;
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, a.T, im.tile_max, im.tile_order);
+    const int blocks = 32 * ((a.T + 7) / 8);
     hipLaunchKernelGGL(k_render_bwd, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }

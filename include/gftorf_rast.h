@@ -165,6 +165,7 @@ typedef struct gft_layout {
     size_t img_tile_max;      /* uint32[T][4] max n_contrib over each 8x8 quadrant of the tile */
     size_t img_tile_cnt;      /* uint32[T]    instances per tile */
     size_t img_tile_cursor;   /* uint32[T]    scatter cursors */
+    size_t img_tile_order;    /* uint32[T]    tiles by backward weight (written by gft_backward) */
     size_t img_total;
     /* binning */
     size_t bin_keys;          /* uint64[R]    (depth bits << 32 | Gaussian id), grouped by tile, unsorted */
