@@ -24,6 +24,7 @@ class Config(C.Structure):
         ("near_n", C.c_float), ("far_n", C.c_float), ("depth_range", C.c_float),
         ("phase_offset", C.c_float), ("dc_offset", C.c_float),
         ("use_view_dependent_phase", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("want_backward", C.c_int32),
         ("bg_stride_c", C.c_int64), ("bg_stride_y", C.c_int64), ("bg_stride_x", C.c_int64),
     ]
 
@@ -46,7 +47,7 @@ BACKWARD_FIELDS = [
 ]
 
 LAYOUT_FIELDS = [
-    "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_rect", "geom_clamped",
+    "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_rect", "geom_dirgrad", "geom_clamped",
     "geom_ctrl", "geom_total",
     "img_pix_state", "img_ranges", "img_tile_max", "img_tile_cnt", "img_tile_cursor", "img_tile_order", "img_total",
     "bin_keys", "bin_point_list", "bin_total",

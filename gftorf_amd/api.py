@@ -101,7 +101,7 @@ def _bg_strides(bg, H, W, dev):
         % (tuple(bg.shape),))
 
 
-def _make_config(s, P, M, M_p, H, W, phase_offset, dc_offset, bgs):
+def _make_config(s, P, M, M_p, H, W, phase_offset, dc_offset, bgs, want_backward):
     c = _lib.Config()
     c.P, c.D, c.M, c.M_p, c.W, c.H = P, int(s.sh_degree), M, M_p, W, H
     c.tanfovx, c.tanfovy = float(s.tanfovx), float(s.tanfovy)
@@ -111,6 +111,7 @@ def _make_config(s, P, M, M_p, H, W, phase_offset, dc_offset, bgs):
     c.use_view_dependent_phase = int(bool(s.use_view_dependent_phase))
     c.prefiltered = int(bool(s.prefiltered))
     c.debug = int(bool(s.debug))
+    c.want_backward = int(bool(want_backward))
     c.bg_stride_c, c.bg_stride_y, c.bg_stride_x = bgs
     return c
 
@@ -170,7 +171,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         geom = torch.empty((lib.gft_geom_bytes(P),), device=dev, dtype=torch.uint8)
         img = torch.empty((lib.gft_image_bytes(W, H),), device=dev, dtype=torch.uint8)
 
-        cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx))
+        # the backward can only run if autograd tracks one of the inputs
+        want_bw = any(ctx.needs_input_grad)
+        cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw)
         io = _lib.ForwardIO()
         io.bg, io.means3D = _ptr(bg_c), _ptr(means3D_c) if P else None
         io.colors_precomp, io.phasors_precomp, io.opacities = _ptr(colors_c), _ptr(phasors_c), _ptr(opac_c)
@@ -212,6 +215,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = R
         last_call_stats["num_rendered"] = R
         ctx.scalars = (ph_off, dc_off)
+        ctx.want_bw = want_bw
         ctx.bg = (bg_c, bsc, bsy, bsx)
         ctx.consts = (view_c, proj_c, campos_c)
         ctx.present = (sh_c is not None, sh_p_c is not None, colors_c is not None, phasors_c is not None,
@@ -270,7 +274,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_offsets = torch.empty((2,), **f32)
         acc = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32)
 
-        cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx))
+        cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), ctx.want_bw)
         io = _lib.BackwardIO()
         io.bg, io.means3D, io.radii = _ptr(bg_c), _ptr(means3D) if P else None, _ptr(radii) if P else None
         io.scales = _ptr(scales) if has_scales else None

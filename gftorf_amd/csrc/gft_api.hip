@@ -37,6 +37,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->geom_depth = o;    o = align_up(o + p * 4);
     L->geom_tiles = o;    o = align_up(o + p * 4);
     L->geom_rect = o;     o = align_up(o + p * 8);
+    L->geom_dirgrad = o;  o = align_up(o + p * 64);
     L->geom_clamped = o;  o = align_up(o + p);
     L->geom_ctrl = o;     o = align_up(o + GFT_CTRL_WORDS * 4);
     L->geom_total = o;
@@ -68,6 +69,7 @@ GeomView gft_geom_view(void* base, const gft_layout& L)
     g.depth = (float*)(b + L.geom_depth);
     g.tiles = (uint32_t*)(b + L.geom_tiles);
     g.rect = (ushort4*)(b + L.geom_rect);
+    g.dirgrad = (float4*)(b + L.geom_dirgrad);
     g.clamped = (uint8_t*)(b + L.geom_clamped);
     g.ctrl = (uint32_t*)(b + L.geom_ctrl);
     return g;

@@ -16,6 +16,7 @@ struct GeomView {
     float* depth;       // [P]
     uint32_t* tiles;    // [P]
     ushort4* rect;      // [P] tile rectangle {x0,y0,x1,y1}; all zero when culled
+    float4* dirgrad;    // [P][4] d(rgb)/d(dir) 9, d(phase,amp)/d(dir) 6, pad (forward with want_backward)
     uint8_t* clamped;   // [P]
     uint32_t* ctrl;     // [8]
 };

@@ -223,6 +223,88 @@ __device__ __forceinline__ void sh_backward(int deg, int M, float x, float y, fl
     ddir[0] = sx; ddir[1] = sy; ddir[2] = sz;
 }
 
+// d(SH polynomial)/d(unit direction) per channel: the same sums the reference backward forms
+// from the coefficients (backward.cu:58-60,78-80,99-122).  Evaluated in the forward (which
+// has the row in registers) when a backward will follow, so the backward needs no SH reads.
+template <int NC>
+__device__ __forceinline__ void sh_dir_grad(int deg, float x, float y, float z, const float* sh, float* ddx,
+                                            float* ddy, float* ddz)
+{
+#pragma unroll
+    for (int c = 0; c < NC; c++) { ddx[c] = 0.f; ddy[c] = 0.f; ddz[c] = 0.f; }
+    if (deg > 0) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            ddx[c] = -SH_C1 * sh[3 * NC + c];
+            ddy[c] = -SH_C1 * sh[1 * NC + c];
+            ddz[c] = SH_C1 * sh[2 * NC + c];
+        }
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const float s4 = sh[4 * NC + c], s5 = sh[5 * NC + c], s6 = sh[6 * NC + c], s7 = sh[7 * NC + c],
+                            s8 = sh[8 * NC + c];
+                ddx[c] += SH_C2[0] * y * s4 + SH_C2[2] * 2.f * -x * s6 + SH_C2[3] * z * s7 + SH_C2[4] * 2.f * x * s8;
+                ddy[c] += SH_C2[0] * x * s4 + SH_C2[1] * z * s5 + SH_C2[2] * 2.f * -y * s6 + SH_C2[4] * 2.f * -y * s8;
+                ddz[c] += SH_C2[1] * y * s5 + SH_C2[2] * 2.f * 2.f * z * s6 + SH_C2[3] * x * s7;
+            }
+            if (deg > 2) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const float s9 = sh[9 * NC + c], s10 = sh[10 * NC + c], s11 = sh[11 * NC + c],
+                                s12 = sh[12 * NC + c], s13 = sh[13 * NC + c], s14 = sh[14 * NC + c],
+                                s15 = sh[15 * NC + c];
+                    ddx[c] += (SH_C3[0] * s9 * 3.f * 2.f * xy + SH_C3[1] * s10 * yz +
+                               SH_C3[2] * s11 * -2.f * xy + SH_C3[3] * s12 * -3.f * 2.f * xz +
+                               SH_C3[4] * s13 * (-3.f * xx + 4.f * zz - yy) + SH_C3[5] * s14 * 2.f * xz +
+                               SH_C3[6] * s15 * 3.f * (xx - yy));
+                    ddy[c] += (SH_C3[0] * s9 * 3.f * (xx - yy) + SH_C3[1] * s10 * xz +
+                               SH_C3[2] * s11 * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * s12 * -3.f * 2.f * yz +
+                               SH_C3[4] * s13 * -2.f * xy + SH_C3[5] * s14 * -2.f * yz +
+                               SH_C3[6] * s15 * -3.f * 2.f * xy);
+                    ddz[c] += (SH_C3[1] * s10 * xy + SH_C3[2] * s11 * 4.f * 2.f * yz +
+                               SH_C3[3] * s12 * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * s13 * 4.f * 2.f * xz +
+                               SH_C3[5] * s14 * (xx - yy));
+                }
+            }
+        }
+    }
+}
+
+// dL/dsh[k][c] = basis_k(dir) * dres[c] for the active coefficients, zero up to M (no SH data needed)
+template <int NC>
+__device__ __forceinline__ void sh_backward_basis(int deg, int M, float x, float y, float z, const float* dres,
+                                                  float* dsh)
+{
+    float d[16];
+    d[0] = SH_C0;
+#pragma unroll
+    for (int k = 1; k < 16; k++) d[k] = 0.f;
+    if (deg > 0) {
+        d[1] = -SH_C1 * y; d[2] = SH_C1 * z; d[3] = -SH_C1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            d[4] = SH_C2[0] * xy; d[5] = SH_C2[1] * yz; d[6] = SH_C2[2] * (2.f * zz - xx - yy);
+            d[7] = SH_C2[3] * xz; d[8] = SH_C2[4] * (xx - yy);
+            if (deg > 2) {
+                d[9] = SH_C3[0] * y * (3.f * xx - yy);
+                d[10] = SH_C3[1] * xy * z;
+                d[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+                d[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                d[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+                d[14] = SH_C3[5] * z * (xx - yy);
+                d[15] = SH_C3[6] * x * (xx - 3.f * yy);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (k < M) dsh[k * NC + c] = d[k] * dres[c];
+}
+
 // ---- coalesced SH rows through LDS ---------------------------------------------
 // A wave owns 64 consecutive Gaussians whose SH rows form one contiguous block of
 // 64*M*NC floats: moved as 16-byte vectors with consecutive lanes on consecutive
@@ -377,6 +459,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
 
                     float rgb[3] = {0.f, 0.f, 0.f};
                     uint32_t clamp_bits = 0;
+                    float dgc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // d rgb / d dir
+                    float dgp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                  // d (phase, amp) / d dir
                     if (a.io.colors_precomp != nullptr) {
                         rgb[0] = a.io.colors_precomp[3 * idx];
                         rgb[1] = a.io.colors_precomp[3 * idx + 1];
@@ -388,6 +472,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                             float v[4 * SH_ROW_F4];
                             lds_row_load<SH_ROW_F4>(v, sh_l + lane * SH_ROW_PAD);
                             sh_eval<3>(a.c.D, dx, dy, dz, v, res);
+                            if (a.c.want_backward) sh_dir_grad<3>(a.c.D, dx, dy, dz, v, dgc, dgc + 3, dgc + 6);
                         } else if (a.c.M == 16) {
                             // whole 192-byte row as twelve 16-byte loads (4x fewer TA requests than dwords)
                             float v[4 * SH_ROW_F4];
@@ -398,8 +483,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                                 v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
                             }
                             sh_eval<3>(a.c.D, dx, dy, dz, v, res);
+                            if (a.c.want_backward) sh_dir_grad<3>(a.c.D, dx, dy, dz, v, dgc, dgc + 3, dgc + 6);
                         } else {
-                            sh_eval<3>(a.c.D, dx, dy, dz, a.io.shs + (size_t)idx * a.c.M * 3, res);
+                            const float* sp3 = a.io.shs + (size_t)idx * a.c.M * 3;
+                            sh_eval<3>(a.c.D, dx, dy, dz, sp3, res);
+                            if (a.c.want_backward) sh_dir_grad<3>(a.c.D, dx, dy, dz, sp3, dgc, dgc + 3, dgc + 6);
                         }
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
@@ -435,6 +523,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                             float v[4 * SHP_ROW_F4];
                             lds_row_load<SHP_ROW_F4>(v, shp_l + lane * SHP_ROW_PAD);
                             sh_eval<2>(a.c.D, dx, dy, dz, v, res);
+                            if (a.c.want_backward) sh_dir_grad<2>(a.c.D, dx, dy, dz, v, dgp, dgp + 2, dgp + 4);
                             sp0 = v[0];
                         } else if (a.c.M_p == 16) {
                             float v[4 * SHP_ROW_F4];
@@ -445,10 +534,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                                 v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
                             }
                             sh_eval<2>(a.c.D, dx, dy, dz, v, res);
+                            if (a.c.want_backward) sh_dir_grad<2>(a.c.D, dx, dy, dz, v, dgp, dgp + 2, dgp + 4);
                             sp0 = v[0];
                         } else {
                             const float* sp = a.io.shs_p + (size_t)idx * a.c.M_p * 2;
                             sh_eval<2>(a.c.D, dx, dy, dz, sp, res);
+                            if (a.c.want_backward) sh_dir_grad<2>(a.c.D, dx, dy, dz, sp, dgp, dgp + 2, dgp + 4);
                             sp0 = sp[0];
                         }
                         res[0] += 0.5f;
@@ -475,6 +566,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                     a.g.rec_a[2 * idx + 1] = make_float4(conz, a.io.opacities[idx], dist_ndc, dist);
                     a.g.rec_b[2 * idx] = make_float4(rgb[0], rgb[1], rgb[2], ph[0]);
                     a.g.rec_b[2 * idx + 1] = make_float4(ph[1], ph[2], phase_sh, amplitude);
+                    if (a.c.want_backward) {
+                        a.g.dirgrad[4 * idx] = make_float4(dgc[0], dgc[1], dgc[2], dgc[3]);
+                        a.g.dirgrad[4 * idx + 1] = make_float4(dgc[4], dgc[5], dgc[6], dgc[7]);
+                        a.g.dirgrad[4 * idx + 2] = make_float4(dgc[8], dgp[0], dgp[1], dgp[2]);
+                        a.g.dirgrad[4 * idx + 3] = make_float4(dgp[3], dgp[4], dgp[5], 0.f);
+                    }
                     a.g.depth[idx] = vz;
                     a.g.clamped[idx] = (uint8_t)clamp_bits;
                     radius = (int)my_radius;
@@ -510,7 +607,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
     float4* sh_l = lds_rows + wave * ((a.stage_sh ? 64 * SH_ROW_PAD : 0) + (a.stage_shp ? 64 * SHP_ROW_PAD : 0));
     float4* shp_l = sh_l + (a.stage_sh ? 64 * SH_ROW_PAD : 0);
     const size_t g0 = (size_t)blockIdx.x * PRE_BLOCK + (size_t)wave * 64;
-    if (a.stage_sh | a.stage_shp) {
+    // with the forward's direction-gradient record no SH coefficient is read here; the LDS rows
+    // then only serve to turn the per-lane gradient rows into coalesced 16-byte stores
+    const bool have_dg = a.c.want_backward != 0;
+    if ((a.stage_sh | a.stage_shp) && !have_dg) {
         if (a.stage_sh) wave_rows_to_lds<SH_ROW_F4>(sh_l, reinterpret_cast<const float4*>(a.io.shs), g0, (size_t)P, lane);
         if (a.stage_shp) wave_rows_to_lds<SHP_ROW_F4>(shp_l, reinterpret_cast<const float4*>(a.io.shs_p), g0, (size_t)P, lane);
         __syncthreads();
@@ -629,7 +729,19 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
                 float dres[3], ddir[3], dm[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) dres[c] = dcolor[c] * (((clamp_bits >> c) & 1u) ? 0.f : 1.f);
-                if (a.stage_sh) {
+                if (have_dg) {
+                    const float4 g0v = a.g.dirgrad[4 * idx], g1v = a.g.dirgrad[4 * idx + 1], g2v = a.g.dirgrad[4 * idx + 2];
+                    ddir[0] = g0v.x * dres[0]; ddir[0] = ddir[0] + g0v.y * dres[1]; ddir[0] = ddir[0] + g0v.z * dres[2];
+                    ddir[1] = g0v.w * dres[0]; ddir[1] = ddir[1] + g1v.x * dres[1]; ddir[1] = ddir[1] + g1v.y * dres[2];
+                    ddir[2] = g1v.z * dres[0]; ddir[2] = ddir[2] + g1v.w * dres[1]; ddir[2] = ddir[2] + g2v.x * dres[2];
+                    if (a.stage_sh) {
+                        float v[4 * SH_ROW_F4];
+                        sh_backward_basis<3>(a.c.D, 16, dx, dy, dz, dres, v);
+                        lds_row_store<SH_ROW_F4>(sh_l + lane * SH_ROW_PAD, v);
+                    } else {
+                        sh_backward_basis<3>(a.c.D, M, dx, dy, dz, dres, dsh);
+                    }
+                } else if (a.stage_sh) {
                     float v[4 * SH_ROW_F4];
                     lds_row_load<SH_ROW_F4>(v, sh_l + lane * SH_ROW_PAD);
                     sh_backward<3>(a.c.D, M, dx, dy, dz, v, dres, v, ddir);     // in place
@@ -668,7 +780,19 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
                 float dres[2], ddir[3], dm[3];
                 dres[0] = dCW[0];
                 dres[1] = dCW[1] * ((clamp_bits & 8u) ? 0.f : 1.f);
-                if (a.stage_shp) {
+                if (have_dg) {
+                    const float4 g2v = a.g.dirgrad[4 * idx + 2], g3v = a.g.dirgrad[4 * idx + 3];
+                    ddir[0] = g2v.y * dres[0]; ddir[0] = ddir[0] + g2v.z * dres[1];
+                    ddir[1] = g2v.w * dres[0]; ddir[1] = ddir[1] + g3v.x * dres[1];
+                    ddir[2] = g3v.y * dres[0]; ddir[2] = ddir[2] + g3v.z * dres[1];
+                    if (a.stage_shp) {
+                        float v[4 * SHP_ROW_F4];
+                        sh_backward_basis<2>(a.c.D, 16, dx, dy, dz, dres, v);
+                        lds_row_store<SHP_ROW_F4>(shp_l + lane * SHP_ROW_PAD, v);
+                    } else {
+                        sh_backward_basis<2>(a.c.D, M_p, dx, dy, dz, dres, dsh_p);
+                    }
+                } else if (a.stage_shp) {
                     float v[4 * SHP_ROW_F4];
                     lds_row_load<SHP_ROW_F4>(v, shp_l + lane * SHP_ROW_PAD);
                     sh_backward<2>(a.c.D, M_p, dx, dy, dz, v, dres, v, ddir);   // in place

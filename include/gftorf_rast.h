@@ -62,6 +62,10 @@ typedef struct gft_config {
     int32_t use_view_dependent_phase;
     int32_t prefiltered;
     int32_t debug;   /* synchronise + check after every stage (reference CHECK_CUDA) */
+    /* forward: also store the 64-byte per-Gaussian record d(colour, phase, amplitude)/d(view
+     * direction) so the backward does not have to re-read the 320 B of SH coefficients;
+     * backward: that record is present in `geom` (same value as in the forward call) */
+    int32_t want_backward;
     /* background [7,H,W] addressed as bg[c*sc + y*sy + x*sx] (element strides), so
      * the reference's expanded constant background (train.py:127) needs no copy */
     int64_t bg_stride_c, bg_stride_y, bg_stride_x;
@@ -156,6 +160,7 @@ typedef struct gft_layout {
     size_t geom_depth;        /* float[P]     view-space z (sort key bits) */
     size_t geom_tiles;        /* uint32[P]    tiles touched */
     size_t geom_rect;         /* uint16[P][4] tile rectangle {x0,y0,x1,y1} (all 0 when culled) */
+    size_t geom_dirgrad;      /* float[P][16] d rgb/d dir (9), d (phase,amp)/d dir (6), pad; only with want_backward */
     size_t geom_clamped;      /* uint8[P]     bit0..2 rgb clamped, bit3 amplitude clamped */
     size_t geom_ctrl;         /* uint32[8]    {R, flags, max tile list length, ...} */
     size_t geom_total;
