@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 ACC_STRIDE = 16
 
 _lib = None
@@ -48,8 +48,8 @@ BACKWARD_FIELDS = [
 
 LAYOUT_FIELDS = [
     "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_rect", "geom_dirgrad", "geom_clamped",
-    "geom_ctrl", "geom_total",
-    "img_pix_state", "img_ranges", "img_tile_max", "img_tile_cnt", "img_tile_cursor", "img_tile_order", "img_total",
+    "geom_total",
+    "img_pix_state", "img_ranges", "img_tile_max", "img_ctrl", "img_tile_cnt", "img_tile_cursor", "img_tile_order", "img_total",
     "bin_keys", "bin_point_list", "bin_total",
 ]
 
@@ -76,7 +76,7 @@ class Profile(C.Structure):
 
 EXPORTS = [
     "gft_abi_version", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes", "gft_acc_bytes",
-    "gft_get_layout", "gft_forward_preprocess", "gft_forward_render", "gft_backward",
+    "gft_get_layout", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_backward",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
 ]
 
@@ -108,9 +108,11 @@ def load():
     lib.gft_get_layout.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(Layout)]
     lib.gft_forward_preprocess.restype = C.c_int
     lib.gft_forward_preprocess.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO),
-                                           C.POINTER(C.c_int64)]
+                                           C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gft_forward_render.restype = C.c_int
-    lib.gft_forward_render.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64]
+    lib.gft_forward.restype = C.c_int
+    lib.gft_forward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64, C.POINTER(C.c_int64)]
+    lib.gft_forward_render.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64, C.c_int64]
     lib.gft_backward.restype = C.c_int
     lib.gft_backward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(BackwardIO), C.c_int64]
     lib.gft_mark_visible.restype = C.c_int

@@ -45,7 +45,14 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 # (Gaussian, tile) instance count of the most recent forward (diagnostics / bench)
-last_call_stats = {"num_rendered": 0}
+last_call_stats = {"num_rendered": 0, "binning_instances": 0, "restarted": False}
+
+# Instance count of the previous forward per (device, P, W, H).  A training loop renders
+# similar frames back to back, so the binning buffer can be sized before the device has
+# counted (gft_forward: no host round trip in the middle of the forward); a frame that needs
+# more than the guess re-runs stage 2 with the exact size.
+_instance_hint = {}
+_HINT_HEADROOM = 1.25
 
 
 def cpu_deep_copy_tuple(input_tuple):
@@ -196,15 +203,37 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             stream = torch.cuda.current_stream(dev).cuda_stream
             num_rendered = C.c_int64(0)
+            max_list = C.c_int64(0)
+            hint_key = (dev.index, P, W, H)
+            hint = _instance_hint.get(hint_key)
+            restarted = False
             try:
                 with torch.cuda.device(dev):
-                    _lib.check(lib.gft_forward_preprocess(stream, C.byref(cfg), C.byref(io), C.byref(num_rendered)))
-                    R = int(num_rendered.value)
-                    # sized after the one blocking read, like the reference's resize callback
-                    # (rasterize_points.cu:27-33, rasterizer_impl.cu:311-315)
-                    binning = torch.empty((lib.gft_binning_bytes(R, W, H),), device=dev, dtype=torch.uint8)
-                    io.binning = binning.data_ptr()
-                    _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), R))
+                    if hint is None:
+                        # first frame of this shape: size the buffer after the one blocking
+                        # read, like the reference's resize callback
+                        # (rasterize_points.cu:27-33, rasterizer_impl.cu:311-315)
+                        _lib.check(lib.gft_forward_preprocess(stream, C.byref(cfg), C.byref(io),
+                                                              C.byref(num_rendered), C.byref(max_list)))
+                        R = cap = int(num_rendered.value)
+                        binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
+                        io.binning = binning.data_ptr()
+                        _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, int(max_list.value)))
+                    else:
+                        cap = int(hint * _HINT_HEADROOM) + 4096
+                        binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
+                        io.binning = binning.data_ptr()
+                        _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), cap, C.byref(num_rendered)))
+                        R = int(num_rendered.value)
+                        if R > cap:
+                            restarted = True
+                            cap = R
+                            binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
+                            io.binning = binning.data_ptr()
+                            _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, 0))
+                    _instance_hint[hint_key] = R
+                    if len(_instance_hint) > 64:
+                        _instance_hint.pop(next(iter(_instance_hint)))
             except Exception as ex:
                 if s.debug:
                     torch.save(cpu_args, "snapshot_fw.dump")
@@ -213,7 +242,9 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         ctx.raster_settings = s
         ctx.num_rendered = R
-        last_call_stats["num_rendered"] = R
+        ctx.binning_instances = cap if P else 0
+        last_call_stats.update(num_rendered=R, binning_instances=ctx.binning_instances,
+                               restarted=bool(P) and restarted)
         ctx.scalars = (ph_off, dc_off)
         ctx.want_bw = want_bw
         ctx.bg = (bg_c, bsc, bsy, bsx)
@@ -304,7 +335,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         stream = torch.cuda.current_stream(dev).cuda_stream
         try:
             with torch.cuda.device(dev):
-                _lib.check(lib.gft_backward(stream, C.byref(cfg), C.byref(io), ctx.num_rendered))
+                _lib.check(lib.gft_backward(stream, C.byref(cfg), C.byref(io), ctx.binning_instances))
         except Exception as ex:
             if s.debug:
                 torch.save(cpu_args, "snapshot_bw.dump")

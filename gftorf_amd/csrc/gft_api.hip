@@ -39,7 +39,6 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->geom_rect = o;     o = align_up(o + p * 8);
     L->geom_dirgrad = o;  o = align_up(o + p * 64);
     L->geom_clamped = o;  o = align_up(o + p);
-    L->geom_ctrl = o;     o = align_up(o + GFT_CTRL_WORDS * 4);
     L->geom_total = o;
 
     const size_t n = (size_t)W * (size_t)H;
@@ -48,6 +47,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->img_pix_state = o;   o = align_up(o + n * 16);
     L->img_ranges = o;      o = align_up(o + T * 8);
     L->img_tile_max = o;    o = align_up(o + T * 4 * 4);   // one entry per 8x8 quadrant
+    L->img_ctrl = o;        o += GFT_CTRL_WORDS * 4;          // ctrl words and tile counters are contiguous
     L->img_tile_cnt = o;    o = align_up(o + T * 4);
     L->img_tile_cursor = o; o = align_up(o + T * 4);
     L->img_tile_order = o;  o = align_up(o + T * 4);
@@ -71,7 +71,6 @@ GeomView gft_geom_view(void* base, const gft_layout& L)
     g.rect = (ushort4*)(b + L.geom_rect);
     g.dirgrad = (float4*)(b + L.geom_dirgrad);
     g.clamped = (uint8_t*)(b + L.geom_clamped);
-    g.ctrl = (uint32_t*)(b + L.geom_ctrl);
     return g;
 }
 
@@ -82,6 +81,7 @@ ImgView gft_img_view(void* base, const gft_layout& L)
     v.pix_state = (float4*)(b + L.img_pix_state);
     v.ranges = (uint2*)(b + L.img_ranges);
     v.tile_max = (uint32_t*)(b + L.img_tile_max);
+    v.ctrl = (uint32_t*)(b + L.img_ctrl);
     v.tile_cnt = (uint32_t*)(b + L.img_tile_cnt);
     v.tile_cursor = (uint32_t*)(b + L.img_tile_cursor);
     v.tile_order = (uint32_t*)(b + L.img_tile_order);
@@ -233,83 +233,219 @@ static int check_config(const gft_config* c)
     return 0;
 }
 
-// ---- forward, stage 1 -----------------------------------------------------------
-extern "C" int gft_forward_preprocess(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
-                                      int64_t* num_rendered)
+// ---- host mailbox ---------------------------------------------------------------
+// The instance count R, the "prefiltered point culled" flag and the longest tile list are the
+// only values the host needs from the device during a forward (reference: blocking cudaMemcpy,
+// rasterizer_impl.cu:311).  The scan workgroup stores them into pinned host memory and the host
+// polls the sequence word, so no copy kernel and no interrupt-driven wake-up sit on the path,
+// and with gft_forward() the stage-2 kernels are already queued behind the scan.
+struct Mailbox {
+    std::mutex mu;
+    uint32_t* host = nullptr;      // GFT_MAIL_SLOTS x GFT_CTRL_WORDS words, pinned + mapped
+    uint32_t* dev = nullptr;
+    uint32_t next = 0;
+};
+#define GFT_MAIL_SLOTS 256
+static Mailbox g_mail;
+
+static int mailbox_acquire(uint32_t** dev_slot, volatile uint32_t** host_slot, uint32_t* seq)
 {
-    if (check_config(cfg)) return 1;
-    if (!io || !num_rendered) return gft_fail("gft_forward_preprocess: NULL argument");
-    *num_rendered = 0;
-    if (cfg->P == 0) return 0;
+    std::lock_guard<std::mutex> lk(g_mail.mu);
+    if (!g_mail.host) {
+        void* p = nullptr;
+        const size_t bytes = (size_t)GFT_MAIL_SLOTS * GFT_CTRL_WORDS * sizeof(uint32_t);
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped);
+        }
+        if (e != hipSuccess) return gft_fail("mailbox: hipHostMalloc failed: %s", hipGetErrorString(e));
+        memset(p, 0, bytes);
+        void* d = nullptr;
+        e = hipHostGetDevicePointer(&d, p, 0);
+        if (e != hipSuccess) { (void)hipHostFree(p); return gft_fail("mailbox: no device pointer: %s", hipGetErrorString(e)); }
+        g_mail.host = (uint32_t*)p;
+        g_mail.dev = (uint32_t*)d;
+    }
+    g_mail.next++;
+    if (g_mail.next == 0) g_mail.next = 1;          // 0 marks an empty slot
+    const uint32_t slot = g_mail.next % GFT_MAIL_SLOTS;
+    *seq = g_mail.next;
+    *dev_slot = g_mail.dev + (size_t)slot * GFT_CTRL_WORDS;
+    *host_slot = g_mail.host + (size_t)slot * GFT_CTRL_WORDS;
+    return 0;
+}
+
+// Spin on the sequence word; every few microseconds ask the stream whether it is idle or
+// broken, so a failed launch can never turn into an endless wait.
+static int mailbox_wait(hipStream_t s, volatile uint32_t* host_slot, uint32_t seq, uint32_t out[GFT_CTRL_WORDS])
+{
+    for (;;) {
+        for (int i = 0; i < 4096; i++) {
+            if (__atomic_load_n(&host_slot[GFT_CTRL_SEQ], __ATOMIC_ACQUIRE) == seq) goto ready;
+            __builtin_ia32_pause();
+        }
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) {
+            if (__atomic_load_n(&host_slot[GFT_CTRL_SEQ], __ATOMIC_ACQUIRE) == seq) goto ready;
+            return gft_fail("forward: the stream drained but the tile scan never reported");
+        }
+        if (q != hipErrorNotReady) return gft_fail("forward: %s", hipGetErrorString(q));
+    }
+ready:
+    for (int i = 0; i < GFT_CTRL_WORDS; i++) out[i] = host_slot[i];
+    return 0;
+}
+
+static int check_stage1(const gft_config* cfg, const gft_forward_io* io, const char* who)
+{
     if (!io->means3D || !io->opacities || !io->viewmatrix || !io->projmatrix || !io->campos || !io->geom ||
         !io->radii || !io->pixels)
-        return gft_fail("gft_forward_preprocess: required pointer is NULL");
+        return gft_fail("%s: required pointer is NULL", who);
     if ((io->shs == nullptr) == (io->colors_precomp == nullptr))
         return gft_fail("Please provide excatly one of either SHs or precomputed colors!");
     if ((io->scales == nullptr || io->rotations == nullptr) == (io->cov3D_precomp == nullptr))
         return gft_fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
     if ((io->shs != nullptr) != (cfg->M > 0) || (io->shs_p != nullptr) != (cfg->M_p > 0))
         return gft_fail("M / M_p do not match the presence of shs / shs_p");
-    if (!io->img) return gft_fail("gft_forward_preprocess: img buffer is NULL");
+    if (!io->img) return gft_fail("%s: img buffer is NULL", who);
+    return 0;
+}
+
+static int check_stage2(const gft_forward_io* io, const char* who)
+{
+    if (!io->img || !io->bg || !io->out_color || !io->out_phasor || !io->out_depth || !io->out_normal ||
+        !io->out_acc || !io->out_entropy || !io->out_depth_distortion || !io->out_amp_distortion ||
+        !io->out_distribution)
+        return gft_fail("%s: required pointer is NULL", who);
+    return 0;
+}
+
+// preprocess + tile counting + scan; the totals arrive in the mailbox slot
+static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
+                          const ImgView& im, uint32_t* mail_dev, uint32_t seq)
+{
+    {
+        // ctrl words + per-tile counters: one clear
+        const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+        GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, (GFT_CTRL_WORDS + (size_t)gx * gy) * sizeof(uint32_t), s));
+    }
+    {
+        StageTimer t(s, ST_PRE_FWD);
+        GFT_STAGE(s, cfg, "preprocess_fwd", gft_launch_preprocess_fwd(s, *cfg, *io, g, im));
+    }
+    {
+        StageTimer t(s, ST_TILE_COUNT);
+        GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im, mail_dev, seq));
+    }
+    return 0;
+}
+
+// scatter + per-tile sort + render; `cap` = instances the binning buffer holds.  With
+// check_cap the kernels compare the device-side count against it and do nothing on overflow.
+static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
+                          const ImgView& im, const BinView& b, bool binned, int64_t max_tile_list, bool check_cap,
+                          uint32_t cap)
+{
+    if (binned) {
+        {
+            StageTimer t(s, ST_TILE_SCATTER);
+            GFT_STAGE(s, cfg, "tile_scatter", gft_launch_tile_scatter(s, *cfg, g, im, b, cap));
+        }
+        {
+            StageTimer t(s, ST_TILE_SORT);
+            GFT_STAGE(s, cfg, "tile_sort", gft_launch_tile_sort(s, *cfg, max_tile_list, im, b, cap));
+        }
+    }
+    {
+        StageTimer t(s, ST_RENDER_FWD);
+        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, check_cap, cap));
+    }
+    if (g_prof.on) { std::lock_guard<std::mutex> lk(g_prof.mu); g_prof.fwd++; }
+    return 0;
+}
+
+// ---- forward, stage 1 -----------------------------------------------------------
+extern "C" int gft_forward_preprocess(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
+                                      int64_t* num_rendered, int64_t* max_tile_list)
+{
+    if (max_tile_list) *max_tile_list = 0;
+    if (check_config(cfg)) return 1;
+    if (!io || !num_rendered) return gft_fail("gft_forward_preprocess: NULL argument");
+    *num_rendered = 0;
+    if (cfg->P == 0) return 0;
+    if (check_stage1(cfg, io, "gft_forward_preprocess")) return 1;
     hipStream_t s = (hipStream_t)hip_stream;
     gft_layout L;
     gft_compute_layout(cfg->P, cfg->W, cfg->H, 0, &L);
     GeomView g = gft_geom_view(io->geom, L);
     ImgView im = gft_img_view(io->img, L);
-
-    GFT_CHECK_HIP(hipMemsetAsync(g.ctrl, 0, GFT_CTRL_WORDS * sizeof(uint32_t), s));
-    {
-        StageTimer t(s, ST_PRE_FWD);
-        GFT_STAGE(s, cfg, "preprocess_fwd", gft_launch_preprocess_fwd(s, *cfg, *io, g));
-    }
-    {
-        StageTimer t(s, ST_TILE_COUNT);
-        GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im));
-    }
+    uint32_t* mail_dev; volatile uint32_t* mail_host; uint32_t seq;
+    if (mailbox_acquire(&mail_dev, &mail_host, &seq)) return 1;
+    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq)) return 1;
     // the one blocking read of the forward (reference rasterizer_impl.cu:311)
-    uint32_t host[GFT_CTRL_WORDS] = {0};
-    GFT_CHECK_HIP(hipMemcpyAsync(host, g.ctrl, sizeof(host), hipMemcpyDeviceToHost, s));
-    GFT_CHECK_HIP(hipStreamSynchronize(s));
+    uint32_t host[GFT_CTRL_WORDS];
+    if (mailbox_wait(s, mail_host, seq, host)) return 1;
     if (host[GFT_CTRL_FLAGS] & 1u)
         return gft_fail("Point is filtered although prefiltered is set. This shouldn't happen!");
     *num_rendered = (int64_t)host[GFT_CTRL_TOTAL];
+    if (max_tile_list) *max_tile_list = (int64_t)host[GFT_CTRL_MAXCNT];
     return 0;
 }
 
 // ---- forward, stage 2 -----------------------------------------------------------
 extern "C" int gft_forward_render(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
-                                  int64_t num_rendered)
+                                  int64_t binning_instances, int64_t max_tile_list)
 {
     if (check_config(cfg)) return 1;
     if (!io) return gft_fail("gft_forward_render: io is NULL");
-    if (!io->img || !io->bg || !io->out_color || !io->out_phasor || !io->out_depth || !io->out_normal ||
-        !io->out_acc || !io->out_entropy || !io->out_depth_distortion || !io->out_amp_distortion ||
-        !io->out_distribution)
-        return gft_fail("gft_forward_render: required pointer is NULL");
-    if (num_rendered > 0 && !io->binning) return gft_fail("gft_forward_render: binning buffer is NULL");
+    if (check_stage2(io, "gft_forward_render")) return 1;
+    if (binning_instances < 0 || binning_instances > 0xffffffffll) return gft_fail("gft_forward_render: bad instance count");
+    if (binning_instances > 0 && !io->binning) return gft_fail("gft_forward_render: binning buffer is NULL");
     if (cfg->P > 0 && (!io->geom || !io->radii || !io->pixels)) return gft_fail("gft_forward_render: geom/radii/pixels NULL");
     hipStream_t s = (hipStream_t)hip_stream;
-    const int64_t R = cfg->P == 0 ? 0 : num_rendered;
+    const int64_t R = cfg->P == 0 ? 0 : binning_instances;
     gft_layout L;
     gft_compute_layout(cfg->P, cfg->W, cfg->H, R, &L);
     GeomView g = gft_geom_view(io->geom, L);
     ImgView im = gft_img_view(io->img, L);
     BinView b = gft_bin_view(io->binning, L);
-    if (R > 0) {
-        {
-            StageTimer t(s, ST_TILE_SCATTER);
-            GFT_STAGE(s, cfg, "tile_scatter", gft_launch_tile_scatter(s, *cfg, g, im, b));
-        }
-        {
-            StageTimer t(s, ST_TILE_SORT);
-            GFT_STAGE(s, cfg, "tile_sort", gft_launch_tile_sort(s, *cfg, im, b));
-        }
+    if (cfg->P == 0) {
+        // no stage 1 ran: every tile list is empty
+        const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+        GFT_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s));
     }
-    {
-        StageTimer t(s, ST_RENDER_FWD);
-        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b));
-    }
-    if (g_prof.on) { std::lock_guard<std::mutex> lk(g_prof.mu); g_prof.fwd++; }
+    return enqueue_stage2(s, cfg, io, g, im, b, R > 0, max_tile_list, cfg->P > 0, (uint32_t)R);
+}
+
+// ---- forward, one call ------------------------------------------------------------
+extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
+                           int64_t binning_instances, int64_t* num_rendered)
+{
+    if (check_config(cfg)) return 1;
+    if (!io || !num_rendered) return gft_fail("gft_forward: NULL argument");
+    *num_rendered = 0;
+    if (check_stage2(io, "gft_forward")) return 1;
+    if (binning_instances < 0 || binning_instances > 0xffffffffll) return gft_fail("gft_forward: bad instance count");
+    if (cfg->P == 0) return gft_forward_render(hip_stream, cfg, io, 0, 0);
+    if (check_stage1(cfg, io, "gft_forward")) return 1;
+    if (binning_instances > 0 && !io->binning) return gft_fail("gft_forward: binning buffer is NULL");
+    hipStream_t s = (hipStream_t)hip_stream;
+    gft_layout L;
+    gft_compute_layout(cfg->P, cfg->W, cfg->H, binning_instances, &L);
+    GeomView g = gft_geom_view(io->geom, L);
+    ImgView im = gft_img_view(io->img, L);
+    BinView b = gft_bin_view(io->binning, L);
+    uint32_t* mail_dev; volatile uint32_t* mail_host; uint32_t seq;
+    if (mailbox_acquire(&mail_dev, &mail_host, &seq)) return 1;
+    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq)) return 1;
+    // stage 2 is queued before R is known; its kernels check R against the buffer themselves
+    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, 0, true, (uint32_t)binning_instances)) return 1;
+    uint32_t host[GFT_CTRL_WORDS];
+    if (mailbox_wait(s, mail_host, seq, host)) return 1;
+    if (host[GFT_CTRL_FLAGS] & 1u)
+        return gft_fail("Point is filtered although prefiltered is set. This shouldn't happen!");
+    *num_rendered = (int64_t)host[GFT_CTRL_TOTAL];
     return 0;
 }
 
@@ -319,8 +455,11 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     if (check_config(cfg)) return 1;
     if (!io) return gft_fail("gft_backward: io is NULL");
     hipStream_t s = (hipStream_t)hip_stream;
-    if (io->dL_dphase_offset) GFT_CHECK_HIP(hipMemsetAsync(io->dL_dphase_offset, 0, sizeof(float), s));
-    if (io->dL_ddc_offset) GFT_CHECK_HIP(hipMemsetAsync(io->dL_ddc_offset, 0, sizeof(float), s));
+    // k_offset_reduce overwrites both scalars whenever shs_p is given
+    if (cfg->P == 0 || io->shs_p == nullptr) {
+        if (io->dL_dphase_offset) GFT_CHECK_HIP(hipMemsetAsync(io->dL_dphase_offset, 0, sizeof(float), s));
+        if (io->dL_ddc_offset) GFT_CHECK_HIP(hipMemsetAsync(io->dL_ddc_offset, 0, sizeof(float), s));
+    }
     if (cfg->P == 0) return 0;
     if (!io->means3D || !io->radii || !io->viewmatrix || !io->projmatrix || !io->campos || !io->geom || !io->img ||
         !io->bg || !io->acc || !io->dL_dmeans3D || !io->dL_dmeans2D || !io->dL_dopacity || !io->dL_dphase_offset ||

@@ -18,13 +18,13 @@ struct GeomView {
     ushort4* rect;      // [P] tile rectangle {x0,y0,x1,y1}; all zero when culled
     float4* dirgrad;    // [P][4] d(rgb)/d(dir) 9, d(phase,amp)/d(dir) 6, pad (forward with want_backward)
     uint8_t* clamped;   // [P]
-    uint32_t* ctrl;     // [8]
 };
 
 struct ImgView {
     float4* pix_state;    // [N] {final_T, n_contrib bits, w_z, w_z2}
     uint2* ranges;        // [T]
     uint32_t* tile_max;   // [T]
+    uint32_t* ctrl;       // [8], directly followed by tile_cnt (one memset clears both)
     uint32_t* tile_cnt;   // [T]
     uint32_t* tile_cursor;// [T]
     uint32_t* tile_order; // [T] tiles by backward weight, heaviest first (written by the backward)
@@ -39,6 +39,8 @@ struct BinView {
 #define GFT_CTRL_TOTAL 0     // R = number of (Gaussian, tile) instances
 #define GFT_CTRL_FLAGS 1     // bit0: prefiltered point culled
 #define GFT_CTRL_MAXCNT 2    // longest tile list
+#define GFT_CTRL_DONE 3      // finished k_tile_count workgroups (ticket for the fused scan)
+#define GFT_CTRL_SEQ 3       // host mailbox only: sequence number, written last
 #define GFT_CTRL_WORDS 8
 
 void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* L);
@@ -57,14 +59,15 @@ int gft_fail(const char* fmt, ...);
 
 // ---- stage launchers (each enqueues on `s`, returns hipError_t) -----------
 hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
-                                     const GeomView& g);
-hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im);
+                                     const GeomView& g, const ImgView& im);
+hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
+                                 uint32_t* mail, uint32_t seq);
 hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                   const BinView& b);
-hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, const ImgView& im,
-                                const BinView& b);
+                                   const BinView& b, uint32_t cap);
+hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_tile_list, const ImgView& im,
+                                const BinView& b, uint32_t cap);
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
-                                 const GeomView& g, const ImgView& im, const BinView& b);
+                                 const GeomView& g, const ImgView& im, const BinView& b, bool check_cap, uint32_t cap);
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b);
 hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,

@@ -9,8 +9,9 @@
 // emitted in id order produces.  MI355X form (integer work, HBM-bound, no global sort):
 //
 //   k_tile_count   : LDS histogram of tile hits per 4096-Gaussian block, one global
-//                    atomic per (block, tile)                           [8 B/Gaussian]
-//   k_tile_scan    : exclusive scan over tiles -> ranges[tile] = [first,last), R, max
+//                    atomic per (block, tile)                           [8 B/Gaussian];
+//                    the last workgroup to finish scans the counters:
+//                    ranges[tile] = [first,last), R, longest list -> ctrl + host mailbox
 //   k_tile_scatter : each block reserves one chunk per tile with a single global atomic
 //                    and writes its (depth bits << 32 | id) keys there   [8 B/instance]
 //   k_tile_sort    : one workgroup per tile: bitonic sort of the tile's keys in LDS
@@ -23,16 +24,91 @@
 
 namespace {
 
+#ifndef BIN_THREADS
 #define BIN_THREADS 1024                    // 16 waves per workgroup keep one CU busy on its own
+#endif
+#ifndef BIN_ITEMS
 #define BIN_ITEMS 4                         // Gaussians per thread in count / scatter
+#endif
 #define BIN_CHUNK (BIN_THREADS * BIN_ITEMS)  // 4096 Gaussians per workgroup
 #define BIN_LDS_MAX_TILES 16384            // LDS histogram limit (2 x 64 KB in the scatter)
 
+// Every workgroup walks the tile table from a different start so that the ~P/4096 workgroups
+// do not queue up on the same counter at the same time.
+__device__ __forceinline__ int rotated_tile(int i, int T)
+{
+    const int rot = (int)(((uint64_t)blockIdx.x * (uint64_t)T) / gridDim.x);
+    const int t = i + rot;
+    return t >= T ? t - T : t;
+}
+
+// Exclusive scan of tile_cnt by one workgroup (the last one of k_tile_count): ranges, zeroed
+// cursors, totals into ctrl and into the host mailbox (pinned memory the host polls instead of
+// a blocking copy; sequence number written last with release / system scope).
+__device__ void tile_scan_block(int T, const uint32_t* tile_cnt, uint2* __restrict__ ranges,
+                                uint32_t* __restrict__ cursor, uint32_t* ctrl, uint32_t* mail, uint32_t seq)
+{
+    constexpr int NW = BIN_THREADS / 64;
+    __shared__ uint32_t wtot[NW];
+    __shared__ uint32_t wmax[NW];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t vmax = 0;
+    for (int base = 0; base < T; base += BIN_THREADS) {
+        const int i = base + threadIdx.x;
+        // counters were accumulated by atomics of other workgroups (other XCDs): device-scope load
+        const uint32_t v = (i < T) ? __hip_atomic_load(&tile_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        vmax = max(vmax, v);
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wtot[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wtot[w];
+        const uint32_t carry = carry_s;
+        if (i < T) {
+            const uint32_t first = carry + woff + x - v;
+            ranges[i] = v ? make_uint2(first, first + v) : make_uint2(0u, 0u);   // untouched tiles: (0,0) like the reference
+            cursor[i] = 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == BIN_THREADS - 1) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
+    if (lane == 0) wmax[wave] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0;
+        for (int w = 0; w < NW; w++) m = max(m, wmax[w]);
+        const uint32_t total = carry_s;
+        const uint32_t flags = __hip_atomic_load(&ctrl[GFT_CTRL_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctrl[GFT_CTRL_TOTAL] = total;
+        ctrl[GFT_CTRL_MAXCNT] = m;
+        if (mail) {
+            mail[GFT_CTRL_TOTAL] = total;
+            mail[GFT_CTRL_FLAGS] = flags;
+            mail[GFT_CTRL_MAXCNT] = m;
+            __hip_atomic_store(&mail[GFT_CTRL_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <bool USE_LDS>
 __global__ __launch_bounds__(BIN_THREADS) void k_tile_count(int P, int gx, int T, const ushort4* __restrict__ rect,
-                                                          uint32_t* __restrict__ tile_cnt)
+                                                          uint32_t* tile_cnt, uint2* __restrict__ ranges,
+                                                          uint32_t* __restrict__ cursor, uint32_t* ctrl,
+                                                          uint32_t* mail, uint32_t seq)
 {
     extern __shared__ uint32_t hist[];
+    __shared__ uint32_t s_last;
     const int tid = threadIdx.x;
     if (USE_LDS) {
         for (int i = tid; i < T; i += BIN_THREADS) hist[i] = 0;
@@ -54,58 +130,21 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_count(int P, int gx, int T
     if (USE_LDS) {
         __syncthreads();
         for (int i = tid; i < T; i += BIN_THREADS) {
-            const uint32_t h = hist[i];
-            if (h) atomicAdd(&tile_cnt[i], h);
+            const int t = rotated_tile(i, T);
+            const uint32_t h = hist[t];
+            if (h) atomicAdd(&tile_cnt[t], h);
         }
     }
-}
-
-// One workgroup: ranges = exclusive scan of tile_cnt; totals into ctrl; cursors zeroed.
-__global__ __launch_bounds__(1024) void k_tile_scan(int T, const uint32_t* __restrict__ tile_cnt,
-                                                    uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
-                                                    uint32_t* __restrict__ ctrl)
-{
-    __shared__ uint32_t wtot[16];
-    __shared__ uint32_t wmax[16];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
+    // The workgroup that draws the last ticket scans.  Every counter update above is a
+    // device-scope atomic, complete once vmcnt drains, and the scan reads the counters with
+    // device-scope loads: no cache write-back / invalidate (__threadfence would flush the
+    // L2 lines the preprocess kernel just wrote, ~50 us) is needed for that hand-over.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t vmax = 0;
-    for (int base = 0; base < T; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = (i < T) ? tile_cnt[i] : 0u;
-        vmax = max(vmax, v);
-        uint32_t x = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d, 64);
-            if (lane >= d) x += y;
-        }
-        if (lane == 63) wtot[wave] = x;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; w++) woff += wtot[w];
-        const uint32_t carry = carry_s;
-        if (i < T) {
-            const uint32_t first = carry + woff + x - v;
-            ranges[i] = v ? make_uint2(first, first + v) : make_uint2(0u, 0u);   // untouched tiles: (0,0) like the reference
-            cursor[i] = 0;
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + x;
-        __syncthreads();
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
-    if (lane == 0) wmax[wave] = vmax;
+    if (tid == 0) s_last = atomicAdd(&ctrl[GFT_CTRL_DONE], 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t m = 0;
-        for (int w = 0; w < 16; w++) m = max(m, wmax[w]);
-        ctrl[GFT_CTRL_TOTAL] = carry_s;
-        ctrl[GFT_CTRL_MAXCNT] = m;
-    }
+    if (!s_last) return;
+    tile_scan_block(T, tile_cnt, ranges, cursor, ctrl, mail, seq);
 }
 
 template <bool USE_LDS>
@@ -113,9 +152,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int
                                                             const float* __restrict__ depth,
                                                             const uint2* __restrict__ ranges,
                                                             uint32_t* __restrict__ cursor,
-                                                            uint64_t* __restrict__ keys)
+                                                            uint64_t* __restrict__ keys,
+                                                            const uint32_t* __restrict__ ctrl, uint32_t cap)
 {
     extern __shared__ uint32_t sh[];
+    if (ctrl[GFT_CTRL_TOTAL] > cap) return;      // binning buffer too small: the host re-runs stage 2
     uint32_t* cnt = sh;          // [T] instances of this block per tile, then running slot
     uint32_t* first = sh + T;    // [T] global position of this block's chunk in the tile segment
     const int tid = threadIdx.x;
@@ -134,10 +175,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int
         }
         __syncthreads();
         for (int i = tid; i < T; i += BIN_THREADS) {
-            const uint32_t c = cnt[i];
+            const int t = rotated_tile(i, T);
+            const uint32_t c = cnt[t];
             if (c) {
-                first[i] = ranges[i].x + atomicAdd(&cursor[i], c);
-                cnt[i] = 0;
+                first[t] = ranges[t].x + atomicAdd(&cursor[t], c);
+                cnt[t] = 0;
             }
         }
         __syncthreads();
@@ -294,9 +336,11 @@ __device__ __forceinline__ void bitonic_blocked(uint64_t* sk, int tid)
 // Sort class A: tile lists of up to 4096 keys, 33.8 KB of LDS.
 __global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_small(const uint2* __restrict__ ranges,
                                                                const uint64_t* __restrict__ keys,
-                                                               uint32_t* __restrict__ point_list)
+                                                               uint32_t* __restrict__ point_list,
+                                                               const uint32_t* __restrict__ ctrl, uint32_t cap)
 {
     __shared__ uint64_t sk[4096 + 128];
+    if (ctrl[GFT_CTRL_TOTAL] > cap) return;
     const uint2 r = ranges[blockIdx.x];
     const uint32_t n = r.y - r.x;
     if (n == 0 || n > 4096u) return;
@@ -322,41 +366,40 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_small(const uint2* __re
     for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[sort_slot(i)];
 }
 
-// Sort class B: tile lists of 4097..16384 keys, 128 KB of dynamic LDS (rare).
-__global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_lds(const uint2* __restrict__ ranges,
-                                                             const uint64_t* __restrict__ keys,
+// Sort classes B and C (rare): tile lists of 4097..16384 keys are sorted in 128 KB of dynamic
+// LDS, longer ones in place in global memory with the same network.  A few workgroups stride
+// over the tile table, so a frame without long lists costs one short launch.
+__global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_big(int T, const uint2* __restrict__ ranges, uint64_t* keys,
                                                              uint32_t* __restrict__ point_list, uint32_t lo,
-                                                             uint32_t hi)
+                                                             uint32_t hi, const uint32_t* __restrict__ ctrl,
+                                                             uint32_t cap)
 {
     extern __shared__ uint64_t sk_dyn[];
     uint64_t* sk = sk_dyn;
-    const uint2 r = ranges[blockIdx.x];
-    const uint32_t n = r.y - r.x;
-    if (n <= lo || n > hi) return;
+    if (ctrl[GFT_CTRL_TOTAL] > cap) return;
+    if (ctrl[GFT_CTRL_MAXCNT] <= lo) return;
     const int tid = threadIdx.x;
-    const uint32_t npad = next_pow2(n);
-    for (uint32_t i = tid; i < n; i += GFT_BLOCK) sk[i] = keys[r.x + i];
-    __syncthreads();
-    bitonic_ascending(n, npad, tid, [&](uint32_t i) { return sk[i]; }, [&](uint32_t i, uint64_t v) { sk[i] = v; },
-                      [] { __syncthreads(); });
-    for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[i];
-}
-
-// Fallback for tile lists that do not fit LDS: same network on the key segment in global
-// memory (in place), one workgroup per tile.
-__global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_global(const uint2* __restrict__ ranges, uint64_t* keys,
-                                                                uint32_t* __restrict__ point_list, uint32_t lo)
-{
-    const uint2 r = ranges[blockIdx.x];
-    const uint32_t n = r.y - r.x;
-    if (n <= lo) return;
-    const int tid = threadIdx.x;
-    uint64_t* seg = keys + r.x;
-    const uint32_t npad = next_pow2(n);
-    bitonic_ascending(n, npad, tid, [&](uint32_t i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
-                      [&](uint32_t i, uint64_t v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
-                      [] { __threadfence_block(); __syncthreads(); });
-    for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)seg[i];
+    for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
+        const uint2 r = ranges[tile];
+        const uint32_t n = r.y - r.x;
+        if (n <= lo) continue;                       // uniform per workgroup
+        const uint32_t npad = next_pow2(n);
+        if (n <= hi) {
+            for (uint32_t i = tid; i < n; i += GFT_BLOCK) sk[i] = keys[r.x + i];
+            __syncthreads();
+            bitonic_ascending(n, npad, tid, [&](uint32_t i) { return sk[i]; },
+                              [&](uint32_t i, uint64_t v) { sk[i] = v; }, [] { __syncthreads(); });
+            for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[i];
+            __syncthreads();
+        } else {
+            uint64_t* seg = keys + r.x;
+            bitonic_ascending(n, npad, tid,
+                              [&](uint32_t i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
+                              [&](uint32_t i, uint64_t v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
+                              [] { __threadfence_block(); __syncthreads(); });
+            for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)seg[i];
+        }
+    }
 }
 
 }  // namespace
@@ -364,23 +407,23 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_global(const uint2* __r
 #define SORT_LDS_SMALL 4096u      // 32 KB of LDS
 #define SORT_LDS_LARGE 16384u     // 128 KB of LDS
 
-hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im)
+hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
+                                 uint32_t* mail, uint32_t seq)
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
-    hipError_t e = hipMemsetAsync(im.tile_cnt, 0, (size_t)T * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
     const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
     if (T <= BIN_LDS_MAX_TILES)
-        hipLaunchKernelGGL(k_tile_count<true>, dim3(blocks), dim3(BIN_THREADS), (size_t)T * 4, s, c.P, gx, T, g.rect, im.tile_cnt);
+        hipLaunchKernelGGL(k_tile_count<true>, dim3(blocks), dim3(BIN_THREADS), (size_t)T * 4, s, c.P, gx, T, g.rect,
+                           im.tile_cnt, im.ranges, im.tile_cursor, im.ctrl, mail, seq);
     else
-        hipLaunchKernelGGL(k_tile_count<false>, dim3(blocks), dim3(BIN_THREADS), 0, s, c.P, gx, T, g.rect, im.tile_cnt);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, im.tile_cnt, im.ranges, im.tile_cursor, g.ctrl);
+        hipLaunchKernelGGL(k_tile_count<false>, dim3(blocks), dim3(BIN_THREADS), 0, s, c.P, gx, T, g.rect, im.tile_cnt,
+                           im.ranges, im.tile_cursor, im.ctrl, mail, seq);
     return hipGetLastError();
 }
 
 hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                   const BinView& b)
+                                   const BinView& b, uint32_t cap)
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
@@ -393,30 +436,30 @@ hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const Geo
             attr_set = true;
         }
         hipLaunchKernelGGL(k_tile_scatter<true>, dim3(blocks), dim3(BIN_THREADS), (size_t)T * 8, s, c.P, gx, T, g.rect,
-                           g.depth, im.ranges, im.tile_cursor, b.keys);
+                           g.depth, im.ranges, im.tile_cursor, b.keys, im.ctrl, cap);
     } else {
         hipLaunchKernelGGL(k_tile_scatter<false>, dim3(blocks), dim3(BIN_THREADS), 0, s, c.P, gx, T, g.rect, g.depth,
-                           im.ranges, im.tile_cursor, b.keys);
+                           im.ranges, im.tile_cursor, b.keys, im.ctrl, cap);
     }
     return hipGetLastError();
 }
 
-hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b)
+hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_tile_list, const ImgView& im,
+                                const BinView& b, uint32_t cap)
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort_lds),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort_big),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_LARGE * 8);
         attr_set = true;
     }
-    // Three size classes, always launched (a workgroup whose tile is in another class exits at
-    // once): that keeps the host from having to read the longest list length back.
-    hipLaunchKernelGGL(k_tile_sort_small, dim3(T), dim3(GFT_BLOCK), 0, s, im.ranges, b.keys, b.point_list);
-    hipLaunchKernelGGL(k_tile_sort_lds, dim3(T), dim3(GFT_BLOCK), (size_t)SORT_LDS_LARGE * 8, s, im.ranges, b.keys,
-                       b.point_list, SORT_LDS_SMALL, SORT_LDS_LARGE);
-    hipLaunchKernelGGL(k_tile_sort_global, dim3(T), dim3(GFT_BLOCK), 0, s, im.ranges, b.keys, b.point_list,
-                       SORT_LDS_LARGE);
+    hipLaunchKernelGGL(k_tile_sort_small, dim3(T), dim3(GFT_BLOCK), 0, s, im.ranges, b.keys, b.point_list, im.ctrl, cap);
+    // the longest list (known to the host in the two-stage flow, <= 0 otherwise) tells whether
+    // any tile needs the large classes
+    if (max_tile_list <= 0 || max_tile_list > (int64_t)SORT_LDS_SMALL)
+        hipLaunchKernelGGL(k_tile_sort_big, dim3(T < 256 ? T : 256), dim3(GFT_BLOCK), (size_t)SORT_LDS_LARGE * 8, s, T,
+                           im.ranges, b.keys, b.point_list, SORT_LDS_SMALL, SORT_LDS_LARGE, im.ctrl, cap);
     return hipGetLastError();
 }

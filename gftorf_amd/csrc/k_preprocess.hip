@@ -387,6 +387,7 @@ struct PreFwdArgs {
     gft_config c;
     gft_forward_io io;
     GeomView g;
+    uint32_t* ctrl;
     float focal_x, focal_y, dist2phase;
     int gx, gy;
     int stage_sh, stage_shp;   // SH rows staged through LDS (M == 16)
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
         const Mat16 V = load_mat(a.io.viewmatrix);
         const float vz = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
         if (vz < a.c.near_n || vz > a.c.far_n) {
-            if (a.c.prefiltered) atomicOr(&a.g.ctrl[GFT_CTRL_FLAGS], 1u);
+            if (a.c.prefiltered) atomicOr(&a.ctrl[GFT_CTRL_FLAGS], 1u);
         } else {
             const float vx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
             const float vy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
@@ -948,12 +949,14 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_mark_visible(int P, const float* 
 
 }  // namespace
 
-hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g)
+hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
+                                     const ImgView& im)
 {
     PreFwdArgs a;
     a.c = c;
     a.io = io;
     a.g = g;
+    a.ctrl = im.ctrl;
     // reference rasterizer_impl.cu:249-250, forward.cu:752
     a.focal_y = c.H / (2.0f * c.tanfovy);
     a.focal_x = c.W / (2.0f * c.tanfovx);

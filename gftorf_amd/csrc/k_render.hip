@@ -91,6 +91,8 @@ struct RenderFwdArgs {
     float* out_color; float* out_phasor; float* out_depth; float* out_normal; float* out_acc;
     float* out_entropy; float* out_dd; float* out_ad; float* out_distribution;
     float* pixels;
+    const uint32_t* __restrict__ ctrl;   // NULL: no instance-count check
+    uint32_t cap;
 };
 
 __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
@@ -100,6 +102,8 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     __shared__ uint32_t sId[RB];
     __shared__ uint32_t sCnt[RB];
 
+    // binning buffer smaller than the instance count: nothing was binned, the host re-runs stage 2
+    if (a.ctrl && a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
     const int V = a.T * 4;
     const int v = unit_of_block(blockIdx.x, V);
     if (v >= V) return;
@@ -510,9 +514,11 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
 }  // namespace
 
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
-                                 const ImgView& im, const BinView& b)
+                                 const ImgView& im, const BinView& b, bool check_cap, uint32_t cap)
 {
     RenderFwdArgs a;
+    a.ctrl = check_cap ? im.ctrl : nullptr;
+    a.cap = cap;
     a.W = c.W; a.H = c.H;
     a.gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X;
     const int gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;

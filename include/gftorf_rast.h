@@ -7,7 +7,7 @@
  * submodules/diff-gaussian-rasterization-w-tof/ of brownvc/gftorf):
  *
  *   _C.rasterize_gaussians           (RAST/rasterize_points.cu:42-165)
- *        -> gft_forward_preprocess() + gft_forward_render()
+ *        -> gft_forward_preprocess() + gft_forward_render(), or gft_forward()
  *   _C.rasterize_gaussians_backward  (RAST/rasterize_points.cu:167-281)
  *        -> gft_backward()
  *   _C.mark_visible                  (RAST/rasterize_points.cu:283-304)
@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GFT_ABI_VERSION 1
+#define GFT_ABI_VERSION 2
 
 /* compile-time constants of the reference (RAST/cuda_rasterizer/config.h:15-23) */
 #define GFT_NUM_CHANNELS 3
@@ -162,12 +162,12 @@ typedef struct gft_layout {
     size_t geom_rect;         /* uint16[P][4] tile rectangle {x0,y0,x1,y1} (all 0 when culled) */
     size_t geom_dirgrad;      /* float[P][16] d rgb/d dir (9), d (phase,amp)/d dir (6), pad; only with want_backward */
     size_t geom_clamped;      /* uint8[P]     bit0..2 rgb clamped, bit3 amplitude clamped */
-    size_t geom_ctrl;         /* uint32[8]    {R, flags, max tile list length, ...} */
     size_t geom_total;
     /* img */
     size_t img_pix_state;     /* float[N][4]  {final_T, n_contrib(bits), w_z, w_z2} */
     size_t img_ranges;        /* uint32[T][2] [first,last) of the tile's list */
     size_t img_tile_max;      /* uint32[T][4] max n_contrib over each 8x8 quadrant of the tile */
+    size_t img_ctrl;          /* uint32[8]    {R, flags, max tile list length, ...}; tile_cnt follows directly */
     size_t img_tile_cnt;      /* uint32[T]    instances per tile */
     size_t img_tile_cursor;   /* uint32[T]    scatter cursors */
     size_t img_tile_order;    /* uint32[T]    tiles by backward weight (written by gft_backward) */
@@ -194,19 +194,37 @@ size_t gft_binning_bytes(int64_t R, int32_t W, int32_t H);
 size_t gft_acc_bytes(int32_t P);
 int gft_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* out /*host*/);
 
-/* Stage 1 of the forward: preprocess (reference K1) + inclusive scan, then one
- * blocking read of the number of (Gaussian, tile) instances, exactly where the
- * reference blocks (RAST/cuda_rasterizer/rasterizer_impl.cu:311).
- * *num_rendered (host) receives R; the caller then sizes `binning`. */
+/* The forward in two stages, shaped like the reference's resize callbacks
+ * (RAST/rasterize_points.cu:27-33): the binning buffer is sized after stage 1.
+ *
+ * Stage 1: preprocess (reference K1), per-tile instance counts and their scan, then
+ * the one blocking read of the number of (Gaussian, tile) instances, where the
+ * reference blocks too (RAST/cuda_rasterizer/rasterizer_impl.cu:311).  The device
+ * posts the totals into pinned host memory which this call polls.
+ * *num_rendered (host) receives R; the caller then sizes `binning` for R instances. */
 int gft_forward_preprocess(void* hip_stream, const gft_config* cfg,
-                           const gft_forward_io* io, int64_t* num_rendered /*host*/);
+                           const gft_forward_io* io, int64_t* num_rendered /*host*/,
+                           int64_t* max_tile_list /*host, may be NULL: longest per-tile list*/);
 
-/* Stage 2 of the forward: duplicate-with-keys, sort, tile ranges, per-tile blend. */
+/* Stage 2: per-tile key scatter, per-tile sort, per-tile blend.
+ * `binning_instances` = the instance count `binning` was sized for (>= R); the same
+ * value goes to gft_backward, it fixes the layout inside the buffer. */
 int gft_forward_render(void* hip_stream, const gft_config* cfg,
-                       const gft_forward_io* io, int64_t num_rendered);
+                       const gft_forward_io* io, int64_t binning_instances,
+                       int64_t max_tile_list /* from stage 1; <= 0 = unknown */);
+
+/* The forward in one call, for callers that can guess R (a training loop: R of the
+ * previous iteration plus headroom).  `io->binning` holds `binning_instances`
+ * instances.  Both stages are queued back to back, so the device never waits for the
+ * host; the call returns as soon as the device has posted R (stage 2 may still run).
+ * If *num_rendered > binning_instances the stage-2 kernels have done nothing (they
+ * compare the device-side count themselves): allocate for *num_rendered and call
+ * gft_forward_render().  Results are identical to the two-stage flow. */
+int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
+                int64_t binning_instances, int64_t* num_rendered /*host*/);
 
 int gft_backward(void* hip_stream, const gft_config* cfg,
-                 const gft_backward_io* io, int64_t num_rendered);
+                 const gft_backward_io* io, int64_t binning_instances);
 
 int gft_mark_visible(void* hip_stream, int32_t P, const float* means3D,
                      const float* viewmatrix, const float* projmatrix,

@@ -72,7 +72,9 @@ def test_size_queries_and_layout_need_no_gpu(lib):
     assert lib.gft_image_bytes(640, 480) >= 640 * 480 * 16 + 1200 * 12
     L = _lib.get_layout(1000, 640, 480, 5000)
     offs = [getattr(L, n) for n in _lib.LAYOUT_FIELDS]
-    assert all(o % 256 == 0 for o in offs)
+    # every region is 256-B aligned, except tile_cnt which directly follows the 32-B ctrl block
+    assert all(o % 256 == 0 for n, o in zip(_lib.LAYOUT_FIELDS, offs) if n != "img_tile_cnt")
+    assert L.img_tile_cnt == L.img_ctrl + 32
     assert L.geom_rec_b >= 32 * 1000 and L.bin_point_list >= 8 * 5000 and L.bin_total >= 12 * 5000
     assert lib.gft_binning_bytes(0, 640, 480) >= 0
 
@@ -83,13 +85,13 @@ def test_argument_errors_are_reported(lib):
     c.P, c.W, c.H, c.D, c.M = 4, 64, 64, 5, 16
     io = _lib.ForwardIO()
     R = C.c_int64(0)
-    assert lib.gft_forward_preprocess(None, C.byref(c), C.byref(io), C.byref(R)) != 0
+    assert lib.gft_forward_preprocess(None, C.byref(c), C.byref(io), C.byref(R), None) != 0
     assert "sh_degree" in _lib.last_error()
     c.D, c.M = 3, 4
-    assert lib.gft_forward_preprocess(None, C.byref(c), C.byref(io), C.byref(R)) != 0
+    assert lib.gft_forward_preprocess(None, C.byref(c), C.byref(io), C.byref(R), None) != 0
     assert "coefficients" in _lib.last_error()
     c.M = 16
-    assert lib.gft_forward_preprocess(None, C.byref(c), C.byref(io), C.byref(R)) != 0
+    assert lib.gft_forward_preprocess(None, C.byref(c), C.byref(io), C.byref(R), None) != 0
     assert "NULL" in _lib.last_error()
 
 

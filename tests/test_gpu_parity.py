@@ -60,12 +60,13 @@ def raw_forward(scene, dev, inputs=None):
         setattr(io, n, planes[a].data_ptr())
     io.pixels, io.radii = p(pixels), p(radii)
     R = C.c_int64(0)
+    MX = C.c_int64(0)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    _lib.check(lib.gft_forward_preprocess(stream, C.byref(c), C.byref(io), C.byref(R)))
+    _lib.check(lib.gft_forward_preprocess(stream, C.byref(c), C.byref(io), C.byref(R), C.byref(MX)))
     R = int(R.value)
     binning = torch.zeros(lib.gft_binning_bytes(R, W, H), device=dev, dtype=torch.uint8)
     io.binning = p(binning)
-    _lib.check(lib.gft_forward_render(stream, C.byref(c), C.byref(io), R))
+    _lib.check(lib.gft_forward_render(stream, C.byref(c), C.byref(io), R, int(MX.value)))
     torch.cuda.synchronize()
     L = _lib.get_layout(P, W, H, R)
     keep = (T, view, proj, campos, bg)
@@ -83,7 +84,7 @@ def raw_forward(scene, dev, inputs=None):
         tiles=view_of(geom, L.geom_tiles, P, torch.int32).astype(np.uint32),
         rect=view_of(geom, L.geom_rect, P * 4, torch.int16).astype(np.uint16).reshape(P, 4),
         clamped=view_of(geom, L.geom_clamped, P, torch.uint8),
-        ctrl=view_of(geom, L.geom_ctrl, 8, torch.int32).astype(np.uint32),
+        ctrl=view_of(img, L.img_ctrl, 8, torch.int32).astype(np.uint32),
         pix_state=view_of(img, L.img_pix_state, W * H * 4, torch.float32).reshape(H * W, 4),
         ranges=view_of(img, L.img_ranges, Tn * 2, torch.int32).astype(np.uint32).reshape(Tn, 2),
         tile_max=view_of(img, L.img_tile_max, Tn * 4, torch.int32).astype(np.uint32).reshape(Tn, 4),
@@ -342,3 +343,35 @@ def test_two_calls_accumulate_on_shared_means2d(oracle, gpu):
     with torch.no_grad():
         o3 = r(**kw)
     torch.testing.assert_close(o3[0], o1[0].detach(), rtol=0, atol=0)
+
+
+def test_one_call_forward_matches_two_stage(oracle, gpu):
+    """gft_forward (binning buffer sized from the previous frame, no host round trip) must give
+    the results of the two-stage flow bit for bit: with headroom, with an exact fit, and when the
+    guess is too small (stage-2 kernels skip themselves, the host re-runs stage 2)."""
+    from gftorf_amd import api
+    scene = Hh.small_scene(P=3000, seed=11)
+    api._instance_hint.clear()
+    ref_out, ref_grads, _ = Hh.run_gpu(scene, gpu)               # first frame: two-stage flow
+    R = api.last_call_stats["num_rendered"]
+    assert R > 0 and api.last_call_stats["binning_instances"] == R and not api.last_call_stats["restarted"]
+    key = next(iter(api._instance_hint))
+    for hint, restarted in ((None, False), (R, False), (1, True), (0, True)):
+        if hint is not None:
+            api._instance_hint[key] = hint
+        out, grads, _ = Hh.run_gpu(scene, gpu)
+        st = api.last_call_stats
+        assert st["num_rendered"] == R and st["restarted"] == restarted
+        assert st["binning_instances"] >= R
+        for k in ref_out:
+            np.testing.assert_array_equal(out[k], ref_out[k], err_msg=k)
+        for k in ref_grads:
+            if ref_grads[k] is not None:
+                # atomics: summation order differs between runs
+                Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
+    # a frame with far fewer instances than the guess
+    small = Hh.small_scene(P=3000, seed=11)
+    small["gaussians"]["opacities"] = np.full_like(small["gaussians"]["opacities"], 1e-4)   # all culled (alpha < 1/255)
+    f, b = Hh.run_oracle(oracle, small)
+    out, grads, _ = Hh.run_gpu(small, gpu)
+    check_outputs(f, out)
