@@ -258,36 +258,41 @@ __device__ __forceinline__ float swap16_add(float x, float y)
     return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
-__device__ __forceinline__ float row_sum_to_lane15(float v)
+// Last stage of the wave reduction: four registers, each holding in every 16-lane row the 16
+// partials of one value, are folded into one register.  Folding two registers with a lane
+// exchange costs two DPP adds (each writes one half of the lanes via bank_mask) and halves
+// the partial count of both, so 4 registers x 16 partials need 4 + 2 + 2 instructions instead
+// of the 4 x 4 of a per-register scan.  Afterwards quad q of row r holds, in all four lanes,
+// the total of the value that register q had in row r.  (VALU write -> DPP read of the same
+// VGPR needs two wait states: s_nop where the schedule does not provide them.)
+__device__ __forceinline__ float row_fold4(float t0, float t1, float t2, float t3)
 {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), GFT_DPP_ROW_SHR(1), 0xf, 0xf, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), GFT_DPP_ROW_SHR(2), 0xf, 0xf, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), GFT_DPP_ROW_SHR(4), 0xf, 0xf, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), GFT_DPP_ROW_SHR(8), 0xf, 0xf, false));
-    return v;
-}
-
-// Inclusive scan inside every 16-lane row of four registers at once (lane 15/31/47/63 end up
-// with the row totals).  One v_add_f32_dpp per step and register; the four chains are
-// interleaved so consecutive DPP reads of a register are three instructions apart (the
-// VALU-write -> DPP-read hazard needs two wait states, covered by the leading s_nop for the
-// first step).
-__device__ __forceinline__ void row_scan4(float& t0, float& t1, float& t2, float& t3)
-{
-#define GFT_DPP_STEP(N)                                                                    \
-    "v_add_f32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-    "v_add_f32_dpp %1, %1, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-    "v_add_f32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-    "v_add_f32_dpp %3, %3, %3 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-    asm volatile("s_nop 1\n\t" GFT_DPP_STEP(1) GFT_DPP_STEP(2) GFT_DPP_STEP(4) GFT_DPP_STEP(8) "s_nop 1"
-                 : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
-#undef GFT_DPP_STEP
+    asm volatile(
+        "s_nop 1\n\t"
+        // distance 8: t0 <- {t0 | t2}, t1 <- {t1 | t3}   (lanes 0-7 | lanes 8-15 of every row)
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 0\n\t"
+        // distance 4: quads {t0, t1, t2, t3}
+        "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1\n\t"
+        // inside the quads
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(t0), "+v"(t1)
+        : "v"(t2), "v"(t3));
+    return t0;
 }
 
 // Sum 15 per-lane values over the 64 lanes of the wave and store the totals to row[0..14]
 // (row[15] receives a duplicate) in LDS.  Halving tree: 15 -> 8 registers (lane halves:
-// value i | value i+8), 8 -> 4 (16-lane rows: values i, i+4, i+8, i+12), then a 4-step DPP
-// scan inside each row; lane 15 + 16 r owns values 4 r' .. with one 16-byte LDS store.
+// value i | value i+8), 8 -> 4 (16-lane rows: values i, i+4, i+8, i+12), then row_fold4:
+// quad q of row r ends up with value 4 r + q, stored by its first lane (16 lanes x 4 bytes).
 __device__ __forceinline__ void wave_reduce15_store(const float* v, float* row, int lane)
 {
     float s[8];
@@ -297,11 +302,9 @@ __device__ __forceinline__ void wave_reduce15_store(const float* v, float* row, 
     float t[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) t[i] = swap16_add(s[i], s[i + 4]);      // rows: i, i+4, i+8, i+12 (i = 3: 3,7,11,7)
-    row_scan4(t[0], t[1], t[2], t[3]);
-    if ((lane & 15) == 15) {
-        const int r = lane >> 4;                                        // row r holds values r*4 + i in t[i]
-        *reinterpret_cast<float4*>(row + 4 * r) = make_float4(t[0], t[1], t[2], t[3]);
-    }
+    const float tot = row_fold4(t[0], t[1], t[2], t[3]);                // row r, quad q: value q + 4 r
+    // t[q] holds value q + 4 r in row r -> natural position 4 r + q = lane >> 2
+    if ((lane & 3) == 0) row[lane >> 2] = tot;
 }
 
 // Heavy-first launch order for the backward: the work of a quadrant is proportional to its
