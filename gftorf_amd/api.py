@@ -45,7 +45,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 # (Gaussian, tile) instance count of the most recent forward (diagnostics / bench)
-last_call_stats = {"num_rendered": 0, "binning_instances": 0, "restarted": False}
+last_call_stats = {"num_rendered": 0, "binning_instances": 0, "restarted": False, "max_tile_list": 0}
 
 # Instance count of the previous forward per (device, P, W, H).  A training loop renders
 # similar frames back to back, so the binning buffer can be sized before the device has
@@ -223,14 +223,16 @@ class _RasterizeGaussians(torch.autograd.Function):
                         cap = int(hint * _HINT_HEADROOM) + 4096
                         binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                         io.binning = binning.data_ptr()
-                        _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), cap, C.byref(num_rendered)))
+                        _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), cap, C.byref(num_rendered),
+                                                   C.byref(max_list)))
                         R = int(num_rendered.value)
                         if R > cap:
                             restarted = True
                             cap = R
                             binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                             io.binning = binning.data_ptr()
-                            _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, 0))
+                            _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap,
+                                                              int(max_list.value)))
                     _instance_hint[hint_key] = R
                     if len(_instance_hint) > 64:
                         _instance_hint.pop(next(iter(_instance_hint)))
@@ -244,7 +246,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = R
         ctx.binning_instances = cap if P else 0
         last_call_stats.update(num_rendered=R, binning_instances=ctx.binning_instances,
-                               restarted=bool(P) and restarted)
+                               restarted=bool(P) and restarted, max_tile_list=int(max_list.value) if P else 0)
         ctx.scalars = (ph_off, dc_off)
         ctx.want_bw = want_bw
         ctx.bg = (bg_c, bsc, bsy, bsx)

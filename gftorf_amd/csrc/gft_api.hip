@@ -420,8 +420,9 @@ extern "C" int gft_forward_render(void* hip_stream, const gft_config* cfg, const
 
 // ---- forward, one call ------------------------------------------------------------
 extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
-                           int64_t binning_instances, int64_t* num_rendered)
+                           int64_t binning_instances, int64_t* num_rendered, int64_t* max_tile_list)
 {
+    if (max_tile_list) *max_tile_list = 0;
     if (check_config(cfg)) return 1;
     if (!io || !num_rendered) return gft_fail("gft_forward: NULL argument");
     *num_rendered = 0;
@@ -446,6 +447,7 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     if (host[GFT_CTRL_FLAGS] & 1u)
         return gft_fail("Point is filtered although prefiltered is set. This shouldn't happen!");
     *num_rendered = (int64_t)host[GFT_CTRL_TOTAL];
+    if (max_tile_list) *max_tile_list = (int64_t)host[GFT_CTRL_MAXCNT];
     return 0;
 }
 

@@ -12,8 +12,9 @@
 //                    atomic per (block, tile)                           [8 B/Gaussian];
 //                    the last workgroup to finish scans the counters:
 //                    ranges[tile] = [first,last), R, longest list -> ctrl + host mailbox
-//   k_tile_scatter : each block reserves one chunk per tile with a single global atomic
-//                    and writes its (depth bits << 32 | id) keys there   [8 B/instance]
+//   k_tile_scatter : each block reserves one chunk per tile with a single global atomic,
+//                    groups its (depth bits << 32 | id) keys by tile in LDS and writes every
+//                    chunk with one instruction                          [8 B/instance]
 //   k_tile_sort    : one workgroup per tile: bitonic sort of the tile's keys in LDS
 //                    (all comparators ascending, so the power-of-two padding never
 //                    moves), writes the id list               [8 B read + 4 B written]
@@ -32,6 +33,7 @@ namespace {
 #endif
 #define BIN_CHUNK (BIN_THREADS * BIN_ITEMS)  // 4096 Gaussians per workgroup
 #define BIN_LDS_MAX_TILES 16384            // LDS histogram limit (2 x 64 KB in the scatter)
+#define BIN_STAGE_LDS_BYTES (156 * 1024)   // dynamic LDS of the staged scatter (160 KB per CU minus static)
 
 // Every workgroup walks the tile table from a different start so that the ~P/4096 workgroups
 // do not queue up on the same counter at the same time.
@@ -147,21 +149,35 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_count(int P, int gx, int T
     tile_scan_block(T, tile_cnt, ranges, cursor, ctrl, mail, seq);
 }
 
-template <bool USE_LDS>
+// MODE 0: global cursors only (tile table too large for LDS)
+// MODE 1: LDS counters, one reserved chunk per (workgroup, tile), keys written straight to HBM
+// MODE 2: as 1, but the workgroup's keys are first grouped by tile in LDS (`stage_cap` keys)
+//         and every chunk is then written by one instruction.  With direct 8-byte writes a
+//         chunk's line is touched a dozen times over the workgroup's lifetime and the ~30 MB
+//         key array does not stay in the 4 MB L2s: 100 MB of write-backs for 29 MB of keys
+//         (rocprofv3 WRITE_SIZE).  A workgroup with more instances than `stage_cap` writes
+//         directly (MODE 1 behaviour).
+template <int MODE>
 __global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int T, const ushort4* __restrict__ rect,
                                                             const float* __restrict__ depth,
                                                             const uint2* __restrict__ ranges,
                                                             uint32_t* __restrict__ cursor,
                                                             uint64_t* __restrict__ keys,
-                                                            const uint32_t* __restrict__ ctrl, uint32_t cap)
+                                                            const uint32_t* __restrict__ ctrl, uint32_t cap,
+                                                            uint32_t stage_cap)
 {
     extern __shared__ uint32_t sh[];
     if (ctrl[GFT_CTRL_TOTAL] > cap) return;      // binning buffer too small: the host re-runs stage 2
     uint32_t* cnt = sh;          // [T] instances of this block per tile, then running slot
     uint32_t* first = sh + T;    // [T] global position of this block's chunk in the tile segment
+    uint32_t* lstart = sh + 2 * T;                                   // [T] MODE 2: chunk start in the LDS stage
+    uint64_t* stage = reinterpret_cast<uint64_t*>(sh + 3 * T + (T & 1));   // MODE 2: stage_cap keys, 8-B aligned
+    __shared__ uint32_t s_wave_tot[BIN_THREADS / 64];
+    __shared__ uint32_t s_block_tot;
     const int tid = threadIdx.x;
     const int base = blockIdx.x * BIN_CHUNK;
-    if (USE_LDS) {
+    bool staged = false;
+    if (MODE >= 1) {
         for (int i = tid; i < T; i += BIN_THREADS) cnt[i] = 0;
         __syncthreads();
 #pragma unroll 4
@@ -174,6 +190,31 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int
             }
         }
         __syncthreads();
+        if (MODE == 2) {
+            // exclusive scan of cnt over the tile table: K consecutive tiles per thread
+            const int K = (T + BIN_THREADS - 1) / BIN_THREADS;
+            const int t0 = tid * K;
+            uint32_t mine = 0;
+            for (int k = 0; k < K; k++)
+                if (t0 + k < T) mine += cnt[t0 + k];
+            uint32_t x = mine;
+            const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if (lane >= d) x += y;
+            }
+            if (lane == 63) s_wave_tot[wave] = x;
+            __syncthreads();
+            uint32_t woff = 0;
+            for (int w = 0; w < wave; w++) woff += s_wave_tot[w];
+            if (tid == BIN_THREADS - 1) s_block_tot = woff + x;
+            uint32_t run = woff + x - mine;
+            for (int k = 0; k < K; k++)
+                if (t0 + k < T) { lstart[t0 + k] = run; run += cnt[t0 + k]; }
+            __syncthreads();
+            staged = s_block_tot <= stage_cap;
+        }
         for (int i = tid; i < T; i += BIN_THREADS) {
             const int t = rotated_tile(i, T);
             const uint32_t c = cnt[t];
@@ -194,12 +235,27 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int
                 for (int y = r.y; y < r.w; y++)
                     for (int x = r.x; x < r.z; x++) {
                         const int t = y * gx + x;
-                        uint32_t pos;
-                        if (USE_LDS) pos = first[t] + atomicAdd(&cnt[t], 1u);
-                        else pos = ranges[t].x + atomicAdd(&cursor[t], 1u);
-                        keys[pos] = key;
+                        if (MODE == 2 && staged) {
+                            stage[lstart[t] + atomicAdd(&cnt[t], 1u)] = key;
+                        } else {
+                            uint32_t pos;
+                            if (MODE >= 1) pos = first[t] + atomicAdd(&cnt[t], 1u);
+                            else pos = ranges[t].x + atomicAdd(&cursor[t], 1u);
+                            keys[pos] = key;
+                        }
                     }
             }
+        }
+    }
+    if (MODE == 2 && staged) {
+        __syncthreads();
+        // one wave per tile chunk: contiguous LDS run -> contiguous run of the tile segment
+        const int lane = tid & 63;
+        for (int t = tid >> 6; t < T; t += BIN_THREADS / 64) {
+            const uint32_t c = cnt[t];
+            if (c == 0) continue;
+            const uint32_t src = lstart[t], dst = first[t];
+            for (uint32_t i = lane; i < c; i += 64) keys[dst + i] = stage[src + i];
         }
     }
 }
@@ -207,12 +263,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int
 // Bitonic network with ascending comparators only: merge step k starts with the
 // mirror stage (i <-> i ^ (k-1)), then half-cleaners at distances k/4 .. 1.
 // Elements at positions >= n are +inf by construction and never move.
-template <typename Ld, typename St, typename Sync>
+template <int THREADS, typename Ld, typename St, typename Sync>
 __device__ __forceinline__ void bitonic_ascending(uint32_t n, uint32_t npad, int tid, Ld ld, St st, Sync sync)
 {
     for (uint32_t k = 2; k <= npad; k <<= 1) {
         const uint32_t half = k >> 1;
-        for (uint32_t c = tid; c < (npad >> 1); c += GFT_BLOCK) {
+        for (uint32_t c = tid; c < (npad >> 1); c += THREADS) {
             const uint32_t blk = c / half, off = c - blk * half;
             const uint32_t i = blk * k + off, l = blk * k + (k - 1 - off);
             if (l < n) {
@@ -222,7 +278,7 @@ __device__ __forceinline__ void bitonic_ascending(uint32_t n, uint32_t npad, int
         }
         sync();
         for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-            for (uint32_t c = tid; c < (npad >> 1); c += GFT_BLOCK) {
+            for (uint32_t c = tid; c < (npad >> 1); c += THREADS) {
                 const uint32_t i = ((c & ~(j - 1)) << 1) | (c & (j - 1)), l = i + j;
                 if (l < n) {
                     const uint64_t a = ld(i), b = ld(l);
@@ -242,7 +298,7 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t n)
 }
 
 // ---- register-blocked bitonic sort (lists of 1025..4096 keys) -------------------
-// Standard bitonic network on npad = 256 << LOG_E keys (+inf padded).  A thread owns
+// Standard bitonic network on npad = (1 << LOG_T) << LOG_E keys (+inf padded), 1 << LOG_T threads.  A thread owns
 // E = 2^LOG_E keys in registers; which keys depends on the layout b: the thread's register
 // index supplies key-index bits [b, b+LOG_E), the thread id supplies the rest.  All stages
 // whose distance bit falls inside [b, b+LOG_E) are compare-exchanges between registers; the
@@ -300,11 +356,11 @@ __device__ __forceinline__ void reg_stage_dyn(uint64_t* v, int s_local, int t, i
     }
 }
 
-template <int LOG_E>
+template <int LOG_E, int LOG_T>
 __device__ __forceinline__ void bitonic_blocked(uint64_t* sk, int tid)
 {
     constexpr int E = 1 << LOG_E;
-    constexpr int LG = 8 + LOG_E;          // log2(npad), 256 threads
+    constexpr int LG = LOG_T + LOG_E;      // log2(npad)
     uint64_t v[E];
     int b = 0;                             // current layout (compile-time after unrolling)
     regs_from_lds<LOG_E>(v, sk, tid, 0);
@@ -353,26 +409,28 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_small(const uint2* __re
         const uint32_t npad = next_pow2(n);
         for (uint32_t i = tid; i < n; i += GFT_BLOCK) sk[i] = keys[r.x + i];
         __syncthreads();
-        bitonic_ascending(n, npad, tid, [&](uint32_t i) { return sk[i]; }, [&](uint32_t i, uint64_t v) { sk[i] = v; },
-                          [] { __syncthreads(); });
+        bitonic_ascending<GFT_BLOCK>(n, npad, tid, [&](uint32_t i) { return sk[i]; }, [&](uint32_t i, uint64_t v) { sk[i] = v; },
+                                     [] { __syncthreads(); });
         for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[i];
         return;
     }
     const uint32_t npad = n <= 2048u ? 2048u : 4096u;
     for (uint32_t i = tid; i < npad; i += GFT_BLOCK) sk[sort_slot(i)] = i < n ? keys[r.x + i] : ~0ull;
     __syncthreads();
-    if (npad == 2048u) bitonic_blocked<3>(sk, tid);
-    else bitonic_blocked<4>(sk, tid);
+    if (npad == 2048u) bitonic_blocked<3, 8>(sk, tid);
+    else bitonic_blocked<4, 8>(sk, tid);
     for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[sort_slot(i)];
 }
 
-// Sort classes B and C (rare): tile lists of 4097..16384 keys are sorted in 128 KB of dynamic
-// LDS, longer ones in place in global memory with the same network.  A few workgroups stride
-// over the tile table, so a frame without long lists costs one short launch.
-__global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_big(int T, const uint2* __restrict__ ranges, uint64_t* keys,
-                                                             uint32_t* __restrict__ point_list, uint32_t lo,
-                                                             uint32_t hi, const uint32_t* __restrict__ ctrl,
-                                                             uint32_t cap)
+// Sort classes B and C: tile lists of 4097..16384 keys are sorted by 1024 threads with the
+// register-blocked network in 132 KB of dynamic LDS (8 or 16 keys per thread), longer ones in
+// place in global memory with the plain network.  Up to one workgroup per CU strides over the
+// tile table, so a frame without long lists costs one short launch.
+#define SORT_BIG_THREADS 1024
+__global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_sort_big(int T, const uint2* __restrict__ ranges,
+                                                                    uint64_t* keys, uint32_t* __restrict__ point_list,
+                                                                    uint32_t lo, uint32_t hi,
+                                                                    const uint32_t* __restrict__ ctrl, uint32_t cap)
 {
     extern __shared__ uint64_t sk_dyn[];
     uint64_t* sk = sk_dyn;
@@ -383,21 +441,23 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_big(int T, const uint2*
         const uint2 r = ranges[tile];
         const uint32_t n = r.y - r.x;
         if (n <= lo) continue;                       // uniform per workgroup
-        const uint32_t npad = next_pow2(n);
         if (n <= hi) {
-            for (uint32_t i = tid; i < n; i += GFT_BLOCK) sk[i] = keys[r.x + i];
+            const uint32_t npad = n <= 8192u ? 8192u : 16384u;
+            for (uint32_t i = tid; i < npad; i += SORT_BIG_THREADS) sk[sort_slot(i)] = i < n ? keys[r.x + i] : ~0ull;
             __syncthreads();
-            bitonic_ascending(n, npad, tid, [&](uint32_t i) { return sk[i]; },
-                              [&](uint32_t i, uint64_t v) { sk[i] = v; }, [] { __syncthreads(); });
-            for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[i];
+            if (npad == 8192u) bitonic_blocked<3, 10>(sk, tid);
+            else bitonic_blocked<4, 10>(sk, tid);
+            for (uint32_t i = tid; i < n; i += SORT_BIG_THREADS) point_list[r.x + i] = (uint32_t)sk[sort_slot(i)];
             __syncthreads();
         } else {
             uint64_t* seg = keys + r.x;
-            bitonic_ascending(n, npad, tid,
-                              [&](uint32_t i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
-                              [&](uint32_t i, uint64_t v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
-                              [] { __threadfence_block(); __syncthreads(); });
-            for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)seg[i];
+            const uint32_t npad = next_pow2(n);
+            bitonic_ascending<SORT_BIG_THREADS>(
+                n, npad, tid,
+                [&](uint32_t i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
+                [&](uint32_t i, uint64_t v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
+                [] { __threadfence_block(); __syncthreads(); });
+            for (uint32_t i = tid; i < n; i += SORT_BIG_THREADS) point_list[r.x + i] = (uint32_t)seg[i];
         }
     }
 }
@@ -405,7 +465,8 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_big(int T, const uint2*
 }  // namespace
 
 #define SORT_LDS_SMALL 4096u      // 32 KB of LDS
-#define SORT_LDS_LARGE 16384u     // 128 KB of LDS
+#define SORT_LDS_LARGE 16384u     // 128 KB of LDS (+ 4 KB of bank padding)
+#define SORT_LDS_LARGE_BYTES ((SORT_LDS_LARGE + SORT_LDS_LARGE / 32) * 8)
 
 hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
                                  uint32_t* mail, uint32_t seq)
@@ -428,19 +489,31 @@ hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const Geo
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
     const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
-    if (T <= BIN_LDS_MAX_TILES) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_scatter<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BIN_LDS_MAX_TILES * 4);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(k_tile_scatter<true>, dim3(blocks), dim3(BIN_THREADS), (size_t)T * 8, s, c.P, gx, T, g.rect,
-                           g.depth, im.ranges, im.tile_cursor, b.keys, im.ctrl, cap);
-    } else {
-        hipLaunchKernelGGL(k_tile_scatter<false>, dim3(blocks), dim3(BIN_THREADS), 0, s, c.P, gx, T, g.rect, g.depth,
-                           im.ranges, im.tile_cursor, b.keys, im.ctrl, cap);
+    if (T > BIN_LDS_MAX_TILES) {
+        hipLaunchKernelGGL(k_tile_scatter<0>, dim3(blocks), dim3(BIN_THREADS), 0, s, c.P, gx, T, g.rect, g.depth,
+                           im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, 0u);
+        return hipGetLastError();
     }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_scatter<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BIN_LDS_MAX_TILES * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_scatter<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BIN_STAGE_LDS_BYTES);
+        attr_set = true;
+    }
+    // Staging pays when a workgroup's instances (about cap / blocks; cap is R plus the caller's
+    // headroom) fit the LDS that the three per-tile tables leave free; workgroups that exceed it
+    // write directly.  It also pins one workgroup per CU, so it is not used when most would not fit.
+    const size_t tables = ((size_t)3 * T + (T & 1)) * 4;
+    const size_t stage_cap = tables + 4096 * 8 <= BIN_STAGE_LDS_BYTES ? (BIN_STAGE_LDS_BYTES - tables) / 8 : 0;
+    const size_t expect = blocks > 0 ? (size_t)cap / (size_t)blocks : 0;
+    if (stage_cap > 0 && expect <= stage_cap + stage_cap / 2)
+        hipLaunchKernelGGL(k_tile_scatter<2>, dim3(blocks), dim3(BIN_THREADS), tables + stage_cap * 8, s, c.P, gx, T,
+                           g.rect, g.depth, im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, (uint32_t)stage_cap);
+    else
+        hipLaunchKernelGGL(k_tile_scatter<1>, dim3(blocks), dim3(BIN_THREADS), (size_t)T * 8, s, c.P, gx, T, g.rect,
+                           g.depth, im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, 0u);
     return hipGetLastError();
 }
 
@@ -452,14 +525,14 @@ hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort_big),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_LARGE * 8);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_LARGE_BYTES);
         attr_set = true;
     }
     hipLaunchKernelGGL(k_tile_sort_small, dim3(T), dim3(GFT_BLOCK), 0, s, im.ranges, b.keys, b.point_list, im.ctrl, cap);
     // the longest list (known to the host in the two-stage flow, <= 0 otherwise) tells whether
     // any tile needs the large classes
     if (max_tile_list <= 0 || max_tile_list > (int64_t)SORT_LDS_SMALL)
-        hipLaunchKernelGGL(k_tile_sort_big, dim3(T < 256 ? T : 256), dim3(GFT_BLOCK), (size_t)SORT_LDS_LARGE * 8, s, T,
+        hipLaunchKernelGGL(k_tile_sort_big, dim3(T < 256 ? T : 256), dim3(SORT_BIG_THREADS), (size_t)SORT_LDS_LARGE_BYTES, s, T,
                            im.ranges, b.keys, b.point_list, SORT_LDS_SMALL, SORT_LDS_LARGE, im.ctrl, cap);
     return hipGetLastError();
 }

@@ -221,7 +221,8 @@ int gft_forward_render(void* hip_stream, const gft_config* cfg,
  * compare the device-side count themselves): allocate for *num_rendered and call
  * gft_forward_render().  Results are identical to the two-stage flow. */
 int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
-                int64_t binning_instances, int64_t* num_rendered /*host*/);
+                int64_t binning_instances, int64_t* num_rendered /*host*/,
+                int64_t* max_tile_list /*host, may be NULL*/);
 
 int gft_backward(void* hip_stream, const gft_config* cfg,
                  const gft_backward_io* io, int64_t binning_instances);
