@@ -25,6 +25,7 @@ class Config(C.Structure):
         ("phase_offset", C.c_float), ("dc_offset", C.c_float),
         ("use_view_dependent_phase", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("want_backward", C.c_int32),
+        ("acc_zeroed", C.c_int32),
         ("bg_stride_c", C.c_int64), ("bg_stride_y", C.c_int64), ("bg_stride_x", C.c_int64),
     ]
 
@@ -34,7 +35,7 @@ FORWARD_FIELDS = [
     "cov3D_precomp", "viewmatrix", "projmatrix", "campos", "shs", "shs_p",
     "geom", "img", "binning",
     "out_color", "out_phasor", "out_depth", "out_normal", "out_acc", "out_entropy",
-    "out_depth_distortion", "out_amp_distortion", "pixels", "out_distribution", "radii",
+    "out_depth_distortion", "out_amp_distortion", "pixels", "out_distribution", "radii", "acc",
 ]
 
 BACKWARD_FIELDS = [

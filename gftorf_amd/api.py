@@ -193,6 +193,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         io.out_depth_distortion, io.out_amp_distortion = depth_distortion.data_ptr(), amp_distortion.data_ptr()
         io.out_distribution = distribution.data_ptr()
         io.pixels, io.radii = _ptr(pixels) if P else None, _ptr(radii) if P else None
+        # the backward's accumulator: cleared by the forward under its render kernel
+        acc_buf = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32) if (want_bw and P) else None
+        io.acc = _ptr(acc_buf)
 
         R = 0
         if P == 0:
@@ -249,6 +252,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                restarted=bool(P) and restarted, max_tile_list=int(max_list.value) if P else 0)
         ctx.scalars = (ph_off, dc_off)
         ctx.want_bw = want_bw
+        ctx.acc = acc_buf          # zeroed, valid for the first backward of this forward
         ctx.bg = (bg_c, bsc, bsy, bsx)
         ctx.consts = (view_c, proj_c, campos_c)
         ctx.present = (sh_c is not None, sh_p_c is not None, colors_c is not None, phasors_c is not None,
@@ -305,9 +309,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_scales = torch.empty((P, 3), **f32) if has_scales else None
         grad_rotations = torch.empty((P, 4), **f32) if has_scales else None
         grad_offsets = torch.empty((2,), **f32)
-        acc = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32)
+        acc, ctx.acc = ctx.acc, None
+        acc_zeroed = acc is not None
+        if acc is None:            # second backward through the same forward (retain_graph)
+            acc = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32)
 
         cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), ctx.want_bw)
+        cfg.acc_zeroed = int(acc_zeroed)
         io = _lib.BackwardIO()
         io.bg, io.means3D, io.radii = _ptr(bg_c), _ptr(means3D) if P else None, _ptr(radii) if P else None
         io.scales = _ptr(scales) if has_scales else None

@@ -347,6 +347,10 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
                           const ImgView& im, const BinView& b, bool binned, int64_t max_tile_list, bool check_cap,
                           uint32_t cap)
 {
+    // The backward's accumulator clear (64 B per Gaussian of pure HBM writes) rides along with the
+    // tile sort, whose workgroups are bound by LDS and VALU: each writes a slice of zeros first.
+    float* clear = (io->acc && cfg->want_backward && cfg->P > 0) ? io->acc : nullptr;
+    const size_t clear_bytes = (size_t)cfg->P * GFT_ACC_STRIDE * sizeof(float);
     if (binned) {
         {
             StageTimer t(s, ST_TILE_SCATTER);
@@ -354,8 +358,10 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
         }
         {
             StageTimer t(s, ST_TILE_SORT);
-            GFT_STAGE(s, cfg, "tile_sort", gft_launch_tile_sort(s, *cfg, max_tile_list, im, b, cap));
+            GFT_STAGE(s, cfg, "tile_sort", gft_launch_tile_sort(s, *cfg, max_tile_list, im, b, cap, clear, clear_bytes));
         }
+    } else if (clear) {
+        GFT_CHECK_HIP(hipMemsetAsync(clear, 0, clear_bytes, s));
     }
     {
         StageTimer t(s, ST_RENDER_FWD);
@@ -482,7 +488,7 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     ImgView im = gft_img_view(const_cast<void*>(io->img), L);
     BinView b = gft_bin_view(const_cast<void*>(io->binning), L);
 
-    {
+    if (!cfg->acc_zeroed) {
         StageTimer t(s, ST_MEMSET);
         GFT_CHECK_HIP(hipMemsetAsync(io->acc, 0, (size_t)cfg->P * GFT_ACC_STRIDE * sizeof(float), s));
     }

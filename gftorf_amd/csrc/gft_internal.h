@@ -65,7 +65,7 @@ hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomV
 hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
                                    const BinView& b, uint32_t cap);
 hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_tile_list, const ImgView& im,
-                                const BinView& b, uint32_t cap);
+                                const BinView& b, uint32_t cap, float* clear, size_t clear_bytes);
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b, bool check_cap, uint32_t cap);
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,

@@ -393,10 +393,18 @@ __device__ __forceinline__ void bitonic_blocked(uint64_t* sk, int tid)
 __global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_small(const uint2* __restrict__ ranges,
                                                                const uint64_t* __restrict__ keys,
                                                                uint32_t* __restrict__ point_list,
-                                                               const uint32_t* __restrict__ ctrl, uint32_t cap)
+                                                               const uint32_t* __restrict__ ctrl, uint32_t cap,
+                                                               float4* __restrict__ clear, size_t clear_vec4)
 {
     __shared__ uint64_t sk[4096 + 128];
     if (ctrl[GFT_CTRL_TOTAL] > cap) return;
+    // fire-and-forget zero fill of the backward's accumulator (see gft_api.hip enqueue_stage2):
+    // the stores drain while this workgroup sorts in LDS
+    if (clear) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t i = (size_t)blockIdx.x * GFT_BLOCK + threadIdx.x; i < clear_vec4; i += (size_t)gridDim.x * GFT_BLOCK)
+            clear[i] = z;
+    }
     const uint2 r = ranges[blockIdx.x];
     const uint32_t n = r.y - r.x;
     if (n == 0 || n > 4096u) return;
@@ -518,7 +526,7 @@ hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const Geo
 }
 
 hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_tile_list, const ImgView& im,
-                                const BinView& b, uint32_t cap)
+                                const BinView& b, uint32_t cap, float* clear, size_t clear_bytes)
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
@@ -528,7 +536,8 @@ hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_LARGE_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_tile_sort_small, dim3(T), dim3(GFT_BLOCK), 0, s, im.ranges, b.keys, b.point_list, im.ctrl, cap);
+    hipLaunchKernelGGL(k_tile_sort_small, dim3(T), dim3(GFT_BLOCK), 0, s, im.ranges, b.keys, b.point_list, im.ctrl, cap,
+                       reinterpret_cast<float4*>(clear), clear_bytes / 16);
     // the longest list (known to the host in the two-stage flow, <= 0 otherwise) tells whether
     // any tile needs the large classes
     if (max_tile_list <= 0 || max_tile_list > (int64_t)SORT_LDS_SMALL)

@@ -66,6 +66,8 @@ typedef struct gft_config {
      * direction) so the backward does not have to re-read the 320 B of SH coefficients;
      * backward: that record is present in `geom` (same value as in the forward call) */
     int32_t want_backward;
+    /* backward only: `acc` was cleared by the forward (gft_forward_io.acc), skip the clear */
+    int32_t acc_zeroed;
     /* background [7,H,W] addressed as bg[c*sc + y*sy + x*sx] (element strides), so
      * the reference's expanded constant background (train.py:127) needs no copy */
     int64_t bg_stride_c, bg_stride_y, bg_stride_x;
@@ -104,6 +106,10 @@ typedef struct gft_forward_io {
     float* pixels;                 /* [P,1] contributing-pixel count per Gaussian */
     float* out_distribution;       /* [3,H,W] first-hit (alpha, dist, amplitude/d^2) */
     int32_t* radii;                /* [P] */
+    /* optional: the backward's accumulator (gft_acc_bytes(P)).  With want_backward the forward
+     * clears it as a side job of the LDS-bound tile sort (64 B/Gaussian of HBM writes that
+     * would otherwise be a separate pass of the backward); pass cfg.acc_zeroed to gft_backward. */
+    float* acc;
 } gft_forward_io;
 
 /* Tensors of the backward call (RAST/rasterize_points.cu:167-198). */
@@ -133,7 +139,8 @@ typedef struct gft_backward_io {
     const void* img;
     const void* binning;
     /* backward scratch of gft_acc_bytes(P) bytes: [P, GFT_ACC_STRIDE] floats (zeroed by the
-     * library) followed by two partial sums per 64-Gaussian block */
+     * library, here or -- cfg.acc_zeroed -- already in the forward) followed by two partial
+     * sums per 64-Gaussian block */
     float* acc;
     /* outputs, written in full (zeros for culled Gaussians); NULL = not wanted */
     float* dL_dmeans3D;     /* [P,3] */

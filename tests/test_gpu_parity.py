@@ -375,3 +375,24 @@ def test_one_call_forward_matches_two_stage(oracle, gpu):
     f, b = Hh.run_oracle(oracle, small)
     out, grads, _ = Hh.run_gpu(small, gpu)
     check_outputs(f, out)
+
+
+def test_backward_twice_through_one_forward(gpu):
+    """The forward clears the backward's accumulator (side stream); a second backward through the
+    same forward (retain_graph) must clear its own and give the same gradients."""
+    from gftorf_amd import GaussianRasterizer
+    scene = Hh.small_scene(P=400, seed=5)
+    st = Hh.gpu_settings(scene, gpu)
+    g = {k: torch.tensor(v, device=gpu, requires_grad=True) for k, v in scene["gaussians"].items()}
+    m2d = torch.zeros(400, 3, device=gpu, requires_grad=True)
+    out = GaussianRasterizer(st)(means3D=g["means3D"], means2D=m2d, opacities=g["opacities"], shs=g["shs"],
+                                 shs_p=g["shs_p"], scales=g["scales"], rotations=g["rotations"],
+                                 phase_offset=0.1, dc_offset=0.05)
+    loss = out[0].sum() + out[1].sum()
+    loss.backward(retain_graph=True)
+    first = {k: v.grad.clone() for k, v in g.items()}
+    for v in g.values():
+        v.grad = None
+    loss.backward()
+    for k, v in g.items():
+        torch.testing.assert_close(v.grad, first[k], rtol=1e-4, atol=1e-6)
