@@ -632,16 +632,18 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
         if (visible) {
             // accumulators written by the render backward
             const float4* ap = reinterpret_cast<const float4*>(a.io.acc + (size_t)idx * GFT_ACC_STRIDE);
-            // row = {dmean2D.xy, dconic.xyw, dopacity, dcolor[3], XR, XI, X2, XQ, ddist, dndc}
+            // row = {dcolor[3], ddist | dmean2D.xy, dconic.xy | XR, XI, X2, XQ | dconic.w, dopacity, dndc, -}
+            // (the order the render backward's pairwise wave reduction produces, k_render.hip)
             const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
-            dmean2d[0] = a0.x; dmean2d[1] = a0.y;
-            const float dconx = a0.z, dcony = a0.w, dconw = a1.x;
-            dopac = a1.y;
-            dcolor[0] = a1.z; dcolor[1] = a1.w; dcolor[2] = a2.x;
+            dcolor[0] = a0.x; dcolor[1] = a0.y; dcolor[2] = a0.z;
+            const float ddist_in = a0.w;
+            dmean2d[0] = a1.x; dmean2d[1] = a1.y;
+            const float dconx = a1.z, dcony = a1.w, dconw = a3.x;
+            dopac = a3.y;
+            const float dndc_in = a3.z;
             // phasor-plane gradients arrive already folded onto the (R, I, Am) basis:
             // XR = sum w_p (g0+g3-g4), XI = sum w_p (g1+g5-g6), X2 = sum w_p g2, XQ = sum w_p (g3+g4+g5+g6)
-            const float XR = a2.y, XI = a2.z, X2 = a2.w, XQ = a3.x;
-            const float ddist_in = a3.y, dndc_in = a3.z;
+            const float XR = a2.x, XI = a2.y, X2 = a2.z, XQ = a2.w;
 
             const float px = a.io.means3D[3 * idx], py = a.io.means3D[3 * idx + 1], pz = a.io.means3D[3 * idx + 2];
             const Mat16 V = load_mat(a.io.viewmatrix);

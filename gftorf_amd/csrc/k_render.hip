@@ -297,21 +297,41 @@ __device__ __forceinline__ float row_fold4(float t0, float t1, float t2, float t
     return t0;
 }
 
-// Sum 15 per-lane values over the 64 lanes of the wave and store the totals to row[0..14]
-// (row[15] receives a duplicate) in LDS.  Halving tree: 15 -> 8 registers (lane halves:
-// value i | value i+8), 8 -> 4 (16-lane rows: values i, i+4, i+8, i+12), then row_fold4:
-// quad q of row r ends up with value 4 r + q, stored by its first lane (16 lanes x 4 bytes).
-__device__ __forceinline__ void wave_reduce15_store(const float* v, float* row, int lane)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// swap-and-add on register pairs: the permlane swaps work in place on both operands, the two
+// sums are one v_pk_add_f32
+__device__ __forceinline__ v2f swap32_add2(v2f x, v2f y)
 {
-    float s[8];
-#pragma unroll
-    for (int i = 0; i < 7; i++) s[i] = swap32_add(v[i], v[i + 8]);      // lo half: value i, hi half: value i+8
-    s[7] = swap32_add(v[7], v[7]);                                      // both halves: value 7
-    float t[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) t[i] = swap16_add(s[i], s[i + 4]);      // rows: i, i+4, i+8, i+12 (i = 3: 3,7,11,7)
-    const float tot = row_fold4(t[0], t[1], t[2], t[3]);                // row r, quad q: value q + 4 r
-    // t[q] holds value q + 4 r in row r -> natural position 4 r + q = lane >> 2
+    const u32x2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.x), __float_as_uint(y.x), false, false);
+    const u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.y), __float_as_uint(y.y), false, false);
+    const v2f p = {__uint_as_float(a.x), __uint_as_float(b.x)};
+    const v2f q = {__uint_as_float(a.y), __uint_as_float(b.y)};
+    return p + q;
+}
+
+__device__ __forceinline__ v2f swap16_add2(v2f x, v2f y)
+{
+    const u32x2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x.x), __float_as_uint(y.x), false, false);
+    const u32x2 b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x.y), __float_as_uint(y.y), false, false);
+    const v2f p = {__uint_as_float(a.x), __uint_as_float(b.x)};
+    const v2f q = {__uint_as_float(a.y), __uint_as_float(b.y)};
+    return p + q;
+}
+
+// Sum 16 per-lane values (8 "low" L[0..7], 8 "high" H[0..7], as register pairs) over the 64
+// lanes of the wave and store the totals to row[0..15] in LDS:
+//   row[0..3] = L[0..3], row[4..7] = L[4..7], row[8..11] = H[0..3], row[12..15] = H[4..7].
+// Halving tree: 16 -> 8 registers (lane halves: L[i] | H[i]), 8 -> 4 (16-lane rows: L[i], L[i+4],
+// H[i], H[i+4]), then row_fold4: quad q of row r ends up with the value of position 4 r + q,
+// stored by its first lane (16 lanes x 4 bytes).
+__device__ __forceinline__ void wave_reduce16_store(v2f L01, v2f L23, v2f L45, v2f L67, v2f H01, v2f H23, v2f H45,
+                                                    v2f H67, float* row, int lane)
+{
+    const v2f s01 = swap32_add2(L01, H01), s23 = swap32_add2(L23, H23);
+    const v2f s45 = swap32_add2(L45, H45), s67 = swap32_add2(L67, H67);
+    const v2f t01 = swap16_add2(s01, s45), t23 = swap16_add2(s23, s67);
+    const float tot = row_fold4(t01.x, t01.y, t23.x, t23.y);
     if ((lane & 3) == 0) row[lane >> 2] = tot;
 }
 
@@ -415,6 +435,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     // sum_k p_k g_k = R*GR + I*GI + Am*GA; K9 needs sum w_p*{GR, GI, g2, GQ}
     const float GR = gp0 + gp3 - gp4, GI = gp1 + gp5 - gp6, GQ = (gp3 + gp4) + (gp5 + gp6);
     const float GA = gp2 + a.dc_offset * GQ;
+    // per-pixel factors of the eight sums that are (pixel constant) x (w_c or w_p), as register pairs
+    const v2f gA01 = {gc0, gc1}, gA23 = {gc2, gd}, gB01 = {GR, GI}, gB23 = {gp2, GQ};
 
     // Back-to-front recurrences.  The reference keeps one "accumulated behind" value per
     // channel (accum_rec[3], accum_rec_p[7], _d, _a, _dd; backward.cu:776-833); only their
@@ -453,7 +475,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
             // Every lane runs the same arithmetic; lanes that do not blend this splat use
             // alpha = G = 0, which leaves T unchanged (rcp(1) == 1) and makes all 15 partials
             // exactly zero; only the five recurrence registers need a select.
-            float v[GFT_NUM_ACC];
+            // accumulator row = {dcolor[3], ddist | dmean2D.xy, dconic.xy | XR, XI, X2, XQ | dconic.w, dopacity, dndc, -}
+            v2f L01, L23, L45, L67, H01, H23, H45, H67;
             {
                 const float4 b0 = sB[2 * j], b1 = sB[2 * j + 1];
                 const float al = contrib ? alpha : 0.f;
@@ -487,25 +510,27 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
                 Lp = contrib ? Dp : Lp;
                 last_alpha = contrib ? alpha : last_alpha;
 
-                v[6] = wc * gc0; v[7] = wc * gc1; v[8] = wc * gc2;
-                v[9] = wp * GR; v[10] = wp * GI; v[11] = wp * gp2; v[12] = wp * GQ;
-                v[13] = wc * gd;
-                v[14] = wc * (t2 + A2 * z);           // gdd*2*alpha*T*(z(1-Tf) - wz)
+                L01 = gA01 * wc;                      // w_c * (g_c0, g_c1)
+                L23 = gA23 * wc;                      // w_c * (g_c2, g_dist)
+                H01 = gB01 * wp;                      // w_p * (GR, GI)
+                H23 = gB23 * wp;                      // w_p * (g_p2, GQ)
 
                 const float dL_dG = a1.y * dL_dalpha;
                 const float gdx = Gm * dx, gdy = Gm * dy;
                 const float dG_ddelx = -gdx * a0.z - gdy * a0.w;
                 const float dG_ddely = -gdy * a1.x - gdx * a0.w;
-                v[0] = dL_dG * dG_ddelx * ddelx_dx;
-                v[1] = dL_dG * dG_ddely * ddely_dy;
                 const float h = -0.5f * dL_dG;
-                v[2] = h * gdx * dx;
-                v[3] = h * gdx * dy;
-                v[4] = h * gdy * dy;
-                v[5] = Gm * dL_dalpha;
+                L45.x = dL_dG * dG_ddelx * ddelx_dx;  // dmean2D.x
+                L45.y = dL_dG * dG_ddely * ddely_dy;  // dmean2D.y
+                L67.x = h * gdx * dx;                 // dconic.x
+                L67.y = h * gdx * dy;                 // dconic.y
+                H45.x = h * gdy * dy;                 // dconic.w
+                H45.y = Gm * dL_dalpha;               // dopacity
+                H67.x = wc * (t2 + A2 * z);           // gdd*2*alpha*T*(z(1-Tf) - wz)
+                H67.y = 0.f;
             }
             // 64 pixels -> one partial per value, parked in the batch's LDS table
-            wave_reduce15_store(v, &sAcc[j * ACC_LDS_STRIDE], lane);
+            wave_reduce16_store(L01, L23, L45, L67, H01, H23, H45, H67, &sAcc[j * ACC_LDS_STRIDE], lane);
             touched |= 1ull << j;
         }
         __syncthreads();
