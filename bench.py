@@ -249,7 +249,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": scene["label"], "P": P, "W": W, "H": H, "sh_degree": cfg["D"],
-                       "P_visible": P_vis, "num_rendered": R, "frames_per_step": world,
+                       "P_visible": P_vis, "num_rendered": R,
+                       "longest_tile_list": int(api.last_call_stats["max_tile_list"]), "frames_per_step": world,
                        "parallelism": "frame-sharded x%d (no data-path collective)" % world},
             "mpix_per_s": value * N / 1e6,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
