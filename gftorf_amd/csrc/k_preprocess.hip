@@ -326,6 +326,16 @@ __device__ __forceinline__ int padded_slot(int e)
     return row * (ROW_F4 + 1) + (e - row * ROW_F4);
 }
 
+typedef float gft_v4f __attribute__((ext_vector_type(4)));
+// streaming store for data written once and not read again by this library (SH gradients):
+// measured -3.7 us on k_preprocess_bwd.  (Streaming *loads* of the SH rows are a loss: the
+// twelve 16-byte loads of a row rely on the cache keeping its lines, 126 -> 208 us.)
+__device__ __forceinline__ void store_stream(float4* p, float4 v)
+{
+    const gft_v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<gft_v4f*>(p));
+}
+
 template <int ROW_F4>
 __device__ __forceinline__ void wave_rows_to_lds(float4* dst, const float4* __restrict__ src, size_t first_gaussian,
                                                  size_t P, int lane)
@@ -348,7 +358,7 @@ __device__ __forceinline__ void wave_rows_from_lds(float4* __restrict__ dst, con
 #pragma unroll
     for (int q = 0; q < ROW_F4; q++) {
         const size_t i = g0 + (size_t)(q * 64 + lane);
-        if (i < lim) dst[i] = src[padded_slot<ROW_F4>(q * 64 + lane)];
+        if (i < lim) store_stream(&dst[i], src[padded_slot<ROW_F4>(q * 64 + lane)]);
     }
 }
 
@@ -970,6 +980,7 @@ hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const g
     // Measured on MI355X (1 M Gaussians): staging the forward's SH rows through LDS costs more
     // in occupancy than the strided reads cost in TA cycles (0.155 vs 0.128 ms); the backward,
     // which also writes 320 B of SH gradients per Gaussian, gains from it (0.32 -> 0.245 ms).
+    // (re-measured with the final kernel: staging shs_p only 113 vs 111 us, shs only 128, both 178)
     a.stage_sh = a.stage_shp = 0;
     const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_PAD : 0) + (a.stage_shp ? SHP_ROW_PAD : 0));
     static bool attr_set = false;
