@@ -36,6 +36,8 @@ WORKLOADS = {
                label="500k Gaussians, 640x480, SH deg 3, RGB+ToF phasor, forward+backward"),
     "C5": dict(P=5_000_000, W=1920, H=1080, D=3, sh_coeffs=16, tof=True,
                label="5M Gaussians, 1920x1080, SH deg 3, RGB+ToF phasor, forward+backward"),
+    "clustered": dict(P=1_000_000, W=640, H=480, D=3, sh_coeffs=16, tof=True, cluster=0.4,
+                      label="1M Gaussians concentrated at the image centre, 640x480 (load-balance check)"),
     "tiny": dict(P=20_000, W=256, H=256, D=3, sh_coeffs=16, tof=True,
                  label="20k Gaussians, 256x256 (plumbing check only)"),
 }

@@ -61,13 +61,18 @@ def make_camera(W, H, fovx_deg=60.0, znear=0.45, zfar=6.05, w2c=None):
 
 
 def make_gaussians(P, cam, seed, sh_coeffs=16, scale_lo=0.002, scale_hi=0.02,
-                   z_lo=1.0, z_hi=5.5, spread=1.05):
+                   z_lo=1.0, z_hi=5.5, spread=1.05, cluster=0.0):
     """Gaussians placed in the camera frustum (camera space), mapped to world by
     the inverse of cam['w2c'].  Returns a dict of float32 arrays."""
     rng = np.random.default_rng(seed)
     z = rng.uniform(z_lo, z_hi, P)
     u = rng.uniform(-spread, spread, P)
     v = rng.uniform(-spread, spread, P)
+    if cluster > 0.0:
+        # screen-space density falling off from the image centre (robustness workloads only;
+        # the BASELINE configs are uniform, SURVEY 8(d))
+        u = np.clip(rng.normal(0.0, cluster, P), -spread, spread)
+        v = np.clip(rng.normal(0.0, cluster, P), -spread, spread)
     pc = np.stack([u * z * cam["tanfovx"], v * z * cam["tanfovy"], z, np.ones(P)], 1)
     c2w = np.linalg.inv(cam["w2c"].astype(np.float64))
     means3D = (pc @ c2w.T)[:, :3].astype(np.float32)
@@ -115,7 +120,7 @@ def make_scene(name_or_cfg, seed=1234, w2c=None, P=None):
     if P is not None:
         cfg["P"] = P
     cam = make_camera(cfg["W"], cfg["H"], w2c=w2c)
-    g = make_gaussians(cfg["P"], cam, seed, sh_coeffs=cfg["sh_coeffs"])
+    g = make_gaussians(cfg["P"], cam, seed, sh_coeffs=cfg["sh_coeffs"], cluster=cfg.get("cluster", 0.0))
     if not cfg.get("tof", True):
         g["shs_p"] = None
     return dict(cfg=cfg, cam=cam, gaussians=g, bg=make_background(cfg["W"], cfg["H"], seed),
