@@ -112,7 +112,7 @@ def load():
                                            C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gft_forward_render.restype = C.c_int
     lib.gft_forward.restype = C.c_int
-    lib.gft_forward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64,
+    lib.gft_forward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64, C.c_int64,
                                 C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gft_forward_render.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64, C.c_int64]
     lib.gft_backward.restype = C.c_int

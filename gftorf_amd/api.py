@@ -53,6 +53,7 @@ last_call_stats = {"num_rendered": 0, "binning_instances": 0, "restarted": False
 # more than the guess re-runs stage 2 with the exact size.
 _instance_hint = {}
 _HINT_HEADROOM = 1.25
+_LIST_HEADROOM = 1.2      # longest tile list of the previous frame -> guess for this one
 
 
 def cpu_deep_copy_tuple(input_tuple):
@@ -208,7 +209,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             num_rendered = C.c_int64(0)
             max_list = C.c_int64(0)
             hint_key = (dev.index, P, W, H)
-            hint = _instance_hint.get(hint_key)
+            hint, list_hint = _instance_hint.get(hint_key, (None, 0))
             restarted = False
             try:
                 with torch.cuda.device(dev):
@@ -226,7 +227,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                         cap = int(hint * _HINT_HEADROOM) + 4096
                         binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                         io.binning = binning.data_ptr()
-                        _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), cap, C.byref(num_rendered),
+                        _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), cap,
+                                                   int(list_hint * _LIST_HEADROOM) + 1, C.byref(num_rendered),
                                                    C.byref(max_list)))
                         R = int(num_rendered.value)
                         if R > cap:
@@ -236,7 +238,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                             io.binning = binning.data_ptr()
                             _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap,
                                                               int(max_list.value)))
-                    _instance_hint[hint_key] = R
+                    _instance_hint[hint_key] = (R, int(max_list.value))
                     if len(_instance_hint) > 64:
                         _instance_hint.pop(next(iter(_instance_hint)))
             except Exception as ex:

@@ -426,7 +426,8 @@ extern "C" int gft_forward_render(void* hip_stream, const gft_config* cfg, const
 
 // ---- forward, one call ------------------------------------------------------------
 extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
-                           int64_t binning_instances, int64_t* num_rendered, int64_t* max_tile_list)
+                           int64_t binning_instances, int64_t max_tile_list_hint, int64_t* num_rendered,
+                           int64_t* max_tile_list)
 {
     if (max_tile_list) *max_tile_list = 0;
     if (check_config(cfg)) return 1;
@@ -447,13 +448,23 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     if (mailbox_acquire(&mail_dev, &mail_host, &seq)) return 1;
     if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq)) return 1;
     // stage 2 is queued before R is known; its kernels check R against the buffer themselves
-    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, 0, true, (uint32_t)binning_instances)) return 1;
+    const uint32_t cap = (uint32_t)binning_instances;
+    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, max_tile_list_hint, true, cap)) return 1;
     uint32_t host[GFT_CTRL_WORDS];
     if (mailbox_wait(s, mail_host, seq, host)) return 1;
     if (host[GFT_CTRL_FLAGS] & 1u)
         return gft_fail("Point is filtered although prefiltered is set. This shouldn't happen!");
     *num_rendered = (int64_t)host[GFT_CTRL_TOTAL];
     if (max_tile_list) *max_tile_list = (int64_t)host[GFT_CTRL_MAXCNT];
+    // The hint said "no tile list longer than the short-sort limit" and the frame has one: its
+    // tiles were rendered unsorted.  Sort them and render again (the contributing-pixel counters
+    // are the only accumulated output).
+    if (max_tile_list_hint > 0 && max_tile_list_hint <= GFT_SHORT_LIST_MAX && host[GFT_CTRL_MAXCNT] > GFT_SHORT_LIST_MAX &&
+        host[GFT_CTRL_TOTAL] <= cap && binning_instances > 0) {
+        GFT_CHECK_HIP(hipMemsetAsync(io->pixels, 0, (size_t)cfg->P * sizeof(float), s));
+        GFT_STAGE(s, cfg, "tile_sort_long", gft_launch_tile_sort_long(s, *cfg, im, b, cap));
+        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, true, cap));
+    }
     return 0;
 }
 

@@ -42,6 +42,7 @@ struct BinView {
 #define GFT_CTRL_DONE 3      // finished k_tile_count workgroups (ticket for the fused scan)
 #define GFT_CTRL_SEQ 3       // host mailbox only: sequence number, written last
 #define GFT_CTRL_WORDS 8
+#define GFT_SHORT_LIST_MAX 4096   // tile lists up to this length are sorted by one 256-thread workgroup
 
 void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* L);
 GeomView gft_geom_view(void* base, const gft_layout& L);
@@ -66,6 +67,8 @@ hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const Geo
                                    const BinView& b, uint32_t cap);
 hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_tile_list, const ImgView& im,
                                 const BinView& b, uint32_t cap, float* clear, size_t clear_bytes);
+hipError_t gft_launch_tile_sort_long(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b,
+                                     uint32_t cap);
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b, bool check_cap, uint32_t cap);
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,

@@ -389,6 +389,33 @@ __device__ __forceinline__ void bitonic_blocked(uint64_t* sk, int tid)
     __syncthreads();
 }
 
+// Sorts keys[first, first + n), n <= 4096, into point_list[first, first + n) (ids only) through
+// the 33.8 KB LDS buffer `sk`.  Called by all 256 threads of a workgroup with uniform arguments.
+__device__ __forceinline__ void sort_range_small(uint32_t first, uint32_t n, const uint64_t* __restrict__ keys,
+                                                 uint32_t* __restrict__ point_list, uint64_t* sk, int tid)
+{
+    if (n == 0) return;
+    if (n == 1) {
+        if (tid == 0) point_list[first] = (uint32_t)keys[first];
+        return;
+    }
+    if (n <= 1024u) {
+        const uint32_t npad = next_pow2(n);
+        for (uint32_t i = tid; i < n; i += GFT_BLOCK) sk[i] = keys[first + i];
+        __syncthreads();
+        bitonic_ascending<GFT_BLOCK>(n, npad, tid, [&](uint32_t i) { return sk[i]; }, [&](uint32_t i, uint64_t v) { sk[i] = v; },
+                                     [] { __syncthreads(); });
+        for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[first + i] = (uint32_t)sk[i];
+        return;
+    }
+    const uint32_t npad = n <= 2048u ? 2048u : 4096u;
+    for (uint32_t i = tid; i < npad; i += GFT_BLOCK) sk[sort_slot(i)] = i < n ? keys[first + i] : ~0ull;
+    __syncthreads();
+    if (npad == 2048u) bitonic_blocked<3, 8>(sk, tid);
+    else bitonic_blocked<4, 8>(sk, tid);
+    for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[first + i] = (uint32_t)sk[sort_slot(i)];
+}
+
 // Sort class A: tile lists of up to 4096 keys, 33.8 KB of LDS.
 __global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_small(const uint2* __restrict__ ranges,
                                                                const uint64_t* __restrict__ keys,
@@ -407,33 +434,23 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_small(const uint2* __re
     }
     const uint2 r = ranges[blockIdx.x];
     const uint32_t n = r.y - r.x;
-    if (n == 0 || n > 4096u) return;
-    const int tid = threadIdx.x;
-    if (n == 1) {
-        if (tid == 0) point_list[r.x] = (uint32_t)keys[r.x];
+    if (n > 4096u) {
+        // long list: sorted by k_tile_sort_big.  The id list is filled in scatter order here so that
+        // it holds valid ids even when that kernel is only launched after a first render
+        // (gft_forward with a wrong list-length guess).
+        for (uint32_t i = threadIdx.x; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)keys[r.x + i];
         return;
     }
-    if (n <= 1024u) {
-        const uint32_t npad = next_pow2(n);
-        for (uint32_t i = tid; i < n; i += GFT_BLOCK) sk[i] = keys[r.x + i];
-        __syncthreads();
-        bitonic_ascending<GFT_BLOCK>(n, npad, tid, [&](uint32_t i) { return sk[i]; }, [&](uint32_t i, uint64_t v) { sk[i] = v; },
-                                     [] { __syncthreads(); });
-        for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[i];
-        return;
-    }
-    const uint32_t npad = n <= 2048u ? 2048u : 4096u;
-    for (uint32_t i = tid; i < npad; i += GFT_BLOCK) sk[sort_slot(i)] = i < n ? keys[r.x + i] : ~0ull;
-    __syncthreads();
-    if (npad == 2048u) bitonic_blocked<3, 8>(sk, tid);
-    else bitonic_blocked<4, 8>(sk, tid);
-    for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[sort_slot(i)];
+    sort_range_small(r.x, n, keys, point_list, sk, threadIdx.x);
 }
 
-// Sort classes B and C: tile lists of 4097..16384 keys are sorted by 1024 threads with the
-// register-blocked network in 132 KB of dynamic LDS (8 or 16 keys per thread), longer ones in
-// place in global memory with the plain network.  Up to one workgroup per CU strides over the
-// tile table, so a frame without long lists costs one short launch.
+// Long lists: 4097..16384 keys are sorted by 1024 threads with the register-blocked network in
+// 132 KB of dynamic LDS (8 or 16 keys per thread), longer ones in place in global memory with the
+// plain network.  Up to one workgroup per CU strides over the tile table.
+// (Tried and dropped: splitting a long list into 2..32 depth buckets -- sample-sort splitters in
+// a 1024-thread partition kernel -- and sorting the buckets as short lists.  5 M @ 1080p, 9150
+// keys per tile: 3.0-6.0 ms against 3.6 ms for this whole-list network; centre-heavy 1 M frame:
+// 272 vs 239 us.  The 4096-key unit has a 60 us latency; long lists need a different sort.)
 #define SORT_BIG_THREADS 1024
 __global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_sort_big(int T, const uint2* __restrict__ ranges,
                                                                     uint64_t* keys, uint32_t* __restrict__ point_list,
@@ -530,18 +547,26 @@ hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
+    hipLaunchKernelGGL(k_tile_sort_small, dim3(T), dim3(GFT_BLOCK), 0, s, im.ranges, b.keys, b.point_list, im.ctrl, cap,
+                       reinterpret_cast<float4*>(clear), clear_bytes / 16);
+    // the longest list (known to the host in the two-stage flow, a guess of the caller in the
+    // one-call flow, <= 0 = unknown) tells whether any tile needs the long-list path
+    if (max_tile_list <= 0 || max_tile_list > (int64_t)SORT_LDS_SMALL) return gft_launch_tile_sort_long(s, c, im, b, cap);
+    return hipGetLastError();
+}
+
+hipError_t gft_launch_tile_sort_long(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b,
+                                     uint32_t cap)
+{
+    const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    const int T = gx * gy;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort_big),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_LARGE_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_tile_sort_small, dim3(T), dim3(GFT_BLOCK), 0, s, im.ranges, b.keys, b.point_list, im.ctrl, cap,
-                       reinterpret_cast<float4*>(clear), clear_bytes / 16);
-    // the longest list (known to the host in the two-stage flow, <= 0 otherwise) tells whether
-    // any tile needs the large classes
-    if (max_tile_list <= 0 || max_tile_list > (int64_t)SORT_LDS_SMALL)
-        hipLaunchKernelGGL(k_tile_sort_big, dim3(T < 256 ? T : 256), dim3(SORT_BIG_THREADS), (size_t)SORT_LDS_LARGE_BYTES, s, T,
-                           im.ranges, b.keys, b.point_list, SORT_LDS_SMALL, SORT_LDS_LARGE, im.ctrl, cap);
+    hipLaunchKernelGGL(k_tile_sort_big, dim3(T < 256 ? T : 256), dim3(SORT_BIG_THREADS), (size_t)SORT_LDS_LARGE_BYTES, s, T,
+                       im.ranges, b.keys, b.point_list, SORT_LDS_SMALL, SORT_LDS_LARGE, im.ctrl, cap);
     return hipGetLastError();
 }

@@ -226,10 +226,14 @@ int gft_forward_render(void* hip_stream, const gft_config* cfg,
  * host; the call returns as soon as the device has posted R (stage 2 may still run).
  * If *num_rendered > binning_instances the stage-2 kernels have done nothing (they
  * compare the device-side count themselves): allocate for *num_rendered and call
- * gft_forward_render().  Results are identical to the two-stage flow. */
+ * gft_forward_render().  `max_tile_list_hint`: the caller's guess of the longest
+ * per-tile list (e.g. last frame's, with margin; <= 0 = unknown).  A guess at or below
+ * 4096 skips the launches of the long-list sort; if the frame then does have a longer
+ * list the library sorts it and renders again before returning.  Results are identical
+ * to the two-stage flow in every case. */
 int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
-                int64_t binning_instances, int64_t* num_rendered /*host*/,
-                int64_t* max_tile_list /*host, may be NULL*/);
+                int64_t binning_instances, int64_t max_tile_list_hint,
+                int64_t* num_rendered /*host*/, int64_t* max_tile_list /*host, may be NULL*/);
 
 int gft_backward(void* hip_stream, const gft_config* cfg,
                  const gft_backward_io* io, int64_t binning_instances);

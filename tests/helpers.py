@@ -9,12 +9,12 @@ GRAD_KEYS = ["color", "phasor", "depth", "acc", "depth_distortion"]
 
 
 def small_scene(P=400, W=80, H=48, seed=3, D=3, sh_coeffs=16, scale_lo=0.01, scale_hi=0.12,
-                w2c="tilted", spread=1.05, tof=True, opacity=None):
+                w2c="tilted", spread=1.05, tof=True, opacity=None, z_lo=1.0, z_hi=5.5):
     if isinstance(w2c, str):
         w2c = synth.look_at_w2c(0.15, -0.1, 0.05, (0.1, -0.05, 0.2)) if w2c == "tilted" else None
     cam = synth.make_camera(W, H, w2c=w2c)
     g = synth.make_gaussians(P, cam, seed, sh_coeffs=sh_coeffs, scale_lo=scale_lo, scale_hi=scale_hi,
-                             spread=spread)
+                             spread=spread, z_lo=z_lo, z_hi=z_hi)
     if not tof:
         g["shs_p"] = None
     if opacity is not None:

@@ -103,7 +103,8 @@ SCENES = {
     "identity_cam": dict(w2c=None),
     "tiny_splats": dict(scale_lo=0.001, scale_hi=0.004, P=600),
     "opaque_early_exit": dict(P=2500, W=64, H=48, scale_lo=0.05, scale_hi=0.25, opacity=0.95),  # T < 1e-4 termination
-    "long_lists_lds128k": dict(P=9000, W=32, H=32, scale_lo=0.05, scale_hi=0.3),    # 4096 < tile list <= 16384
+    "long_lists_lds128k": dict(P=9000, W=32, H=32, scale_lo=0.05, scale_hi=0.3),    # 4096 < tile list <= 16384: depth-bucket split
+    "long_lists_flat": dict(P=9000, W=32, H=32, scale_lo=0.05, scale_hi=0.3, w2c=None, z_lo=3.0, z_hi=3.0),   # all depths equal: splitters and order decided by the id half of the keys
     "long_lists_global": dict(P=24000, W=32, H=16, scale_lo=0.05, scale_hi=0.3),    # tile list > 16384: global-memory sort
 }
 
@@ -358,7 +359,7 @@ def test_one_call_forward_matches_two_stage(oracle, gpu):
     key = next(iter(api._instance_hint))
     for hint, restarted in ((None, False), (R, False), (1, True), (0, True)):
         if hint is not None:
-            api._instance_hint[key] = hint
+            api._instance_hint[key] = (hint, api._instance_hint[key][1])
         out, grads, _ = Hh.run_gpu(scene, gpu)
         st = api.last_call_stats
         assert st["num_rendered"] == R and st["restarted"] == restarted
@@ -396,3 +397,27 @@ def test_backward_twice_through_one_forward(gpu):
     loss.backward()
     for k, v in g.items():
         torch.testing.assert_close(v.grad, first[k], rtol=1e-4, atol=1e-6)
+
+
+def test_one_call_forward_with_wrong_list_guess(oracle, gpu):
+    """One-call flow on a frame whose longest tile list is over the short-sort limit while the
+    caller's guess (previous frame) said it would not be: the library sorts the long lists and
+    renders again; outputs, counters and gradients equal the two-stage flow."""
+    from gftorf_amd import api
+    scene = Hh.small_scene(**SCENES["long_lists_lds128k"])
+    api._instance_hint.clear()
+    ref_out, ref_grads, _ = Hh.run_gpu(scene, gpu)               # two-stage flow
+    R, longest = api.last_call_stats["num_rendered"], api.last_call_stats["max_tile_list"]
+    assert longest > 4096
+    key = next(iter(api._instance_hint))
+    for list_guess in (100, longest):                             # wrong guess, right guess
+        api._instance_hint[key] = (R, list_guess)
+        out, grads, _ = Hh.run_gpu(scene, gpu)
+        assert api.last_call_stats["num_rendered"] == R and not api.last_call_stats["restarted"]
+        for k in ref_out:
+            np.testing.assert_array_equal(out[k], ref_out[k], err_msg=k)
+        for k in ref_grads:
+            if ref_grads[k] is not None:
+                Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
+    f, b = Hh.run_oracle(oracle, scene)
+    check_outputs(f, ref_out)
