@@ -75,10 +75,35 @@ class Profile(C.Structure):
                                                            ("backward_calls", C.c_int64)]
 
 
+# ---- fused input assembly (include/gftorf_assemble.h) -------------------------------------------
+ASSEMBLE_PTRS_IN = ["xyz", "screenspace", "opacity", "scaling", "rotation", "rotation_raw", "feat_color",
+                    "feat_phasor", "motion_mask", "d_xyz", "d_rot", "d_sh", "d_sh_p"]
+ASSEMBLE_SCALARS = ["d_xyz_scalar", "d_rot_scalar", "d_sh_scalar", "d_sh_p_scalar"]
+ASSEMBLE_PTRS_OUT = ["scratch", "out_means3D", "out_means2D", "out_opacity", "out_scales", "out_rotations",
+                     "out_shs", "out_shs_p"]
+ASSEMBLE_FIELDS = ASSEMBLE_PTRS_IN + ASSEMBLE_SCALARS + ASSEMBLE_PTRS_OUT
+ASSEMBLE_BWD_HEAD = ["scratch", "rotation_raw", "d_rot"]
+ASSEMBLE_BWD_TAIL = ["g_means3D", "g_means2D", "g_opacity", "g_scales", "g_rotations", "g_shs", "g_shs_p",
+                     "g_xyz", "g_screenspace", "g_opacity_in", "g_scaling", "g_rotation", "g_rotation_raw",
+                     "g_feat_color", "g_feat_phasor", "g_d_xyz", "g_d_rot", "g_d_sh", "g_d_sh_p"]
+ASSEMBLE_BWD_FIELDS = ASSEMBLE_BWD_HEAD + ["d_rot_scalar"] + ASSEMBLE_BWD_TAIL
+
+
+class AssembleIO(C.Structure):
+    _fields_ = ([(n, _fp) for n in ASSEMBLE_PTRS_IN] + [(n, C.c_float) for n in ASSEMBLE_SCALARS] +
+                [(n, _fp) for n in ASSEMBLE_PTRS_OUT])
+
+
+class AssembleBwdIO(C.Structure):
+    _fields_ = ([(n, _fp) for n in ASSEMBLE_BWD_HEAD] + [("d_rot_scalar", C.c_float)] +
+                [(n, _fp) for n in ASSEMBLE_BWD_TAIL])
+
+
 EXPORTS = [
     "gft_abi_version", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes", "gft_acc_bytes",
     "gft_get_layout", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_backward",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
+    "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
 ]
 
 
@@ -111,6 +136,16 @@ def load():
     lib.gft_forward_preprocess.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO),
                                            C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gft_forward_render.restype = C.c_int
+    lib.gft_assemble_scratch_bytes.restype = C.c_size_t
+    lib.gft_assemble_scratch_bytes.argtypes = [C.c_int32]
+    lib.gft_assemble_forward.restype = C.c_int
+    lib.gft_assemble_forward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.POINTER(AssembleIO)]
+    lib.gft_assemble_backward.restype = C.c_int
+    lib.gft_assemble_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.POINTER(AssembleBwdIO)]
+    lib.gft_assemble_num_dynamic.restype = C.c_int
+    lib.gft_assemble_num_dynamic.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
     lib.gft_forward.restype = C.c_int
     lib.gft_forward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64, C.c_int64,
                                 C.POINTER(C.c_int64), C.POINTER(C.c_int64)]

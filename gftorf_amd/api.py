@@ -47,7 +47,7 @@ class GaussianRasterizationSettings(NamedTuple):
 # (Gaussian, tile) instance count of the most recent forward (diagnostics / bench)
 last_call_stats = {"num_rendered": 0, "binning_instances": 0, "restarted": False, "max_tile_list": 0}
 
-# Instance count of the previous forward per (device, P, W, H).  A training loop renders
+# Instance count (and longest tile list) of the recent forwards per (device, P, W, H).  A training loop renders
 # similar frames back to back, so the binning buffer can be sized before the device has
 # counted (gft_forward: no host round trip in the middle of the forward); a frame that needs
 # more than the guess re-runs stage 2 with the exact size.
@@ -238,7 +238,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                             io.binning = binning.data_ptr()
                             _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap,
                                                               int(max_list.value)))
-                    _instance_hint[hint_key] = (R, int(max_list.value))
+                    # slowly decaying maximum: alternating views of one scene (colour / ToF camera,
+                    # random training views) keep the larger count as the guess
+                    prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
+                    _instance_hint[hint_key] = (max(R, int((prev_r or 0) * 0.95)),
+                                                max(int(max_list.value), int(prev_l * 0.95)))
                     if len(_instance_hint) > 64:
                         _instance_hint.pop(next(iter(_instance_hint)))
             except Exception as ex:

@@ -1,0 +1,160 @@
+"""Fused assembly of the rasterizer's per-Gaussian inputs.
+
+Replaces, in the reference's ``render`` (``gaussian_renderer/__init__.py:81-105``), the seven
+``torch.zeros`` allocations and the fourteen boolean-mask assignments
+
+    means3D[~motion_mask] = pc.get_xyz[~motion_mask]              # "static" in render_regions
+    means3D[motion_mask]  = pc.get_xyz[motion_mask] + d_xyz        # "dynamic" in render_regions
+    rotations[motion_mask] = pc.rotation_activation(pc._rotation[motion_mask] + d_rot)
+    shs[motion_mask] = pc.get_features_color[motion_mask] + d_sh   ...
+
+by one call with the same results and the same gradients:
+
+    means3D, means2D, opacity, scales, rotations, shs, shs_p = assemble_inputs(
+        pc.get_xyz, screenspace_points, pc.get_opacity, pc.get_scaling, pc.get_rotation, pc._rotation,
+        pc.get_features_color, pc.get_features_phasor, pc.get_motion_mask,
+        d_xyz, d_rot, d_sh, d_sh_p, render_regions)
+
+``d_*`` are the deformation network's outputs for the dynamic Gaussians (one row per True of
+``motion_mask``, ``scene/gaussian_model.py:170-174``) or Python floats (``train.py:164``).
+The work is done by hand-written gfx950 kernels (``csrc/k_assemble.hip``) through the C ABI in
+``include/gftorf_assemble.h``; there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _is_tensor(x):
+    return isinstance(x, torch.Tensor)
+
+
+def _f32c(t, dev, name):
+    if t.device != dev:
+        raise RuntimeError("gftorf_amd.assemble_inputs: %s is on %s, expected %s" % (name, t.device, dev))
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _p(t):
+    return t.data_ptr() if t is not None and t.numel() else None
+
+
+class _AssembleInputs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, screenspace, opacity, scaling, rotation, rotation_raw, feat_color, feat_phasor,
+                motion_mask, d_xyz, d_rot, d_sh, d_sh_p, render_static, render_dynamic, validate):
+        lib = _lib.load()
+        dev = xyz.device
+        if dev.type != "cuda":
+            raise RuntimeError("gftorf_amd.assemble_inputs runs on a HIP device only (xyz is on %s); "
+                               "there is no CPU path" % (dev,))
+        P = xyz.size(0)
+        M, M_p = feat_color.size(1), feat_phasor.size(1)
+        src = [_f32c(t, dev, n) for t, n in ((xyz, "xyz"), (screenspace, "screenspace_points"), (opacity, "opacity"),
+                                              (scaling, "scaling"), (rotation, "rotation"), (rotation_raw, "_rotation"),
+                                              (feat_color, "features_color"), (feat_phasor, "features_phasor"))]
+        xyz_c, ssp_c, op_c, sc_c, rot_c, raw_c, fc_c, fp_c = src
+        if motion_mask.dtype != torch.bool or motion_mask.numel() != P:
+            raise RuntimeError("motion_mask must be a bool tensor with one entry per Gaussian")
+        mask_c = motion_mask.to(dev).contiguous()
+        offs = []
+        for t, n, shape in ((d_xyz, "d_xyz", (3,)), (d_rot, "d_rot", (4,)), (d_sh, "d_sh", (M, 3)), (d_sh_p, "d_sh_p", (M_p, 2))):
+            if _is_tensor(t):
+                if tuple(t.shape[1:]) != shape:
+                    raise RuntimeError("%s has shape %s, expected (num_dynamic, %s)" % (n, tuple(t.shape), ", ".join(map(str, shape))))
+                offs.append(_f32c(t, dev, n))
+            else:
+                offs.append(float(t))
+        f32 = dict(device=dev, dtype=torch.float32)
+        means3D = torch.empty((P, 3), **f32)
+        means2D = torch.empty((P, 3), **f32)
+        out_op = torch.empty(opacity.shape, **f32)
+        scales = torch.empty((P, 3), **f32)
+        rotations = torch.empty((P, 4), **f32)
+        shs = torch.empty((P, M, 3), **f32)
+        shs_p = torch.empty((P, M_p, 2), **f32)
+        scratch = torch.empty((lib.gft_assemble_scratch_bytes(P),), device=dev, dtype=torch.uint8)
+
+        io = _lib.AssembleIO()
+        io.xyz, io.screenspace, io.opacity, io.scaling = _p(xyz_c), _p(ssp_c), _p(op_c), _p(sc_c)
+        io.rotation, io.rotation_raw, io.feat_color, io.feat_phasor = _p(rot_c), _p(raw_c), _p(fc_c), _p(fp_c)
+        io.motion_mask = _p(mask_c)
+        for name, v in zip(("d_xyz", "d_rot", "d_sh", "d_sh_p"), offs):
+            if _is_tensor(v):
+                setattr(io, name, _p(v))
+            else:
+                setattr(io, name + "_scalar", v)
+        io.scratch = scratch.data_ptr()
+        io.out_means3D, io.out_means2D, io.out_opacity = _p(means3D), _p(means2D), _p(out_op)
+        io.out_scales, io.out_rotations, io.out_shs, io.out_shs_p = _p(scales), _p(rotations), _p(shs), _p(shs_p)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(lib.gft_assemble_forward(stream, P, M, M_p, int(render_static), int(render_dynamic), C.byref(io)))
+            if validate:
+                # the reference's masked assignment raises when d_* has another row count
+                nd = C.c_int64(0)
+                _lib.check(lib.gft_assemble_num_dynamic(stream, P, scratch.data_ptr(), C.byref(nd)))
+                for v, n in zip(offs, ("d_xyz", "d_rot", "d_sh", "d_sh_p")):
+                    if _is_tensor(v) and v.size(0) != nd.value:
+                        raise RuntimeError("shape mismatch: %s has %d rows, motion_mask selects %d Gaussians"
+                                           % (n, v.size(0), nd.value))
+        ctx.sizes = (P, M, M_p, int(render_static), int(render_dynamic))
+        ctx.offs_scalar = [None if _is_tensor(v) else v for v in offs]
+        ctx.off_rows = [v.size(0) if _is_tensor(v) else 0 for v in offs]
+        ctx.opacity_shape = opacity.shape
+        ctx.save_for_backward(raw_c, offs[1] if _is_tensor(offs[1]) else raw_c.new_empty(0), scratch)
+        ctx.set_materialize_grads(False)
+        return means3D, means2D, out_op, scales, rotations, shs, shs_p
+
+    @staticmethod
+    def backward(ctx, g_means3D, g_means2D, g_opacity, g_scales, g_rotations, g_shs, g_shs_p):
+        lib = _lib.load()
+        raw_c, d_rot_c, scratch = ctx.saved_tensors
+        P, M, M_p, rs, rd = ctx.sizes
+        dev = raw_c.device
+        need = ctx.needs_input_grad
+        f32 = dict(device=dev, dtype=torch.float32)
+        new = lambda want, shape: torch.empty(shape, **f32) if want else None
+        g_xyz, g_ssp = new(need[0], (P, 3)), new(need[1], (P, 3))
+        g_op, g_sc = new(need[2], tuple(ctx.opacity_shape)), new(need[3], (P, 3))
+        g_rot, g_raw = new(need[4], (P, 4)), new(need[5], (P, 4))
+        g_fc, g_fp = new(need[6], (P, M, 3)), new(need[7], (P, M_p, 2))
+        nd = ctx.off_rows
+        g_dxyz = new(need[9] and nd[0] >= 0 and ctx.offs_scalar[0] is None, (nd[0], 3))
+        g_drot = new(need[10] and ctx.offs_scalar[1] is None, (nd[1], 4))
+        g_dsh = new(need[11] and ctx.offs_scalar[2] is None, (nd[2], M, 3))
+        g_dshp = new(need[12] and ctx.offs_scalar[3] is None, (nd[3], M_p, 2))
+
+        gc = lambda t, n: None if t is None else _f32c(t, dev, "grad_" + n)
+        gs = [gc(t, n) for t, n in ((g_means3D, "means3D"), (g_means2D, "means2D"), (g_opacity, "opacity"),
+                                    (g_scales, "scales"), (g_rotations, "rotations"), (g_shs, "shs"), (g_shs_p, "shs_p"))]
+        io = _lib.AssembleBwdIO()
+        io.scratch, io.rotation_raw = scratch.data_ptr(), _p(raw_c)
+        if ctx.offs_scalar[1] is None:
+            io.d_rot = _p(d_rot_c)
+        else:
+            io.d_rot_scalar = ctx.offs_scalar[1]
+        (io.g_means3D, io.g_means2D, io.g_opacity, io.g_scales, io.g_rotations, io.g_shs, io.g_shs_p) = [_p(t) for t in gs]
+        io.g_xyz, io.g_screenspace, io.g_opacity_in, io.g_scaling = _p(g_xyz), _p(g_ssp), _p(g_op), _p(g_sc)
+        io.g_rotation, io.g_rotation_raw, io.g_feat_color, io.g_feat_phasor = _p(g_rot), _p(g_raw), _p(g_fc), _p(g_fp)
+        io.g_d_xyz, io.g_d_rot, io.g_d_sh, io.g_d_sh_p = _p(g_dxyz), _p(g_drot), _p(g_dsh), _p(g_dshp)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(lib.gft_assemble_backward(stream, P, M, M_p, rs, rd, C.byref(io)))
+        return (g_xyz, g_ssp, g_op, g_sc, g_rot, g_raw, g_fc, g_fp, None, g_dxyz, g_drot, g_dsh, g_dshp,
+                None, None, None)
+
+
+def assemble_inputs(xyz, screenspace_points, opacity, scaling, rotation, rotation_raw, features_color,
+                    features_phasor, motion_mask, d_xyz=0.0, d_rot=0.0, d_sh=0.0, d_sh_p=0.0,
+                    render_regions=("static", "dynamic"), validate=False):
+    """Returns ``(means3D, means2D, opacity, scales, rotations, shs, shs_p)`` exactly as lines 81-105
+    of the reference's ``gaussian_renderer/__init__.py`` build them.  ``validate=True`` adds the
+    reference's row-count check of the ``d_*`` tensors (one blocking read)."""
+    return _AssembleInputs.apply(xyz, screenspace_points, opacity, scaling, rotation, rotation_raw,
+                                 features_color, features_phasor, motion_mask, d_xyz, d_rot, d_sh, d_sh_p,
+                                 "static" in render_regions, "dynamic" in render_regions, validate)

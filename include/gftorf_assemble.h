@@ -1,0 +1,106 @@
+/*
+ * gftorf_assemble.h -- C ABI of the fused input assembly of libgftorf_rast.so (gfx950).
+ *
+ * SURVEY section 8(f) row 1.  Replaces the eager-PyTorch glue that builds the rasterizer's
+ * seven per-Gaussian inputs before every render in the reference
+ * (gaussian_renderer/__init__.py:81-105 of brownvc/gftorf):
+ *
+ *     means3D = zeros; means2D = zeros; opacity = zeros; ...            (:81-87)
+ *     if "static"  in render_regions: X[~motion_mask] = src[~motion_mask]          (:89-96)
+ *     if "dynamic" in render_regions: means3D[motion_mask] = xyz[motion_mask] + d_xyz
+ *                                     rotations[motion_mask] = normalize(_rotation[motion_mask] + d_rot)
+ *                                     shs[motion_mask] = features_color[motion_mask] + d_sh ...  (:97-104)
+ *
+ * and its autograd backward.  The d_* offsets are the deformation network's outputs for the
+ * dynamic Gaussians, one row per True of motion_mask in order (scene/gaussian_model.py:170-174),
+ * or the Python float 0.0 when there is no deformation (train.py:164).
+ *
+ * Plain device pointers and sizes, no torch types; every entry point returns 0 on success
+ * (message from gft_last_error()).  The caller owns all memory; outputs and gradients are
+ * written in full, so they can be allocated uninitialised.
+ */
+#ifndef GFTORF_ASSEMBLE_H
+#define GFTORF_ASSEMBLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gft_assemble_io {
+    /* per-Gaussian sources (what the reference reads through pc.get_*), all fp32 contiguous */
+    const float* xyz;            /* [P,3]   pc.get_xyz */
+    const float* screenspace;    /* [P,3]   screenspace_points (zeros; gradient sink) */
+    const float* opacity;        /* [P,1]   pc.get_opacity   (activated) */
+    const float* scaling;        /* [P,3]   pc.get_scaling   (activated) */
+    const float* rotation;       /* [P,4]   pc.get_rotation  (normalised; used for static rows) */
+    const float* rotation_raw;   /* [P,4]   pc._rotation     (used for dynamic rows) */
+    const float* feat_color;     /* [P,M,3] pc.get_features_color,  NULL iff M == 0 */
+    const float* feat_phasor;    /* [P,M_p,2] pc.get_features_phasor, NULL iff M_p == 0 */
+    const uint8_t* motion_mask;  /* [P]     torch.bool */
+    /* offsets of the dynamic rows: [Nd,3], [Nd,4], [Nd,M,3], [Nd,M_p,2]; NULL = use the scalar */
+    const float* d_xyz;
+    const float* d_rot;
+    const float* d_sh;
+    const float* d_sh_p;
+    float d_xyz_scalar, d_rot_scalar, d_sh_scalar, d_sh_p_scalar;
+    /* scratch of gft_assemble_scratch_bytes(P): the rank of every dynamic row (forward ->
+     * backward hand-off) and the block sums of the rank scan */
+    void* scratch;
+    /* outputs = the rasterizer's inputs */
+    float* out_means3D;          /* [P,3] */
+    float* out_means2D;          /* [P,3] */
+    float* out_opacity;          /* [P,1] */
+    float* out_scales;           /* [P,3] */
+    float* out_rotations;        /* [P,4] */
+    float* out_shs;              /* [P,M,3] */
+    float* out_shs_p;            /* [P,M_p,2] */
+} gft_assemble_io;
+
+typedef struct gft_assemble_bwd_io {
+    const void* scratch;         /* as written by the forward */
+    const float* rotation_raw;   /* [P,4] */
+    const float* d_rot;          /* [Nd,4] or NULL (scalar) */
+    float d_rot_scalar;
+    /* upstream gradients of the seven outputs; NULL = zeros */
+    const float* g_means3D;
+    const float* g_means2D;
+    const float* g_opacity;
+    const float* g_scales;
+    const float* g_rotations;
+    const float* g_shs;
+    const float* g_shs_p;
+    /* gradients of the sources, written in full; NULL = not wanted */
+    float* g_xyz;                /* [P,3] */
+    float* g_screenspace;        /* [P,3] */
+    float* g_opacity_in;         /* [P,1] */
+    float* g_scaling;            /* [P,3] */
+    float* g_rotation;           /* [P,4]  static rows, zeros elsewhere */
+    float* g_rotation_raw;       /* [P,4]  dynamic rows (through the normalisation), zeros elsewhere */
+    float* g_feat_color;         /* [P,M,3] */
+    float* g_feat_phasor;        /* [P,M_p,2] */
+    float* g_d_xyz;              /* [Nd,3] */
+    float* g_d_rot;              /* [Nd,4] */
+    float* g_d_sh;               /* [Nd,M,3] */
+    float* g_d_sh_p;             /* [Nd,M_p,2] */
+} gft_assemble_bwd_io;
+
+size_t gft_assemble_scratch_bytes(int32_t P);
+
+/* render_static / render_dynamic: "static" / "dynamic" in render_regions */
+int gft_assemble_forward(void* hip_stream, int32_t P, int32_t M, int32_t M_p, int32_t render_static,
+                         int32_t render_dynamic, const gft_assemble_io* io);
+
+/* number of True entries of motion_mask as counted by the forward (blocking read; the
+ * reference's masked assignment raises when d_* has another row count) */
+int gft_assemble_num_dynamic(void* hip_stream, int32_t P, const void* scratch, int64_t* num_dynamic /*host*/);
+
+int gft_assemble_backward(void* hip_stream, int32_t P, int32_t M, int32_t M_p, int32_t render_static,
+                          int32_t render_dynamic, const gft_assemble_bwd_io* io);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -23,10 +23,16 @@ def lib():
     return _lib.load()
 
 
+HEADERS = [HEADER, os.path.join(ROOT, "include", "gftorf_assemble.h")]
+
+
 def declared_functions():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(gft_[a-z_0-9]+)\s*\(", src)))
+    names = set()
+    for h in HEADERS:
+        src = open(h).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(gft_[a-z_0-9]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -44,8 +50,10 @@ def test_header_is_plain_c_and_matches_ctypes(tmp_path, lib):
     fields = {"gft_config": [f[0] for f in _lib.Config._fields_],
               "gft_forward_io": _lib.FORWARD_FIELDS, "gft_backward_io": _lib.BACKWARD_FIELDS,
               "gft_layout": _lib.LAYOUT_FIELDS,
-              "gft_profile": _lib.PROFILE_FIELDS + ["forward_calls", "backward_calls"]}
-    body = ['#include <stdio.h>', '#include <stddef.h>', '#include "gftorf_rast.h"', 'int main(void){']
+              "gft_profile": _lib.PROFILE_FIELDS + ["forward_calls", "backward_calls"],
+              "gft_assemble_io": _lib.ASSEMBLE_FIELDS, "gft_assemble_bwd_io": _lib.ASSEMBLE_BWD_FIELDS}
+    body = ['#include <stdio.h>', '#include <stddef.h>', '#include "gftorf_rast.h"', '#include "gftorf_assemble.h"',
+            'int main(void){']
     for s, fl in fields.items():
         body.append('printf("%s %%zu\\n", sizeof(%s));' % (s, s))
         for f in fl:
@@ -56,7 +64,8 @@ def test_header_is_plain_c_and_matches_ctypes(tmp_path, lib):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     out = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
     mirrors = {"gft_config": _lib.Config, "gft_forward_io": _lib.ForwardIO, "gft_backward_io": _lib.BackwardIO,
-               "gft_layout": _lib.Layout, "gft_profile": _lib.Profile}
+               "gft_layout": _lib.Layout, "gft_profile": _lib.Profile,
+               "gft_assemble_io": _lib.AssembleIO, "gft_assemble_bwd_io": _lib.AssembleBwdIO}
     for s, cls in mirrors.items():
         assert int(out[s]) == C.sizeof(cls), s
         for f in fields[s]:

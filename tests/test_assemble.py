@@ -1,0 +1,144 @@
+"""Fused input assembly: oracle pins on CPU, HIP parity on the GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import assemble_ref as R   # noqa: E402
+
+
+def make_case(P, M=16, M_p=16, frac=0.3, seed=0, offsets="tensor", mask=None):
+    rng = np.random.default_rng(seed)
+    f = lambda *s: rng.normal(0, 1, s).astype(np.float32)
+    m = (rng.random(P) < frac) if mask is None else mask
+    nd = int(m.sum())
+    raw = f(P, 4)
+    c = dict(xyz=f(P, 3), ssp=f(P, 3), opacity=rng.random((P, 1)).astype(np.float32), scaling=np.exp(f(P, 3) * 0.3),
+             rotation=raw / np.linalg.norm(raw, axis=1, keepdims=True), rotation_raw=raw, fc=f(P, M, 3), fp=f(P, M_p, 2),
+             mask=m)
+    if offsets == "tensor":
+        c.update(d_xyz=f(nd, 3) * 0.1, d_rot=f(nd, 4) * 0.1, d_sh=f(nd, M, 3) * 0.1, d_sh_p=f(nd, M_p, 2) * 0.1)
+    elif offsets == "float":
+        c.update(d_xyz=0.0, d_rot=0.0, d_sh=0.0, d_sh_p=0.0)
+    else:   # the deformation network returns zeros for d_rot / d_sh_p (utils/time_utils.py:127)
+        c.update(d_xyz=f(nd, 3) * 0.1, d_rot=0.0, d_sh=f(nd, M, 3) * 0.1, d_sh_p=0.0)
+    return c
+
+
+ORDER = ["xyz", "ssp", "opacity", "scaling", "rotation", "rotation_raw", "fc", "fp", "mask", "d_xyz", "d_rot", "d_sh", "d_sh_p"]
+OUTS = ["means3D", "means2D", "opacity", "scales", "rotations", "shs", "shs_p"]
+
+
+def tensors(c, dev, grad):
+    out = []
+    for k in ORDER:
+        v = c[k]
+        if isinstance(v, np.ndarray):
+            t = torch.tensor(v, device=dev)
+            if grad and t.dtype == torch.float32:
+                t.requires_grad_(True)
+            out.append(t)
+        else:
+            out.append(v)
+    return out
+
+
+def run(fn, c, dev, regions, grad=True, seed=7, **kw):
+    args = tensors(c, dev, grad)
+    outs = fn(*args, render_regions=regions, **kw)
+    grads = None
+    if grad:
+        g = np.random.default_rng(seed)
+        loss = sum((o * torch.tensor(g.normal(0, 1, tuple(o.shape)).astype(np.float32), device=dev)).sum() for o in outs)
+        loss.backward()
+        grads = {k: (a.grad.cpu().numpy() if isinstance(a, torch.Tensor) and a.grad is not None else None)
+                 for k, a in zip(ORDER, args)}
+    return [o.detach().cpu().numpy() for o in outs], grads
+
+
+@pytest.mark.parametrize("regions", [("static", "dynamic"), ("static",), ("dynamic",), ()])
+@pytest.mark.parametrize("offsets", ["tensor", "float"])
+def test_eager_restatement_equals_loops(regions, offsets):
+    c = make_case(257, M=4, M_p=4, seed=3, offsets=offsets)
+    got, _ = run(R.assemble_eager, c, "cpu", regions, grad=False)
+    ref = R.assemble_loops(*[c[k] for k in ORDER], render_regions=regions)
+    for name, a, b in zip(OUTS, got, ref):
+        np.testing.assert_allclose(a, b, rtol=2e-7, atol=0, err_msg=name)
+
+
+def test_eager_gradients_reach_every_source():
+    c = make_case(100, M=4, M_p=4, seed=5)
+    _, g = run(R.assemble_eager, c, "cpu", ("static", "dynamic"))
+    m = c["mask"]
+    assert np.abs(g["rotation"][m]).max() == 0 and np.abs(g["rotation"][~m]).max() > 0
+    assert np.abs(g["rotation_raw"][~m]).max() == 0 and np.abs(g["rotation_raw"][m]).max() > 0
+    for k in ("d_xyz", "d_rot", "d_sh", "d_sh_p", "xyz", "ssp", "opacity", "scaling", "fc", "fp"):
+        assert g[k] is not None and np.abs(g[k]).max() > 0, k
+
+
+def test_product_raises_on_cpu_tensors():
+    from gftorf_amd import assemble_inputs
+    c = make_case(8, M=4, M_p=4)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        assemble_inputs(*tensors(c, "cpu", False))
+
+
+CASES = {
+    "metric_shape": dict(P=5000, M=16, M_p=16),
+    "odd_rows": dict(P=1025, M=9, M_p=9),                 # 27 / 18 floats per row: scalar path
+    "one_coeff": dict(P=300, M=1, M_p=1),
+    "all_static": dict(P=2049, M=16, M_p=16, frac=0.0),
+    "all_dynamic": dict(P=2047, M=16, M_p=16, frac=1.0),
+    "mlp_zeros": dict(P=3000, M=16, M_p=16, offsets="mlp"),
+    "float_offsets": dict(P=3000, M=16, M_p=16, offsets="float"),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regions", [("static", "dynamic"), ("static",), ("dynamic",), ()])
+@pytest.mark.parametrize("name", list(CASES))
+def test_hip_assembly_vs_oracle(name, regions, gpu):
+    from gftorf_amd import assemble_inputs
+    c = make_case(seed=11, **CASES[name])
+    # with nothing rendered the eager outputs are constants (no graph): every gradient is zero
+    ref, rg = run(R.assemble_eager, c, "cpu", regions, grad=bool(regions))
+    got, gg = run(assemble_inputs, c, gpu, regions, validate=True)
+    if not regions:
+        rg = {k: None for k in ORDER}
+    for n, a, b in zip(OUTS, ref, got):
+        if n == "rotations":
+            np.testing.assert_allclose(b, a, rtol=3e-7, atol=1e-7, err_msg=n)     # sqrt / divide rounding
+        else:
+            np.testing.assert_array_equal(b, a, err_msg=n)                       # copies and single adds
+    for k in ORDER:
+        if rg[k] is None:
+            assert gg[k] is None or gg[k].size == 0 or np.abs(gg[k]).max() == 0, k
+            continue
+        if k == "rotation_raw" or k == "d_rot":
+            np.testing.assert_allclose(gg[k], rg[k], rtol=2e-5, atol=2e-6, err_msg=k)
+        else:
+            np.testing.assert_array_equal(gg[k], rg[k], err_msg=k)
+
+
+@pytest.mark.gpu
+def test_hip_assembly_edge_cases(gpu):
+    from gftorf_amd import assemble_inputs
+    # no Gaussians
+    c = make_case(0, M=16, M_p=16)
+    outs = assemble_inputs(*tensors(c, gpu, False))
+    assert [tuple(o.shape) for o in outs] == [(0, 3), (0, 3), (0, 1), (0, 3), (0, 4), (0, 16, 3), (0, 16, 2)]
+    # wrong row count of the offsets is reported like the reference's masked assignment would
+    c = make_case(500, M=4, M_p=4, seed=2)
+    c["d_xyz"] = c["d_xyz"][:-1]
+    with pytest.raises(RuntimeError, match="shape mismatch"):
+        assemble_inputs(*tensors(c, gpu, False), validate=True)
+    # a degenerate dynamic quaternion takes the clamped branch of normalize
+    c = make_case(64, M=4, M_p=4, seed=4, offsets="float", mask=np.ones(64, bool))
+    c["rotation_raw"][:] = 0
+    ref, _ = run(R.assemble_eager, c, "cpu", ("dynamic",), grad=False)
+    got, _ = run(assemble_inputs, c, gpu, ("dynamic",), grad=False)
+    np.testing.assert_array_equal(got[4], ref[4])
