@@ -184,6 +184,58 @@ def load_traffic(kernel, workload):
         return None
 
 
+def assemble_extra(dev, P=1_000_000, frac=0.3, M=16, steps=20, warmup=5):
+    """SURVEY 8(f) row 1 beside the headline metric: the fused input assembly (forward + backward)
+    against the reference's eager-PyTorch glue (gaussian_renderer/__init__.py:81-105, restated in
+    oracle/assemble_ref.py) on the same device.  Algorithmic bytes per Gaussian at M = 16, fp32:
+    forward reads 12+12+4+12+16+192+128 = 376 (+ 348 of offsets for a dynamic row) and writes 388;
+    backward reads 388 and writes 392 (+ 348 for a dynamic row)."""
+    import numpy as np
+    import torch
+    from gftorf_amd import assemble_inputs
+    from oracle import assemble_ref
+    rng = np.random.default_rng(99)
+    f = lambda *s: torch.tensor(rng.normal(0, 1, s).astype(np.float32), device=dev)
+    mask = torch.tensor(rng.random(P) < frac, device=dev)
+    nd = int(mask.sum().item())
+    raw = f(P, 4)
+    src = [f(P, 3), f(P, 3), torch.rand((P, 1), device=dev), f(P, 3).exp(), torch.nn.functional.normalize(raw), raw,
+           f(P, M, 3), f(P, M, 2)]
+    offs = [f(nd, 3), f(nd, 4), f(nd, M, 3), f(nd, M, 2)]
+    for t in src + offs:
+        t.requires_grad_(True)
+    gout = None
+
+    def step(fn):
+        nonlocal gout
+        outs = fn(*src, mask, *offs)
+        if gout is None:
+            gout = [torch.randn_like(o) for o in outs]
+        torch.autograd.backward(outs, gout)
+        for t in src + offs:
+            t.grad = None
+
+    def timed(fn, n, w):
+        for _ in range(w):
+            step(fn)
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            step(fn)
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / n
+
+    fused_ms = timed(assemble_inputs, steps, warmup)
+    eager_ms = timed(assemble_ref.assemble_eager, max(3, steps // 4), 2)
+    bytes_alg = P * (376 + 388 + 388 + 392) + nd * (348 + 348)
+    return {"what": "fused input assembly fwd+bwd (SURVEY 8(f)#1), %d Gaussians, %d dynamic, SH 16" % (P, nd),
+            "fused_ms": fused_ms, "eager_torch_ms": eager_ms, "speedup_vs_eager": eager_ms / fused_ms,
+            "algorithmic_bytes": bytes_alg, "achieved_GBs": bytes_alg / (fused_ms * 1e-3) / 1e9,
+            "frac_of_hbm_peak": bytes_alg / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +244,7 @@ def main():
     ap.add_argument("--workload", default="metric", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the fused-assembly measurement")
     args = ap.parse_args()
 
     import torch
@@ -264,6 +317,10 @@ def main():
                               "gpu_ms_sum_of_stages": sum(stage_ms.values())},
             "stage_ms": stage_ms,
         }
+        if world == 1 and not args.no_extras and args.workload == "metric":
+            del state, step
+            torch.cuda.empty_cache()
+            out["extras"] = {"assemble_inputs": assemble_extra(dev)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, budget_s=args.cpu_budget)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
