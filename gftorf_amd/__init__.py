@@ -8,5 +8,6 @@ operator API, hand-written gfx950 HIP kernels behind a C ABI
 from .api import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians,  # noqa: F401
                   _RasterizeGaussians)
 from .assemble import assemble_inputs  # noqa: F401
+from .knn import distCUDA2  # noqa: F401
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "assemble_inputs"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "assemble_inputs", "distCUDA2"]

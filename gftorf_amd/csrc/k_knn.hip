@@ -1,0 +1,296 @@
+// k_knn.hip -- mean squared distance to the 3 nearest neighbours of every point (gfx950).
+//
+// Drop-in arithmetic of the reference's second native extension, simple_knn._C.distCUDA2
+// (submodules/simple-knn/simple_knn.cu:185-220, spatial.cu:14-25), which
+// scene/gaussian_model.py:194-199 calls once to initialise the Gaussian scales: exact 3-NN
+// (self excluded by index, duplicates count with distance 0), result (d0 + d1 + d2) / 3.
+// The reference groups points into boxes of 1024 along a Morton curve (CUB radix sort) and
+// prunes boxes by their distance to the query; any grouping gives the same result, only the
+// amount of pruning changes.  MI355X form, everything on the device, no host round trip:
+//
+//   k_knn_bounds  : bounding box (block partials, last workgroup reduces; like the reference the
+//                   reduction starts from 0, so the box contains the origin, simple_knn.cu:190-198)
+//   k_knn_codes   : 30-bit Morton code per point, histogram of its top 15 bits (32768 cells)
+//   k_knn_scan    : exclusive scan of the cell counters
+//   k_knn_scatter : counting-sort placement by cell (order inside a cell is arbitrary: it only
+//                   decides which points share a box, never a result)
+//   k_knn_boxes   : min/max of every run of 1024 placed points
+//   k_knn_search  : one workgroup per 256 consecutive (spatially close) points: the box table is
+//                   walked once per workgroup, a box that any lane still needs is staged in LDS
+//                   (12 KB) and scanned with broadcast reads
+#include "gft_internal.h"
+#include "gftorf_knn.h"
+
+#include <cfloat>
+
+namespace {
+
+#define KNN_BOX 1024
+#define KNN_CELLS 32768
+#define KNN_BLOCK 256
+
+struct Bounds { float mn[3], mx[3]; };
+
+__global__ __launch_bounds__(KNN_BLOCK) void k_knn_bounds(int P, const float* __restrict__ pts, Bounds* partial,
+                                                          uint32_t* ticket, Bounds* __restrict__ out)
+{
+    __shared__ float s[6][KNN_BLOCK / 64];
+    __shared__ uint32_t s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};               // the reference's reduction starts from (0,0,0)
+    for (int i = blockIdx.x * KNN_BLOCK + tid; i < P; i += gridDim.x * KNN_BLOCK) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float x = pts[3 * (size_t)i + c];
+            v[c] = fminf(v[c], x);
+            v[3 + c] = fmaxf(v[3 + c], x);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const float o = __shfl_xor(v[c], d, 64);
+            v[c] = c < 3 ? fminf(v[c], o) : fmaxf(v[c], o);
+        }
+        if (lane == 0) s[c][wave] = v[c];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        Bounds b;
+        for (int c = 0; c < 3; c++) {
+            b.mn[c] = s[c][0]; b.mx[c] = s[3 + c][0];
+            for (int w = 1; w < KNN_BLOCK / 64; w++) { b.mn[c] = fminf(b.mn[c], s[c][w]); b.mx[c] = fmaxf(b.mx[c], s[3 + c][w]); }
+        }
+        for (int c = 0; c < 3; c++) {
+            __hip_atomic_store(&partial[blockIdx.x].mn[c], b.mn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&partial[blockIdx.x].mx[c], b.mx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last || tid != 0) return;
+    Bounds b;
+    for (int c = 0; c < 3; c++) { b.mn[c] = 0.f; b.mx[c] = 0.f; }
+    for (uint32_t k = 0; k < gridDim.x; k++)
+        for (int c = 0; c < 3; c++) {
+            b.mn[c] = fminf(b.mn[c], __hip_atomic_load(&partial[k].mn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            b.mx[c] = fmaxf(b.mx[c], __hip_atomic_load(&partial[k].mx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+    *out = b;
+    *ticket = 0;
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t x)       // simple_knn.cu:45-52
+{
+    x = (x | (x << 16)) & 0x030000FF;
+    x = (x | (x << 8)) & 0x0300F00F;
+    x = (x | (x << 4)) & 0x030C30C3;
+    x = (x | (x << 2)) & 0x09249249;
+    return x;
+}
+
+__global__ __launch_bounds__(KNN_BLOCK) void k_knn_codes(int P, const float* __restrict__ pts,
+                                                         const Bounds* __restrict__ bounds, uint32_t* __restrict__ cell_of,
+                                                         uint32_t* __restrict__ cell_cnt)
+{
+    const int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    const Bounds b = *bounds;
+    uint32_t q[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        // simple_knn.cu:56-58: ((x - min) / (max - min)) * 1023, truncated; a flat axis gives 0/0 there,
+        // any cell is as good here
+        const float ext = b.mx[c] - b.mn[c];
+        const float t = ext > 0.f ? ((pts[3 * (size_t)i + c] - b.mn[c]) / ext) * 1023.0f : 0.f;
+        q[c] = (uint32_t)fminf(fmaxf(t, 0.f), 1023.0f);
+    }
+    const uint32_t code = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    const uint32_t cell = code >> 15;
+    cell_of[i] = cell;
+    atomicAdd(&cell_cnt[cell], 1u);
+}
+
+__global__ __launch_bounds__(1024) void k_knn_scan(uint32_t* cell_cnt, uint32_t* __restrict__ cell_cur)
+{
+    __shared__ uint32_t s_w[16];
+    constexpr int PER = KNN_CELLS / 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { loc[k] = cell_cnt[tid * PER + k]; sum += loc[k]; }
+    uint32_t x = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    uint32_t off = x - sum;
+    for (int w = 0; w < wave; w++) off += s_w[w];
+#pragma unroll
+    for (int k = 0; k < PER; k++) { cell_cur[tid * PER + k] = off; off += loc[k]; cell_cnt[tid * PER + k] = 0; }
+}
+
+__global__ __launch_bounds__(KNN_BLOCK) void k_knn_scatter(int P, const uint32_t* __restrict__ cell_of,
+                                                           uint32_t* __restrict__ cell_cur, uint32_t* __restrict__ order)
+{
+    const int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    order[atomicAdd(&cell_cur[cell_of[i]], 1u)] = (uint32_t)i;
+}
+
+// placed coordinates (so the search reads them contiguously) and box bounds
+__global__ __launch_bounds__(KNN_BOX) void k_knn_boxes(int P, const float* __restrict__ pts, const uint32_t* __restrict__ order,
+                                                       float* __restrict__ placed, Bounds* __restrict__ boxes)
+{
+    __shared__ float s[6][KNN_BOX / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = blockIdx.x * KNN_BOX + tid;
+    float v[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (j < P) {
+        const uint32_t i = order[j];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float x = pts[3 * (size_t)i + c];
+            placed[3 * (size_t)j + c] = x;
+            v[c] = x; v[3 + c] = x;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const float o = __shfl_xor(v[c], d, 64);
+            v[c] = c < 3 ? fminf(v[c], o) : fmaxf(v[c], o);
+        }
+        if (lane == 0) s[c][wave] = v[c];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        Bounds b;
+        for (int c = 0; c < 3; c++) {
+            b.mn[c] = s[c][0]; b.mx[c] = s[3 + c][0];
+            for (int w = 1; w < KNN_BOX / 64; w++) { b.mn[c] = fminf(b.mn[c], s[c][w]); b.mx[c] = fmaxf(b.mx[c], s[3 + c][w]); }
+        }
+        boxes[blockIdx.x] = b;
+    }
+}
+
+// simple_knn.cu:119-129
+__device__ __forceinline__ float box_point_dist2(const Bounds& b, float px, float py, float pz)
+{
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (px < b.mn[0] || px > b.mx[0]) dx = fminf(fabsf(px - b.mn[0]), fabsf(px - b.mx[0]));
+    if (py < b.mn[1] || py > b.mx[1]) dy = fminf(fabsf(py - b.mn[1]), fabsf(py - b.mx[1]));
+    if (pz < b.mn[2] || pz > b.mx[2]) dz = fminf(fabsf(pz - b.mn[2]), fabsf(pz - b.mx[2]));
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+// simple_knn.cu:131-146 (insertion into the three smallest); the squared distance is the
+// expression d.x*d.x + d.y*d.y + d.z*d.z as nvcc contracts it by default
+__device__ __forceinline__ void keep3(float px, float py, float pz, float qx, float qy, float qz, float* best)
+{
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    float dist = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        if (best[j] > dist) {
+            const float t = best[j];
+            best[j] = dist;
+            dist = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(KNN_BLOCK) void k_knn_search(int P, const float* __restrict__ placed,
+                                                          const uint32_t* __restrict__ order,
+                                                          const Bounds* __restrict__ boxes, float* __restrict__ out)
+{
+    __shared__ float s_pts[KNN_BOX * 3];
+    __shared__ uint32_t s_any;
+    const int tid = threadIdx.x;
+    const int j = blockIdx.x * KNN_BLOCK + tid;
+    const bool in = j < P;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (in) { px = placed[3 * (size_t)j]; py = placed[3 * (size_t)j + 1]; pz = placed[3 * (size_t)j + 2]; }
+    float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    // first bound from the neighbours along the placement order (simple_knn.cu:156-161)
+    if (in) {
+        const int lo = max(0, j - 3), hi = min(P - 1, j + 3);
+        for (int i = lo; i <= hi; i++)
+            if (i != j) keep3(px, py, pz, placed[3 * (size_t)i], placed[3 * (size_t)i + 1], placed[3 * (size_t)i + 2], best);
+    }
+    const float reject = best[2];
+    best[0] = best[1] = best[2] = FLT_MAX;
+    const int nboxes = (P + KNN_BOX - 1) / KNN_BOX;
+    for (int b = 0; b < nboxes; b++) {
+        bool want = false;
+        if (in) {
+            const float d = box_point_dist2(boxes[b], px, py, pz);
+            want = !(d > reject || d > best[2]);                 // simple_knn.cu:171-173
+        }
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        if (want) s_any = 1;                                     // benign race: every writer stores 1
+        __syncthreads();
+        if (s_any) {                                             // uniform per workgroup
+            const int first = b * KNN_BOX, cnt = min(KNN_BOX, P - first);
+            for (int k = tid; k < cnt * 3; k += KNN_BLOCK) s_pts[k] = placed[3 * (size_t)first + k];
+            __syncthreads();
+            if (want) {
+                for (int k = 0; k < cnt; k++)
+                    if (first + k != j) keep3(px, py, pz, s_pts[3 * k], s_pts[3 * k + 1], s_pts[3 * k + 2], best);
+            }
+        }
+        __syncthreads();
+    }
+    if (in) out[order[j]] = (best[0] + best[1] + best[2]) / 3.0f;
+}
+
+}  // namespace
+
+extern "C" size_t gft_knn_scratch_bytes(int32_t P)
+{
+    const size_t p = (size_t)(P > 0 ? P : 0);
+    const size_t nboxes = (p + KNN_BOX - 1) / KNN_BOX;
+    // cell_of u32[P] | order u32[P] | placed f32[3P] | boxes | cell_cnt, cell_cur u32[32768] each |
+    // bounds partials (256) + result + ticket
+    return p * 4 * 2 + p * 12 + nboxes * sizeof(Bounds) + 2 * KNN_CELLS * 4 + 258 * sizeof(Bounds) + 1024;
+}
+
+extern "C" int gft_knn_mean_dist2(void* hip_stream, int32_t P, const float* points, float* mean_dist2, void* scratch)
+{
+    if (P < 0) return gft_fail("gft_knn_mean_dist2: P < 0");
+    if (P == 0) return 0;
+    if (!points || !mean_dist2 || !scratch) return gft_fail("gft_knn_mean_dist2: NULL pointer");
+    hipStream_t s = (hipStream_t)hip_stream;
+    const size_t p = (size_t)P;
+    const int nboxes = (P + KNN_BOX - 1) / KNN_BOX;
+    char* b = (char*)scratch;
+    uint32_t* cell_of = (uint32_t*)b;             b += p * 4;
+    uint32_t* order = (uint32_t*)b;               b += p * 4;
+    float* placed = (float*)b;                    b += p * 12;
+    b = (char*)(((uintptr_t)b + 255) & ~(uintptr_t)255);
+    Bounds* boxes = (Bounds*)b;                   b += (size_t)nboxes * sizeof(Bounds);
+    uint32_t* cell_cnt = (uint32_t*)b;            b += KNN_CELLS * 4;
+    uint32_t* cell_cur = (uint32_t*)b;            b += KNN_CELLS * 4;
+    Bounds* partial = (Bounds*)b;                 b += 256 * sizeof(Bounds);
+    Bounds* bounds = (Bounds*)b;                  b += sizeof(Bounds);
+    uint32_t* ticket = (uint32_t*)b;
+    GFT_CHECK_HIP(hipMemsetAsync(cell_cnt, 0, KNN_CELLS * 4, s));
+    GFT_CHECK_HIP(hipMemsetAsync(ticket, 0, 4, s));
+    const int blocks = (P + KNN_BLOCK - 1) / KNN_BLOCK;
+    hipLaunchKernelGGL(k_knn_bounds, dim3(blocks < 256 ? blocks : 256), dim3(KNN_BLOCK), 0, s, P, points, partial, ticket, bounds);
+    hipLaunchKernelGGL(k_knn_codes, dim3(blocks), dim3(KNN_BLOCK), 0, s, P, points, bounds, cell_of, cell_cnt);
+    hipLaunchKernelGGL(k_knn_scan, dim3(1), dim3(1024), 0, s, cell_cnt, cell_cur);
+    hipLaunchKernelGGL(k_knn_scatter, dim3(blocks), dim3(KNN_BLOCK), 0, s, P, cell_of, cell_cur, order);
+    hipLaunchKernelGGL(k_knn_boxes, dim3(nboxes), dim3(KNN_BOX), 0, s, P, points, order, placed, boxes);
+    hipLaunchKernelGGL(k_knn_search, dim3(blocks), dim3(KNN_BLOCK), 0, s, P, placed, order, boxes, mean_dist2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gft_fail("gft_knn_mean_dist2: %s", hipGetErrorString(e));
+    return 0;
+}

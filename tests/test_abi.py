@@ -23,7 +23,7 @@ def lib():
     return _lib.load()
 
 
-HEADERS = [HEADER, os.path.join(ROOT, "include", "gftorf_assemble.h")]
+HEADERS = [HEADER, os.path.join(ROOT, "include", "gftorf_assemble.h"), os.path.join(ROOT, "include", "gftorf_knn.h")]
 
 
 def declared_functions():
