@@ -236,6 +236,40 @@ def assemble_extra(dev, P=1_000_000, frac=0.3, M=16, steps=20, warmup=5):
             "frac_of_hbm_peak": bytes_alg / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def knn_extra(dev, P=1_000_000):
+    """SURVEY 8(f) row 3 beside the headline metric: distCUDA2 (mean squared distance to the 3
+    nearest neighbours, the scale initialisation of scene/gaussian_model.py:194-199) on a
+    clustered cloud; CPU baseline = the oracle's kd-tree port on a bounded sample."""
+    import time
+    import numpy as np
+    import torch
+    from gftorf_amd import distCUDA2
+    from oracle import knn_ref
+    rng = np.random.default_rng(5)
+    c = rng.normal(0, 3, (8, 3))
+    pts = (c[rng.integers(0, 8, P)] + rng.normal(0, 0.05, (P, 3)) + 20.0).astype(np.float32)
+    pts[: P // 10] = rng.uniform(-10, 10, (P // 10, 3)).astype(np.float32) + 20.0
+    t = torch.tensor(pts, device=dev)
+    distCUDA2(t)
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        out = distCUDA2(t)
+    b.record()
+    torch.cuda.synchronize(dev)
+    gpu_ms = a.elapsed_time(b) / 5
+    n_cpu = 200_000
+    t0 = time.time()
+    ref = knn_ref.mean_dist2_kdtree(pts[:n_cpu])
+    cpu_s = time.time() - t0
+    sub = distCUDA2(t[:n_cpu]).cpu().numpy()
+    err = float(np.max(np.abs(sub - ref) / np.maximum(ref, 1e-30)))
+    return {"what": "distCUDA2, %d clustered points" % P, "gpu_ms": gpu_ms, "mpoints_per_s": P / gpu_ms / 1e3,
+            "cpu_kdtree_port": {"points": n_cpu, "seconds": cpu_s, "mpoints_per_s": n_cpu / cpu_s / 1e6, "cores": 1},
+            "max_rel_err_vs_oracle_on_sample": err, "checksum": float(out.double().sum().item())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -320,7 +354,7 @@ def main():
         if world == 1 and not args.no_extras and args.workload == "metric":
             del state, step
             torch.cuda.empty_cache()
-            out["extras"] = {"assemble_inputs": assemble_extra(dev)}
+            out["extras"] = {"assemble_inputs": assemble_extra(dev), "knn": knn_extra(dev)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, budget_s=args.cpu_budget)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]

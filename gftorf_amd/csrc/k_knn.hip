@@ -10,11 +10,10 @@
 //
 //   k_knn_bounds  : bounding box (block partials, last workgroup reduces; like the reference the
 //                   reduction starts from 0, so the box contains the origin, simple_knn.cu:190-198)
-//   k_knn_codes   : 30-bit Morton code per point, histogram of its top 15 bits (32768 cells)
-//   k_knn_scan    : exclusive scan of the cell counters
-//   k_knn_scatter : counting-sort placement by cell (order inside a cell is arbitrary: it only
-//                   decides which points share a box, never a result)
-//   k_knn_boxes   : min/max of every run of 1024 placed points
+//   k_knn_codes   : 30-bit Morton code per point
+//   k_radix_*     : LSD radix sort of (code, index) pairs, 8-bit digits, 4 passes: per-block digit
+//                   histograms, one scan, stable scatter (ranks from wave ballots + LDS row offsets)
+//   k_knn_boxes   : min/max of every run of 1024 points along the curve
 //   k_knn_search  : one workgroup per 256 consecutive (spatially close) points: the box table is
 //                   walked once per workgroup, a box that any lane still needs is staged in LDS
 //                   (12 KB) and scanned with broadcast reads
@@ -26,7 +25,6 @@
 namespace {
 
 #define KNN_BOX 1024
-#define KNN_CELLS 32768
 #define KNN_BLOCK 256
 
 struct Bounds { float mn[3], mx[3]; };
@@ -92,8 +90,8 @@ __device__ __forceinline__ uint32_t spread10(uint32_t x)       // simple_knn.cu:
 }
 
 __global__ __launch_bounds__(KNN_BLOCK) void k_knn_codes(int P, const float* __restrict__ pts,
-                                                         const Bounds* __restrict__ bounds, uint32_t* __restrict__ cell_of,
-                                                         uint32_t* __restrict__ cell_cnt)
+                                                         const Bounds* __restrict__ bounds, uint32_t* __restrict__ codes,
+                                                         uint32_t* __restrict__ index)
 {
     const int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
     if (i >= P) return;
@@ -102,45 +100,142 @@ __global__ __launch_bounds__(KNN_BLOCK) void k_knn_codes(int P, const float* __r
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         // simple_knn.cu:56-58: ((x - min) / (max - min)) * 1023, truncated; a flat axis gives 0/0 there,
-        // any cell is as good here
+        // any code is as good here
         const float ext = b.mx[c] - b.mn[c];
         const float t = ext > 0.f ? ((pts[3 * (size_t)i + c] - b.mn[c]) / ext) * 1023.0f : 0.f;
         q[c] = (uint32_t)fminf(fmaxf(t, 0.f), 1023.0f);
     }
-    const uint32_t code = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
-    const uint32_t cell = code >> 15;
-    cell_of[i] = cell;
-    atomicAdd(&cell_cnt[cell], 1u);
+    codes[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    index[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(1024) void k_knn_scan(uint32_t* cell_cnt, uint32_t* __restrict__ cell_cur)
+// ---- LSD radix sort of (key, value) pairs, 8-bit digits ------------------------------------
+#define RS_THREADS 256
+#define RS_ITEMS 8
+#define RS_CHUNK (RS_THREADS * RS_ITEMS)      // 2048 pairs per workgroup
+#define RS_ROWS (RS_CHUNK / 64)               // 32 rows of 64 consecutive pairs
+
+// hist[digit * nblocks + block]
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(int n, const uint32_t* __restrict__ keys, int shift,
+                                                           uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s_h[256];
+    const int tid = threadIdx.x;
+    s_h[tid] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_CHUNK;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const int i = base + k * RS_THREADS + tid;
+        if (i < n) atomicAdd(&s_h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)tid * gridDim.x + blockIdx.x] = s_h[tid];
+}
+
+// exclusive scan of `count` words in place by one workgroup
+__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* data, int count)
 {
     __shared__ uint32_t s_w[16];
-    constexpr int PER = KNN_CELLS / 1024;
+    __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t loc[PER], sum = 0;
-#pragma unroll
-    for (int k = 0; k < PER; k++) { loc[k] = cell_cnt[tid * PER + k]; sum += loc[k]; }
-    uint32_t x = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    if (lane == 63) s_w[wave] = x;
+    if (tid == 0) s_carry = 0;
     __syncthreads();
-    uint32_t off = x - sum;
-    for (int w = 0; w < wave; w++) off += s_w[w];
+    for (int base = 0; base < count; base += 1024) {
+        const int i = base + tid;
+        const uint32_t v = i < count ? data[i] : 0u;
+        uint32_t x = v;
 #pragma unroll
-    for (int k = 0; k < PER; k++) { cell_cur[tid * PER + k] = off; off += loc[k]; cell_cnt[tid * PER + k] = 0; }
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t off = s_carry;
+        for (int w = 0; w < wave; w++) off += s_w[w];
+        if (i < count) data[i] = off + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = off + x;
+        __syncthreads();
+    }
 }
 
-__global__ __launch_bounds__(KNN_BLOCK) void k_knn_scatter(int P, const uint32_t* __restrict__ cell_of,
-                                                           uint32_t* __restrict__ cell_cur, uint32_t* __restrict__ order)
+// Stable scatter: row r of a workgroup = 64 consecutive pairs; the rank of a pair among the pairs of
+// its row with the same digit comes from 8 ballots, the rows before it from an LDS table.
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(int n, const uint32_t* __restrict__ keys,
+                                                              const uint32_t* __restrict__ vals, int shift,
+                                                              const uint32_t* __restrict__ hist,
+                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out)
 {
-    const int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
-    if (i >= P) return;
-    order[atomicAdd(&cell_cur[cell_of[i]], 1u)] = (uint32_t)i;
+    __shared__ uint32_t s_row[RS_ROWS][256];          // pairs of digit d in row r, then offsets
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < RS_ROWS * 256; k += RS_THREADS) (&s_row[0][0])[k] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_CHUNK;
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const int row = k * (RS_THREADS / 64) + wave;              // rows in pair order
+        const int i = base + row * 64 + lane;
+        const bool in = i < n;
+        key[k] = in ? keys[i] : 0xffffffffu;
+        val[k] = in ? vals[i] : 0u;
+        const uint32_t d = in ? (key[k] >> shift) & 255u : 256u;
+        unsigned long long same = __builtin_amdgcn_ballot_w64(in);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(bit);
+            same &= bit ? m : ~m;
+        }
+        rank[k] = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (in && rank[k] == 0) s_row[row][d] = (uint32_t)__popcll(same);
+    }
+    __syncthreads();
+    {
+        // digit `tid`: running offset over the rows, starting at this workgroup's slot of the scan
+        uint32_t off = hist[(size_t)tid * gridDim.x + blockIdx.x];
+        for (int r = 0; r < RS_ROWS; r++) {
+            const uint32_t c = s_row[r][tid];
+            s_row[r][tid] = off;
+            off += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const int row = k * (RS_THREADS / 64) + wave;
+        const int i = base + row * 64 + lane;
+        if (i < n) {
+            const uint32_t pos = s_row[row][(key[k] >> shift) & 255u] + rank[k];
+            keys_out[pos] = key[k];
+            vals_out[pos] = val[k];
+        }
+    }
+}
+
+// sorts (keys, vals) by the low `bits` bits of the key; result in (keys, vals); (tk, tv) temporaries
+hipError_t radix_sort_pairs(hipStream_t s, int n, uint32_t* keys, uint32_t* vals, uint32_t* tk, uint32_t* tv,
+                            uint32_t* hist, int bits)
+{
+    const int nblocks = (n + RS_CHUNK - 1) / RS_CHUNK;
+    uint32_t *ki = keys, *vi = vals, *ko = tk, *vo = tv;
+    int passes = 0;
+    for (int shift = 0; shift < bits; shift += 8, passes++) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, s, n, ki, shift, hist);
+        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, hist, 256 * nblocks);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, s, n, ki, vi, shift, hist, ko, vo);
+        uint32_t* t = ki; ki = ko; ko = t;
+        t = vi; vi = vo; vo = t;
+    }
+    if (passes & 1) {       // odd number of passes: the result sits in the temporaries
+        hipError_t e = hipMemcpyAsync(keys, ki, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(vals, vi, (size_t)n * 4, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipGetLastError();
 }
 
 // placed coordinates (so the search reads them contiguously) and box bounds
@@ -257,9 +352,10 @@ extern "C" size_t gft_knn_scratch_bytes(int32_t P)
 {
     const size_t p = (size_t)(P > 0 ? P : 0);
     const size_t nboxes = (p + KNN_BOX - 1) / KNN_BOX;
-    // cell_of u32[P] | order u32[P] | placed f32[3P] | boxes | cell_cnt, cell_cur u32[32768] each |
+    const size_t nrs = (p + RS_CHUNK - 1) / RS_CHUNK;
+    // codes, order, two sort temporaries u32[P] | placed f32[3P] | boxes | radix histograms |
     // bounds partials (256) + result + ticket
-    return p * 4 * 2 + p * 12 + nboxes * sizeof(Bounds) + 2 * KNN_CELLS * 4 + 258 * sizeof(Bounds) + 1024;
+    return p * 4 * 4 + p * 12 + nboxes * sizeof(Bounds) + 256 * nrs * 4 + 258 * sizeof(Bounds) + 2048;
 }
 
 extern "C" int gft_knn_mean_dist2(void* hip_stream, int32_t P, const float* points, float* mean_dist2, void* scratch)
@@ -270,27 +366,28 @@ extern "C" int gft_knn_mean_dist2(void* hip_stream, int32_t P, const float* poin
     hipStream_t s = (hipStream_t)hip_stream;
     const size_t p = (size_t)P;
     const int nboxes = (P + KNN_BOX - 1) / KNN_BOX;
+    const size_t nrs = (p + RS_CHUNK - 1) / RS_CHUNK;
     char* b = (char*)scratch;
-    uint32_t* cell_of = (uint32_t*)b;             b += p * 4;
+    uint32_t* codes = (uint32_t*)b;               b += p * 4;
     uint32_t* order = (uint32_t*)b;               b += p * 4;
+    uint32_t* tk = (uint32_t*)b;                  b += p * 4;
+    uint32_t* tv = (uint32_t*)b;                  b += p * 4;
     float* placed = (float*)b;                    b += p * 12;
     b = (char*)(((uintptr_t)b + 255) & ~(uintptr_t)255);
     Bounds* boxes = (Bounds*)b;                   b += (size_t)nboxes * sizeof(Bounds);
-    uint32_t* cell_cnt = (uint32_t*)b;            b += KNN_CELLS * 4;
-    uint32_t* cell_cur = (uint32_t*)b;            b += KNN_CELLS * 4;
+    uint32_t* hist = (uint32_t*)b;                b += 256 * nrs * 4;
     Bounds* partial = (Bounds*)b;                 b += 256 * sizeof(Bounds);
     Bounds* bounds = (Bounds*)b;                  b += sizeof(Bounds);
     uint32_t* ticket = (uint32_t*)b;
-    GFT_CHECK_HIP(hipMemsetAsync(cell_cnt, 0, KNN_CELLS * 4, s));
     GFT_CHECK_HIP(hipMemsetAsync(ticket, 0, 4, s));
     const int blocks = (P + KNN_BLOCK - 1) / KNN_BLOCK;
     hipLaunchKernelGGL(k_knn_bounds, dim3(blocks < 256 ? blocks : 256), dim3(KNN_BLOCK), 0, s, P, points, partial, ticket, bounds);
-    hipLaunchKernelGGL(k_knn_codes, dim3(blocks), dim3(KNN_BLOCK), 0, s, P, points, bounds, cell_of, cell_cnt);
-    hipLaunchKernelGGL(k_knn_scan, dim3(1), dim3(1024), 0, s, cell_cnt, cell_cur);
-    hipLaunchKernelGGL(k_knn_scatter, dim3(blocks), dim3(KNN_BLOCK), 0, s, P, cell_of, cell_cur, order);
+    hipLaunchKernelGGL(k_knn_codes, dim3(blocks), dim3(KNN_BLOCK), 0, s, P, points, bounds, codes, order);
+    hipError_t e = radix_sort_pairs(s, P, codes, order, tk, tv, hist, 30);
+    if (e != hipSuccess) return gft_fail("gft_knn_mean_dist2: sort: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(k_knn_boxes, dim3(nboxes), dim3(KNN_BOX), 0, s, P, points, order, placed, boxes);
     hipLaunchKernelGGL(k_knn_search, dim3(blocks), dim3(KNN_BLOCK), 0, s, P, placed, order, boxes, mean_dist2);
-    hipError_t e = hipGetLastError();
+    e = hipGetLastError();
     if (e != hipSuccess) return gft_fail("gft_knn_mean_dist2: %s", hipGetErrorString(e));
     return 0;
 }
