@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 ACC_STRIDE = 16
 
 _lib = None
@@ -40,7 +40,7 @@ FORWARD_FIELDS = [
 
 BACKWARD_FIELDS = [
     "bg", "means3D", "radii", "scales", "rotations", "cov3D_precomp", "viewmatrix", "projmatrix",
-    "campos", "shs", "shs_p",
+    "campos", "shs", "shs_p", "opacities",
     "dL_dout_color", "dL_dout_phasor", "dL_dout_depth", "dL_dout_acc", "dL_dout_depth_distortion",
     "geom", "img", "binning", "acc",
     "dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dcov3D", "dL_dsh", "dL_dsh_p",

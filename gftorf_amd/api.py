@@ -267,7 +267,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                          dc_offset.shape if isinstance(dc_offset, torch.Tensor) else None)
         ctx.set_materialize_grads(False)
         dummy = means3D_c.new_empty(0)
-        ctx.save_for_backward(means3D_c,
+        ctx.save_for_backward(means3D_c, opac_c if opac_c is not None else dummy,
                               sh_c if sh_c is not None else dummy, sh_p_c if sh_p_c is not None else dummy,
                               scales_c if scales_c is not None else dummy, rot_c if rot_c is not None else dummy,
                               cov_c if cov_c is not None else dummy, radii, geom, binning, img)
@@ -280,7 +280,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                  grad_entropy, grad_depth_distortion, grad_amp_distortion, grad_pixels, grad_distribution, _):
         s = ctx.raster_settings
         lib = _lib.load()
-        means3D, sh, sh_p, scales, rotations, cov3D, radii, geom, binning, img = ctx.saved_tensors
+        means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, binning, img = ctx.saved_tensors
         has_sh, has_sh_p, has_colors, has_phasors, has_scales, has_cov = ctx.present
         dev = means3D.device
         P = means3D.size(0)
@@ -330,6 +330,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         io.viewmatrix, io.projmatrix, io.campos = _ptr(view_c), _ptr(proj_c), _ptr(campos_c)
         io.shs = _ptr(sh) if has_sh else None
         io.shs_p = _ptr(sh_p) if has_sh_p else None
+        io.opacities = _ptr(opac) if P else None
         io.dL_dout_color, io.dL_dout_phasor = _ptr(g_color), _ptr(g_phasor)
         io.dL_dout_depth, io.dL_dout_acc, io.dL_dout_depth_distortion = _ptr(g_depth), _ptr(g_acc), _ptr(g_dd)
         io.geom, io.img, io.binning = _ptr(geom), _ptr(img), _ptr(binning)

@@ -642,13 +642,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
         if (visible) {
             // accumulators written by the render backward
             const float4* ap = reinterpret_cast<const float4*>(a.io.acc + (size_t)idx * GFT_ACC_STRIDE);
-            // row = {dcolor[3], ddist | dmean2D.xy, dconic.xy | XR, XI, X2, XQ | dconic.w, dopacity, dndc, -}
+            // row = {dcolor[3], ddist | dmean2D.xy', dconic.xy' | XR, XI, X2, XQ | dconic.w', dopacity, dndc, -}
             // (the order the render backward's pairwise wave reduction produces, k_render.hip)
             const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
             dcolor[0] = a0.x; dcolor[1] = a0.y; dcolor[2] = a0.z;
             const float ddist_in = a0.w;
-            dmean2d[0] = a1.x; dmean2d[1] = a1.y;
-            const float dconx = a1.z, dcony = a1.w, dconw = a3.x;
+            // the five geometric sums arrive without their per-Gaussian factors (k_render_bwd):
+            // dL/dmean2D.xy = -o (0.5 W, 0.5 H) * sum,  dL/dconic = -o/2 * sum
+            const float nop = -a.io.opacities[idx];
+            dmean2d[0] = a1.x * (nop * 0.5f * (float)a.c.W); dmean2d[1] = a1.y * (nop * 0.5f * (float)a.c.H);
+            const float dconx = a1.z * (0.5f * nop), dcony = a1.w * (0.5f * nop), dconw = a3.x * (0.5f * nop);
             dopac = a3.y;
             const float dndc_in = a3.z;
             // phasor-plane gradients arrive already folded onto the (R, I, Am) basis:

@@ -442,10 +442,13 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     // channel (accum_rec[3], accum_rec_p[7], _d, _a, _dd; backward.cu:776-833); only their
     // gradient-weighted sums enter dL_dalpha and all channels of a group share one linear
     // recurrence, so two scalars per group are enough:
-    //   S1 <- la*L1 + (1-la)  *S1,  L1 = sum_k c_k g_k + dist*g_d + g_a + dL_dw   (colour, dist, acc, dd)
-    //   Sp <- la*Lp + (1-la)^2*Sp,  Lp = sum_k p_k gp_k                           (ToF phasor)
+    //   S1 <- a*D1 + (1-a)  *S1,  D1 = sum_k c_k g_k + dist*g_d + g_a + dL_dw   (colour, dist, acc, dd)
+    //   Sp <- a*Dp + (1-a)^2*Sp,  Dp = sum_k p_k gp_k                           (ToF phasor)
+    // updated right after a splat has used them (the reference does the same update lazily at the
+    // next splat with last_alpha / last_color: same operands, same value).  A lane that does not
+    // blend the splat has a = 0 and keeps S exactly, so no select is needed.
     float T = T_final;
-    float S1 = 0.f, L1 = 0.f, Sp = 0.f, Lp = 0.f, last_alpha = 0.f;
+    float S1 = 0.f, Sp = 0.f;
 
     for (int hi = tmax; hi > 0; hi -= RB) {        // list indices [hi-n, hi), descending
         const int n = min(RB, hi);
@@ -473,8 +476,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
             if (wave_ballot(contrib) == 0ull) continue;   // wave-uniform skip
 
             // Every lane runs the same arithmetic; lanes that do not blend this splat use
-            // alpha = G = 0, which leaves T unchanged (rcp(1) == 1) and makes all 15 partials
-            // exactly zero; only the five recurrence registers need a select.
+            // alpha = G = 0, which leaves T and the two recurrences unchanged (rcp(1) == 1) and
+            // makes all 15 partials exactly zero.
             // accumulator row = {dcolor[3], ddist | dmean2D.xy, dconic.xy | XR, XI, X2, XQ | dconic.w, dopacity, dndc, -}
             v2f L01, L23, L45, L67, H01, H23, H45, H67;
             {
@@ -486,7 +489,6 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
                 T = T * rcp_1ma;
                 const float wc = al * T;             // dchannel_dcolor == dchannel_ddepth
                 const float wp = wc * T;             // dchannel_dphasor = alpha*T*T
-                const float one_m_la = 1.f - last_alpha;
                 const float dist = a1.w, z = a1.z;
                 const float t2 = fmaf(A2, z, B2);    // A2 z + B2
                 const float dL_dw = fmaf(t2, z, C2);
@@ -494,38 +496,33 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
                 float D1 = b0.x * gc0;
                 D1 = fmaf(b0.y, gc1, D1); D1 = fmaf(b0.z, gc2, D1); D1 = fmaf(dist, gd, D1);
                 D1 += ga + dL_dw;
-                const float S1n = fmaf(last_alpha, L1, one_m_la * S1);
 
                 float Dp = b0.w * GR;
                 Dp = fmaf(b1.x, GI, Dp); Dp = fmaf(b1.y, GA, Dp);
-                const float Spn = fmaf(last_alpha, Lp, one_m_la * one_m_la * Sp);
 
                 // alpha also scales what is left for the background (reference :850-858)
                 const float bgf = -T_final * rcp_1ma;
-                const float dL_dalpha = fmaf(D1 - S1n, T, fmaf(fmaf(-2.f * one_m_a, Spn, Dp), T * T, bgf * bg_sum));
+                const float dL_dalpha = fmaf(D1 - S1, T, fmaf(fmaf(-2.f * one_m_a, Sp, Dp), T * T, bgf * bg_sum));
 
-                S1 = contrib ? S1n : S1;
-                L1 = contrib ? D1 : L1;
-                Sp = contrib ? Spn : Sp;
-                Lp = contrib ? Dp : Lp;
-                last_alpha = contrib ? alpha : last_alpha;
+                S1 = fmaf(al, D1, one_m_a * S1);
+                Sp = fmaf(al, Dp, one_m_a * one_m_a * Sp);
 
                 L01 = gA01 * wc;                      // w_c * (g_c0, g_c1)
                 L23 = gA23 * wc;                      // w_c * (g_c2, g_dist)
                 H01 = gB01 * wp;                      // w_p * (GR, GI)
                 H23 = gB23 * wp;                      // w_p * (g_p2, GQ)
 
-                const float dL_dG = a1.y * dL_dalpha;
-                const float gdx = Gm * dx, gdy = Gm * dy;
-                const float dG_ddelx = -gdx * a0.z - gdy * a0.w;
-                const float dG_ddely = -gdy * a1.x - gdx * a0.w;
-                const float h = -0.5f * dL_dG;
-                L45.x = dL_dG * dG_ddelx * ddelx_dx;  // dmean2D.x
-                L45.y = dL_dG * dG_ddely * ddely_dy;  // dmean2D.y
-                L67.x = h * gdx * dx;                 // dconic.x
-                L67.y = h * gdx * dy;                 // dconic.y
-                H45.x = h * gdy * dy;                 // dconic.w
-                H45.y = Gm * dL_dalpha;               // dopacity
+                // E = G dL/dalpha; the per-splat factors of the five geometric sums (opacity, -1/2,
+                // 0.5 W, 0.5 H) are applied once per Gaussian in k_preprocess_bwd:
+                //   dL/dmean2D.x = -o 0.5W sum E (dx a + dy b),  dL/dconic.x = -o/2 sum E dx^2, ...
+                const float E = Gm * dL_dalpha;
+                const float Edx = E * dx, Edy = E * dy;
+                L45.x = E * fmaf(dy, a0.w, dx * a0.z);    // dmean2D.x / (-o 0.5 W)
+                L45.y = E * fmaf(dx, a0.w, dy * a1.x);    // dmean2D.y / (-o 0.5 H)
+                L67.x = Edx * dx;                         // dconic.x / (-o/2)
+                L67.y = Edx * dy;                         // dconic.y / (-o/2)
+                H45.x = Edy * dy;                         // dconic.w / (-o/2)
+                H45.y = E;                                // dopacity
                 H67.x = wc * (t2 + A2 * z);           // gdd*2*alpha*T*(z(1-Tf) - wz)
                 H67.y = 0.f;
             }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GFT_ABI_VERSION 2
+#define GFT_ABI_VERSION 3
 
 /* compile-time constants of the reference (RAST/cuda_rasterizer/config.h:15-23) */
 #define GFT_NUM_CHANNELS 3
@@ -126,6 +126,7 @@ typedef struct gft_backward_io {
     const float* campos;
     const float* shs;
     const float* shs_p;
+    const float* opacities;                  /* [P] as given to the forward */
     /* upstream gradients, contiguous [C,H,W]; NULL = all zeros.  Gradients of
      * normal / entropy / amp_distortion / pixels / distribution are accepted by
      * the reference and ignored by its kernels, so they are not part of the ABI */
