@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     uint32_t last_contributor = 0;
     float C0 = 0, C1 = 0, C2 = 0;
     float PR = 0, PI = 0, PA = 0;     // ToF phasor on its (R, I, Am) basis
-    float Dd = 0, A = 0, DD = 0, DD_D = 0, DD_D2 = 0;
+    float Dd = 0, A = 0, DD_D = 0, DD_D2 = 0;
     float WD0 = 0, WD1 = 0, WD2 = 0;
 
     for (int base = 0; base < total; base += RB) {
@@ -177,10 +177,13 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
                 WD0 = is_first ? alpha : WD0;
                 WD1 = is_first ? dist : WD1;
                 WD2 = is_first ? b1.y : WD2;
+                // depth distortion: the reference adds w (z^2 A - 2 z D + D2) per splat (A, D, D2 = sums
+                // over the splats in front, forward.cu:604-611), which telescopes to
+                // sum_{i>j} w_i w_j (z_i - z_j)^2 = A D2 - D^2 of the final sums: formed once per pixel
                 const float z = a1.z;
-                DD += w * (z * z * A - 2.0f * z * DD_D + DD_D2);
-                DD_D += w * z;
-                DD_D2 += w * z * z;
+                const float wz = w * z;
+                DD_D += wz;
+                DD_D2 = fmaf(wz, z, DD_D2);
                 A += w;
                 T = T * (1 - al);
                 last_contributor = contrib ? (uint32_t)(base + j + 1) : last_contributor;
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
         a.out_phasor[6 * HW + pix] = (dcA - PI) + T * g6;
         a.out_depth[pix] = Dd;
         a.out_acc[pix] = A;
-        a.out_dd[pix] = DD;
+        a.out_dd[pix] = fmaf(A, DD_D2, -DD_D * DD_D);
         a.out_distribution[pix] = WD0;
         a.out_distribution[HW + pix] = WD1;
         a.out_distribution[2 * HW + pix] = WD2;
