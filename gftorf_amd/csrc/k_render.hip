@@ -107,8 +107,6 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
 {
     __shared__ float4 sA[RB * 2];
     __shared__ float4 sB[RB * 2];
-    __shared__ uint32_t sId[RB];
-    __shared__ uint32_t sCnt[RB];
 
     // binning buffer smaller than the instance count: nothing was binned, the host re-runs stage 2
     if (a.ctrl && a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
@@ -138,11 +136,12 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
         if (wave_ballot(!done) == 0ull) break;
         const int n = min(RB, total - base);
         bool reach = false;
-        __syncthreads();                         // previous batch's count flush has read LDS
+        uint32_t my_id = 0;
+        uint32_t cnt = 0;                        // lane j: pixels of this quadrant that blend splat j of the batch
+        __syncthreads();                         // previous batch has read LDS
         if (lane < n) {
             const uint32_t id = a.point_list[range.x + base + lane];
-            sId[lane] = id;
-            sCnt[lane] = 0;
+            my_id = id;
             reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, (float)qx0, (float)qy0);
         }
         uint64_t m = to_sgpr(wave_ballot(reach));
@@ -187,16 +186,16 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
                 A += w;
                 T = T * (1 - al);
                 last_contributor = contrib ? (uint32_t)(base + j + 1) : last_contributor;
-                // pixels[id] += 1 for every contributing pixel: wave popcount -> LDS
-                if (lane == 0) sCnt[j] = (uint32_t)__popcll(cm);
+                // pixels[id] += 1 for every contributing pixel: wave popcount, parked in lane j
+                {
+                    const uint32_t pc = (uint32_t)__popcll(cm);
+                    // (gfx9: one SGPR per VALU op on the constant bus, the lane select goes through m0)
+                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(cnt) : "s"(pc), "s"(j) : "m0");
+                }
             }
             if (wave_ballot(term) != 0ull && wave_ballot(!done) == 0ull) break;
         }
-        __syncthreads();
-        if (lane < n) {
-            const uint32_t cnt = sCnt[lane];
-            if (cnt) atomicAdd(&a.pixels[sId[lane]], (float)cnt);
-        }
+        if (cnt) atomicAdd(&a.pixels[my_id], (float)cnt);
     }
 
     if (inside) {
