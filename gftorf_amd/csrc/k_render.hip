@@ -47,6 +47,20 @@ __device__ __forceinline__ float gft_exp(float x) { return __builtin_amdgcn_exp2
 // ballot straight from the compare (HIP's __ballot(int) costs a v_cndmask + v_cmp per call)
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// select by a wave-uniform 64-bit lane mask held in SGPRs (bit set -> a): one v_cndmask, no compare
+__device__ __forceinline__ float sel_mask(unsigned long long m, float a, float b)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t sel_mask(unsigned long long m, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+
 __device__ __forceinline__ uint64_t to_sgpr(unsigned long long m)
 {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)m), hi = __builtin_amdgcn_readfirstlane((uint32_t)(m >> 32));
@@ -123,7 +137,9 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
 
-    bool done = !inside;
+    // Predicates are wave-uniform 64-bit lane masks: every ballot below takes a single compare,
+    // the combinations are scalar ALU work and the selects read the masks from SGPRs.
+    unsigned long long done_m = ~wave_ballot(inside);     // pixels outside the image never blend
     float T = 1.0f;
     uint32_t last_contributor = 0;
     float C0 = 0, C1 = 0, C2 = 0;
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
 
     for (int base = 0; base < total; base += RB) {
         // all 64 pixels finished -> the rest of the list is never used
-        if (wave_ballot(!done) == 0ull) break;
+        if (done_m == ~0ull) break;
         const int n = min(RB, total - base);
         bool reach = false;
         uint32_t my_id = 0;
@@ -154,28 +170,27 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
             const float dx = a0.x - pxf, dy = a0.y - pyf;
             const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
             const float alpha = fminf(0.99f, a1.y * gft_exp(power));
-            const bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (wave_ballot(valid) == 0ull) continue;          // wave-uniform skip
+            const unsigned long long vm = wave_ballot(!(power > 0.0f)) & wave_ballot(!(alpha < 1.0f / 255.0f)) & ~done_m;
+            if (vm == 0ull) continue;                        // wave-uniform skip
             const float test_T = T * (1 - alpha);
-            const bool term = valid && test_T < 0.0001f;    // this pixel is saturated: splat not blended
-            const bool contrib = valid && !term;
-            done = done || term;
-            const unsigned long long cm = wave_ballot(contrib);
+            const unsigned long long tm = vm & wave_ballot(test_T < 0.0001f);   // saturated here: splat not blended
+            const unsigned long long cm = vm & ~tm;
+            done_m |= tm;
             if (cm != 0ull) {
                 // Branch-free blend: lanes that do not take this splat use alpha = 0, which adds
                 // exact zeros and leaves T unchanged.
                 const float4 b0 = sB[2 * j], b1 = sB[2 * j + 1];
-                const float al = contrib ? alpha : 0.f;
+                const float al = sel_mask(cm, alpha, 0.f);
                 const float w = al * T;
                 const float w_p = w * T;
                 C0 += b0.x * w; C1 += b0.y * w; C2 += b0.z * w;
                 PR += b0.w * w_p; PI += b1.x * w_p; PA += b1.y * w_p;
                 const float dist = a1.w;
                 Dd += dist * w;
-                const bool is_first = contrib && last_contributor == 0u;
-                WD0 = is_first ? alpha : WD0;
-                WD1 = is_first ? dist : WD1;
-                WD2 = is_first ? b1.y : WD2;
+                const unsigned long long fm = cm & wave_ballot(last_contributor == 0u);
+                WD0 = sel_mask(fm, alpha, WD0);
+                WD1 = sel_mask(fm, dist, WD1);
+                WD2 = sel_mask(fm, b1.y, WD2);
                 // depth distortion: the reference adds w (z^2 A - 2 z D + D2) per splat (A, D, D2 = sums
                 // over the splats in front, forward.cu:604-611), which telescopes to
                 // sum_{i>j} w_i w_j (z_i - z_j)^2 = A D2 - D^2 of the final sums: formed once per pixel
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
                 DD_D2 = fmaf(wz, z, DD_D2);
                 A += w;
                 T = T * (1 - al);
-                last_contributor = contrib ? (uint32_t)(base + j + 1) : last_contributor;
+                last_contributor = sel_mask(cm, (uint32_t)(base + j + 1), last_contributor);
                 // pixels[id] += 1 for every contributing pixel: wave popcount, parked in lane j
                 {
                     const uint32_t pc = (uint32_t)__popcll(cm);
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
                     asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(cnt) : "s"(pc), "s"(j) : "m0");
                 }
             }
-            if (wave_ballot(term) != 0ull && wave_ballot(!done) == 0ull) break;
+            if (done_m == ~0ull) break;
         }
         if (cnt) atomicAdd(&a.pixels[my_id], (float)cnt);
     }
