@@ -39,6 +39,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->geom_rect = o;     o = align_up(o + p * 8);
     L->geom_dirgrad = o;  o = align_up(o + p * 64);
     L->geom_clamped = o;  o = align_up(o + p);
+    L->geom_blockhist = o; o = align_up(o + ((p + 4095) / 4096) * GFT_BLOCKHIST_TILES * 2);
     L->geom_total = o;
 
     const size_t n = (size_t)W * (size_t)H;
@@ -71,6 +72,7 @@ GeomView gft_geom_view(void* base, const gft_layout& L)
     g.rect = (ushort4*)(b + L.geom_rect);
     g.dirgrad = (float4*)(b + L.geom_dirgrad);
     g.clamped = (uint8_t*)(b + L.geom_clamped);
+    g.blockhist = (uint16_t*)(b + L.geom_blockhist);
     return g;
 }
 

@@ -18,6 +18,7 @@ struct GeomView {
     ushort4* rect;      // [P] tile rectangle {x0,y0,x1,y1}; all zero when culled
     float4* dirgrad;    // [P][4] d(rgb)/d(dir) 9, d(phase,amp)/d(dir) 6, pad (forward with want_backward)
     uint8_t* clamped;   // [P]
+    uint16_t* blockhist; // [ceil(P/4096)][GFT_BLOCKHIST_TILES] tile hits of every 4096-Gaussian block (T <= GFT_BLOCKHIST_TILES)
 };
 
 struct ImgView {
@@ -42,6 +43,7 @@ struct BinView {
 #define GFT_CTRL_DONE 3      // finished k_tile_count workgroups (ticket for the fused scan)
 #define GFT_CTRL_SEQ 3       // host mailbox only: sequence number, written last
 #define GFT_CTRL_WORDS 8
+#define GFT_BLOCKHIST_TILES 2048
 #define GFT_SHORT_LIST_MAX 4096   // tile lists up to this length are sorted by one 256-thread workgroup
 
 void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* L);

@@ -107,7 +107,7 @@ template <bool USE_LDS>
 __global__ __launch_bounds__(BIN_THREADS) void k_tile_count(int P, int gx, int T, const ushort4* __restrict__ rect,
                                                           uint32_t* tile_cnt, uint2* __restrict__ ranges,
                                                           uint32_t* __restrict__ cursor, uint32_t* ctrl,
-                                                          uint32_t* mail, uint32_t seq)
+                                                          uint32_t* mail, uint32_t seq, uint16_t* __restrict__ blockhist)
 {
     extern __shared__ uint32_t hist[];
     __shared__ uint32_t s_last;
@@ -135,6 +135,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_count(int P, int gx, int T
             const int t = rotated_tile(i, T);
             const uint32_t h = hist[t];
             if (h) atomicAdd(&tile_cnt[t], h);
+            // kept for the scatter, which would otherwise walk the rectangles a second time to count
+            if (blockhist) blockhist[(size_t)blockIdx.x * GFT_BLOCKHIST_TILES + t] = (uint16_t)h;
         }
     }
     // The workgroup that draws the last ticket scans.  Every counter update above is a
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int
                                                             uint32_t* __restrict__ cursor,
                                                             uint64_t* __restrict__ keys,
                                                             const uint32_t* __restrict__ ctrl, uint32_t cap,
-                                                            uint32_t stage_cap)
+                                                            uint32_t stage_cap, const uint16_t* __restrict__ blockhist)
 {
     extern __shared__ uint32_t sh[];
     if (ctrl[GFT_CTRL_TOTAL] > cap) return;      // binning buffer too small: the host re-runs stage 2
@@ -178,15 +180,20 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int
     const int base = blockIdx.x * BIN_CHUNK;
     bool staged = false;
     if (MODE >= 1) {
-        for (int i = tid; i < T; i += BIN_THREADS) cnt[i] = 0;
-        __syncthreads();
+        if (blockhist) {
+            // the count kernel kept this workgroup's histogram
+            for (int i = tid; i < T; i += BIN_THREADS) cnt[i] = blockhist[(size_t)blockIdx.x * GFT_BLOCKHIST_TILES + i];
+        } else {
+            for (int i = tid; i < T; i += BIN_THREADS) cnt[i] = 0;
+            __syncthreads();
 #pragma unroll 4
-        for (int k = 0; k < BIN_ITEMS; k++) {
-            const int idx = base + k * BIN_THREADS + tid;
-            if (idx < P) {
-                const ushort4 r = rect[idx];
-                for (int y = r.y; y < r.w; y++)
-                    for (int x = r.x; x < r.z; x++) atomicAdd(&cnt[y * gx + x], 1u);
+            for (int k = 0; k < BIN_ITEMS; k++) {
+                const int idx = base + k * BIN_THREADS + tid;
+                if (idx < P) {
+                    const ushort4 r = rect[idx];
+                    for (int y = r.y; y < r.w; y++)
+                        for (int x = r.x; x < r.z; x++) atomicAdd(&cnt[y * gx + x], 1u);
+                }
             }
         }
         __syncthreads();
@@ -506,10 +513,11 @@ hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomV
     const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
     if (T <= BIN_LDS_MAX_TILES)
         hipLaunchKernelGGL(k_tile_count<true>, dim3(blocks), dim3(BIN_THREADS), (size_t)T * 4, s, c.P, gx, T, g.rect,
-                           im.tile_cnt, im.ranges, im.tile_cursor, im.ctrl, mail, seq);
+                           im.tile_cnt, im.ranges, im.tile_cursor, im.ctrl, mail, seq,
+                           (T <= GFT_BLOCKHIST_TILES && BIN_CHUNK == 4096) ? g.blockhist : nullptr);
     else
         hipLaunchKernelGGL(k_tile_count<false>, dim3(blocks), dim3(BIN_THREADS), 0, s, c.P, gx, T, g.rect, im.tile_cnt,
-                           im.ranges, im.tile_cursor, im.ctrl, mail, seq);
+                           im.ranges, im.tile_cursor, im.ctrl, mail, seq, nullptr);
     return hipGetLastError();
 }
 
@@ -521,7 +529,7 @@ hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const Geo
     const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
     if (T > BIN_LDS_MAX_TILES) {
         hipLaunchKernelGGL(k_tile_scatter<0>, dim3(blocks), dim3(BIN_THREADS), 0, s, c.P, gx, T, g.rect, g.depth,
-                           im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, 0u);
+                           im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, 0u, nullptr);
         return hipGetLastError();
     }
     static bool attr_set = false;
@@ -538,12 +546,13 @@ hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const Geo
     const size_t tables = ((size_t)3 * T + (T & 1)) * 4;
     const size_t stage_cap = tables + 4096 * 8 <= BIN_STAGE_LDS_BYTES ? (BIN_STAGE_LDS_BYTES - tables) / 8 : 0;
     const size_t expect = blocks > 0 ? (size_t)cap / (size_t)blocks : 0;
+    const uint16_t* bh = (T <= GFT_BLOCKHIST_TILES && BIN_CHUNK == 4096) ? g.blockhist : nullptr;
     if (stage_cap > 0 && expect <= stage_cap + stage_cap / 2)
         hipLaunchKernelGGL(k_tile_scatter<2>, dim3(blocks), dim3(BIN_THREADS), tables + stage_cap * 8, s, c.P, gx, T,
-                           g.rect, g.depth, im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, (uint32_t)stage_cap);
+                           g.rect, g.depth, im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, (uint32_t)stage_cap, bh);
     else
         hipLaunchKernelGGL(k_tile_scatter<1>, dim3(blocks), dim3(BIN_THREADS), (size_t)T * 8, s, c.P, gx, T, g.rect,
-                           g.depth, im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, 0u);
+                           g.depth, im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, 0u, bh);
     return hipGetLastError();
 }
 

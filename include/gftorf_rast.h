@@ -170,6 +170,7 @@ typedef struct gft_layout {
     size_t geom_rect;         /* uint16[P][4] tile rectangle {x0,y0,x1,y1} (all 0 when culled) */
     size_t geom_dirgrad;      /* float[P][16] d rgb/d dir (9), d (phase,amp)/d dir (6), pad; only with want_backward */
     size_t geom_clamped;      /* uint8[P]     bit0..2 rgb clamped, bit3 amplitude clamped */
+    size_t geom_blockhist;    /* uint16[ceil(P/4096)][2048] instances per (4096-Gaussian block, tile); used when T <= 2048 */
     size_t geom_total;
     /* img */
     size_t img_pix_state;     /* float[N][4]  {final_T, n_contrib(bits), w_z, w_z2} */
