@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
                 DD_D += wz;
                 DD_D2 = fmaf(wz, z, DD_D2);
                 A += w;
-                T = T * (1 - al);
+                T = sel_mask(cm, test_T, T);         // T (1 - alpha) for the lanes that blend
                 last_contributor = sel_mask(cm, (uint32_t)(base + j + 1), last_contributor);
                 // pixels[id] += 1 for every contributing pixel: wave popcount, parked in lane j
                 {
@@ -446,8 +446,9 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     }
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     // depth-distortion weight gradient dL_dw(z) = gdd*(z^2 (1-Tf) - 2 z wz + wz2) = (A2 z + B2) z + C2
-    const float A2 = gdd * (1 - T_final), B2 = -2.0f * gdd * wz_tot, C2 = gdd * wz2_tot;
-    const float bg_sum = bg_dot + bg_dot_p;
+    // (the constant g_acc rides on C2: dL_dw only ever appears as g_acc + dL_dw)
+    const float A2 = gdd * (1 - T_final), B2 = -2.0f * gdd * wz_tot, C2 = gdd * wz2_tot + ga;
+    const float bg_k = -T_final * (bg_dot + bg_dot_p);       // background term of dL_dalpha, times 1/(1-alpha)
     // upstream phasor gradients folded onto the per-splat basis (R, I, Am):
     // sum_k p_k g_k = R*GR + I*GI + Am*GA; K9 needs sum w_p*{GR, GI, g2, GQ}
     const float GR = gp0 + gp3 - gp4, GI = gp1 + gp5 - gp6, GQ = (gp3 + gp4) + (gp5 + gp6);
@@ -508,18 +509,17 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
                 const float wp = wc * T;             // dchannel_dphasor = alpha*T*T
                 const float dist = a1.w, z = a1.z;
                 const float t2 = fmaf(A2, z, B2);    // A2 z + B2
-                const float dL_dw = fmaf(t2, z, C2);
+                const float dL_dw_ga = fmaf(t2, z, C2);   // g_acc + dL_dw
 
                 float D1 = b0.x * gc0;
                 D1 = fmaf(b0.y, gc1, D1); D1 = fmaf(b0.z, gc2, D1); D1 = fmaf(dist, gd, D1);
-                D1 += ga + dL_dw;
+                D1 += dL_dw_ga;
 
                 float Dp = b0.w * GR;
                 Dp = fmaf(b1.x, GI, Dp); Dp = fmaf(b1.y, GA, Dp);
 
-                // alpha also scales what is left for the background (reference :850-858)
-                const float bgf = -T_final * rcp_1ma;
-                const float dL_dalpha = fmaf(D1 - S1, T, fmaf(fmaf(-2.f * one_m_a, Sp, Dp), T * T, bgf * bg_sum));
+                // alpha also scales what is left for the background (reference :850-858): -T_final/(1-alpha) * bg . g
+                const float dL_dalpha = fmaf(D1 - S1, T, fmaf(fmaf(-2.f * one_m_a, Sp, Dp), T * T, bg_k * rcp_1ma));
 
                 S1 = fmaf(al, D1, one_m_a * S1);
                 Sp = fmaf(al, Dp, one_m_a * one_m_a * Sp);
