@@ -270,6 +270,40 @@ def knn_extra(dev, P=1_000_000):
             "max_rel_err_vs_oracle_on_sample": err, "checksum": float(out.double().sum().item())}
 
 
+def adam_extra(dev, P=1_000_000, steps=10):
+    """SURVEY 8(f) row 4 (optimizer part): one Adam step over the reference's per-Gaussian parameter
+    groups (scene/gaussian_model.py:247-274: 91 floats per Gaussian), FusedAdam against
+    torch.optim.Adam as the reference constructs it, same device.  28 B of HBM per element."""
+    import torch
+    from gftorf_amd import FusedAdam
+    shapes = [(P, 3), (P, 1, 3), (P, 15, 3), (P, 1, 1), (P, 15, 1), (P, 1, 1), (P, 15, 1), (P, 1), (P, 3), (P, 4), (P, 1, 3)]
+
+    def make(cls):
+        ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        return cls([{"params": [p], "lr": 1e-3} for p in ps], lr=0.0, eps=1e-15), ps
+
+    def timed(cls):
+        opt, ps = make(cls)
+        for _ in range(3):
+            opt.step()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            opt.step()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / steps, sum(p.numel() for p in ps)
+
+    fused_ms, n = timed(FusedAdam)
+    torch_ms, _ = timed(torch.optim.Adam)
+    return {"what": "Adam step, %d Gaussians x %d floats" % (P, n // P), "fused_ms": fused_ms, "torch_adam_ms": torch_ms,
+            "speedup_vs_torch": torch_ms / fused_ms, "algorithmic_bytes": 28 * n,
+            "achieved_GBs": 28 * n / (fused_ms * 1e-3) / 1e9, "frac_of_hbm_peak": 28 * n / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -354,7 +388,8 @@ def main():
         if world == 1 and not args.no_extras and args.workload == "metric":
             del state, step
             torch.cuda.empty_cache()
-            out["extras"] = {"assemble_inputs": assemble_extra(dev), "knn": knn_extra(dev)}
+            out["extras"] = {"assemble_inputs": assemble_extra(dev), "knn": knn_extra(dev),
+                             "adam": adam_extra(dev)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, budget_s=args.cpu_budget)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]

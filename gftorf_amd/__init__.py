@@ -9,5 +9,6 @@ from .api import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_g
                   _RasterizeGaussians)
 from .assemble import assemble_inputs  # noqa: F401
 from .knn import distCUDA2  # noqa: F401
+from .optim import FusedAdam  # noqa: F401
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "assemble_inputs", "distCUDA2"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "assemble_inputs", "distCUDA2", "FusedAdam"]

@@ -104,7 +104,7 @@ EXPORTS = [
     "gft_get_layout", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_backward",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
-    "gft_knn_scratch_bytes", "gft_knn_mean_dist2",
+    "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step",
 ]
 
 
@@ -137,6 +137,9 @@ def load():
     lib.gft_forward_preprocess.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO),
                                            C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gft_forward_render.restype = C.c_int
+    lib.gft_adam_step.restype = C.c_int
+    lib.gft_adam_step.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64]
     lib.gft_knn_scratch_bytes.restype = C.c_size_t
     lib.gft_knn_scratch_bytes.argtypes = [C.c_int32]
     lib.gft_knn_mean_dist2.restype = C.c_int

@@ -1,0 +1,85 @@
+// k_adam.hip -- fused Adam step (gfx950): one pass, 16-byte accesses, HBM-bound (28 B per element).
+// Arithmetic of torch/optim/adam.py `_single_tensor_adam` (no amsgrad / maximize), which the
+// reference's optimizer follows (scene/gaussian_model.py:274, train.py:470).
+#include "gft_internal.h"
+#include "gftorf_optim.h"
+
+#include <cmath>
+
+namespace {
+
+#define ADAM_BLOCK 256
+
+struct AdamArgs {
+    int64_t n;
+    float* p; const float* g; float* m; float* v;
+    float one_m_beta1, beta2, one_m_beta2, step_size, bias2_sqrt, eps, weight_decay;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a)
+{
+#pragma clang fp contract(off)
+    if (a.weight_decay != 0.f) g = g + a.weight_decay * p;
+    m = m + a.one_m_beta1 * (g - m);                          // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * a.beta2 + (a.one_m_beta2 * g) * g;                // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
+    p = p + (-a.step_size) * (m / denom);                     // addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__global__ __launch_bounds__(ADAM_BLOCK) void k_adam_step(AdamArgs a)
+{
+    const int64_t n4 = a.n >> 2;
+    const int64_t i = (int64_t)blockIdx.x * ADAM_BLOCK + threadIdx.x;
+    if (i < n4) {
+        float4 p = reinterpret_cast<float4*>(a.p)[i];
+        const float4 g = reinterpret_cast<const float4*>(a.g)[i];
+        float4 m = reinterpret_cast<float4*>(a.m)[i];
+        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        adam_one(p.x, g.x, m.x, v.x, a);
+        adam_one(p.y, g.y, m.y, v.y, a);
+        adam_one(p.z, g.z, m.z, v.z, a);
+        adam_one(p.w, g.w, m.w, v.w, a);
+        reinterpret_cast<float4*>(a.p)[i] = p;
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+    }
+    // tail (n not a multiple of 4): the first workgroup's first lanes
+    const int64_t tail = a.n & 3;
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < tail) {
+        const int64_t k = (n4 << 2) + threadIdx.x;
+        float p = a.p[k], m = a.m[k], v = a.v[k];
+        adam_one(p, a.g[k], m, v, a);
+        a.p[k] = p; a.m[k] = m; a.v[k] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int gft_adam_step(void* hip_stream, int64_t n, float* param, const float* grad, float* exp_avg,
+                             float* exp_avg_sq, double lr, double beta1, double beta2, double eps, double weight_decay,
+                             int64_t step)
+{
+    if (n < 0) return gft_fail("gft_adam_step: n < 0");
+    if (step < 1) return gft_fail("gft_adam_step: step must be >= 1");
+    if (n == 0) return 0;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return gft_fail("gft_adam_step: NULL pointer");
+    if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0)
+        return gft_fail("gft_adam_step: pointers must be 16-byte aligned");
+    AdamArgs a;
+    a.n = n; a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq;
+    // torch/optim/adam.py: bias_correction1 = 1 - beta1 ** step; step_size = lr / bias_correction1;
+    // bias_correction2_sqrt = (1 - beta2 ** step) ** 0.5 -- Python floats, rounded when they meet a tensor
+    a.one_m_beta1 = (float)(1.0 - beta1);
+    a.beta2 = (float)beta2;
+    a.one_m_beta2 = (float)(1.0 - beta2);
+    a.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+    a.bias2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    a.eps = (float)eps;
+    a.weight_decay = (float)weight_decay;
+    const int64_t n4 = n >> 2;
+    const int64_t blocks = n4 > 0 ? (n4 + ADAM_BLOCK - 1) / ADAM_BLOCK : 1;
+    hipLaunchKernelGGL(k_adam_step, dim3((unsigned)blocks), dim3(ADAM_BLOCK), 0, (hipStream_t)hip_stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gft_fail("gft_adam_step: %s", hipGetErrorString(e));
+    return 0;
+}

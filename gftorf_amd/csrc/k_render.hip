@@ -205,7 +205,9 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
                 {
                     const uint32_t pc = (uint32_t)__popcll(cm);
                     // (gfx9: one SGPR per VALU op on the constant bus, the lane select goes through m0)
-                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(cnt) : "s"(pc), "s"(j) : "m0");
+                    uint32_t m0_keep;
+                    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                                 : "+v"(cnt), "=&s"(m0_keep) : "s"(pc), "s"(j));
                 }
             }
             if (done_m == ~0ull) break;
@@ -444,7 +446,6 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
         bg_dot_p = 0.f + b0 * gp0; bg_dot_p += b1 * gp1; bg_dot_p += b2 * gp2; bg_dot_p += b3 * gp3;
         bg_dot_p += b4 * gp4; bg_dot_p += b5 * gp5; bg_dot_p += b6 * gp6;
     }
-    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     // depth-distortion weight gradient dL_dw(z) = gdd*(z^2 (1-Tf) - 2 z wz + wz2) = (A2 z + B2) z + C2
     // (the constant g_acc rides on C2: dL_dw only ever appears as g_acc + dL_dw)
     const float A2 = gdd * (1 - T_final), B2 = -2.0f * gdd * wz_tot, C2 = gdd * wz2_tot + ga;

@@ -1,0 +1,61 @@
+"""Fused Adam for the Gaussian parameters (optimizer part).
+
+``FusedAdam`` is a ``torch.optim.Adam`` whose ``step()`` runs one hand-written gfx950 kernel per
+parameter tensor (``csrc/k_adam.hip``, ``include/gftorf_optim.h``) instead of torch's multi-tensor
+path; constructor, ``param_groups``, ``state`` (``step`` / ``exp_avg`` / ``exp_avg_sq``),
+``state_dict`` and ``zero_grad`` are torch's own, so the reference's densification code, which
+edits the optimizer state in place (``scene/gaussian_model.py:456-540``), works unchanged.
+Use: replace ``torch.optim.Adam(l, lr=0.0, eps=1e-15)`` at ``scene/gaussian_model.py:274`` by
+``gftorf_amd.FusedAdam(l, lr=0.0, eps=1e-15)``.
+"""
+import torch
+
+from . import _lib
+
+
+class FusedAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
+        if amsgrad or kw.get("maximize") or kw.get("capturable") or kw.get("differentiable"):
+            raise NotImplementedError("gftorf_amd.FusedAdam: amsgrad / maximize / capturable / differentiable are not supported")
+        kw.pop("foreach", None)
+        kw.pop("fused", None)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, **kw)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
+            if isinstance(lr, torch.Tensor):
+                lr = float(lr)
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.device.type != "cuda":
+                    raise RuntimeError("gftorf_amd.FusedAdam runs on a HIP device only (parameter on %s); there is no CPU path" % (p.device,))
+                if p.grad.is_sparse:
+                    raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("gftorf_amd.FusedAdam: parameters must be contiguous float32 tensors")
+                state = self.state[p]
+                if len(state) == 0:
+                    # same state as torch.optim.Adam._init_group
+                    state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["step"] += 1
+                t = int(state["step"])
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                m, v = state["exp_avg"], state["exp_avg_sq"]
+                if not (m.is_contiguous() and v.is_contiguous()):
+                    raise RuntimeError("gftorf_amd.FusedAdam: optimizer state must be contiguous")
+                with torch.cuda.device(p.device):
+                    _lib.check(lib.gft_adam_step(torch.cuda.current_stream(p.device).cuda_stream, p.numel(),
+                                                 p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                                 float(lr), float(beta1), float(beta2), float(eps), float(wd), t))
+        return loss

@@ -1,0 +1,36 @@
+/*
+ * gftorf_optim.h -- C ABI of the fused Adam step of libgftorf_rast.so (gfx950).
+ *
+ * SURVEY section 8(f) row 4 (optimizer part).  The reference updates its ~91 floats per Gaussian
+ * with `torch.optim.Adam(l, lr=0.0, eps=1e-15)` (scene/gaussian_model.py:274, stepped at
+ * train.py:470), whose default multi-tensor path runs one elementwise kernel per arithmetic
+ * operation.  This is the same update (torch/optim/adam.py `_single_tensor_adam`, no amsgrad, no
+ * maximize) in one pass: 16 B read + 12 B written per element.
+ *
+ *   g' = g + weight_decay * p
+ *   m  = m + (1 - beta1) * (g' - m)                       (lerp)
+ *   v  = beta2 * v + (1 - beta2) * g' * g'
+ *   p  = p - (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ *
+ * Device pointers, fp32; returns 0 on success (gft_last_error()).
+ */
+#ifndef GFTORF_OPTIM_H
+#define GFTORF_OPTIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Hyper-parameters as torch holds them (Python floats = double); `step` = t, the 1-based count of
+ * this update.  Derived factors (1 - beta, lr / (1 - beta1^t), sqrt(1 - beta2^t)) are formed in
+ * double precision and rounded to fp32 once, as torch does. */
+int gft_adam_step(void* hip_stream, int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -23,7 +23,8 @@ def lib():
     return _lib.load()
 
 
-HEADERS = [HEADER, os.path.join(ROOT, "include", "gftorf_assemble.h"), os.path.join(ROOT, "include", "gftorf_knn.h")]
+HEADERS = [HEADER, os.path.join(ROOT, "include", "gftorf_assemble.h"), os.path.join(ROOT, "include", "gftorf_knn.h"),
+           os.path.join(ROOT, "include", "gftorf_optim.h")]
 
 
 def declared_functions():
