@@ -50,7 +50,7 @@ BACKWARD_FIELDS = [
 LAYOUT_FIELDS = [
     "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_rect", "geom_dirgrad", "geom_clamped",
     "geom_blockhist", "geom_total",
-    "img_pix_state", "img_ranges", "img_tile_max", "img_ctrl", "img_tile_cnt", "img_tile_cursor", "img_tile_order", "img_total",
+    "img_pix_state", "img_ranges", "img_tile_max", "img_ctrl", "img_tile_cnt", "img_tile_cursor", "img_tile_order", "img_front_len", "img_unit_flag", "img_resume_state", "img_total",
     "bin_keys", "bin_point_list", "bin_total",
 ]
 
@@ -100,7 +100,7 @@ class AssembleBwdIO(C.Structure):
 
 
 EXPORTS = [
-    "gft_abi_version", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes", "gft_acc_bytes",
+    "gft_abi_version", "gft_lazy_sort", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes", "gft_acc_bytes",
     "gft_get_layout", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_backward",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",

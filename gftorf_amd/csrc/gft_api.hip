@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -52,6 +53,9 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->img_tile_cnt = o;    o = align_up(o + T * 4);
     L->img_tile_cursor = o; o = align_up(o + T * 4);
     L->img_tile_order = o;  o = align_up(o + T * 4);
+    L->img_front_len = o;   o = align_up(o + T * 4);
+    L->img_unit_flag = o;   o = align_up(o + T * 16);
+    L->img_resume_state = o; o = align_up(o + n * 64);
     L->img_total = o;
 
     const size_t r = (size_t)(R > 0 ? R : 0);
@@ -87,6 +91,9 @@ ImgView gft_img_view(void* base, const gft_layout& L)
     v.tile_cnt = (uint32_t*)(b + L.img_tile_cnt);
     v.tile_cursor = (uint32_t*)(b + L.img_tile_cursor);
     v.tile_order = (uint32_t*)(b + L.img_tile_order);
+    v.front_len = (uint32_t*)(b + L.img_front_len);
+    v.unit_flag = (uint32_t*)(b + L.img_unit_flag);
+    v.resume_state = (float4*)(b + L.img_resume_state);
     return v;
 }
 
@@ -343,6 +350,16 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
     return 0;
 }
 
+// GFT_LAZY_SORT=0 in the environment sorts every tile list whole (k_tile_sort_small / _big) instead of
+// head first, tail on demand (k_tile_front / k_tile_tail); results are identical.
+static bool lazy_sort_enabled()
+{
+    static const bool on = [] { const char* e = getenv("GFT_LAZY_SORT"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
+
+extern "C" int gft_lazy_sort(void) { return lazy_sort_enabled() ? 1 : 0; }
+
 // scatter + per-tile sort + render; `cap` = instances the binning buffer holds.  With
 // check_cap the kernels compare the device-side count against it and do nothing on overflow.
 static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
@@ -353,6 +370,7 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
     // tile sort, whose workgroups are bound by LDS and VALU: each writes a slice of zeros first.
     float* clear = (io->acc && cfg->want_backward && cfg->P > 0) ? io->acc : nullptr;
     const size_t clear_bytes = (size_t)cfg->P * GFT_ACC_STRIDE * sizeof(float);
+    const bool lazy = binned && lazy_sort_enabled();
     if (binned) {
         {
             StageTimer t(s, ST_TILE_SCATTER);
@@ -360,14 +378,29 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
         }
         {
             StageTimer t(s, ST_TILE_SORT);
-            GFT_STAGE(s, cfg, "tile_sort", gft_launch_tile_sort(s, *cfg, max_tile_list, im, b, cap, clear, clear_bytes));
+            if (lazy)
+                GFT_STAGE(s, cfg, "tile_front", gft_launch_tile_front(s, *cfg, im, b, cap, clear, clear_bytes));
+            else
+                GFT_STAGE(s, cfg, "tile_sort", gft_launch_tile_sort(s, *cfg, max_tile_list, im, b, cap, clear, clear_bytes));
         }
     } else if (clear) {
         GFT_CHECK_HIP(hipMemsetAsync(clear, 0, clear_bytes, s));
     }
     {
         StageTimer t(s, ST_RENDER_FWD);
-        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, check_cap, cap));
+        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, check_cap, cap, lazy ? 1 : 0));
+    }
+    if (lazy) {
+        // quadrants that used up the sorted head of their list: sort those tails, continue those quadrants
+        // (both kernels leave at once when the first pass raised no flag)
+        {
+            StageTimer t(s, ST_TILE_SORT);
+            GFT_STAGE(s, cfg, "tile_tail", gft_launch_tile_tail(s, *cfg, g, im, b, cap));
+        }
+        {
+            StageTimer t(s, ST_RENDER_FWD);
+            GFT_STAGE(s, cfg, "render_resume", gft_launch_render_fwd(s, *cfg, *io, g, im, b, check_cap, cap, 2));
+        }
     }
     if (g_prof.on) { std::lock_guard<std::mutex> lk(g_prof.mu); g_prof.fwd++; }
     return 0;
@@ -461,11 +494,11 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     // The hint said "no tile list longer than the short-sort limit" and the frame has one: its
     // tiles were rendered unsorted.  Sort them and render again (the contributing-pixel counters
     // are the only accumulated output).
-    if (max_tile_list_hint > 0 && max_tile_list_hint <= GFT_SHORT_LIST_MAX && host[GFT_CTRL_MAXCNT] > GFT_SHORT_LIST_MAX &&
-        host[GFT_CTRL_TOTAL] <= cap && binning_instances > 0) {
+    if (!lazy_sort_enabled() && max_tile_list_hint > 0 && max_tile_list_hint <= GFT_SHORT_LIST_MAX &&
+        host[GFT_CTRL_MAXCNT] > GFT_SHORT_LIST_MAX && host[GFT_CTRL_TOTAL] <= cap && binning_instances > 0) {
         GFT_CHECK_HIP(hipMemsetAsync(io->pixels, 0, (size_t)cfg->P * sizeof(float), s));
         GFT_STAGE(s, cfg, "tile_sort_long", gft_launch_tile_sort_long(s, *cfg, im, b, cap));
-        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, true, cap));
+        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, true, cap, 0));
     }
     return 0;
 }

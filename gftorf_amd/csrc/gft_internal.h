@@ -29,6 +29,9 @@ struct ImgView {
     uint32_t* tile_cnt;   // [T]
     uint32_t* tile_cursor;// [T]
     uint32_t* tile_order; // [T] tiles by backward weight, heaviest first (written by the backward)
+    uint32_t* front_len;  // [T] lazy sort: length of the sorted head of the tile's id list
+    uint32_t* unit_flag;  // [4T] lazy sort: quadrant reached the end of the head unsaturated
+    float4* resume_state; // [N][4] lazy sort: blend state of the pixels of flagged quadrants
 };
 
 struct BinView {
@@ -40,6 +43,7 @@ struct BinView {
 #define GFT_CTRL_TOTAL 0     // R = number of (Gaussian, tile) instances
 #define GFT_CTRL_FLAGS 1     // bit0: prefiltered point culled
 #define GFT_CTRL_MAXCNT 2    // longest tile list
+#define GFT_CTRL_NFLAG 4     // lazy sort: number of flagged quadrants
 #define GFT_CTRL_DONE 3      // finished k_tile_count workgroups (ticket for the fused scan)
 #define GFT_CTRL_SEQ 3       // host mailbox only: sequence number, written last
 #define GFT_CTRL_WORDS 8
@@ -69,10 +73,15 @@ hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const Geo
                                    const BinView& b, uint32_t cap);
 hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_tile_list, const ImgView& im,
                                 const BinView& b, uint32_t cap, float* clear, size_t clear_bytes);
+hipError_t gft_launch_tile_front(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b, uint32_t cap,
+                                 float* clear, size_t clear_bytes);
+hipError_t gft_launch_tile_tail(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
+                                const BinView& b, uint32_t cap);
 hipError_t gft_launch_tile_sort_long(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b,
                                      uint32_t cap);
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
-                                 const GeomView& g, const ImgView& im, const BinView& b, bool check_cap, uint32_t cap);
+                                 const GeomView& g, const ImgView& im, const BinView& b, bool check_cap, uint32_t cap,
+                                 int lazy);
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b);
 hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,

@@ -362,8 +362,11 @@ __device__ __forceinline__ void reg_stage_dyn(uint64_t* v, int s_local, int t, i
     case 0: reg_stage<LOG_E, 0>(v, t, b, m, LG); break;
     case 1: reg_stage<LOG_E, 1>(v, t, b, m, LG); break;
     case 2: reg_stage<LOG_E, 2>(v, t, b, m, LG); break;
-    default:
+    case 3:
         if (LOG_E > 3) reg_stage<LOG_E, (LOG_E > 3 ? 3 : 0)>(v, t, b, m, LG);
+        break;
+    default:
+        if (LOG_E > 4) reg_stage<LOG_E, (LOG_E > 4 ? 4 : 0)>(v, t, b, m, LG);
         break;
     }
 }
@@ -456,6 +459,181 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_small(const uint2* __re
     sort_range_small(r.x, n, keys, point_list, sk, threadIdx.x);
 }
 
+// ---- lazy sort: sorted front + unsorted tail ----------------------------------------------
+// A pixel stops consuming its tile list when its transmittance drops below 1e-4, so in a dense
+// frame most of a long list is never read (1 M metric frame: 3031 entries per tile, 430 walked).
+// Lists longer than FRONT_DIRECT are therefore split: the nearest ~FRONT_TARGET keys (every key
+// <= a splitter picked from 256 sorted samples) are sorted into the head of the id list, the
+// other ids follow unsorted.  The render kernel walks the head; a quadrant that reaches its end
+// with unsaturated pixels raises a flag and saves its state, k_tile_tail then sorts the rest of
+// that tile's list and the render kernel resumes those quadrants (same arithmetic sequence as a
+// single pass, bit-identical results).
+#define FRONT_DIRECT 1024u       // lists up to this length are sorted whole
+#define FRONT_TARGET 940u        // wanted length of the sorted head of a longer list
+#define FRONT_MAX 1024u          // capacity of the head sort (8 KB of LDS: many workgroups per CU)
+#define FRONT_BINS 256
+#define FRONT_UNROLL 4
+
+// The head = every key whose depth falls into the first bins of a 256-bin histogram (linear in the
+// depth value between the list's nearest and farthest key) up to the bin where the running count
+// reaches FRONT_TARGET; if that bin overshoots FRONT_MAX the bins before it are taken.
+__global__ __launch_bounds__(GFT_BLOCK) void k_tile_front(const uint2* __restrict__ ranges,
+                                                          const uint64_t* __restrict__ keys,
+                                                          uint32_t* __restrict__ point_list,
+                                                          uint32_t* __restrict__ front_len, uint32_t* __restrict__ unit_flag,
+                                                          const uint32_t* __restrict__ ctrl, uint32_t cap,
+                                                          float4* __restrict__ clear, size_t clear_vec4)
+{
+    __shared__ uint64_t sk[FRONT_MAX];
+    __shared__ uint32_t s_hist[FRONT_BINS];
+    __shared__ uint32_t s_min[GFT_BLOCK / 64], s_max[GFT_BLOCK / 64];
+    __shared__ uint32_t s_cut, s_kf, s_nf, s_nt;
+    if (ctrl[GFT_CTRL_TOTAL] > cap) return;
+    // fire-and-forget zero fill of the backward's accumulator (see gft_api.hip enqueue_stage2):
+    // the stores drain while this workgroup sorts in LDS
+    if (clear) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t i = (size_t)blockIdx.x * GFT_BLOCK + threadIdx.x; i < clear_vec4; i += (size_t)gridDim.x * GFT_BLOCK)
+            clear[i] = z;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const uint2 r = ranges[tile];
+    const uint32_t n = r.y - r.x;
+    if (tid < 4) unit_flag[4 * tile + tid] = 0;
+    if (n <= FRONT_DIRECT) {
+        if (n == 1u) {
+            if (tid == 0) point_list[r.x] = (uint32_t)keys[r.x];
+        } else if (n > 1u) {
+            const uint32_t npad = next_pow2(n);
+            for (uint32_t i = tid; i < n; i += GFT_BLOCK) sk[i] = keys[r.x + i];
+            __syncthreads();
+            bitonic_ascending<GFT_BLOCK>(n, npad, tid, [&](uint32_t i) { return sk[i]; }, [&](uint32_t i, uint64_t v) { sk[i] = v; },
+                                         [] { __syncthreads(); });
+            for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[i];
+        }
+        if (tid == 0) front_len[tile] = n;
+        return;
+    }
+    // pass 1: depth range (depth bits of a positive float order like the value)
+    uint32_t dmin = 0xffffffffu, dmax = 0u;
+    // (every pass keeps FRONT_UNROLL loads per lane in flight: the loops are latency-bound otherwise)
+    for (uint32_t i0 = 0; i0 < n; i0 += FRONT_UNROLL * GFT_BLOCK) {
+        uint64_t k4[FRONT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FRONT_UNROLL; u++) {
+            const uint32_t i = i0 + u * GFT_BLOCK + tid;
+            k4[u] = i < n ? keys[r.x + i] : keys[r.x];
+        }
+#pragma unroll
+        for (int u = 0; u < FRONT_UNROLL; u++) {
+            const uint32_t d = (uint32_t)(k4[u] >> 32);
+            dmin = min(dmin, d);
+            dmax = max(dmax, d);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, o, 64));
+        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, o, 64));
+    }
+    if (lane == 0) { s_min[wave] = dmin; s_max[wave] = dmax; }
+    s_hist[tid] = 0;                                         // FRONT_BINS == GFT_BLOCK
+    __syncthreads();
+    for (int w = 0; w < GFT_BLOCK / 64; w++) { dmin = min(dmin, s_min[w]); dmax = max(dmax, s_max[w]); }
+    const float zmin = __uint_as_float(dmin);
+    const float zspan = __uint_as_float(dmax) - zmin;
+    const float scale = zspan > 0.f ? (float)FRONT_BINS / zspan : 0.f;
+    auto bin_of = [&](uint64_t k) {
+        const uint32_t b = (uint32_t)((__uint_as_float((uint32_t)(k >> 32)) - zmin) * scale);   // monotone in the depth
+        return b < FRONT_BINS ? b : FRONT_BINS - 1u;
+    };
+    // pass 2: histogram
+    for (uint32_t i0 = 0; i0 < n; i0 += FRONT_UNROLL * GFT_BLOCK) {
+        uint64_t k4[FRONT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FRONT_UNROLL; u++) {
+            const uint32_t i = i0 + u * GFT_BLOCK + tid;
+            k4[u] = i < n ? keys[r.x + i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < FRONT_UNROLL; u++)
+            if (i0 + u * GFT_BLOCK + tid < n) atomicAdd(&s_hist[bin_of(k4[u])], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // inclusive scan of the 256 bins by one wave (4 bins per lane), then the cut
+        uint32_t h[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { h[k] = s_hist[4 * lane + k]; sum += h[k]; }
+        uint32_t x = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        uint32_t run = x - sum;
+        // first bin whose inclusive count reaches the target
+        uint32_t cut = 0xffffffffu, kf_at = 0, kf_before = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t before = run;
+            run += h[k];
+            if (cut == 0xffffffffu && run >= FRONT_TARGET) { cut = 4 * lane + k; kf_at = run; kf_before = before; }
+        }
+        // lowest lane that found one
+        const unsigned long long found = __builtin_amdgcn_ballot_w64(cut != 0xffffffffu);
+        const int src = found ? (int)__builtin_ctzll(found) : 0;
+        cut = (uint32_t)__shfl((int)cut, src, 64);
+        kf_at = (uint32_t)__shfl((int)kf_at, src, 64);
+        kf_before = (uint32_t)__shfl((int)kf_before, src, 64);
+        if (lane == 0) {
+            // bins [0, cut] if they fit, else [0, cut): cut_excl = number of bins taken
+            if (kf_at <= FRONT_MAX) { s_cut = cut + 1u; s_kf = kf_at; }
+            else { s_cut = cut; s_kf = kf_before; }            // (one bin alone overshoots: shorter head)
+            s_nf = 0; s_nt = 0;
+        }
+    }
+    __syncthreads();
+    const uint32_t nbins = s_cut, kf = s_kf;                  // kf <= FRONT_MAX by construction
+    const uint32_t npad = next_pow2(kf < 2u ? 2u : kf);
+    for (uint32_t i = tid + kf; i < npad; i += GFT_BLOCK) sk[i] = ~0ull;
+    // pass 3: head keys to LDS, tail ids behind the head in the id list
+    for (uint32_t i0 = 0; i0 < n; i0 += FRONT_UNROLL * GFT_BLOCK) {
+        uint64_t k4[FRONT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FRONT_UNROLL; u++) {
+            const uint32_t i = i0 + u * GFT_BLOCK + tid;
+            k4[u] = i < n ? keys[r.x + i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < FRONT_UNROLL; u++) {
+            const bool in = i0 + u * GFT_BLOCK + tid < n;
+            const uint64_t k = k4[u];
+            const bool head = in && bin_of(k) < nbins;
+            const bool tail = in && !head;
+            // one LDS atomic per wave and destination
+            const unsigned long long hm = __builtin_amdgcn_ballot_w64(head), tm = __builtin_amdgcn_ballot_w64(tail);
+            uint32_t hb = 0, tb = 0;
+            if (lane == 0) {
+                if (hm) hb = atomicAdd(&s_nf, (uint32_t)__popcll(hm));
+                if (tm) tb = atomicAdd(&s_nt, (uint32_t)__popcll(tm));
+            }
+            hb = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb);
+            tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            if (head) sk[hb + (uint32_t)__popcll(hm & lt)] = k;
+            else if (tail) point_list[r.x + kf + tb + (uint32_t)__popcll(tm & lt)] = (uint32_t)k;
+        }
+    }
+    __syncthreads();
+    if (kf > 1u)
+        bitonic_ascending<GFT_BLOCK>(kf, npad, tid, [&](uint32_t i) { return sk[i]; }, [&](uint32_t i, uint64_t v) { sk[i] = v; },
+                                     [] { __syncthreads(); });
+    for (uint32_t i = tid; i < kf; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[i];
+    if (tid == 0) front_len[tile] = kf;
+}
+
 // Long lists: 4097..16384 keys are sorted by 1024 threads with the register-blocked network in
 // 132 KB of dynamic LDS (8 or 16 keys per thread), longer ones in place in global memory with the
 // plain network.  Up to one workgroup per CU strides over the tile table.
@@ -464,6 +642,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_small(const uint2* __re
 // keys per tile: 3.0-6.0 ms against 3.6 ms for this whole-list network; centre-heavy 1 M frame:
 // 272 vs 239 us.  The 4096-key unit has a 60 us latency; long lists need a different sort.)
 #define SORT_BIG_THREADS 1024
+#define SORT_LDS_LARGE_KEYS 16384u
 __global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_sort_big(int T, const uint2* __restrict__ ranges,
                                                                     uint64_t* keys, uint32_t* __restrict__ point_list,
                                                                     uint32_t lo, uint32_t hi,
@@ -495,6 +674,68 @@ __global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_sort_big(int T, const
                 [&](uint32_t i, uint64_t v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
                 [] { __threadfence_block(); __syncthreads(); });
             for (uint32_t i = tid; i < n; i += SORT_BIG_THREADS) point_list[r.x + i] = (uint32_t)seg[i];
+        }
+    }
+}
+
+// Sorts the unsorted tail of the id list of every tile that has a flagged quadrant (lazy sort,
+// see k_tile_front): keys are rebuilt from the ids (depth gather), sorted by 1024 threads with
+// the register-blocked network in LDS (up to 16384 keys) or in place in the key array beyond.
+__global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_tail(int T, const uint2* __restrict__ ranges, uint64_t* keys,
+                                                                uint32_t* __restrict__ point_list,
+                                                                const float* __restrict__ depth,
+                                                                const uint32_t* __restrict__ front_len,
+                                                                const uint32_t* __restrict__ unit_flag,
+                                                                const uint32_t* __restrict__ ctrl, uint32_t cap)
+{
+    extern __shared__ uint64_t sk_dyn[];
+    uint64_t* sk = sk_dyn;
+    if (ctrl[GFT_CTRL_TOTAL] > cap) return;
+    if (ctrl[GFT_CTRL_NFLAG] == 0u) return;
+    const int tid = threadIdx.x;
+    for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
+        const uint4 f = reinterpret_cast<const uint4*>(unit_flag)[tile];
+        if ((f.x | f.y | f.z | f.w) == 0u) continue;           // uniform per workgroup
+        const uint2 r = ranges[tile];
+        const uint32_t kf = front_len[tile];
+        const uint32_t first = r.x + kf, nt = (r.y - r.x) - kf;
+        if (nt == 0u) continue;
+        auto key_of = [&](uint32_t i) {
+            const uint32_t id = point_list[first + i];
+            return ((uint64_t)__float_as_uint(depth[id]) << 32) | id;
+        };
+        if (nt <= SORT_LDS_LARGE_KEYS) {
+            if (nt <= 1024u) {
+                const uint32_t npad = next_pow2(nt < 2u ? 2u : nt);
+                for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) sk[i] = key_of(i);
+                __syncthreads();
+                bitonic_ascending<SORT_BIG_THREADS>(nt, npad, tid, [&](uint32_t i) { return sk[i]; },
+                                                    [&](uint32_t i, uint64_t v) { sk[i] = v; }, [] { __syncthreads(); });
+                for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) point_list[first + i] = (uint32_t)sk[i];
+            } else {
+                const uint32_t npad = nt <= 4096u ? 4096u : (nt <= 8192u ? 8192u : 16384u);
+                // all keys are built before any id is overwritten (the ids live in point_list)
+                for (uint32_t i = tid; i < npad; i += SORT_BIG_THREADS) sk[sort_slot(i)] = i < nt ? key_of(i) : ~0ull;
+                __syncthreads();
+                if (npad == 4096u) bitonic_blocked<2, 10>(sk, tid);
+                else if (npad == 8192u) bitonic_blocked<3, 10>(sk, tid);
+                else bitonic_blocked<4, 10>(sk, tid);
+                for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) point_list[first + i] = (uint32_t)sk[sort_slot(i)];
+            }
+            __syncthreads();
+        } else {
+            uint64_t* seg = keys + first;                       // the scattered keys are no longer needed
+            for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) seg[i] = key_of(i);
+            __threadfence_block();
+            __syncthreads();
+            const uint32_t npad = next_pow2(nt);
+            bitonic_ascending<SORT_BIG_THREADS>(
+                nt, npad, tid,
+                [&](uint32_t i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
+                [&](uint32_t i, uint64_t v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
+                [] { __threadfence_block(); __syncthreads(); });
+            for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) point_list[first + i] = (uint32_t)seg[i];
+            __syncthreads();
         }
     }
 }
@@ -566,6 +807,32 @@ hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_
     // the longest list (known to the host in the two-stage flow, a guess of the caller in the
     // one-call flow, <= 0 = unknown) tells whether any tile needs the long-list path
     if (max_tile_list <= 0 || max_tile_list > (int64_t)SORT_LDS_SMALL) return gft_launch_tile_sort_long(s, c, im, b, cap);
+    return hipGetLastError();
+}
+
+hipError_t gft_launch_tile_front(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b, uint32_t cap,
+                                 float* clear, size_t clear_bytes)
+{
+    const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    const int T = gx * gy;
+    hipLaunchKernelGGL(k_tile_front, dim3(T), dim3(GFT_BLOCK), 0, s, im.ranges, b.keys, b.point_list, im.front_len,
+                       im.unit_flag, im.ctrl, cap, reinterpret_cast<float4*>(clear), clear_bytes / 16);
+    return hipGetLastError();
+}
+
+hipError_t gft_launch_tile_tail(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
+                                const BinView& b, uint32_t cap)
+{
+    const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    const int T = gx * gy;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SORT_LDS_LARGE_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_tile_tail, dim3(T < 256 ? T : 256), dim3(SORT_BIG_THREADS), (size_t)SORT_LDS_LARGE_BYTES, s, T,
+                       im.ranges, b.keys, b.point_list, g.depth, im.front_len, im.unit_flag, im.ctrl, cap);
     return hipGetLastError();
 }
 

@@ -115,6 +115,12 @@ struct RenderFwdArgs {
     float* pixels;
     const uint32_t* __restrict__ ctrl;   // NULL: no instance-count check
     uint32_t cap;
+    // lazy sort (k_binning.hip, k_tile_front): only the head of every id list is sorted
+    const uint32_t* __restrict__ front_len;   // NULL: lists are sorted whole
+    uint32_t* __restrict__ unit_flag;
+    uint32_t* nflag;
+    float4* __restrict__ resume_state;
+    int resume;                               // second pass: continue the flagged quadrants behind the head
 };
 
 __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
@@ -124,6 +130,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
 
     // binning buffer smaller than the instance count: nothing was binned, the host re-runs stage 2
     if (a.ctrl && a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
+    if (a.resume && *a.nflag == 0u) return;               // no quadrant asked for its tail
     const int V = a.T * 4;
     const int v = unit_of_block(blockIdx.x, V);
     if (v >= V) return;
@@ -135,7 +142,13 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = a.ranges[tile];
-    const int total = (int)(range.y - range.x);
+    const int full = (int)(range.y - range.x);
+    const int head = a.front_len ? (int)a.front_len[tile] : full;
+    // first pass: list positions [0, head); resume pass: [head, full) of the flagged quadrants
+    if (a.resume && a.unit_flag[v] == 0u) return;
+    const int begin = a.resume ? head : 0;
+    const int total = a.resume ? full : head;
+    const size_t pix_i = inside ? (size_t)a.W * py + px : 0;
 
     // Predicates are wave-uniform 64-bit lane masks: every ballot below takes a single compare,
     // the combinations are scalar ALU work and the selects read the masks from SGPRs.
@@ -146,8 +159,21 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     float PR = 0, PI = 0, PA = 0;     // ToF phasor on its (R, I, Am) basis
     float Dd = 0, A = 0, DD_D = 0, DD_D2 = 0;
     float WD0 = 0, WD1 = 0, WD2 = 0;
+    if (a.resume) {
+        bool was_done = true;
+        if (inside) {
+            const float4 s0 = a.resume_state[4 * pix_i], s1 = a.resume_state[4 * pix_i + 1];
+            const float4 s2 = a.resume_state[4 * pix_i + 2], s3 = a.resume_state[4 * pix_i + 3];
+            T = s0.x; C0 = s0.y; C1 = s0.z; C2 = s0.w;
+            PR = s1.x; PI = s1.y; PA = s1.z; Dd = s1.w;
+            A = s2.x; DD_D = s2.y; DD_D2 = s2.z; WD0 = s2.w;
+            WD1 = s3.x; WD2 = s3.y; last_contributor = __float_as_uint(s3.z);
+            was_done = s3.w != 0.f;
+        }
+        done_m = wave_ballot(was_done);
+    }
 
-    for (int base = 0; base < total; base += RB) {
+    for (int base = begin; base < total; base += RB) {
         // all 64 pixels finished -> the rest of the list is never used
         if (done_m == ~0ull) break;
         const int n = min(RB, total - base);
@@ -213,6 +239,22 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
             if (done_m == ~0ull) break;
         }
         if (cnt) atomicAdd(&a.pixels[my_id], (float)cnt);
+    }
+
+    // The sorted head is used up, pixels are still unsaturated and the list goes on: park the blend
+    // state and ask for the tail (k_tile_tail sorts it, the resume pass continues from here).
+    if (!a.resume && head < full && done_m != ~0ull) {
+        if (inside) {
+            const bool is_done = (done_m >> lane) & 1ull;
+            a.resume_state[4 * pix_i] = make_float4(T, C0, C1, C2);
+            a.resume_state[4 * pix_i + 1] = make_float4(PR, PI, PA, Dd);
+            a.resume_state[4 * pix_i + 2] = make_float4(A, DD_D, DD_D2, WD0);
+            a.resume_state[4 * pix_i + 3] = make_float4(WD1, WD2, __uint_as_float(last_contributor), is_done ? 1.f : 0.f);
+        }
+        if (lane == 0) {
+            a.unit_flag[v] = 1u;
+            atomicAdd(a.nflag, 1u);
+        }
     }
 
     if (inside) {
@@ -565,7 +607,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
 }  // namespace
 
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
-                                 const ImgView& im, const BinView& b, bool check_cap, uint32_t cap)
+                                 const ImgView& im, const BinView& b, bool check_cap, uint32_t cap, int lazy)
 {
     RenderFwdArgs a;
     a.ctrl = check_cap ? im.ctrl : nullptr;
@@ -582,6 +624,12 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     a.out_normal = io.out_normal; a.out_acc = io.out_acc; a.out_entropy = io.out_entropy;
     a.out_dd = io.out_depth_distortion; a.out_ad = io.out_amp_distortion;
     a.out_distribution = io.out_distribution; a.pixels = io.pixels;
+    // lazy: 0 = lists sorted whole, 1 = first pass over the sorted heads, 2 = resume pass
+    a.front_len = lazy ? im.front_len : nullptr;
+    a.unit_flag = im.unit_flag;
+    a.nflag = im.ctrl + GFT_CTRL_NFLAG;
+    a.resume_state = im.resume_state;
+    a.resume = lazy == 2;
     const int blocks = 8 * ((a.T * 4 + 7) / 8);
     hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();

@@ -180,6 +180,9 @@ typedef struct gft_layout {
     size_t img_tile_cnt;      /* uint32[T]    instances per tile */
     size_t img_tile_cursor;   /* uint32[T]    scatter cursors */
     size_t img_tile_order;    /* uint32[T]    tiles by backward weight (written by gft_backward) */
+    size_t img_front_len;     /* uint32[T]    length of the sorted head of the tile's id list (lazy sort) */
+    size_t img_unit_flag;     /* uint32[4T]   quadrant ran out of sorted ids before saturating (lazy sort) */
+    size_t img_resume_state;  /* float[N][16] blend state of such quadrants' pixels */
     size_t img_total;
     /* binning */
     size_t bin_keys;          /* uint64[R]    (depth bits << 32 | Gaussian id), grouped by tile, unsorted */
@@ -195,6 +198,8 @@ typedef struct gft_profile {
 } gft_profile;
 
 int gft_abi_version(void);
+/* 1: tile lists are sorted head first, tail on demand (default); 0: whole (GFT_LAZY_SORT=0) */
+int gft_lazy_sort(void);
 const char* gft_last_error(void);   /* host string, thread local */
 
 size_t gft_geom_bytes(int32_t P);
