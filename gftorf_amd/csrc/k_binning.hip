@@ -271,9 +271,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int
 // mirror stage (i <-> i ^ (k-1)), then half-cleaners at distances k/4 .. 1.
 // Elements at positions >= n are +inf by construction and never move.
 template <int THREADS, typename Ld, typename St, typename Sync>
-__device__ __forceinline__ void bitonic_ascending(uint32_t n, uint32_t npad, int tid, Ld ld, St st, Sync sync)
+__device__ __forceinline__ void bitonic_ascending(uint32_t n, uint32_t npad, int tid, Ld ld, St st, Sync sync,
+                                                  uint32_t k_first = 2)
 {
-    for (uint32_t k = 2; k <= npad; k <<= 1) {
+    // k_first > 2: runs of k_first / 2 keys are already ascending
+    for (uint32_t k = k_first; k <= npad; k <<= 1) {
         const uint32_t half = k >> 1;
         for (uint32_t c = tid; c < (npad >> 1); c += THREADS) {
             const uint32_t blk = c / half, off = c - blk * half;
@@ -371,8 +373,18 @@ __device__ __forceinline__ void reg_stage_dyn(uint64_t* v, int s_local, int t, i
     }
 }
 
-template <int LOG_E, int LOG_T>
-__device__ __forceinline__ void bitonic_blocked(uint64_t* sk, int tid)
+struct BlockSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
+// the keys of the network belong to one wave: LDS operations of a wave complete in order
+struct WaveSync {
+    __device__ __forceinline__ void operator()() const
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+template <int LOG_E, int LOG_T, typename Sync = BlockSync>
+__device__ __forceinline__ void bitonic_blocked(uint64_t* sk, int tid, Sync sync = Sync())
 {
     constexpr int E = 1 << LOG_E;
     constexpr int LG = LOG_T + LOG_E;      // log2(npad)
@@ -389,9 +401,9 @@ __device__ __forceinline__ void bitonic_blocked(uint64_t* sk, int tid)
             int nb = (s / LOG_E) * LOG_E;
             if (nb > LG - LOG_E) nb = LG - LOG_E;
             if (nb != b) {
-                __syncthreads();
+                sync();
                 regs_to_lds<LOG_E>(v, sk, tid, b);
-                __syncthreads();
+                sync();
                 b = nb;
                 regs_from_lds<LOG_E>(v, sk, tid, b);
             }
@@ -399,9 +411,9 @@ __device__ __forceinline__ void bitonic_blocked(uint64_t* sk, int tid)
         }
     }
     // b == 0 here (the last stages of every merge are in the natural layout)
-    __syncthreads();
+    sync();
     regs_to_lds<LOG_E>(v, sk, tid, 0);
-    __syncthreads();
+    sync();
 }
 
 // Sorts keys[first, first + n), n <= 4096, into point_list[first, first + n) (ids only) through
@@ -474,6 +486,32 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_sort_small(const uint2* __re
 #define FRONT_BINS 256
 #define FRONT_UNROLL 4
 
+// Sorts the n keys in sk[0, npad) (pads = ~0, npad a power of two <= 1024) with 256 threads and
+// writes the ids.  1024-key class: every wave first sorts its own quarter of 256 keys in registers
+// (no workgroup barrier: the keys of a quarter belong to one wave), then the two last merge steps
+// (19 stages) run across the workgroup -- 19 barriers instead of the 55 of the plain network.
+__device__ __forceinline__ void head_sort_and_store(uint64_t* sk, uint32_t n, uint32_t npad, int tid, uint32_t* __restrict__ ids)
+{
+    if (n <= 1u) {
+        if (n == 1u && tid == 0) ids[0] = (uint32_t)sk[0];
+        return;
+    }
+    if (npad == 1024u) {
+        const int lane = tid & 63, wave = tid >> 6;
+        bitonic_blocked<2, 6, WaveSync>(sk + 256 * wave, lane, WaveSync());
+        __syncthreads();
+        // key i of a sorted quarter sits at its swizzled slot
+        auto slot = [](uint32_t i) { return (i & ~255u) | sort_slot(i & 255u); };
+        bitonic_ascending<GFT_BLOCK>(n, npad, tid, [&](uint32_t i) { return sk[slot(i)]; },
+                                     [&](uint32_t i, uint64_t v) { sk[slot(i)] = v; }, [] { __syncthreads(); }, 512u);
+        for (uint32_t i = tid; i < n; i += GFT_BLOCK) ids[i] = (uint32_t)sk[slot(i)];
+        return;
+    }
+    bitonic_ascending<GFT_BLOCK>(n, npad, tid, [&](uint32_t i) { return sk[i]; }, [&](uint32_t i, uint64_t v) { sk[i] = v; },
+                                 [] { __syncthreads(); });
+    for (uint32_t i = tid; i < n; i += GFT_BLOCK) ids[i] = (uint32_t)sk[i];
+}
+
 // The head = every key whose depth falls into the first bins of a 256-bin histogram (linear in the
 // depth value between the list's nearest and farthest key) up to the bin where the running count
 // reaches FRONT_TARGET; if that bin overshoots FRONT_MAX the bins before it are taken.
@@ -506,11 +544,9 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_front(const uint2* __restric
             if (tid == 0) point_list[r.x] = (uint32_t)keys[r.x];
         } else if (n > 1u) {
             const uint32_t npad = next_pow2(n);
-            for (uint32_t i = tid; i < n; i += GFT_BLOCK) sk[i] = keys[r.x + i];
+            for (uint32_t i = tid; i < npad; i += GFT_BLOCK) sk[i] = i < n ? keys[r.x + i] : ~0ull;
             __syncthreads();
-            bitonic_ascending<GFT_BLOCK>(n, npad, tid, [&](uint32_t i) { return sk[i]; }, [&](uint32_t i, uint64_t v) { sk[i] = v; },
-                                         [] { __syncthreads(); });
-            for (uint32_t i = tid; i < n; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[i];
+            head_sort_and_store(sk, n, npad, tid, point_list + r.x);
         }
         if (tid == 0) front_len[tile] = n;
         return;
@@ -627,10 +663,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_front(const uint2* __restric
         }
     }
     __syncthreads();
-    if (kf > 1u)
-        bitonic_ascending<GFT_BLOCK>(kf, npad, tid, [&](uint32_t i) { return sk[i]; }, [&](uint32_t i, uint64_t v) { sk[i] = v; },
-                                     [] { __syncthreads(); });
-    for (uint32_t i = tid; i < kf; i += GFT_BLOCK) point_list[r.x + i] = (uint32_t)sk[i];
+    head_sort_and_store(sk, kf, npad, tid, point_list + r.x);
     if (tid == 0) front_len[tile] = kf;
 }
 
