@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the fused-assembly measurement")
+    ap.add_argument("--spin-up", type=float, default=0.3, help="seconds of untimed steps before the warm-up")
     args = ap.parse_args()
 
     import torch
@@ -336,6 +337,14 @@ def main():
     scene = build_scene(args.workload, env["rank"], world)
     step, state, _ = gpu_step_fn(scene, dev)
     sync = torch.cuda.synchronize
+
+    # Device spin-up before the W warm-up steps: the power management raises the clocks over the first
+    # tens of milliseconds of load, and W steps of 0.65 ms are over before that (an occasional 30 % slower
+    # timed leg with normal per-kernel times in the profiled leg was the symptom).  Untimed.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spin_up:
+        step()
+    sync()
 
     elapsed = timed_steps(step, args.steps, args.warmup, sync, dist)
 

@@ -524,72 +524,82 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
         uint64_t touched = 0;
         __syncthreads();
 
+        // alpha of splat j for this pixel and whether the pixel blended it in the forward
+        auto eval = [&](int j, float4& a0, float4& a1, float& dx, float& dy, float& G, float& alpha) -> bool {
+            const int c = hi - 1 - j;               // list position of this splat
+            a0 = sA[2 * j]; a1 = sA[2 * j + 1];
+            dx = a0.x - pxf; dy = a0.y - pyf;
+            const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+            G = gft_exp(power);
+            alpha = fminf(0.99f, a1.y * G);
+            return (c < n_contrib) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+        };
+        // Gradient contributions of splat j, reduced over the 64 pixels into `row`.  Every lane runs
+        // the same arithmetic; lanes that do not blend this splat use alpha = G = 0, which leaves T and
+        // the two recurrences unchanged (rcp(1) == 1) and makes all 15 partials exactly zero.
+        // accumulator row = {dcolor[3], ddist | dmean2D.xy, dconic.xy | XR, XI, X2, XQ | dconic.w, dopacity, dndc, -}
+        auto blend = [&](int j, float* row, const float4& a0, const float4& a1, float dx, float dy, float G, float alpha,
+                         bool contrib) {
+            v2f L01, L23, L45, L67, H01, H23, H45, H67;
+            const float4 b0 = sB[2 * j], b1 = sB[2 * j + 1];
+            const float al = contrib ? alpha : 0.f;
+            const float Gm = contrib ? G : 0.f;
+            const float one_m_a = 1.f - al;
+            const float rcp_1ma = __builtin_amdgcn_rcpf(one_m_a);
+            T = T * rcp_1ma;
+            const float wc = al * T;             // dchannel_dcolor == dchannel_ddepth
+            const float wp = wc * T;             // dchannel_dphasor = alpha*T*T
+            const float dist = a1.w, z = a1.z;
+            const float t2 = fmaf(A2, z, B2);    // A2 z + B2
+            const float dL_dw_ga = fmaf(t2, z, C2);   // g_acc + dL_dw
+
+            float D1 = b0.x * gc0;
+            D1 = fmaf(b0.y, gc1, D1); D1 = fmaf(b0.z, gc2, D1); D1 = fmaf(dist, gd, D1);
+            D1 += dL_dw_ga;
+
+            float Dp = b0.w * GR;
+            Dp = fmaf(b1.x, GI, Dp); Dp = fmaf(b1.y, GA, Dp);
+
+            // alpha also scales what is left for the background (reference :850-858): -T_final/(1-alpha) * bg . g
+            const float dL_dalpha = fmaf(D1 - S1, T, fmaf(fmaf(-2.f * one_m_a, Sp, Dp), T * T, bg_k * rcp_1ma));
+
+            S1 = fmaf(al, D1, one_m_a * S1);
+            Sp = fmaf(al, Dp, one_m_a * one_m_a * Sp);
+
+            L01 = gA01 * wc;                      // w_c * (g_c0, g_c1)
+            L23 = gA23 * wc;                      // w_c * (g_c2, g_dist)
+            H01 = gB01 * wp;                      // w_p * (GR, GI)
+            H23 = gB23 * wp;                      // w_p * (g_p2, GQ)
+
+            // E = G dL/dalpha; the per-splat factors of the five geometric sums (opacity, -1/2,
+            // 0.5 W, 0.5 H) are applied once per Gaussian in k_preprocess_bwd:
+            //   dL/dmean2D.x = -o 0.5W sum E (dx a + dy b),  dL/dconic.x = -o/2 sum E dx^2, ...
+            const float E = Gm * dL_dalpha;
+            const float Edx = E * dx, Edy = E * dy;
+            L45.x = E * fmaf(dy, a0.w, dx * a0.z);    // dmean2D.x / (-o 0.5 W)
+            L45.y = E * fmaf(dx, a0.w, dy * a1.x);    // dmean2D.y / (-o 0.5 H)
+            L67.x = Edx * dx;                         // dconic.x / (-o/2)
+            L67.y = Edx * dy;                         // dconic.y / (-o/2)
+            H45.x = Edy * dy;                         // dconic.w / (-o/2)
+            H45.y = E;                                // dopacity
+            H67.x = wc * (t2 + A2 * z);           // gdd*2*alpha*T*(z(1-Tf) - wz)
+            H67.y = 0.f;
+            // 64 pixels -> one partial per value, parked in the batch's LDS table
+            wave_reduce16_store(L01, L23, L45, L67, H01, H23, H45, H67, row, lane);
+        };
+
         while (m) {
             const int j = (int)__builtin_ctzll(m);
             m &= m - 1;
-            const int c = hi - 1 - j;               // list position of this splat
-            const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
-            const float dx = a0.x - pxf, dy = a0.y - pyf;
-            const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-            const float G = gft_exp(power);
-            const float alpha = fminf(0.99f, a1.y * G);
-            const bool contrib = (c < n_contrib) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            float4 a0, a1;
+            float dx, dy, G, alpha;
+            const bool contrib = eval(j, a0, a1, dx, dy, G, alpha);
             if (wave_ballot(contrib) == 0ull) continue;   // wave-uniform skip
-
-            // Every lane runs the same arithmetic; lanes that do not blend this splat use
-            // alpha = G = 0, which leaves T and the two recurrences unchanged (rcp(1) == 1) and
-            // makes all 15 partials exactly zero.
-            // accumulator row = {dcolor[3], ddist | dmean2D.xy, dconic.xy | XR, XI, X2, XQ | dconic.w, dopacity, dndc, -}
-            v2f L01, L23, L45, L67, H01, H23, H45, H67;
-            {
-                const float4 b0 = sB[2 * j], b1 = sB[2 * j + 1];
-                const float al = contrib ? alpha : 0.f;
-                const float Gm = contrib ? G : 0.f;
-                const float one_m_a = 1.f - al;
-                const float rcp_1ma = __builtin_amdgcn_rcpf(one_m_a);
-                T = T * rcp_1ma;
-                const float wc = al * T;             // dchannel_dcolor == dchannel_ddepth
-                const float wp = wc * T;             // dchannel_dphasor = alpha*T*T
-                const float dist = a1.w, z = a1.z;
-                const float t2 = fmaf(A2, z, B2);    // A2 z + B2
-                const float dL_dw_ga = fmaf(t2, z, C2);   // g_acc + dL_dw
-
-                float D1 = b0.x * gc0;
-                D1 = fmaf(b0.y, gc1, D1); D1 = fmaf(b0.z, gc2, D1); D1 = fmaf(dist, gd, D1);
-                D1 += dL_dw_ga;
-
-                float Dp = b0.w * GR;
-                Dp = fmaf(b1.x, GI, Dp); Dp = fmaf(b1.y, GA, Dp);
-
-                // alpha also scales what is left for the background (reference :850-858): -T_final/(1-alpha) * bg . g
-                const float dL_dalpha = fmaf(D1 - S1, T, fmaf(fmaf(-2.f * one_m_a, Sp, Dp), T * T, bg_k * rcp_1ma));
-
-                S1 = fmaf(al, D1, one_m_a * S1);
-                Sp = fmaf(al, Dp, one_m_a * one_m_a * Sp);
-
-                L01 = gA01 * wc;                      // w_c * (g_c0, g_c1)
-                L23 = gA23 * wc;                      // w_c * (g_c2, g_dist)
-                H01 = gB01 * wp;                      // w_p * (GR, GI)
-                H23 = gB23 * wp;                      // w_p * (g_p2, GQ)
-
-                // E = G dL/dalpha; the per-splat factors of the five geometric sums (opacity, -1/2,
-                // 0.5 W, 0.5 H) are applied once per Gaussian in k_preprocess_bwd:
-                //   dL/dmean2D.x = -o 0.5W sum E (dx a + dy b),  dL/dconic.x = -o/2 sum E dx^2, ...
-                const float E = Gm * dL_dalpha;
-                const float Edx = E * dx, Edy = E * dy;
-                L45.x = E * fmaf(dy, a0.w, dx * a0.z);    // dmean2D.x / (-o 0.5 W)
-                L45.y = E * fmaf(dx, a0.w, dy * a1.x);    // dmean2D.y / (-o 0.5 H)
-                L67.x = Edx * dx;                         // dconic.x / (-o/2)
-                L67.y = Edx * dy;                         // dconic.y / (-o/2)
-                H45.x = Edy * dy;                         // dconic.w / (-o/2)
-                H45.y = E;                                // dopacity
-                H67.x = wc * (t2 + A2 * z);           // gdd*2*alpha*T*(z(1-Tf) - wz)
-                H67.y = 0.f;
-            }
-            // 64 pixels -> one partial per value, parked in the batch's LDS table
-            wave_reduce16_store(L01, L23, L45, L67, H01, H23, H45, H67, &sAcc[j * ACC_LDS_STRIDE], lane);
+            blend(j, &sAcc[j * ACC_LDS_STRIDE], a0, a1, dx, dy, G, alpha, contrib);
             touched |= 1ull << j;
         }
+        // (issuing two splats per iteration in one basic block so that the scheduler can overlap their
+        // exp / rcp / DPP latencies was measured: 214 vs 198 us, dropped)
         __syncthreads();
 
         // flush: one 60-byte burst of float atomics (a single 64-byte row) per splat that received a contribution
