@@ -787,7 +787,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
 
             // ---- ToF phasor chain (reference backward.cu:527-587) ----
             const float4 b2 = a.g.rec_b[2 * idx + 1];     // {I, Am, phase_sh, amplitude}
-            const float dist = a.g.rec_a[2 * idx + 1].w;
+            // distance to the camera: the forward's expression on the same view-space position (bit-identical;
+            // re-reading it from rec_a would cost a 32-byte sector per Gaussian for 4 bytes)
+            const float dist = sqrtf(mvx * mvx + mvy * mvy + mvz * mvz);
             if (a.io.shs_p != nullptr) {
                 float phase = dist * a.dist2phase + a.c.phase_offset;
                 if (a.c.use_view_dependent_phase) phase += b2.z;
