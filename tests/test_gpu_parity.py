@@ -438,3 +438,42 @@ def test_one_call_forward_with_wrong_list_guess(oracle, gpu):
                 Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
     f, b = Hh.run_oracle(oracle, scene)
     check_outputs(f, ref_out)
+
+
+LAZY_CASES = {
+    # lists of 1.2k..5k keys per tile: the sorted head (~940 keys) is not enough for the far pixels
+    "thin_fog": dict(P=40000, W=64, H=64, scale_lo=0.01, scale_hi=0.05, opacity=0.02),            # nothing saturates: every quadrant resumes
+    "mixed": dict(P=30000, W=96, H=64, scale_lo=0.005, scale_hi=0.08),                             # some quadrants saturate in the head
+    "dense_opaque": dict(P=30000, W=64, H=48, scale_lo=0.02, scale_hi=0.1, opacity=0.9),           # all saturate early: no tail is ever sorted
+    "one_long_tile": dict(P=6000, W=16, H=16, scale_lo=0.02, scale_hi=0.06, opacity=0.05, spread=0.3),
+}
+
+
+@pytest.mark.parametrize("name", list(LAZY_CASES))
+def test_lazy_sort_resume_paths(name, oracle, gpu):
+    """Head-first tile sort (k_tile_front / k_tile_tail / resumed quadrants): images, counters and
+    gradients against the oracle, and the structure of the id lists, on frames that exercise
+    'never resumes', 'always resumes' and the mix."""
+    scene = Hh.small_scene(seed=21, **LAZY_CASES[name])
+    f, b = Hh.run_oracle(oracle, scene)
+    st = raw_forward(scene, gpu)
+    lens = f.ranges[:, 1] - f.ranges[:, 0]
+    if st["lazy"]:
+        long_tiles = lens > 1024
+        assert long_tiles.any(), "case does not reach the lazy path"
+        flagged = st["unit_flag"].any(1)
+        assert int(st["ctrl"][4]) == int(st["unit_flag"].sum())
+        if name == "thin_fog":
+            assert flagged[long_tiles].all()
+        if name == "dense_opaque":
+            assert not flagged.any()
+        for t in np.nonzero(long_tiles)[0]:
+            a, e = int(f.ranges[t, 0]), int(f.ranges[t, 1])
+            k = int(st["front_len"][t])
+            assert 0 < k <= 1024
+            np.testing.assert_array_equal(st["point_list"][a:a + k], f.point_list[a:a + k])
+            if flagged[t]:
+                np.testing.assert_array_equal(st["point_list"][a:e], f.point_list[a:e])
+    out, grads, _ = Hh.run_gpu(scene, gpu)
+    check_outputs(f, out)
+    check_grads(b, grads, scene)
