@@ -40,7 +40,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->geom_rect = o;     o = align_up(o + p * 8);
     L->geom_dirgrad = o;  o = align_up(o + p * 64);
     L->geom_clamped = o;  o = align_up(o + p);
-    L->geom_blockhist = o; o = align_up(o + ((p + 4095) / 4096) * GFT_BLOCKHIST_TILES * 2);
+    L->geom_blockhist = o; o = align_up(o + ((p + BIN_CHUNK - 1) / BIN_CHUNK) * GFT_BLOCKHIST_TILES * 2);
     L->geom_total = o;
 
     const size_t n = (size_t)W * (size_t)H;

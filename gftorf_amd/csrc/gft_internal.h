@@ -48,6 +48,14 @@ struct BinView {
 #define GFT_CTRL_SEQ 3       // host mailbox only: sequence number, written last
 #define GFT_CTRL_WORDS 8
 #define GFT_BLOCKHIST_TILES 2048
+// binning workgroup shape (k_binning.hip): 16 waves per workgroup keep one CU busy on their own
+#ifndef BIN_THREADS
+#define BIN_THREADS 1024
+#endif
+#ifndef BIN_ITEMS
+#define BIN_ITEMS 4                          // Gaussians per thread in count / scatter
+#endif
+#define BIN_CHUNK (BIN_THREADS * BIN_ITEMS)  // Gaussians per workgroup
 #define GFT_SHORT_LIST_MAX 4096   // tile lists up to this length are sorted by one 256-thread workgroup
 
 void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* L);

@@ -25,13 +25,7 @@
 
 namespace {
 
-#ifndef BIN_THREADS
-#define BIN_THREADS 1024                    // 16 waves per workgroup keep one CU busy on its own
-#endif
-#ifndef BIN_ITEMS
-#define BIN_ITEMS 4                         // Gaussians per thread in count / scatter
-#endif
-#define BIN_CHUNK (BIN_THREADS * BIN_ITEMS)  // 4096 Gaussians per workgroup
+// BIN_THREADS / BIN_ITEMS / BIN_CHUNK: gft_internal.h (the geom layout depends on them)
 #define BIN_LDS_MAX_TILES 16384            // LDS histogram limit (2 x 64 KB in the scatter)
 #define BIN_STAGE_LDS_BYTES (156 * 1024)   // dynamic LDS of the staged scatter (160 KB per CU minus static)
 
@@ -788,7 +782,7 @@ hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomV
     if (T <= BIN_LDS_MAX_TILES)
         hipLaunchKernelGGL(k_tile_count<true>, dim3(blocks), dim3(BIN_THREADS), (size_t)T * 4, s, c.P, gx, T, g.rect,
                            im.tile_cnt, im.ranges, im.tile_cursor, im.ctrl, mail, seq,
-                           (T <= GFT_BLOCKHIST_TILES && BIN_CHUNK == 4096) ? g.blockhist : nullptr);
+                           T <= GFT_BLOCKHIST_TILES ? g.blockhist : nullptr);
     else
         hipLaunchKernelGGL(k_tile_count<false>, dim3(blocks), dim3(BIN_THREADS), 0, s, c.P, gx, T, g.rect, im.tile_cnt,
                            im.ranges, im.tile_cursor, im.ctrl, mail, seq, nullptr);
@@ -820,7 +814,7 @@ hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const Geo
     const size_t tables = ((size_t)3 * T + (T & 1)) * 4;
     const size_t stage_cap = tables + 4096 * 8 <= BIN_STAGE_LDS_BYTES ? (BIN_STAGE_LDS_BYTES - tables) / 8 : 0;
     const size_t expect = blocks > 0 ? (size_t)cap / (size_t)blocks : 0;
-    const uint16_t* bh = (T <= GFT_BLOCKHIST_TILES && BIN_CHUNK == 4096) ? g.blockhist : nullptr;
+    const uint16_t* bh = T <= GFT_BLOCKHIST_TILES ? g.blockhist : nullptr;
     if (stage_cap > 0 && expect <= stage_cap + stage_cap / 2)
         hipLaunchKernelGGL(k_tile_scatter<2>, dim3(blocks), dim3(BIN_THREADS), tables + stage_cap * 8, s, c.P, gx, T,
                            g.rect, g.depth, im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, (uint32_t)stage_cap, bh);
