@@ -945,26 +945,36 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
 __global__ __launch_bounds__(1024) void k_offset_reduce(int nblocks, const float2* __restrict__ part,
                                                         float* __restrict__ out_phase, float* __restrict__ out_dc)
 {
-    __shared__ float s0[1024], s1[1024];
+    // fixed summation order (deterministic): thread-strided partial sums, butterfly inside the wave,
+    // then the 16 wave sums in order
+    __shared__ float s0[16], s1[16];
     float p = 0.f, d = 0.f;
-    for (int i = threadIdx.x; i < nblocks; i += 1024) {
-        const float2 v = part[i];
+    // two partials per 16-byte load
+    const float4* part4 = reinterpret_cast<const float4*>(part);
+    const int n4 = nblocks >> 1;
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+        const float4 v = part4[i];
+        p += v.x + v.z;
+        d += v.y + v.w;
+    }
+    if ((nblocks & 1) && threadIdx.x == 0) {
+        const float2 v = part[nblocks - 1];
         p += v.x;
         d += v.y;
     }
-    s0[threadIdx.x] = p;
-    s1[threadIdx.x] = d;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) {
-            s0[threadIdx.x] += s0[threadIdx.x + w];
-            s1[threadIdx.x] += s1[threadIdx.x + w];
-        }
-        __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        p += __shfl_xor(p, o, 64);
+        d += __shfl_xor(d, o, 64);
     }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s0[wave] = p; s1[wave] = d; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        *out_phase = s0[0];
-        *out_dc = s1[0];
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 16; w++) { a += s0[w]; b += s1[w]; }
+        *out_phase = a;
+        *out_dc = b;
     }
 }
 
