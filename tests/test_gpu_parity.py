@@ -477,3 +477,35 @@ def test_lazy_sort_resume_paths(name, oracle, gpu):
     out, grads, _ = Hh.run_gpu(scene, gpu)
     check_outputs(f, out)
     check_grads(b, grads, scene)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_configurations(seed, oracle, gpu):
+    """Seeded sweep over frame shapes, densities, SH degrees, camera poses and scale modifiers:
+    images, counters and every gradient against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    W = int(rng.integers(17, 130))
+    H = int(rng.integers(9, 90))
+    P = int(rng.integers(50, 6000))
+    D = int(rng.integers(0, 4))
+    M = int(rng.choice([c for c in (1, 4, 9, 16) if c >= (D + 1) ** 2]))
+    lo = float(10 ** rng.uniform(-3.0, -1.3))
+    hi = lo * float(10 ** rng.uniform(0.2, 1.3))
+    w2c = synth_pose(rng)
+    scene = Hh.small_scene(P=P, W=W, H=H, seed=int(rng.integers(1 << 30)), D=D, sh_coeffs=M, scale_lo=lo, scale_hi=hi,
+                           w2c=w2c, spread=float(rng.uniform(0.6, 1.8)),
+                           opacity=None if rng.random() < 0.6 else float(rng.uniform(0.02, 0.98)))
+    scene["use_view_dependent_phase"] = bool(rng.integers(0, 2))
+    scene["phase_offset"] = float(rng.uniform(-0.5, 0.5))
+    scene["dc_offset"] = float(rng.uniform(0.0, 0.2))
+    over = dict(scale_modifier=float(rng.choice([1.0, 0.7, 1.3])))
+    f, b = Hh.run_oracle(oracle, scene, **over)
+    out, grads, _ = Hh.run_gpu(scene, gpu, optimize_offsets=True, **over)
+    check_outputs(f, out)
+    check_grads(b, grads, scene)
+
+
+def synth_pose(rng):
+    from gftorf_amd import synth
+    return synth.look_at_w2c(float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2)),
+                             (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.1, 0.4))))
