@@ -1,0 +1,120 @@
+"""ORACLE (test infrastructure only) of the deformation network -- SURVEY section 8(f) row 2.
+
+CPU restatement (numpy) of ``utils/time_utils.py`` of the reference:
+
+* :func:`embed`        -- ``get_embedder`` / ``Embedder.embed`` (time_utils.py:8-53): include_input,
+  log-sampled frequencies 2^0 .. 2^(multires-1), per frequency sin then cos of all input dims.
+* :func:`forward`      -- ``DeformNetwork.forward`` (time_utils.py:103-127): 8 x (Linear + ReLU) of width
+  256, the embedded input concatenated IN FRONT of the activations after layer 4 (``skips = [D // 2]``),
+  heads ``xyz_warp`` and ``r``/``g``/``b`` (stacked on the last axis); ``d_rot`` and ``d_sh_p`` are
+  returned as ZEROS by the reference (time_utils.py:127), the ``rot`` and ``a`` heads never reach an output.
+* :func:`backward`     -- the adjoint of the above, written out by hand (chain rule of Linear / ReLU);
+  inputs are not differentiated (the reference detaches them, scene/gaussian_model.py:172).
+
+Parameters are a dict with the reference's ``state_dict`` names (``linear.0.weight`` ... ``b.bias``), numpy
+arrays in torch's ``[out, in]`` layout.  ``dtype=np.float64`` gives the accuracy reference of the float32
+comparisons.  Pinned against the reference's own module by ``tests/golden/deform.npz``
+(``tests/golden/make_golden.py``).
+
+Only tests/, __graft_entry__.smoke() and bench.py's baseline leg may import this module.
+"""
+import numpy as np
+
+D, W, XYZ_MULTIRES, T_MULTIRES, NUM_SHS = 8, 256, 10, 6, 16
+SKIP = D // 2                                    # time_utils.py:62
+XYZ_CH = 3 + 3 * 2 * XYZ_MULTIRES                # 63
+T_CH = 1 + 2 * T_MULTIRES                        # 13
+IN_CH = XYZ_CH + T_CH                            # 76
+HEADS = ("xyz_warp", "r", "g", "b")              # heads that reach an output
+UNUSED = ("rot", "a")                            # computed by the reference, discarded (time_utils.py:118-127)
+
+
+def param_shapes():
+    """state_dict names -> shapes (time_utils.py:68-81)."""
+    s = {}
+    for i in range(D):
+        fan_in = IN_CH if i == 0 else (W + IN_CH if i == SKIP + 1 else W)
+        s["linear.%d.weight" % i] = (W, fan_in)
+        s["linear.%d.bias" % i] = (W,)
+    for name, out in (("xyz_warp", 3), ("rot", 4), ("r", NUM_SHS), ("g", NUM_SHS), ("b", NUM_SHS), ("a", NUM_SHS)):
+        s[name + ".weight"] = (out, W)
+        s[name + ".bias"] = (out,)
+    return s
+
+
+def random_params(seed, head_std=0.05):
+    """Seeded parameters of a usable magnitude (Xavier-like trunk; heads larger than the reference's
+    1e-5 initialisation so that outputs and gradients are well away from zero)."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, shape in param_shapes().items():
+        if name.endswith(".bias"):
+            p[name] = rng.normal(0.0, 0.02, shape).astype(np.float32)
+        elif name.startswith("linear."):
+            p[name] = rng.normal(0.0, np.sqrt(2.0 / (shape[0] + shape[1])), shape).astype(np.float32)
+        else:
+            p[name] = rng.normal(0.0, head_std, shape).astype(np.float32)
+    return p
+
+
+def embed_one(v, multires, dtype):
+    """Embedder.embed (time_utils.py:24-53) of v[n, d]."""
+    v = np.asarray(v, dtype)
+    parts = [v]
+    for f in range(multires):
+        freq = dtype(2.0 ** f)                   # 2 ** linspace(0, multires-1, multires), exact
+        parts.append(np.sin(v * freq))
+        parts.append(np.cos(v * freq))
+    return np.concatenate(parts, axis=-1)
+
+
+def embed(x, t, dtype=np.float32):
+    """cat([x_emb, t_emb]) (time_utils.py:104-107): [n, 76]."""
+    return np.concatenate([embed_one(x, XYZ_MULTIRES, dtype), embed_one(t, T_MULTIRES, dtype)], axis=-1)
+
+
+def _trunk(params, x, t, dtype):
+    emb = embed(x, t, dtype)
+    h = emb
+    inputs, outs = [], []
+    for i in range(D):                           # time_utils.py:109-113
+        w = params["linear.%d.weight" % i].astype(dtype)
+        b = params["linear.%d.bias" % i].astype(dtype)
+        inputs.append(h)
+        z = h @ w.T + b
+        a = np.maximum(z, 0)
+        outs.append(a)
+        h = np.concatenate([emb, a], axis=-1) if i == SKIP else a
+    return emb, inputs, outs, h
+
+
+def forward(params, x, t, dtype=np.float32):
+    """Returns (d_xyz[n,3], d_rot[n,4] = 0, d_sh[n,16,3], d_sh_p[n,16,2] = 0) (time_utils.py:115-127)."""
+    _, _, _, h = _trunk(params, x, t, dtype)
+    head = lambda n: h @ params[n + ".weight"].astype(dtype).T + params[n + ".bias"].astype(dtype)
+    d_xyz = head("xyz_warp")
+    d_sh = np.stack([head("r"), head("g"), head("b")], axis=-1)
+    n = d_xyz.shape[0]
+    return d_xyz, np.zeros((n, 4), dtype), d_sh, np.zeros((n, NUM_SHS, 2), dtype)
+
+
+def backward(params, x, t, g_dxyz, g_dsh, dtype=np.float32):
+    """Gradients of sum(d_xyz * g_dxyz) + sum(d_sh * g_dsh) w.r.t. every parameter that reaches an output;
+    the ``rot`` / ``a`` heads get None as under the reference's autograd."""
+    emb, inputs, outs, h = _trunk(params, x, t, dtype)
+    g = {n + s: None for n in UNUSED for s in (".weight", ".bias")}
+    g_dxyz = np.asarray(g_dxyz, dtype)
+    g_dsh = np.asarray(g_dsh, dtype)
+    dh = np.zeros_like(h)
+    for name, go in (("xyz_warp", g_dxyz), ("r", g_dsh[:, :, 0]), ("g", g_dsh[:, :, 1]), ("b", g_dsh[:, :, 2])):
+        g[name + ".weight"] = go.T @ h
+        g[name + ".bias"] = go.sum(axis=0)
+        dh = dh + go @ params[name + ".weight"].astype(dtype)
+    for i in reversed(range(D)):
+        dz = dh * (outs[i] > 0)
+        g["linear.%d.weight" % i] = dz.T @ inputs[i]
+        g["linear.%d.bias" % i] = dz.sum(axis=0)
+        dh = dz @ params["linear.%d.weight" % i].astype(dtype)
+        if i == SKIP + 1:
+            dh = dh[:, IN_CH:]                   # the embedded part of the skip input has no parameters
+    return g

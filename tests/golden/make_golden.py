@@ -7,6 +7,10 @@ files themselves never travel; only the input/output vectors written here do.
                    coefficients/directions, degrees 0..3
   camera.npz     : utils/graphics_utils.py getProjectionMatrix (55-75),
                    getProjectionMatrixShift (77-109), getWorld2View2 (38-49)
+  deform.npz     : utils/time_utils.py DeformNetwork (56-127), forward and autograd backward on CPU
+                   (its two hard-wired ``.cuda()`` calls are made no-ops for the run), with the seeded
+                   parameters of oracle/deform_ref.random_params; only inputs, outputs and gradients
+                   (small ones whole, weight gradients as strided samples) are stored
 """
 import math
 import os
@@ -20,7 +24,43 @@ from utils.sh_utils import eval_sh, RGB2SH, PA2SH  # noqa: E402
 from utils.graphics_utils import (getProjectionMatrix, getProjectionMatrixShift,  # noqa: E402
                                   getWorld2View2)
 
+from utils.time_utils import DeformNetwork  # noqa: E402
+
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle import deform_ref  # noqa: E402
+
+DEFORM_SEED = 77
+
+
+def deform_fixture():
+    torch.Tensor.cuda = lambda self, *a, **k: self          # time_utils.py:121,127 on a CPU-only host
+    net = DeformNetwork()
+    net.isotropic = False
+    params = deform_ref.random_params(DEFORM_SEED)
+    net.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    rng = np.random.default_rng(DEFORM_SEED + 1)
+    n = 48
+    x = rng.random((n, 3)).astype(np.float32)
+    t = np.full((n, 1), 0.37, np.float32)
+    t[n // 2:] = rng.random((n - n // 2, 1)).astype(np.float32)
+    g_dxyz = rng.normal(size=(n, 3)).astype(np.float32)
+    g_dsh = rng.normal(size=(n, 16, 3)).astype(np.float32)
+    d_xyz, d_rot, d_sh, d_sh_p = net(torch.tensor(x), torch.tensor(t))
+    ((d_xyz * torch.tensor(g_dxyz)).sum() + (d_sh * torch.tensor(g_dsh)).sum()).backward()
+    out = dict(x=x, t=t, g_dxyz=g_dxyz, g_dsh=g_dsh, seed=np.int64(DEFORM_SEED),
+               d_xyz=d_xyz.detach().numpy(), d_rot=d_rot.numpy(), d_sh=d_sh.detach().numpy(),
+               d_sh_p=d_sh_p.numpy())
+    none = []
+    for name, p in net.named_parameters():
+        if p.grad is None:
+            none.append(name)
+        elif p.grad.numel() <= 4096:
+            out["grad:" + name] = p.grad.numpy()
+        else:
+            out["grad_s:" + name] = p.grad.numpy()[::8, ::4]   # strided sample of a [256, in] matrix
+    out["grad_none"] = np.array(none)
+    np.savez(os.path.join(HERE, "deform.npz"), **out)
 
 
 def main():
@@ -60,6 +100,7 @@ def main():
     cams["w2v_R"], cams["w2v_t"] = R, t
     cams["w2v"] = getWorld2View2(R, t)
     np.savez(os.path.join(HERE, "camera.npz"), **cams)
+    deform_fixture()
     print("wrote", sorted(os.listdir(HERE)))
 
 
