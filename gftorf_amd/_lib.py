@@ -99,12 +99,22 @@ class AssembleBwdIO(C.Structure):
                 [(n, _fp) for n in ASSEMBLE_BWD_TAIL])
 
 
+class DeformParams(C.Structure):
+    """gft_deform_params / gft_deform_grads (include/gftorf_deform.h): same field order."""
+    _fields_ = [("linear_w", _fp * 8), ("linear_b", _fp * 8), ("xyz_w", _fp), ("xyz_b", _fp), ("r_w", _fp), ("r_b", _fp),
+                ("g_w", _fp), ("g_b", _fp), ("b_w", _fp), ("b_b", _fp)]
+
+
+DEFORM_FIELDS = [f[0] for f in DeformParams._fields_]
+
 EXPORTS = [
     "gft_abi_version", "gft_lazy_sort", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes", "gft_acc_bytes",
     "gft_get_layout", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_backward",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
     "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step",
+    "gft_deform_packed_bytes", "gft_deform_saved_bytes", "gft_deform_scratch_bytes", "gft_deform_pack",
+    "gft_deform_forward", "gft_deform_backward",
 ]
 
 
@@ -140,6 +150,20 @@ def load():
     lib.gft_adam_step.restype = C.c_int
     lib.gft_adam_step.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64]
+    lib.gft_deform_packed_bytes.restype = C.c_size_t
+    lib.gft_deform_packed_bytes.argtypes = []
+    lib.gft_deform_saved_bytes.restype = C.c_size_t
+    lib.gft_deform_saved_bytes.argtypes = [C.c_int64]
+    lib.gft_deform_scratch_bytes.restype = C.c_size_t
+    lib.gft_deform_scratch_bytes.argtypes = [C.c_int64]
+    lib.gft_deform_pack.restype = C.c_int
+    lib.gft_deform_pack.argtypes = [C.c_void_p, C.POINTER(DeformParams), C.c_void_p]
+    lib.gft_deform_forward.restype = C.c_int
+    lib.gft_deform_forward.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
+    lib.gft_deform_backward.restype = C.c_int
+    lib.gft_deform_backward.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(DeformParams)]
     lib.gft_knn_scratch_bytes.restype = C.c_size_t
     lib.gft_knn_scratch_bytes.argtypes = [C.c_int32]
     lib.gft_knn_mean_dist2.restype = C.c_int

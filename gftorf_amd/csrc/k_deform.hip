@@ -1,0 +1,714 @@
+// k_deform.hip -- the deformation network (reference utils/time_utils.py:56-127) on the gfx950 fp32
+// matrix cores.  See include/gftorf_deform.h for the contract.
+//
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32]; lane l holds A[i = l & 31][k = l >> 5] and
+// B[k = l >> 5][j = l & 31]; D: column = l & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5).
+// 64 cycles per instruction per SIMD = the fp32 peak (157 TFLOP/s), so the kernels only have to
+// keep one wave per SIMD fed: operands come as 16-byte LDS reads (4 k per read, the packed weights
+// are interleaved [k/4][n][4] for that), weights stream L2 -> registers -> LDS one 16-k chunk
+// ahead of the chunk being multiplied.
+#include "gft_internal.h"
+#include "gftorf_deform.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int DF_D = GFT_DEFORM_LAYERS;
+constexpr int DF_W = GFT_DEFORM_WIDTH;
+constexpr int DF_IN = GFT_DEFORM_INPUTS;   // 76
+constexpr int DF_INK = 80;                 // encoding as a GEMM k-extent (multiple of 16, zero rows)
+constexpr int DF_EMB = 96;                 // stored encoding row (3 column tiles of the weight-gradient GEMM)
+constexpr int DF_HEAD = 64;                // head columns: 48 (d_sh, [coefficient][channel]) + 3 (d_xyz) + pad
+constexpr int DF_TILE = 64;                // points per workgroup
+constexpr int DF_HS = 260;                 // LDS row strides (floats): 16-byte reads of 16 rows hit 16 bank groups
+constexpr int DF_ES = 84;
+constexpr int DF_OS = 68;
+constexpr int DF_CHUNK_F4 = 1024;          // one 16-k x 256-column weight chunk, in float4
+
+// packed parameter buffer (floats): forward stream, backward stream, biases
+constexpr int64_t DF_F_SZ0 = (int64_t)DF_INK * DF_W;                  // 20480
+constexpr int64_t DF_F_SZ = (int64_t)DF_W * DF_W;                     // 65536
+constexpr int64_t DF_F_SZ5 = DF_F_SZ0 + DF_F_SZ;                      // 86016
+constexpr int64_t DF_F_HEAD_SZ = (int64_t)DF_W * DF_HEAD;             // 16384
+constexpr int64_t DF_F_TOTAL = DF_F_SZ0 + 6 * DF_F_SZ + DF_F_SZ5 + DF_F_HEAD_SZ;   // 516096
+constexpr int64_t DF_B_BASE = DF_F_TOTAL;
+constexpr int64_t DF_B_TOTAL = DF_F_HEAD_SZ + 7 * DF_F_SZ;            // 475136
+constexpr int64_t DF_BIAS_BASE = DF_B_BASE + DF_B_TOTAL;              // 991232
+constexpr int64_t DF_PACKED_FLOATS = DF_BIAS_BASE + DF_D * DF_W + DF_HEAD;   // 993344
+
+__host__ __device__ constexpr int64_t df_fwd_offset(int l)
+{
+    return l == 0 ? 0 : l <= 5 ? DF_F_SZ0 + (int64_t)(l - 1) * DF_F_SZ : l <= 7 ? DF_F_SZ0 + 4 * DF_F_SZ + DF_F_SZ5 + (int64_t)(l - 6) * DF_F_SZ
+                                                                                : DF_F_TOTAL - DF_F_HEAD_SZ;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack
+// ---------------------------------------------------------------------------------------------
+struct PackArgs {
+    gft_deform_params p;
+    float* out;
+};
+
+// head column hc -> (weight row pointer, bias): columns 0..47 are d_sh[coefficient c][channel ch] = c*3+ch
+__device__ __forceinline__ const float* head_row(const gft_deform_params& p, int hc, float& bias)
+{
+    if (hc < 48) {
+        const int c = hc / 3, ch = hc - 3 * c;
+        const float* w = ch == 0 ? p.r_w : ch == 1 ? p.g_w : p.b_w;
+        const float* b = ch == 0 ? p.r_b : ch == 1 ? p.g_b : p.b_b;
+        bias = b[c];
+        return w + (size_t)c * DF_W;
+    }
+    if (hc < 51) {
+        bias = p.xyz_b[hc - 48];
+        return p.xyz_w + (size_t)(hc - 48) * DF_W;
+    }
+    bias = 0.f;
+    return nullptr;
+}
+
+__global__ __launch_bounds__(256) void k_deform_pack(PackArgs a)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= DF_PACKED_FLOATS) return;
+    float v = 0.f;
+    if (e < DF_F_TOTAL) {
+        // forward stream: per layer [k/4][ncol][4], element (k, n) = W[n][k]
+        int l = 8;
+        for (int q = 0; q < 8; q++)
+            if (e < df_fwd_offset(q + 1)) { l = q; break; }
+        const int64_t r = e - df_fwd_offset(l);
+        const int ncol = l == 8 ? DF_HEAD : DF_W;
+        const int kq = (int)(r / (ncol * 4)), n = (int)((r >> 2) % ncol), k = 4 * kq + (int)(r & 3);
+        if (l == 8) {
+            float bias;
+            const float* row = head_row(a.p, n, bias);
+            v = row ? row[k] : 0.f;
+        } else if (l == 0) {
+            v = k < DF_IN ? a.p.linear_w[0][(size_t)n * DF_IN + k] : 0.f;
+        } else if (l == 5) {
+            const int ld = DF_W + DF_IN;
+            v = k < DF_IN ? a.p.linear_w[5][(size_t)n * ld + k] : k < DF_INK ? 0.f : a.p.linear_w[5][(size_t)n * ld + (k - 4)];
+        } else {
+            v = a.p.linear_w[l][(size_t)n * DF_W + k];
+        }
+    } else if (e < DF_BIAS_BASE) {
+        // backward stream: head first, then layers 7..1; element (k = output, n = input) = W[k][n]
+        const int64_t r0 = e - DF_B_BASE;
+        if (r0 < DF_F_HEAD_SZ) {
+            const int kq = (int)(r0 / (DF_W * 4)), n = (int)((r0 >> 2) % DF_W), k = 4 * kq + (int)(r0 & 3);
+            float bias;
+            const float* row = head_row(a.p, k, bias);
+            v = row ? row[n] : 0.f;
+        } else {
+            const int64_t r1 = r0 - DF_F_HEAD_SZ;
+            const int l = 7 - (int)(r1 / DF_F_SZ);
+            const int64_t r = r1 % DF_F_SZ;
+            const int kq = (int)(r / (DF_W * 4)), n = (int)((r >> 2) % DF_W), k = 4 * kq + (int)(r & 3);
+            v = l == 5 ? a.p.linear_w[5][(size_t)k * (DF_W + DF_IN) + DF_IN + n] : a.p.linear_w[l][(size_t)k * DF_W + n];
+        }
+    } else {
+        const int r = (int)(e - DF_BIAS_BASE);
+        if (r < DF_D * DF_W) v = a.p.linear_b[r >> 8][r & 255];
+        else (void)head_row(a.p, r - DF_D * DF_W, v);
+    }
+    a.out[e] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the chunked GEMM both walks use: acc[rt][ct] += A[64 x 16] * Wchunk[16 x ncol]
+// ---------------------------------------------------------------------------------------------
+template <int NR, int NC>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NR][NC])
+{
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[r][c][q] = 0.f;
+}
+
+// a_lane: the lane's row (l & 31) of the A tile at k = 4 * (l >> 5) of this chunk; wc: the lane's
+// float4 of the chunk, [(l >> 5)][column (l & 31) of the wave's first column tile].
+// k order inside a chunk: (0,4) (1,5) (2,6) (3,7) (8,12) ... -- any fixed order is a valid fp32 sum.
+template <int NR, int NC, int NCOL>
+__device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NR][NC], const float* a_lane, int a_stride, const float4* wc)
+{
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        float4 av[NR], bv[NC];
+#pragma unroll
+        for (int rt = 0; rt < NR; rt++) av[rt] = *reinterpret_cast<const float4*>(a_lane + rt * 32 * a_stride + 8 * r);
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++) bv[ct] = wc[2 * r * NCOL + ct * 32];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int rt = 0; rt < NR; rt++)
+#pragma unroll
+                for (int ct = 0; ct < NC; ct++) {
+                    const float x = s == 0 ? av[rt].x : s == 1 ? av[rt].y : s == 2 ? av[rt].z : av[rt].w;
+                    const float y = s == 0 ? bv[ct].x : s == 1 ? bv[ct].y : s == 2 ? bv[ct].z : bv[ct].w;
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[rt][ct], 0, 0, 0);
+                }
+    }
+}
+
+// The weight stream: chunks lie back to back in the packed buffer in the order they are used; while
+// chunk c is multiplied out of one LDS buffer, chunk c+1 travels global -> registers -> other buffer.
+struct WeightStream {
+    const float4* next;      // next chunk to fetch
+    float4* lds;             // [2][DF_CHUNK_F4]
+    int buf;                 // LDS buffer holding the chunk to multiply next
+};
+
+__device__ __forceinline__ void stream_prime(WeightStream& ws, int tid, int nf4)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (q < nf4) ws.lds[tid + 256 * q] = ws.next[tid + 256 * q];
+    ws.next += nf4 * 256;
+    ws.buf = 0;
+    __syncthreads();
+}
+
+// nchunks chunks of this segment; last_next_f4 = float4 per thread of the chunk that follows the
+// segment (4: 256-column chunk, 1: 64-column chunk, 0: end of stream).  Ends with a barrier.
+template <int NR, int NC, int NCOL>
+__device__ __forceinline__ void run_chunks(f32x16 (&acc)[NR][NC], const float* a_lane, int a_stride, int nchunks,
+                                           int last_next_f4, WeightStream& ws, int tid, int b_lane_off)
+{
+    for (int c = 0; c < nchunks; c++) {
+        const int nf4 = (c + 1 < nchunks) ? NCOL / 64 : last_next_f4;
+        // (named registers, not an array: a conditionally filled array ends up in scratch)
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
+        if (nf4 > 0) p0 = ws.next[tid];
+        if (nf4 > 1) {
+            p1 = ws.next[tid + 256];
+            p2 = ws.next[tid + 512];
+            p3 = ws.next[tid + 768];
+        }
+        chunk_mfma<NR, NC, NCOL>(acc, a_lane + c * 16, a_stride, ws.lds + ws.buf * DF_CHUNK_F4 + b_lane_off);
+        float4* wd = ws.lds + (ws.buf ^ 1) * DF_CHUNK_F4;
+        if (nf4 > 0) wd[tid] = p0;
+        if (nf4 > 1) {
+            wd[tid + 256] = p1;
+            wd[tid + 512] = p2;
+            wd[tid + 768] = p3;
+        }
+        ws.next += nf4 * 256;
+        ws.buf ^= 1;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+// ---------------------------------------------------------------------------------------------
+// forward walk
+// ---------------------------------------------------------------------------------------------
+struct FwdArgs {
+    int64_t n, n_pad, t_stride;
+    const float* xyz; const float* t;
+    const float* packed;
+    float* emb;       // [n_pad][96] or null
+    float* acts;      // [8][n_pad][256] or null
+    float* d_xyz; float* d_sh;
+};
+
+constexpr size_t DF_FWD_LDS = (size_t)(DF_TILE * DF_HS + DF_TILE * DF_ES) * 4 + 2 * DF_CHUNK_F4 * 16;   // 120832
+
+template <bool SAVE>
+__global__ __launch_bounds__(256) void k_deform_fwd(FwdArgs a)
+{
+    extern __shared__ float4 df_lds[];
+    float* hA = reinterpret_cast<float*>(df_lds);
+    float* eA = hA + DF_TILE * DF_HS;
+    WeightStream ws;
+    ws.lds = reinterpret_cast<float4*>(eA + DF_TILE * DF_ES);
+    ws.next = reinterpret_cast<const float4*>(a.packed);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * DF_TILE;
+
+    // positional encoding (time_utils.py:24-53): [x, sin(2^f x), cos(2^f x)]_f for all dims, then t
+    {
+        const int pt = tid & 63, grp = tid >> 6;
+        const int64_t p = p0 + pt;
+        float* e = eA + pt * DF_ES;
+        if (grp < 3) {
+            const float v = p < a.n ? a.xyz[3 * p + grp] : 0.f;
+            e[grp] = v;
+#pragma unroll
+            for (int f = 0; f < 10; f++) {
+                const float w = v * (float)(1 << f);
+                e[3 + 6 * f + grp] = sinf(w);
+                e[6 + 6 * f + grp] = cosf(w);
+            }
+        } else {
+            const float v = p < a.n ? a.t[p * a.t_stride] : 0.f;
+            e[63] = v;
+#pragma unroll
+            for (int f = 0; f < 6; f++) {
+                const float w = v * (float)(1 << f);
+                e[64 + 2 * f] = sinf(w);
+                e[65 + 2 * f] = cosf(w);
+            }
+            e[76] = e[77] = e[78] = e[79] = 0.f;
+        }
+    }
+    stream_prime(ws, tid, 4);   // barrier inside: the encoding is visible too
+    if (SAVE) {
+        for (int q = tid; q < DF_TILE * DF_EMB; q += 256) {
+            const int row = q / DF_EMB, col = q - row * DF_EMB;
+            a.emb[(p0 + row) * DF_EMB + col] = col < DF_INK ? eA[row * DF_ES + col] : 0.f;
+        }
+    }
+
+    const int n0 = wave * 64;
+    const float* bias = a.packed + DF_BIAS_BASE;
+    const float* e_lane = eA + li * DF_ES + 4 * hh;
+    const float* h_lane = hA + li * DF_HS + 4 * hh;
+    const int b_off = hh * DF_W + n0 + li;
+    f32x16 acc[2][2];
+    for (int l = 0; l < DF_D; l++) {
+        zero_acc(acc);
+        if (l == 0) {
+            run_chunks<2, 2, DF_W>(acc, e_lane, DF_ES, DF_INK / 16, 4, ws, tid, b_off);
+        } else {
+            // after layer 4 the encoding is concatenated in front (time_utils.py:112-113)
+            if (l == 5) run_chunks<2, 2, DF_W>(acc, e_lane, DF_ES, DF_INK / 16, 4, ws, tid, b_off);
+            run_chunks<2, 2, DF_W>(acc, h_lane, DF_HS, DF_W / 16, l == 7 ? 1 : 4, ws, tid, b_off);
+        }
+        // bias + ReLU -> next layer's A tile (every wave is past its last read of hA: run_chunks ends with a barrier)
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+            const int col = n0 + 32 * ct + li;
+            const float bv = bias[l * DF_W + col];
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int row = 32 * rt + acc_row(q, hh);
+                    const float v = fmaxf(acc[rt][ct][q] + bv, 0.f);
+                    hA[row * DF_HS + col] = v;
+                    if (SAVE) a.acts[((int64_t)l * a.n_pad + p0 + row) * DF_W + col] = v;
+                }
+        }
+        __syncthreads();
+    }
+    // heads: 64 columns, one 32x32 tile per wave
+    {
+        f32x16 hacc[1][1];
+        zero_acc(hacc);
+        const int rt = wave >> 1, ct = wave & 1;
+        run_chunks<1, 1, DF_HEAD>(hacc, hA + (32 * rt + li) * DF_HS + 4 * hh, DF_HS, DF_W / 16, 0, ws, tid,
+                                  hh * DF_HEAD + 32 * ct + li);
+        const int col = 32 * ct + li;
+        const float bv = bias[DF_D * DF_W + col];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int64_t p = p0 + 32 * rt + acc_row(q, hh);
+            if (p < a.n) {
+                const float v = hacc[0][0][q] + bv;
+                if (col < 48) a.d_sh[p * 48 + col] = v;
+                else if (col < 51) a.d_xyz[p * 3 + (col - 48)] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward walk: dz_l = dh_l * [act_l > 0], dh_{l-1} = dz_l W_l
+// ---------------------------------------------------------------------------------------------
+struct BwdArgs {
+    int64_t n, n_pad;
+    const float* packed;
+    const float* acts;      // [8][n_pad][256]
+    const float* g_dxyz; const float* g_dsh;
+    float* dz;              // [8][n_pad][256]
+    float* dzh;             // [n_pad][64]
+};
+
+constexpr size_t DF_BWD_LDS = (size_t)(DF_TILE * DF_HS + DF_TILE * DF_OS) * 4 + 2 * DF_CHUNK_F4 * 16;   // 116736
+
+__global__ __launch_bounds__(256) void k_deform_bwd(BwdArgs a)
+{
+    extern __shared__ float4 df_lds[];
+    float* gA = reinterpret_cast<float*>(df_lds);
+    float* oA = gA + DF_TILE * DF_HS;
+    WeightStream ws;
+    ws.lds = reinterpret_cast<float4*>(oA + DF_TILE * DF_OS);
+    ws.next = reinterpret_cast<const float4*>(a.packed + DF_B_BASE);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * DF_TILE;
+
+    // upstream gradients as the head's output tile: [d_sh (48) | d_xyz (3) | 0]
+    for (int q = tid; q < DF_TILE * DF_HEAD; q += 256) {
+        const int row = q >> 6, col = q & 63;
+        const int64_t p = p0 + row;
+        float v = 0.f;
+        if (p < a.n) {
+            if (col < 48) v = a.g_dsh ? a.g_dsh[p * 48 + col] : 0.f;
+            else if (col < 51) v = a.g_dxyz ? a.g_dxyz[p * 3 + (col - 48)] : 0.f;
+        }
+        oA[row * DF_OS + col] = v;
+        a.dzh[p * DF_HEAD + col] = v;
+    }
+    stream_prime(ws, tid, 4);
+
+    const int n0 = wave * 64;
+    const int b_off = hh * DF_W + n0 + li;
+    f32x16 acc[2][2];
+    float mask[2][2][16];
+    auto load_mask = [&](int l) {
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    mask[rt][ct][q] = a.acts[((int64_t)l * a.n_pad + p0 + 32 * rt + acc_row(q, hh)) * DF_W + n0 + 32 * ct + li];
+    };
+    load_mask(DF_D - 1);
+    zero_acc(acc);
+    run_chunks<2, 2, DF_W>(acc, oA + li * DF_OS + 4 * hh, DF_OS, DF_HEAD / 16, 4, ws, tid, b_off);   // dh_7
+    for (int l = DF_D - 1; l >= 0; l--) {
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int row = 32 * rt + acc_row(q, hh), col = n0 + 32 * ct + li;
+                    const float v = mask[rt][ct][q] > 0.f ? acc[rt][ct][q] : 0.f;
+                    if (l > 0) gA[row * DF_HS + col] = v;
+                    a.dz[((int64_t)l * a.n_pad + p0 + row) * DF_W + col] = v;
+                }
+        if (l == 0) break;
+        __syncthreads();
+        load_mask(l - 1);
+        zero_acc(acc);
+        run_chunks<2, 2, DF_W>(acc, gA + li * DF_HS + 4 * hh, DF_HS, DF_W / 16, l > 1 ? 4 : 0, ws, tid, b_off);   // dh_{l-1}
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight / bias gradients: dW[out][in] = sum over points of dz[p][out] * x[p][in], split over point
+// ranges; operands are read straight from global (lane = consecutive column: coalesced rows)
+// ---------------------------------------------------------------------------------------------
+constexpr int DW_JOBS = 10;
+// partial-sum block of one split (floats)
+constexpr int64_t DW_OFF_L0 = 0;                                         // [256][96]
+constexpr int64_t DW_OFF_L(int l) { return (int64_t)DF_W * DF_EMB + (int64_t)(l - 1) * DF_F_SZ; }   // l = 1..7: [256][256] (layer 5: hidden part)
+constexpr int64_t DW_OFF_L5E = (int64_t)DF_W * DF_EMB + 7 * DF_F_SZ;     // [256][96]
+constexpr int64_t DW_OFF_HEAD = DW_OFF_L5E + (int64_t)DF_W * DF_EMB;     // [64][256]
+constexpr int64_t DW_OFF_BIAS = DW_OFF_HEAD + (int64_t)DF_HEAD * DF_W;   // [8][256] + [64]
+constexpr int64_t DW_PART_FLOATS = DW_OFF_BIAS + DF_D * DF_W + DF_HEAD;
+
+struct DwArgs {
+    int64_t n_pad;
+    int tiles_per_split;    // 64-point tiles per split
+    const float* emb; const float* acts; const float* dz; const float* dzh;
+    float* part;            // [splits][DW_PART_FLOATS]
+};
+
+template <int WN, int WK, bool SPLIT_N, bool BIAS>
+__device__ __forceinline__ void dw_job(const float* A, int lda, const float* B, int ldb, float* out, int out_ld,
+                                       float* bias_out, int64_t p_begin, int64_t p_end, int wave, int li, int hh)
+{
+    const int n_base = SPLIT_N ? wave * WN * 32 : 0;
+    const int k_base = SPLIT_N ? 0 : wave * WK * 32;
+    f32x16 acc[WN][WK];
+    zero_acc(acc);
+    float bsum[WN];
+#pragma unroll
+    for (int x = 0; x < WN; x++) bsum[x] = 0.f;
+    const float* Ap = A + (p_begin + hh) * lda + n_base + li;
+    const float* Bp = B + (p_begin + hh) * ldb + k_base + li;
+    float av[2][4][WN], bv[2][4][WK];
+    auto fetch = [&](int slot) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#pragma unroll
+            for (int x = 0; x < WN; x++) av[slot][s][x] = Ap[(int64_t)2 * s * lda + 32 * x];
+#pragma unroll
+            for (int y = 0; y < WK; y++) bv[slot][s][y] = Bp[(int64_t)2 * s * ldb + 32 * y];
+        }
+        Ap += 8 * lda;
+        Bp += 8 * ldb;
+    };
+    auto mul = [&](int slot) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#pragma unroll
+            for (int x = 0; x < WN; x++) {
+                if (BIAS) bsum[x] += av[slot][s][x];
+#pragma unroll
+                for (int y = 0; y < WK; y++)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[slot][s][x], bv[slot][s][y], acc[x][y], 0, 0, 0);
+            }
+        }
+    };
+    // 8 points per step, 16 per loop trip (the ranges are multiples of 64), next step's operands in flight
+    if (p_begin < p_end) {
+        fetch(0);
+        for (int64_t p = p_begin; p < p_end; p += 16) {
+            fetch(1);
+            mul(0);
+            if (p + 16 < p_end) fetch(0);
+            mul(1);
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < WN; x++)
+#pragma unroll
+        for (int y = 0; y < WK; y++)
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                out[(int64_t)(n_base + 32 * x + acc_row(q, hh)) * out_ld + k_base + 32 * y + li] = acc[x][y][q];
+    if (BIAS && (SPLIT_N || wave == 0)) {
+#pragma unroll
+        for (int x = 0; x < WN; x++) {
+            const float tot = bsum[x] + __shfl_xor(bsum[x], 32);
+            if (hh == 0) bias_out[n_base + 32 * x + li] = tot;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_deform_dw(DwArgs a)
+{
+    const int job = blockIdx.x, split = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int64_t p_begin = (int64_t)split * a.tiles_per_split * DF_TILE;
+    int64_t p_end = p_begin + (int64_t)a.tiles_per_split * DF_TILE;
+    if (p_end > a.n_pad) p_end = a.n_pad;
+    float* part = a.part + (int64_t)split * DW_PART_FLOATS;
+    const int64_t plane = a.n_pad * DF_W;
+    if (job < 7) {
+        // hidden-input layers 7..1 (heaviest first): x = act_{l-1}
+        const int l = 7 - job;
+        dw_job<2, 8, true, true>(a.dz + l * plane, DF_W, a.acts + (l - 1) * plane, DF_W, part + DW_OFF_L(l), DF_W,
+                                 part + DW_OFF_BIAS + l * DF_W, p_begin, p_end, wave, li, hh);
+    } else if (job == 7) {
+        dw_job<2, 3, true, true>(a.dz, DF_W, a.emb, DF_EMB, part + DW_OFF_L0, DF_EMB, part + DW_OFF_BIAS, p_begin, p_end,
+                                 wave, li, hh);
+    } else if (job == 8) {
+        dw_job<2, 3, true, false>(a.dz + 5 * plane, DF_W, a.emb, DF_EMB, part + DW_OFF_L5E, DF_EMB, nullptr, p_begin, p_end,
+                                  wave, li, hh);
+    } else {
+        dw_job<2, 2, false, true>(a.dzh, DF_HEAD, a.acts + 7 * plane, DF_W, part + DW_OFF_HEAD, DF_W,
+                                  part + DW_OFF_BIAS + DF_D * DF_W, p_begin, p_end, wave, li, hh);
+    }
+}
+
+// sum of the splits, written in torch's layouts
+struct ReduceSeg {
+    float* dst;
+    int rows, cols, dst_ld, dst_col0;
+    int64_t src_off;
+    int src_ld, row_mul, row_add;     // source row = row * row_mul + row_add
+};
+constexpr int DF_MAX_SEGS = 32;
+struct ReduceArgs {
+    const float* part;
+    int splits, nseg;
+    ReduceSeg seg[DF_MAX_SEGS];
+};
+
+__global__ __launch_bounds__(256) void k_deform_reduce(ReduceArgs a)
+{
+    const ReduceSeg& sg = a.seg[blockIdx.y];
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)sg.rows * sg.cols) return;
+    const int row = (int)(e / sg.cols), col = (int)(e - (int64_t)row * sg.cols);
+    const float* src = a.part + sg.src_off + (int64_t)(row * sg.row_mul + sg.row_add) * sg.src_ld + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= a.splits; s += 4) {
+        s0 += src[(int64_t)s * DW_PART_FLOATS];
+        s1 += src[(int64_t)(s + 1) * DW_PART_FLOATS];
+        s2 += src[(int64_t)(s + 2) * DW_PART_FLOATS];
+        s3 += src[(int64_t)(s + 3) * DW_PART_FLOATS];
+    }
+    for (; s < a.splits; s++) s0 += src[(int64_t)s * DW_PART_FLOATS];
+    sg.dst[(int64_t)row * sg.dst_ld + sg.dst_col0 + col] = (s0 + s1) + (s2 + s3);
+}
+
+int64_t pad_points(int64_t n) { return (n + DF_TILE - 1) / DF_TILE * DF_TILE; }
+
+int dw_splits(int64_t n_pad, int* tiles_per_split)
+{
+    const int64_t tiles = n_pad / DF_TILE;
+    // 7 heavy jobs per split: 146 splits = 1022 workgroups = 4 per CU
+    int64_t splits = tiles / 4;
+    if (splits < 1) splits = 1;
+    if (splits > 146) splits = 146;
+    const int64_t tps = (tiles + splits - 1) / splits;
+    *tiles_per_split = (int)tps;
+    return (int)((tiles + tps - 1) / tps);
+}
+
+bool attrs_set = false;
+void set_attrs()
+{
+    if (attrs_set) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_BWD_LDS);
+    attrs_set = true;
+}
+
+}  // namespace
+
+extern "C" size_t gft_deform_packed_bytes(void) { return (size_t)DF_PACKED_FLOATS * sizeof(float); }
+
+extern "C" size_t gft_deform_saved_bytes(int64_t n)
+{
+    if (n <= 0) return 0;
+    return (size_t)pad_points(n) * (DF_EMB + DF_D * DF_W) * sizeof(float);
+}
+
+extern "C" size_t gft_deform_scratch_bytes(int64_t n)
+{
+    if (n <= 0) return 0;
+    const int64_t n_pad = pad_points(n);
+    int tps;
+    const int splits = dw_splits(n_pad, &tps);
+    return ((size_t)n_pad * (DF_D * DF_W + DF_HEAD) + (size_t)splits * DW_PART_FLOATS) * sizeof(float);
+}
+
+extern "C" int gft_deform_pack(void* hip_stream, const gft_deform_params* p, void* packed)
+{
+    if (!p || !packed) return gft_fail("gft_deform_pack: NULL argument");
+    for (int l = 0; l < DF_D; l++)
+        if (!p->linear_w[l] || !p->linear_b[l]) return gft_fail("gft_deform_pack: linear.%d parameters are NULL", l);
+    if (!p->xyz_w || !p->xyz_b || !p->r_w || !p->r_b || !p->g_w || !p->g_b || !p->b_w || !p->b_b)
+        return gft_fail("gft_deform_pack: head parameters are NULL");
+    PackArgs a;
+    a.p = *p;
+    a.out = (float*)packed;
+    hipLaunchKernelGGL(k_deform_pack, dim3((unsigned)((DF_PACKED_FLOATS + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, a);
+    GFT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gft_deform_forward(void* hip_stream, int64_t n, const float* xyz, const float* t, int64_t t_stride,
+                                  const void* packed, void* saved, float* d_xyz, float* d_sh)
+{
+    if (n < 0) return gft_fail("gft_deform_forward: n < 0");
+    if (n == 0) return 0;
+    if (!xyz || !t || !packed || !d_xyz || !d_sh) return gft_fail("gft_deform_forward: NULL argument");
+    if (t_stride != 0 && t_stride != 1) return gft_fail("gft_deform_forward: t_stride must be 0 or 1");
+    if (n > ((int64_t)1 << 31) * DF_TILE / 2) return gft_fail("gft_deform_forward: n too large");
+    set_attrs();
+    FwdArgs a;
+    a.n = n;
+    a.n_pad = pad_points(n);
+    a.t_stride = t_stride;
+    a.xyz = xyz;
+    a.t = t;
+    a.packed = (const float*)packed;
+    a.emb = (float*)saved;
+    a.acts = saved ? (float*)saved + a.n_pad * DF_EMB : nullptr;
+    a.d_xyz = d_xyz;
+    a.d_sh = d_sh;
+    const dim3 grid((unsigned)(a.n_pad / DF_TILE));
+    if (saved) hipLaunchKernelGGL(k_deform_fwd<true>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
+    else hipLaunchKernelGGL(k_deform_fwd<false>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
+    GFT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gft_deform_backward(void* hip_stream, int64_t n, const void* packed, const void* saved, const float* g_d_xyz,
+                                   const float* g_d_sh, void* scratch, const gft_deform_grads* g)
+{
+    if (n < 0) return gft_fail("gft_deform_backward: n < 0");
+    if (!g) return gft_fail("gft_deform_backward: grads is NULL");
+    for (int l = 0; l < DF_D; l++)
+        if (!g->linear_w[l] || !g->linear_b[l]) return gft_fail("gft_deform_backward: linear.%d gradient pointers are NULL", l);
+    if (!g->xyz_w || !g->xyz_b || !g->r_w || !g->r_b || !g->g_w || !g->g_b || !g->b_w || !g->b_b)
+        return gft_fail("gft_deform_backward: head gradient pointers are NULL");
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (n == 0) {
+        for (int l = 0; l < DF_D; l++) {
+            const size_t in = l == 0 ? DF_IN : l == 5 ? DF_W + DF_IN : DF_W;
+            GFT_CHECK_HIP(hipMemsetAsync(g->linear_w[l], 0, (size_t)DF_W * in * sizeof(float), s));
+            GFT_CHECK_HIP(hipMemsetAsync(g->linear_b[l], 0, DF_W * sizeof(float), s));
+        }
+        GFT_CHECK_HIP(hipMemsetAsync(g->xyz_w, 0, 3 * DF_W * sizeof(float), s));
+        GFT_CHECK_HIP(hipMemsetAsync(g->xyz_b, 0, 3 * sizeof(float), s));
+        float* hw[3] = {g->r_w, g->g_w, g->b_w};
+        float* hb[3] = {g->r_b, g->g_b, g->b_b};
+        for (int c = 0; c < 3; c++) {
+            GFT_CHECK_HIP(hipMemsetAsync(hw[c], 0, 16 * DF_W * sizeof(float), s));
+            GFT_CHECK_HIP(hipMemsetAsync(hb[c], 0, 16 * sizeof(float), s));
+        }
+        return 0;
+    }
+    if (!packed || !saved || !scratch) return gft_fail("gft_deform_backward: NULL argument");
+    set_attrs();
+    const int64_t n_pad = pad_points(n);
+    const float* emb = (const float*)saved;
+    const float* acts = emb + n_pad * DF_EMB;
+    float* dz = (float*)scratch;
+    float* dzh = dz + n_pad * DF_D * DF_W;
+    float* part = dzh + n_pad * DF_HEAD;
+    {
+        BwdArgs a;
+        a.n = n; a.n_pad = n_pad;
+        a.packed = (const float*)packed;
+        a.acts = acts;
+        a.g_dxyz = g_d_xyz; a.g_dsh = g_d_sh;
+        a.dz = dz; a.dzh = dzh;
+        hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(n_pad / DF_TILE)), dim3(256), DF_BWD_LDS, s, a);
+        GFT_CHECK_HIP(hipGetLastError());
+    }
+    int tps;
+    const int splits = dw_splits(n_pad, &tps);
+    {
+        DwArgs a;
+        a.n_pad = n_pad;
+        a.tiles_per_split = tps;
+        a.emb = emb; a.acts = acts; a.dz = dz; a.dzh = dzh;
+        a.part = part;
+        hipLaunchKernelGGL(k_deform_dw, dim3(DW_JOBS, splits), dim3(256), 0, s, a);
+        GFT_CHECK_HIP(hipGetLastError());
+    }
+    {
+        ReduceArgs a;
+        a.part = part;
+        a.splits = splits;
+        int k = 0;
+        auto seg = [&](float* dst, int rows, int cols, int dst_ld, int dst_col0, int64_t src_off, int src_ld, int mul, int add) {
+            ReduceSeg& sg = a.seg[k++];
+            sg.dst = dst; sg.rows = rows; sg.cols = cols; sg.dst_ld = dst_ld; sg.dst_col0 = dst_col0;
+            sg.src_off = src_off; sg.src_ld = src_ld; sg.row_mul = mul; sg.row_add = add;
+        };
+        seg(g->linear_w[0], DF_W, DF_IN, DF_IN, 0, DW_OFF_L0, DF_EMB, 1, 0);
+        for (int l = 1; l < DF_D; l++) {
+            if (l == 5) {
+                seg(g->linear_w[5], DF_W, DF_IN, DF_W + DF_IN, 0, DW_OFF_L5E, DF_EMB, 1, 0);
+                seg(g->linear_w[5], DF_W, DF_W, DF_W + DF_IN, DF_IN, DW_OFF_L(5), DF_W, 1, 0);
+            } else {
+                seg(g->linear_w[l], DF_W, DF_W, DF_W, 0, DW_OFF_L(l), DF_W, 1, 0);
+            }
+        }
+        for (int l = 0; l < DF_D; l++) seg(g->linear_b[l], 1, DF_W, DF_W, 0, DW_OFF_BIAS + l * DF_W, DF_W, 1, 0);
+        float* hw[3] = {g->r_w, g->g_w, g->b_w};
+        float* hb[3] = {g->r_b, g->g_b, g->b_b};
+        for (int c = 0; c < 3; c++) {
+            seg(hw[c], 16, DF_W, DF_W, 0, DW_OFF_HEAD, DF_W, 3, c);
+            // bias: a [16] vector gathered with stride 3 from the head's 64 column sums
+            seg(hb[c], 16, 1, 1, 0, DW_OFF_BIAS + DF_D * DF_W, 1, 3, c);
+        }
+        seg(g->xyz_w, 3, DF_W, DF_W, 0, DW_OFF_HEAD, DF_W, 1, 48);
+        seg(g->xyz_b, 3, 1, 1, 0, DW_OFF_BIAS + DF_D * DF_W, 1, 1, 48);
+        a.nseg = k;
+        hipLaunchKernelGGL(k_deform_reduce, dim3((DF_W * DF_W + 255) / 256, k), dim3(256), 0, s, a);
+        GFT_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
+}

@@ -1,0 +1,175 @@
+"""The deformation network on the gfx950 matrix cores.
+
+Host-side mirror of the reference's ``DeformNetwork`` (``utils/time_utils.py:56-127``): same
+constructor, same parameter names and shapes (a ``deform_model.pth`` written by the reference's
+``DeformModel.save`` loads with ``load_state_dict``, ``scene/deform_model.py:35-40``), same four
+results of ``forward(x, t)``:
+
+    d_xyz [n,3], zeros [n,4], d_sh [n,16,3], zeros [n,16,2]
+
+(the reference returns zeros for the rotation and phasor offsets, ``time_utils.py:127``, and its
+``rot`` / ``a`` heads never reach an output: their parameters exist here for the state_dict and,
+as under the reference's autograd, never receive a gradient).
+
+The arithmetic is done by hand-written fp32 MFMA kernels (``csrc/k_deform.hip``) behind the C ABI
+of ``include/gftorf_deform.h``; there is no CPU path and no torch GEMM in it.  Inputs are not
+differentiated: the reference passes detached positions (``scene/gaussian_model.py:172``).
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+
+_D, _W, _XYZ_MULTIRES, _T_MULTIRES, _SH_DEGREE = 8, 256, 10, 6, 3
+_IN = 3 + 6 * _XYZ_MULTIRES + 1 + 2 * _T_MULTIRES      # 76
+
+
+def _param_list(mod):
+    ps = []
+    for l in mod.linear:
+        ps += [l.weight, l.bias]
+    for h in (mod.xyz_warp, mod.r, mod.g, mod.b):
+        ps += [h.weight, h.bias]
+    return ps
+
+
+def _fill(struct, tensors):
+    """24 tensors in _param_list order -> gft_deform_params / gft_deform_grads."""
+    for i in range(_D):
+        struct.linear_w[i] = tensors[2 * i].data_ptr()
+        struct.linear_b[i] = tensors[2 * i + 1].data_ptr()
+    k = 2 * _D
+    (struct.xyz_w, struct.xyz_b, struct.r_w, struct.r_b, struct.g_w, struct.g_b, struct.b_w, struct.b_b) = [
+        t.data_ptr() for t in tensors[k:k + 8]]
+    return struct
+
+
+class _DeformFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t, *params):
+        lib = _lib.load()
+        dev = x.device
+        if dev.type != "cuda":
+            raise RuntimeError("gftorf_amd.DeformNetwork runs on a HIP device only (x is on %s); there is no CPU path" % (dev,))
+        if x.dim() != 2 or x.size(1) != 3:
+            raise RuntimeError("x must have dimensions (num_points, 3)")
+        n = x.size(0)
+        if t.numel() != n and t.numel() != 1:
+            raise RuntimeError("t must hold one value per point, got %s for %d points" % (tuple(t.shape), n))
+        x_c = x.detach().float().contiguous()
+        if t.numel() == 1 or (t.dim() >= 1 and t.stride(0) == 0):
+            t_c, t_stride = t.detach().float().reshape(-1)[:1].contiguous(), 0       # one time for all points
+        else:
+            t_c, t_stride = t.detach().float().reshape(-1).contiguous(), 1
+        if t_c.device != dev:
+            raise RuntimeError("t is on %s, expected %s" % (t_c.device, dev))
+        ps = []
+        for p in params:
+            if p.device != dev or p.dtype != torch.float32:
+                raise RuntimeError("DeformNetwork parameters must be float32 on %s" % (dev,))
+            ps.append(p.detach().contiguous())
+        need_bw = any(ctx.needs_input_grad[2:])      # all False under torch.no_grad()
+        f32 = dict(device=dev, dtype=torch.float32)
+        packed = torch.empty((lib.gft_deform_packed_bytes() // 4,), **f32)
+        d_xyz = torch.empty((n, 3), **f32)
+        d_sh = torch.empty((n, 16, 3), **f32)
+        saved = torch.empty((lib.gft_deform_saved_bytes(n) // 4,), **f32) if (need_bw and n > 0) else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(lib.gft_deform_pack(stream, C.byref(_fill(_lib.DeformParams(), ps)), packed.data_ptr()))
+            _lib.check(lib.gft_deform_forward(stream, n, x_c.data_ptr() if n else None, t_c.data_ptr() if n else None,
+                                              t_stride, packed.data_ptr(), saved.data_ptr() if saved is not None else None,
+                                              d_xyz.data_ptr() if n else None, d_sh.data_ptr() if n else None))
+        ctx.n = n
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.save_for_backward(packed, saved if saved is not None else packed.new_empty(0))
+        ctx.set_materialize_grads(False)
+        return d_xyz, d_sh
+
+    @staticmethod
+    def backward(ctx, g_dxyz, g_dsh):
+        lib = _lib.load()
+        packed, saved = ctx.saved_tensors
+        dev = packed.device
+        n = ctx.n
+        if n > 0 and saved.numel() == 0:
+            raise RuntimeError("DeformNetwork: backward through a forward that ran without gradients")
+        f32 = dict(device=dev, dtype=torch.float32)
+        grads = [torch.empty(s, **f32) for s in ctx.shapes]
+        gx = g_dxyz.float().contiguous() if g_dxyz is not None else None
+        gs = g_dsh.float().contiguous() if g_dsh is not None else None
+        scratch = torch.empty((lib.gft_deform_scratch_bytes(n) // 4,), **f32)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(lib.gft_deform_backward(stream, n, packed.data_ptr(), saved.data_ptr() if n else None,
+                                               gx.data_ptr() if (gx is not None and n) else None,
+                                               gs.data_ptr() if (gs is not None and n) else None,
+                                               scratch.data_ptr() if n else None,
+                                               C.byref(_fill(_lib.DeformParams(), grads))))
+        return (None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[2:]))
+
+
+class DeformNetwork(nn.Module):
+    """Drop-in for ``utils.time_utils.DeformNetwork`` (time_utils.py:56-127)."""
+
+    def __init__(self, D=8, W=256, xyz_multires=10, t_multires=6, sh_degree=3):
+        super().__init__()
+        if (D, W, xyz_multires, t_multires, sh_degree) != (_D, _W, _XYZ_MULTIRES, _T_MULTIRES, _SH_DEGREE):
+            raise NotImplementedError(
+                "gftorf_amd.DeformNetwork is built for the reference's default architecture "
+                "(D=8, W=256, xyz_multires=10, t_multires=6, sh_degree=3); got %s" % ((D, W, xyz_multires, t_multires, sh_degree),))
+        self.D, self.W = D, W
+        self.xyz_multires, self.t_multires = xyz_multires, t_multires
+        self.skips = [D // 2]
+        self.xyz_input_ch, self.t_input_ch = 3 + 6 * xyz_multires, 1 + 2 * t_multires
+        self.num_shs = (1 + sh_degree) ** 2
+        # layer i + 1 takes the re-injected encoding when i is a skip (time_utils.py:69-73)
+        widths = [_IN] + [W + _IN if i in self.skips else W for i in range(D - 1)]
+        self.linear = nn.ModuleList([nn.Linear(w_in, W) for w_in in widths])
+        self.xyz_warp = nn.Linear(W, 3)
+        self.rot = nn.Linear(W, 4)
+        self.r = nn.Linear(W, self.num_shs)
+        self.g = nn.Linear(W, self.num_shs)
+        self.b = nn.Linear(W, self.num_shs)
+        self.a = nn.Linear(W, self.num_shs)
+        self.isotropic = False
+
+    def initialize_weights(self, args):
+        """time_utils.py:83-101: Xavier-normal trunk with zero biases, heads N(0, 1e-5) (``xyz_warp``
+        Xavier-normal instead when ``args.xavier_init_dxyz``)."""
+        self.isotropic = args.isotropic_gaussians
+        for l in self.linear:
+            nn.init.xavier_normal_(l.weight)
+            nn.init.constant_(l.bias, 0.0)
+        if args.xavier_init_dxyz:
+            nn.init.xavier_normal_(self.xyz_warp.weight)
+        else:
+            nn.init.normal_(self.xyz_warp.weight, mean=0.0, std=1e-5)
+        nn.init.constant_(self.xyz_warp.bias, 0.0)
+        for head in (self.rot, self.r, self.g, self.b, self.a):
+            nn.init.normal_(head.weight, mean=0.0, std=1e-5)
+            nn.init.constant_(head.bias, 0.0)
+
+    def forward(self, x, t):
+        d_xyz, d_sh = _DeformFn.apply(x, t, *_param_list(self))
+        n = x.size(0)
+        zeros = lambda *shape: torch.zeros(shape, device=x.device, dtype=torch.float32)
+        return d_xyz, zeros(n, 4), d_sh, zeros(n, self.num_shs, 2)
+
+
+def flat_grad_bucket(module):
+    """The gradients of the parameters that receive one, as ONE flat fp32 tensor (517 959 - 5 140 unused
+    head values = 512 819 elements, 2.05 MB) plus the function that scatters a (reduced) bucket back:
+    the unit of the data-parallel all-reduce over RCCL."""
+    ps = [p for p in _param_list(module) if p.grad is not None]
+    flat = torch.cat([p.grad.reshape(-1) for p in ps]) if ps else torch.empty(0)
+
+    def scatter_back(bucket):
+        o = 0
+        for p in ps:
+            k = p.numel()
+            p.grad.copy_(bucket[o:o + k].view_as(p.grad))
+            o += k
+    return flat, scatter_back

@@ -1,0 +1,87 @@
+/*
+ * gftorf_deform.h -- C ABI of the deformation network of libgftorf_rast.so (gfx950).
+ *
+ * `DeformNetwork` of the reference (utils/time_utils.py:56-127),
+ * queried 1-4 times per training iteration for the dynamic Gaussians
+ * (scene/gaussian_model.py:170-174, train.py:164-177): positional encoding of (xyz, t)
+ * (10 and 6 octaves, 76 inputs), 8 x (Linear + ReLU) of width 256 with the encoding
+ * concatenated in front of the activations after layer 4, heads `xyz_warp` (3) and
+ * `r`/`g`/`b` (16 each).  The reference returns zeros for the rotation and phasor offsets
+ * (time_utils.py:127) and never uses its `rot` / `a` heads; those are not computed here.
+ *
+ * This is the one GEMM-shaped piece of the path: the kernels run on the fp32 matrix cores
+ * (`v_mfma_f32_32x32x2_f32`: fp32 operands, fp32 accumulation, a k-ordered fma chain per output),
+ * so results are fp32 like the reference's torch modules (no reduced-precision operands).
+ *
+ *   forward : one workgroup per 64 points walks all layers with the activations in LDS
+ *             (weights streamed from L2), saving the post-ReLU activations for the backward
+ *   backward: the same walk in reverse for the activation gradients, then the weight / bias
+ *             gradients as point-split GEMMs (partial sums + one reduction: deterministic)
+ *
+ * Only the reference's default architecture (D = 8, W = 256, xyz_multires = 10,
+ * t_multires = 6, sh_degree = 3; arguments/__init__.py) is built.  All pointers are device
+ * pointers to fp32; every function returns 0 on success (gft_last_error()).  Inputs are not
+ * differentiated (the reference detaches them, scene/gaussian_model.py:172).
+ */
+#ifndef GFTORF_DEFORM_H
+#define GFTORF_DEFORM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFT_DEFORM_LAYERS 8
+#define GFT_DEFORM_WIDTH 256
+#define GFT_DEFORM_INPUTS 76     /* 63 (xyz) + 13 (t) encoded inputs */
+#define GFT_DEFORM_NUM_SHS 16
+
+/* Parameters in torch's layout (`nn.Linear.weight` = [out, in] row-major), state_dict names in
+ * the comments.  linear_w[0] is [256,76], linear_w[5] is [256,332] (encoding first), the others
+ * [256,256]. */
+typedef struct gft_deform_params {
+    const float* linear_w[GFT_DEFORM_LAYERS];   /* linear.{i}.weight */
+    const float* linear_b[GFT_DEFORM_LAYERS];   /* linear.{i}.bias   [256] */
+    const float* xyz_w;                         /* xyz_warp.weight   [3,256] */
+    const float* xyz_b;                         /* xyz_warp.bias     [3] */
+    const float* r_w; const float* r_b;         /* r.weight [16,256], r.bias [16] */
+    const float* g_w; const float* g_b;
+    const float* b_w; const float* b_b;
+} gft_deform_params;
+
+/* Gradients, same shapes; every tensor is written in full (nothing has to be zeroed). */
+typedef struct gft_deform_grads {
+    float* linear_w[GFT_DEFORM_LAYERS];
+    float* linear_b[GFT_DEFORM_LAYERS];
+    float* xyz_w; float* xyz_b;
+    float* r_w; float* r_b;
+    float* g_w; float* g_b;
+    float* b_w; float* b_b;
+} gft_deform_grads;
+
+/* Sizes of the caller-owned buffers. */
+size_t gft_deform_packed_bytes(void);            /* weights re-laid for the kernels */
+size_t gft_deform_saved_bytes(int64_t n);        /* forward -> backward hand-off (encoding + 8 activations) */
+size_t gft_deform_scratch_bytes(int64_t n);      /* backward scratch */
+
+/* Re-lays the parameters for the matrix-core kernels (k-interleaved, both directions, biases).
+ * Call after every parameter update, before forward / backward. */
+int gft_deform_pack(void* hip_stream, const gft_deform_params* params, void* packed);
+
+/* d_xyz[n,3], d_sh[n,16,3] for xyz[n,3] and t (t_stride = 1: one value per point, [n,1];
+ * t_stride = 0: one value for all points, as scene/gaussian_model.py:171 expands it).
+ * saved = NULL: inference, nothing is kept for a backward. */
+int gft_deform_forward(void* hip_stream, int64_t n, const float* xyz, const float* t, int64_t t_stride,
+                       const void* packed, void* saved, float* d_xyz, float* d_sh);
+
+/* Gradients of the parameters for upstream gradients g_d_xyz[n,3] and g_d_sh[n,16,3]
+ * (either may be NULL = zeros).  `packed` and `saved` as the forward left them. */
+int gft_deform_backward(void* hip_stream, int64_t n, const void* packed, const void* saved, const float* g_d_xyz,
+                        const float* g_d_sh, void* scratch, const gft_deform_grads* grads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -88,6 +88,21 @@ def _trunk(params, x, t, dtype):
     return emb, inputs, outs, h
 
 
+def relu_margin(params, x, t):
+    """Per point, the smallest |pre-activation| over all 8 x 256 units (float64).  The gradient is
+    discontinuous where a pre-activation crosses zero, so comparisons of gradients between two
+    arithmetics leave out the points whose margin is within rounding distance of that edge."""
+    emb = embed(x, t, np.float64)
+    h = emb
+    margin = np.full(emb.shape[0], np.inf)
+    for i in range(D):
+        z = h @ params["linear.%d.weight" % i].astype(np.float64).T + params["linear.%d.bias" % i].astype(np.float64)
+        margin = np.minimum(margin, np.abs(z).min(axis=1))
+        a = np.maximum(z, 0)
+        h = np.concatenate([emb, a], axis=-1) if i == SKIP else a
+    return margin
+
+
 def forward(params, x, t, dtype=np.float32):
     """Returns (d_xyz[n,3], d_rot[n,4] = 0, d_sh[n,16,3], d_sh_p[n,16,2] = 0) (time_utils.py:115-127)."""
     _, _, _, h = _trunk(params, x, t, dtype)

@@ -60,6 +60,7 @@ def deform_fixture():
         else:
             out["grad_s:" + name] = p.grad.numpy()[::8, ::4]   # strided sample of a [256, in] matrix
     out["grad_none"] = np.array(none)
+    out["param_names"] = np.array(list(net.state_dict().keys()))
     np.savez(os.path.join(HERE, "deform.npz"), **out)
 
 

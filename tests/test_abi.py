@@ -24,7 +24,7 @@ def lib():
 
 
 HEADERS = [HEADER, os.path.join(ROOT, "include", "gftorf_assemble.h"), os.path.join(ROOT, "include", "gftorf_knn.h"),
-           os.path.join(ROOT, "include", "gftorf_optim.h")]
+           os.path.join(ROOT, "include", "gftorf_optim.h"), os.path.join(ROOT, "include", "gftorf_deform.h")]
 
 
 def declared_functions():
@@ -52,9 +52,10 @@ def test_header_is_plain_c_and_matches_ctypes(tmp_path, lib):
               "gft_forward_io": _lib.FORWARD_FIELDS, "gft_backward_io": _lib.BACKWARD_FIELDS,
               "gft_layout": _lib.LAYOUT_FIELDS,
               "gft_profile": _lib.PROFILE_FIELDS + ["forward_calls", "backward_calls"],
-              "gft_assemble_io": _lib.ASSEMBLE_FIELDS, "gft_assemble_bwd_io": _lib.ASSEMBLE_BWD_FIELDS}
+              "gft_assemble_io": _lib.ASSEMBLE_FIELDS, "gft_assemble_bwd_io": _lib.ASSEMBLE_BWD_FIELDS,
+              "gft_deform_params": _lib.DEFORM_FIELDS, "gft_deform_grads": _lib.DEFORM_FIELDS}
     body = ['#include <stdio.h>', '#include <stddef.h>', '#include "gftorf_rast.h"', '#include "gftorf_assemble.h"',
-            'int main(void){']
+            '#include "gftorf_deform.h"', 'int main(void){']
     for s, fl in fields.items():
         body.append('printf("%s %%zu\\n", sizeof(%s));' % (s, s))
         for f in fl:
@@ -66,7 +67,8 @@ def test_header_is_plain_c_and_matches_ctypes(tmp_path, lib):
     out = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
     mirrors = {"gft_config": _lib.Config, "gft_forward_io": _lib.ForwardIO, "gft_backward_io": _lib.BackwardIO,
                "gft_layout": _lib.Layout, "gft_profile": _lib.Profile,
-               "gft_assemble_io": _lib.AssembleIO, "gft_assemble_bwd_io": _lib.AssembleBwdIO}
+               "gft_assemble_io": _lib.AssembleIO, "gft_assemble_bwd_io": _lib.AssembleBwdIO,
+               "gft_deform_params": _lib.DeformParams, "gft_deform_grads": _lib.DeformParams}
     for s, cls in mirrors.items():
         assert int(out[s]) == C.sizeof(cls), s
         for f in fields[s]:
@@ -157,3 +159,20 @@ def test_bench_refuses_to_run_without_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "HIP device" in (r.stderr + r.stdout)
+
+
+def test_deform_size_queries_and_argument_errors(lib):
+    from gftorf_amd import _lib
+    # 20480 + 6*65536 + 86016 + 16384 forward, 16384 + 7*65536 backward, 2112 biases
+    assert lib.gft_deform_packed_bytes() == 993344 * 4
+    assert lib.gft_deform_saved_bytes(0) == 0 and lib.gft_deform_scratch_bytes(0) == 0
+    # per point (padded to 64): 96 encoding + 8*256 activations
+    assert lib.gft_deform_saved_bytes(1) == 64 * (96 + 2048) * 4
+    assert lib.gft_deform_saved_bytes(65) == 128 * (96 + 2048) * 4
+    assert lib.gft_deform_scratch_bytes(1000) > 1024 * (2048 + 64) * 4
+    assert lib.gft_deform_pack(None, None, None) != 0
+    assert "NULL" in _lib.last_error()
+    assert lib.gft_deform_forward(None, -1, None, None, 1, None, None, None, None) != 0
+    assert lib.gft_deform_forward(None, 0, None, None, 1, None, None, None, None) == 0      # nothing to do
+    assert lib.gft_deform_forward(None, 5, None, None, 1, None, None, None, None) != 0
+    assert lib.gft_deform_backward(None, 5, None, None, None, None, None, None) != 0

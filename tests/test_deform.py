@@ -67,3 +67,167 @@ def test_embedding_layout():
     assert e[0, 63] == t[0, 0]
     np.testing.assert_array_equal(e[0, 64:66], [np.sin(t[0, 0]), np.cos(t[0, 0])])
     np.testing.assert_array_equal(e[0, 74:76], [np.sin(t[0, 0] * np.float32(32)), np.cos(t[0, 0] * np.float32(32))])
+
+
+def test_module_mirrors_reference_state_dict():
+    from gftorf_amd.deform import DeformNetwork
+    net = DeformNetwork()
+    sd = net.state_dict()
+    shapes = deform_ref.param_shapes()
+    assert list(sd.keys()) == list(np.load(GOLDEN)["param_names"])      # names and ORDER of the reference's module
+    assert {k: tuple(v.shape) for k, v in sd.items()} == shapes
+    assert sum(v.numel() for v in sd.values()) == 517959              # (SURVEY section 8(e) quotes 522 055; the module holds 517 959)
+    with pytest.raises(NotImplementedError):
+        DeformNetwork(W=128)
+
+
+def test_product_fails_loudly_without_a_device():
+    from gftorf_amd.deform import DeformNetwork
+    net = DeformNetwork()
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        net(torch.zeros(4, 3), torch.zeros(4, 1))
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU: the HIP path (through the C ABI) against the oracle
+# ---------------------------------------------------------------------------------------------
+def _net(seed, dev):
+    from gftorf_amd.deform import DeformNetwork
+    params = deform_ref.random_params(seed)
+    net = DeformNetwork()
+    net.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    return net.to(dev), params
+
+
+def _inputs(n, seed, shared_t):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, 3)).astype(np.float32)
+    t = np.full((n, 1), rng.random(), np.float32) if shared_t else rng.random((n, 1)).astype(np.float32)
+    return x, t
+
+
+FWD_TOL = 3e-6      # of the max-norm, fp32 sums of 76..332 products per layer against float64
+BWD_TOL = 2e-5      # weight gradients are sums over all points as well
+
+
+@pytest.mark.gpu
+def test_forward_matches_reference_golden_vectors():
+    dev = torch.device("cuda:0")
+    g = np.load(GOLDEN)
+    net, _ = _net(int(g["seed"]), dev)
+    with torch.no_grad():
+        d_xyz, d_rot, d_sh, d_sh_p = net(torch.tensor(g["x"], device=dev), torch.tensor(g["t"], device=dev))
+    assert _rel(d_xyz.cpu().numpy(), g["d_xyz"]) < FWD_TOL
+    assert _rel(d_sh.cpu().numpy(), g["d_sh"]) < FWD_TOL
+    assert d_rot.shape == g["d_rot"].shape and not d_rot.any()
+    assert d_sh_p.shape == g["d_sh_p"].shape and not d_sh_p.any()
+
+
+@pytest.mark.gpu
+def test_backward_matches_reference_golden_vectors():
+    dev = torch.device("cuda:0")
+    g = np.load(GOLDEN)
+    net, _ = _net(int(g["seed"]), dev)
+    d_xyz, _, d_sh, _ = net(torch.tensor(g["x"], device=dev), torch.tensor(g["t"], device=dev))
+    ((d_xyz * torch.tensor(g["g_dxyz"], device=dev)).sum() + (d_sh * torch.tensor(g["g_dsh"], device=dev)).sum()).backward()
+    grads = {k: p.grad for k, p in net.named_parameters()}
+    assert sorted(k for k, v in grads.items() if v is None) == sorted(g["grad_none"].tolist())
+    for key in g.files:
+        if key.startswith("grad:"):
+            assert _rel(grads[key[5:]].cpu().numpy(), g[key]) < BWD_TOL, key
+        elif key.startswith("grad_s:"):
+            assert _rel(grads[key[7:]].cpu().numpy()[::8, ::4], g[key]) < BWD_TOL, key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,shared_t", [(1, False), (63, True), (64, False), (65, True), (1000, False), (5000, True)])
+def test_forward_against_oracle(n, shared_t):
+    dev = torch.device("cuda:0")
+    net, params = _net(11, dev)
+    x, t = _inputs(n, 100 + n, shared_t)
+    tt = torch.tensor(t[:1], device=dev).expand(n, -1) if shared_t else torch.tensor(t, device=dev)   # gaussian_model.py:171
+    with torch.no_grad():
+        d_xyz, d_rot, d_sh, d_sh_p = net(torch.tensor(x, device=dev), tt)
+    ref = deform_ref.forward(params, x, t, dtype=np.float64)
+    assert d_xyz.shape == (n, 3) and d_sh.shape == (n, 16, 3) and d_rot.shape == (n, 4) and d_sh_p.shape == (n, 16, 2)
+    assert _rel(d_xyz.cpu().numpy(), ref[0]) < FWD_TOL
+    assert _rel(d_sh.cpu().numpy(), ref[2]) < FWD_TOL
+    # the float32 oracle is no closer to float64 than the device is, within a small factor
+    o32 = deform_ref.forward(params, x, t)
+    assert _rel(d_sh.cpu().numpy(), ref[2]) < 4 * max(_rel(o32[2], ref[2]), 2e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [48, 333, 5000])
+def test_backward_against_oracle(n):
+    dev = torch.device("cuda:0")
+    net, params = _net(12, dev)
+    x, t = _inputs(n + n // 8, 200 + n, False)
+    # a ReLU whose input is within rounding of zero may switch differently in fp32 and in float64 and
+    # changes the gradient by a finite amount: keep the n points that are furthest from such an edge
+    keep = np.sort(np.argsort(-deform_ref.relu_margin(params, x, t))[:n])
+    assert deform_ref.relu_margin(params, x, t)[keep].min() > 1e-6
+    x, t = x[keep], t[keep]
+    rng = np.random.default_rng(n)
+    g_dxyz, g_dsh = rng.normal(size=(n, 3)).astype(np.float32), rng.normal(size=(n, 16, 3)).astype(np.float32)
+    d_xyz, _, d_sh, _ = net(torch.tensor(x, device=dev), torch.tensor(t, device=dev))
+    ((d_xyz * torch.tensor(g_dxyz, device=dev)).sum() + (d_sh * torch.tensor(g_dsh, device=dev)).sum()).backward()
+    ref = deform_ref.backward(params, x, t, g_dxyz, g_dsh, dtype=np.float64)
+    for name, p in net.named_parameters():
+        if ref[name] is None:
+            assert p.grad is None, name
+        else:
+            assert p.grad.shape == p.shape
+            assert _rel(p.grad.cpu().numpy(), ref[name]) < BWD_TOL, name
+
+
+@pytest.mark.gpu
+def test_backward_with_one_output_unused_and_accumulation():
+    dev = torch.device("cuda:0")
+    net, params = _net(13, dev)
+    n = 200
+    x, t = _inputs(n, 7, True)
+    xs, ts = torch.tensor(x, device=dev), torch.tensor(t, device=dev)
+    g_dxyz = np.random.default_rng(1).normal(size=(n, 3)).astype(np.float32)
+    # only d_xyz reaches the loss (train.py:171-176 queries discard the other results)
+    d_xyz, _, _, _ = net(xs, ts)
+    (d_xyz * torch.tensor(g_dxyz, device=dev)).sum().backward()
+    ref = deform_ref.backward(params, x, t, g_dxyz, np.zeros((n, 16, 3), np.float32), dtype=np.float64)
+    assert _rel(net.linear[3].weight.grad.cpu().numpy(), ref["linear.3.weight"]) < BWD_TOL
+    assert _rel(net.xyz_warp.weight.grad.cpu().numpy(), ref["xyz_warp.weight"]) < BWD_TOL
+    assert not net.r.weight.grad.any() and not net.b.bias.grad.any()
+    # a second query accumulates into .grad like any autograd op (2-4 queries per iteration)
+    first = net.linear[3].weight.grad.clone()
+    d_xyz, _, _, _ = net(xs, ts)
+    (d_xyz * torch.tensor(g_dxyz, device=dev)).sum().backward()
+    torch.testing.assert_close(net.linear[3].weight.grad, 2 * first, rtol=1e-6, atol=0)
+
+
+@pytest.mark.gpu
+def test_inference_path_and_determinism():
+    dev = torch.device("cuda:0")
+    net, _ = _net(14, dev)
+    x, t = _inputs(777, 3, False)
+    xs, ts = torch.tensor(x, device=dev), torch.tensor(t, device=dev)
+    with torch.no_grad():
+        a = net(xs, ts)
+    b = net(xs, ts)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])      # saving activations changes no result
+    g = torch.ones_like(b[2])
+    b[2].backward(g)
+    g1 = [p.grad.clone() for p in net.parameters() if p.grad is not None]
+    net.zero_grad()
+    c = net(xs, ts)
+    c[2].backward(g)
+    g2 = [p.grad for p in net.parameters() if p.grad is not None]
+    assert all(torch.equal(u, v) for u, v in zip(g1, g2))           # split sums + one reduction: no atomics
+
+
+@pytest.mark.gpu
+def test_zero_points():
+    dev = torch.device("cuda:0")
+    net, _ = _net(15, dev)
+    d_xyz, d_rot, d_sh, d_sh_p = net(torch.zeros((0, 3), device=dev), torch.zeros((0, 1), device=dev))
+    assert d_xyz.shape == (0, 3) and d_sh.shape == (0, 16, 3) and d_rot.shape == (0, 4) and d_sh_p.shape == (0, 16, 2)
+    (d_xyz.sum() + d_sh.sum()).backward()
+    assert not net.linear[0].weight.grad.any() and not net.r.bias.grad.any()
