@@ -236,6 +236,70 @@ def assemble_extra(dev, P=1_000_000, frac=0.3, M=16, steps=20, warmup=5):
             "frac_of_hbm_peak": bytes_alg / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 in / fp32 accumulate
+
+
+def deform_extra(dev, n=300_000, steps=10, warmup=3):
+    """SURVEY 8(f) row 2 beside the headline metric: one query of the deformation network for the dynamic
+    Gaussians of the metric frame (30 % of 1 M), forward + backward, against the eager-torch statements
+    of the reference's module (utils/time_utils.py:103-127, restated in oracle/deform_ref.py) on the same
+    device.  Algorithmic multiply-adds per point: forward 76*256 + 6*256*256 + 332*256 + 51*256 = 510 720;
+    backward 7*256*256 + 51*256 (activation gradients) + 510 720 (weight gradients)."""
+    import numpy as np
+    import torch
+    from gftorf_amd import DeformNetwork, _lib
+    from oracle import deform_ref
+    params = deform_ref.random_params(3)
+    net = DeformNetwork()
+    net.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    net = net.to(dev)
+    pt = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in params.items()}
+    rng = np.random.default_rng(4)
+    x = torch.tensor(rng.random((n, 3)).astype(np.float32), device=dev)
+    t = torch.full((1, 1), 0.4, device=dev).expand(n, -1)          # scene/gaussian_model.py:171
+    g_dxyz, g_dsh = torch.randn((n, 3), device=dev), torch.randn((n, 16, 3), device=dev)
+
+    def ours():
+        d_xyz, _, d_sh, _ = net(x, t)
+        torch.autograd.backward([d_xyz, d_sh], [g_dxyz, g_dsh])
+        net.zero_grad(set_to_none=True)
+
+    def ours_fwd():
+        with torch.no_grad():
+            net(x, t)
+
+    def eager():
+        d_xyz, _, d_sh, _ = deform_ref.deform_eager(pt, x, t)
+        torch.autograd.backward([d_xyz, d_sh], [g_dxyz, g_dsh])
+        for p in pt.values():
+            p.grad = None
+
+    def timed(fn, k, w):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(k):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / k
+
+    ms = timed(ours, steps, warmup)
+    fwd_ms = timed(ours_fwd, steps, warmup)
+    eager_ms = timed(eager, max(3, steps // 2), 2)
+    macs_fwd = 76 * 256 + 6 * 256 * 256 + 332 * 256 + 51 * 256
+    macs = macs_fwd + (7 * 256 * 256 + 51 * 256) + macs_fwd
+    tf = 2.0 * macs * n / (ms * 1e-3) / 1e12
+    tf_fwd = 2.0 * macs_fwd * n / (fwd_ms * 1e-3) / 1e12
+    return {"what": "deformation network fwd+bwd (SURVEY 8(f)#2), %d points, fp32 MFMA" % n,
+            "fwd_bwd_ms": ms, "inference_fwd_ms": fwd_ms, "eager_torch_ms": eager_ms, "speedup_vs_eager": eager_ms / ms,
+            "algorithmic_flops": 2.0 * macs * n, "achieved_TFLOPs": tf, "inference_TFLOPs": tf_fwd,
+            "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS,
+            "inference_frac_of_peak": tf_fwd / FP32_MFMA_PEAK_TFLOPS}
+
+
 def knn_extra(dev, P=1_000_000):
     """SURVEY 8(f) row 3 beside the headline metric: distCUDA2 (mean squared distance to the 3
     nearest neighbours, the scale initialisation of scene/gaussian_model.py:194-199) on a
@@ -398,7 +462,7 @@ def main():
             del state, step
             torch.cuda.empty_cache()
             out["extras"] = {"assemble_inputs": assemble_extra(dev), "knn": knn_extra(dev),
-                             "adam": adam_extra(dev)}
+                             "adam": adam_extra(dev), "deform_network": deform_extra(dev)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, budget_s=args.cpu_budget)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]

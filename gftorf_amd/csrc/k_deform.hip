@@ -10,6 +10,9 @@
 #include "gft_internal.h"
 #include "gftorf_deform.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -22,26 +25,17 @@ constexpr int DF_EMB = 96;                 // stored encoding row (3 column tile
 constexpr int DF_HEAD = 64;                // head columns: 48 (d_sh, [coefficient][channel]) + 3 (d_xyz) + pad
 constexpr int DF_TILE = 64;                // points per workgroup
 constexpr int DF_HS = 260;                 // LDS row strides (floats): 16-byte reads of 16 rows hit 16 bank groups
-constexpr int DF_ES = 84;
-constexpr int DF_OS = 68;
-constexpr int DF_CHUNK_F4 = 1024;          // one 16-k x 256-column weight chunk, in float4
 
 // packed parameter buffer (floats): forward stream, backward stream, biases
 constexpr int64_t DF_F_SZ0 = (int64_t)DF_INK * DF_W;                  // 20480
 constexpr int64_t DF_F_SZ = (int64_t)DF_W * DF_W;                     // 65536
-constexpr int64_t DF_F_SZ5 = DF_F_SZ0 + DF_F_SZ;                      // 86016
 constexpr int64_t DF_F_HEAD_SZ = (int64_t)DF_W * DF_HEAD;             // 16384
-constexpr int64_t DF_F_TOTAL = DF_F_SZ0 + 6 * DF_F_SZ + DF_F_SZ5 + DF_F_HEAD_SZ;   // 516096
+// forward stream, in the order it is used: L0 | L5 (encoding rows) | L1 L2 L3 L4 | L5 (hidden rows) | L6 | L7 | heads
+constexpr int64_t DF_F_TOTAL = 2 * DF_F_SZ0 + 7 * DF_F_SZ + DF_F_HEAD_SZ;   // 516096
 constexpr int64_t DF_B_BASE = DF_F_TOTAL;
 constexpr int64_t DF_B_TOTAL = DF_F_HEAD_SZ + 7 * DF_F_SZ;            // 475136
 constexpr int64_t DF_BIAS_BASE = DF_B_BASE + DF_B_TOTAL;              // 991232
 constexpr int64_t DF_PACKED_FLOATS = DF_BIAS_BASE + DF_D * DF_W + DF_HEAD;   // 993344
-
-__host__ __device__ constexpr int64_t df_fwd_offset(int l)
-{
-    return l == 0 ? 0 : l <= 5 ? DF_F_SZ0 + (int64_t)(l - 1) * DF_F_SZ : l <= 7 ? DF_F_SZ0 + 4 * DF_F_SZ + DF_F_SZ5 + (int64_t)(l - 6) * DF_F_SZ
-                                                                                : DF_F_TOTAL - DF_F_HEAD_SZ;
-}
 
 // ---------------------------------------------------------------------------------------------
 // pack
@@ -75,24 +69,25 @@ __global__ __launch_bounds__(256) void k_deform_pack(PackArgs a)
     if (e >= DF_PACKED_FLOATS) return;
     float v = 0.f;
     if (e < DF_F_TOTAL) {
-        // forward stream: per layer [k/4][ncol][4], element (k, n) = W[n][k]
-        int l = 8;
-        for (int q = 0; q < 8; q++)
-            if (e < df_fwd_offset(q + 1)) { l = q; break; }
-        const int64_t r = e - df_fwd_offset(l);
-        const int ncol = l == 8 ? DF_HEAD : DF_W;
-        const int kq = (int)(r / (ncol * 4)), n = (int)((r >> 2) % ncol), k = 4 * kq + (int)(r & 3);
-        if (l == 8) {
+        // forward stream: per segment [k/4][ncol][4], element (k, n) = W[n][k]
+        if (e < 2 * DF_F_SZ0) {
+            const int l = e < DF_F_SZ0 ? 0 : 5;
+            const int64_t r = e < DF_F_SZ0 ? e : e - DF_F_SZ0;
+            const int kq = (int)(r / (DF_W * 4)), n = (int)((r >> 2) % DF_W), k = 4 * kq + (int)(r & 3);
+            const int ld = l == 0 ? DF_IN : DF_W + DF_IN;
+            v = k < DF_IN ? a.p.linear_w[l][(size_t)n * ld + k] : 0.f;
+        } else if (e < DF_F_TOTAL - DF_F_HEAD_SZ) {
+            const int64_t r1 = e - 2 * DF_F_SZ0;
+            const int l = 1 + (int)(r1 / DF_F_SZ);
+            const int64_t r = r1 % DF_F_SZ;
+            const int kq = (int)(r / (DF_W * 4)), n = (int)((r >> 2) % DF_W), k = 4 * kq + (int)(r & 3);
+            v = l == 5 ? a.p.linear_w[5][(size_t)n * (DF_W + DF_IN) + DF_IN + k] : a.p.linear_w[l][(size_t)n * DF_W + k];
+        } else {
+            const int64_t r = e - (DF_F_TOTAL - DF_F_HEAD_SZ);
+            const int kq = (int)(r / (DF_HEAD * 4)), n = (int)((r >> 2) % DF_HEAD), k = 4 * kq + (int)(r & 3);
             float bias;
             const float* row = head_row(a.p, n, bias);
             v = row ? row[k] : 0.f;
-        } else if (l == 0) {
-            v = k < DF_IN ? a.p.linear_w[0][(size_t)n * DF_IN + k] : 0.f;
-        } else if (l == 5) {
-            const int ld = DF_W + DF_IN;
-            v = k < DF_IN ? a.p.linear_w[5][(size_t)n * ld + k] : k < DF_INK ? 0.f : a.p.linear_w[5][(size_t)n * ld + (k - 4)];
-        } else {
-            v = a.p.linear_w[l][(size_t)n * DF_W + k];
         }
     } else if (e < DF_BIAS_BASE) {
         // backward stream: head first, then layers 7..1; element (k = output, n = input) = W[k][n]
@@ -118,7 +113,10 @@ __global__ __launch_bounds__(256) void k_deform_pack(PackArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// the chunked GEMM both walks use: acc[rt][ct] += A[64 x 16] * Wchunk[16 x ncol]
+// the streamed GEMM both walks use: acc[rt][ct] += (A[64 x K] * W[K x ncol])^T, 16 k per chunk.
+// The weights are the MFMA's A operand and the activations its B operand, so a result tile has the POINT on
+// the lane and the output column on the registers: registers 4g..4g+3 of lane (j, hh) are columns
+// 8g + 4hh .. +3 of point j -- 16-byte LDS and global stores in the epilogues.
 // ---------------------------------------------------------------------------------------------
 template <int NR, int NC>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NR][NC])
@@ -131,80 +129,72 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NR][NC])
             for (int q = 0; q < 16; q++) acc[r][c][q] = 0.f;
 }
 
-// a_lane: the lane's row (l & 31) of the A tile at k = 4 * (l >> 5) of this chunk; wc: the lane's
-// float4 of the chunk, [(l >> 5)][column (l & 31) of the wave's first column tile].
+__device__ __forceinline__ float f4_get(const float4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
+
+// A wave owns its columns of W: no other wave reads them, so the weights go L2 -> registers directly
+// (lane (j, hh) reads the float4 [k/4 = 2r + hh][column j]: 512 contiguous bytes per half wave), one
+// chunk ahead of the multiply; the A tile (activations, shared by the four waves) is read from LDS, one
+// chunk ahead as well.  No barrier inside a layer.
 // k order inside a chunk: (0,4) (1,5) (2,6) (3,7) (8,12) ... -- any fixed order is a valid fp32 sum.
-template <int NR, int NC, int NCOL>
-__device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[NR][NC], const float* a_lane, int a_stride, const float4* wc)
+template <int NC, int NCOL>
+__device__ __forceinline__ void load_w(float4 (&w)[2][NC], const float4* wlane)
 {
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        float4 av[NR], bv[NC];
+    for (int r = 0; r < 2; r++)
 #pragma unroll
-        for (int rt = 0; rt < NR; rt++) av[rt] = *reinterpret_cast<const float4*>(a_lane + rt * 32 * a_stride + 8 * r);
-#pragma unroll
-        for (int ct = 0; ct < NC; ct++) bv[ct] = wc[2 * r * NCOL + ct * 32];
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int rt = 0; rt < NR; rt++)
-#pragma unroll
-                for (int ct = 0; ct < NC; ct++) {
-                    const float x = s == 0 ? av[rt].x : s == 1 ? av[rt].y : s == 2 ? av[rt].z : av[rt].w;
-                    const float y = s == 0 ? bv[ct].x : s == 1 ? bv[ct].y : s == 2 ? bv[ct].z : bv[ct].w;
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[rt][ct], 0, 0, 0);
-                }
-    }
+        for (int ct = 0; ct < NC; ct++) w[r][ct] = wlane[2 * r * NCOL + ct * 32];
 }
 
-// The weight stream: chunks lie back to back in the packed buffer in the order they are used; while
-// chunk c is multiplied out of one LDS buffer, chunk c+1 travels global -> registers -> other buffer.
-struct WeightStream {
-    const float4* next;      // next chunk to fetch
-    float4* lds;             // [2][DF_CHUNK_F4]
-    int buf;                 // LDS buffer holding the chunk to multiply next
-};
-
-__device__ __forceinline__ void stream_prime(WeightStream& ws, int tid, int nf4)
-{
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        if (q < nf4) ws.lds[tid + 256 * q] = ws.next[tid + 256 * q];
-    ws.next += nf4 * 256;
-    ws.buf = 0;
-    __syncthreads();
-}
-
-// nchunks chunks of this segment; last_next_f4 = float4 per thread of the chunk that follows the
-// segment (4: 256-column chunk, 1: 64-column chunk, 0: end of stream).  Ends with a barrier.
+// wlane: the lane's float4 of the segment's first chunk ([hh][first column + j]); wcur: that chunk, already
+// loaded.  more_after: the stream continues with a chunk of the same shape (it is prefetched into wcur).
 template <int NR, int NC, int NCOL>
-__device__ __forceinline__ void run_chunks(f32x16 (&acc)[NR][NC], const float* a_lane, int a_stride, int nchunks,
-                                           int last_next_f4, WeightStream& ws, int tid, int b_lane_off)
+__device__ __forceinline__ void stream_gemm(f32x16 (&acc)[NR][NC], const float* a_lane, int a_stride, int nchunks,
+                                            const float4*& wlane, float4 (&wcur)[2][NC], bool more_after)
 {
+    float4 acur[2][NR];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int rt = 0; rt < NR; rt++) acur[r][rt] = *reinterpret_cast<const float4*>(a_lane + rt * 32 * a_stride + 8 * r);
     for (int c = 0; c < nchunks; c++) {
-        const int nf4 = (c + 1 < nchunks) ? NCOL / 64 : last_next_f4;
-        // (named registers, not an array: a conditionally filled array ends up in scratch)
-        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
-        if (nf4 > 0) p0 = ws.next[tid];
-        if (nf4 > 1) {
-            p1 = ws.next[tid + 256];
-            p2 = ws.next[tid + 512];
-            p3 = ws.next[tid + 768];
+        const bool last = c + 1 >= nchunks;
+        // (unconditional loads from clamped addresses: conditionally filled arrays end up in scratch)
+        const float4* wn = wlane + ((!last || more_after) ? 4 * NCOL : 0);
+        const float* an = a_lane + (last ? c : c + 1) * 16;
+        float4 wnxt[2][NC], anxt[2][NR];
+        load_w<NC, NCOL>(wnxt, wn);
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int rt = 0; rt < NR; rt++) anxt[r][rt] = *reinterpret_cast<const float4*>(an + rt * 32 * a_stride + 8 * r);
+        // keep the loads above the multiply (the scheduler otherwise sinks them to their use, after it)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int rt = 0; rt < NR; rt++)
+#pragma unroll
+                    for (int ct = 0; ct < NC; ct++)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(wcur[r][ct], s), f4_get(acur[r][rt], s),
+                                                                           acc[rt][ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        wlane = wn;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++) wcur[r][ct] = wnxt[r][ct];
+#pragma unroll
+            for (int rt = 0; rt < NR; rt++) acur[r][rt] = anxt[r][rt];
         }
-        chunk_mfma<NR, NC, NCOL>(acc, a_lane + c * 16, a_stride, ws.lds + ws.buf * DF_CHUNK_F4 + b_lane_off);
-        float4* wd = ws.lds + (ws.buf ^ 1) * DF_CHUNK_F4;
-        if (nf4 > 0) wd[tid] = p0;
-        if (nf4 > 1) {
-            wd[tid + 256] = p1;
-            wd[tid + 512] = p2;
-            wd[tid + 768] = p3;
-        }
-        ws.next += nf4 * 256;
-        ws.buf ^= 1;
-        __syncthreads();
     }
 }
 
+
+// first column (within its 32-column tile) of register group g = registers 4g..4g+3
+__device__ __forceinline__ int acc_col4(int g, int hh) { return 8 * g + 4 * hh; }
+// row of register `reg` of a 32x32 result tile
 __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
 // ---------------------------------------------------------------------------------------------
@@ -219,84 +209,101 @@ struct FwdArgs {
     float* d_xyz; float* d_sh;
 };
 
-constexpr size_t DF_FWD_LDS = (size_t)(DF_TILE * DF_HS + DF_TILE * DF_ES) * 4 + 2 * DF_CHUNK_F4 * 16;   // 120832
+constexpr size_t DF_LDS = (size_t)DF_TILE * DF_HS * 4;   // 66560: two workgroups per CU
 
 template <bool SAVE>
-__global__ __launch_bounds__(256) void k_deform_fwd(FwdArgs a)
+__global__ __launch_bounds__(256, 2) void k_deform_fwd(FwdArgs a)
 {
     extern __shared__ float4 df_lds[];
     float* hA = reinterpret_cast<float*>(df_lds);
-    float* eA = hA + DF_TILE * DF_HS;
-    WeightStream ws;
-    ws.lds = reinterpret_cast<float4*>(eA + DF_TILE * DF_ES);
-    ws.next = reinterpret_cast<const float4*>(a.packed);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * DF_TILE;
+    const int n0 = wave * 64;
+    const float4* wlane = reinterpret_cast<const float4*>(a.packed) + hh * DF_W + n0 + li;
+    float4 wcur[2][2];
+    load_w<2, DF_W>(wcur, wlane);
 
-    // positional encoding (time_utils.py:24-53): [x, sin(2^f x), cos(2^f x)]_f for all dims, then t
+    // positional encoding (time_utils.py:24-53): [x, sin(2^f x), cos(2^f x)]_f for all dims, then t;
+    // it sits in the first 80 columns of the activation tile until layer 0 has been multiplied
     {
         const int pt = tid & 63, grp = tid >> 6;
         const int64_t p = p0 + pt;
-        float* e = eA + pt * DF_ES;
+        float* e = hA + pt * DF_HS;
         if (grp < 3) {
             const float v = p < a.n ? a.xyz[3 * p + grp] : 0.f;
             e[grp] = v;
 #pragma unroll
             for (int f = 0; f < 10; f++) {
-                const float w = v * (float)(1 << f);
-                e[3 + 6 * f + grp] = sinf(w);
-                e[6 + 6 * f + grp] = cosf(w);
+                float sn, cs;
+                sincosf(v * (float)(1 << f), &sn, &cs);
+                e[3 + 6 * f + grp] = sn;
+                e[6 + 6 * f + grp] = cs;
             }
         } else {
             const float v = p < a.n ? a.t[p * a.t_stride] : 0.f;
             e[63] = v;
 #pragma unroll
             for (int f = 0; f < 6; f++) {
-                const float w = v * (float)(1 << f);
-                e[64 + 2 * f] = sinf(w);
-                e[65 + 2 * f] = cosf(w);
+                float sn, cs;
+                sincosf(v * (float)(1 << f), &sn, &cs);
+                e[64 + 2 * f] = sn;
+                e[65 + 2 * f] = cs;
             }
             e[76] = e[77] = e[78] = e[79] = 0.f;
         }
     }
-    stream_prime(ws, tid, 4);   // barrier inside: the encoding is visible too
+    __syncthreads();
     if (SAVE) {
         for (int q = tid; q < DF_TILE * DF_EMB; q += 256) {
             const int row = q / DF_EMB, col = q - row * DF_EMB;
-            a.emb[(p0 + row) * DF_EMB + col] = col < DF_INK ? eA[row * DF_ES + col] : 0.f;
+            a.emb[(p0 + row) * DF_EMB + col] = col < DF_INK ? hA[row * DF_HS + col] : 0.f;
         }
     }
 
-    const int n0 = wave * 64;
     const float* bias = a.packed + DF_BIAS_BASE;
-    const float* e_lane = eA + li * DF_ES + 4 * hh;
     const float* h_lane = hA + li * DF_HS + 4 * hh;
-    const int b_off = hh * DF_W + n0 + li;
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], acc5[2][2];
+    // layer 0, and the encoding's share of layer 5 (time_utils.py:112-113 concatenates it in front of the
+    // activations after layer 4): both multiply the encoding, which is in LDS only now
+    zero_acc(acc);
+    stream_gemm<2, 2, DF_W>(acc, h_lane, DF_HS, DF_INK / 16, wlane, wcur, true);
+    zero_acc(acc5);
+    stream_gemm<2, 2, DF_W>(acc5, h_lane, DF_HS, DF_INK / 16, wlane, wcur, true);
     for (int l = 0; l < DF_D; l++) {
-        zero_acc(acc);
-        if (l == 0) {
-            run_chunks<2, 2, DF_W>(acc, e_lane, DF_ES, DF_INK / 16, 4, ws, tid, b_off);
-        } else {
-            // after layer 4 the encoding is concatenated in front (time_utils.py:112-113)
-            if (l == 5) run_chunks<2, 2, DF_W>(acc, e_lane, DF_ES, DF_INK / 16, 4, ws, tid, b_off);
-            run_chunks<2, 2, DF_W>(acc, h_lane, DF_HS, DF_W / 16, l == 7 ? 1 : 4, ws, tid, b_off);
+        if (l > 0) {
+            if (l == 5) {
+#pragma unroll
+                for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ct++) acc[rt][ct] = acc5[rt][ct];
+            } else {
+                zero_acc(acc);
+            }
+            stream_gemm<2, 2, DF_W>(acc, h_lane, DF_HS, DF_W / 16, wlane, wcur, l < 7);
         }
-        // bias + ReLU -> next layer's A tile (every wave is past its last read of hA: run_chunks ends with a barrier)
+        // bias (its latency passes in the barrier), ReLU -> next layer's A tile
+        float4 bv[2][4];
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++) {
-            const int col = n0 + 32 * ct + li;
-            const float bv = bias[l * DF_W + col];
+        for (int ct = 0; ct < 2; ct++)
 #pragma unroll
-            for (int rt = 0; rt < 2; rt++)
+            for (int g = 0; g < 4; g++)
+                bv[ct][g] = *reinterpret_cast<const float4*>(bias + l * DF_W + n0 + 32 * ct + acc_col4(g, hh));
+        __syncthreads();      // every wave is past its last read of this layer's input
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int row = 32 * rt + acc_row(q, hh);
-                    const float v = fmaxf(acc[rt][ct][q] + bv, 0.f);
-                    hA[row * DF_HS + col] = v;
-                    if (SAVE) a.acts[((int64_t)l * a.n_pad + p0 + row) * DF_W + col] = v;
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int row = 32 * rt + li, col = n0 + 32 * ct + acc_col4(g, hh);
+                    float4 v;
+                    v.x = fmaxf(acc[rt][ct][4 * g] + bv[ct][g].x, 0.f);
+                    v.y = fmaxf(acc[rt][ct][4 * g + 1] + bv[ct][g].y, 0.f);
+                    v.z = fmaxf(acc[rt][ct][4 * g + 2] + bv[ct][g].z, 0.f);
+                    v.w = fmaxf(acc[rt][ct][4 * g + 3] + bv[ct][g].w, 0.f);
+                    *reinterpret_cast<float4*>(hA + row * DF_HS + col) = v;
+                    if (SAVE) *reinterpret_cast<float4*>(a.acts + ((int64_t)l * a.n_pad + p0 + row) * DF_W + col) = v;
                 }
-        }
         __syncthreads();
     }
     // heads: 64 columns, one 32x32 tile per wave
@@ -304,17 +311,25 @@ __global__ __launch_bounds__(256) void k_deform_fwd(FwdArgs a)
         f32x16 hacc[1][1];
         zero_acc(hacc);
         const int rt = wave >> 1, ct = wave & 1;
-        run_chunks<1, 1, DF_HEAD>(hacc, hA + (32 * rt + li) * DF_HS + 4 * hh, DF_HS, DF_W / 16, 0, ws, tid,
-                                  hh * DF_HEAD + 32 * ct + li);
-        const int col = 32 * ct + li;
-        const float bv = bias[DF_D * DF_W + col];
+        const float4* hl = reinterpret_cast<const float4*>(a.packed + DF_F_TOTAL - DF_F_HEAD_SZ) + hh * DF_HEAD + 32 * ct + li;
+        float4 hw[2][1];
+        load_w<1, DF_HEAD>(hw, hl);
+        stream_gemm<1, 1, DF_HEAD>(hacc, hA + (32 * rt + li) * DF_HS + 4 * hh, DF_HS, DF_W / 16, hl, hw, false);
+        const int64_t p = p0 + 32 * rt + li;
+        if (p < a.n) {
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int64_t p = p0 + 32 * rt + acc_row(q, hh);
-            if (p < a.n) {
-                const float v = hacc[0][0][q] + bv;
-                if (col < 48) a.d_sh[p * 48 + col] = v;
-                else if (col < 51) a.d_xyz[p * 3 + (col - 48)] = v;
+            for (int g = 0; g < 4; g++) {
+                const int col = 32 * ct + acc_col4(g, hh);
+                const float4 bq = *reinterpret_cast<const float4*>(bias + DF_D * DF_W + col);
+                const float4 v = make_float4(hacc[0][0][4 * g] + bq.x, hacc[0][0][4 * g + 1] + bq.y, hacc[0][0][4 * g + 2] + bq.z,
+                                             hacc[0][0][4 * g + 3] + bq.w);
+                if (col < 48) {
+                    *reinterpret_cast<float4*>(a.d_sh + p * 48 + col) = v;
+                } else if (col == 48) {
+                    a.d_xyz[p * 3] = v.x;
+                    a.d_xyz[p * 3 + 1] = v.y;
+                    a.d_xyz[p * 3 + 2] = v.z;
+                }
             }
         }
     }
@@ -332,20 +347,18 @@ struct BwdArgs {
     float* dzh;             // [n_pad][64]
 };
 
-constexpr size_t DF_BWD_LDS = (size_t)(DF_TILE * DF_HS + DF_TILE * DF_OS) * 4 + 2 * DF_CHUNK_F4 * 16;   // 116736
-
-__global__ __launch_bounds__(256) void k_deform_bwd(BwdArgs a)
+__global__ __launch_bounds__(256, 2) void k_deform_bwd(BwdArgs a)
 {
     extern __shared__ float4 df_lds[];
     float* gA = reinterpret_cast<float*>(df_lds);
-    float* oA = gA + DF_TILE * DF_HS;
-    WeightStream ws;
-    ws.lds = reinterpret_cast<float4*>(oA + DF_TILE * DF_OS);
-    ws.next = reinterpret_cast<const float4*>(a.packed + DF_B_BASE);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * DF_TILE;
+    const int n0 = wave * 64;
+    const float4* wlane = reinterpret_cast<const float4*>(a.packed + DF_B_BASE) + hh * DF_W + n0 + li;
+    float4 wcur[2][2];
+    load_w<2, DF_W>(wcur, wlane);
 
-    // upstream gradients as the head's output tile: [d_sh (48) | d_xyz (3) | 0]
+    // upstream gradients as the head's output tile: [d_sh (48) | d_xyz (3) | 0], in the first 64 columns
     for (int q = tid; q < DF_TILE * DF_HEAD; q += 256) {
         const int row = q >> 6, col = q & 63;
         const int64_t p = p0 + row;
@@ -354,44 +367,42 @@ __global__ __launch_bounds__(256) void k_deform_bwd(BwdArgs a)
             if (col < 48) v = a.g_dsh ? a.g_dsh[p * 48 + col] : 0.f;
             else if (col < 51) v = a.g_dxyz ? a.g_dxyz[p * 3 + (col - 48)] : 0.f;
         }
-        oA[row * DF_OS + col] = v;
+        gA[row * DF_HS + col] = v;
         a.dzh[p * DF_HEAD + col] = v;
     }
-    stream_prime(ws, tid, 4);
+    __syncthreads();
 
-    const int n0 = wave * 64;
-    const int b_off = hh * DF_W + n0 + li;
+    const float* g_lane = gA + li * DF_HS + 4 * hh;
     f32x16 acc[2][2];
-    float mask[2][2][16];
-    auto load_mask = [&](int l) {
-#pragma unroll
-        for (int rt = 0; rt < 2; rt++)
-#pragma unroll
-            for (int ct = 0; ct < 2; ct++)
-#pragma unroll
-                for (int q = 0; q < 16; q++)
-                    mask[rt][ct][q] = a.acts[((int64_t)l * a.n_pad + p0 + 32 * rt + acc_row(q, hh)) * DF_W + n0 + 32 * ct + li];
-    };
-    load_mask(DF_D - 1);
     zero_acc(acc);
-    run_chunks<2, 2, DF_W>(acc, oA + li * DF_OS + 4 * hh, DF_OS, DF_HEAD / 16, 4, ws, tid, b_off);   // dh_7
+    stream_gemm<2, 2, DF_W>(acc, g_lane, DF_HS, DF_HEAD / 16, wlane, wcur, true);   // dh_7
     for (int l = DF_D - 1; l >= 0; l--) {
+        __syncthreads();      // every wave is past its last read of the previous gradient tile
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-            for (int ct = 0; ct < 2; ct++)
+            for (int ct = 0; ct < 2; ct++) {
+                const int row = 32 * rt + li;
+                float4 mask[4];
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int row = 32 * rt + acc_row(q, hh), col = n0 + 32 * ct + li;
-                    const float v = mask[rt][ct][q] > 0.f ? acc[rt][ct][q] : 0.f;
-                    if (l > 0) gA[row * DF_HS + col] = v;
-                    a.dz[((int64_t)l * a.n_pad + p0 + row) * DF_W + col] = v;
+                for (int g = 0; g < 4; g++)
+                    mask[g] = *reinterpret_cast<const float4*>(a.acts + ((int64_t)l * a.n_pad + p0 + row) * DF_W + n0 + 32 * ct + acc_col4(g, hh));
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int col = n0 + 32 * ct + acc_col4(g, hh);
+                    float4 v;
+                    v.x = mask[g].x > 0.f ? acc[rt][ct][4 * g] : 0.f;
+                    v.y = mask[g].y > 0.f ? acc[rt][ct][4 * g + 1] : 0.f;
+                    v.z = mask[g].z > 0.f ? acc[rt][ct][4 * g + 2] : 0.f;
+                    v.w = mask[g].w > 0.f ? acc[rt][ct][4 * g + 3] : 0.f;
+                    if (l > 0) *reinterpret_cast<float4*>(gA + row * DF_HS + col) = v;
+                    *reinterpret_cast<float4*>(a.dz + ((int64_t)l * a.n_pad + p0 + row) * DF_W + col) = v;
                 }
+            }
         if (l == 0) break;
         __syncthreads();
-        load_mask(l - 1);
         zero_acc(acc);
-        run_chunks<2, 2, DF_W>(acc, gA + li * DF_HS + 4 * hh, DF_HS, DF_W / 16, l > 1 ? 4 : 0, ws, tid, b_off);   // dh_{l-1}
+        stream_gemm<2, 2, DF_W>(acc, g_lane, DF_HS, DF_W / 16, wlane, wcur, l > 1);   // dh_{l-1}
     }
 }
 
@@ -555,13 +566,14 @@ bool attrs_set = false;
 void set_attrs()
 {
     if (attrs_set) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_BWD_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_LDS);
     attrs_set = true;
 }
 
 }  // namespace
+
 
 extern "C" size_t gft_deform_packed_bytes(void) { return (size_t)DF_PACKED_FLOATS * sizeof(float); }
 
@@ -616,8 +628,8 @@ extern "C" int gft_deform_forward(void* hip_stream, int64_t n, const float* xyz,
     a.d_xyz = d_xyz;
     a.d_sh = d_sh;
     const dim3 grid((unsigned)(a.n_pad / DF_TILE));
-    if (saved) hipLaunchKernelGGL(k_deform_fwd<true>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
-    else hipLaunchKernelGGL(k_deform_fwd<false>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
+    if (saved) hipLaunchKernelGGL(k_deform_fwd<true>, grid, dim3(256), DF_LDS, (hipStream_t)hip_stream, a);
+    else hipLaunchKernelGGL(k_deform_fwd<false>, grid, dim3(256), DF_LDS, (hipStream_t)hip_stream, a);
     GFT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -663,7 +675,7 @@ extern "C" int gft_deform_backward(void* hip_stream, int64_t n, const void* pack
         a.acts = acts;
         a.g_dxyz = g_d_xyz; a.g_dsh = g_d_sh;
         a.dz = dz; a.dzh = dzh;
-        hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(n_pad / DF_TILE)), dim3(256), DF_BWD_LDS, s, a);
+        hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(n_pad / DF_TILE)), dim3(256), DF_LDS, s, a);
         GFT_CHECK_HIP(hipGetLastError());
     }
     int tps;

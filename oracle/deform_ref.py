@@ -16,6 +16,9 @@ arrays in torch's ``[out, in]`` layout.  ``dtype=np.float64`` gives the accuracy
 comparisons.  Pinned against the reference's own module by ``tests/golden/deform.npz``
 (``tests/golden/make_golden.py``).
 
+* :func:`deform_eager` -- the same statements on torch tensors (eager ``F.linear`` / ``relu`` / ``cat``, autograd
+  for the backward): what the reference's module runs on a GPU; bench.py times it beside the HIP path.
+
 Only tests/, __graft_entry__.smoke() and bench.py's baseline leg may import this module.
 """
 import numpy as np
@@ -133,3 +136,29 @@ def backward(params, x, t, g_dxyz, g_dsh, dtype=np.float32):
         if i == SKIP + 1:
             dh = dh[:, IN_CH:]                   # the embedded part of the skip input has no parameters
     return g
+
+
+def deform_eager(params, x, t):
+    """time_utils.py:103-127 on torch tensors (``params``: name -> tensor, torch layout), including the two
+    heads the reference computes and throws away."""
+    import torch
+    import torch.nn.functional as F
+
+    def emb_one(v, multires):
+        parts = [v]
+        for f in range(multires):
+            parts += [torch.sin(v * float(2 ** f)), torch.cos(v * float(2 ** f))]
+        return torch.cat(parts, -1)
+
+    emb = torch.cat([emb_one(x, XYZ_MULTIRES), emb_one(t, T_MULTIRES)], dim=-1)
+    h = emb
+    for i in range(D):
+        h = F.relu(F.linear(h, params["linear.%d.weight" % i], params["linear.%d.bias" % i]))
+        if i == SKIP:
+            h = torch.cat([emb, h], -1)
+    head = lambda n: F.linear(h, params[n + ".weight"], params[n + ".bias"])
+    d_xyz = head("xyz_warp")
+    d_sh_a = head("a")                                   # time_utils.py:119, unused
+    d_rot = head("rot")                                  # time_utils.py:125, replaced by zeros
+    d_sh = torch.stack([head("r"), head("g"), head("b")], dim=-1)
+    return d_xyz, torch.zeros_like(d_rot), d_sh, torch.zeros(d_sh_a.shape + (2,), device=x.device)

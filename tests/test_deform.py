@@ -55,6 +55,25 @@ def test_oracle_float32_close_to_float64():
     assert _rel(a[0], b[0]) < 5e-6 and _rel(a[2], b[2]) < 5e-6
 
 
+def test_eager_torch_restatement_matches_numpy_oracle():
+    params = deform_ref.random_params(21)
+    rng = np.random.default_rng(22)
+    x, t = rng.random((40, 3)).astype(np.float32), rng.random((40, 1)).astype(np.float32)
+    pt = {k: torch.tensor(v, requires_grad=True) for k, v in params.items()}
+    g_dxyz, g_dsh = rng.normal(size=(40, 3)).astype(np.float32), rng.normal(size=(40, 16, 3)).astype(np.float32)
+    d_xyz, d_rot, d_sh, d_sh_p = deform_ref.deform_eager(pt, torch.tensor(x), torch.tensor(t))
+    ref = deform_ref.forward(params, x, t, dtype=np.float64)
+    assert _rel(d_xyz.detach().numpy(), ref[0]) < 3e-6 and _rel(d_sh.detach().numpy(), ref[2]) < 3e-6
+    assert not d_rot.any() and not d_sh_p.any() and d_sh_p.shape == (40, 16, 2)
+    ((d_xyz * torch.tensor(g_dxyz)).sum() + (d_sh * torch.tensor(g_dsh)).sum()).backward()
+    gref = deform_ref.backward(params, x, t, g_dxyz, g_dsh, dtype=np.float64)
+    for k, v in gref.items():
+        if v is None:
+            assert pt[k].grad is None
+        else:
+            assert _rel(pt[k].grad.numpy(), v) < 2e-5, k
+
+
 def test_embedding_layout():
     x = np.array([[0.1, 0.2, 0.3]], np.float32)
     t = np.array([[0.5]], np.float32)
