@@ -300,6 +300,69 @@ def deform_extra(dev, n=300_000, steps=10, warmup=3):
             "inference_frac_of_peak": tf_fwd / FP32_MFMA_PEAK_TFLOPS}
 
 
+def deform_exchange(dev, dist, rank, world, n=300_000, steps=10, warmup=3):
+    """The path's one exchange step, measured on all ranks beside the sharded raster metric:
+    every rank queries the deformation network for its own frame's time (fwd + bwd, 30 % of 1 M Gaussians),
+    then ONE all-reduce of the 2.05 MB gradient bucket (RCCL over xGMI) makes the replicas' gradients equal.
+    Barrier-bracketed, MAX over ranks, like the headline timing."""
+    import numpy as np
+    import torch
+    from gftorf_amd import DeformNetwork
+    from gftorf_amd.deform import allreduce_gradients, flat_grad_bucket
+    torch.manual_seed(7)                                  # identical replicas
+    net = DeformNetwork()
+    for name, p in net.named_parameters():
+        if name.endswith("weight"):
+            torch.nn.init.normal_(p, 0.0, 0.06)
+    net = net.to(dev)
+    rng = np.random.default_rng(11)                       # same Gaussians on every rank, own frame time
+    x = torch.tensor(rng.random((n, 3)).astype(np.float32), device=dev)
+    g_dxyz, g_dsh = torch.randn((n, 3), device=dev), torch.randn((n, 16, 3), device=dev)
+    nbytes = [0]
+
+    def make_step(exchange):
+        def step_fn():
+            t = torch.full((1, 1), (rank + 0.5) / world, device=dev).expand(n, -1)
+            d_xyz, _, d_sh, _ = net(x, t)
+            torch.autograd.backward([d_xyz, d_sh], [g_dxyz, g_dsh])
+            if exchange:
+                nbytes[0] = allreduce_gradients(net, dist, average=True)
+            else:
+                flat_grad_bucket(net)                     # same bucket assembly, no exchange
+        return step_fn
+
+    def run(exchange):
+        fn = make_step(exchange)
+
+        def one():
+            fn()
+            net.zero_grad(set_to_none=True)
+        return timed_steps(one, steps, warmup, lambda: torch.cuda.synchronize(dev), dist) / steps * 1e3
+
+    local_ms = run(False)
+    total_ms = run(True)
+    # replicas must hold bit-identical gradients after the exchange
+    make_step(True)()
+    flat, _ = flat_grad_bucket(net)
+    probe = torch.stack([flat.double().sum(), flat.double().abs().max()])
+    on_dev = dist.get_backend() == "nccl"
+    lo, hi = (probe.clone(), probe.clone()) if on_dev else (probe.cpu(), probe.cpu())
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    net.zero_grad(set_to_none=True)
+    # the collective alone
+    buf = torch.zeros(nbytes[0] // 4, device=dev if on_dev else "cpu")
+
+    def only():
+        dist.all_reduce(buf)
+    coll_ms = timed_steps(only, 5 * steps, warmup, lambda: torch.cuda.synchronize(dev), dist) / (5 * steps) * 1e3
+    return {"what": "deform network fwd+bwd on %d points per rank + all-reduce of the gradient bucket" % n,
+            "backend": dist.get_backend(), "bucket_bytes": nbytes[0], "ms_per_step_no_exchange": local_ms,
+            "ms_per_step": total_ms, "allreduce_alone_ms": coll_ms,
+            "allreduce_busbw_GBs": 2.0 * (world - 1) / world * nbytes[0] / (coll_ms * 1e-3) / 1e9,
+            "replicas_identical": bool(torch.equal(lo, hi))}
+
+
 def knn_extra(dev, P=1_000_000):
     """SURVEY 8(f) row 3 beside the headline metric: distCUDA2 (mean squared distance to the 3
     nearest neighbours, the scale initialisation of scene/gaussian_model.py:194-199) on a
@@ -389,13 +452,20 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the rasterizer has no CPU path)")
     from gftorf_amd import _lib
     _lib.load()
-    torch.cuda.set_device(env["local_rank"])
-    dev = torch.device("cuda", env["local_rank"])
+    # GFT_BENCH_REHEARSAL=1: all ranks on device 0 with the gloo backend, to rehearse the N > 1 code path on
+    # a one-GPU box (RCCL refuses two ranks on one device); never set by the driver
+    rehearsal = os.environ.get("GFT_BENCH_REHEARSAL") == "1"
+    local = 0 if rehearsal else env["local_rank"]
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist_mod.init_process_group(backend="gloo")
+        else:
+            dist_mod.init_process_group(backend="nccl", device_id=dev)
         dist = dist_mod
 
     scene = build_scene(args.workload, env["rank"], world)
@@ -430,6 +500,14 @@ def main():
     from gftorf_amd import api
     R = int(api.last_call_stats["num_rendered"])
 
+    exchange = None
+    if dist is not None and not args.no_extras:
+        # the deform-network exchange leg runs on every rank (it holds the path's only collective)
+        try:
+            exchange = deform_exchange(dev, dist, env["rank"], world)
+        except Exception as e:                            # reported, never fatal for the headline line
+            exchange = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if env["rank"] == 0:
         per_kernel, whole = algorithmic_bytes(P, P_vis, R, N, T)
         calls = max(prof["forward_calls"], 1)
@@ -447,7 +525,8 @@ def main():
             "config": {"workload": scene["label"], "P": P, "W": W, "H": H, "sh_degree": cfg["D"],
                        "P_visible": P_vis, "num_rendered": R,
                        "longest_tile_list": int(api.last_call_stats["max_tile_list"]), "frames_per_step": world,
-                       "parallelism": "frame-sharded x%d (no data-path collective)" % world},
+                       "parallelism": "frame-sharded x%d (no collective in the raster path; the deform-gradient all-reduce is "
+                                      "measured in deform_exchange)" % world},
             "mpix_per_s": value * N / 1e6,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom, args.workload),
@@ -458,6 +537,8 @@ def main():
                               "gpu_ms_sum_of_stages": sum(stage_ms.values())},
             "stage_ms": stage_ms,
         }
+        if exchange is not None:
+            out["deform_exchange"] = exchange
         if world == 1 and not args.no_extras and args.workload == "metric":
             del state, step
             torch.cuda.empty_cache()

@@ -173,3 +173,23 @@ def flat_grad_bucket(module):
             p.grad.copy_(bucket[o:o + k].view_as(p.grad))
             o += k
     return flat, scatter_back
+
+
+def allreduce_gradients(module, dist, average=True):
+    """Data-parallel step of the deformation network: every rank has rendered its own
+    frame; ONE all-reduce of the flat gradient bucket (RCCL over xGMI when the process group's backend is
+    ``nccl``) leaves the same summed (or averaged) gradients on all replicas.  Returns the bucket's bytes."""
+    flat, scatter_back = flat_grad_bucket(module)
+    if flat.numel() == 0:
+        return 0
+    if flat.is_cuda and dist.get_backend() != "nccl":
+        # rehearsal on a CPU backend (gloo): stage through the host
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
+    scatter_back(flat)
+    return flat.numel() * flat.element_size()

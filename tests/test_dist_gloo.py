@@ -55,6 +55,51 @@ def test_two_rank_frame_sharding_and_timing():
     assert t0 >= 5 * 0.04 * 0.9                # ... which is the slow rank's time
 
 
+def _worker_deform(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from gftorf_amd.deform import DeformNetwork, allreduce_gradients, flat_grad_bucket
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)                       # replicas start identical
+    net = DeformNetwork()
+    # the gradients a rank's own frame produced (stand-ins: the kernels need a GPU); rot / a get none
+    g = torch.Generator().manual_seed(100 + rank)
+    for name, p in net.named_parameters():
+        if not name.startswith(("rot.", "a.")):
+            p.grad = torch.randn(p.shape, generator=g)
+    mine = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    nbytes = allreduce_gradients(net, dist, average=True)
+    flat, _ = flat_grad_bucket(net)
+    q.put((rank, nbytes, {n: v for n, v in mine.items() if n in ("linear.5.weight", "b.bias")},
+           {n: p.grad.clone() for n, p in net.named_parameters() if n in ("linear.5.weight", "b.bias")},
+           float(flat.double().sum()), [n for n, p in net.named_parameters() if p.grad is None]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_deform_gradient_allreduce():
+    """The one exchange step of the path: all-reduce of the deformation network's gradient
+    bucket; here over gloo with two CPU ranks."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_deform, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, nb0, mine0, red0, sum0, none0), (_, nb1, mine1, red1, sum1, none1) = res
+    assert nb0 == nb1 == (517959 - 5140) * 4                # every parameter that receives a gradient, once
+    assert none0 == none1 == ["rot.weight", "rot.bias", "a.weight", "a.bias"]
+    for n in ("linear.5.weight", "b.bias"):
+        torch.testing.assert_close(red0[n], (mine0[n] + mine1[n]) / 2)
+        assert torch.equal(red0[n], red1[n])                  # replicas hold identical gradients afterwards
+    assert sum0 == sum1
+
+
 def test_algorithmic_bytes_formula():
     sys.path.insert(0, ROOT)
     import bench
