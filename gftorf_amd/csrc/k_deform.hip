@@ -206,10 +206,14 @@ struct FwdArgs {
     const float* packed;
     float* emb;       // [n_pad][96] or null
     float* acts;      // [8][n_pad][256] or null
+    uint32_t* signs;  // [8][n_pad][8] or null: bit c of word w = activation 32 w + c is positive
     float* d_xyz; float* d_sh;
 };
 
+constexpr int DF_BIAS_FLOATS = DF_D * DF_W + DF_HEAD;      // 2368
+constexpr int DF_SIGN_WORDS = DF_W / 32;                   // ReLU sign bits of one point and layer: 8 words
 constexpr size_t DF_LDS = (size_t)DF_TILE * DF_HS * 4;   // 66560: two workgroups per CU
+constexpr size_t DF_FWD_LDS = DF_LDS + DF_BIAS_FLOATS * 4;   // + all biases: 76032
 
 template <bool SAVE>
 __global__ __launch_bounds__(256, 2) void k_deform_fwd(FwdArgs a)
@@ -222,6 +226,9 @@ __global__ __launch_bounds__(256, 2) void k_deform_fwd(FwdArgs a)
     const float4* wlane = reinterpret_cast<const float4*>(a.packed) + hh * DF_W + n0 + li;
     float4 wcur[2][2];
     load_w<2, DF_W>(wcur, wlane);
+    // all biases (9.5 KB) go to LDS once: an epilogue then waits for an LDS read, not for L2
+    float* bL = hA + DF_TILE * DF_HS;
+    for (int q = tid; q < DF_BIAS_FLOATS; q += 256) bL[q] = a.packed[DF_BIAS_BASE + q];
 
     // positional encoding (time_utils.py:24-53): [x, sin(2^f x), cos(2^f x)]_f for all dims, then t;
     // it sits in the first 80 columns of the activation tile until layer 0 has been multiplied
@@ -260,7 +267,6 @@ __global__ __launch_bounds__(256, 2) void k_deform_fwd(FwdArgs a)
         }
     }
 
-    const float* bias = a.packed + DF_BIAS_BASE;
     const float* h_lane = hA + li * DF_HS + 4 * hh;
     f32x16 acc[2][2], acc5[2][2];
     // layer 0, and the encoding's share of layer 5 (time_utils.py:112-113 concatenates it in front of the
@@ -281,18 +287,19 @@ __global__ __launch_bounds__(256, 2) void k_deform_fwd(FwdArgs a)
             }
             stream_gemm<2, 2, DF_W>(acc, h_lane, DF_HS, DF_W / 16, wlane, wcur, l < 7);
         }
-        // bias (its latency passes in the barrier), ReLU -> next layer's A tile
+        // bias, ReLU -> next layer's A tile
         float4 bv[2][4];
 #pragma unroll
         for (int ct = 0; ct < 2; ct++)
 #pragma unroll
             for (int g = 0; g < 4; g++)
-                bv[ct][g] = *reinterpret_cast<const float4*>(bias + l * DF_W + n0 + 32 * ct + acc_col4(g, hh));
+                bv[ct][g] = *reinterpret_cast<const float4*>(bL + l * DF_W + n0 + 32 * ct + acc_col4(g, hh));
         __syncthreads();      // every wave is past its last read of this layer's input
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-            for (int ct = 0; ct < 2; ct++)
+            for (int ct = 0; ct < 2; ct++) {
+                uint32_t bits = 0;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const int row = 32 * rt + li, col = n0 + 32 * ct + acc_col4(g, hh);
@@ -302,8 +309,18 @@ __global__ __launch_bounds__(256, 2) void k_deform_fwd(FwdArgs a)
                     v.z = fmaxf(acc[rt][ct][4 * g + 2] + bv[ct][g].z, 0.f);
                     v.w = fmaxf(acc[rt][ct][4 * g + 3] + bv[ct][g].w, 0.f);
                     *reinterpret_cast<float4*>(hA + row * DF_HS + col) = v;
-                    if (SAVE) *reinterpret_cast<float4*>(a.acts + ((int64_t)l * a.n_pad + p0 + row) * DF_W + col) = v;
+                    if (SAVE) {
+                        *reinterpret_cast<float4*>(a.acts + ((int64_t)l * a.n_pad + p0 + row) * DF_W + col) = v;
+                        bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
+                                << acc_col4(g, hh);
+                    }
                 }
+                if (SAVE) {
+                    // the other half wave holds the other 16 columns of this 32-column word
+                    bits |= (uint32_t)__shfl_xor((int)bits, 32);
+                    if (hh == 0) a.signs[((int64_t)l * a.n_pad + p0 + 32 * rt + li) * DF_SIGN_WORDS + 2 * wave + ct] = bits;
+                }
+            }
         __syncthreads();
     }
     // heads: 64 columns, one 32x32 tile per wave
@@ -320,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void k_deform_fwd(FwdArgs a)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int col = 32 * ct + acc_col4(g, hh);
-                const float4 bq = *reinterpret_cast<const float4*>(bias + DF_D * DF_W + col);
+                const float4 bq = *reinterpret_cast<const float4*>(bL + DF_D * DF_W + col);
                 const float4 v = make_float4(hacc[0][0][4 * g] + bq.x, hacc[0][0][4 * g + 1] + bq.y, hacc[0][0][4 * g + 2] + bq.z,
                                              hacc[0][0][4 * g + 3] + bq.w);
                 if (col < 48) {
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void k_deform_fwd(FwdArgs a)
 struct BwdArgs {
     int64_t n, n_pad;
     const float* packed;
-    const float* acts;      // [8][n_pad][256]
+    const uint32_t* signs;  // [8][n_pad][8]
     const float* g_dxyz; const float* g_dsh;
     float* dz;              // [8][n_pad][256]
     float* dzh;             // [n_pad][64]
@@ -374,6 +391,15 @@ __global__ __launch_bounds__(256, 2) void k_deform_bwd(BwdArgs a)
 
     const float* g_lane = gA + li * DF_HS + 4 * hh;
     f32x16 acc[2][2];
+    // ReLU signs of the lane's point and the wave's 64 columns (2 words per row tile), fetched before the
+    // multiply that produces the gradient they gate
+    uint2 sg[2];
+    auto load_signs = [&](int l) {
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+            sg[rt] = *reinterpret_cast<const uint2*>(a.signs + ((int64_t)l * a.n_pad + p0 + 32 * rt + li) * DF_SIGN_WORDS + 2 * wave);
+    };
+    load_signs(DF_D - 1);
     zero_acc(acc);
     stream_gemm<2, 2, DF_W>(acc, g_lane, DF_HS, DF_HEAD / 16, wlane, wcur, true);   // dh_7
     for (int l = DF_D - 1; l >= 0; l--) {
@@ -383,24 +409,23 @@ __global__ __launch_bounds__(256, 2) void k_deform_bwd(BwdArgs a)
 #pragma unroll
             for (int ct = 0; ct < 2; ct++) {
                 const int row = 32 * rt + li;
-                float4 mask[4];
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-                    mask[g] = *reinterpret_cast<const float4*>(a.acts + ((int64_t)l * a.n_pad + p0 + row) * DF_W + n0 + 32 * ct + acc_col4(g, hh));
+                const uint32_t word = ct == 0 ? sg[rt].x : sg[rt].y;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const int col = n0 + 32 * ct + acc_col4(g, hh);
+                    const uint32_t m = word >> acc_col4(g, hh);
                     float4 v;
-                    v.x = mask[g].x > 0.f ? acc[rt][ct][4 * g] : 0.f;
-                    v.y = mask[g].y > 0.f ? acc[rt][ct][4 * g + 1] : 0.f;
-                    v.z = mask[g].z > 0.f ? acc[rt][ct][4 * g + 2] : 0.f;
-                    v.w = mask[g].w > 0.f ? acc[rt][ct][4 * g + 3] : 0.f;
+                    v.x = (m & 1u) ? acc[rt][ct][4 * g] : 0.f;
+                    v.y = (m & 2u) ? acc[rt][ct][4 * g + 1] : 0.f;
+                    v.z = (m & 4u) ? acc[rt][ct][4 * g + 2] : 0.f;
+                    v.w = (m & 8u) ? acc[rt][ct][4 * g + 3] : 0.f;
                     if (l > 0) *reinterpret_cast<float4*>(gA + row * DF_HS + col) = v;
                     *reinterpret_cast<float4*>(a.dz + ((int64_t)l * a.n_pad + p0 + row) * DF_W + col) = v;
                 }
             }
         if (l == 0) break;
         __syncthreads();
+        load_signs(l - 1);
         zero_acc(acc);
         stream_gemm<2, 2, DF_W>(acc, g_lane, DF_HS, DF_W / 16, wlane, wcur, l > 1);   // dh_{l-1}
     }
@@ -439,17 +464,23 @@ __device__ __forceinline__ void dw_job(const float* A, int lda, const float* B, 
     for (int x = 0; x < WN; x++) bsum[x] = 0.f;
     const float* Ap = A + (p_begin + hh) * lda + n_base + li;
     const float* Bp = B + (p_begin + hh) * ldb + k_base + li;
-    float av[2][4][WN], bv[2][4][WK];
+    // operands of four 8-point steps in registers: three steps (12 k cycles of multiplies) in flight ahead of
+    // the one being multiplied -- the operands stream from HBM
+    float av[4][4][WN], bv[4][4][WK];
+    int64_t pf = p_begin;          // first point of the next step to fetch
     auto fetch = [&](int slot) {
+        if (pf < p_end) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+            for (int s = 0; s < 4; s++) {
 #pragma unroll
-            for (int x = 0; x < WN; x++) av[slot][s][x] = Ap[(int64_t)2 * s * lda + 32 * x];
+                for (int x = 0; x < WN; x++) av[slot][s][x] = Ap[(int64_t)2 * s * lda + 32 * x];
 #pragma unroll
-            for (int y = 0; y < WK; y++) bv[slot][s][y] = Bp[(int64_t)2 * s * ldb + 32 * y];
+                for (int y = 0; y < WK; y++) bv[slot][s][y] = Bp[(int64_t)2 * s * ldb + 32 * y];
+            }
+            Ap += 8 * lda;
+            Bp += 8 * ldb;
         }
-        Ap += 8 * lda;
-        Bp += 8 * ldb;
+        pf += 8;
     };
     auto mul = [&](int slot) {
 #pragma unroll
@@ -463,14 +494,20 @@ __device__ __forceinline__ void dw_job(const float* A, int lda, const float* B, 
             }
         }
     };
-    // 8 points per step, 16 per loop trip (the ranges are multiples of 64), next step's operands in flight
+    // 32 points per loop trip (the ranges are multiples of 64)
     if (p_begin < p_end) {
         fetch(0);
-        for (int64_t p = p_begin; p < p_end; p += 16) {
-            fetch(1);
+        fetch(1);
+        fetch(2);
+        for (int64_t p = p_begin; p < p_end; p += 32) {
+            fetch(3);
             mul(0);
-            if (p + 16 < p_end) fetch(0);
+            fetch(0);
             mul(1);
+            fetch(1);
+            mul(2);
+            fetch(2);
+            mul(3);
         }
     }
 #pragma unroll
@@ -566,8 +603,8 @@ bool attrs_set = false;
 void set_attrs()
 {
     if (attrs_set) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_LDS);
     attrs_set = true;
 }
@@ -580,7 +617,7 @@ extern "C" size_t gft_deform_packed_bytes(void) { return (size_t)DF_PACKED_FLOAT
 extern "C" size_t gft_deform_saved_bytes(int64_t n)
 {
     if (n <= 0) return 0;
-    return (size_t)pad_points(n) * (DF_EMB + DF_D * DF_W) * sizeof(float);
+    return (size_t)pad_points(n) * (DF_EMB + DF_D * DF_W + DF_D * DF_SIGN_WORDS) * sizeof(float);
 }
 
 extern "C" size_t gft_deform_scratch_bytes(int64_t n)
@@ -625,11 +662,12 @@ extern "C" int gft_deform_forward(void* hip_stream, int64_t n, const float* xyz,
     a.packed = (const float*)packed;
     a.emb = (float*)saved;
     a.acts = saved ? (float*)saved + a.n_pad * DF_EMB : nullptr;
+    a.signs = saved ? reinterpret_cast<uint32_t*>(a.acts + a.n_pad * DF_D * DF_W) : nullptr;
     a.d_xyz = d_xyz;
     a.d_sh = d_sh;
     const dim3 grid((unsigned)(a.n_pad / DF_TILE));
-    if (saved) hipLaunchKernelGGL(k_deform_fwd<true>, grid, dim3(256), DF_LDS, (hipStream_t)hip_stream, a);
-    else hipLaunchKernelGGL(k_deform_fwd<false>, grid, dim3(256), DF_LDS, (hipStream_t)hip_stream, a);
+    if (saved) hipLaunchKernelGGL(k_deform_fwd<true>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
+    else hipLaunchKernelGGL(k_deform_fwd<false>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
     GFT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -672,7 +710,7 @@ extern "C" int gft_deform_backward(void* hip_stream, int64_t n, const void* pack
         BwdArgs a;
         a.n = n; a.n_pad = n_pad;
         a.packed = (const float*)packed;
-        a.acts = acts;
+        a.signs = reinterpret_cast<const uint32_t*>(acts + n_pad * DF_D * DF_W);
         a.g_dxyz = g_d_xyz; a.g_dsh = g_d_sh;
         a.dz = dz; a.dzh = dzh;
         hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(n_pad / DF_TILE)), dim3(256), DF_LDS, s, a);

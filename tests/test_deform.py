@@ -250,3 +250,44 @@ def test_zero_points():
     assert d_xyz.shape == (0, 3) and d_sh.shape == (0, 16, 3) and d_rot.shape == (0, 4) and d_sh_p.shape == (0, 16, 2)
     (d_xyz.sum() + d_sh.sum()).backward()
     assert not net.linear[0].weight.grad.any() and not net.r.bias.grad.any()
+
+
+@pytest.mark.gpu
+def test_full_size_properties():
+    """1 M points (every Gaussian of the metric frame dynamic): size-independent properties instead of the oracle."""
+    dev = torch.device("cuda:0")
+    net, params = _net(16, dev)
+    n = 1_000_000
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.rand((n, 3), generator=g).to(dev)
+    t = torch.rand((n, 1), generator=g).to(dev)
+    with torch.no_grad():
+        full = net(x, t)
+    # (1) a point's result does not depend on the batch it is in or on its place in it (bit-exact)
+    idx = torch.randperm(n, generator=g)[:5000].to(dev)
+    with torch.no_grad():
+        part = net(x[idx], t[idx])
+    assert torch.equal(part[0], full[0][idx]) and torch.equal(part[2], full[2][idx])
+    # ... and a sample of it agrees with the oracle
+    sel = idx[:256].cpu().numpy()
+    ref = deform_ref.forward(params, x.cpu().numpy()[sel], t.cpu().numpy()[sel], dtype=np.float64)
+    assert _rel(full[0][idx[:256]].cpu().numpy(), ref[0]) < FWD_TOL and _rel(full[2][idx[:256]].cpu().numpy(), ref[2]) < FWD_TOL
+
+    def grads(sl, scale):
+        net.zero_grad(set_to_none=True)
+        d_xyz, _, d_sh, _ = net(x[sl], t[sl])
+        torch.autograd.backward([d_xyz, d_sh], [g_dxyz[sl] * scale, g_dsh[sl] * scale])
+        return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    g_dxyz = torch.randn((n, 3), generator=g).to(dev)
+    g_dsh = torch.randn((n, 16, 3), generator=g).to(dev)
+    whole = grads(slice(0, n), 1.0)
+    # (2) the backward is linear in the upstream gradient: a power-of-two scale is exact
+    twice = grads(slice(0, n), 2.0)
+    assert all(torch.equal(twice[k], 2 * whole[k]) for k in whole)
+    # (3) ... and additive over a partition of the points (different split sums: fp32 tolerance)
+    h = 437_123
+    a, b = grads(slice(0, h), 1.0), grads(slice(h, n), 1.0)
+    for k in whole:
+        assert _rel((a[k] + b[k]).cpu().numpy(), whole[k].cpu().numpy()) < 2e-5, k
+    assert len(whole) == 24
