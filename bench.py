@@ -289,6 +289,16 @@ def deform_extra(dev, n=300_000, steps=10, warmup=3):
     ms = timed(ours, steps, warmup)
     fwd_ms = timed(ours_fwd, steps, warmup)
     eager_ms = timed(eager, max(3, steps // 2), 2)
+    # CPU beside it: the numpy oracle (fp32 BLAS on the host cores), forward + backward, on a bounded sample
+    import os
+    import time
+    ns = 20_000
+    xs, ts = x[:ns].cpu().numpy(), np.full((ns, 1), 0.4, np.float32)
+    gx, gs = g_dxyz[:ns].cpu().numpy(), g_dsh[:ns].cpu().numpy()
+    deform_ref.backward(params, xs[:2000], ts[:2000], gx[:2000], gs[:2000])
+    t0 = time.perf_counter()
+    deform_ref.backward(params, xs, ts, gx, gs)
+    cpu_s = time.perf_counter() - t0
     macs_fwd = 76 * 256 + 6 * 256 * 256 + 332 * 256 + 51 * 256
     macs = macs_fwd + (7 * 256 * 256 + 51 * 256) + macs_fwd
     tf = 2.0 * macs * n / (ms * 1e-3) / 1e12
@@ -297,7 +307,10 @@ def deform_extra(dev, n=300_000, steps=10, warmup=3):
             "fwd_bwd_ms": ms, "inference_fwd_ms": fwd_ms, "eager_torch_ms": eager_ms, "speedup_vs_eager": eager_ms / ms,
             "algorithmic_flops": 2.0 * macs * n, "achieved_TFLOPs": tf, "inference_TFLOPs": tf_fwd,
             "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS,
-            "inference_frac_of_peak": tf_fwd / FP32_MFMA_PEAK_TFLOPS}
+            "inference_frac_of_peak": tf_fwd / FP32_MFMA_PEAK_TFLOPS,
+            "points_per_s": n / (ms * 1e-3),
+            "cpu_baseline": {"value": ns / cpu_s, "unit": "points/s", "cores": os.cpu_count(), "kind": "port",
+                             "sample": "%d points, forward + backward of oracle/deform_ref.py (numpy fp32 BLAS)" % ns}}
 
 
 def deform_exchange(dev, dist, rank, world, n=300_000, steps=10, warmup=3):

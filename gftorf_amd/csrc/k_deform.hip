@@ -23,14 +23,20 @@ constexpr int DF_IN = GFT_DEFORM_INPUTS;   // 76
 constexpr int DF_INK = 80;                 // encoding as a GEMM k-extent (multiple of 16, zero rows)
 constexpr int DF_EMB = 96;                 // stored encoding row (3 column tiles of the weight-gradient GEMM)
 constexpr int DF_HEAD = 64;                // head columns: 48 (d_sh, [coefficient][channel]) + 3 (d_xyz) + pad
-constexpr int DF_TILE = 64;                // points per workgroup
+// 32-point row tiles per wave = points per workgroup / 32.  Measured on MI355X (300 k points): forward 64 points
+// 2.70 ms (one workgroup per CU; 2.83 with two), 96 points 3.21 ms; backward 64 points 2.89 ms, 96 points 2.81 ms.
+constexpr int DF_NR_FWD = 2;
+constexpr int DF_NR_BWD = 3;
+constexpr int DF_PAD = 192;                // point counts are padded to a multiple of both walk tiles and of 64
+constexpr int DF_ES = 84;                  // LDS row stride of the encoding
+constexpr int DF_DW_TILE = 64;             // point granularity of the weight-gradient splits
 constexpr int DF_HS = 260;                 // LDS row strides (floats): 16-byte reads of 16 rows hit 16 bank groups
 
 // packed parameter buffer (floats): forward stream, backward stream, biases
 constexpr int64_t DF_F_SZ0 = (int64_t)DF_INK * DF_W;                  // 20480
 constexpr int64_t DF_F_SZ = (int64_t)DF_W * DF_W;                     // 65536
 constexpr int64_t DF_F_HEAD_SZ = (int64_t)DF_W * DF_HEAD;             // 16384
-// forward stream, in the order it is used: L0 | L5 (encoding rows) | L1 L2 L3 L4 | L5 (hidden rows) | L6 | L7 | heads
+// forward stream, in the order it is used: L0 | L1 L2 L3 L4 | L5 (encoding rows) | L5 (hidden rows) | L6 | L7 | heads
 constexpr int64_t DF_F_TOTAL = 2 * DF_F_SZ0 + 7 * DF_F_SZ + DF_F_HEAD_SZ;   // 516096
 constexpr int64_t DF_B_BASE = DF_F_TOTAL;
 constexpr int64_t DF_B_TOTAL = DF_F_HEAD_SZ + 7 * DF_F_SZ;            // 475136
@@ -70,14 +76,15 @@ __global__ __launch_bounds__(256) void k_deform_pack(PackArgs a)
     float v = 0.f;
     if (e < DF_F_TOTAL) {
         // forward stream: per segment [k/4][ncol][4], element (k, n) = W[n][k]
-        if (e < 2 * DF_F_SZ0) {
+        const int64_t enc5 = DF_F_SZ0 + 4 * DF_F_SZ;          // start of layer 5's encoding rows
+        if (e < DF_F_SZ0 || (e >= enc5 && e < enc5 + DF_F_SZ0)) {
             const int l = e < DF_F_SZ0 ? 0 : 5;
-            const int64_t r = e < DF_F_SZ0 ? e : e - DF_F_SZ0;
+            const int64_t r = e < DF_F_SZ0 ? e : e - enc5;
             const int kq = (int)(r / (DF_W * 4)), n = (int)((r >> 2) % DF_W), k = 4 * kq + (int)(r & 3);
             const int ld = l == 0 ? DF_IN : DF_W + DF_IN;
             v = k < DF_IN ? a.p.linear_w[l][(size_t)n * ld + k] : 0.f;
         } else if (e < DF_F_TOTAL - DF_F_HEAD_SZ) {
-            const int64_t r1 = e - 2 * DF_F_SZ0;
+            const int64_t r1 = e < enc5 ? e - DF_F_SZ0 : e - 2 * DF_F_SZ0;
             const int l = 1 + (int)(r1 / DF_F_SZ);
             const int64_t r = r1 % DF_F_SZ;
             const int kq = (int)(r / (DF_W * 4)), n = (int)((r >> 2) % DF_W), k = 4 * kq + (int)(r & 3);
@@ -212,30 +219,31 @@ struct FwdArgs {
 
 constexpr int DF_BIAS_FLOATS = DF_D * DF_W + DF_HEAD;      // 2368
 constexpr int DF_SIGN_WORDS = DF_W / 32;                   // ReLU sign bits of one point and layer: 8 words
-constexpr size_t DF_LDS = (size_t)DF_TILE * DF_HS * 4;   // 66560: two workgroups per CU
-constexpr size_t DF_FWD_LDS = DF_LDS + DF_BIAS_FLOATS * 4;   // + all biases: 76032
+constexpr size_t DF_FWD_LDS = ((size_t)32 * DF_NR_FWD * (DF_HS + DF_ES) + DF_BIAS_FLOATS) * 4;   // activations + encoding + all biases: 97536
+constexpr size_t DF_BWD_LDS = (size_t)32 * DF_NR_BWD * DF_HS * 4;                               // 99840
 
 template <bool SAVE>
-__global__ __launch_bounds__(256, 2) void k_deform_fwd(FwdArgs a)
+__global__ __launch_bounds__(256) void k_deform_fwd(FwdArgs a)
 {
     extern __shared__ float4 df_lds[];
     float* hA = reinterpret_cast<float*>(df_lds);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
-    const int64_t p0 = (int64_t)blockIdx.x * DF_TILE;
+    const int64_t p0 = (int64_t)blockIdx.x * (32 * DF_NR_FWD);
     const int n0 = wave * 64;
     const float4* wlane = reinterpret_cast<const float4*>(a.packed) + hh * DF_W + n0 + li;
     float4 wcur[2][2];
     load_w<2, DF_W>(wcur, wlane);
     // all biases (9.5 KB) go to LDS once: an epilogue then waits for an LDS read, not for L2
-    float* bL = hA + DF_TILE * DF_HS;
+    float* eA = hA + (32 * DF_NR_FWD) * DF_HS;
+    float* bL = eA + (32 * DF_NR_FWD) * DF_ES;
     for (int q = tid; q < DF_BIAS_FLOATS; q += 256) bL[q] = a.packed[DF_BIAS_BASE + q];
 
-    // positional encoding (time_utils.py:24-53): [x, sin(2^f x), cos(2^f x)]_f for all dims, then t;
-    // it sits in the first 80 columns of the activation tile until layer 0 has been multiplied
-    {
-        const int pt = tid & 63, grp = tid >> 6;
+    // positional encoding (time_utils.py:24-53): [x, sin(2^f x), cos(2^f x)]_f for all dims, then t
+    for (int pb = 0; pb < (32 * DF_NR_FWD); pb += 64) {
+        const int pt = pb + (tid & 63), grp = tid >> 6;
+        if (pt >= (32 * DF_NR_FWD)) break;
         const int64_t p = p0 + pt;
-        float* e = hA + pt * DF_HS;
+        float* e = eA + pt * DF_ES;
         if (grp < 3) {
             const float v = p < a.n ? a.xyz[3 * p + grp] : 0.f;
             e[grp] = v;
@@ -261,31 +269,23 @@ __global__ __launch_bounds__(256, 2) void k_deform_fwd(FwdArgs a)
     }
     __syncthreads();
     if (SAVE) {
-        for (int q = tid; q < DF_TILE * DF_EMB; q += 256) {
+        for (int q = tid; q < (32 * DF_NR_FWD) * DF_EMB; q += 256) {
             const int row = q / DF_EMB, col = q - row * DF_EMB;
-            a.emb[(p0 + row) * DF_EMB + col] = col < DF_INK ? hA[row * DF_HS + col] : 0.f;
+            a.emb[(p0 + row) * DF_EMB + col] = col < DF_INK ? eA[row * DF_ES + col] : 0.f;
         }
     }
 
     const float* h_lane = hA + li * DF_HS + 4 * hh;
-    f32x16 acc[2][2], acc5[2][2];
-    // layer 0, and the encoding's share of layer 5 (time_utils.py:112-113 concatenates it in front of the
-    // activations after layer 4): both multiply the encoding, which is in LDS only now
-    zero_acc(acc);
-    stream_gemm<2, 2, DF_W>(acc, h_lane, DF_HS, DF_INK / 16, wlane, wcur, true);
-    zero_acc(acc5);
-    stream_gemm<2, 2, DF_W>(acc5, h_lane, DF_HS, DF_INK / 16, wlane, wcur, true);
+    const float* e_lane = eA + li * DF_ES + 4 * hh;
+    f32x16 acc[DF_NR_FWD][2];
     for (int l = 0; l < DF_D; l++) {
-        if (l > 0) {
-            if (l == 5) {
-#pragma unroll
-                for (int rt = 0; rt < 2; rt++)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ct++) acc[rt][ct] = acc5[rt][ct];
-            } else {
-                zero_acc(acc);
-            }
-            stream_gemm<2, 2, DF_W>(acc, h_lane, DF_HS, DF_W / 16, wlane, wcur, l < 7);
+        zero_acc(acc);
+        if (l == 0) {
+            stream_gemm<DF_NR_FWD, 2, DF_W>(acc, e_lane, DF_ES, DF_INK / 16, wlane, wcur, true);
+        } else {
+            // after layer 4 the encoding is concatenated in front (time_utils.py:112-113)
+            if (l == 5) stream_gemm<DF_NR_FWD, 2, DF_W>(acc, e_lane, DF_ES, DF_INK / 16, wlane, wcur, true);
+            stream_gemm<DF_NR_FWD, 2, DF_W>(acc, h_lane, DF_HS, DF_W / 16, wlane, wcur, l < 7);
         }
         // bias, ReLU -> next layer's A tile
         float4 bv[2][4];
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void k_deform_fwd(FwdArgs a)
                 bv[ct][g] = *reinterpret_cast<const float4*>(bL + l * DF_W + n0 + 32 * ct + acc_col4(g, hh));
         __syncthreads();      // every wave is past its last read of this layer's input
 #pragma unroll
-        for (int rt = 0; rt < 2; rt++)
+        for (int rt = 0; rt < DF_NR_FWD; rt++)
 #pragma unroll
             for (int ct = 0; ct < 2; ct++) {
                 uint32_t bits = 0;
@@ -323,31 +323,51 @@ __global__ __launch_bounds__(256, 2) void k_deform_fwd(FwdArgs a)
             }
         __syncthreads();
     }
-    // heads: 64 columns, one 32x32 tile per wave
+    // heads: 64 columns
     {
-        f32x16 hacc[1][1];
-        zero_acc(hacc);
-        const int rt = wave >> 1, ct = wave & 1;
+        const int ct = wave & 1;
         const float4* hl = reinterpret_cast<const float4*>(a.packed + DF_F_TOTAL - DF_F_HEAD_SZ) + hh * DF_HEAD + 32 * ct + li;
         float4 hw[2][1];
         load_w<1, DF_HEAD>(hw, hl);
-        stream_gemm<1, 1, DF_HEAD>(hacc, hA + (32 * rt + li) * DF_HS + 4 * hh, DF_HS, DF_W / 16, hl, hw, false);
-        const int64_t p = p0 + 32 * rt + li;
-        if (p < a.n) {
+        auto store_head = [&](const f32x16& t, int row0) {
+            const int64_t p = p0 + row0 + li;
+            if (p < a.n) {
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int col = 32 * ct + acc_col4(g, hh);
-                const float4 bq = *reinterpret_cast<const float4*>(bL + DF_D * DF_W + col);
-                const float4 v = make_float4(hacc[0][0][4 * g] + bq.x, hacc[0][0][4 * g + 1] + bq.y, hacc[0][0][4 * g + 2] + bq.z,
-                                             hacc[0][0][4 * g + 3] + bq.w);
-                if (col < 48) {
-                    *reinterpret_cast<float4*>(a.d_sh + p * 48 + col) = v;
-                } else if (col == 48) {
-                    a.d_xyz[p * 3] = v.x;
-                    a.d_xyz[p * 3 + 1] = v.y;
-                    a.d_xyz[p * 3 + 2] = v.z;
+                for (int g = 0; g < 4; g++) {
+                    const int col = 32 * ct + acc_col4(g, hh);
+                    const float4 bq = *reinterpret_cast<const float4*>(bL + DF_D * DF_W + col);
+                    const float4 v = make_float4(t[4 * g] + bq.x, t[4 * g + 1] + bq.y, t[4 * g + 2] + bq.z, t[4 * g + 3] + bq.w);
+                    if (col < 48) {
+                        *reinterpret_cast<float4*>(a.d_sh + p * 48 + col) = v;
+                    } else if (col == 48) {
+                        a.d_xyz[p * 3] = v.x;
+                        a.d_xyz[p * 3 + 1] = v.y;
+                        a.d_xyz[p * 3 + 2] = v.z;
+                    }
                 }
             }
+        };
+        if (DF_NR_FWD == 3) {
+            // 3 row tiles x 2 column tiles over 4 waves: waves 0,1 take row tiles 0,1, waves 2,3 row tile 2
+            if (wave < 2) {
+                f32x16 hacc[2][1];
+                zero_acc(hacc);
+                stream_gemm<2, 1, DF_HEAD>(hacc, hA + li * DF_HS + 4 * hh, DF_HS, DF_W / 16, hl, hw, false);
+                store_head(hacc[0][0], 0);
+                store_head(hacc[1][0], 32);
+            } else {
+                f32x16 hacc[1][1];
+                zero_acc(hacc);
+                stream_gemm<1, 1, DF_HEAD>(hacc, hA + (64 + li) * DF_HS + 4 * hh, DF_HS, DF_W / 16, hl, hw, false);
+                store_head(hacc[0][0], 64);
+            }
+        } else {
+            // 2 x 2 tiles: one per wave
+            const int r0 = 32 * (wave >> 1);
+            f32x16 hacc[1][1];
+            zero_acc(hacc);
+            stream_gemm<1, 1, DF_HEAD>(hacc, hA + (r0 + li) * DF_HS + 4 * hh, DF_HS, DF_W / 16, hl, hw, false);
+            store_head(hacc[0][0], r0);
         }
     }
 }
@@ -364,19 +384,19 @@ struct BwdArgs {
     float* dzh;             // [n_pad][64]
 };
 
-__global__ __launch_bounds__(256, 2) void k_deform_bwd(BwdArgs a)
+__global__ __launch_bounds__(256) void k_deform_bwd(BwdArgs a)
 {
     extern __shared__ float4 df_lds[];
     float* gA = reinterpret_cast<float*>(df_lds);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
-    const int64_t p0 = (int64_t)blockIdx.x * DF_TILE;
+    const int64_t p0 = (int64_t)blockIdx.x * (32 * DF_NR_BWD);
     const int n0 = wave * 64;
     const float4* wlane = reinterpret_cast<const float4*>(a.packed + DF_B_BASE) + hh * DF_W + n0 + li;
     float4 wcur[2][2];
     load_w<2, DF_W>(wcur, wlane);
 
     // upstream gradients as the head's output tile: [d_sh (48) | d_xyz (3) | 0], in the first 64 columns
-    for (int q = tid; q < DF_TILE * DF_HEAD; q += 256) {
+    for (int q = tid; q < (32 * DF_NR_BWD) * DF_HEAD; q += 256) {
         const int row = q >> 6, col = q & 63;
         const int64_t p = p0 + row;
         float v = 0.f;
@@ -390,22 +410,22 @@ __global__ __launch_bounds__(256, 2) void k_deform_bwd(BwdArgs a)
     __syncthreads();
 
     const float* g_lane = gA + li * DF_HS + 4 * hh;
-    f32x16 acc[2][2];
+    f32x16 acc[DF_NR_BWD][2];
     // ReLU signs of the lane's point and the wave's 64 columns (2 words per row tile), fetched before the
     // multiply that produces the gradient they gate
-    uint2 sg[2];
+    uint2 sg[DF_NR_BWD];
     auto load_signs = [&](int l) {
 #pragma unroll
-        for (int rt = 0; rt < 2; rt++)
+        for (int rt = 0; rt < DF_NR_BWD; rt++)
             sg[rt] = *reinterpret_cast<const uint2*>(a.signs + ((int64_t)l * a.n_pad + p0 + 32 * rt + li) * DF_SIGN_WORDS + 2 * wave);
     };
     load_signs(DF_D - 1);
     zero_acc(acc);
-    stream_gemm<2, 2, DF_W>(acc, g_lane, DF_HS, DF_HEAD / 16, wlane, wcur, true);   // dh_7
+    stream_gemm<DF_NR_BWD, 2, DF_W>(acc, g_lane, DF_HS, DF_HEAD / 16, wlane, wcur, true);   // dh_7
     for (int l = DF_D - 1; l >= 0; l--) {
         __syncthreads();      // every wave is past its last read of the previous gradient tile
 #pragma unroll
-        for (int rt = 0; rt < 2; rt++)
+        for (int rt = 0; rt < DF_NR_BWD; rt++)
 #pragma unroll
             for (int ct = 0; ct < 2; ct++) {
                 const int row = 32 * rt + li;
@@ -427,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void k_deform_bwd(BwdArgs a)
         __syncthreads();
         load_signs(l - 1);
         zero_acc(acc);
-        stream_gemm<2, 2, DF_W>(acc, g_lane, DF_HS, DF_W / 16, wlane, wcur, l > 1);   // dh_{l-1}
+        stream_gemm<DF_NR_BWD, 2, DF_W>(acc, g_lane, DF_HS, DF_W / 16, wlane, wcur, l > 1);   // dh_{l-1}
     }
 }
 
@@ -530,8 +550,8 @@ __global__ __launch_bounds__(256) void k_deform_dw(DwArgs a)
 {
     const int job = blockIdx.x, split = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
-    const int64_t p_begin = (int64_t)split * a.tiles_per_split * DF_TILE;
-    int64_t p_end = p_begin + (int64_t)a.tiles_per_split * DF_TILE;
+    const int64_t p_begin = (int64_t)split * a.tiles_per_split * DF_DW_TILE;
+    int64_t p_end = p_begin + (int64_t)a.tiles_per_split * DF_DW_TILE;
     if (p_end > a.n_pad) p_end = a.n_pad;
     float* part = a.part + (int64_t)split * DW_PART_FLOATS;
     const int64_t plane = a.n_pad * DF_W;
@@ -585,11 +605,11 @@ __global__ __launch_bounds__(256) void k_deform_reduce(ReduceArgs a)
     sg.dst[(int64_t)row * sg.dst_ld + sg.dst_col0 + col] = (s0 + s1) + (s2 + s3);
 }
 
-int64_t pad_points(int64_t n) { return (n + DF_TILE - 1) / DF_TILE * DF_TILE; }
+int64_t pad_points(int64_t n) { return (n + DF_PAD - 1) / DF_PAD * DF_PAD; }
 
 int dw_splits(int64_t n_pad, int* tiles_per_split)
 {
-    const int64_t tiles = n_pad / DF_TILE;
+    const int64_t tiles = n_pad / DF_DW_TILE;
     // 7 heavy jobs per split: 146 splits = 1022 workgroups = 4 per CU
     int64_t splits = tiles / 4;
     if (splits < 1) splits = 1;
@@ -605,7 +625,7 @@ void set_attrs()
     if (attrs_set) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_BWD_LDS);
     attrs_set = true;
 }
 
@@ -651,7 +671,7 @@ extern "C" int gft_deform_forward(void* hip_stream, int64_t n, const float* xyz,
     if (n == 0) return 0;
     if (!xyz || !t || !packed || !d_xyz || !d_sh) return gft_fail("gft_deform_forward: NULL argument");
     if (t_stride != 0 && t_stride != 1) return gft_fail("gft_deform_forward: t_stride must be 0 or 1");
-    if (n > ((int64_t)1 << 31) * DF_TILE / 2) return gft_fail("gft_deform_forward: n too large");
+    if (n > ((int64_t)1 << 31) * 16) return gft_fail("gft_deform_forward: n too large");
     set_attrs();
     FwdArgs a;
     a.n = n;
@@ -665,7 +685,8 @@ extern "C" int gft_deform_forward(void* hip_stream, int64_t n, const float* xyz,
     a.signs = saved ? reinterpret_cast<uint32_t*>(a.acts + a.n_pad * DF_D * DF_W) : nullptr;
     a.d_xyz = d_xyz;
     a.d_sh = d_sh;
-    const dim3 grid((unsigned)(a.n_pad / DF_TILE));
+    // all padded rows are computed and saved: the weight-gradient GEMMs multiply them (by zero gradients)
+    const dim3 grid((unsigned)(a.n_pad / (32 * DF_NR_FWD)));
     if (saved) hipLaunchKernelGGL(k_deform_fwd<true>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
     else hipLaunchKernelGGL(k_deform_fwd<false>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
     GFT_CHECK_HIP(hipGetLastError());
@@ -713,7 +734,7 @@ extern "C" int gft_deform_backward(void* hip_stream, int64_t n, const void* pack
         a.signs = reinterpret_cast<const uint32_t*>(acts + n_pad * DF_D * DF_W);
         a.g_dxyz = g_d_xyz; a.g_dsh = g_d_sh;
         a.dz = dz; a.dzh = dzh;
-        hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(n_pad / DF_TILE)), dim3(256), DF_LDS, s, a);
+        hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(n_pad / (32 * DF_NR_BWD))), dim3(256), DF_BWD_LDS, s, a);
         GFT_CHECK_HIP(hipGetLastError());
     }
     int tps;

@@ -166,9 +166,9 @@ def test_deform_size_queries_and_argument_errors(lib):
     # 20480 + 6*65536 + 86016 + 16384 forward, 16384 + 7*65536 backward, 2112 biases
     assert lib.gft_deform_packed_bytes() == 993344 * 4
     assert lib.gft_deform_saved_bytes(0) == 0 and lib.gft_deform_scratch_bytes(0) == 0
-    # per point (padded to 64): 96 encoding + 8*256 activations + 8*8 words of ReLU sign bits
-    assert lib.gft_deform_saved_bytes(1) == 64 * (96 + 2048 + 64) * 4
-    assert lib.gft_deform_saved_bytes(65) == 128 * (96 + 2048 + 64) * 4
+    # per point (padded to 192): 96 encoding + 8*256 activations + 8*8 words of ReLU sign bits
+    assert lib.gft_deform_saved_bytes(1) == 192 * (96 + 2048 + 64) * 4
+    assert lib.gft_deform_saved_bytes(193) == 384 * (96 + 2048 + 64) * 4
     assert lib.gft_deform_scratch_bytes(1000) > 1024 * (2048 + 64) * 4
     assert lib.gft_deform_pack(None, None, None) != 0
     assert "NULL" in _lib.last_error()
