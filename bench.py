@@ -376,6 +376,56 @@ def deform_exchange(dev, dist, rank, world, n=300_000, steps=10, warmup=3):
             "replicas_identical": bool(torch.equal(lo, hi))}
 
 
+def densify_extra(dev, P=1_000_000):
+    """SURVEY 8(f) row 4 (bookkeeping part) beside the headline metric: the per-iteration statistics update
+    (train.py:441-449) and one pruning step over the model's 11 parameter tensors with their Adam moments
+    and the 3 statistics tensors (scene/gaussian_model.py:473-514), against the reference's eager statements
+    (oracle/densify_ref.py) on the same device.  Algorithmic bytes: statistics 1 + 33 per visible Gaussian
+    (flag; xy gradient, pixels, radius, and three read-modify-writes); pruning: every row read once, every
+    kept row written once, + mask and rank."""
+    import numpy as np
+    import torch
+    from gftorf_amd import densify
+    from oracle import densify_ref
+    g = torch.Generator().manual_seed(12)
+    f = lambda *s: torch.randn(s, generator=g).to(dev)
+    vis = (torch.rand(P, generator=g) < 0.9).to(dev)
+    grad, pixels = f(P, 3) * 1e-3, (torch.rand((P, 1), generator=g) * 300).floor().to(dev)
+    radii = (torch.rand(P, generator=g) * 40).to(torch.int32).to(dev) * vis
+    acc, den, mr = torch.zeros((P, 1), device=dev), torch.zeros((P, 1), device=dev), torch.zeros(P, device=dev)
+
+    def timed(fn, k, w=2):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(k):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / k
+
+    stats_ms = timed(lambda: densify.add_densification_stats(acc, den, mr, grad, vis, pixels, radii), 20)
+    stats_eager_ms = timed(lambda: densify_ref.add_densification_stats_eager(acc, den, mr, grad, vis, pixels, radii), 5)
+    nvis = int(vis.sum().item())
+    stats_bytes = P + 44 * nvis
+    rows = [(3,), (1, 3), (15, 3), (1, 1), (15, 1), (1, 1), (15, 1), (1,), (3,), (4,), (3,)]
+    tensors = [f(P, *r) for r in rows for _ in range(3)] + [acc, den, mr]        # parameter + two moments each
+    keep = (torch.rand(P, generator=g) < 0.9).to(dev)
+    prune_ms = timed(lambda: densify.select_rows(keep, *tensors), 5)
+    prune_eager_ms = timed(lambda: [t[keep] for t in tensors], 3)
+    nkeep = int(keep.sum().item())
+    row_bytes = sum(t.numel() // P * 4 for t in tensors)
+    prune_bytes = P * (row_bytes + 1 + 4 + 4) + nkeep * row_bytes
+    return {"what": "per-Gaussian bookkeeping (SURVEY 8(f)#4), %d Gaussians" % P,
+            "stats_ms": stats_ms, "stats_eager_torch_ms": stats_eager_ms, "stats_speedup": stats_eager_ms / stats_ms,
+            "stats_GBs": stats_bytes / (stats_ms * 1e-3) / 1e9, "stats_frac_of_hbm_peak": stats_bytes / (stats_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "prune_tensors": len(tensors), "prune_ms": prune_ms, "prune_eager_torch_ms": prune_eager_ms,
+            "prune_speedup": prune_eager_ms / prune_ms, "prune_GBs": prune_bytes / (prune_ms * 1e-3) / 1e9,
+            "prune_frac_of_hbm_peak": prune_bytes / (prune_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
 def knn_extra(dev, P=1_000_000):
     """SURVEY 8(f) row 3 beside the headline metric: distCUDA2 (mean squared distance to the 3
     nearest neighbours, the scale initialisation of scene/gaussian_model.py:194-199) on a
@@ -556,7 +606,8 @@ def main():
             del state, step
             torch.cuda.empty_cache()
             out["extras"] = {"assemble_inputs": assemble_extra(dev), "knn": knn_extra(dev),
-                             "adam": adam_extra(dev), "deform_network": deform_extra(dev)}
+                             "adam": adam_extra(dev), "deform_network": deform_extra(dev),
+                             "densify": densify_extra(dev)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, budget_s=args.cpu_budget)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]

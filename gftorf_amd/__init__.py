@@ -11,6 +11,7 @@ from .assemble import assemble_inputs  # noqa: F401
 from .knn import distCUDA2  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
 from .deform import DeformNetwork  # noqa: F401
+from . import densify  # noqa: F401
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "assemble_inputs", "distCUDA2", "FusedAdam",
-           "DeformNetwork"]
+           "DeformNetwork", "densify"]

@@ -115,6 +115,7 @@ EXPORTS = [
     "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step",
     "gft_deform_packed_bytes", "gft_deform_saved_bytes", "gft_deform_scratch_bytes", "gft_deform_pack",
     "gft_deform_forward", "gft_deform_backward",
+    "gft_densify_stats", "gft_rows_rank_scratch_bytes", "gft_rows_rank", "gft_rows_gather",
 ]
 
 
@@ -164,6 +165,14 @@ def load():
     lib.gft_deform_backward.restype = C.c_int
     lib.gft_deform_backward.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(DeformParams)]
+    lib.gft_densify_stats.restype = C.c_int
+    lib.gft_densify_stats.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8
+    lib.gft_rows_rank_scratch_bytes.restype = C.c_size_t
+    lib.gft_rows_rank_scratch_bytes.argtypes = [C.c_int64]
+    lib.gft_rows_rank.restype = C.c_int
+    lib.gft_rows_rank.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.gft_rows_gather.restype = C.c_int
+    lib.gft_rows_gather.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.gft_knn_scratch_bytes.restype = C.c_size_t
     lib.gft_knn_scratch_bytes.argtypes = [C.c_int32]
     lib.gft_knn_mean_dist2.restype = C.c_int

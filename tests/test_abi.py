@@ -24,7 +24,8 @@ def lib():
 
 
 HEADERS = [HEADER, os.path.join(ROOT, "include", "gftorf_assemble.h"), os.path.join(ROOT, "include", "gftorf_knn.h"),
-           os.path.join(ROOT, "include", "gftorf_optim.h"), os.path.join(ROOT, "include", "gftorf_deform.h")]
+           os.path.join(ROOT, "include", "gftorf_optim.h"), os.path.join(ROOT, "include", "gftorf_deform.h"),
+           os.path.join(ROOT, "include", "gftorf_densify.h")]
 
 
 def declared_functions():
