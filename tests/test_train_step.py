@@ -80,3 +80,61 @@ def test_training_iteration_chain_matches_composed_oracles():
             assert p.grad is None, name
         else:
             assert _rel(p.grad.cpu().numpy(), o_net[name]) < 2e-3, name
+
+
+@pytest.mark.gpu
+def test_optimisation_loop_reduces_the_loss():
+    """The reference's loop shape for 60 iterations on a small scene: network query, assembly, colour + ToF
+    render, L1 losses against renders of the unperturbed scene, backward, FusedAdam on the Gaussians, Adam on
+    the network, densification statistics.  The loss must fall: gradients are useful, not only equal."""
+    from gftorf_amd import DeformNetwork, FusedAdam, GaussianRasterizer, assemble_inputs, densify
+    dev = torch.device("cuda:0")
+    scene = helpers.small_scene(P=1500, W=96, H=64, seed=33)
+    g = scene["gaussians"]
+    P = g["means3D"].shape[0]
+    rng = np.random.default_rng(3)
+    mask = torch.tensor(rng.random(P) < 0.3, device=dev)
+    t32 = lambda a: torch.tensor(np.asarray(a, np.float32), device=dev)
+    rast = GaussianRasterizer(raster_settings=helpers.gpu_settings(scene, dev))
+
+    def render(xyz, opac, scal, rot, fc, fp):
+        ssp = torch.zeros((P, 3), device=dev, requires_grad=True)
+        out = rast(means3D=xyz, means2D=ssp, opacities=opac, shs=fc, shs_p=fp, scales=scal, rotations=rot,
+                   phase_offset=scene["phase_offset"], dc_offset=scene["dc_offset"])
+        return dict(zip(helpers.OUT_NAMES, out)), ssp
+
+    with torch.no_grad():
+        target, _ = render(t32(g["means3D"]), t32(g["opacities"]).reshape(P, 1), t32(g["scales"]), t32(g["rotations"]),
+                           t32(g["shs"]), t32(g["shs_p"]))
+    # start from a perturbed copy; the dynamic third is additionally displaced through the network
+    leaf = dict(xyz=t32(g["means3D"] + rng.normal(0, 0.01, (P, 3))), opacity=t32(g["opacities"]).reshape(P, 1) * 0.8,
+                scaling=t32(g["scales"] * 1.15), rotation_raw=t32(g["rotations"]), fc=t32(g["shs"] * 0.8), fp=t32(g["shs_p"] * 0.9))
+    for v in leaf.values():
+        v.requires_grad_(True)
+    net = DeformNetwork().to(dev)
+    torch.manual_seed(0)
+    for n_, p_ in net.named_parameters():
+        torch.nn.init.normal_(p_, 0.0, 0.03 if n_.startswith("linear") and n_.endswith("weight") else 1e-3)
+    opt = FusedAdam([{"params": [v], "lr": lr, "name": k} for (k, v), lr in
+                     zip(leaf.items(), (2e-4, 1e-2, 2e-3, 1e-3, 2e-3, 2e-3))], lr=0.0, eps=1e-15)
+    opt_net = torch.optim.Adam(net.parameters(), lr=1e-4, eps=1e-15)
+    x_n = ((leaf["xyz"].detach() - leaf["xyz"].detach().min(0).values) /
+           (leaf["xyz"].detach().max(0).values - leaf["xyz"].detach().min(0).values))[mask]
+    acc_s, den_s, maxr = torch.zeros((P, 1), device=dev), torch.zeros((P, 1), device=dev), torch.zeros(P, device=dev)
+    losses = []
+    for it in range(60):
+        d_xyz, d_rot, d_sh, d_sh_p = net(x_n, torch.full((1, 1), 0.5, device=dev).expand(x_n.size(0), -1))
+        ssp0 = torch.zeros((P, 3), device=dev)
+        m3, _, op, sc, rot, shs, shs_p = assemble_inputs(leaf["xyz"], ssp0, leaf["opacity"], leaf["scaling"],
+                                                         torch.nn.functional.normalize(leaf["rotation_raw"]), leaf["rotation_raw"],
+                                                         leaf["fc"], leaf["fp"], mask, d_xyz, d_rot, d_sh, d_sh_p)
+        out, ssp = render(m3, op, sc, rot, shs, shs_p)
+        loss = (out["color"] - target["color"]).abs().mean() + (out["phasor"] - target["phasor"]).abs().mean() * 0.5
+        loss.backward()
+        densify.add_densification_stats(acc_s, den_s, maxr, ssp.grad, out["radii"] > 0, out["pixels"], out["radii"])
+        opt.step(); opt_net.step()
+        opt.zero_grad(set_to_none=True); opt_net.zero_grad(set_to_none=True)
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses))
+    assert np.mean(losses[-5:]) < 0.6 * np.mean(losses[:5]), (losses[:5], losses[-5:])
+    assert den_s.sum() > 0 and maxr.max() > 0
