@@ -467,35 +467,42 @@ constexpr int64_t DW_PART_FLOATS = DW_OFF_BIAS + DF_D * DF_W + DF_HEAD;
 struct DwArgs {
     int64_t n_pad;
     int tiles_per_split;    // 64-point tiles per split
+    int splits;
     const float* emb; const float* acts; const float* dz; const float* dzh;
     float* part;            // [splits][DW_PART_FLOATS]
 };
 
-template <int WN, int WK, bool SPLIT_N, bool BIAS>
-__device__ __forceinline__ void dw_job(const float* A, int lda, const float* B, int ldb, float* out, int out_ld,
-                                       float* bias_out, int64_t p_begin, int64_t p_end, int wave, int li, int hh)
+// V consecutive floats as one load / store (V = 2, 3, 4: global_load_dwordx2/x3/x4)
+template <int V> struct FVec { float v[V]; };
+template <> struct __attribute__((aligned(8))) FVec<2> { float v[2]; };
+template <> struct __attribute__((aligned(16))) FVec<4> { float v[4]; };
+
+// One wave's block of dW: 32*VN output rows (n) x 32*VK input columns (k), summed over the points of the range.
+// A lane loads VN consecutive columns of dz and VK consecutive columns of x for its point (two vector loads per
+// two points instead of VN + VK scalar ones: the loads' address processing, not the multiplies, set the pace
+// of the scalar version) and uses element t in tile t, so tile (tn, tk) holds rows n = n_base + VN*i + tn and
+// columns k = k_base + VK*j + tk: VK consecutive k per lane and register -> vector stores.
+template <int VN, int VK, bool BIAS>
+__device__ __forceinline__ void dw_job(const float* A, int lda, int n_base, const float* B, int ldb, int k_base, float* out,
+                                       int out_ld, float* bias_out, bool write_bias, int64_t p_begin, int64_t p_end, int li, int hh)
 {
-    const int n_base = SPLIT_N ? wave * WN * 32 : 0;
-    const int k_base = SPLIT_N ? 0 : wave * WK * 32;
-    f32x16 acc[WN][WK];
+    f32x16 acc[VN][VK];
     zero_acc(acc);
-    float bsum[WN];
+    float bsum[VN];
 #pragma unroll
-    for (int x = 0; x < WN; x++) bsum[x] = 0.f;
-    const float* Ap = A + (p_begin + hh) * lda + n_base + li;
-    const float* Bp = B + (p_begin + hh) * ldb + k_base + li;
-    // operands of four 8-point steps in registers: three steps (12 k cycles of multiplies) in flight ahead of
-    // the one being multiplied -- the operands stream from HBM
-    float av[4][4][WN], bv[4][4][WK];
+    for (int x = 0; x < VN; x++) bsum[x] = 0.f;
+    const float* Ap = A + (p_begin + hh) * lda + n_base + VN * li;
+    const float* Bp = B + (p_begin + hh) * ldb + k_base + VK * li;
+    // operands of four 8-point steps in registers: three steps in flight ahead of the one being multiplied
+    FVec<VN> av[4][4];
+    FVec<VK> bv[4][4];
     int64_t pf = p_begin;          // first point of the next step to fetch
     auto fetch = [&](int slot) {
         if (pf < p_end) {
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-#pragma unroll
-                for (int x = 0; x < WN; x++) av[slot][s][x] = Ap[(int64_t)2 * s * lda + 32 * x];
-#pragma unroll
-                for (int y = 0; y < WK; y++) bv[slot][s][y] = Bp[(int64_t)2 * s * ldb + 32 * y];
+                av[slot][s] = *reinterpret_cast<const FVec<VN>*>(Ap + (int64_t)2 * s * lda);
+                bv[slot][s] = *reinterpret_cast<const FVec<VK>*>(Bp + (int64_t)2 * s * ldb);
             }
             Ap += 8 * lda;
             Bp += 8 * ldb;
@@ -506,11 +513,11 @@ __device__ __forceinline__ void dw_job(const float* A, int lda, const float* B, 
 #pragma unroll
         for (int s = 0; s < 4; s++) {
 #pragma unroll
-            for (int x = 0; x < WN; x++) {
-                if (BIAS) bsum[x] += av[slot][s][x];
+            for (int x = 0; x < VN; x++) {
+                if (BIAS) bsum[x] += av[slot][s].v[x];
 #pragma unroll
-                for (int y = 0; y < WK; y++)
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[slot][s][x], bv[slot][s][y], acc[x][y], 0, 0, 0);
+                for (int y = 0; y < VK; y++)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[slot][s].v[x], bv[slot][s].v[y], acc[x][y], 0, 0, 0);
             }
         }
     };
@@ -531,24 +538,36 @@ __device__ __forceinline__ void dw_job(const float* A, int lda, const float* B, 
         }
     }
 #pragma unroll
-    for (int x = 0; x < WN; x++)
+    for (int x = 0; x < VN; x++)
 #pragma unroll
-        for (int y = 0; y < WK; y++)
+        for (int q = 0; q < 16; q++) {
+            FVec<VK> o;
 #pragma unroll
-            for (int q = 0; q < 16; q++)
-                out[(int64_t)(n_base + 32 * x + acc_row(q, hh)) * out_ld + k_base + 32 * y + li] = acc[x][y][q];
-    if (BIAS && (SPLIT_N || wave == 0)) {
+            for (int y = 0; y < VK; y++) o.v[y] = acc[x][y][q];
+            *reinterpret_cast<FVec<VK>*>(out + (int64_t)(n_base + VN * acc_row(q, hh) + x) * out_ld + k_base + VK * li) = o;
+        }
+    if (BIAS && write_bias) {
 #pragma unroll
-        for (int x = 0; x < WN; x++) {
+        for (int x = 0; x < VN; x++) {
             const float tot = bsum[x] + __shfl_xor(bsum[x], 32);
-            if (hh == 0) bias_out[n_base + 32 * x + li] = tot;
+            if (hh == 0) bias_out[n_base + VN * li + x] = tot;
         }
     }
 }
 
 __global__ __launch_bounds__(256) void k_deform_dw(DwArgs a)
 {
-    const int job = blockIdx.x, split = blockIdx.y;
+    // heavy jobs first: the 7 hidden-layer GEMMs of every split (7 * 146 = 4 workgroups per CU, one resident at
+    // a time), then the three light jobs, which fill the CUs as they run out of heavy ones
+    int job, split;
+    if ((int)blockIdx.x < 7 * a.splits) {
+        job = blockIdx.x % 7;
+        split = blockIdx.x / 7;
+    } else {
+        const int r = blockIdx.x - 7 * a.splits;
+        job = 7 + r % 3;
+        split = r / 3;
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int64_t p_begin = (int64_t)split * a.tiles_per_split * DF_DW_TILE;
     int64_t p_end = p_begin + (int64_t)a.tiles_per_split * DF_DW_TILE;
@@ -556,19 +575,21 @@ __global__ __launch_bounds__(256) void k_deform_dw(DwArgs a)
     float* part = a.part + (int64_t)split * DW_PART_FLOATS;
     const int64_t plane = a.n_pad * DF_W;
     if (job < 7) {
-        // hidden-input layers 7..1 (heaviest first): x = act_{l-1}
+        // hidden-input layers 7..1 (heaviest first): x = act_{l-1}; waves take the four 128 x 128 quadrants
         const int l = 7 - job;
-        dw_job<2, 8, true, true>(a.dz + l * plane, DF_W, a.acts + (l - 1) * plane, DF_W, part + DW_OFF_L(l), DF_W,
-                                 part + DW_OFF_BIAS + l * DF_W, p_begin, p_end, wave, li, hh);
+        dw_job<4, 4, true>(a.dz + l * plane, DF_W, 128 * (wave & 1), a.acts + (l - 1) * plane, DF_W, 128 * (wave >> 1),
+                           part + DW_OFF_L(l), DF_W, part + DW_OFF_BIAS + l * DF_W, (wave >> 1) == 0, p_begin, p_end, li, hh);
     } else if (job == 7) {
-        dw_job<2, 3, true, true>(a.dz, DF_W, a.emb, DF_EMB, part + DW_OFF_L0, DF_EMB, part + DW_OFF_BIAS, p_begin, p_end,
-                                 wave, li, hh);
+        // layer 0 and the encoding rows of layer 5: x = encoding (96 stored columns); waves take 64 output rows each
+        dw_job<2, 3, true>(a.dz, DF_W, 64 * wave, a.emb, DF_EMB, 0, part + DW_OFF_L0, DF_EMB, part + DW_OFF_BIAS, true, p_begin,
+                           p_end, li, hh);
     } else if (job == 8) {
-        dw_job<2, 3, true, false>(a.dz + 5 * plane, DF_W, a.emb, DF_EMB, part + DW_OFF_L5E, DF_EMB, nullptr, p_begin, p_end,
-                                  wave, li, hh);
+        dw_job<2, 3, false>(a.dz + 5 * plane, DF_W, 64 * wave, a.emb, DF_EMB, 0, part + DW_OFF_L5E, DF_EMB, nullptr, false,
+                            p_begin, p_end, li, hh);
     } else {
-        dw_job<2, 2, false, true>(a.dzh, DF_HEAD, a.acts + 7 * plane, DF_W, part + DW_OFF_HEAD, DF_W,
-                                  part + DW_OFF_BIAS + DF_D * DF_W, p_begin, p_end, wave, li, hh);
+        // heads: 64 output rows, waves take 64 input columns each
+        dw_job<2, 2, true>(a.dzh, DF_HEAD, 0, a.acts + 7 * plane, DF_W, 64 * wave, part + DW_OFF_HEAD, DF_W,
+                           part + DW_OFF_BIAS + DF_D * DF_W, wave == 0, p_begin, p_end, li, hh);
     }
 }
 
@@ -743,9 +764,10 @@ extern "C" int gft_deform_backward(void* hip_stream, int64_t n, const void* pack
         DwArgs a;
         a.n_pad = n_pad;
         a.tiles_per_split = tps;
+        a.splits = splits;
         a.emb = emb; a.acts = acts; a.dz = dz; a.dzh = dzh;
         a.part = part;
-        hipLaunchKernelGGL(k_deform_dw, dim3(DW_JOBS, splits), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_deform_dw, dim3(DW_JOBS * splits), dim3(256), 0, s, a);
         GFT_CHECK_HIP(hipGetLastError());
     }
     {
