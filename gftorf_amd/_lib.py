@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 ACC_STRIDE = 16
 
 _lib = None
@@ -50,7 +50,7 @@ BACKWARD_FIELDS = [
 LAYOUT_FIELDS = [
     "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_rect", "geom_dirgrad", "geom_clamped",
     "geom_blockhist", "geom_total",
-    "img_pix_state", "img_ranges", "img_tile_max", "img_ctrl", "img_tile_cnt", "img_tile_cursor", "img_tile_order", "img_front_len", "img_unit_flag", "img_resume_state", "img_total",
+    "img_pix_state", "img_ranges", "img_tile_max", "img_ctrl", "img_tile_cnt", "img_tile_cursor", "img_tile_order", "img_front_len", "img_unit_flag", "img_resume_state", "img_pix_sums", "img_total",
     "bin_keys", "bin_point_list", "bin_total",
 ]
 

@@ -56,6 +56,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->img_front_len = o;   o = align_up(o + T * 4);
     L->img_unit_flag = o;   o = align_up(o + T * 16);
     L->img_resume_state = o; o = align_up(o + n * 64);
+    L->img_pix_sums = o;    o = align_up(o + n * 32);
     L->img_total = o;
 
     const size_t r = (size_t)(R > 0 ? R : 0);
@@ -94,6 +95,7 @@ ImgView gft_img_view(void* base, const gft_layout& L)
     v.front_len = (uint32_t*)(b + L.img_front_len);
     v.unit_flag = (uint32_t*)(b + L.img_unit_flag);
     v.resume_state = (float4*)(b + L.img_resume_state);
+    v.pix_sums = (float4*)(b + L.img_pix_sums);
     return v;
 }
 

@@ -23,6 +23,7 @@ struct GeomView {
 
 struct ImgView {
     float4* pix_state;    // [N] {final_T, n_contrib bits, w_z, w_z2}
+    float4* pix_sums;     // [N][2] {C0, C1, C2, R}, {I, Am, dist, A}: final sums of the blend, without background
     uint2* ranges;        // [T]
     uint32_t* tile_max;   // [T]
     uint32_t* ctrl;       // [8], directly followed by tile_cnt (one memset clears both)

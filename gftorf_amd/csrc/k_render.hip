@@ -28,7 +28,6 @@
 namespace {
 
 #define RB 64                // splats per staged batch = lanes per wave
-#define ACC_LDS_STRIDE 16
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -109,6 +108,7 @@ struct RenderFwdArgs {
     int64_t bsc, bsy, bsx;
     float dc_offset;
     float4* __restrict__ pix_state;
+    float4* __restrict__ pix_sums;
     uint32_t* __restrict__ quad_max;
     float* out_color; float* out_phasor; float* out_depth; float* out_normal; float* out_acc;
     float* out_entropy; float* out_dd; float* out_ad; float* out_distribution;
@@ -261,6 +261,8 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
         const size_t HW = (size_t)a.H * a.W;
         const size_t pix = (size_t)a.W * py + px;
         a.pix_state[pix] = make_float4(T, __uint_as_float(last_contributor), DD_D, DD_D2);
+        a.pix_sums[2 * pix] = make_float4(C0, C1, C2, PR);
+        a.pix_sums[2 * pix + 1] = make_float4(PI, PA, Dd, A);
         const float* bgp = a.bg + (int64_t)py * a.bsy + (int64_t)px * a.bsx;
         const float g0 = bgp[0], g1 = bgp[a.bsc], g2 = bgp[2 * a.bsc], g3 = bgp[3 * a.bsc];
         const float g4 = bgp[4 * a.bsc], g5 = bgp[5 * a.bsc], g6 = bgp[6 * a.bsc];
@@ -306,6 +308,8 @@ struct RenderBwdArgs {
     int64_t bsc, bsy, bsx;
     float dc_offset;
     const float4* __restrict__ pix_state;
+    const float4* __restrict__ pix_sums;
+    int split;                 // 1: deep quadrants are shared by two waves
     const uint32_t* __restrict__ quad_max;
     const uint32_t* __restrict__ order;     // tiles, heaviest first
     const float* __restrict__ g_color; const float* __restrict__ g_phasor; const float* __restrict__ g_depth;
@@ -380,20 +384,16 @@ __device__ __forceinline__ v2f swap16_add2(v2f x, v2f y)
     return p + q;
 }
 
-// Sum 16 per-lane values (8 "low" L[0..7], 8 "high" H[0..7], as register pairs) over the 64
-// lanes of the wave and store the totals to row[0..15] in LDS:
-//   row[0..3] = L[0..3], row[4..7] = L[4..7], row[8..11] = H[0..3], row[12..15] = H[4..7].
+// Sum 16 per-lane values (8 "low" L[0..7], 8 "high" H[0..7], as register pairs) over the 64 lanes of the
+// wave; position k = {L[0..3], L[4..7], H[0..3], H[4..7]}[k] ends up in lane 4 k (other lanes: unspecified).
 // Halving tree: 16 -> 8 registers (lane halves: L[i] | H[i]), 8 -> 4 (16-lane rows: L[i], L[i+4],
-// H[i], H[i+4]), then row_fold4: quad q of row r ends up with the value of position 4 r + q,
-// stored by its first lane (16 lanes x 4 bytes).
-__device__ __forceinline__ void wave_reduce16_store(v2f L01, v2f L23, v2f L45, v2f L67, v2f H01, v2f H23, v2f H45,
-                                                    v2f H67, float* row, int lane)
+// H[i], H[i+4]), then row_fold4: quad q of row r ends up with the value of position 4 r + q.
+__device__ __forceinline__ float wave_reduce16(v2f L01, v2f L23, v2f L45, v2f L67, v2f H01, v2f H23, v2f H45, v2f H67)
 {
     const v2f s01 = swap32_add2(L01, H01), s23 = swap32_add2(L23, H23);
     const v2f s45 = swap32_add2(L45, H45), s67 = swap32_add2(L67, H67);
     const v2f t01 = swap16_add2(s01, s45), t23 = swap16_add2(s23, s67);
-    const float tot = row_fold4(t01.x, t01.y, t23.x, t23.y);
-    if ((lane & 3) == 0) row[lane >> 2] = tot;
+    return row_fold4(t01.x, t01.y, t23.x, t23.y);
 }
 
 // Heavy-first launch order for the backward: the work of a quadrant is proportional to its
@@ -442,16 +442,39 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     __shared__ float4 sA[RB * 2];
     __shared__ float4 sB[RB * 2];
     __shared__ uint32_t sId[RB];
-    __shared__ float sAcc[RB * ACC_LDS_STRIDE];
 
     // block b runs on XCD b & 7; slot b >> 3 of that XCD takes quadrant (slot & 3) of the tile of
     // weight rank 8 * (slot >> 2) + xcd: heavy tiles first, a tile's quadrants on one XCD
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int rank = 8 * (slot >> 2) + xcd;
+    // Every quadrant has two workgroups: all quadrant waves are resident from the start (4.7 per SIMD at the
+    // metric size) and each is a serial chain over its list, so the deepest lists (twice the mean) set the
+    // kernel's duration while the SIMDs run empty.  A deep list [0, tmax) is therefore cut at b: segment 0 walks
+    // [b, tmax) back to front from the final state as before, segment 1 first repeats the forward blend over
+    // [0, b) (same operations as k_render_fwd: the same transmittance and partial sums), which gives it the
+    // state the serial walk would have at b -- what lies behind b is (final sums - sums up to b) -- and then
+    // walks [0, b) back to front.
+    // (first all segment-0 workgroups in heavy-first order, then all segment-1 ones: the dispatcher deals
+    // consecutive workgroups round-robin to the CUs, so alternating the two kinds would put them on
+    // alternate CUs)
+    const int half = a.split ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int seg = (int)blockIdx.x >= half ? 1 : 0;
+    const int bid = (int)blockIdx.x - seg * half;
+    const int xcd = bid & 7, qslot = bid >> 3;
+    const int rank = 8 * (qslot >> 2) + xcd;
     if (rank >= a.T) return;
-    const int v_unit = (int)a.order[rank] * 4 + (slot & 3);
+    const int v_unit = (int)a.order[rank] * 4 + (qslot & 3);
     const int tmax = (int)a.quad_max[v_unit];
     if (tmax == 0) return;
+    // cut: segment 1 repeats the forward before it can start and is launched behind all segment-0 workgroups
+    int cut = 0;
+    if (a.split && tmax >= 3 * RB) {
+        const int nb = (tmax + RB - 1) / RB;
+        const int kA = (nb * 48 + 32) >> 6;                    // batches of segment 0: 3/4 (measured best of 0.5 ... 0.8)
+        cut = tmax - kA * RB;
+        if (cut < 0) cut = 0;
+    }
+    if (seg == 1 && cut == 0) return;
+    const int hi_first = seg == 0 ? tmax : cut;                // list range [lo_last, hi_first) of this segment
+    const int lo_last = seg == 0 ? cut : 0;
     const int tile = v_unit >> 2, quad = v_unit & 3;
     const int lane = threadIdx.x;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -511,8 +534,64 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     float T = T_final;
     float S1 = 0.f, Sp = 0.f;
 
-    for (int hi = tmax; hi > 0; hi -= RB) {        // list indices [hi-n, hi), descending
-        const int n = min(RB, hi);
+    if (seg == 1) {
+        // forward blend over [0, cut), operation for operation as k_render_fwd does it
+        float fT = 1.0f, qC0 = 0, qC1 = 0, qC2 = 0, qPR = 0, qPI = 0, qPA = 0, qDd = 0, qA = 0, qDD_D = 0, qDD_D2 = 0;
+        for (int base = 0; base < cut; base += RB) {
+            const int n = min(RB, cut - base);
+            bool reach = false;
+            __syncthreads();
+            if (lane < n) {
+                const uint32_t id = a.point_list[r0 + (uint32_t)(base + lane)];
+                reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, (float)qx0, (float)qy0);
+            }
+            uint64_t m = to_sgpr(wave_ballot(reach));
+            __syncthreads();
+            while (m) {
+                const int j = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
+                const float dx = a0.x - pxf, dy = a0.y - pyf;
+                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+                const float alpha = fminf(0.99f, a1.y * gft_exp(power));
+                const bool contrib = (base + j < n_contrib) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const unsigned long long cm = wave_ballot(contrib);
+                if (cm == 0ull) continue;
+                const float4 b0 = sB[2 * j], b1 = sB[2 * j + 1];
+                const float al = sel_mask(cm, alpha, 0.f);
+                const float w = al * fT;
+                const float w_p = w * fT;
+                qC0 += b0.x * w; qC1 += b0.y * w; qC2 += b0.z * w;
+                qPR += b0.w * w_p; qPI += b1.x * w_p; qPA += b1.y * w_p;
+                const float dist = a1.w;
+                qDd += dist * w;
+                const float z = a1.z;
+                const float wz = w * z;
+                qDD_D += wz;
+                qDD_D2 = fmaf(wz, z, qDD_D2);
+                qA += w;
+                fT = sel_mask(cm, fT * (1 - alpha), fT);
+            }
+        }
+        // what the serial walk holds when it arrives at `cut`:
+        //   S1 = sum_{k >= cut} w_k D1_k / T_cut,  Sp = sum_{k >= cut} w_k T_k Dp_k / T_cut^2,
+        // the sums taken as (whole list) - (entries before cut); a pixel whose list ended before `cut` has equal
+        // sums on both sides and gets exact zeros
+        float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
+        if (inside) { f0 = a.pix_sums[2 * pix]; f1 = a.pix_sums[2 * pix + 1]; }
+        float R1 = (f0.x - qC0) * gc0;
+        R1 = fmaf(f0.y - qC1, gc1, R1); R1 = fmaf(f0.z - qC2, gc2, R1); R1 = fmaf(f1.z - qDd, gd, R1);
+        R1 = fmaf(A2, wz2_tot - qDD_D2, R1); R1 = fmaf(B2, wz_tot - qDD_D, R1); R1 = fmaf(C2, f1.w - qA, R1);
+        float Rp = (f0.w - qPR) * GR;
+        Rp = fmaf(f1.x - qPI, GI, Rp); Rp = fmaf(f1.y - qPA, GA, Rp);
+        const float rT = __builtin_amdgcn_rcpf(fT);
+        T = fT;
+        S1 = R1 * rT;
+        Sp = Rp * rT * rT;
+    }
+
+    for (int hi = hi_first; hi > lo_last; hi -= RB) {        // list indices [hi-n, hi), descending
+        const int n = min(RB, hi - lo_last);
         bool reach = false;
         __syncthreads();                           // previous batch's flush has read LDS
         if (lane < n) {
@@ -521,7 +600,6 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
             reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, (float)qx0, (float)qy0);
         }
         uint64_t m = to_sgpr(wave_ballot(reach));
-        uint64_t touched = 0;
         __syncthreads();
 
         // alpha of splat j for this pixel and whether the pixel blended it in the forward
@@ -538,7 +616,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
         // the same arithmetic; lanes that do not blend this splat use alpha = G = 0, which leaves T and
         // the two recurrences unchanged (rcp(1) == 1) and makes all 15 partials exactly zero.
         // accumulator row = {dcolor[3], ddist | dmean2D.xy, dconic.xy | XR, XI, X2, XQ | dconic.w, dopacity, dndc, -}
-        auto blend = [&](int j, float* row, const float4& a0, const float4& a1, float dx, float dy, float G, float alpha,
+        auto blend = [&](int j, const float4& a0, const float4& a1, float dx, float dy, float G, float alpha,
                          bool contrib) {
             v2f L01, L23, L45, L67, H01, H23, H45, H67;
             const float4 b0 = sB[2 * j], b1 = sB[2 * j + 1];
@@ -584,8 +662,11 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
             H45.y = E;                                // dopacity
             H67.x = wc * (t2 + A2 * z);           // gdd*2*alpha*T*(z(1-Tf) - wz)
             H67.y = 0.f;
-            // 64 pixels -> one partial per value, parked in the batch's LDS table
-            wave_reduce16_store(L01, L23, L45, L67, H01, H23, H45, H67, row, lane);
+            // 64 pixels -> one partial per value in every fourth lane: 15 of them go straight to the Gaussian's
+            // accumulator row (one 64-byte line of float atomics, fire and forget)
+            const float tot = wave_reduce16(L01, L23, L45, L67, H01, H23, H45, H67);
+            if ((lane & 3) == 0 && lane < 4 * GFT_NUM_ACC && tot != 0.f)
+                atomicAdd(&a.acc[(size_t)sId[j] * GFT_ACC_STRIDE + (lane >> 2)], tot);
         };
 
         while (m) {
@@ -595,22 +676,10 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
             float dx, dy, G, alpha;
             const bool contrib = eval(j, a0, a1, dx, dy, G, alpha);
             if (wave_ballot(contrib) == 0ull) continue;   // wave-uniform skip
-            blend(j, &sAcc[j * ACC_LDS_STRIDE], a0, a1, dx, dy, G, alpha, contrib);
-            touched |= 1ull << j;
+            blend(j, a0, a1, dx, dy, G, alpha, contrib);
         }
         // (issuing two splats per iteration in one basic block so that the scheduler can overlap their
         // exp / rcp / DPP latencies was measured: 214 vs 198 us, dropped)
-        __syncthreads();
-
-        // flush: one 60-byte burst of float atomics (a single 64-byte row) per splat that received a contribution
-        while (touched) {
-            const int j = (int)__builtin_ctzll(touched);
-            touched &= touched - 1;
-            if (lane < GFT_NUM_ACC) {
-                const float val = sAcc[j * ACC_LDS_STRIDE + lane];
-                if (val != 0.f) atomicAdd(&a.acc[(size_t)sId[j] * GFT_ACC_STRIDE + lane], val);
-            }
-        }
     }
 }
 
@@ -630,6 +699,7 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     a.bg = io.bg; a.bsc = c.bg_stride_c; a.bsy = c.bg_stride_y; a.bsx = c.bg_stride_x;
     a.dc_offset = c.dc_offset;
     a.pix_state = im.pix_state; a.quad_max = im.tile_max;
+    a.pix_sums = im.pix_sums;
     a.out_color = io.out_color; a.out_phasor = io.out_phasor; a.out_depth = io.out_depth;
     a.out_normal = io.out_normal; a.out_acc = io.out_acc; a.out_entropy = io.out_entropy;
     a.out_dd = io.out_depth_distortion; a.out_ad = io.out_amp_distortion;
@@ -662,7 +732,12 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     a.acc = io.acc;
     a.order = im.tile_order;
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, a.T, im.tile_max, im.tile_order);
-    const int blocks = 32 * ((a.T + 7) / 8);
+    a.pix_sums = im.pix_sums;
+    static const int split_on = [] { const char* e = getenv("GFT_BWD_SPLIT"); return e ? atoi(e) != 0 : 1; }();
+    // two waves per deep quadrant only while one wave per quadrant leaves wave slots empty (8 per SIMD = 8192);
+    // with more quadrants than that (5 M @ 1080p: 32640) the repeated forward is only extra work (measured)
+    a.split = split_on && 4 * a.T <= 12288;
+    const int blocks = (a.split ? 64 : 32) * ((a.T + 7) / 8);
     hipLaunchKernelGGL(k_render_bwd, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GFT_ABI_VERSION 3
+#define GFT_ABI_VERSION 4
 
 /* compile-time constants of the reference (RAST/cuda_rasterizer/config.h:15-23) */
 #define GFT_NUM_CHANNELS 3
@@ -183,6 +183,7 @@ typedef struct gft_layout {
     size_t img_front_len;     /* uint32[T]    length of the sorted head of the tile's id list (lazy sort) */
     size_t img_unit_flag;     /* uint32[4T]   quadrant ran out of sorted ids before saturating (lazy sort) */
     size_t img_resume_state;  /* float[N][16] blend state of such quadrants' pixels */
+    size_t img_pix_sums;      /* float[N][8]  final blend sums {C0,C1,C2,R | I,Am,dist,A}: the split backward starts mid-list from them */
     size_t img_total;
     /* binning */
     size_t bin_keys;          /* uint64[R]    (depth bits << 32 | Gaussian id), grouped by tile, unsorted */
