@@ -243,6 +243,9 @@ int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* i
                 int64_t binning_instances, int64_t max_tile_list_hint,
                 int64_t* num_rendered /*host*/, int64_t* max_tile_list /*host, may be NULL*/);
 
+/* The backward of the forward whose scratch buffers `io` carries.  Gradient sums are added with float atomics
+ * (as in the reference), so two runs agree to rounding, not bit for bit.  GFT_BWD_SPLIT=0 in the environment
+ * keeps one wave per pixel quadrant (default: deep quadrants are walked by two waves). */
 int gft_backward(void* hip_stream, const gft_config* cfg,
                  const gft_backward_io* io, int64_t binning_instances);
 
