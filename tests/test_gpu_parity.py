@@ -3,6 +3,7 @@ identical seeded inputs.  Integer/index stages bit-exact, fp32 stages within the
 tolerances written below (north star: rendered L1 < 1e-5, bit-exact tile/key
 indexing)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -509,3 +510,34 @@ def synth_pose(rng):
     from gftorf_amd import synth
     return synth.look_at_w2c(float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2)),
                              (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.1, 0.4))))
+
+
+@pytest.mark.gpu
+def test_split_backward_matches_one_wave_per_quadrant(tmp_path):
+    """Deep quadrants are walked by two waves; GFT_BWD_SPLIT=0 keeps the serial walk.  Both
+    must give the same gradients up to the rounding of the second wave's starting state."""
+    import subprocess
+    import sys
+    scene_kw = SCENES["deep_lists"]
+    child = tmp_path / "serial.py"
+    out = tmp_path / "serial.npz"
+    child.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import helpers\n"
+        "scene = helpers.small_scene(**%r)\n"
+        "o, g, t = helpers.run_gpu(scene, torch.device('cuda:0'))\n"
+        "np.savez(%r, **{k: v for k, v in g.items() if v is not None})\n"
+        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+           scene_kw, str(out)))
+    subprocess.check_call([sys.executable, str(child)], env=dict(os.environ, GFT_BWD_SPLIT="0"), timeout=300)
+    serial = np.load(out)
+    scene = Hh.small_scene(**scene_kw)
+    _, grads, _ = Hh.run_gpu(scene, torch.device("cuda:0"))
+    worst = 0.0
+    for k in serial.files:
+        den = np.abs(serial[k]).max() + 1e-30
+        worst = max(worst, float(np.abs(serial[k] - grads[k]).max() / den))
+    assert worst < 2e-5, worst
+    # and the split really was in use here: the scene has quadrants deeper than three batches
+    assert os.environ.get("GFT_BWD_SPLIT", "1") != "0"
