@@ -426,6 +426,95 @@ def densify_extra(dev, P=1_000_000):
             "prune_frac_of_hbm_peak": prune_bytes / (prune_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def train_iteration_extra(dev, scene, steps=10, warmup=3):
+    """One iteration of the reference's loop shape (train.py:164-177, 441-449, 470-474) at the metric size: one
+    deformation-network query for the dynamic 30 %, input assembly and a colour + ToF render pair (two rasterizer
+    forward + backward), densification statistics, Adam on the Gaussians and on the network.  `hip`: every piece
+    from this package; `eager`: the same rasterizer with the reference's eager statements around it
+    (oracle/*_ref.py restatements on the device, torch.optim.Adam).  There is no reference rasterizer for
+    ROCm, so both columns share ours."""
+    import numpy as np
+    import torch
+    from gftorf_amd import (DeformNetwork, FusedAdam, GaussianRasterizationSettings, GaussianRasterizer, assemble_inputs,
+                            densify)
+    from oracle import assemble_ref, deform_ref, densify_ref
+    cam, cfg, g = scene["cam"], scene["cfg"], scene["gaussians"]
+    P = cfg["P"]
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
+    settings = GaussianRasterizationSettings(
+        image_height=cfg["H"], image_width=cfg["W"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t(scene["bg"]),
+        scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=cfg["D"],
+        campos=t(cam["campos"]), prefiltered=False, debug=False, near_n=cam["znear"], far_n=cam["zfar"],
+        depth_range=scene["depth_range"], use_view_dependent_phase=scene["use_view_dependent_phase"])
+    rast = GaussianRasterizer(settings)
+    rng = np.random.default_rng(21)
+    mask = torch.tensor(rng.random(P) < 0.3, device=dev)
+    params = deform_ref.random_params(9, head_std=1e-3)
+    gr = {k: t(v) for k, v in scene["grads"].items()}
+
+    def build(fused):
+        leaf = dict(xyz=t(g["means3D"]), opacity=t(g["opacities"]).reshape(P, 1), scaling=t(g["scales"]),
+                    rotation_raw=t(g["rotations"]), fc=t(g["shs"]), fp=t(g["shs_p"]))
+        for v in leaf.values():
+            v.requires_grad_(True)
+        groups = [{"params": [v], "lr": 1e-5, "name": k} for k, v in leaf.items()]
+        if fused:
+            net = DeformNetwork()
+            net.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+            net = net.to(dev)
+            opt, net_params = FusedAdam(groups, lr=0.0, eps=1e-15), list(net.parameters())
+        else:
+            net = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in params.items()}
+            opt, net_params = torch.optim.Adam(groups, lr=0.0, eps=1e-15), list(net.values())
+        opt_net = torch.optim.Adam(net_params, lr=1e-6, eps=1e-15)
+        x_n = leaf["xyz"].detach()[mask]
+        x_n = (x_n - x_n.min(0).values) / (x_n.max(0).values - x_n.min(0).values)
+        stats = [torch.zeros((P, 1), device=dev), torch.zeros((P, 1), device=dev), torch.zeros(P, device=dev)]
+
+        def iteration():
+            tt = torch.full((1, 1), 0.4, device=dev).expand(x_n.size(0), -1)
+            d = net(x_n, tt) if fused else deform_ref.deform_eager(net, x_n, tt)
+            loss, views = 0.0, []
+            for _ in range(2):                                  # colour camera and ToF camera (train.py:181, 188)
+                ssp = torch.zeros((P, 3), device=dev, requires_grad=True)
+                rot = torch.nn.functional.normalize(leaf["rotation_raw"])
+                args = (leaf["xyz"], ssp, leaf["opacity"], leaf["scaling"], rot, leaf["rotation_raw"], leaf["fc"], leaf["fp"],
+                        mask) + tuple(d)
+                m3, m2, op, sc, ro, shs, shp = assemble_inputs(*args) if fused else assemble_ref.assemble_eager(*args)
+                out = rast(means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro,
+                           phase_offset=scene["phase_offset"], dc_offset=scene["dc_offset"])
+                loss = loss + (out[0] * gr["color"]).sum() + (out[1] * gr["phasor"]).sum() + (out[2] * gr["depth"]).sum()
+                views.append((ssp, out[10], out[8]))
+            loss.backward()                                     # one backward for the summed losses (train.py:364-366)
+            for ssp, radii, pixels in views:
+                if fused:
+                    densify.add_densification_stats(stats[0], stats[1], stats[2], ssp.grad, radii > 0, pixels, radii)
+                else:
+                    densify_ref.add_densification_stats_eager(stats[0], stats[1], stats[2], ssp.grad, radii > 0, pixels, radii)
+            opt.step(); opt_net.step()
+            opt.zero_grad(set_to_none=True); opt_net.zero_grad(set_to_none=True)
+        return iteration
+
+    def timed(fn, k, w):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(k):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / k
+
+    hip_ms = timed(build(True), steps, warmup)
+    torch.cuda.empty_cache()
+    eager_ms = timed(build(False), max(3, steps // 2), 2)
+    return {"what": "one training iteration of the reference's loop shape, %d Gaussians (30 %% dynamic), %dx%d: network query, "
+                    "2 x (assembly + raster fwd/bwd + statistics), Adam" % (P, cfg["W"], cfg["H"]),
+            "hip_ms": hip_ms, "hip_it_per_s": 1e3 / hip_ms, "eager_glue_ms": eager_ms, "speedup": eager_ms / hip_ms}
+
+
 def knn_extra(dev, P=1_000_000):
     """SURVEY 8(f) row 3 beside the headline metric: distCUDA2 (mean squared distance to the 3
     nearest neighbours, the scale initialisation of scene/gaussian_model.py:194-199) on a
@@ -605,9 +694,11 @@ def main():
         if world == 1 and not args.no_extras and args.workload == "metric":
             del state, step
             torch.cuda.empty_cache()
+            train_extra = train_iteration_extra(dev, scene)
+            torch.cuda.empty_cache()
             out["extras"] = {"assemble_inputs": assemble_extra(dev), "knn": knn_extra(dev),
                              "adam": adam_extra(dev), "deform_network": deform_extra(dev),
-                             "densify": densify_extra(dev)}
+                             "densify": densify_extra(dev), "train_iteration": train_extra}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, budget_s=args.cpu_budget)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
