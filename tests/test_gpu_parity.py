@@ -110,6 +110,7 @@ SCENES = {
     "long_lists_lds128k": dict(P=9000, W=32, H=32, scale_lo=0.05, scale_hi=0.3),    # 4096 < tile list <= 16384: depth-bucket split
     "long_lists_flat": dict(P=9000, W=32, H=32, scale_lo=0.05, scale_hi=0.3, w2c=None, z_lo=3.0, z_hi=3.0),   # all depths equal: splitters and order decided by the id half of the keys
     "long_lists_global": dict(P=24000, W=32, H=16, scale_lo=0.05, scale_hi=0.3),    # tile list > 16384: global-memory sort
+    "scatter_direct": dict(P=9000, W=64, H=64, scale_lo=0.25, scale_hi=0.6),         # 30 k instances per 4096-Gaussian workgroup: more than the LDS stage takes, keys are written directly
 }
 
 
