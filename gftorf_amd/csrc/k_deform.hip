@@ -4,9 +4,10 @@
 // v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32]; lane l holds A[i = l & 31][k = l >> 5] and
 // B[k = l >> 5][j = l & 31]; D: column = l & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5).
 // 64 cycles per instruction per SIMD = the fp32 peak (157 TFLOP/s), so the kernels only have to
-// keep one wave per SIMD fed: operands come as 16-byte LDS reads (4 k per read, the packed weights
-// are interleaved [k/4][n][4] for that), weights stream L2 -> registers -> LDS one 16-k chunk
-// ahead of the chunk being multiplied.
+// keep one wave per SIMD fed.  The walks keep a tile of points' activations in LDS (16-byte reads,
+// 4 k per read) and stream the weights L2 -> registers, each wave its own 64 output columns (the packed
+// weights are interleaved [k/4][n][4] for 16-byte loads), one 16-k chunk ahead of the multiply; the
+// weight-gradient kernel reads both operands straight from global memory.
 #include "gft_internal.h"
 #include "gftorf_deform.h"
 
