@@ -44,6 +44,25 @@ constexpr int64_t DF_B_TOTAL = DF_F_HEAD_SZ + 7 * DF_F_SZ;            // 475136
 constexpr int64_t DF_BIAS_BASE = DF_B_BASE + DF_B_TOTAL;              // 991232
 constexpr int64_t DF_PACKED_FLOATS = DF_BIAS_BASE + DF_D * DF_W + DF_HEAD;   // 993344
 
+// bf16 plane copy of the two weight streams (after the fp32 floats): every fp32 weight as hi + mid + lo bf16
+// (24 mantissa bits), per segment [plane][k/8][n][8]: the operand layout of v_mfma_f32_32x32x16_bf16
+constexpr int64_t DF_BF_ELEMS = DF_F_TOTAL + DF_B_TOTAL;              // weights in both streams
+constexpr int64_t DF_BF_FLOATS = DF_BF_ELEMS * 3 / 2;                 // 3 x 2 bytes each
+constexpr int DF_NSEG = 18;
+// stream segments: first element (in either representation's element count), rows K, columns
+struct DfSeg { int64_t off; int K, ncol; };
+__host__ __device__ inline DfSeg df_seg(int s)
+{
+    // forward: L0 | L1..L4 | L5 encoding rows | L5 hidden rows, L6, L7 | heads; backward: heads, L7 .. L1
+    if (s == 0) return {0, DF_INK, DF_W};
+    if (s <= 4) return {DF_F_SZ0 + (int64_t)(s - 1) * DF_F_SZ, DF_W, DF_W};
+    if (s == 5) return {DF_F_SZ0 + 4 * DF_F_SZ, DF_INK, DF_W};
+    if (s <= 8) return {2 * DF_F_SZ0 + (int64_t)(s - 2) * DF_F_SZ, DF_W, DF_W};
+    if (s == 9) return {DF_F_TOTAL - DF_F_HEAD_SZ, DF_W, DF_HEAD};
+    if (s == 10) return {DF_B_BASE, DF_HEAD, DF_W};
+    return {DF_B_BASE + DF_F_HEAD_SZ + (int64_t)(s - 11) * DF_F_SZ, DF_W, DF_W};
+}
+
 // ---------------------------------------------------------------------------------------------
 // pack
 // ---------------------------------------------------------------------------------------------
@@ -118,6 +137,37 @@ __global__ __launch_bounds__(256) void k_deform_pack(PackArgs a)
         else (void)head_row(a.p, r - DF_D * DF_W, v);
     }
     a.out[e] = v;
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = hi + mid + lo to 24 bits: every product of two such numbers is the sum of nine exact bf16 products
+__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo)
+{
+    hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    mid = (__bf16)r1;
+    lo = (__bf16)(r1 - (float)mid);
+}
+
+// fp32 packed streams ([k/4][n][4] per segment) -> bf16 planes ([plane][k/8][n][8] per segment)
+__global__ __launch_bounds__(256) void k_deform_pack_bf(const float* __restrict__ packed, __bf16* __restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= DF_BF_ELEMS) return;
+    int sgi = 0;
+    for (int q = 1; q < DF_NSEG; q++)
+        if (e >= df_seg(q).off) sgi = q;
+    const DfSeg sg = df_seg(sgi);
+    const int64_t r = e - sg.off;
+    const int kq = (int)(r / (sg.ncol * 4)), n = (int)((r >> 2) % sg.ncol), k = 4 * kq + (int)(r & 3);
+    __bf16 hi, mid, lo;
+    split3(packed[e], hi, mid, lo);
+    const int64_t plane = (int64_t)sg.K * sg.ncol;
+    const int64_t o = 3 * sg.off + ((int64_t)(k >> 3) * sg.ncol + n) * 8 + (k & 7);
+    out[o] = hi;
+    out[o + plane] = mid;
+    out[o + 2 * plane] = lo;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -369,6 +419,257 @@ __global__ __launch_bounds__(256) void k_deform_fwd(FwdArgs a)
             zero_acc(hacc);
             stream_gemm<1, 1, DF_HEAD>(hacc, hA + (r0 + li) * DF_HS + 4 * hh, DF_HS, DF_W / 16, hl, hw, false);
             store_head(hacc[0][0], r0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward walk on three bf16 planes: six bf16 MFMAs per product (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid;
+// the three dropped terms are below 2^-23 of the product) accumulate in fp32 -- the error against float64 is
+// that of an fp32 fma chain (profiles/experiments/bf16x3_gemm.hip: 5.4e-7 vs 5.5e-7), at up to 2.7 x the rate
+// of v_mfma_f32_32x32x2_f32.  Activations live in LDS as three bf16 planes (the epilogue splits them),
+// weights come as three bf16 planes from the packed copy.
+// ---------------------------------------------------------------------------------------------
+constexpr int DF_BH = 264;                 // bf16 per activation row of a plane (528 B: 16-byte reads of 16 rows hit 16 bank groups)
+constexpr int DF_BE = 88;                  // bf16 per encoding row of a plane
+constexpr size_t DF_BF_ACT_PLANE = (size_t)64 * DF_BH * 2, DF_BF_ENC_PLANE = (size_t)64 * DF_BE * 2;
+constexpr size_t DF_FWD_BF_LDS = 3 * DF_BF_ACT_PLANE + 3 * DF_BF_ENC_PLANE + (size_t)DF_BIAS_FLOATS * 4;   // 144640
+
+struct WSeg {                              // a weight segment as this lane sees it
+    const uint4* p;                        // plane 0, chunk 0: [h][first column + lane]
+    int plane;                             // uint4 between planes
+};
+
+__device__ __forceinline__ WSeg wseg(const __bf16* bf, int s, int lane_col, int hh)
+{
+    const DfSeg sg = df_seg(s);
+    WSeg w;
+    w.p = reinterpret_cast<const uint4*>(bf + 3 * sg.off) + hh * sg.ncol + lane_col;
+    w.plane = sg.K * sg.ncol / 8;
+    return w;
+}
+
+template <int NC, int NCOL>
+__device__ __forceinline__ void load_wbf(uint4 (&w)[3][NC], const WSeg& sgp, int chunk)
+{
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++) w[pl][ct] = sgp.p[(size_t)pl * sgp.plane + (size_t)(2 * chunk) * NCOL + 32 * ct];
+}
+
+__device__ __forceinline__ bf16x8 as_bf(const uint4& v)
+{
+    bf16x8 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+
+// acc[rt][ct] += (A[64 x 16 nchunks] W)^T; a_lane: this lane's row of plane 0 at k = 8 hh (bytes); wcur: chunk 0 of
+// `cur`, already loaded; `nxt`: the segment that follows (its chunk 0 is prefetched into wcur), or null.
+template <int NR, int NC, int NCOL>
+__device__ __forceinline__ void stream_gemm_bf(f32x16 (&acc)[NR][NC], const char* a_lane, int a_row_bytes, size_t a_plane_bytes,
+                                               int nchunks, const WSeg& cur, const WSeg* nxt, uint4 (&wcur)[3][NC])
+{
+    uint4 acur[3][NR];
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+        for (int rt = 0; rt < NR; rt++)
+            acur[pl][rt] = *reinterpret_cast<const uint4*>(a_lane + pl * a_plane_bytes + (size_t)rt * 32 * a_row_bytes);
+    for (int c = 0; c < nchunks; c++) {
+        const bool last = c + 1 >= nchunks;
+        uint4 wnxt[3][NC], anxt[3][NR];
+        // (unconditional loads from valid addresses: conditionally filled arrays end up in scratch)
+        if (!last) load_wbf<NC, NCOL>(wnxt, cur, c + 1);
+        else load_wbf<NC, NCOL>(wnxt, nxt ? *nxt : cur, 0);
+        const int cn = last ? c : c + 1;
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+            for (int rt = 0; rt < NR; rt++)
+                anxt[pl][rt] = *reinterpret_cast<const uint4*>(a_lane + pl * a_plane_bytes + (size_t)rt * 32 * a_row_bytes + cn * 32);
+        __builtin_amdgcn_sched_barrier(0);
+        // weights are the MFMA's A operand, activations its B operand (point on the lane, see stream_gemm)
+#pragma unroll
+        for (int term = 0; term < 6; term++) {
+            const int pw = term == 0 ? 0 : term == 1 ? 1 : term == 2 ? 0 : term == 3 ? 2 : term == 4 ? 0 : 1;
+            const int pa = term == 0 ? 0 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 2 : 1;
+#pragma unroll
+            for (int rt = 0; rt < NR; rt++)
+#pragma unroll
+                for (int ct = 0; ct < NC; ct++)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(wcur[pw][ct]), as_bf(acur[pa][rt]), acc[rt][ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++) wcur[pl][ct] = wnxt[pl][ct];
+#pragma unroll
+            for (int rt = 0; rt < NR; rt++) acur[pl][rt] = anxt[pl][rt];
+        }
+    }
+}
+
+// four consecutive fp32 values of one point -> 4 bf16 in each of the three planes
+__device__ __forceinline__ void store_split4(char* plane0, size_t plane_bytes, size_t byte_off, const float4& v)
+{
+    __bf16 h[4], m[4], l[4];
+    split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]);
+    split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
+    uint2 ph, pm, pl;
+    __builtin_memcpy(&ph, h, 8); __builtin_memcpy(&pm, m, 8); __builtin_memcpy(&pl, l, 8);
+    *reinterpret_cast<uint2*>(plane0 + byte_off) = ph;
+    *reinterpret_cast<uint2*>(plane0 + plane_bytes + byte_off) = pm;
+    *reinterpret_cast<uint2*>(plane0 + 2 * plane_bytes + byte_off) = pl;
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(256) void k_deform_fwd_bf(FwdArgs a)
+{
+    extern __shared__ float4 df_lds[];
+    char* hP = reinterpret_cast<char*>(df_lds);                  // activation planes [3][64][264] bf16
+    char* eP = hP + 3 * DF_BF_ACT_PLANE;                         // encoding planes   [3][64][88]  bf16
+    float* bL = reinterpret_cast<float*>(eP + 3 * DF_BF_ENC_PLANE);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int n0 = wave * 64;
+    const __bf16* bf = reinterpret_cast<const __bf16*>(a.packed + DF_PACKED_FLOATS);
+    WSeg seg = wseg(bf, 0, n0 + li, hh);
+    uint4 wcur[3][2];
+    load_wbf<2, DF_W>(wcur, seg, 0);
+    for (int q = tid; q < DF_BIAS_FLOATS; q += 256) bL[q] = a.packed[DF_BIAS_BASE + q];
+
+    // positional encoding (time_utils.py:24-53), split into the three planes; the fp32 values are saved for the
+    // weight-gradient GEMMs
+    {
+        const int pt = tid & 63, grp = tid >> 6;
+        const int64_t p = p0 + pt;
+        auto put = [&](int col, float v) {
+            __bf16 h, m, l;
+            split3(v, h, m, l);
+            __bf16* e = reinterpret_cast<__bf16*>(eP) + pt * DF_BE + col;
+            e[0] = h;
+            e[DF_BF_ENC_PLANE / 2] = m;
+            e[DF_BF_ENC_PLANE] = l;
+            if (SAVE) a.emb[p * DF_EMB + col] = v;
+        };
+        if (grp < 3) {
+            const float v = p < a.n ? a.xyz[3 * p + grp] : 0.f;
+            put(grp, v);
+#pragma unroll
+            for (int f = 0; f < 10; f++) {
+                float sn, cs;
+                sincosf(v * (float)(1 << f), &sn, &cs);
+                put(3 + 6 * f + grp, sn);
+                put(6 + 6 * f + grp, cs);
+            }
+        } else {
+            const float v = p < a.n ? a.t[p * a.t_stride] : 0.f;
+            put(63, v);
+#pragma unroll
+            for (int f = 0; f < 6; f++) {
+                float sn, cs;
+                sincosf(v * (float)(1 << f), &sn, &cs);
+                put(64 + 2 * f, sn);
+                put(65 + 2 * f, cs);
+            }
+#pragma unroll
+            for (int c = DF_IN; c < DF_EMB; c++) {
+                if (c < DF_INK) put(c, 0.f);
+                else if (SAVE) a.emb[p * DF_EMB + c] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    const char* h_lane = hP + (size_t)li * DF_BH * 2 + 16 * hh;
+    const char* e_lane = eP + (size_t)li * DF_BE * 2 + 16 * hh;
+    f32x16 acc[2][2];
+    for (int l = 0; l < DF_D; l++) {
+        zero_acc(acc);
+        if (l == 0) {
+            const WSeg nx = wseg(bf, 1, n0 + li, hh);
+            stream_gemm_bf<2, 2, DF_W>(acc, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur);
+            seg = nx;
+        } else {
+            if (l == 5) {
+                // after layer 4 the encoding is concatenated in front (time_utils.py:112-113)
+                const WSeg nx = wseg(bf, 6, n0 + li, hh);
+                stream_gemm_bf<2, 2, DF_W>(acc, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur);
+                seg = nx;
+            }
+            // segments: layers 1..4 -> 1..4, encoding rows of 5 -> 5, hidden rows of 5, 6, 7 -> 6, 7, 8
+            const int s_next = l < 4 ? l + 1 : l == 4 ? 5 : l < 7 ? l + 2 : -1;
+            if (s_next >= 0) {
+                const WSeg nx = wseg(bf, s_next, n0 + li, hh);
+                stream_gemm_bf<2, 2, DF_W>(acc, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, &nx, wcur);
+                seg = nx;
+            } else {
+                stream_gemm_bf<2, 2, DF_W>(acc, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur);
+            }
+        }
+        float4 bv[2][4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                bv[ct][g] = *reinterpret_cast<const float4*>(bL + l * DF_W + n0 + 32 * ct + acc_col4(g, hh));
+        __syncthreads();      // every wave is past its last read of this layer's input
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int row = 32 * rt + li, col = n0 + 32 * ct + acc_col4(g, hh);
+                    float4 v;
+                    v.x = fmaxf(acc[rt][ct][4 * g] + bv[ct][g].x, 0.f);
+                    v.y = fmaxf(acc[rt][ct][4 * g + 1] + bv[ct][g].y, 0.f);
+                    v.z = fmaxf(acc[rt][ct][4 * g + 2] + bv[ct][g].z, 0.f);
+                    v.w = fmaxf(acc[rt][ct][4 * g + 3] + bv[ct][g].w, 0.f);
+                    store_split4(hP, DF_BF_ACT_PLANE, ((size_t)row * DF_BH + col) * 2, v);
+                    if (SAVE) {
+                        *reinterpret_cast<float4*>(a.acts + ((int64_t)l * a.n_pad + p0 + row) * DF_W + col) = v;
+                        bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
+                                << acc_col4(g, hh);
+                    }
+                }
+                if (SAVE) {
+                    bits |= (uint32_t)__shfl_xor((int)bits, 32);
+                    if (hh == 0) a.signs[((int64_t)l * a.n_pad + p0 + 32 * rt + li) * DF_SIGN_WORDS + 2 * wave + ct] = bits;
+                }
+            }
+        __syncthreads();
+    }
+    // heads: 64 columns, one 32 x 32 tile per wave
+    {
+        const int ct = wave & 1, r0 = 32 * (wave >> 1);
+        const WSeg hs = wseg(bf, 9, 32 * ct + li, hh);
+        uint4 hw[3][1];
+        load_wbf<1, DF_HEAD>(hw, hs, 0);
+        f32x16 hacc[1][1];
+        zero_acc(hacc);
+        stream_gemm_bf<1, 1, DF_HEAD>(hacc, hP + (size_t)(r0 + li) * DF_BH * 2 + 16 * hh, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, hs,
+                                      nullptr, hw);
+        const int64_t p = p0 + r0 + li;
+        if (p < a.n) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = 32 * ct + acc_col4(g, hh);
+                const float4 bq = *reinterpret_cast<const float4*>(bL + DF_D * DF_W + col);
+                const float4 v = make_float4(hacc[0][0][4 * g] + bq.x, hacc[0][0][4 * g + 1] + bq.y, hacc[0][0][4 * g + 2] + bq.z,
+                                             hacc[0][0][4 * g + 3] + bq.w);
+                if (col < 48) {
+                    *reinterpret_cast<float4*>(a.d_sh + p * 48 + col) = v;
+                } else if (col == 48) {
+                    a.d_xyz[p * 3] = v.x;
+                    a.d_xyz[p * 3 + 1] = v.y;
+                    a.d_xyz[p * 3 + 2] = v.z;
+                }
+            }
         }
     }
 }
@@ -641,10 +942,19 @@ int dw_splits(int64_t n_pad, int* tiles_per_split)
     return (int)((tiles + tps - 1) / tps);
 }
 
+// GFT_DEFORM_BF16X3=0: the walks multiply with v_mfma_f32_32x32x2_f32 instead of six bf16 MFMAs per product
+bool bf16_planes()
+{
+    static const bool on = [] { const char* e = getenv("GFT_DEFORM_BF16X3"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
+
 bool attrs_set = false;
 void set_attrs()
 {
     if (attrs_set) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd_bf<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_BF_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd_bf<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_BF_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_BWD_LDS);
@@ -654,7 +964,7 @@ void set_attrs()
 }  // namespace
 
 
-extern "C" size_t gft_deform_packed_bytes(void) { return (size_t)DF_PACKED_FLOATS * sizeof(float); }
+extern "C" size_t gft_deform_packed_bytes(void) { return (size_t)(DF_PACKED_FLOATS + DF_BF_FLOATS) * sizeof(float); }
 
 extern "C" size_t gft_deform_saved_bytes(int64_t n)
 {
@@ -683,6 +993,9 @@ extern "C" int gft_deform_pack(void* hip_stream, const gft_deform_params* p, voi
     a.out = (float*)packed;
     hipLaunchKernelGGL(k_deform_pack, dim3((unsigned)((DF_PACKED_FLOATS + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, a);
     GFT_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_deform_pack_bf, dim3((unsigned)((DF_BF_ELEMS + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                       (const float*)packed, reinterpret_cast<__bf16*>((float*)packed + DF_PACKED_FLOATS));
+    GFT_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
@@ -709,8 +1022,13 @@ extern "C" int gft_deform_forward(void* hip_stream, int64_t n, const float* xyz,
     a.d_sh = d_sh;
     // all padded rows are computed and saved: the weight-gradient GEMMs multiply them (by zero gradients)
     const dim3 grid((unsigned)(a.n_pad / (32 * DF_NR_FWD)));
-    if (saved) hipLaunchKernelGGL(k_deform_fwd<true>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
-    else hipLaunchKernelGGL(k_deform_fwd<false>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
+    if (bf16_planes()) {
+        if (saved) hipLaunchKernelGGL(k_deform_fwd_bf<true>, grid, dim3(256), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);
+        else hipLaunchKernelGGL(k_deform_fwd_bf<false>, grid, dim3(256), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);
+    } else {
+        if (saved) hipLaunchKernelGGL(k_deform_fwd<true>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
+        else hipLaunchKernelGGL(k_deform_fwd<false>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
+    }
     GFT_CHECK_HIP(hipGetLastError());
     return 0;
 }

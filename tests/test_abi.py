@@ -165,7 +165,7 @@ def test_bench_refuses_to_run_without_gpu():
 def test_deform_size_queries_and_argument_errors(lib):
     from gftorf_amd import _lib
     # 20480 + 6*65536 + 86016 + 16384 forward, 16384 + 7*65536 backward, 2112 biases
-    assert lib.gft_deform_packed_bytes() == 993344 * 4
+    assert lib.gft_deform_packed_bytes() == (993344 + 991232 * 3 // 2) * 4      # + three bf16 planes of both weight streams
     assert lib.gft_deform_saved_bytes(0) == 0 and lib.gft_deform_scratch_bytes(0) == 0
     # per point (padded to 192): 96 encoding + 8*256 activations + 8*8 words of ReLU sign bits
     assert lib.gft_deform_saved_bytes(1) == 192 * (96 + 2048 + 64) * 4
