@@ -753,6 +753,90 @@ __global__ __launch_bounds__(256) void k_deform_bwd(BwdArgs a)
     }
 }
 
+// backward walk on three bf16 planes (64 points per workgroup): as k_deform_bwd, with the gradient tile in LDS
+// as hi / mid / lo planes and the weights from the bf16 copy of the backward stream
+constexpr size_t DF_BWD_BF_LDS = 3 * DF_BF_ACT_PLANE;   // 101376
+
+__global__ __launch_bounds__(256) void k_deform_bwd_bf(BwdArgs a)
+{
+    extern __shared__ float4 df_lds[];
+    char* gP = reinterpret_cast<char*>(df_lds);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int n0 = wave * 64;
+    const __bf16* bf = reinterpret_cast<const __bf16*>(a.packed + DF_PACKED_FLOATS);
+    WSeg seg = wseg(bf, 10, n0 + li, hh);
+    uint4 wcur[3][2];
+    load_wbf<2, DF_W>(wcur, seg, 0);
+
+    // upstream gradients as the head's output tile: [d_sh (48) | d_xyz (3) | 0], in the first 64 columns
+    for (int q = tid; q < 64 * (DF_HEAD / 4); q += 256) {
+        const int row = q >> 4, col = (q & 15) * 4;
+        const int64_t p = p0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < a.n) {
+            if (col < 48) {
+                if (a.g_dsh) v = *reinterpret_cast<const float4*>(a.g_dsh + p * 48 + col);
+            } else if (col == 48 && a.g_dxyz) {
+                v.x = a.g_dxyz[p * 3]; v.y = a.g_dxyz[p * 3 + 1]; v.z = a.g_dxyz[p * 3 + 2];
+            }
+        }
+        store_split4(gP, DF_BF_ACT_PLANE, ((size_t)row * DF_BH + col) * 2, v);
+        *reinterpret_cast<float4*>(a.dzh + p * DF_HEAD + col) = v;
+    }
+    __syncthreads();
+
+    const char* g_lane = gP + (size_t)li * DF_BH * 2 + 16 * hh;
+    f32x16 acc[2][2];
+    uint2 sg[2];
+    auto load_signs = [&](int l) {
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+            sg[rt] = *reinterpret_cast<const uint2*>(a.signs + ((int64_t)l * a.n_pad + p0 + 32 * rt + li) * DF_SIGN_WORDS + 2 * wave);
+    };
+    load_signs(DF_D - 1);
+    zero_acc(acc);
+    {
+        const WSeg nx = wseg(bf, 11, n0 + li, hh);
+        stream_gemm_bf<2, 2, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_HEAD / 16, seg, &nx, wcur);   // dh_7
+        seg = nx;
+    }
+    for (int l = DF_D - 1; l >= 0; l--) {
+        __syncthreads();      // every wave is past its last read of the previous gradient tile
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) {
+                const int row = 32 * rt + li;
+                const uint32_t word = ct == 0 ? sg[rt].x : sg[rt].y;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int col = n0 + 32 * ct + acc_col4(g, hh);
+                    const uint32_t m = word >> acc_col4(g, hh);
+                    float4 v;
+                    v.x = (m & 1u) ? acc[rt][ct][4 * g] : 0.f;
+                    v.y = (m & 2u) ? acc[rt][ct][4 * g + 1] : 0.f;
+                    v.z = (m & 4u) ? acc[rt][ct][4 * g + 2] : 0.f;
+                    v.w = (m & 8u) ? acc[rt][ct][4 * g + 3] : 0.f;
+                    if (l > 0) store_split4(gP, DF_BF_ACT_PLANE, ((size_t)row * DF_BH + col) * 2, v);
+                    *reinterpret_cast<float4*>(a.dz + ((int64_t)l * a.n_pad + p0 + row) * DF_W + col) = v;
+                }
+            }
+        if (l == 0) break;
+        __syncthreads();
+        load_signs(l - 1);
+        zero_acc(acc);
+        // segment of W_l in the backward stream: 11 + (7 - l); the walk ends with W_1
+        if (l > 1) {
+            const WSeg nx = wseg(bf, 11 + (7 - l) + 1, n0 + li, hh);
+            stream_gemm_bf<2, 2, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, &nx, wcur);   // dh_{l-1}
+            seg = nx;
+        } else {
+            stream_gemm_bf<2, 2, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight / bias gradients: dW[out][in] = sum over points of dz[p][out] * x[p][in], split over point
 // ranges; operands are read straight from global (lane = consecutive column: coalesced rows)
@@ -953,6 +1037,7 @@ bool attrs_set = false;
 void set_attrs()
 {
     if (attrs_set) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_bwd_bf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_BWD_BF_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd_bf<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_BF_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd_bf<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_BF_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
@@ -1074,7 +1159,8 @@ extern "C" int gft_deform_backward(void* hip_stream, int64_t n, const void* pack
         a.signs = reinterpret_cast<const uint32_t*>(acts + n_pad * DF_D * DF_W);
         a.g_dxyz = g_d_xyz; a.g_dsh = g_d_sh;
         a.dz = dz; a.dzh = dzh;
-        hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(n_pad / (32 * DF_NR_BWD))), dim3(256), DF_BWD_LDS, s, a);
+        if (bf16_planes()) hipLaunchKernelGGL(k_deform_bwd_bf, dim3((unsigned)(n_pad / 64)), dim3(256), DF_BWD_BF_LDS, s, a);
+        else hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(n_pad / (32 * DF_NR_BWD))), dim3(256), DF_BWD_LDS, s, a);
         GFT_CHECK_HIP(hipGetLastError());
     }
     int tps;
