@@ -237,6 +237,7 @@ def assemble_extra(dev, P=1_000_000, frac=0.3, M=16, steps=20, warmup=5):
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 in / fp32 accumulate
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA; a product of the deformation network costs six of them
 
 
 def deform_extra(dev, n=300_000, steps=10, warmup=3):
@@ -303,10 +304,12 @@ def deform_extra(dev, n=300_000, steps=10, warmup=3):
     macs = macs_fwd + (7 * 256 * 256 + 51 * 256) + macs_fwd
     tf = 2.0 * macs * n / (ms * 1e-3) / 1e12
     tf_fwd = 2.0 * macs_fwd * n / (fwd_ms * 1e-3) / 1e12
-    return {"what": "deformation network fwd+bwd (SURVEY 8(f)#2), %d points, fp32 MFMA" % n,
+    return {"what": "deformation network fwd+bwd (SURVEY 8(f)#2), %d points, fp32 results from six bf16 MFMAs per product "
+                    "(GFT_DEFORM_BF16X3=0: fp32-operand MFMA)" % n,
             "fwd_bwd_ms": ms, "inference_fwd_ms": fwd_ms, "eager_torch_ms": eager_ms, "speedup_vs_eager": eager_ms / ms,
             "algorithmic_flops": 2.0 * macs * n, "achieved_TFLOPs": tf, "inference_TFLOPs": tf_fwd,
             "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS,
+            "bf16x6_bound_TFLOPs": BF16_MFMA_PEAK_TFLOPS / 6.0, "frac_of_bf16x6_bound": tf / (BF16_MFMA_PEAK_TFLOPS / 6.0),
             "inference_frac_of_peak": tf_fwd / FP32_MFMA_PEAK_TFLOPS,
             "points_per_s": n / (ms * 1e-3),
             "cpu_baseline": {"value": ns / cpu_s, "unit": "points/s", "cores": os.cpu_count(), "kind": "port",

@@ -941,6 +941,116 @@ __device__ __forceinline__ void dw_job(const float* A, int lda, int n_base, cons
     }
 }
 
+// The same block of dW from six bf16 MFMAs per product: a lane loads, per 16-point step, the eight values of its
+// output row (column of dz) and of its input column (column of x) at its eight points -- v_mfma_f32_32x32x16_bf16
+// wants eight consecutive k per lane, k = point here -- splits them into hi / mid / lo and multiplies; the
+// operands stay fp32 in memory (4 B per element from HBM instead of 6), the split costs VALU time between the
+// multiplies of consecutive steps.
+template <int TN, int TK, bool BIAS>
+__device__ __forceinline__ void dw_job_bf(const float* A, int lda, int n_base, const float* B, int ldb, int k_base, float* out,
+                                          int out_ld, float* bias_out, bool write_bias, int64_t p_begin, int64_t p_end, int li, int hh)
+{
+    f32x16 acc[TN][TK];
+    zero_acc(acc);
+    float bsum[TN];
+#pragma unroll
+    for (int x = 0; x < TN; x++) bsum[x] = 0.f;
+    const float* Ap = A + (p_begin + 8 * hh) * lda + n_base + li;
+    const float* Bp = B + (p_begin + 8 * hh) * ldb + k_base + li;
+    float ra[TN][8], rb[TK][8];                     // raw values of the next step
+    auto fetch = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+#pragma unroll
+            for (int x = 0; x < TN; x++) ra[x][j] = Ap[(int64_t)j * lda + 32 * x];
+#pragma unroll
+            for (int y = 0; y < TK; y++) rb[y][j] = Bp[(int64_t)j * ldb + 32 * y];
+        }
+        Ap += 16 * lda;
+        Bp += 16 * ldb;
+    };
+    auto split8 = [&](const float (&v)[8], bf16x8 (&pl)[3]) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            __bf16 h, m, l;
+            split3(v[j], h, m, l);
+            pl[0][j] = h; pl[1][j] = m; pl[2][j] = l;
+        }
+    };
+    if (p_begin < p_end) fetch();
+    for (int64_t p = p_begin; p < p_end; p += 16) {
+        bf16x8 pa[TN][3], pb[TK][3];
+#pragma unroll
+        for (int x = 0; x < TN; x++) {
+            if (BIAS) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) bsum[x] += ra[x][j];
+            }
+            split8(ra[x], pa[x]);
+        }
+#pragma unroll
+        for (int y = 0; y < TK; y++) split8(rb[y], pb[y]);
+        if (p + 16 < p_end) fetch();                 // next step's loads fly during the multiplies
+#pragma unroll
+        for (int term = 0; term < 6; term++) {
+            const int pw = term == 0 ? 0 : term == 1 ? 1 : term == 2 ? 0 : term == 3 ? 2 : term == 4 ? 0 : 1;
+            const int pv = term == 0 ? 0 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 2 : 1;
+#pragma unroll
+            for (int x = 0; x < TN; x++)
+#pragma unroll
+                for (int y = 0; y < TK; y++)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[x][pw], pb[y][pv], acc[x][y], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < TN; x++)
+#pragma unroll
+        for (int y = 0; y < TK; y++)
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                out[(int64_t)(n_base + 32 * x + acc_row(q, hh)) * out_ld + k_base + 32 * y + li] = acc[x][y][q];
+    if (BIAS && write_bias) {
+#pragma unroll
+        for (int x = 0; x < TN; x++) {
+            const float tot = bsum[x] + __shfl_xor(bsum[x], 32);
+            if (hh == 0) bias_out[n_base + 32 * x + li] = tot;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_deform_dw_bf(DwArgs a)
+{
+    int job, split;
+    if ((int)blockIdx.x < 7 * a.splits) {
+        job = blockIdx.x % 7;
+        split = blockIdx.x / 7;
+    } else {
+        const int r = blockIdx.x - 7 * a.splits;
+        job = 7 + r % 3;
+        split = r / 3;
+    }
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int64_t p_begin = (int64_t)split * a.tiles_per_split * DF_DW_TILE;
+    int64_t p_end = p_begin + (int64_t)a.tiles_per_split * DF_DW_TILE;
+    if (p_end > a.n_pad) p_end = a.n_pad;
+    float* part = a.part + (int64_t)split * DW_PART_FLOATS;
+    const int64_t plane = a.n_pad * DF_W;
+    if (job < 7) {
+        const int l = 7 - job;
+        dw_job_bf<4, 4, true>(a.dz + l * plane, DF_W, 128 * (wave & 1), a.acts + (l - 1) * plane, DF_W, 128 * (wave >> 1),
+                              part + DW_OFF_L(l), DF_W, part + DW_OFF_BIAS + l * DF_W, (wave >> 1) == 0, p_begin, p_end, li, hh);
+    } else if (job == 7) {
+        dw_job_bf<2, 3, true>(a.dz, DF_W, 64 * wave, a.emb, DF_EMB, 0, part + DW_OFF_L0, DF_EMB, part + DW_OFF_BIAS, true, p_begin,
+                              p_end, li, hh);
+    } else if (job == 8) {
+        dw_job_bf<2, 3, false>(a.dz + 5 * plane, DF_W, 64 * wave, a.emb, DF_EMB, 0, part + DW_OFF_L5E, DF_EMB, nullptr, false,
+                               p_begin, p_end, li, hh);
+    } else {
+        dw_job_bf<2, 2, true>(a.dzh, DF_HEAD, 0, a.acts + 7 * plane, DF_W, 64 * wave, part + DW_OFF_HEAD, DF_W,
+                              part + DW_OFF_BIAS + DF_D * DF_W, wave == 0, p_begin, p_end, li, hh);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_deform_dw(DwArgs a)
 {
     // heavy jobs first: the 7 hidden-layer GEMMs of every split (7 * 146 = 4 workgroups per CU, one resident at
@@ -1172,7 +1282,8 @@ extern "C" int gft_deform_backward(void* hip_stream, int64_t n, const void* pack
         a.splits = splits;
         a.emb = emb; a.acts = acts; a.dz = dz; a.dzh = dzh;
         a.part = part;
-        hipLaunchKernelGGL(k_deform_dw, dim3(DW_JOBS * splits), dim3(256), 0, s, a);
+        if (bf16_planes()) hipLaunchKernelGGL(k_deform_dw_bf, dim3(DW_JOBS * splits), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_deform_dw, dim3(DW_JOBS * splits), dim3(256), 0, s, a);
         GFT_CHECK_HIP(hipGetLastError());
     }
     {

@@ -9,9 +9,12 @@
  * `r`/`g`/`b` (16 each).  The reference returns zeros for the rotation and phasor offsets
  * (time_utils.py:127) and never uses its `rot` / `a` heads; those are not computed here.
  *
- * This is the one GEMM-shaped piece of the path: the kernels run on the fp32 matrix cores
- * (`v_mfma_f32_32x32x2_f32`: fp32 operands, fp32 accumulation, a k-ordered fma chain per output),
- * so results are fp32 like the reference's torch modules (no reduced-precision operands).
+ * This is the one GEMM-shaped piece of the path and it runs on the matrix cores with fp32 results: every fp32
+ * operand is split exactly into three bf16 numbers (hi + mid + lo = 24 mantissa bits) and a product is the sum of
+ * six `v_mfma_f32_32x32x16_bf16` terms (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the three dropped terms are
+ * below 2^-23 of the product), accumulated in fp32: the error against a float64 product is that of an fp32 fma
+ * chain (measured 5.4e-7 vs 5.5e-7 of the max-norm), at up to 2.7 x the rate of the fp32-operand MFMA.
+ * GFT_DEFORM_BF16X3=0 in the environment selects `v_mfma_f32_32x32x2_f32` (fp32 operands) instead.
  *
  *   forward : one workgroup per 64 points walks all layers with the activations in LDS
  *             (weights streamed from L2), saving the post-ReLU activations for the backward

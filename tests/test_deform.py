@@ -291,3 +291,17 @@ def test_full_size_properties():
     for k in whole:
         assert _rel((a[k] + b[k]).cpu().numpy(), whole[k].cpu().numpy()) < 2e-5, k
     assert len(whole) == 24
+
+
+@pytest.mark.gpu
+def test_fp32_mfma_walks_still_match():
+    """GFT_DEFORM_BF16X3=0 selects the walks on v_mfma_f32_32x32x2_f32 (the default multiplies three bf16 planes per
+    operand, six MFMAs per product).  The switch is read once per process: the oracle comparisons run again in a child."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_deform.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "against_oracle or golden_vectors or determinism"],
+                       env=dict(os.environ, GFT_DEFORM_BF16X3="0"), cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
