@@ -10,7 +10,7 @@ cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv
 python3 - <<'PY'
 import csv, glob, collections, json, re
 def kname(n):
-    m = re.search(r"(k_deform_[a-z]+)(<[^>]*>)?", n)
+    m = re.search(r"(k_deform_[a-z_]+)(<[^>]*>)?", n)
     return (m.group(1) + (m.group(2) or "")) if m else None
 res = {}
 for f in glob.glob("gpurun_out/dprof/stats/**/*kernel_stats.csv", recursive=True):
