@@ -244,14 +244,16 @@ def deform_extra(dev, n=300_000, steps=10, warmup=3):
     """SURVEY 8(f) row 2 beside the headline metric: one query of the deformation network for the dynamic
     Gaussians of the metric frame (30 % of 1 M), forward + backward, against the eager-torch statements
     of the reference's module (utils/time_utils.py:103-127, restated in oracle/deform_ref.py) on the same
-    device.  Algorithmic multiply-adds per point: forward 76*256 + 6*256*256 + 332*256 + 51*256 = 510 720;
-    backward 7*256*256 + 51*256 (activation gradients) + 510 720 (weight gradients)."""
+    device.  The network is the one the reference constructs (scene/deform_model.py:9-16: t_multires 10, 84
+    encoded inputs).  Algorithmic multiply-adds per point: forward 84*256 + 6*256*256 + 340*256 + 51*256 =
+    514 816; backward 7*256*256 + 51*256 (activation gradients) + 514 816 (weight gradients).  The roofline is the
+    matrix pipe at six bf16 MFMAs per fp32 product (2 500 / 6 = 417 TFLOP/s of fp32 products)."""
     import numpy as np
     import torch
-    from gftorf_amd import DeformNetwork, _lib
+    from gftorf_amd import reference_network, _lib
     from oracle import deform_ref
     params = deform_ref.random_params(3)
-    net = DeformNetwork()
+    net = reference_network()
     net.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
     net = net.to(dev)
     pt = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in params.items()}
@@ -300,7 +302,8 @@ def deform_extra(dev, n=300_000, steps=10, warmup=3):
     t0 = time.perf_counter()
     deform_ref.backward(params, xs, ts, gx, gs)
     cpu_s = time.perf_counter() - t0
-    macs_fwd = 76 * 256 + 6 * 256 * 256 + 332 * 256 + 51 * 256
+    n_in = net.xyz_input_ch + net.t_input_ch                     # 84
+    macs_fwd = n_in * 256 + 6 * 256 * 256 + (n_in + 256) * 256 + 51 * 256
     macs = macs_fwd + (7 * 256 * 256 + 51 * 256) + macs_fwd
     tf = 2.0 * macs * n / (ms * 1e-3) / 1e12
     tf_fwd = 2.0 * macs_fwd * n / (fwd_ms * 1e-3) / 1e12
@@ -308,9 +311,14 @@ def deform_extra(dev, n=300_000, steps=10, warmup=3):
                     "(GFT_DEFORM_BF16X3=0: fp32-operand MFMA)" % n,
             "fwd_bwd_ms": ms, "inference_fwd_ms": fwd_ms, "eager_torch_ms": eager_ms, "speedup_vs_eager": eager_ms / ms,
             "algorithmic_flops": 2.0 * macs * n, "achieved_TFLOPs": tf, "inference_TFLOPs": tf_fwd,
-            "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS,
-            "bf16x6_bound_TFLOPs": BF16_MFMA_PEAK_TFLOPS / 6.0, "frac_of_bf16x6_bound": tf / (BF16_MFMA_PEAK_TFLOPS / 6.0),
-            "inference_frac_of_peak": tf_fwd / FP32_MFMA_PEAK_TFLOPS,
+            "architecture": dict(D=net.D, W=net.W, xyz_multires=net.xyz_multires, t_multires=net.t_multires,
+                                 encoded_inputs=n_in, parameters=sum(p.numel() for p in net.parameters())),
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": BF16_MFMA_PEAK_TFLOPS / 6.0, "unit": "TFLOP/s",
+                         "frac": tf / (BF16_MFMA_PEAK_TFLOPS / 6.0),
+                         "note": "fp32 products on the bf16 matrix pipe cost six v_mfma_f32_32x32x16_bf16 each: "
+                                 "peak = 2500 / 6 TFLOP/s of fp32 multiply-adds"},
+            "inference_frac": tf_fwd / (BF16_MFMA_PEAK_TFLOPS / 6.0),
+            "ratio_to_fp32_operand_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS,
             "points_per_s": n / (ms * 1e-3),
             "cpu_baseline": {"value": ns / cpu_s, "unit": "points/s", "cores": os.cpu_count(), "kind": "port",
                              "sample": "%d points, forward + backward of oracle/deform_ref.py (numpy fp32 BLAS)" % ns}}
@@ -319,14 +327,14 @@ def deform_extra(dev, n=300_000, steps=10, warmup=3):
 def deform_exchange(dev, dist, rank, world, n=300_000, steps=10, warmup=3):
     """The path's one exchange step, measured on all ranks beside the sharded raster metric:
     every rank queries the deformation network for its own frame's time (fwd + bwd, 30 % of 1 M Gaussians),
-    then ONE all-reduce of the 2.05 MB gradient bucket (RCCL over xGMI) makes the replicas' gradients equal.
+    then ONE all-reduce of the 2.07 MB gradient bucket (RCCL over xGMI) makes the replicas' gradients equal.
     Barrier-bracketed, MAX over ranks, like the headline timing."""
     import numpy as np
     import torch
-    from gftorf_amd import DeformNetwork
+    from gftorf_amd import reference_network
     from gftorf_amd.deform import allreduce_gradients, flat_grad_bucket
     torch.manual_seed(7)                                  # identical replicas
-    net = DeformNetwork()
+    net = reference_network()
     for name, p in net.named_parameters():
         if name.endswith("weight"):
             torch.nn.init.normal_(p, 0.0, 0.06)
@@ -438,7 +446,7 @@ def train_iteration_extra(dev, scene, steps=10, warmup=3):
     ROCm, so both columns share ours."""
     import numpy as np
     import torch
-    from gftorf_amd import (DeformNetwork, FusedAdam, GaussianRasterizationSettings, GaussianRasterizer, assemble_inputs,
+    from gftorf_amd import (reference_network, FusedAdam, GaussianRasterizationSettings, GaussianRasterizer, assemble_inputs,
                             densify)
     from oracle import assemble_ref, deform_ref, densify_ref
     cam, cfg, g = scene["cam"], scene["cfg"], scene["gaussians"]
@@ -462,7 +470,7 @@ def train_iteration_extra(dev, scene, steps=10, warmup=3):
             v.requires_grad_(True)
         groups = [{"params": [v], "lr": 1e-5, "name": k} for k, v in leaf.items()]
         if fused:
-            net = DeformNetwork()
+            net = reference_network()
             net.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
             net = net.to(dev)
             opt, net_params = FusedAdam(groups, lr=0.0, eps=1e-15), list(net.parameters())

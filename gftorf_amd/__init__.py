@@ -10,8 +10,8 @@ from .api import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_g
 from .assemble import assemble_inputs  # noqa: F401
 from .knn import distCUDA2  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
-from .deform import DeformNetwork  # noqa: F401
+from .deform import DeformNetwork, REFERENCE_ARCH, reference_network  # noqa: F401
 from . import densify  # noqa: F401
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "assemble_inputs", "distCUDA2", "FusedAdam",
-           "DeformNetwork", "densify"]
+           "DeformNetwork", "REFERENCE_ARCH", "reference_network", "densify"]

@@ -8,7 +8,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
+DEFORM_MAX_INPUTS = 96          # GFT_DEFORM_MAX_INPUTS (include/gftorf_deform.h)
 ACC_STRIDE = 16
 
 _lib = None
@@ -113,7 +114,7 @@ EXPORTS = [
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
     "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step",
-    "gft_deform_packed_bytes", "gft_deform_saved_bytes", "gft_deform_scratch_bytes", "gft_deform_pack",
+    "gft_deform_inputs", "gft_deform_packed_bytes", "gft_deform_saved_bytes", "gft_deform_scratch_bytes", "gft_deform_pack",
     "gft_deform_forward", "gft_deform_backward",
     "gft_densify_stats", "gft_rows_rank_scratch_bytes", "gft_rows_rank", "gft_rows_gather",
 ]
@@ -158,12 +159,14 @@ def load():
     lib.gft_deform_scratch_bytes.restype = C.c_size_t
     lib.gft_deform_scratch_bytes.argtypes = [C.c_int64]
     lib.gft_deform_pack.restype = C.c_int
-    lib.gft_deform_pack.argtypes = [C.c_void_p, C.POINTER(DeformParams), C.c_void_p]
+    lib.gft_deform_inputs.restype = C.c_int
+    lib.gft_deform_inputs.argtypes = [C.c_int, C.c_int]
+    lib.gft_deform_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(DeformParams), C.c_void_p]
     lib.gft_deform_forward.restype = C.c_int
-    lib.gft_deform_forward.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+    lib.gft_deform_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]
     lib.gft_deform_backward.restype = C.c_int
-    lib.gft_deform_backward.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    lib.gft_deform_backward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(DeformParams)]
     lib.gft_densify_stats.restype = C.c_int
     lib.gft_densify_stats.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8

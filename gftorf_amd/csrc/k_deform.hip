@@ -20,16 +20,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int DF_D = GFT_DEFORM_LAYERS;
 constexpr int DF_W = GFT_DEFORM_WIDTH;
-constexpr int DF_IN = GFT_DEFORM_INPUTS;   // 76
-constexpr int DF_INK = 80;                 // encoding as a GEMM k-extent (multiple of 16, zero rows)
-constexpr int DF_EMB = 96;                 // stored encoding row (3 column tiles of the weight-gradient GEMM)
+// The encoded input has `in` = 3 + 6 xyz_multires + 1 + 2 t_multires columns (run-time: 84 for the reference's
+// configured network, arguments/__init__.py:68-69; 76 for the class default, time_utils.py:57); every buffer holds
+// DF_INK = 96 columns, the ones from `in` on are zero (zero weight rows, zero encoding columns).
+constexpr int DF_INK = GFT_DEFORM_MAX_INPUTS;   // encoding as a GEMM k-extent (multiple of 16)
+constexpr int DF_EMB = GFT_DEFORM_MAX_INPUTS;   // stored encoding row (3 column tiles of the weight-gradient GEMM)
+static_assert(DF_INK == 96, "the encoding tiles assume 96 columns");
 constexpr int DF_HEAD = 64;                // head columns: 48 (d_sh, [coefficient][channel]) + 3 (d_xyz) + pad
 // 32-point row tiles per wave = points per workgroup / 32.  Measured on MI355X (300 k points): forward 64 points
 // 2.70 ms (one workgroup per CU; 2.83 with two), 96 points 3.21 ms; backward 64 points 2.89 ms, 96 points 2.81 ms.
 constexpr int DF_NR_FWD = 2;
 constexpr int DF_NR_BWD = 3;
 constexpr int DF_PAD = 192;                // point counts are padded to a multiple of both walk tiles and of 64
-constexpr int DF_ES = 84;                  // LDS row stride of the encoding
+constexpr int DF_ES = 100;                 // LDS row stride of the encoding (16-byte reads of 16 rows hit 16 bank groups)
 constexpr int DF_DW_TILE = 64;             // point granularity of the weight-gradient splits
 constexpr int DF_HS = 260;                 // LDS row strides (floats): 16-byte reads of 16 rows hit 16 bank groups
 
@@ -69,6 +72,7 @@ __host__ __device__ inline DfSeg df_seg(int s)
 struct PackArgs {
     gft_deform_params p;
     float* out;
+    int in;                                // encoded inputs (<= DF_INK)
 };
 
 // head column hc -> (weight row pointer, bias): columns 0..47 are d_sh[coefficient c][channel ch] = c*3+ch
@@ -101,14 +105,14 @@ __global__ __launch_bounds__(256) void k_deform_pack(PackArgs a)
             const int l = e < DF_F_SZ0 ? 0 : 5;
             const int64_t r = e < DF_F_SZ0 ? e : e - enc5;
             const int kq = (int)(r / (DF_W * 4)), n = (int)((r >> 2) % DF_W), k = 4 * kq + (int)(r & 3);
-            const int ld = l == 0 ? DF_IN : DF_W + DF_IN;
-            v = k < DF_IN ? a.p.linear_w[l][(size_t)n * ld + k] : 0.f;
+            const int ld = l == 0 ? a.in : DF_W + a.in;
+            v = k < a.in ? a.p.linear_w[l][(size_t)n * ld + k] : 0.f;
         } else if (e < DF_F_TOTAL - DF_F_HEAD_SZ) {
             const int64_t r1 = e < enc5 ? e - DF_F_SZ0 : e - 2 * DF_F_SZ0;
             const int l = 1 + (int)(r1 / DF_F_SZ);
             const int64_t r = r1 % DF_F_SZ;
             const int kq = (int)(r / (DF_W * 4)), n = (int)((r >> 2) % DF_W), k = 4 * kq + (int)(r & 3);
-            v = l == 5 ? a.p.linear_w[5][(size_t)n * (DF_W + DF_IN) + DF_IN + k] : a.p.linear_w[l][(size_t)n * DF_W + k];
+            v = l == 5 ? a.p.linear_w[5][(size_t)n * (DF_W + a.in) + a.in + k] : a.p.linear_w[l][(size_t)n * DF_W + k];
         } else {
             const int64_t r = e - (DF_F_TOTAL - DF_F_HEAD_SZ);
             const int kq = (int)(r / (DF_HEAD * 4)), n = (int)((r >> 2) % DF_HEAD), k = 4 * kq + (int)(r & 3);
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void k_deform_pack(PackArgs a)
             const int l = 7 - (int)(r1 / DF_F_SZ);
             const int64_t r = r1 % DF_F_SZ;
             const int kq = (int)(r / (DF_W * 4)), n = (int)((r >> 2) % DF_W), k = 4 * kq + (int)(r & 3);
-            v = l == 5 ? a.p.linear_w[5][(size_t)k * (DF_W + DF_IN) + DF_IN + n] : a.p.linear_w[l][(size_t)k * DF_W + n];
+            v = l == 5 ? a.p.linear_w[5][(size_t)k * (DF_W + a.in) + a.in + n] : a.p.linear_w[l][(size_t)k * DF_W + n];
         }
     } else {
         const int r = (int)(e - DF_BIAS_BASE);
@@ -260,6 +264,7 @@ __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 *
 // ---------------------------------------------------------------------------------------------
 struct FwdArgs {
     int64_t n, n_pad, t_stride;
+    int xm, tm;       // octaves of the xyz / t encodings (time_utils.py:64-65)
     const float* xyz; const float* t;
     const float* packed;
     float* emb;       // [n_pad][96] or null
@@ -298,8 +303,7 @@ __global__ __launch_bounds__(256) void k_deform_fwd(FwdArgs a)
         if (grp < 3) {
             const float v = p < a.n ? a.xyz[3 * p + grp] : 0.f;
             e[grp] = v;
-#pragma unroll
-            for (int f = 0; f < 10; f++) {
+            for (int f = 0; f < a.xm; f++) {
                 float sn, cs;
                 sincosf(v * (float)(1 << f), &sn, &cs);
                 e[3 + 6 * f + grp] = sn;
@@ -307,22 +311,22 @@ __global__ __launch_bounds__(256) void k_deform_fwd(FwdArgs a)
             }
         } else {
             const float v = p < a.n ? a.t[p * a.t_stride] : 0.f;
-            e[63] = v;
-#pragma unroll
-            for (int f = 0; f < 6; f++) {
+            const int t0 = 3 + 6 * a.xm;
+            e[t0] = v;
+            for (int f = 0; f < a.tm; f++) {
                 float sn, cs;
                 sincosf(v * (float)(1 << f), &sn, &cs);
-                e[64 + 2 * f] = sn;
-                e[65 + 2 * f] = cs;
+                e[t0 + 1 + 2 * f] = sn;
+                e[t0 + 2 + 2 * f] = cs;
             }
-            e[76] = e[77] = e[78] = e[79] = 0.f;
+            for (int c = t0 + 1 + 2 * a.tm; c < DF_INK; c++) e[c] = 0.f;
         }
     }
     __syncthreads();
     if (SAVE) {
         for (int q = tid; q < (32 * DF_NR_FWD) * DF_EMB; q += 256) {
             const int row = q / DF_EMB, col = q - row * DF_EMB;
-            a.emb[(p0 + row) * DF_EMB + col] = col < DF_INK ? eA[row * DF_ES + col] : 0.f;
+            a.emb[(p0 + row) * DF_EMB + col] = eA[row * DF_ES + col];
         }
     }
 
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(256) void k_deform_fwd(FwdArgs a)
 // weights come as three bf16 planes from the packed copy.
 // ---------------------------------------------------------------------------------------------
 constexpr int DF_BH = 264;                 // bf16 per activation row of a plane (528 B: 16-byte reads of 16 rows hit 16 bank groups)
-constexpr int DF_BE = 88;                  // bf16 per encoding row of a plane
+constexpr int DF_BE = 104;                 // bf16 per encoding row of a plane (208 B: 16-byte reads of 16 rows hit 16 bank groups)
 constexpr size_t DF_BF_ACT_PLANE = (size_t)64 * DF_BH * 2, DF_BF_ENC_PLANE = (size_t)64 * DF_BE * 2;
 constexpr size_t DF_FWD_BF_LDS = 3 * DF_BF_ACT_PLANE + 3 * DF_BF_ENC_PLANE + (size_t)DF_BIAS_FLOATS * 4;   // 144640
 
@@ -558,8 +562,7 @@ __global__ __launch_bounds__(256) void k_deform_fwd_bf(FwdArgs a)
         if (grp < 3) {
             const float v = p < a.n ? a.xyz[3 * p + grp] : 0.f;
             put(grp, v);
-#pragma unroll
-            for (int f = 0; f < 10; f++) {
+            for (int f = 0; f < a.xm; f++) {
                 float sn, cs;
                 sincosf(v * (float)(1 << f), &sn, &cs);
                 put(3 + 6 * f + grp, sn);
@@ -567,19 +570,15 @@ __global__ __launch_bounds__(256) void k_deform_fwd_bf(FwdArgs a)
             }
         } else {
             const float v = p < a.n ? a.t[p * a.t_stride] : 0.f;
-            put(63, v);
-#pragma unroll
-            for (int f = 0; f < 6; f++) {
+            const int t0 = 3 + 6 * a.xm;
+            put(t0, v);
+            for (int f = 0; f < a.tm; f++) {
                 float sn, cs;
                 sincosf(v * (float)(1 << f), &sn, &cs);
-                put(64 + 2 * f, sn);
-                put(65 + 2 * f, cs);
+                put(t0 + 1 + 2 * f, sn);
+                put(t0 + 2 + 2 * f, cs);
             }
-#pragma unroll
-            for (int c = DF_IN; c < DF_EMB; c++) {
-                if (c < DF_INK) put(c, 0.f);
-                else if (SAVE) a.emb[p * DF_EMB + c] = 0.f;
-            }
+            for (int c = t0 + 1 + 2 * a.tm; c < DF_INK; c++) put(c, 0.f);
         }
     }
     __syncthreads();
@@ -1159,6 +1158,16 @@ void set_attrs()
 }  // namespace
 
 
+// encoded inputs of an (xyz_multires, t_multires) network, or -1 when the kernels do not hold it
+int arch_inputs(int xm, int tm)
+{
+    if (xm < 0 || tm < 0 || xm > 16 || tm > 24) return -1;
+    const int in = 3 + 6 * xm + 1 + 2 * tm;
+    return in <= DF_INK ? in : -1;
+}
+
+extern "C" int gft_deform_inputs(int xyz_multires, int t_multires) { return arch_inputs(xyz_multires, t_multires); }
+
 extern "C" size_t gft_deform_packed_bytes(void) { return (size_t)(DF_PACKED_FLOATS + DF_BF_FLOATS) * sizeof(float); }
 
 extern "C" size_t gft_deform_saved_bytes(int64_t n)
@@ -1176,9 +1185,13 @@ extern "C" size_t gft_deform_scratch_bytes(int64_t n)
     return ((size_t)n_pad * (DF_D * DF_W + DF_HEAD) + (size_t)splits * DW_PART_FLOATS) * sizeof(float);
 }
 
-extern "C" int gft_deform_pack(void* hip_stream, const gft_deform_params* p, void* packed)
+extern "C" int gft_deform_pack(void* hip_stream, int xyz_multires, int t_multires, const gft_deform_params* p, void* packed)
 {
     if (!p || !packed) return gft_fail("gft_deform_pack: NULL argument");
+    const int in = arch_inputs(xyz_multires, t_multires);
+    if (in < 0)
+        return gft_fail("gft_deform_pack: xyz_multires = %d, t_multires = %d give more than %d encoded inputs", xyz_multires,
+                        t_multires, DF_INK);
     for (int l = 0; l < DF_D; l++)
         if (!p->linear_w[l] || !p->linear_b[l]) return gft_fail("gft_deform_pack: linear.%d parameters are NULL", l);
     if (!p->xyz_w || !p->xyz_b || !p->r_w || !p->r_b || !p->g_w || !p->g_b || !p->b_w || !p->b_b)
@@ -1186,6 +1199,7 @@ extern "C" int gft_deform_pack(void* hip_stream, const gft_deform_params* p, voi
     PackArgs a;
     a.p = *p;
     a.out = (float*)packed;
+    a.in = in;
     hipLaunchKernelGGL(k_deform_pack, dim3((unsigned)((DF_PACKED_FLOATS + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, a);
     GFT_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_deform_pack_bf, dim3((unsigned)((DF_BF_ELEMS + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
@@ -1194,10 +1208,13 @@ extern "C" int gft_deform_pack(void* hip_stream, const gft_deform_params* p, voi
     return 0;
 }
 
-extern "C" int gft_deform_forward(void* hip_stream, int64_t n, const float* xyz, const float* t, int64_t t_stride,
-                                  const void* packed, void* saved, float* d_xyz, float* d_sh)
+extern "C" int gft_deform_forward(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const float* xyz, const float* t,
+                                  int64_t t_stride, const void* packed, void* saved, float* d_xyz, float* d_sh)
 {
     if (n < 0) return gft_fail("gft_deform_forward: n < 0");
+    if (arch_inputs(xyz_multires, t_multires) < 0)
+        return gft_fail("gft_deform_forward: xyz_multires = %d, t_multires = %d give more than %d encoded inputs", xyz_multires,
+                        t_multires, DF_INK);
     if (n == 0) return 0;
     if (!xyz || !t || !packed || !d_xyz || !d_sh) return gft_fail("gft_deform_forward: NULL argument");
     if (t_stride != 0 && t_stride != 1) return gft_fail("gft_deform_forward: t_stride must be 0 or 1");
@@ -1207,6 +1224,8 @@ extern "C" int gft_deform_forward(void* hip_stream, int64_t n, const float* xyz,
     a.n = n;
     a.n_pad = pad_points(n);
     a.t_stride = t_stride;
+    a.xm = xyz_multires;
+    a.tm = t_multires;
     a.xyz = xyz;
     a.t = t;
     a.packed = (const float*)packed;
@@ -1228,10 +1247,15 @@ extern "C" int gft_deform_forward(void* hip_stream, int64_t n, const float* xyz,
     return 0;
 }
 
-extern "C" int gft_deform_backward(void* hip_stream, int64_t n, const void* packed, const void* saved, const float* g_d_xyz,
-                                   const float* g_d_sh, void* scratch, const gft_deform_grads* g)
+extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const void* packed,
+                                   const void* saved, const float* g_d_xyz, const float* g_d_sh, void* scratch,
+                                   const gft_deform_grads* g)
 {
     if (n < 0) return gft_fail("gft_deform_backward: n < 0");
+    const int DF_IN = arch_inputs(xyz_multires, t_multires);
+    if (DF_IN < 0)
+        return gft_fail("gft_deform_backward: xyz_multires = %d, t_multires = %d give more than %d encoded inputs", xyz_multires,
+                        t_multires, DF_INK);
     if (!g) return gft_fail("gft_deform_backward: grads is NULL");
     for (int l = 0; l < DF_D; l++)
         if (!g->linear_w[l] || !g->linear_b[l]) return gft_fail("gft_deform_backward: linear.%d gradient pointers are NULL", l);

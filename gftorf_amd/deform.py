@@ -23,8 +23,7 @@ from torch import nn
 
 from . import _lib
 
-_D, _W, _XYZ_MULTIRES, _T_MULTIRES, _SH_DEGREE = 8, 256, 10, 6, 3
-_IN = 3 + 6 * _XYZ_MULTIRES + 1 + 2 * _T_MULTIRES      # 76
+_D, _W, _SH_DEGREE = 8, 256, 3
 
 
 def _param_list(mod):
@@ -49,7 +48,7 @@ def _fill(struct, tensors):
 
 class _DeformFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, t, *params):
+    def forward(ctx, xm, tm, x, t, *params):
         lib = _lib.load()
         dev = x.device
         if dev.type != "cuda":
@@ -71,7 +70,7 @@ class _DeformFn(torch.autograd.Function):
             if p.device != dev or p.dtype != torch.float32:
                 raise RuntimeError("DeformNetwork parameters must be float32 on %s" % (dev,))
             ps.append(p.detach().contiguous())
-        need_bw = any(ctx.needs_input_grad[2:])      # all False under torch.no_grad()
+        need_bw = any(ctx.needs_input_grad[4:])      # all False under torch.no_grad()
         f32 = dict(device=dev, dtype=torch.float32)
         packed = torch.empty((lib.gft_deform_packed_bytes() // 4,), **f32)
         d_xyz = torch.empty((n, 3), **f32)
@@ -79,11 +78,12 @@ class _DeformFn(torch.autograd.Function):
         saved = torch.empty((lib.gft_deform_saved_bytes(n) // 4,), **f32) if (need_bw and n > 0) else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            _lib.check(lib.gft_deform_pack(stream, C.byref(_fill(_lib.DeformParams(), ps)), packed.data_ptr()))
-            _lib.check(lib.gft_deform_forward(stream, n, x_c.data_ptr() if n else None, t_c.data_ptr() if n else None,
+            _lib.check(lib.gft_deform_pack(stream, xm, tm, C.byref(_fill(_lib.DeformParams(), ps)), packed.data_ptr()))
+            _lib.check(lib.gft_deform_forward(stream, xm, tm, n, x_c.data_ptr() if n else None, t_c.data_ptr() if n else None,
                                               t_stride, packed.data_ptr(), saved.data_ptr() if saved is not None else None,
                                               d_xyz.data_ptr() if n else None, d_sh.data_ptr() if n else None))
         ctx.n = n
+        ctx.arch = (xm, tm)
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.save_for_backward(packed, saved if saved is not None else packed.new_empty(0))
         ctx.set_materialize_grads(False)
@@ -104,23 +104,33 @@ class _DeformFn(torch.autograd.Function):
         scratch = torch.empty((lib.gft_deform_scratch_bytes(n) // 4,), **f32)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            _lib.check(lib.gft_deform_backward(stream, n, packed.data_ptr(), saved.data_ptr() if n else None,
+            _lib.check(lib.gft_deform_backward(stream, ctx.arch[0], ctx.arch[1], n, packed.data_ptr(), saved.data_ptr() if n else None,
                                                gx.data_ptr() if (gx is not None and n) else None,
                                                gs.data_ptr() if (gs is not None and n) else None,
                                                scratch.data_ptr() if n else None,
                                                C.byref(_fill(_lib.DeformParams(), grads))))
-        return (None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[2:]))
+        return (None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[4:]))
 
 
 class DeformNetwork(nn.Module):
-    """Drop-in for ``utils.time_utils.DeformNetwork`` (time_utils.py:56-127)."""
+    """Drop-in for ``utils.time_utils.DeformNetwork`` (time_utils.py:56-127).
+
+    The reference constructs it as ``DeformNetwork(D=8, W=256, xyz_multires=10, t_multires=10, sh_degree=3)``
+    (``scene/deform_model.py:9-16`` from ``arguments/__init__.py:66-69``; ``configs/torf.json:9-12`` and
+    ``configs/ftorf.json`` say the same): 84 encoded inputs, ``linear.0.weight [256, 84]``,
+    ``linear.5.weight [256, 340]``, 522 055 parameters.  The signature's own default ``t_multires=6`` (76
+    inputs) is kept as the reference has it.  Any octave counts whose encoding has at most 96 columns run on
+    the same kernels; D, W and the SH degree are those of every shipped configuration."""
 
     def __init__(self, D=8, W=256, xyz_multires=10, t_multires=6, sh_degree=3):
         super().__init__()
-        if (D, W, xyz_multires, t_multires, sh_degree) != (_D, _W, _XYZ_MULTIRES, _T_MULTIRES, _SH_DEGREE):
+        n_in = 3 + 6 * xyz_multires + 1 + 2 * t_multires
+        if (D, W, sh_degree) != (_D, _W, _SH_DEGREE) or xyz_multires < 0 or t_multires < 0 or n_in > _lib.DEFORM_MAX_INPUTS:
             raise NotImplementedError(
-                "gftorf_amd.DeformNetwork is built for the reference's default architecture "
-                "(D=8, W=256, xyz_multires=10, t_multires=6, sh_degree=3); got %s" % ((D, W, xyz_multires, t_multires, sh_degree),))
+                "gftorf_amd.DeformNetwork is built for D=8, W=256, sh_degree=3 (every configuration the reference "
+                "ships) and encodings of at most %d columns (xyz_multires=10 with t_multires=10 gives 84); got %s"
+                % (_lib.DEFORM_MAX_INPUTS, (D, W, xyz_multires, t_multires, sh_degree)))
+        _IN = n_in
         self.D, self.W = D, W
         self.xyz_multires, self.t_multires = xyz_multires, t_multires
         self.skips = [D // 2]
@@ -154,15 +164,25 @@ class DeformNetwork(nn.Module):
             nn.init.constant_(head.bias, 0.0)
 
     def forward(self, x, t):
-        d_xyz, d_sh = _DeformFn.apply(x, t, *_param_list(self))
+        d_xyz, d_sh = _DeformFn.apply(self.xyz_multires, self.t_multires, x, t, *_param_list(self))
         n = x.size(0)
         zeros = lambda *shape: torch.zeros(shape, device=x.device, dtype=torch.float32)
         return d_xyz, zeros(n, 4), d_sh, zeros(n, self.num_shs, 2)
 
 
+# scene/deform_model.py:9-16 with the values of arguments/__init__.py:66-69 (= configs/torf.json:9-12, configs/ftorf.json)
+REFERENCE_ARCH = dict(D=8, W=256, xyz_multires=10, t_multires=10, sh_degree=3)
+
+
+def reference_network():
+    """The network as the reference's ``DeformModel`` constructs it (84 encoded inputs, 522 055 parameters)."""
+    return DeformNetwork(**REFERENCE_ARCH)
+
+
 def flat_grad_bucket(module):
-    """The gradients of the parameters that receive one, as ONE flat fp32 tensor (517 959 - 5 140 unused
-    head values = 512 819 elements, 2.05 MB) plus the function that scatters a (reduced) bucket back:
+    """The gradients of the parameters that receive one, as ONE flat fp32 tensor (the reference's network:
+    522 055 - 5 140 unused head values = 516 915 elements, 2.07 MB) plus the function that scatters a
+    (reduced) bucket back:
     the unit of the data-parallel all-reduce over RCCL."""
     ps = [p for p in _param_list(module) if p.grad is not None]
     flat = torch.cat([p.grad.reshape(-1) for p in ps]) if ps else torch.empty(0)

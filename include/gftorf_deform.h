@@ -4,8 +4,11 @@
  * `DeformNetwork` of the reference (utils/time_utils.py:56-127),
  * queried 1-4 times per training iteration for the dynamic Gaussians
  * (scene/gaussian_model.py:170-174, train.py:164-177): positional encoding of (xyz, t)
- * (10 and 6 octaves, 76 inputs), 8 x (Linear + ReLU) of width 256 with the encoding
- * concatenated in front of the activations after layer 4, heads `xyz_warp` (3) and
+ * (xyz_multires and t_multires octaves: 10 and 10 = 84 inputs as the reference constructs it,
+ * scene/deform_model.py:9-16 from arguments/__init__.py:66-69 and configs/{torf,ftorf}.json;
+ * 10 and 6 = 76 inputs are the class defaults, time_utils.py:57), 8 x (Linear + ReLU) of width
+ * 256 with the encoding concatenated in front of the activations after layer 4
+ * (linear.5.weight is [256, in + 256]), heads `xyz_warp` (3) and
  * `r`/`g`/`b` (16 each).  The reference returns zeros for the rotation and phasor offsets
  * (time_utils.py:127) and never uses its `rot` / `a` heads; those are not computed here.
  *
@@ -21,10 +24,12 @@
  *   backward: the same walk in reverse for the activation gradients, then the weight / bias
  *             gradients as point-split GEMMs (partial sums + one reduction: deterministic)
  *
- * Only the reference's default architecture (D = 8, W = 256, xyz_multires = 10,
- * t_multires = 6, sh_degree = 3; arguments/__init__.py) is built.  All pointers are device
- * pointers to fp32; every function returns 0 on success (gft_last_error()).  Inputs are not
- * differentiated (the reference detaches them, scene/gaussian_model.py:172).
+ * Built for D = 8, W = 256, sh_degree = 3 (arguments/__init__.py:66-67, both shipped configs) and any
+ * (xyz_multires, t_multires) whose encoding has at most GFT_DEFORM_MAX_INPUTS columns -- the
+ * octave counts are run-time arguments of every call (gft_deform_inputs() gives the column count, -1
+ * when it does not fit).  All pointers are device pointers to fp32; every function returns 0 on
+ * success (gft_last_error()).  Inputs are not differentiated (the reference detaches them,
+ * scene/gaussian_model.py:172).
  */
 #ifndef GFTORF_DEFORM_H
 #define GFTORF_DEFORM_H
@@ -38,12 +43,13 @@ extern "C" {
 
 #define GFT_DEFORM_LAYERS 8
 #define GFT_DEFORM_WIDTH 256
-#define GFT_DEFORM_INPUTS 76     /* 63 (xyz) + 13 (t) encoded inputs */
+#define GFT_DEFORM_MAX_INPUTS 96 /* encoded inputs the kernels hold: 3 + 6 xyz_multires + 1 + 2 t_multires <= 96 */
 #define GFT_DEFORM_NUM_SHS 16
 
 /* Parameters in torch's layout (`nn.Linear.weight` = [out, in] row-major), state_dict names in
- * the comments.  linear_w[0] is [256,76], linear_w[5] is [256,332] (encoding first), the others
- * [256,256]. */
+ * the comments.  With in = gft_deform_inputs(xyz_multires, t_multires): linear_w[0] is [256,in]
+ * ([256,84] for the reference's configs), linear_w[5] is [256,in+256] (encoding first; [256,340]),
+ * the others [256,256]. */
 typedef struct gft_deform_params {
     const float* linear_w[GFT_DEFORM_LAYERS];   /* linear.{i}.weight */
     const float* linear_b[GFT_DEFORM_LAYERS];   /* linear.{i}.bias   [256] */
@@ -64,25 +70,29 @@ typedef struct gft_deform_grads {
     float* b_w; float* b_b;
 } gft_deform_grads;
 
-/* Sizes of the caller-owned buffers. */
+/* 3 + 6 xyz_multires + 1 + 2 t_multires (time_utils.py:8-53), or -1 when that exceeds
+ * GFT_DEFORM_MAX_INPUTS or an octave count is negative. */
+int gft_deform_inputs(int xyz_multires, int t_multires);
+
+/* Sizes of the caller-owned buffers (the same for every supported encoding). */
 size_t gft_deform_packed_bytes(void);            /* weights re-laid for the kernels */
 size_t gft_deform_saved_bytes(int64_t n);        /* forward -> backward hand-off (encoding + 8 activations) */
 size_t gft_deform_scratch_bytes(int64_t n);      /* backward scratch */
 
 /* Re-lays the parameters for the matrix-core kernels (k-interleaved, both directions, biases).
  * Call after every parameter update, before forward / backward. */
-int gft_deform_pack(void* hip_stream, const gft_deform_params* params, void* packed);
+int gft_deform_pack(void* hip_stream, int xyz_multires, int t_multires, const gft_deform_params* params, void* packed);
 
 /* d_xyz[n,3], d_sh[n,16,3] for xyz[n,3] and t (t_stride = 1: one value per point, [n,1];
  * t_stride = 0: one value for all points, as scene/gaussian_model.py:171 expands it).
  * saved = NULL: inference, nothing is kept for a backward. */
-int gft_deform_forward(void* hip_stream, int64_t n, const float* xyz, const float* t, int64_t t_stride,
-                       const void* packed, void* saved, float* d_xyz, float* d_sh);
+int gft_deform_forward(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const float* xyz, const float* t,
+                       int64_t t_stride, const void* packed, void* saved, float* d_xyz, float* d_sh);
 
 /* Gradients of the parameters for upstream gradients g_d_xyz[n,3] and g_d_sh[n,16,3]
  * (either may be NULL = zeros).  `packed` and `saved` as the forward left them. */
-int gft_deform_backward(void* hip_stream, int64_t n, const void* packed, const void* saved, const float* g_d_xyz,
-                        const float* g_d_sh, void* scratch, const gft_deform_grads* grads);
+int gft_deform_backward(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const void* packed, const void* saved,
+                        const float* g_d_xyz, const float* g_d_sh, void* scratch, const gft_deform_grads* grads);
 
 #ifdef __cplusplus
 }

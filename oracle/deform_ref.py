@@ -23,20 +23,32 @@ Only tests/, __graft_entry__.smoke() and bench.py's baseline leg may import this
 """
 import numpy as np
 
-D, W, XYZ_MULTIRES, T_MULTIRES, NUM_SHS = 8, 256, 10, 6, 16
+D, W, XYZ_MULTIRES, NUM_SHS = 8, 256, 10, 16
+# The reference constructs the network with t_multires = 10 (scene/deform_model.py:9-16 from
+# arguments/__init__.py:66-69, configs/torf.json:9-12, configs/ftorf.json): 84 encoded inputs.  The class
+# signature's default is 6 (time_utils.py:57): 76.  Every function takes ``t_multires``.
+T_MULTIRES = 10
+T_MULTIRES_CLASS_DEFAULT = 6
 SKIP = D // 2                                    # time_utils.py:62
 XYZ_CH = 3 + 3 * 2 * XYZ_MULTIRES                # 63
-T_CH = 1 + 2 * T_MULTIRES                        # 13
-IN_CH = XYZ_CH + T_CH                            # 76
+
+
+def in_ch(t_multires=T_MULTIRES, xyz_multires=XYZ_MULTIRES):
+    """Columns of cat([x_emb, t_emb]) (time_utils.py:64-65): 84 for (10, 10), 76 for (10, 6)."""
+    return 3 + 6 * xyz_multires + 1 + 2 * t_multires
+
+
+IN_CH = in_ch()                                  # 84
 HEADS = ("xyz_warp", "r", "g", "b")              # heads that reach an output
 UNUSED = ("rot", "a")                            # computed by the reference, discarded (time_utils.py:118-127)
 
 
-def param_shapes():
+def param_shapes(t_multires=T_MULTIRES, xyz_multires=XYZ_MULTIRES):
     """state_dict names -> shapes (time_utils.py:68-81)."""
     s = {}
+    n_in = in_ch(t_multires, xyz_multires)
     for i in range(D):
-        fan_in = IN_CH if i == 0 else (W + IN_CH if i == SKIP + 1 else W)
+        fan_in = n_in if i == 0 else (W + n_in if i == SKIP + 1 else W)
         s["linear.%d.weight" % i] = (W, fan_in)
         s["linear.%d.bias" % i] = (W,)
     for name, out in (("xyz_warp", 3), ("rot", 4), ("r", NUM_SHS), ("g", NUM_SHS), ("b", NUM_SHS), ("a", NUM_SHS)):
@@ -45,12 +57,21 @@ def param_shapes():
     return s
 
 
-def random_params(seed, head_std=0.05):
+def arch_of(params):
+    """(xyz_multires, t_multires) of a parameter dict, from the width of ``linear.0.weight`` (xyz_multires is 10
+    in every configuration of the reference)."""
+    n_in = params["linear.0.weight"].shape[1]
+    t2 = n_in - XYZ_CH - 1
+    assert t2 >= 0 and t2 % 2 == 0, n_in
+    return XYZ_MULTIRES, t2 // 2
+
+
+def random_params(seed, head_std=0.05, t_multires=T_MULTIRES):
     """Seeded parameters of a usable magnitude (Xavier-like trunk; heads larger than the reference's
     1e-5 initialisation so that outputs and gradients are well away from zero)."""
     rng = np.random.default_rng(seed)
     p = {}
-    for name, shape in param_shapes().items():
+    for name, shape in param_shapes(t_multires).items():
         if name.endswith(".bias"):
             p[name] = rng.normal(0.0, 0.02, shape).astype(np.float32)
         elif name.startswith("linear."):
@@ -71,13 +92,13 @@ def embed_one(v, multires, dtype):
     return np.concatenate(parts, axis=-1)
 
 
-def embed(x, t, dtype=np.float32):
-    """cat([x_emb, t_emb]) (time_utils.py:104-107): [n, 76]."""
-    return np.concatenate([embed_one(x, XYZ_MULTIRES, dtype), embed_one(t, T_MULTIRES, dtype)], axis=-1)
+def embed(x, t, dtype=np.float32, t_multires=T_MULTIRES):
+    """cat([x_emb, t_emb]) (time_utils.py:104-107): [n, 63 + 1 + 2 t_multires]."""
+    return np.concatenate([embed_one(x, XYZ_MULTIRES, dtype), embed_one(t, t_multires, dtype)], axis=-1)
 
 
 def _trunk(params, x, t, dtype):
-    emb = embed(x, t, dtype)
+    emb = embed(x, t, dtype, arch_of(params)[1])
     h = emb
     inputs, outs = [], []
     for i in range(D):                           # time_utils.py:109-113
@@ -95,7 +116,7 @@ def relu_margin(params, x, t):
     """Per point, the smallest |pre-activation| over all 8 x 256 units (float64).  The gradient is
     discontinuous where a pre-activation crosses zero, so comparisons of gradients between two
     arithmetics leave out the points whose margin is within rounding distance of that edge."""
-    emb = embed(x, t, np.float64)
+    emb = embed(x, t, np.float64, arch_of(params)[1])
     h = emb
     margin = np.full(emb.shape[0], np.inf)
     for i in range(D):
@@ -134,7 +155,7 @@ def backward(params, x, t, g_dxyz, g_dsh, dtype=np.float32):
         g["linear.%d.bias" % i] = dz.sum(axis=0)
         dh = dz @ params["linear.%d.weight" % i].astype(dtype)
         if i == SKIP + 1:
-            dh = dh[:, IN_CH:]                   # the embedded part of the skip input has no parameters
+            dh = dh[:, emb.shape[1]:]            # the embedded part of the skip input has no parameters
     return g
 
 
@@ -150,7 +171,8 @@ def deform_eager(params, x, t):
             parts += [torch.sin(v * float(2 ** f)), torch.cos(v * float(2 ** f))]
         return torch.cat(parts, -1)
 
-    emb = torch.cat([emb_one(x, XYZ_MULTIRES), emb_one(t, T_MULTIRES)], dim=-1)
+    t_multires = (params["linear.0.weight"].shape[1] - XYZ_CH - 1) // 2
+    emb = torch.cat([emb_one(x, XYZ_MULTIRES), emb_one(t, t_multires)], dim=-1)
     h = emb
     for i in range(D):
         h = F.relu(F.linear(h, params["linear.%d.weight" % i], params["linear.%d.bias" % i]))

@@ -7,10 +7,13 @@ files themselves never travel; only the input/output vectors written here do.
                    coefficients/directions, degrees 0..3
   camera.npz     : utils/graphics_utils.py getProjectionMatrix (55-75),
                    getProjectionMatrixShift (77-109), getWorld2View2 (38-49)
-  deform.npz     : utils/time_utils.py DeformNetwork (56-127), forward and autograd backward on CPU
-                   (its two hard-wired ``.cuda()`` calls are made no-ops for the run), with the seeded
-                   parameters of oracle/deform_ref.random_params; only inputs, outputs and gradients
-                   (small ones whole, weight gradients as strided samples) are stored
+  deform.npz     : utils/time_utils.py DeformNetwork (56-127) constructed as scene/deform_model.py:9-16 does,
+                   from the defaults of arguments/__init__.py ModelParams (D 8, W 256, xyz_multires 10,
+                   t_multires 10, sh_degree 3 -- also what configs/torf.json and configs/ftorf.json say):
+                   forward and autograd backward on CPU (its two hard-wired ``.cuda()`` calls are made
+                   no-ops for the run), with the seeded parameters of oracle/deform_ref.random_params; only
+                   inputs, outputs and gradients (small ones whole, weight gradients as strided samples)
+  deform_t6.npz  : the same for the class signature's defaults (t_multires 6, time_utils.py:57)
 """
 import math
 import os
@@ -33,11 +36,26 @@ from oracle import deform_ref  # noqa: E402
 DEFORM_SEED = 77
 
 
-def deform_fixture():
+def reference_kwargs():
+    """The keyword arguments scene/deform_model.py:9-15 passes, taken from ModelParams' defaults
+    (arguments/__init__.py:49-69) and checked against the two shipped configs."""
+    import argparse
+    import json
+    from arguments import ModelParams
+    args = ModelParams(argparse.ArgumentParser())
+    kwargs = {'D': args.D, 'W': args.W, 'xyz_multires': args.xyz_multires, 't_multires': args.t_multires,
+              'sh_degree': args.sh_degree}
+    for cfg in ("torf", "ftorf"):
+        j = json.load(open("/root/reference/configs/%s.json" % cfg))
+        assert all(j[k] == v for k, v in kwargs.items()), (cfg, kwargs)
+    return kwargs
+
+
+def deform_fixture(kwargs, fname):
     torch.Tensor.cuda = lambda self, *a, **k: self          # time_utils.py:121,127 on a CPU-only host
-    net = DeformNetwork()
+    net = DeformNetwork(**kwargs)
     net.isotropic = False
-    params = deform_ref.random_params(DEFORM_SEED)
+    params = deform_ref.random_params(DEFORM_SEED, t_multires=net.t_multires)
     net.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
     rng = np.random.default_rng(DEFORM_SEED + 1)
     n = 48
@@ -61,7 +79,10 @@ def deform_fixture():
             out["grad_s:" + name] = p.grad.numpy()[::8, ::4]   # strided sample of a [256, in] matrix
     out["grad_none"] = np.array(none)
     out["param_names"] = np.array(list(net.state_dict().keys()))
-    np.savez(os.path.join(HERE, "deform.npz"), **out)
+    out["param_shapes"] = np.array([";".join(map(str, v.shape)) for v in net.state_dict().values()])
+    out["num_params"] = np.int64(sum(p.numel() for p in net.parameters()))
+    out["kwargs"] = np.array([net.D, net.W, net.xyz_multires, net.t_multires, int(round(net.num_shs ** 0.5)) - 1], np.int64)
+    np.savez(os.path.join(HERE, fname), **out)
 
 
 def main():
@@ -101,7 +122,10 @@ def main():
     cams["w2v_R"], cams["w2v_t"] = R, t
     cams["w2v"] = getWorld2View2(R, t)
     np.savez(os.path.join(HERE, "camera.npz"), **cams)
-    deform_fixture()
+    kw = reference_kwargs()
+    assert kw == dict(D=8, W=256, xyz_multires=10, t_multires=10, sh_degree=3), kw
+    deform_fixture(kw, "deform.npz")
+    deform_fixture({}, "deform_t6.npz")
     print("wrote", sorted(os.listdir(HERE)))
 
 

@@ -164,16 +164,22 @@ def test_bench_refuses_to_run_without_gpu():
 
 def test_deform_size_queries_and_argument_errors(lib):
     from gftorf_amd import _lib
-    # 20480 + 6*65536 + 86016 + 16384 forward, 16384 + 7*65536 backward, 2112 biases
-    assert lib.gft_deform_packed_bytes() == (993344 + 991232 * 3 // 2) * 4      # + three bf16 planes of both weight streams
+    # 2 x 96*256 (layer 0, encoding rows of layer 5) + 7*65536 + 16384 forward, 16384 + 7*65536 backward, 2112 biases
+    assert lib.gft_deform_packed_bytes() == (1001536 + 999424 * 3 // 2) * 4     # + three bf16 planes of both weight streams
+    assert lib.gft_deform_inputs(10, 10) == 84 and lib.gft_deform_inputs(10, 6) == 76      # reference config / class default
+    assert lib.gft_deform_inputs(10, 16) == 96 == _lib.DEFORM_MAX_INPUTS and lib.gft_deform_inputs(10, 17) == -1
+    assert lib.gft_deform_inputs(-1, 6) == -1
     assert lib.gft_deform_saved_bytes(0) == 0 and lib.gft_deform_scratch_bytes(0) == 0
     # per point (padded to 192): 96 encoding + 8*256 activations + 8*8 words of ReLU sign bits
     assert lib.gft_deform_saved_bytes(1) == 192 * (96 + 2048 + 64) * 4
     assert lib.gft_deform_saved_bytes(193) == 384 * (96 + 2048 + 64) * 4
     assert lib.gft_deform_scratch_bytes(1000) > 1024 * (2048 + 64) * 4
-    assert lib.gft_deform_pack(None, None, None) != 0
+    assert lib.gft_deform_pack(None, 10, 10, None, None) != 0
     assert "NULL" in _lib.last_error()
-    assert lib.gft_deform_forward(None, -1, None, None, 1, None, None, None, None) != 0
-    assert lib.gft_deform_forward(None, 0, None, None, 1, None, None, None, None) == 0      # nothing to do
-    assert lib.gft_deform_forward(None, 5, None, None, 1, None, None, None, None) != 0
-    assert lib.gft_deform_backward(None, 5, None, None, None, None, None, None) != 0
+    assert lib.gft_deform_pack(None, 10, 17, C.byref(_lib.DeformParams()), C.c_void_p(64)) != 0
+    assert "encoded inputs" in _lib.last_error()
+    assert lib.gft_deform_forward(None, 10, 10, -1, None, None, 1, None, None, None, None) != 0
+    assert lib.gft_deform_forward(None, 10, 10, 0, None, None, 1, None, None, None, None) == 0      # nothing to do
+    assert lib.gft_deform_forward(None, 10, 10, 5, None, None, 1, None, None, None, None) != 0
+    assert lib.gft_deform_forward(None, 11, 16, 0, None, None, 1, None, None, None, None) != 0      # 102 inputs
+    assert lib.gft_deform_backward(None, 10, 10, 5, None, None, None, None, None, None) != 0

@@ -8,7 +8,12 @@ import torch
 
 from oracle import deform_ref
 
+# deform.npz: the network as the reference constructs it (scene/deform_model.py:9-16, t_multires = 10: 84 inputs);
+# deform_t6.npz: the class signature's defaults (t_multires = 6: 76 inputs)
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "deform.npz")
+GOLDEN_T6 = os.path.join(os.path.dirname(__file__), "golden", "deform_t6.npz")
+GOLDENS = {10: GOLDEN, 6: GOLDEN_T6}
+ARCHS = pytest.mark.parametrize("tm", [10, 6])
 
 
 def _rel(a, b):
@@ -18,9 +23,11 @@ def _rel(a, b):
 # ---------------------------------------------------------------------------------------------
 # CPU: the oracle is pinned by outputs and autograd gradients of the reference's own module
 # ---------------------------------------------------------------------------------------------
-def test_oracle_matches_reference_module_forward():
-    g = np.load(GOLDEN)
-    params = deform_ref.random_params(int(g["seed"]))
+@ARCHS
+def test_oracle_matches_reference_module_forward(tm):
+    g = np.load(GOLDENS[tm])
+    assert int(g["kwargs"][3]) == tm
+    params = deform_ref.random_params(int(g["seed"]), t_multires=tm)
     d_xyz, d_rot, d_sh, d_sh_p = deform_ref.forward(params, g["x"], g["t"])
     assert d_xyz.shape == g["d_xyz"].shape and d_sh.shape == g["d_sh"].shape == (g["x"].shape[0], 16, 3)
     assert _rel(d_xyz, g["d_xyz"]) < 2e-6
@@ -30,9 +37,10 @@ def test_oracle_matches_reference_module_forward():
     assert d_sh_p.shape == g["d_sh_p"].shape and not d_sh_p.any() and not g["d_sh_p"].any()
 
 
-def test_oracle_matches_reference_module_backward():
-    g = np.load(GOLDEN)
-    params = deform_ref.random_params(int(g["seed"]))
+@ARCHS
+def test_oracle_matches_reference_module_backward(tm):
+    g = np.load(GOLDENS[tm])
+    params = deform_ref.random_params(int(g["seed"]), t_multires=tm)
     grads = deform_ref.backward(params, g["x"], g["t"], g["g_dxyz"], g["g_dsh"])
     assert sorted(n for n, v in grads.items() if v is None) == sorted(g["grad_none"].tolist())
     seen = 0
@@ -77,8 +85,12 @@ def test_eager_torch_restatement_matches_numpy_oracle():
 def test_embedding_layout():
     x = np.array([[0.1, 0.2, 0.3]], np.float32)
     t = np.array([[0.5]], np.float32)
-    e = deform_ref.embed(x, t)
+    e10 = deform_ref.embed(x, t)
+    assert e10.shape == (1, 84) and deform_ref.IN_CH == 84
+    np.testing.assert_array_equal(e10[0, 82:84], [np.sin(t[0, 0] * np.float32(512)), np.cos(t[0, 0] * np.float32(512))])
+    e = deform_ref.embed(x, t, t_multires=6)
     assert e.shape == (1, 76)
+    np.testing.assert_array_equal(e10[0, :76], e[0])
     np.testing.assert_array_equal(e[0, :3], x[0])
     np.testing.assert_array_equal(e[0, 3:6], np.sin(x[0]))            # frequency 1: sin of all dims, then cos
     np.testing.assert_array_equal(e[0, 6:9], np.cos(x[0]))
@@ -89,15 +101,34 @@ def test_embedding_layout():
 
 
 def test_module_mirrors_reference_state_dict():
-    from gftorf_amd.deform import DeformNetwork
-    net = DeformNetwork()
+    """The constructor call of scene/deform_model.py:9-16 with the values of arguments/__init__.py:66-69 and
+    configs/{torf,ftorf}.json: linear.0.weight [256,84], linear.5.weight [256,340], 522 055 parameters."""
+    from gftorf_amd.deform import DeformNetwork, REFERENCE_ARCH, reference_network
+    g = np.load(GOLDEN)
+    assert REFERENCE_ARCH == dict(zip(("D", "W", "xyz_multires", "t_multires", "sh_degree"), g["kwargs"].tolist()))
+    net = DeformNetwork(D=8, W=256, xyz_multires=10, t_multires=10, sh_degree=3)
     sd = net.state_dict()
-    shapes = deform_ref.param_shapes()
-    assert list(sd.keys()) == list(np.load(GOLDEN)["param_names"])      # names and ORDER of the reference's module
-    assert {k: tuple(v.shape) for k, v in sd.items()} == shapes
-    assert sum(v.numel() for v in sd.values()) == 517959              # (SURVEY section 8(e) quotes 522 055; the module holds 517 959)
+    assert list(sd.keys()) == list(g["param_names"])      # names and ORDER of the reference's module
+    assert [";".join(map(str, v.shape)) for v in sd.values()] == list(g["param_shapes"])
+    assert {k: tuple(v.shape) for k, v in sd.items()} == deform_ref.param_shapes()
+    assert tuple(sd["linear.0.weight"].shape) == (256, 84) and tuple(sd["linear.5.weight"].shape) == (256, 340)
+    assert sum(v.numel() for v in sd.values()) == int(g["num_params"]) == 522055
+    # a state_dict of the reference's shapes loads (the seeded parameters the fixture's module was given)
+    net.load_state_dict({k: torch.tensor(v) for k, v in deform_ref.random_params(int(g["seed"])).items()})
+    assert {k: tuple(v.shape) for k, v in reference_network().state_dict().items()} == deform_ref.param_shapes()
+    # the class signature's own defaults (t_multires = 6, time_utils.py:57)
+    g6 = np.load(GOLDEN_T6)
+    sd6 = DeformNetwork().state_dict()
+    assert list(sd6.keys()) == list(g6["param_names"])
+    assert [";".join(map(str, v.shape)) for v in sd6.values()] == list(g6["param_shapes"])
+    assert sum(v.numel() for v in sd6.values()) == int(g6["num_params"]) == 517959
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(sd6)                            # [256,76] does not fit [256,84]
     with pytest.raises(NotImplementedError):
         DeformNetwork(W=128)
+    with pytest.raises(NotImplementedError):
+        DeformNetwork(xyz_multires=10, t_multires=17)       # 98 encoded inputs > 96
+    DeformNetwork(xyz_multires=10, t_multires=16)           # 96: the most the kernels hold
 
 
 def test_product_fails_loudly_without_a_device():
@@ -110,10 +141,10 @@ def test_product_fails_loudly_without_a_device():
 # ---------------------------------------------------------------------------------------------
 # GPU: the HIP path (through the C ABI) against the oracle
 # ---------------------------------------------------------------------------------------------
-def _net(seed, dev):
+def _net(seed, dev, tm=10):
     from gftorf_amd.deform import DeformNetwork
-    params = deform_ref.random_params(seed)
-    net = DeformNetwork()
+    params = deform_ref.random_params(seed, t_multires=tm)
+    net = DeformNetwork(D=8, W=256, xyz_multires=10, t_multires=tm, sh_degree=3)
     net.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
     return net.to(dev), params
 
@@ -125,15 +156,16 @@ def _inputs(n, seed, shared_t):
     return x, t
 
 
-FWD_TOL = 3e-6      # of the max-norm, fp32 sums of 76..332 products per layer against float64
+FWD_TOL = 3e-6      # of the max-norm, fp32 sums of 84..340 products per layer against float64
 BWD_TOL = 2e-5      # weight gradients are sums over all points as well
 
 
 @pytest.mark.gpu
-def test_forward_matches_reference_golden_vectors():
+@ARCHS
+def test_forward_matches_reference_golden_vectors(tm):
     dev = torch.device("cuda:0")
-    g = np.load(GOLDEN)
-    net, _ = _net(int(g["seed"]), dev)
+    g = np.load(GOLDENS[tm])
+    net, _ = _net(int(g["seed"]), dev, tm)
     with torch.no_grad():
         d_xyz, d_rot, d_sh, d_sh_p = net(torch.tensor(g["x"], device=dev), torch.tensor(g["t"], device=dev))
     assert _rel(d_xyz.cpu().numpy(), g["d_xyz"]) < FWD_TOL
@@ -143,10 +175,11 @@ def test_forward_matches_reference_golden_vectors():
 
 
 @pytest.mark.gpu
-def test_backward_matches_reference_golden_vectors():
+@ARCHS
+def test_backward_matches_reference_golden_vectors(tm):
     dev = torch.device("cuda:0")
-    g = np.load(GOLDEN)
-    net, _ = _net(int(g["seed"]), dev)
+    g = np.load(GOLDENS[tm])
+    net, _ = _net(int(g["seed"]), dev, tm)
     d_xyz, _, d_sh, _ = net(torch.tensor(g["x"], device=dev), torch.tensor(g["t"], device=dev))
     ((d_xyz * torch.tensor(g["g_dxyz"], device=dev)).sum() + (d_sh * torch.tensor(g["g_dsh"], device=dev)).sum()).backward()
     grads = {k: p.grad for k, p in net.named_parameters()}
@@ -159,10 +192,11 @@ def test_backward_matches_reference_golden_vectors():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,shared_t", [(1, False), (63, True), (64, False), (65, True), (1000, False), (5000, True)])
-def test_forward_against_oracle(n, shared_t):
+@pytest.mark.parametrize("n,shared_t,tm", [(1, False, 10), (63, True, 10), (64, False, 10), (65, True, 10), (1000, False, 10),
+                                           (5000, True, 10), (65, False, 6), (1000, True, 6), (333, False, 0), (333, True, 16)])
+def test_forward_against_oracle(n, shared_t, tm):
     dev = torch.device("cuda:0")
-    net, params = _net(11, dev)
+    net, params = _net(11, dev, tm)
     x, t = _inputs(n, 100 + n, shared_t)
     tt = torch.tensor(t[:1], device=dev).expand(n, -1) if shared_t else torch.tensor(t, device=dev)   # gaussian_model.py:171
     with torch.no_grad():
@@ -177,10 +211,10 @@ def test_forward_against_oracle(n, shared_t):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [48, 333, 5000])
-def test_backward_against_oracle(n):
+@pytest.mark.parametrize("n,tm", [(48, 10), (333, 10), (5000, 10), (333, 6), (200, 16)])
+def test_backward_against_oracle(n, tm):
     dev = torch.device("cuda:0")
-    net, params = _net(12, dev)
+    net, params = _net(12, dev, tm)
     x, t = _inputs(n + n // 8, 200 + n, False)
     # a ReLU whose input is within rounding of zero may switch differently in fp32 and in float64 and
     # changes the gradient by a finite amount: keep the n points that are furthest from such an edge

@@ -58,10 +58,10 @@ def test_two_rank_frame_sharding_and_timing():
 def _worker_deform(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    from gftorf_amd.deform import DeformNetwork, allreduce_gradients, flat_grad_bucket
+    from gftorf_amd.deform import reference_network, allreduce_gradients, flat_grad_bucket
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)                       # replicas start identical
-    net = DeformNetwork()
+    net = reference_network()
     # the gradients a rank's own frame produced (stand-ins: the kernels need a GPU); rot / a get none
     g = torch.Generator().manual_seed(100 + rank)
     for name, p in net.named_parameters():
@@ -92,7 +92,7 @@ def test_two_rank_deform_gradient_allreduce():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, nb0, mine0, red0, sum0, none0), (_, nb1, mine1, red1, sum1, none1) = res
-    assert nb0 == nb1 == (517959 - 5140) * 4                # every parameter that receives a gradient, once
+    assert nb0 == nb1 == (522055 - 5140) * 4                # every parameter that receives a gradient, once
     assert none0 == none1 == ["rot.weight", "rot.bias", "a.weight", "a.bias"]
     for n in ("linear.5.weight", "b.bias"):
         torch.testing.assert_close(red0[n], (mine0[n] + mine1[n]) / 2)

@@ -20,7 +20,7 @@ def _rel(a, b):
 
 @pytest.mark.gpu
 def test_training_iteration_chain_matches_composed_oracles():
-    from gftorf_amd import DeformNetwork, GaussianRasterizer, assemble_inputs
+    from gftorf_amd import reference_network, GaussianRasterizer, assemble_inputs
     dev = torch.device("cuda:0")
     scene = helpers.small_scene(P=700, W=96, H=64, seed=21)
     g = scene["gaussians"]
@@ -35,7 +35,7 @@ def test_training_iteration_chain_matches_composed_oracles():
     opac = g["opacities"].reshape(P, 1)
 
     # ---- HIP chain -------------------------------------------------------------------------------------
-    net = DeformNetwork()
+    net = reference_network()
     net.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
     net = net.to(dev)
     leaf = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in
@@ -87,7 +87,7 @@ def test_optimisation_loop_reduces_the_loss():
     """The reference's loop shape for 60 iterations on a small scene: network query, assembly, colour + ToF
     render, L1 losses against renders of the unperturbed scene, backward, FusedAdam on the Gaussians, Adam on
     the network, densification statistics.  The loss must fall: gradients are useful, not only equal."""
-    from gftorf_amd import DeformNetwork, FusedAdam, GaussianRasterizer, assemble_inputs, densify
+    from gftorf_amd import reference_network, FusedAdam, GaussianRasterizer, assemble_inputs, densify
     dev = torch.device("cuda:0")
     scene = helpers.small_scene(P=1500, W=96, H=64, seed=33)
     g = scene["gaussians"]
@@ -111,7 +111,7 @@ def test_optimisation_loop_reduces_the_loss():
                 scaling=t32(g["scales"] * 1.15), rotation_raw=t32(g["rotations"]), fc=t32(g["shs"] * 0.8), fp=t32(g["shs_p"] * 0.9))
     for v in leaf.values():
         v.requires_grad_(True)
-    net = DeformNetwork().to(dev)
+    net = reference_network().to(dev)
     torch.manual_seed(0)
     for n_, p_ in net.named_parameters():
         torch.nn.init.normal_(p_, 0.0, 0.03 if n_.startswith("linear") and n_.endswith("weight") else 1e-3)
