@@ -82,7 +82,7 @@ ASSEMBLE_PTRS_IN = ["xyz", "screenspace", "opacity", "scaling", "rotation", "rot
 ASSEMBLE_SCALARS = ["d_xyz_scalar", "d_rot_scalar", "d_sh_scalar", "d_sh_p_scalar"]
 ASSEMBLE_PTRS_OUT = ["scratch", "out_means3D", "out_means2D", "out_opacity", "out_scales", "out_rotations",
                      "out_shs", "out_shs_p"]
-ASSEMBLE_FIELDS = ASSEMBLE_PTRS_IN + ASSEMBLE_SCALARS + ASSEMBLE_PTRS_OUT
+ASSEMBLE_FIELDS = ASSEMBLE_PTRS_IN + ASSEMBLE_SCALARS + ASSEMBLE_PTRS_OUT + ["num_offset_rows"]
 ASSEMBLE_BWD_HEAD = ["scratch", "rotation_raw", "d_rot"]
 ASSEMBLE_BWD_TAIL = ["g_means3D", "g_means2D", "g_opacity", "g_scales", "g_rotations", "g_shs", "g_shs_p",
                      "g_xyz", "g_screenspace", "g_opacity_in", "g_scaling", "g_rotation", "g_rotation_raw",
@@ -92,7 +92,7 @@ ASSEMBLE_BWD_FIELDS = ASSEMBLE_BWD_HEAD + ["d_rot_scalar"] + ASSEMBLE_BWD_TAIL
 
 class AssembleIO(C.Structure):
     _fields_ = ([(n, _fp) for n in ASSEMBLE_PTRS_IN] + [(n, C.c_float) for n in ASSEMBLE_SCALARS] +
-                [(n, _fp) for n in ASSEMBLE_PTRS_OUT])
+                [(n, _fp) for n in ASSEMBLE_PTRS_OUT] + [("num_offset_rows", C.c_int64)])
 
 
 class AssembleBwdIO(C.Structure):

@@ -45,7 +45,8 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 # (Gaussian, tile) instance count of the most recent forward (diagnostics / bench)
-last_call_stats = {"num_rendered": 0, "binning_instances": 0, "restarted": False, "max_tile_list": 0}
+last_call_stats = {"num_rendered": 0, "binning_instances": 0, "restarted": False, "max_tile_list": 0,
+                   "forwards": 0, "restarts": 0}
 
 # Instance count (and longest tile list) of the recent forwards per (device, P, W, H).  A training loop renders
 # similar frames back to back, so the binning buffer can be sized before the device has
@@ -131,243 +132,308 @@ def rasterize_gaussians(means3D, means2D, sh, sh_p, colors_precomp, phasors_prec
                                      dc_offset, raster_settings)
 
 
+def _canonical_cap(n):
+    """Binning capacities are multiples of 64 instances: the buffer then holds exactly 12 bytes per instance plus
+    one alignment unit, so the capacity can be read back from the buffer's size (``binning_capacity``) -- the
+    pybind-level backward (``_C.rasterize_gaussians_backward``) gets the buffer, not the capacity."""
+    return (int(n) + 63) // 64 * 64
+
+
+def binning_capacity(binning):
+    """Instances a binning buffer allocated by :func:`native_forward` holds."""
+    return max(0, (binning.numel() - 256) // 12)
+
+
+class _Settings(NamedTuple):
+    """The scalar / camera arguments of ``_C.rasterize_gaussians`` (rasterize_points.h:25-53) by name."""
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    tanfovx: float
+    tanfovy: float
+    image_height: int
+    image_width: int
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    near_n: float
+    far_n: float
+    depth_range: float
+    use_view_dependent_phase: bool
+
+
+def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
+                   cov3Ds_precomp, ph_off, dc_off, want_bw, with_acc):
+    """One forward of the native rasterizer (``RasterizeGaussiansCUDA``, rasterize_points.cu:42-165): allocates the
+    outputs and the three scratch buffers, runs the C ABI on torch's current stream.  ``s`` holds the settings fields
+    (``GaussianRasterizationSettings`` or ``_Settings``), ``ph_off`` / ``dc_off`` are floats.  Returns a dict."""
+    lib = _lib.load()
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("gftorf_amd: the rasterizer runs on a HIP device only (means3D is on %s); "
+                           "there is no CPU path" % (dev,))
+    P = means3D.size(0)
+    H, W = int(s.image_height), int(s.image_width)
+
+    g = lambda t, n: _f32(t, dev, n) if _present(t) else None
+    means3D_c = _f32(means3D, dev, "means3D") if P else means3D
+    sh_c, sh_p_c = g(sh, "shs"), g(sh_p, "shs_p")
+    colors_c, phasors_c = g(colors_precomp, "colors_precomp"), g(phasors_precomp, "phasors_precomp")
+    opac_c = g(opacities, "opacities")
+    scales_c, rot_c, cov_c = g(scales, "scales"), g(rotations, "rotations"), g(cov3Ds_precomp, "cov3D_precomp")
+    view_c = _f32(s.viewmatrix, dev, "viewmatrix")
+    proj_c = _f32(s.projmatrix, dev, "projmatrix")
+    campos_c = _f32(s.campos, dev, "campos")
+    bg_c, bsc, bsy, bsx = _bg_strides(s.bg, H, W, dev)
+    M = sh_c.size(1) if sh_c is not None else 0
+    M_p = sh_p_c.size(1) if sh_p_c is not None else 0
+
+    if s.debug:
+        cpu_args = cpu_deep_copy_tuple((s.bg, means3D, colors_precomp, phasors_precomp, opacities, scales,
+                                        rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix, s.projmatrix,
+                                        s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, sh_p,
+                                        s.sh_degree, s.campos, s.prefiltered, s.debug, s.near_n, s.far_n,
+                                        s.depth_range, s.use_view_dependent_phase, ph_off, dc_off))
+
+    f32 = dict(device=dev, dtype=torch.float32)
+    planes = torch.empty((21, H, W), **f32)
+    color, phasor, depth = planes[0:3], planes[3:10], planes[10:11]
+    normal, acc, entropy = planes[11:14], planes[14:15], planes[15:16]
+    depth_distortion, amp_distortion, distribution = planes[16:17], planes[17:18], planes[18:21]
+    radii = torch.empty((P,), device=dev, dtype=torch.int32)
+    pixels = torch.empty((P, 1), **f32)
+    geom = torch.empty((lib.gft_geom_bytes(P),), device=dev, dtype=torch.uint8)
+    img = torch.empty((lib.gft_image_bytes(W, H),), device=dev, dtype=torch.uint8)
+
+    cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw)
+    io = _lib.ForwardIO()
+    io.bg, io.means3D = _ptr(bg_c), _ptr(means3D_c) if P else None
+    io.colors_precomp, io.phasors_precomp, io.opacities = _ptr(colors_c), _ptr(phasors_c), _ptr(opac_c)
+    io.scales, io.rotations, io.cov3D_precomp = _ptr(scales_c), _ptr(rot_c), _ptr(cov_c)
+    io.viewmatrix, io.projmatrix, io.campos = _ptr(view_c), _ptr(proj_c), _ptr(campos_c)
+    io.shs, io.shs_p = _ptr(sh_c), _ptr(sh_p_c)
+    io.geom, io.img, io.binning = _ptr(geom), _ptr(img), None
+    io.out_color, io.out_phasor, io.out_depth = color.data_ptr(), phasor.data_ptr(), depth.data_ptr()
+    io.out_normal, io.out_acc, io.out_entropy = normal.data_ptr(), acc.data_ptr(), entropy.data_ptr()
+    io.out_depth_distortion, io.out_amp_distortion = depth_distortion.data_ptr(), amp_distortion.data_ptr()
+    io.out_distribution = distribution.data_ptr()
+    io.pixels, io.radii = _ptr(pixels) if P else None, _ptr(radii) if P else None
+    # the backward's accumulator: cleared by the forward under its render kernel
+    acc_buf = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32) if (want_bw and with_acc and P) else None
+    io.acc = _ptr(acc_buf)
+
+    R = cap = 0
+    restarted = False
+    max_list = C.c_int64(0)
+    if P == 0:
+        # the reference skips every kernel and returns its zero-filled outputs
+        # (rasterize_points.cu:104)
+        planes.zero_()
+        binning = torch.empty((0,), device=dev, dtype=torch.uint8)
+    else:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        num_rendered = C.c_int64(0)
+        hint_key = (dev.index, P, W, H)
+        hint, list_hint = _instance_hint.get(hint_key, (None, 0))
+        try:
+            with torch.cuda.device(dev):
+                if hint is None:
+                    # first frame of this shape: size the buffer after the one blocking
+                    # read, like the reference's resize callback
+                    # (rasterize_points.cu:27-33, rasterizer_impl.cu:311-315)
+                    _lib.check(lib.gft_forward_preprocess(stream, C.byref(cfg), C.byref(io),
+                                                          C.byref(num_rendered), C.byref(max_list)))
+                    R = int(num_rendered.value)
+                    cap = _canonical_cap(R)
+                    binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
+                    io.binning = binning.data_ptr()
+                    _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, int(max_list.value)))
+                else:
+                    cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
+                    binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
+                    io.binning = binning.data_ptr()
+                    _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), cap,
+                                               int(list_hint * _LIST_HEADROOM) + 1, C.byref(num_rendered),
+                                               C.byref(max_list)))
+                    R = int(num_rendered.value)
+                    if R > cap:
+                        restarted = True
+                        cap = _canonical_cap(R)
+                        binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
+                        io.binning = binning.data_ptr()
+                        _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap,
+                                                          int(max_list.value)))
+                # slowly decaying maximum: alternating views of one scene (colour / ToF camera,
+                # random training views) keep the larger count as the guess
+                prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
+                _instance_hint[hint_key] = (max(R, int((prev_r or 0) * 0.95)),
+                                            max(int(max_list.value), int(prev_l * 0.95)))
+                if len(_instance_hint) > 64:
+                    _instance_hint.pop(next(iter(_instance_hint)))
+        except Exception as ex:
+            if s.debug:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+            raise ex
+        assert binning_capacity(binning) == cap
+
+    last_call_stats.update(num_rendered=R, binning_instances=cap, restarted=restarted,
+                           max_tile_list=int(max_list.value) if P else 0)
+    last_call_stats["forwards"] = last_call_stats.get("forwards", 0) + 1
+    last_call_stats["restarts"] = last_call_stats.get("restarts", 0) + int(restarted)
+    return dict(R=R, cap=cap, outputs=(color, phasor, depth, normal, acc, entropy, depth_distortion, amp_distortion,
+                                       pixels, distribution, radii),
+                geom=geom, binning=binning, img=img, acc=acc_buf, bg=(bg_c, bsc, bsy, bsx),
+                consts=(view_c, proj_c, campos_c),
+                inputs=(means3D_c, opac_c, sh_c, sh_p_c, scales_c, rot_c, cov_c, colors_c, phasors_c))
+
+
+def native_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, binning, img, bg, consts,
+                    ph_off, dc_off, grads_out, acc, want_colors, want_cov, want_bw_records=True):
+    """One backward of the native rasterizer (``RasterizeGaussiansBackwardCUDA``, rasterize_points.cu:167-281).
+    ``sh`` ... ``cov3D`` are contiguous tensors or None, ``grads_out`` = (color, phasor, depth, acc, depth_distortion)
+    upstream gradients (None = zeros), ``acc`` the accumulator the forward cleared or None.  Returns a dict of
+    gradient tensors (None where the input is absent)."""
+    lib = _lib.load()
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = int(s.image_height), int(s.image_width)
+    bg_c, bsc, bsy, bsx = bg
+    view_c, proj_c, campos_c = consts
+    has_sh, has_sh_p, has_scales, has_cov = sh is not None, sh_p is not None, scales is not None, cov3D is not None
+    M = sh.size(1) if has_sh else 0
+    M_p = sh_p.size(1) if has_sh_p else 0
+
+    def gr(t, c, name):
+        # gradients of normal / entropy / amp_distortion / pixels / distribution are
+        # accepted and ignored, as in the reference kernels (backward.cu:609-630)
+        if t is None:
+            return None
+        if tuple(t.shape) != (c, H, W):
+            raise RuntimeError("grad of %s has shape %s, expected %s" % (name, tuple(t.shape), (c, H, W)))
+        return _f32(t, dev, "grad_" + name)
+
+    g_color, g_phasor = gr(grads_out[0], 3, "color"), gr(grads_out[1], 7, "phasor")
+    g_depth, g_acc = gr(grads_out[2], 1, "depth"), gr(grads_out[3], 1, "acc")
+    g_dd = gr(grads_out[4], 1, "depth_distortion")
+
+    f32 = dict(device=dev, dtype=torch.float32)
+    grad_means3D = torch.empty((P, 3), **f32)
+    grad_means2D = torch.empty((P, 3), **f32)
+    grad_opacities = torch.empty((P, 1), **f32)
+    grad_colors = torch.empty((P, 3), **f32) if want_colors else None
+    grad_cov3D = torch.empty((P, 6), **f32) if want_cov else None
+    grad_sh = torch.empty((P, M, 3), **f32) if has_sh else None
+    grad_sh_p = torch.empty((P, M_p, 2), **f32) if has_sh_p else None
+    grad_scales = torch.empty((P, 3), **f32) if has_scales else None
+    grad_rotations = torch.empty((P, 4), **f32) if has_scales else None
+    grad_offsets = torch.empty((2,), **f32)
+    acc_zeroed = acc is not None
+    if acc is None:            # second backward through the same forward (retain_graph), or the pybind-level route
+        acc = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32)
+
+    cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw_records)
+    cfg.acc_zeroed = int(acc_zeroed)
+    io = _lib.BackwardIO()
+    io.bg, io.means3D, io.radii = _ptr(bg_c), _ptr(means3D) if P else None, _ptr(radii) if P else None
+    io.scales = _ptr(scales) if has_scales else None
+    io.rotations = _ptr(rotations) if has_scales else None
+    io.cov3D_precomp = _ptr(cov3D) if has_cov else None
+    io.viewmatrix, io.projmatrix, io.campos = _ptr(view_c), _ptr(proj_c), _ptr(campos_c)
+    io.shs = _ptr(sh) if has_sh else None
+    io.shs_p = _ptr(sh_p) if has_sh_p else None
+    io.opacities = _ptr(opac) if (P and opac is not None) else None
+    io.dL_dout_color, io.dL_dout_phasor = _ptr(g_color), _ptr(g_phasor)
+    io.dL_dout_depth, io.dL_dout_acc, io.dL_dout_depth_distortion = _ptr(g_depth), _ptr(g_acc), _ptr(g_dd)
+    io.geom, io.img, io.binning = _ptr(geom), _ptr(img), _ptr(binning)
+    io.acc = _ptr(acc) if P else None
+    io.dL_dmeans3D, io.dL_dmeans2D = _ptr(grad_means3D) if P else None, _ptr(grad_means2D) if P else None
+    io.dL_dcolors, io.dL_dopacity, io.dL_dcov3D = _ptr(grad_colors), _ptr(grad_opacities) if P else None, _ptr(grad_cov3D)
+    io.dL_dsh, io.dL_dsh_p = _ptr(grad_sh), _ptr(grad_sh_p)
+    io.dL_dscales, io.dL_drotations = _ptr(grad_scales), _ptr(grad_rotations)
+    io.dL_dphase_offset = grad_offsets.data_ptr()
+    io.dL_ddc_offset = grad_offsets.data_ptr() + 4
+
+    if s.debug:
+        cpu_args = cpu_deep_copy_tuple((s.bg, means3D, radii, scales, rotations, s.scale_modifier, cov3D,
+                                        s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy) + tuple(grads_out) +
+                                       (sh, sh_p, s.sh_degree, s.campos, geom, binning, img,
+                                        s.debug, s.near_n, s.far_n, s.depth_range, s.use_view_dependent_phase,
+                                        ph_off, dc_off))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    try:
+        with torch.cuda.device(dev):
+            _lib.check(lib.gft_backward(stream, C.byref(cfg), C.byref(io), binning_capacity(binning) if P else 0))
+    except Exception as ex:
+        if s.debug:
+            torch.save(cpu_args, "snapshot_bw.dump")
+            print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+        raise ex
+    return dict(means3D=grad_means3D, means2D=grad_means2D, opacities=grad_opacities, colors=grad_colors,
+                cov3D=grad_cov3D, sh=grad_sh, sh_p=grad_sh_p, scales=grad_scales, rotations=grad_rotations,
+                offsets=grad_offsets)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, sh_p, colors_precomp, phasors_precomp, opacities,
                 scales, rotations, cov3Ds_precomp, phase_offset, dc_offset, raster_settings):
         s = raster_settings
-        lib = _lib.load()
-        if means3D.dim() != 2 or means3D.size(1) != 3:
-            raise RuntimeError("means3D must have dimensions (num_points, 3)")
-        dev = means3D.device
-        if dev.type != "cuda":
-            raise RuntimeError("gftorf_amd: the rasterizer runs on a HIP device only (means3D is on %s); "
-                               "there is no CPU path" % (dev,))
-        P = means3D.size(0)
-        H, W = int(s.image_height), int(s.image_width)
-
         ph_off = _scalar(phase_offset)
         dc_off = _scalar(dc_offset)
-
-        g = lambda t, n: _f32(t, dev, n) if _present(t) else None
-        means3D_c = _f32(means3D, dev, "means3D") if P else means3D
-        sh_c, sh_p_c = g(sh, "shs"), g(sh_p, "shs_p")
-        colors_c, phasors_c = g(colors_precomp, "colors_precomp"), g(phasors_precomp, "phasors_precomp")
-        opac_c = g(opacities, "opacities")
-        scales_c, rot_c, cov_c = g(scales, "scales"), g(rotations, "rotations"), g(cov3Ds_precomp, "cov3D_precomp")
-        view_c = _f32(s.viewmatrix, dev, "viewmatrix")
-        proj_c = _f32(s.projmatrix, dev, "projmatrix")
-        campos_c = _f32(s.campos, dev, "campos")
-        bg_c, bsc, bsy, bsx = _bg_strides(s.bg, H, W, dev)
-        M = sh_c.size(1) if sh_c is not None else 0
-        M_p = sh_p_c.size(1) if sh_p_c is not None else 0
-
-        if s.debug:
-            cpu_args = cpu_deep_copy_tuple((s.bg, means3D, colors_precomp, phasors_precomp, opacities, scales,
-                                            rotations, s.scale_modifier, cov3Ds_precomp, s.viewmatrix, s.projmatrix,
-                                            s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, sh_p,
-                                            s.sh_degree, s.campos, s.prefiltered, s.debug, s.near_n, s.far_n,
-                                            s.depth_range, s.use_view_dependent_phase, ph_off, dc_off))
-
-        f32 = dict(device=dev, dtype=torch.float32)
-        planes = torch.empty((21, H, W), **f32)
-        color, phasor, depth = planes[0:3], planes[3:10], planes[10:11]
-        normal, acc, entropy = planes[11:14], planes[14:15], planes[15:16]
-        depth_distortion, amp_distortion, distribution = planes[16:17], planes[17:18], planes[18:21]
-        radii = torch.empty((P,), device=dev, dtype=torch.int32)
-        pixels = torch.empty((P, 1), **f32)
-        geom = torch.empty((lib.gft_geom_bytes(P),), device=dev, dtype=torch.uint8)
-        img = torch.empty((lib.gft_image_bytes(W, H),), device=dev, dtype=torch.uint8)
-
         # the backward can only run if autograd tracks one of the inputs
         want_bw = any(ctx.needs_input_grad)
-        cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw)
-        io = _lib.ForwardIO()
-        io.bg, io.means3D = _ptr(bg_c), _ptr(means3D_c) if P else None
-        io.colors_precomp, io.phasors_precomp, io.opacities = _ptr(colors_c), _ptr(phasors_c), _ptr(opac_c)
-        io.scales, io.rotations, io.cov3D_precomp = _ptr(scales_c), _ptr(rot_c), _ptr(cov_c)
-        io.viewmatrix, io.projmatrix, io.campos = _ptr(view_c), _ptr(proj_c), _ptr(campos_c)
-        io.shs, io.shs_p = _ptr(sh_c), _ptr(sh_p_c)
-        io.geom, io.img, io.binning = _ptr(geom), _ptr(img), None
-        io.out_color, io.out_phasor, io.out_depth = color.data_ptr(), phasor.data_ptr(), depth.data_ptr()
-        io.out_normal, io.out_acc, io.out_entropy = normal.data_ptr(), acc.data_ptr(), entropy.data_ptr()
-        io.out_depth_distortion, io.out_amp_distortion = depth_distortion.data_ptr(), amp_distortion.data_ptr()
-        io.out_distribution = distribution.data_ptr()
-        io.pixels, io.radii = _ptr(pixels) if P else None, _ptr(radii) if P else None
-        # the backward's accumulator: cleared by the forward under its render kernel
-        acc_buf = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32) if (want_bw and P) else None
-        io.acc = _ptr(acc_buf)
-
-        R = 0
-        if P == 0:
-            # the reference skips every kernel and returns its zero-filled outputs
-            # (rasterize_points.cu:104)
-            planes.zero_()
-            binning = torch.empty((0,), device=dev, dtype=torch.uint8)
-        else:
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            num_rendered = C.c_int64(0)
-            max_list = C.c_int64(0)
-            hint_key = (dev.index, P, W, H)
-            hint, list_hint = _instance_hint.get(hint_key, (None, 0))
-            restarted = False
-            try:
-                with torch.cuda.device(dev):
-                    if hint is None:
-                        # first frame of this shape: size the buffer after the one blocking
-                        # read, like the reference's resize callback
-                        # (rasterize_points.cu:27-33, rasterizer_impl.cu:311-315)
-                        _lib.check(lib.gft_forward_preprocess(stream, C.byref(cfg), C.byref(io),
-                                                              C.byref(num_rendered), C.byref(max_list)))
-                        R = cap = int(num_rendered.value)
-                        binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
-                        io.binning = binning.data_ptr()
-                        _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, int(max_list.value)))
-                    else:
-                        cap = int(hint * _HINT_HEADROOM) + 4096
-                        binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
-                        io.binning = binning.data_ptr()
-                        _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), cap,
-                                                   int(list_hint * _LIST_HEADROOM) + 1, C.byref(num_rendered),
-                                                   C.byref(max_list)))
-                        R = int(num_rendered.value)
-                        if R > cap:
-                            restarted = True
-                            cap = R
-                            binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
-                            io.binning = binning.data_ptr()
-                            _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap,
-                                                              int(max_list.value)))
-                    # slowly decaying maximum: alternating views of one scene (colour / ToF camera,
-                    # random training views) keep the larger count as the guess
-                    prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
-                    _instance_hint[hint_key] = (max(R, int((prev_r or 0) * 0.95)),
-                                                max(int(max_list.value), int(prev_l * 0.95)))
-                    if len(_instance_hint) > 64:
-                        _instance_hint.pop(next(iter(_instance_hint)))
-            except Exception as ex:
-                if s.debug:
-                    torch.save(cpu_args, "snapshot_fw.dump")
-                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
-                raise ex
-
+        r = native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
+                           cov3Ds_precomp, ph_off, dc_off, want_bw, True)
+        means3D_c, opac_c, sh_c, sh_p_c, scales_c, rot_c, cov_c, colors_c, phasors_c = r["inputs"]
         ctx.raster_settings = s
-        ctx.num_rendered = R
-        ctx.binning_instances = cap if P else 0
-        last_call_stats.update(num_rendered=R, binning_instances=ctx.binning_instances,
-                               restarted=bool(P) and restarted, max_tile_list=int(max_list.value) if P else 0)
+        ctx.num_rendered = r["R"]
+        ctx.binning_instances = r["cap"]
         ctx.scalars = (ph_off, dc_off)
         ctx.want_bw = want_bw
-        ctx.acc = acc_buf          # zeroed, valid for the first backward of this forward
-        ctx.bg = (bg_c, bsc, bsy, bsx)
-        ctx.consts = (view_c, proj_c, campos_c)
+        ctx.acc = r["acc"]         # zeroed, valid for the first backward of this forward
+        ctx.bg = r["bg"]
+        ctx.consts = r["consts"]
         ctx.present = (sh_c is not None, sh_p_c is not None, colors_c is not None, phasors_c is not None,
                        scales_c is not None, cov_c is not None)
         ctx.in_shapes = (opacities.shape, phase_offset.shape if isinstance(phase_offset, torch.Tensor) else None,
                          dc_offset.shape if isinstance(dc_offset, torch.Tensor) else None)
         ctx.set_materialize_grads(False)
         dummy = means3D_c.new_empty(0)
+        radii = r["outputs"][10]
         ctx.save_for_backward(means3D_c, opac_c if opac_c is not None else dummy,
                               sh_c if sh_c is not None else dummy, sh_p_c if sh_p_c is not None else dummy,
                               scales_c if scales_c is not None else dummy, rot_c if rot_c is not None else dummy,
-                              cov_c if cov_c is not None else dummy, radii, geom, binning, img)
+                              cov_c if cov_c is not None else dummy, radii, r["geom"], r["binning"], r["img"])
         ctx.mark_non_differentiable(radii)
-        return (color, phasor, depth, normal, acc, entropy, depth_distortion, amp_distortion, pixels,
-                distribution, radii)
+        return r["outputs"]
 
     @staticmethod
     def backward(ctx, grad_out_color, grad_out_phasor, grad_out_depth, grad_out_normal, grad_out_acc,
                  grad_entropy, grad_depth_distortion, grad_amp_distortion, grad_pixels, grad_distribution, _):
         s = ctx.raster_settings
-        lib = _lib.load()
         means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, binning, img = ctx.saved_tensors
         has_sh, has_sh_p, has_colors, has_phasors, has_scales, has_cov = ctx.present
-        dev = means3D.device
-        P = means3D.size(0)
-        H, W = int(s.image_height), int(s.image_width)
         ph_off, dc_off = ctx.scalars
-        bg_c, bsc, bsy, bsx = ctx.bg
-        view_c, proj_c, campos_c = ctx.consts
-        M = sh.size(1) if has_sh else 0
-        M_p = sh_p.size(1) if has_sh_p else 0
-
-        def gr(t, c, name):
-            # gradients of normal / entropy / amp_distortion / pixels / distribution are
-            # accepted and ignored, as in the reference kernels (backward.cu:609-630)
-            if t is None:
-                return None
-            if tuple(t.shape) != (c, H, W):
-                raise RuntimeError("grad of %s has shape %s, expected %s" % (name, tuple(t.shape), (c, H, W)))
-            return _f32(t, dev, "grad_" + name)
-
-        g_color, g_phasor = gr(grad_out_color, 3, "color"), gr(grad_out_phasor, 7, "phasor")
-        g_depth, g_acc = gr(grad_out_depth, 1, "depth"), gr(grad_out_acc, 1, "acc")
-        g_dd = gr(grad_depth_distortion, 1, "depth_distortion")
-
-        f32 = dict(device=dev, dtype=torch.float32)
-        grad_means3D = torch.empty((P, 3), **f32)
-        grad_means2D = torch.empty((P, 3), **f32)
-        grad_opacities = torch.empty((P, 1), **f32)
-        grad_colors = torch.empty((P, 3), **f32) if has_colors else None
-        grad_cov3D = torch.empty((P, 6), **f32) if has_cov else None
-        grad_sh = torch.empty((P, M, 3), **f32) if has_sh else None
-        grad_sh_p = torch.empty((P, M_p, 2), **f32) if has_sh_p else None
-        grad_scales = torch.empty((P, 3), **f32) if has_scales else None
-        grad_rotations = torch.empty((P, 4), **f32) if has_scales else None
-        grad_offsets = torch.empty((2,), **f32)
         acc, ctx.acc = ctx.acc, None
-        acc_zeroed = acc is not None
-        if acc is None:            # second backward through the same forward (retain_graph)
-            acc = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32)
-
-        cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), ctx.want_bw)
-        cfg.acc_zeroed = int(acc_zeroed)
-        io = _lib.BackwardIO()
-        io.bg, io.means3D, io.radii = _ptr(bg_c), _ptr(means3D) if P else None, _ptr(radii) if P else None
-        io.scales = _ptr(scales) if has_scales else None
-        io.rotations = _ptr(rotations) if has_scales else None
-        io.cov3D_precomp = _ptr(cov3D) if has_cov else None
-        io.viewmatrix, io.projmatrix, io.campos = _ptr(view_c), _ptr(proj_c), _ptr(campos_c)
-        io.shs = _ptr(sh) if has_sh else None
-        io.shs_p = _ptr(sh_p) if has_sh_p else None
-        io.opacities = _ptr(opac) if P else None
-        io.dL_dout_color, io.dL_dout_phasor = _ptr(g_color), _ptr(g_phasor)
-        io.dL_dout_depth, io.dL_dout_acc, io.dL_dout_depth_distortion = _ptr(g_depth), _ptr(g_acc), _ptr(g_dd)
-        io.geom, io.img, io.binning = _ptr(geom), _ptr(img), _ptr(binning)
-        io.acc = _ptr(acc) if P else None
-        io.dL_dmeans3D, io.dL_dmeans2D = _ptr(grad_means3D) if P else None, _ptr(grad_means2D) if P else None
-        io.dL_dcolors, io.dL_dopacity, io.dL_dcov3D = _ptr(grad_colors), _ptr(grad_opacities) if P else None, _ptr(grad_cov3D)
-        io.dL_dsh, io.dL_dsh_p = _ptr(grad_sh), _ptr(grad_sh_p)
-        io.dL_dscales, io.dL_drotations = _ptr(grad_scales), _ptr(grad_rotations)
-        io.dL_dphase_offset = grad_offsets.data_ptr()
-        io.dL_ddc_offset = grad_offsets.data_ptr() + 4
-
-        if s.debug:
-            cpu_args = cpu_deep_copy_tuple((s.bg, means3D, radii, scales, rotations, s.scale_modifier, cov3D,
-                                            s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color,
-                                            grad_out_phasor, grad_out_depth, grad_out_acc, grad_depth_distortion,
-                                            sh, sh_p, s.sh_degree, s.campos, geom, ctx.num_rendered, binning, img,
-                                            s.debug, s.near_n, s.far_n, s.depth_range, s.use_view_dependent_phase,
-                                            ph_off, dc_off))
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        try:
-            with torch.cuda.device(dev):
-                _lib.check(lib.gft_backward(stream, C.byref(cfg), C.byref(io), ctx.binning_instances))
-        except Exception as ex:
-            if s.debug:
-                torch.save(cpu_args, "snapshot_bw.dump")
-                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
-            raise ex
-
+        g = native_backward(s, means3D, opac, sh if has_sh else None, sh_p if has_sh_p else None,
+                            scales if has_scales else None, rotations if has_scales else None,
+                            cov3D if has_cov else None, radii, geom, binning, img, ctx.bg, ctx.consts, ph_off, dc_off,
+                            (grad_out_color, grad_out_phasor, grad_out_depth, grad_out_acc, grad_depth_distortion),
+                            acc, has_colors, has_cov, ctx.want_bw)
         op_shape, ph_shape, dc_shape = ctx.in_shapes
         grad_phase = grad_dc = None
         if s.optimize_phase_offset and ph_shape is not None:
-            grad_phase = grad_offsets[0:1].reshape(ph_shape)
+            grad_phase = g["offsets"][0:1].reshape(ph_shape)
         if s.optimize_dc_offset and dc_shape is not None:
-            grad_dc = grad_offsets[1:2].reshape(dc_shape)
+            grad_dc = g["offsets"][1:2].reshape(dc_shape)
         # input order of forward(); the reference has no backward for phasors_precomp
-        return (grad_means3D, grad_means2D, grad_sh, grad_sh_p, grad_colors, None,
-                grad_opacities.reshape(op_shape), grad_scales, grad_rotations, grad_cov3D,
+        return (g["means3D"], g["means2D"], g["sh"], g["sh_p"], g["colors"], None,
+                g["opacities"].reshape(op_shape), g["scales"], g["rotations"], g["cov3D"],
                 grad_phase, grad_dc, None)
 
 

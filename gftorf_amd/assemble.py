@@ -69,6 +69,14 @@ class _AssembleInputs(torch.autograd.Function):
                 offs.append(_f32c(t, dev, n))
             else:
                 offs.append(float(t))
+        # every d_* tensor holds one row per dynamic Gaussian (gaussian_renderer/__init__.py:90-104): one row count,
+        # at most P -- checked here without touching the device; the kernels never index past it
+        rows = {n: v.size(0) for v, n in zip(offs, ("d_xyz", "d_rot", "d_sh", "d_sh_p")) if _is_tensor(v)}
+        if len(set(rows.values())) > 1:
+            raise RuntimeError("shape mismatch: the offset tensors disagree on the number of dynamic Gaussians: %s" % (rows,))
+        n_off = next(iter(rows.values())) if rows else 0
+        if n_off > P:
+            raise RuntimeError("shape mismatch: the offset tensors have %d rows for %d Gaussians" % (n_off, P))
         f32 = dict(device=dev, dtype=torch.float32)
         means3D = torch.empty((P, 3), **f32)
         means2D = torch.empty((P, 3), **f32)
@@ -88,6 +96,7 @@ class _AssembleInputs(torch.autograd.Function):
                 setattr(io, name, _p(v))
             else:
                 setattr(io, name + "_scalar", v)
+        io.num_offset_rows = n_off
         io.scratch = scratch.data_ptr()
         io.out_means3D, io.out_means2D, io.out_opacity = _p(means3D), _p(means2D), _p(out_op)
         io.out_scales, io.out_rotations, io.out_shs, io.out_shs_p = _p(scales), _p(rotations), _p(shs), _p(shs_p)
@@ -153,8 +162,10 @@ def assemble_inputs(xyz, screenspace_points, opacity, scaling, rotation, rotatio
                     features_phasor, motion_mask, d_xyz=0.0, d_rot=0.0, d_sh=0.0, d_sh_p=0.0,
                     render_regions=("static", "dynamic"), validate=False):
     """Returns ``(means3D, means2D, opacity, scales, rotations, shs, shs_p)`` exactly as lines 81-105
-    of the reference's ``gaussian_renderer/__init__.py`` build them.  ``validate=True`` adds the
-    reference's row-count check of the ``d_*`` tensors (one blocking read)."""
+    of the reference's ``gaussian_renderer/__init__.py`` build them.  The ``d_*`` tensors must share one row
+    count (checked on the host); a dynamic Gaussian beyond their last row gets NaN outputs and zero gradients
+    (never an out-of-bounds access).  ``validate=True`` adds the reference's exact row-count check against the
+    number of True entries of the mask (one blocking read) and raises like the reference's masked assignment."""
     return _AssembleInputs.apply(xyz, screenspace_points, opacity, scaling, rotation, rotation_raw,
                                  features_color, features_phasor, motion_mask, d_xyz, d_rot, d_sh, d_sh_p,
                                  "static" in render_regions, "dynamic" in render_regions, validate)

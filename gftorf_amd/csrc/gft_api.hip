@@ -518,7 +518,7 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     }
     if (cfg->P == 0) return 0;
     if (!io->means3D || !io->radii || !io->viewmatrix || !io->projmatrix || !io->campos || !io->geom || !io->img ||
-        !io->bg || !io->acc || !io->opacities || !io->dL_dmeans3D || !io->dL_dmeans2D || !io->dL_dopacity || !io->dL_dphase_offset ||
+        !io->bg || !io->acc || !io->dL_dmeans3D || !io->dL_dmeans2D || !io->dL_dopacity || !io->dL_dphase_offset ||
         !io->dL_ddc_offset)
         return gft_fail("gft_backward: required pointer is NULL");
     if (num_rendered > 0 && !io->binning) return gft_fail("gft_backward: binning buffer is NULL");

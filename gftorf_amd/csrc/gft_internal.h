@@ -5,7 +5,24 @@
 #include <stddef.h>
 #include "gftorf_rast.h"
 
+#include <atomic>
+
 #define GFT_ALIGN 256
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: the opt-in is made once per
+// (kernel, device) -- `done` holds one bit per device ordinal -- its error is returned, and two threads that make
+// their first call together both set it (idempotent).
+inline hipError_t gft_lds_opt_in(const void* kernel, size_t bytes, std::atomic<uint64_t>& done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && bit) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 #define GFT_BLOCK 256            // threads per workgroup = one 16x16 tile = 4 waves
 #define GFT_NUM_ACC 15           // accumulators actually used per Gaussian
 

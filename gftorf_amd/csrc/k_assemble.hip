@@ -24,6 +24,8 @@ namespace {
 
 #define ASM_BLOCK 256
 #define ASM_RANK_ROWS 1024          // rows per workgroup of the rank pass
+#define ASM_STATIC 0xffffffffu      // dyn_rank of a static row
+#define ASM_OOB 0x80000000u         // flag on the rank of a dynamic row that has no row in the offset tensors
 
 __global__ __launch_bounds__(ASM_RANK_ROWS) void k_assemble_rank(int P, const uint8_t* __restrict__ mask,
                                                                  uint32_t* block_sums, uint32_t* ticket,
@@ -97,7 +99,11 @@ __global__ __launch_bounds__(ASM_RANK_ROWS) void k_assemble_rows(RowsArgs a)
     for (int w = 0; w < wave; w++) rank += s_w[w];
     rank += (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
     if (!in) return;
-    a.dyn_rank[i] = m ? rank : 0xffffffffu;
+    // A dynamic row whose rank lies beyond the rows of the offset tensors (the reference's masked assignment raises
+    // for such shapes, gaussian_renderer/__init__.py:90-104): nothing is read or written out of bounds, the row's
+    // outputs are NaN (the loss shows it), its rank carries ASM_OOB so that the backward skips it too.
+    const bool oob = m && (int64_t)rank >= a.io.num_offset_rows;
+    a.dyn_rank[i] = m ? (oob ? (rank | ASM_OOB) : rank) : ASM_STATIC;
     const bool on = m ? a.render_dynamic != 0 : a.render_static != 0;
     float3 x = make_float3(0.f, 0.f, 0.f), s2 = x, sc = x;
     float op = 0.f;
@@ -107,7 +113,11 @@ __global__ __launch_bounds__(ASM_RANK_ROWS) void k_assemble_rows(RowsArgs a)
         s2 = make_float3(a.io.screenspace[3 * i], a.io.screenspace[3 * i + 1], a.io.screenspace[3 * i + 2]);
         op = a.io.opacity[i];
         sc = make_float3(a.io.scaling[3 * i], a.io.scaling[3 * i + 1], a.io.scaling[3 * i + 2]);
-        if (m) {
+        if (oob) {
+            const float nan = __builtin_nanf("");
+            x = make_float3(nan, nan, nan);
+            q = make_float4(nan, nan, nan, nan);
+        } else if (m) {
             if (a.io.d_xyz) {
                 x.x += a.io.d_xyz[3 * (size_t)rank]; x.y += a.io.d_xyz[3 * (size_t)rank + 1]; x.z += a.io.d_xyz[3 * (size_t)rank + 2];
             } else {
@@ -147,8 +157,14 @@ __global__ __launch_bounds__(ASM_BLOCK) void k_assemble_wide(size_t total_vec, i
     const size_t row = e / (size_t)row_vec;
     const int col = (int)(e - row * (size_t)row_vec);
     const uint32_t rank = dyn_rank[row];
-    const bool m = rank != 0xffffffffu;
+    const bool m = rank != ASM_STATIC;
     const bool on = m ? render_dynamic != 0 : render_static != 0;
+    if (m && (rank & ASM_OOB)) {              // no row in the offset tensors: see k_assemble_rows
+        const float nan = __builtin_nanf("");
+        if (VEC == 4) reinterpret_cast<float4*>(out)[e] = make_float4(nan, nan, nan, nan);
+        else out[e] = nan;
+        return;
+    }
     if (VEC == 4) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (on) {
@@ -184,9 +200,11 @@ __global__ __launch_bounds__(ASM_BLOCK) void k_assemble_rows_bwd(RowsBwdArgs a)
 {
     const int i = blockIdx.x * ASM_BLOCK + threadIdx.x;
     if (i >= a.P) return;
-    const uint32_t rank = a.dyn_rank[i];
-    const bool m = rank != 0xffffffffu;
-    const bool on = m ? a.render_dynamic != 0 : a.render_static != 0;
+    const uint32_t rank_w = a.dyn_rank[i];
+    const bool m = rank_w != ASM_STATIC;
+    const bool oob = m && (rank_w & ASM_OOB);   // no row in the offset tensors (k_assemble_rows): zero gradients
+    const uint32_t rank = rank_w & ~ASM_OOB;
+    const bool on = (m ? a.render_dynamic != 0 : a.render_static != 0) && !oob;
     float3 gx = make_float3(0.f, 0.f, 0.f), gs = gx, gsc = gx;
     float gop = 0.f;
     float4 gq = make_float4(0.f, 0.f, 0.f, 0.f), gq_raw = gq;
@@ -226,7 +244,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void k_assemble_rows_bwd(RowsBwdArgs a)
     if (a.io.g_scaling) { a.io.g_scaling[3 * i] = gsc.x; a.io.g_scaling[3 * i + 1] = gsc.y; a.io.g_scaling[3 * i + 2] = gsc.z; }
     if (a.io.g_rotation) reinterpret_cast<float4*>(a.io.g_rotation)[i] = gq;
     if (a.io.g_rotation_raw) reinterpret_cast<float4*>(a.io.g_rotation_raw)[i] = gq_raw;
-    if (m) {
+    if (m && !oob) {
         // rows of the offset tensors: every dynamic row is written (zeros when the region is off)
         if (a.io.g_d_xyz) {
             a.io.g_d_xyz[3 * (size_t)rank] = gx.x; a.io.g_d_xyz[3 * (size_t)rank + 1] = gx.y; a.io.g_d_xyz[3 * (size_t)rank + 2] = gx.z;
@@ -246,9 +264,11 @@ __global__ __launch_bounds__(ASM_BLOCK) void k_assemble_wide_bwd(size_t total_ve
     if (e >= total_vec) return;
     const size_t row = e / (size_t)row_vec;
     const int col = (int)(e - row * (size_t)row_vec);
-    const uint32_t rank = dyn_rank[row];
-    const bool m = rank != 0xffffffffu;
-    const bool on = m ? render_dynamic != 0 : render_static != 0;
+    const uint32_t rank_w = dyn_rank[row];
+    const bool oob = rank_w != ASM_STATIC && (rank_w & ASM_OOB);
+    const bool m = rank_w != ASM_STATIC && !oob;
+    const uint32_t rank = rank_w;
+    const bool on = (rank_w != ASM_STATIC ? render_dynamic != 0 : render_static != 0) && !oob;
     if (VEC == 4) {
         const float4 v = (on && g) ? reinterpret_cast<const float4*>(g)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
         if (g_f) reinterpret_cast<float4*>(g_f)[e] = v;
@@ -328,6 +348,8 @@ extern "C" int gft_assemble_forward(void* hip_stream, int32_t P, int32_t M, int3
         return gft_fail("gft_assemble_forward: M does not match feat_color / out_shs");
     if ((M_p > 0) != (io->feat_phasor != nullptr) || (M_p > 0) != (io->out_shs_p != nullptr))
         return gft_fail("gft_assemble_forward: M_p does not match feat_phasor / out_shs_p");
+    if ((io->d_xyz || io->d_rot || io->d_sh || io->d_sh_p) && (io->num_offset_rows < 0 || io->num_offset_rows > P))
+        return gft_fail("gft_assemble_forward: the offset tensors have %lld rows for %d Gaussians", (long long)io->num_offset_rows, P);
     hipStream_t s = (hipStream_t)hip_stream;
     uint32_t *rank, *sums, *ticket, *ndyn;
     assemble_scratch(io->scratch, P, &rank, &sums, &ticket, &ndyn);
@@ -337,6 +359,8 @@ extern "C" int gft_assemble_forward(void* hip_stream, int32_t P, int32_t M, int3
     RowsArgs a;
     a.P = P; a.render_static = render_static; a.render_dynamic = render_dynamic;
     a.io = *io;
+    // rows of the offset tensors; with scalar offsets only, every rank is in range
+    if (!io->d_xyz && !io->d_rot && !io->d_sh && !io->d_sh_p) a.io.num_offset_rows = (int64_t)1 << 40;
     a.dyn_rank = rank;
     a.block_sums = sums;
     hipLaunchKernelGGL(k_assemble_rows, dim3(nrb), dim3(ASM_RANK_ROWS), 0, s, a);

@@ -800,13 +800,11 @@ hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const Geo
                            im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, 0u, nullptr);
         return hipGetLastError();
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_scatter<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BIN_LDS_MAX_TILES * 4);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_scatter<2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, BIN_STAGE_LDS_BYTES);
-        attr_set = true;
+    {
+        static std::atomic<uint64_t> done1{0}, done2{0};
+        hipError_t e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_tile_scatter<1>), 2 * BIN_LDS_MAX_TILES * 4, done1);
+        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_tile_scatter<2>), BIN_STAGE_LDS_BYTES, done2);
+        if (e != hipSuccess) return e;
     }
     // Staging pays when a workgroup's instances (about cap / blocks; cap is R plus the caller's
     // headroom) fit the LDS that the three per-tile tables leave free; workgroups that exceed it
@@ -852,11 +850,10 @@ hipError_t gft_launch_tile_tail(hipStream_t s, const gft_config& c, const GeomVi
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  SORT_LDS_LARGE_BYTES);
-        attr_set = true;
+    {
+        static std::atomic<uint64_t> done{0};
+        const hipError_t e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_tile_tail), SORT_LDS_LARGE_BYTES, done);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_tile_tail, dim3(T < 256 ? T : 256), dim3(SORT_BIG_THREADS), (size_t)SORT_LDS_LARGE_BYTES, s, T,
                        im.ranges, b.keys, b.point_list, g.depth, im.front_len, im.unit_flag, im.ctrl, cap);
@@ -868,11 +865,10 @@ hipError_t gft_launch_tile_sort_long(hipStream_t s, const gft_config& c, const I
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort_big),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_LARGE_BYTES);
-        attr_set = true;
+    {
+        static std::atomic<uint64_t> done{0};
+        const hipError_t e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_tile_sort_big), SORT_LDS_LARGE_BYTES, done);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_tile_sort_big, dim3(T < 256 ? T : 256), dim3(SORT_BIG_THREADS), (size_t)SORT_LDS_LARGE_BYTES, s, T,
                        im.ranges, b.keys, b.point_list, SORT_LDS_SMALL, SORT_LDS_LARGE, im.ctrl, cap);

@@ -1142,24 +1142,29 @@ bool bf16_planes()
     return on;
 }
 
-bool attrs_set = false;
-void set_attrs()
+// the walks' dynamic-LDS opt-in, per device (gft_lds_opt_in)
+hipError_t set_attrs()
 {
-    if (attrs_set) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_bwd_bf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_BWD_BF_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd_bf<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_BF_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd_bf<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_BF_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_FWD_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deform_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_BWD_LDS);
-    attrs_set = true;
+    static std::atomic<uint64_t> done[6];
+    struct { const void* fn; size_t bytes; } k[6] = {
+        {reinterpret_cast<const void*>(&k_deform_bwd_bf), DF_BWD_BF_LDS},
+        {reinterpret_cast<const void*>(&k_deform_fwd_bf<true>), DF_FWD_BF_LDS},
+        {reinterpret_cast<const void*>(&k_deform_fwd_bf<false>), DF_FWD_BF_LDS},
+        {reinterpret_cast<const void*>(&k_deform_fwd<true>), DF_FWD_LDS},
+        {reinterpret_cast<const void*>(&k_deform_fwd<false>), DF_FWD_LDS},
+        {reinterpret_cast<const void*>(&k_deform_bwd), DF_BWD_LDS}};
+    for (int i = 0; i < 6; i++) {
+        const hipError_t e = gft_lds_opt_in(k[i].fn, k[i].bytes, done[i]);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace
 
 
 // encoded inputs of an (xyz_multires, t_multires) network, or -1 when the kernels do not hold it
-int arch_inputs(int xm, int tm)
+static int arch_inputs(int xm, int tm)
 {
     if (xm < 0 || tm < 0 || xm > 16 || tm > 24) return -1;
     const int in = 3 + 6 * xm + 1 + 2 * tm;
@@ -1219,7 +1224,7 @@ extern "C" int gft_deform_forward(void* hip_stream, int xyz_multires, int t_mult
     if (!xyz || !t || !packed || !d_xyz || !d_sh) return gft_fail("gft_deform_forward: NULL argument");
     if (t_stride != 0 && t_stride != 1) return gft_fail("gft_deform_forward: t_stride must be 0 or 1");
     if (n > ((int64_t)1 << 31) * 16) return gft_fail("gft_deform_forward: n too large");
-    set_attrs();
+    GFT_CHECK_HIP(set_attrs());
     FwdArgs a;
     a.n = n;
     a.n_pad = pad_points(n);
@@ -1279,7 +1284,7 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
         return 0;
     }
     if (!packed || !saved || !scratch) return gft_fail("gft_deform_backward: NULL argument");
-    set_attrs();
+    GFT_CHECK_HIP(set_attrs());
     const int64_t n_pad = pad_points(n);
     const float* emb = (const float*)saved;
     const float* acts = emb + n_pad * DF_EMB;

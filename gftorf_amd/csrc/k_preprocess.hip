@@ -664,7 +664,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
             const float ddist_in = a0.w;
             // the five geometric sums arrive without their per-Gaussian factors (k_render_bwd):
             // dL/dmean2D.xy = -o (0.5 W, 0.5 H) * sum,  dL/dconic = -o/2 * sum
-            const float nop = -a.io.opacities[idx];
+            // (the pybind-level backward of the reference has no opacity argument, rasterize_points.h:55-88: the value
+            // the forward stored in the geometry record is the same float)
+            const float nop = -(a.io.opacities ? a.io.opacities[idx] : a.g.rec_a[2 * idx + 1].y);
             dmean2d[0] = a1.x * (nop * 0.5f * (float)a.c.W); dmean2d[1] = a1.y * (nop * 0.5f * (float)a.c.H);
             const float dconx = a1.z * (0.5f * nop), dcony = a1.w * (0.5f * nop), dconw = a3.x * (0.5f * nop);
             dopac = a3.y;
@@ -1013,13 +1015,12 @@ hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const g
     // (re-measured with the final kernel: staging shs_p only 113 vs 111 us, shs only 128, both 178)
     a.stage_sh = a.stage_shp = 0;
     const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_PAD : 0) + (a.stage_shp ? SHP_ROW_PAD : 0));
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess_fwd),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 16 * (SH_ROW_PAD + SHP_ROW_PAD));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess_bwd),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 16 * (SH_ROW_PAD + SHP_ROW_PAD));
-        attr_set = true;
+    {
+        static std::atomic<uint64_t> done_f{0}, done_b{0};
+        hipError_t e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_preprocess_fwd), 4 * 64 * 16 * (SH_ROW_PAD + SHP_ROW_PAD), done_f);
+        if (e == hipSuccess)
+            e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_preprocess_bwd), 4 * 64 * 16 * (SH_ROW_PAD + SHP_ROW_PAD), done_b);
+        if (e != hipSuccess) return e;
     }
     const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;
     hipLaunchKernelGGL(k_preprocess_fwd, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);

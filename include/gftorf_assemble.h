@@ -57,6 +57,11 @@ typedef struct gft_assemble_io {
     float* out_rotations;        /* [P,4] */
     float* out_shs;              /* [P,M,3] */
     float* out_shs_p;            /* [P,M_p,2] */
+    /* Nd: rows of the d_* tensors that are given (all share it; 0 <= Nd <= P; ignored when all four are scalars).
+     * A dynamic Gaussian whose rank among the dynamic ones is >= Nd has no offset row -- the reference's masked
+     * assignment raises for such shapes -- : nothing is read or written out of bounds, that Gaussian's outputs are
+     * NaN and its gradients zero.  gft_assemble_num_dynamic() gives the exact count for a host-side check. */
+    int64_t num_offset_rows;
 } gft_assemble_io;
 
 typedef struct gft_assemble_bwd_io {

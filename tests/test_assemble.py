@@ -136,6 +136,33 @@ def test_hip_assembly_edge_cases(gpu):
     c["d_xyz"] = c["d_xyz"][:-1]
     with pytest.raises(RuntimeError, match="shape mismatch"):
         assemble_inputs(*tensors(c, gpu, False), validate=True)
+    # ... and without the blocking check: every d_* one row short of what the mask selects (the default path of a hot
+    # loop).  Nothing is read or written past the tensors; the Gaussian without an offset row comes out as NaN in
+    # every output an offset enters, its gradients are zero, everybody else is unchanged.
+    c = make_case(500, M=4, M_p=4, seed=2)
+    full, _ = run(assemble_inputs, c, gpu, ("static", "dynamic"), grad=False)
+    nd = int(c["mask"].sum())
+    last = int(np.nonzero(c["mask"])[0][-1])
+    short = dict(c)
+    for k in ("d_xyz", "d_rot", "d_sh", "d_sh_p"):
+        short[k] = c[k][:nd - 1]
+    ts = tensors(short, gpu, True)
+    outs = assemble_inputs(*ts)
+    for i, (o, f) in enumerate(zip(outs, full)):
+        o = o.detach().cpu().numpy()
+        keep = np.ones(500, bool)
+        keep[last] = False
+        np.testing.assert_array_equal(o[keep], f[keep])
+        if i in (0, 4, 5, 6):          # means3D, rotations, shs, shs_p take an offset
+            assert np.isnan(o[last]).all(), i
+    torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+    torch.cuda.synchronize()
+    assert all(t.grad is None or torch.isfinite(t.grad).all() for t in ts if isinstance(t, torch.Tensor) and t.is_floating_point())
+    # offset tensors that disagree on the row count are refused on the host
+    bad = dict(c)
+    bad["d_rot"] = c["d_rot"][:-3]
+    with pytest.raises(RuntimeError, match="disagree"):
+        assemble_inputs(*tensors(bad, gpu, False))
     # a degenerate dynamic quaternion takes the clamped branch of normalize
     c = make_case(64, M=4, M_p=4, seed=4, offsets="float", mask=np.ones(64, bool))
     c["rotation_raw"][:] = 0
