@@ -40,6 +40,12 @@ WORKLOADS = {
                       label="1M Gaussians concentrated at the image centre, 640x480 (load-balance check)"),
     "tiny": dict(P=20_000, W=256, H=256, D=3, sh_coeffs=16, tof=True,
                  label="20k Gaussians, 256x256 (plumbing check only)"),
+    # BASELINE.json config 1: the shape of the reference's CPU-runnable plumbing case, here forward-only on the GPU
+    # with the CPU oracle timed beside it
+    "C1": dict(P=10_000, W=256, H=256, D=0, sh_coeffs=1, tof=False, forward_only=True,
+               label="10k Gaussians, 256x256, SH deg 0, RGB-only forward"),
+    # BASELINE.json config 3: handled by bench_loop.py (the whole optimisation loop, not one rasterizer call)
+    "C3": dict(loop=True),
 }
 
 
@@ -87,20 +93,46 @@ def timed_steps(step_fn, steps, warmup, sync_fn, dist=None):
 # ---------------------------------------------------------------------------
 # algorithmic bytes; P_vis = radii > 0, R = tile instances, N = pixels
 # ---------------------------------------------------------------------------
-def algorithmic_bytes(P, P_vis, R, N, T):
+def algorithmic_bytes(P, P_vis, R, N, T, R_walked=None, forward_only=False):
+    """per visible Gaussian 1516 B, culled 432 B, per instance 268 B (44 B of binning: keys 12, sort 24,
+    ranges 8; 224 B of rendering: K6 76, K7 148), per pixel 224 B.  With ``R_walked`` the rendering bytes are charged
+    only for the list entries a tile walks (up to its deepest contributor): early termination makes the rest of
+    a list dead data that no implementation of the algorithm has to read, so the all-R figure is not a bound."""
     P_cull = P - P_vis
+    Rr = R if R_walked is None else R_walked
     per_kernel = {
         "preprocess_fwd": 484 * P_vis + 48 * P_cull,
         "tile_count": 8 * P_vis + 8 * R,        # reference scan (K2) + tile ranges (K5)
         "tile_scatter": 20 * P_vis + 12 * R,    # reference duplicateWithKeys (K3)
         "tile_sort": 24 * R,                    # reference key sort (K4), one read + one write of a pair
-        "render_fwd": 76 * R + 128 * N,
-        "render_bwd": 148 * R + 96 * N,
+        "render_fwd": 76 * Rr + 128 * N,
+        "render_bwd": 148 * Rr + 96 * N,
         "preprocess_bwd": 928 * P_vis + 384 * P_cull,
         "memset": 76 * P_vis,
     }
-    whole = 1516 * P_vis + 432 * P_cull + 268 * R + 224 * N
+    whole = 1516 * P_vis + 432 * P_cull + 44 * R + 224 * Rr + 224 * N
+    if forward_only:       # SURVEY 8(d): 512 P_vis + 48 P_cull + 120 R + 128 N
+        whole = 512 * P_vis + 48 * P_cull + 44 * R + 76 * Rr + 128 * N
     return per_kernel, whole
+
+
+def walked_instances(dev):
+    """List entries the render stages have to touch: per tile, the deepest contributor over its four 8x8
+    quadrants (the backward starts there; the forward stops a little later, when its last pixel saturates),
+    read from the scratch of the most recent forward."""
+    import torch
+    from gftorf_amd import _lib, api
+    b = api.last_call_buffers
+    if not b or b.get("P", 0) == 0:
+        return None
+    L = _lib.get_layout(b["P"], b["W"], b["H"], b["cap"])
+    T = ((b["W"] + 15) // 16) * ((b["H"] + 15) // 16)
+    tm = b["img"][L.img_tile_max:L.img_tile_max + T * 16].view(torch.int32).reshape(T, 4)
+    ctrl = b["img"][L.img_ctrl:L.img_ctrl + 64].view(torch.int32).cpu().tolist()
+    return {"per_tile_deepest": int(tm.max(dim=1).values.sum().item()), "per_quadrant_sum": int(tm.sum().item()),
+            # lazy binning / lazy sort bookkeeping of that forward (ctrl words, gft_internal.h)
+            "near_slab_instances": ctrl[5], "far_slab_instances_binned": ctrl[8], "flagged_quadrants": ctrl[4],
+            "depth_cut": api.last_call_stats.get("depth_cut", 0.0)}
 
 
 def build_scene(workload, rank, world):
@@ -137,6 +169,14 @@ def gpu_step_fn(scene, dev):
         for v in leaf.values():
             v.grad = None
         means2D.grad = None
+        if cfg.get("forward_only"):
+            with torch.no_grad():
+                outs = rast(means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"], shs=leaf["shs"],
+                            shs_p=leaf.get("shs_p"), scales=leaf["scales"], rotations=leaf["rotations"],
+                            phase_offset=scene["phase_offset"], dc_offset=scene["dc_offset"])
+            state["radii"] = outs[10]
+            state["pixels"] = outs[8]
+            return
         outs = rast(means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"], shs=leaf["shs"],
                     shs_p=leaf.get("shs_p"), scales=leaf["scales"], rotations=leaf["rotations"],
                     phase_offset=scene["phase_offset"], dc_offset=scene["dc_offset"])
@@ -150,7 +190,7 @@ def gpu_step_fn(scene, dev):
     return step, state, leaf
 
 
-def cpu_baseline(scene, budget_s=20.0, max_iters=5):
+def cpu_baseline(scene, budget_s=20.0, max_iters=5, forward_only=False):
     """The CPU oracle (a port of the reference algorithm; the reference itself has no CPU
     rasterizer) timed on this host: full forward+backward of the same frame."""
     from oracle import oracle
@@ -159,29 +199,42 @@ def cpu_baseline(scene, budget_s=20.0, max_iters=5):
     oracle.lib()
     t_all = []
     t_start = time.perf_counter()
-    Hh.run_oracle(oracle, scene)  # warm-up (page faults, thread pool)
+    Hh.run_oracle(oracle, scene, backward=not forward_only)  # warm-up (page faults, thread pool)
     warm = time.perf_counter() - t_start
     while len(t_all) < max_iters and (time.perf_counter() - t_start) < budget_s:
         t0 = time.perf_counter()
-        Hh.run_oracle(oracle, scene)
+        Hh.run_oracle(oracle, scene, backward=not forward_only)
         t_all.append(time.perf_counter() - t0)
     if not t_all:
         t_all = [warm]
     t_all.sort()
     med = t_all[len(t_all) // 2]
     return dict(value=1.0 / med, unit="it/s", cores=oracle.num_threads(), kind="port",
-                sample="%d full forward+backward iterations of the same frame (median %.3f s)" % (len(t_all), med))
+                sample="%d full %s iterations of the same frame (median %.3f s)" % (
+                    len(t_all), "forward" if forward_only else "forward+backward", med))
 
 
-def load_traffic(kernel, workload):
-    """HBM bytes per launch from a committed rocprofv3 --pmc pass, if one exists."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def load_counters(stage, workload):
+    """Counter summary of one stage from the committed rocprofv3 --pmc passes (profiles/collect_pmc.sh +
+    make_counters.py -> profiles/counters.json): HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE), VALU
+    wave-instructions per launch, resident waves per SIMD, VALU issue share.  None when the workload was not profiled."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        return d.get(workload, {}).get(kernel)
+        w = d.get(workload)
+        if not w or stage not in w["stages"]:
+            return None
+        s = dict(w["stages"][stage])
+        s["source"] = w["source"]
+        return s
     except Exception:
         return None
+
+
+FP32_VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector)
+# SURVEY 7.4 #3: a (pixel, Gaussian) pair costs ~30 flop in the forward blend and ~150 flop in the backward
+FLOPS_PER_PAIR = {"render_fwd": 30.0, "render_bwd": 150.0}
 
 
 def assemble_extra(dev, P=1_000_000, frac=0.3, M=16, steps=20, warmup=5):
@@ -597,7 +650,7 @@ def adam_extra(dev, P=1_000_000, steps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50; 7000 iterations for --workload C3)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="metric", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -605,6 +658,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the fused-assembly measurement")
     ap.add_argument("--spin-up", type=float, default=0.3, help="seconds of untimed steps before the warm-up")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 7000 if args.workload == "C3" else 50
 
     import torch
     env = dist_env()
@@ -631,6 +686,10 @@ def main():
             dist_mod.init_process_group(backend="nccl", device_id=dev)
         dist = dist_mod
 
+    from gftorf_amd import api
+    api.keep_last_buffers = True          # the walked-entries figure of path_roofline is read from the last forward's scratch
+    if args.workload == "C3":
+        return main_loop(args, env, world, dev, dist)
     scene = build_scene(args.workload, env["rank"], world)
     step, state, _ = gpu_step_fn(scene, dev)
     sync = torch.cuda.synchronize
@@ -660,8 +719,10 @@ def main():
     T = ((W + 15) // 16) * ((H + 15) // 16)
     radii = state["radii"]
     P_vis = int((radii > 0).sum().item())
-    from gftorf_amd import api
     R = int(api.last_call_stats["num_rendered"])
+    walked = walked_instances(dev)
+    pairs = float(state["pixels"].double().sum().item())      # (pixel, Gaussian) pairs that were blended
+    restarts = (api.last_call_stats.get("restarts", 0), api.last_call_stats.get("forwards", 0))
 
     exchange = None
     if dist is not None and not args.no_extras:
@@ -672,7 +733,10 @@ def main():
             exchange = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if env["rank"] == 0:
-        per_kernel, whole = algorithmic_bytes(P, P_vis, R, N, T)
+        fo = bool(cfg.get("forward_only"))
+        per_kernel, whole = algorithmic_bytes(P, P_vis, R, N, T, forward_only=fo)
+        R_walked = walked["per_tile_deepest"] if walked else R
+        per_kernel_w, whole_w = algorithmic_bytes(P, P_vis, R, N, T, R_walked, forward_only=fo)
         calls = max(prof["forward_calls"], 1)
         stage_ms = {k[:-3]: prof[k] / calls for k in prof if k.endswith("_ms")}
         dom = max(stage_ms, key=lambda k: stage_ms[k])
@@ -680,6 +744,31 @@ def main():
         achieved = per_kernel[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
+        cnt = load_counters(dom, args.workload)
+        traffic = cnt["hbm_bytes"] if cnt else None
+        all_cnt = [load_counters(k, args.workload) for k in stage_ms if k != "memset"]
+        path_traffic = sum(c["hbm_bytes"] for c in all_cnt) if all(all_cnt) else None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": per_kernel[dom], "avg_launch_ms": dom_ms,
+                    # what the counters say this kernel really moves, per launch, over the same duration
+                    "counter_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_ms > 0) else None,
+                    "counter_source": cnt["source"] if cnt else None,
+                    # the same stage charged only for the list entries its tiles walk (early termination)
+                    "algorithmic_bytes_walked": per_kernel_w[dom],
+                    "frac_walked": (per_kernel_w[dom] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_ms > 0 else None}
+        if dom in FLOPS_PER_PAIR:
+            # the render kernels are bound by VALU issue, not by HBM: report that ceiling beside the byte figures
+            useful = pairs * FLOPS_PER_PAIR[dom]
+            roofline["valu"] = {
+                "pair_evaluations": pairs, "flops_per_pair": FLOPS_PER_PAIR[dom],
+                "useful_TFLOPs": useful / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else None,
+                "peak_TFLOPs": FP32_VALU_PEAK_TFLOPS,
+                "useful_frac_of_fp32_valu_peak": useful / (dom_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS if dom_ms > 0 else None,
+                "wave_instructions_per_launch": cnt.get("valu_insts") if cnt else None,
+                "resident_waves_per_simd": cnt.get("mean_resident_waves_per_simd") if cnt else None,
+                "issue_slot_frac": cnt.get("valu_issue_slot_frac") if cnt else None,
+                "source": cnt["source"] if cnt else None}
         out = {
             "metric": "train iters/sec (fwd+bwd raster) + Mpix/s, 1M Gaussians @ 640x480 ToF",
             "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -691,13 +780,25 @@ def main():
                        "parallelism": "frame-sharded x%d (no collective in the raster path; the deform-gradient all-reduce is "
                                       "measured in deform_exchange)" % world},
             "mpix_per_s": value * N / 1e6,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom, args.workload),
-                         "algorithmic_bytes_per_launch": per_kernel[dom], "avg_launch_ms": dom_ms},
-            "path_roofline": {"algorithmic_bytes_per_step": whole,
-                              "achieved_GBs": whole / (ms_per_step * 1e-3) / 1e9,
-                              "frac": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline": roofline,
+            # whole step.  `frac` charges the rendering bytes (224 B per instance) for the list entries the tiles
+            # walk; `frac_all_instances` is SURVEY 8(d)'s formula as written (every instance), which early
+            # termination makes an over-count -- it is not a bound (6290 GB/s is the measured copy ceiling).
+            "path_roofline": {"algorithmic_bytes_per_step": whole_w,
+                              "achieved_GBs": whole_w / (ms_per_step * 1e-3) / 1e9,
+                              "frac": whole_w / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "instances": R, "instances_walked": R_walked,
+                              "instances_walked_per_quadrant_sum": walked["per_quadrant_sum"] if walked else None,
+                              "algorithmic_bytes_all_instances": whole,
+                              "frac_all_instances": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "achievable_copy_GBs": 6290.0,
+                              # HBM bytes of all stages as the counters saw them (profiles/counters.json)
+                              "counter_bytes_per_step": path_traffic,
+                              "counter_frac": (path_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if path_traffic else None,
                               "gpu_ms_sum_of_stages": sum(stage_ms.values())},
+            "binning_restarts": {"restarted_forwards": restarts[0], "forwards": restarts[1]},
+            "lazy_binning": {k: walked[k] for k in ("depth_cut", "near_slab_instances", "far_slab_instances_binned",
+                                                    "flagged_quadrants")} if walked else None,
             "stage_ms": stage_ms,
         }
         if exchange is not None:
@@ -711,8 +812,85 @@ def main():
                              "adam": adam_extra(dev), "deform_network": deform_extra(dev),
                              "densify": densify_extra(dev), "train_iteration": train_extra}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, budget_s=args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(scene, budget_s=args.cpu_budget, forward_only=fo)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_loop(args, env, world, dev, dist):
+    """--workload C3: BASELINE.json config 3, the torf `copier`-shaped optimisation loop (bench_loop.py).  A step is one
+    training iteration; every rank optimises its own replica of the scene (no collective: replicas only)."""
+    import torch
+    import bench_loop
+    from gftorf_amd import _lib, api
+    sync = torch.cuda.synchronize
+    holder = {}
+
+    def region(step_fn, n):
+        holder["step"] = step_fn
+        return timed_steps(step_fn, n, args.warmup, sync, dist)
+    elapsed, rep, info = bench_loop.run(dev, args.steps, sync, region)
+    # roofline leg: per-stage HIP events of the rasterizer calls over 200 more iterations
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    n_prof = 200
+    for _ in range(n_prof):
+        holder["step"]()
+    sync()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    if env["rank"] == 0:
+        cfg = bench_loop.C3
+        P, W, H = cfg["P"], cfg["W"], cfg["H"]
+        N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+        R = int(api.last_call_stats["num_rendered"])
+        walked = walked_instances(dev)
+        fwd_calls, bwd_calls = max(prof["forward_calls"], 1), max(prof["backward_calls"], 1)
+        # two forwards and one backward per iteration: per-call stage times
+        stage_ms = {k[:-3]: prof[k] / (bwd_calls if k in ("render_bwd_ms", "preprocess_bwd_ms", "memset_ms") else fwd_calls)
+                    for k in prof if k.endswith("_ms")}
+        raster_ms_per_it = sum(prof[k] for k in prof if k.endswith("_ms")) / n_prof
+        dom = max(stage_ms, key=lambda k: stage_ms[k])
+        per_kernel, whole = algorithmic_bytes(P, P, R, N, T, walked["per_tile_deepest"] if walked else None)
+        ms = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        achieved = per_kernel[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        out = {
+            "metric": "train iters/sec (fwd+bwd raster) + Mpix/s, 1M Gaussians @ 640x480 ToF",
+            "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: " + cfg["label"], "P": P, "W": W, "H": H, "views": cfg["views"], "sh_degree": cfg["sh_degree"],
+                       "warm_up": cfg["warm_up"], "num_rendered_last_call": R,
+                       "step": "one training iteration: LR schedule, random view + background, deform query (after warm-up), "
+                               "activations, input assembly, colour + ToF rasterizer forward, ToF loss (L2 + SSIM), backward, "
+                               "densification statistics, Adam (Gaussians + network)",
+                       "parallelism": "replicas x%d" % world},
+            "mpix_per_s": value * 2 * N / 1e6,
+            "loop": rep,
+            "raster_ms_per_iteration": raster_ms_per_it, "raster_share_of_iteration": raster_ms_per_it / ms,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": per_kernel[dom],
+                         "avg_launch_ms": stage_ms[dom],
+                         "note": "at 100k Gaussians / 320x240 a rasterizer call is ~0.1 ms of kernels: the iteration is bound by "
+                                 "launch latency and the host, not by HBM (raster_share_of_iteration)"},
+            "stage_ms": stage_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # CPU beside it: the oracle's rasterizer forward+backward on one C3-shaped ToF frame (the rest of the loop is
+            # host-side torch in the reference as well)
+            from gftorf_amd import synth
+            g0, cams = info["frame"]["g0"], info["frame"]["cams"]
+            cam = {k: v for k, v in cams[len(cams) // 2][1].items() if not k.startswith("_")}
+            frame = dict(cfg=dict(P=P, W=W, H=H, D=3, sh_coeffs=16, tof=True), cam=cam, gaussians=g0,
+                         bg=synth.make_background(W, H, 3), grads=synth.make_pixel_grads(W, H, 3), depth_range=cfg["depth_range"],
+                         phase_offset=0.1, dc_offset=0.0, use_view_dependent_phase=True)
+            cb = cpu_baseline(frame, budget_s=args.cpu_budget)
+            cb["sample"] = "rasterizer forward+backward of one C3 ToF frame (100k Gaussians, 320x240): " + cb["sample"]
+            cb["unit"] = "raster fwd+bwd/s"
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -51,7 +51,7 @@ BACKWARD_FIELDS = [
 LAYOUT_FIELDS = [
     "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_rect", "geom_dirgrad", "geom_clamped",
     "geom_blockhist", "geom_total",
-    "img_pix_state", "img_ranges", "img_tile_max", "img_ctrl", "img_tile_cnt", "img_tile_cursor", "img_tile_order", "img_front_len", "img_unit_flag", "img_resume_state", "img_pix_sums", "img_total",
+    "img_pix_state", "img_ranges", "img_tile_max", "img_ctrl", "img_tile_cnt", "img_tile_cnt1", "img_dhist", "img_ranges1", "img_tile_cursor", "img_tile_order", "img_front_len", "img_unit_flag", "img_resume_state", "img_pix_sums", "img_total",
     "bin_keys", "bin_point_list", "bin_total",
 ]
 
@@ -69,6 +69,18 @@ class BackwardIO(C.Structure):
 
 class Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in LAYOUT_FIELDS]
+
+
+class ForwardHints(C.Structure):
+    """gft_forward_hints"""
+    _fields_ = [("binning_instances", C.c_int64), ("max_tile_list", C.c_int64), ("near_instances", C.c_int64),
+                ("depth_cut", C.c_float), ("reserved", C.c_float)]
+
+
+class ForwardReport(C.Structure):
+    """gft_forward_report"""
+    _fields_ = [("num_rendered", C.c_int64), ("max_tile_list", C.c_int64), ("near_instances", C.c_int64),
+                ("depth_cut_next", C.c_float), ("reserved", C.c_float)]
 
 
 class Profile(C.Structure):
@@ -191,9 +203,9 @@ def load():
     lib.gft_assemble_num_dynamic.restype = C.c_int
     lib.gft_assemble_num_dynamic.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
     lib.gft_forward.restype = C.c_int
-    lib.gft_forward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64, C.c_int64,
-                                C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-    lib.gft_forward_render.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64, C.c_int64]
+    lib.gft_forward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.POINTER(ForwardHints),
+                                C.POINTER(ForwardReport)]
+    lib.gft_forward_render.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64, C.c_int64, C.c_float]
     lib.gft_backward.restype = C.c_int
     lib.gft_backward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(BackwardIO), C.c_int64]
     lib.gft_mark_visible.restype = C.c_int

@@ -48,6 +48,11 @@ class GaussianRasterizationSettings(NamedTuple):
 last_call_stats = {"num_rendered": 0, "binning_instances": 0, "restarted": False, "max_tile_list": 0,
                    "forwards": 0, "restarts": 0}
 
+# Diagnostics (bench.py): with keep_last_buffers the scratch buffers of the most recent forward stay referenced here
+# so that a caller can read e.g. the per-quadrant list depths (layout: _lib.get_layout).  Off by default.
+keep_last_buffers = False
+last_call_buffers = {}
+
 # Instance count (and longest tile list) of the recent forwards per (device, P, W, H).  A training loop renders
 # similar frames back to back, so the binning buffer can be sized before the device has
 # counted (gft_forward: no host round trip in the middle of the forward); a frame that needs
@@ -238,7 +243,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         stream = torch.cuda.current_stream(dev).cuda_stream
         num_rendered = C.c_int64(0)
         hint_key = (dev.index, P, W, H)
-        hint, list_hint = _instance_hint.get(hint_key, (None, 0))
+        hint, list_hint, cut_hint, near_hint = _instance_hint.get(hint_key, (None, 0, 0.0, 0))
         try:
             with torch.cuda.device(dev):
                 if hint is None:
@@ -251,27 +256,33 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     cap = _canonical_cap(R)
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
-                    _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, int(max_list.value)))
+                    _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, int(max_list.value), 0.0))
+                    # the first frame of a shape bins every instance and leaves no depth cut for the next one: the
+                    # second frame measures the depth distribution (gft_forward reports it), the third uses it
+                    cut_next, near = 0.0, R
                 else:
                     cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
-                    _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), cap,
-                                               int(list_hint * _LIST_HEADROOM) + 1, C.byref(num_rendered),
-                                               C.byref(max_list)))
-                    R = int(num_rendered.value)
+                    hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
+                                              near_instances=int(near_hint), depth_cut=float(cut_hint))
+                    report = _lib.ForwardReport()
+                    _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), C.byref(hints), C.byref(report)))
+                    R = int(report.num_rendered)
+                    max_list.value = int(report.max_tile_list)
+                    cut_next, near = float(report.depth_cut_next), int(report.near_instances)
                     if R > cap:
                         restarted = True
                         cap = _canonical_cap(R)
                         binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                         io.binning = binning.data_ptr()
                         _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap,
-                                                          int(max_list.value)))
+                                                          int(max_list.value), float(cut_hint)))
                 # slowly decaying maximum: alternating views of one scene (colour / ToF camera,
                 # random training views) keep the larger count as the guess
-                prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
+                prev_r, prev_l = _instance_hint.get(hint_key, (0, 0, 0.0, 0))[:2]
                 _instance_hint[hint_key] = (max(R, int((prev_r or 0) * 0.95)),
-                                            max(int(max_list.value), int(prev_l * 0.95)))
+                                            max(int(max_list.value), int(prev_l * 0.95)), cut_next, near)
                 if len(_instance_hint) > 64:
                     _instance_hint.pop(next(iter(_instance_hint)))
         except Exception as ex:
@@ -282,7 +293,10 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         assert binning_capacity(binning) == cap
 
     last_call_stats.update(num_rendered=R, binning_instances=cap, restarted=restarted,
-                           max_tile_list=int(max_list.value) if P else 0)
+                           max_tile_list=int(max_list.value) if P else 0, depth_cut=float(cut_hint) if (P and hint is not None) else 0.0,
+                           near_instances=near if P else 0)
+    if keep_last_buffers:
+        last_call_buffers.update(geom=geom, img=img, binning=binning, P=P, W=W, H=H, cap=cap)
     last_call_stats["forwards"] = last_call_stats.get("forwards", 0) + 1
     last_call_stats["restarts"] = last_call_stats.get("restarts", 0) + int(restarted)
     return dict(R=R, cap=cap, outputs=(color, phasor, depth, normal, acc, entropy, depth_distortion, amp_distortion,

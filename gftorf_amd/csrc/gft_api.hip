@@ -50,7 +50,10 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->img_ranges = o;      o = align_up(o + T * 8);
     L->img_tile_max = o;    o = align_up(o + T * 4 * 4);   // one entry per 8x8 quadrant
     L->img_ctrl = o;        o += GFT_CTRL_WORDS * 4;          // ctrl words and tile counters are contiguous
-    L->img_tile_cnt = o;    o = align_up(o + T * 4);
+    L->img_tile_cnt = o;    o += T * 4;                       // ... and so are the far-slab counters and the depth histogram
+    L->img_tile_cnt1 = o;   o += T * 4;
+    L->img_dhist = o;       o = align_up(o + GFT_DHIST_BINS * 4);
+    L->img_ranges1 = o;     o = align_up(o + T * 8);
     L->img_tile_cursor = o; o = align_up(o + T * 4);
     L->img_tile_order = o;  o = align_up(o + T * 4);
     L->img_front_len = o;   o = align_up(o + T * 4);
@@ -90,6 +93,9 @@ ImgView gft_img_view(void* base, const gft_layout& L)
     v.tile_max = (uint32_t*)(b + L.img_tile_max);
     v.ctrl = (uint32_t*)(b + L.img_ctrl);
     v.tile_cnt = (uint32_t*)(b + L.img_tile_cnt);
+    v.tile_cnt1 = (uint32_t*)(b + L.img_tile_cnt1);
+    v.dhist = (uint32_t*)(b + L.img_dhist);
+    v.ranges1 = (uint2*)(b + L.img_ranges1);
     v.tile_cursor = (uint32_t*)(b + L.img_tile_cursor);
     v.tile_order = (uint32_t*)(b + L.img_tile_order);
     v.front_len = (uint32_t*)(b + L.img_front_len);
@@ -332,14 +338,32 @@ static int check_stage2(const gft_forward_io* io, const char* who)
     return 0;
 }
 
+static bool lazy_sort_enabled();
+
+// GFT_LAZY_BIN=0 in the environment bins every instance up front (no depth cut); results are identical.
+static bool lazy_bin_enabled()
+{
+    static const bool on = [] { const char* e = getenv("GFT_LAZY_BIN"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
+
+// depth cut of the caller -> float bits the kernels compare depth bits with (positive floats order like their bits)
+static uint32_t cut_bits_of(float depth_cut)
+{
+    if (!(depth_cut > 0.0f) || !lazy_bin_enabled()) return GFT_NO_CUT;      // <= 0, NaN: no cut
+    uint32_t b;
+    memcpy(&b, &depth_cut, 4);
+    return b < GFT_NO_CUT ? b : GFT_NO_CUT;
+}
+
 // preprocess + tile counting + scan; the totals arrive in the mailbox slot
 static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
-                          const ImgView& im, uint32_t* mail_dev, uint32_t seq)
+                          const ImgView& im, uint32_t* mail_dev, uint32_t seq, uint32_t cut_bits)
 {
     {
-        // ctrl words + per-tile counters: one clear
+        // ctrl words, per-tile counters of both slabs and the depth histogram: one clear
         const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
-        GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, (GFT_CTRL_WORDS + (size_t)gx * gy) * sizeof(uint32_t), s));
+        GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, (GFT_CTRL_WORDS + 2 * (size_t)gx * gy + GFT_DHIST_BINS) * sizeof(uint32_t), s));
     }
     {
         StageTimer t(s, ST_PRE_FWD);
@@ -347,7 +371,7 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
     }
     {
         StageTimer t(s, ST_TILE_COUNT);
-        GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im, mail_dev, seq));
+        GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im, mail_dev, seq, cut_bits, 0, 0u));
     }
     return 0;
 }
@@ -364,9 +388,10 @@ extern "C" int gft_lazy_sort(void) { return lazy_sort_enabled() ? 1 : 0; }
 
 // scatter + per-tile sort + render; `cap` = instances the binning buffer holds.  With
 // check_cap the kernels compare the device-side count against it and do nothing on overflow.
+// `cut_bits` as given to stage 1; `expect0`: the caller's estimate of the instances the first scatter moves.
 static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
                           const ImgView& im, const BinView& b, bool binned, int64_t max_tile_list, bool check_cap,
-                          uint32_t cap)
+                          uint32_t cap, uint32_t cut_bits, int64_t expect0)
 {
     // The backward's accumulator clear (64 B per Gaussian of pure HBM writes) rides along with the
     // tile sort, whose workgroups are bound by LDS and VALU: each writes a slice of zeros first.
@@ -376,7 +401,7 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
     if (binned) {
         {
             StageTimer t(s, ST_TILE_SCATTER);
-            GFT_STAGE(s, cfg, "tile_scatter", gft_launch_tile_scatter(s, *cfg, g, im, b, cap));
+            GFT_STAGE(s, cfg, "tile_scatter", gft_launch_tile_scatter(s, *cfg, g, im, b, cap, cut_bits, 0, expect0));
         }
         {
             StageTimer t(s, ST_TILE_SORT);
@@ -394,7 +419,18 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
     }
     if (lazy) {
         // quadrants that used up the sorted head of their list: sort those tails, continue those quadrants
-        // (both kernels leave at once when the first pass raised no flag)
+        // (all these kernels leave at once when the first pass raised no flag).  With a depth cut the far slab
+        // is binned first, for the tiles that have such a quadrant.
+        if (cut_bits != GFT_NO_CUT) {
+            {
+                StageTimer t(s, ST_TILE_COUNT);
+                GFT_STAGE(s, cfg, "tile_count_far", gft_launch_tile_count(s, *cfg, g, im, nullptr, 0u, cut_bits, 1, cap));
+            }
+            {
+                StageTimer t(s, ST_TILE_SCATTER);
+                GFT_STAGE(s, cfg, "tile_scatter_far", gft_launch_tile_scatter(s, *cfg, g, im, b, cap, cut_bits, 1, (int64_t)cap));
+            }
+        }
         {
             StageTimer t(s, ST_TILE_SORT);
             GFT_STAGE(s, cfg, "tile_tail", gft_launch_tile_tail(s, *cfg, g, im, b, cap));
@@ -425,7 +461,7 @@ extern "C" int gft_forward_preprocess(void* hip_stream, const gft_config* cfg, c
     ImgView im = gft_img_view(io->img, L);
     uint32_t* mail_dev; volatile uint32_t* mail_host; uint32_t seq;
     if (mailbox_acquire(&mail_dev, &mail_host, &seq)) return 1;
-    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq)) return 1;
+    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq, GFT_NO_CUT)) return 1;
     // the one blocking read of the forward (reference rasterizer_impl.cu:311)
     uint32_t host[GFT_CTRL_WORDS];
     if (mailbox_wait(s, mail_host, seq, host)) return 1;
@@ -438,7 +474,7 @@ extern "C" int gft_forward_preprocess(void* hip_stream, const gft_config* cfg, c
 
 // ---- forward, stage 2 -----------------------------------------------------------
 extern "C" int gft_forward_render(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
-                                  int64_t binning_instances, int64_t max_tile_list)
+                                  int64_t binning_instances, int64_t max_tile_list, float depth_cut)
 {
     if (check_config(cfg)) return 1;
     if (!io) return gft_fail("gft_forward_render: io is NULL");
@@ -454,25 +490,27 @@ extern "C" int gft_forward_render(void* hip_stream, const gft_config* cfg, const
     ImgView im = gft_img_view(io->img, L);
     BinView b = gft_bin_view(io->binning, L);
     if (cfg->P == 0) {
-        // no stage 1 ran: every tile list is empty
+        // no stage 1 ran: every tile list is empty, all totals are zero
         const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
         GFT_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s));
+        GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, GFT_CTRL_WORDS * sizeof(uint32_t), s));
     }
-    return enqueue_stage2(s, cfg, io, g, im, b, R > 0, max_tile_list, cfg->P > 0, (uint32_t)R);
+    // the cut stage 1 counted with: the near-slab ranges it produced only hold those instances
+    const uint32_t cut_bits = (lazy_sort_enabled() && R > 0) ? cut_bits_of(depth_cut) : GFT_NO_CUT;
+    return enqueue_stage2(s, cfg, io, g, im, b, R > 0, max_tile_list, cfg->P > 0, (uint32_t)R, cut_bits, R);
 }
 
 // ---- forward, one call ------------------------------------------------------------
 extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
-                           int64_t binning_instances, int64_t max_tile_list_hint, int64_t* num_rendered,
-                           int64_t* max_tile_list)
+                           const gft_forward_hints* hints, gft_forward_report* report)
 {
-    if (max_tile_list) *max_tile_list = 0;
+    if (report) memset(report, 0, sizeof(*report));
     if (check_config(cfg)) return 1;
-    if (!io || !num_rendered) return gft_fail("gft_forward: NULL argument");
-    *num_rendered = 0;
+    if (!io || !hints || !report) return gft_fail("gft_forward: NULL argument");
     if (check_stage2(io, "gft_forward")) return 1;
+    const int64_t binning_instances = hints->binning_instances;
     if (binning_instances < 0 || binning_instances > 0xffffffffll) return gft_fail("gft_forward: bad instance count");
-    if (cfg->P == 0) return gft_forward_render(hip_stream, cfg, io, 0, 0);
+    if (cfg->P == 0) return gft_forward_render(hip_stream, cfg, io, 0, 0, 0.0f);
     if (check_stage1(cfg, io, "gft_forward")) return 1;
     if (binning_instances > 0 && !io->binning) return gft_fail("gft_forward: binning buffer is NULL");
     hipStream_t s = (hipStream_t)hip_stream;
@@ -483,20 +521,26 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     BinView b = gft_bin_view(io->binning, L);
     uint32_t* mail_dev; volatile uint32_t* mail_host; uint32_t seq;
     if (mailbox_acquire(&mail_dev, &mail_host, &seq)) return 1;
-    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq)) return 1;
+    // lazy binning needs the flag / resume protocol of the lazy sort and a binning buffer to work with
+    const uint32_t cut_bits = (lazy_sort_enabled() && binning_instances > 0) ? cut_bits_of(hints->depth_cut) : GFT_NO_CUT;
+    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq, cut_bits)) return 1;
     // stage 2 is queued before R is known; its kernels check R against the buffer themselves
     const uint32_t cap = (uint32_t)binning_instances;
-    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, max_tile_list_hint, true, cap)) return 1;
+    const int64_t expect0 = (cut_bits != GFT_NO_CUT && hints->near_instances > 0) ? hints->near_instances : binning_instances;
+    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, cap, cut_bits, expect0)) return 1;
     uint32_t host[GFT_CTRL_WORDS];
     if (mailbox_wait(s, mail_host, seq, host)) return 1;
     if (host[GFT_CTRL_FLAGS] & 1u)
         return gft_fail("Point is filtered although prefiltered is set. This shouldn't happen!");
-    *num_rendered = (int64_t)host[GFT_CTRL_TOTAL];
-    if (max_tile_list) *max_tile_list = (int64_t)host[GFT_CTRL_MAXCNT];
+    report->num_rendered = (int64_t)host[GFT_CTRL_TOTAL];
+    report->max_tile_list = (int64_t)host[GFT_CTRL_MAXCNT];
+    report->near_instances = (int64_t)host[GFT_CTRL_TOTAL0];
+    memcpy(&report->depth_cut_next, &host[GFT_CTRL_CUTNEXT], 4);
+    if (host[GFT_CTRL_CUTNEXT] >= GFT_NO_CUT || !lazy_bin_enabled()) report->depth_cut_next = 0.0f;    // "bin everything"
     // The hint said "no tile list longer than the short-sort limit" and the frame has one: its
     // tiles were rendered unsorted.  Sort them and render again (the contributing-pixel counters
     // are the only accumulated output).
-    if (!lazy_sort_enabled() && max_tile_list_hint > 0 && max_tile_list_hint <= GFT_SHORT_LIST_MAX &&
+    if (!lazy_sort_enabled() && hints->max_tile_list > 0 && hints->max_tile_list <= GFT_SHORT_LIST_MAX &&
         host[GFT_CTRL_MAXCNT] > GFT_SHORT_LIST_MAX && host[GFT_CTRL_TOTAL] <= cap && binning_instances > 0) {
         GFT_CHECK_HIP(hipMemsetAsync(io->pixels, 0, (size_t)cfg->P * sizeof(float), s));
         GFT_STAGE(s, cfg, "tile_sort_long", gft_launch_tile_sort_long(s, *cfg, im, b, cap));

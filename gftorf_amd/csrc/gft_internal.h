@@ -44,7 +44,10 @@ struct ImgView {
     uint2* ranges;        // [T]
     uint32_t* tile_max;   // [T]
     uint32_t* ctrl;       // [8], directly followed by tile_cnt (one memset clears both)
-    uint32_t* tile_cnt;   // [T]
+    uint32_t* tile_cnt;   // [T]  instances per tile of the near slab (all instances without a depth cut)
+    uint32_t* tile_cnt1;  // [T]  lazy binning: instances per flagged tile of the far slab
+    uint32_t* dhist;      // [GFT_DHIST_BINS] instances per log-depth bin (picks the next frame's depth cut)
+    uint2* ranges1;       // [T]  lazy binning: far-slab segment of every tile (valid once a quadrant was flagged)
     uint32_t* tile_cursor;// [T]
     uint32_t* tile_order; // [T] tiles by backward weight, heaviest first (written by the backward)
     uint32_t* front_len;  // [T] lazy sort: length of the sorted head of the tile's id list
@@ -64,7 +67,14 @@ struct BinView {
 #define GFT_CTRL_NFLAG 4     // lazy sort: number of flagged quadrants
 #define GFT_CTRL_DONE 3      // finished k_tile_count workgroups (ticket for the fused scan)
 #define GFT_CTRL_SEQ 3       // host mailbox only: sequence number, written last
-#define GFT_CTRL_WORDS 8
+#define GFT_CTRL_TOTAL0 5    // lazy binning: instances of the near slab (view z <= depth cut), binned up front
+#define GFT_CTRL_CUTNEXT 6   // lazy binning: float bits of the depth cut suggested for the next frame of this kind
+#define GFT_CTRL_DONE1 7     // finished workgroups of the far-slab count (ticket for its scan)
+#define GFT_CTRL_TOTAL1 8    // lazy binning: far-slab instances binned for the flagged tiles
+#define GFT_CTRL_WORDS 16
+#define GFT_DHIST_BINS 256   // log-spaced depth bins between near_n and far_n
+#define GFT_NEAR_SLAB_PER_TILE 896u   // wanted mean list length of the near slab
+#define GFT_NO_CUT 0x7f800000u        // +inf: every instance belongs to the near slab
 #define GFT_BLOCKHIST_TILES 2048
 // binning workgroup shape (k_binning.hip): 16 waves per workgroup keep one CU busy on their own
 #ifndef BIN_THREADS
@@ -93,10 +103,12 @@ int gft_fail(const char* fmt, ...);
 // ---- stage launchers (each enqueues on `s`, returns hipError_t) -----------
 hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
                                      const GeomView& g, const ImgView& im);
+// pass 0: near slab (view z <= cut; everything with GFT_NO_CUT) + depth histogram + scan + mailbox;
+// pass 1: far slab of the tiles with a flagged quadrant (leaves at once when no quadrant was flagged)
 hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                 uint32_t* mail, uint32_t seq);
+                                 uint32_t* mail, uint32_t seq, uint32_t cut_bits, int pass, uint32_t cap);
 hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                   const BinView& b, uint32_t cap);
+                                   const BinView& b, uint32_t cap, uint32_t cut_bits, int pass, int64_t expect);
 hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_tile_list, const ImgView& im,
                                 const BinView& b, uint32_t cap, float* clear, size_t clear_bytes);
 hipError_t gft_launch_tile_front(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b, uint32_t cap,

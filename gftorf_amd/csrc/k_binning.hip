@@ -38,11 +38,35 @@ __device__ __forceinline__ int rotated_tile(int i, int T)
     return t >= T ? t - T : t;
 }
 
-// Exclusive scan of tile_cnt by one workgroup (the last one of k_tile_count): ranges, zeroed
-// cursors, totals into ctrl and into the host mailbox (pinned memory the host polls instead of
-// a blocking copy; sequence number written last with release / system scope).
-__device__ void tile_scan_block(int T, const uint32_t* tile_cnt, uint2* __restrict__ ranges,
-                                uint32_t* __restrict__ cursor, uint32_t* ctrl, uint32_t* mail, uint32_t seq)
+// ---- lazy binning ---------------------------------------------------------------------------
+// A pixel stops reading its tile list once its transmittance is below 1e-4, so in a dense frame most
+// instances are never read (metric frame: 3.6 M instances, 0.6 M up to the deepest contributor of every
+// tile; 5 M @ 1080p: 75 M and 2 M).  With a depth cut only the NEAR slab (view z <= cut) is counted,
+// scattered and sorted up front; a quadrant that runs out of near-slab entries with unsaturated pixels is
+// flagged (the flag of the lazy sort), and only then is the FAR slab binned, for the tiles that have a
+// flagged quadrant (count pass 1, scatter pass 1, k_tile_tail), and those quadrants resume.  Every key of
+// the near slab is smaller than every key of the far slab, so a tile's list is its sorted near segment
+// followed by its sorted far segment: the same order, the same arithmetic, bit-identical results.  The cut
+// is any float; a good one comes from the previous frame: pass 0 also histograms the instances over 256
+// log-spaced depth bins and suggests the cut that puts GFT_NEAR_SLAB_PER_TILE instances per tile into the
+// near slab (no cut when the frame has less than 3 x that).
+struct DepthBins {
+    float inv_near;      // 1 / near_n
+    float scale;         // GFT_DHIST_BINS / log2(far_n / near_n)
+    float near_n;
+};
+
+__device__ __forceinline__ int depth_bin(uint32_t dbits, const DepthBins& db)
+{
+    const float b = __log2f(__uint_as_float(dbits) * db.inv_near) * db.scale;
+    const int i = (int)b;
+    return i < 0 ? 0 : (i >= GFT_DHIST_BINS ? GFT_DHIST_BINS - 1 : i);
+}
+
+// Exclusive scan of tile_cnt by one workgroup (the last one of k_tile_count): ranges (offset by `base`), zeroed
+// cursors; returns the total and the longest list to thread 0.
+__device__ void tile_scan_block(int T, const uint32_t* tile_cnt, uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
+                                uint32_t base, uint32_t& total_out, uint32_t& max_out)
 {
     constexpr int NW = BIN_THREADS / 64;
     __shared__ uint32_t wtot[NW];
@@ -52,8 +76,8 @@ __device__ void tile_scan_block(int T, const uint32_t* tile_cnt, uint2* __restri
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t vmax = 0;
-    for (int base = 0; base < T; base += BIN_THREADS) {
-        const int i = base + threadIdx.x;
+    for (int b0 = 0; b0 < T; b0 += BIN_THREADS) {
+        const int i = b0 + threadIdx.x;
         // counters were accumulated by atomics of other workgroups (other XCDs): device-scope load
         const uint32_t v = (i < T) ? __hip_atomic_load(&tile_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         vmax = max(vmax, v);
@@ -69,7 +93,7 @@ __device__ void tile_scan_block(int T, const uint32_t* tile_cnt, uint2* __restri
         for (int w = 0; w < wave; w++) woff += wtot[w];
         const uint32_t carry = carry_s;
         if (i < T) {
-            const uint32_t first = carry + woff + x - v;
+            const uint32_t first = base + carry + woff + x - v;
             ranges[i] = v ? make_uint2(first, first + v) : make_uint2(0u, 0u);   // untouched tiles: (0,0) like the reference
             cursor[i] = 0;
         }
@@ -81,57 +105,111 @@ __device__ void tile_scan_block(int T, const uint32_t* tile_cnt, uint2* __restri
     for (int d = 32; d > 0; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
     if (lane == 0) wmax[wave] = vmax;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t m = 0;
+    uint32_t m = 0;
+    if (threadIdx.x == 0)
         for (int w = 0; w < NW; w++) m = max(m, wmax[w]);
-        const uint32_t total = carry_s;
-        const uint32_t flags = __hip_atomic_load(&ctrl[GFT_CTRL_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ctrl[GFT_CTRL_TOTAL] = total;
-        ctrl[GFT_CTRL_MAXCNT] = m;
-        if (mail) {
-            mail[GFT_CTRL_TOTAL] = total;
-            mail[GFT_CTRL_FLAGS] = flags;
-            mail[GFT_CTRL_MAXCNT] = m;
-            __hip_atomic_store(&mail[GFT_CTRL_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    total_out = carry_s;
+    max_out = m;
 }
 
-template <bool USE_LDS>
-__global__ __launch_bounds__(BIN_THREADS) void k_tile_count(int P, int gx, int T, const ushort4* __restrict__ rect,
-                                                          uint32_t* tile_cnt, uint2* __restrict__ ranges,
-                                                          uint32_t* __restrict__ cursor, uint32_t* ctrl,
-                                                          uint32_t* mail, uint32_t seq, uint16_t* __restrict__ blockhist)
+struct CountArgs {
+    int P, gx, T;
+    int items;                      // Gaussians per thread (BIN_ITEMS, more when a depth cut leaves few of them to bin)
+    const ushort4* __restrict__ rect;
+    const float* __restrict__ depth;
+    uint32_t cut_bits;              // near slab: depth bits <= cut_bits
+    uint32_t* tile_cnt;             // pass 0: near-slab counters; pass 1: far-slab counters
+    uint2* __restrict__ ranges;     // pass 0: ranges; pass 1: ranges1
+    uint32_t* __restrict__ cursor;
+    uint32_t* ctrl;
+    uint32_t* mail; uint32_t seq;   // pass 0 only
+    uint16_t* __restrict__ blockhist;
+    uint32_t* dhist;                // pass 0 only
+    DepthBins db;
+    uint32_t target;                // wanted near-slab instances of the next frame
+    const uint32_t* __restrict__ unit_flag;   // pass 1 only
+    uint32_t cap;
+};
+
+// tiles with a flagged quadrant as a bit table in LDS (pass 1 of count and scatter)
+__device__ __forceinline__ void load_flagged_tiles(uint32_t* bits, int T, const uint32_t* __restrict__ unit_flag)
+{
+    const int words = (T + 31) >> 5;
+    for (int w = threadIdx.x; w < words; w += BIN_THREADS) bits[w] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) {
+        const uint4 f = reinterpret_cast<const uint4*>(unit_flag)[t];
+        if (f.x | f.y | f.z | f.w) atomicOr(&bits[t >> 5], 1u << (t & 31));
+    }
+    __syncthreads();
+}
+
+template <bool USE_LDS, int PASS>
+__global__ __launch_bounds__(BIN_THREADS) void k_tile_count(CountArgs a)
 {
     extern __shared__ uint32_t hist[];
     __shared__ uint32_t s_last;
+    __shared__ uint32_t s_dh[GFT_DHIST_BINS];
+    __shared__ uint32_t s_flag[BIN_LDS_MAX_TILES / 32];
     const int tid = threadIdx.x;
+    const int T = a.T, gx = a.gx;
+    if (PASS == 1) {
+        // nothing was flagged, the binning buffer is too small, or the far slab is empty: every workgroup leaves
+        if (a.ctrl[GFT_CTRL_NFLAG] == 0u || a.ctrl[GFT_CTRL_TOTAL] > a.cap || a.ctrl[GFT_CTRL_TOTAL] == a.ctrl[GFT_CTRL_TOTAL0])
+            return;
+        if (USE_LDS) load_flagged_tiles(s_flag, T, a.unit_flag);
+    }
     if (USE_LDS) {
         for (int i = tid; i < T; i += BIN_THREADS) hist[i] = 0;
-        __syncthreads();
     }
-    const int base = blockIdx.x * BIN_CHUNK;
-#pragma unroll 4
-    for (int k = 0; k < BIN_ITEMS; k++) {
-        const int idx = base + k * BIN_THREADS + tid;
-        if (idx < P) {
-            const ushort4 r = rect[idx];
+    if (PASS == 0 && tid < GFT_DHIST_BINS) s_dh[tid] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * (BIN_THREADS * a.items);
+    // four Gaussians per trip, their rectangle and depth loads issued together (a.items is a multiple of 4)
+    for (int k0 = 0; k0 < a.items; k0 += 4) {
+        ushort4 r4[4];
+        uint32_t d4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = base + (k0 + u) * BIN_THREADS + tid;
+            const bool in = idx < a.P;
+            r4[u] = in ? a.rect[idx] : make_ushort4(0, 0, 0, 0);
+            d4[u] = in ? __float_as_uint(a.depth[idx]) : 0u;       // (not written for culled Gaussians, not used for them either)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const ushort4 r = r4[u];
+            const uint32_t tiles = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
+            if (tiles == 0u) continue;
+            const uint32_t d = d4[u];
+            if (PASS == 0) atomicAdd(&s_dh[depth_bin(d, a.db)], tiles);
+            if ((PASS == 0) != (d <= a.cut_bits)) continue;          // pass 0: near slab, pass 1: far slab
             for (int y = r.y; y < r.w; y++)
                 for (int x = r.x; x < r.z; x++) {
-                    if (USE_LDS) atomicAdd(&hist[y * gx + x], 1u);
-                    else atomicAdd(&tile_cnt[y * gx + x], 1u);
+                    const int t = y * gx + x;
+                    if (PASS == 1) {
+                        const bool fl = USE_LDS ? ((s_flag[t >> 5] >> (t & 31)) & 1u) != 0u
+                                                : (a.unit_flag[4 * t] | a.unit_flag[4 * t + 1] | a.unit_flag[4 * t + 2] | a.unit_flag[4 * t + 3]) != 0u;
+                        if (!fl) continue;
+                    }
+                    if (USE_LDS) atomicAdd(&hist[t], 1u);
+                    else atomicAdd(&a.tile_cnt[t], 1u);
                 }
         }
     }
+    __syncthreads();
     if (USE_LDS) {
-        __syncthreads();
         for (int i = tid; i < T; i += BIN_THREADS) {
             const int t = rotated_tile(i, T);
             const uint32_t h = hist[t];
-            if (h) atomicAdd(&tile_cnt[t], h);
+            if (h) atomicAdd(&a.tile_cnt[t], h);
             // kept for the scatter, which would otherwise walk the rectangles a second time to count
-            if (blockhist) blockhist[(size_t)blockIdx.x * GFT_BLOCKHIST_TILES + t] = (uint16_t)h;
+            if (a.blockhist) a.blockhist[(size_t)blockIdx.x * GFT_BLOCKHIST_TILES + t] = (uint16_t)h;
         }
+    }
+    if (PASS == 0 && tid < GFT_DHIST_BINS) {
+        const uint32_t h = s_dh[tid];
+        if (h) atomicAdd(&a.dhist[tid], h);
     }
     // The workgroup that draws the last ticket scans.  Every counter update above is a
     // device-scope atomic, complete once vmcnt drains, and the scan reads the counters with
@@ -139,10 +217,48 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_count(int P, int gx, int T
     // L2 lines the preprocess kernel just wrote, ~50 us) is needed for that hand-over.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&ctrl[GFT_CTRL_DONE], 1u) == gridDim.x - 1 ? 1u : 0u;
+    if (tid == 0) s_last = atomicAdd(&a.ctrl[PASS == 0 ? GFT_CTRL_DONE : GFT_CTRL_DONE1], 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
-    tile_scan_block(T, tile_cnt, ranges, cursor, ctrl, mail, seq);
+    uint32_t total = 0, longest = 0;
+    if (PASS == 1) {
+        // far-slab segments follow the near slab in the key / id arrays
+        tile_scan_block(T, a.tile_cnt, a.ranges, a.cursor, a.ctrl[GFT_CTRL_TOTAL0], total, longest);
+        if (tid == 0) a.ctrl[GFT_CTRL_TOTAL1] = total;
+        return;
+    }
+    tile_scan_block(T, a.tile_cnt, a.ranges, a.cursor, 0u, total, longest);
+    // depth histogram: R = all instances; the cut for the next frame = upper edge of the first bin at which the
+    // running count reaches the target
+    __shared__ uint32_t s_cum[GFT_DHIST_BINS];
+    if (tid < GFT_DHIST_BINS) s_cum[tid] = __hip_atomic_load(&a.dhist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0, cut_bin = GFT_DHIST_BINS;
+        for (int b = 0; b < GFT_DHIST_BINS; b++) {
+            run += s_cum[b];
+            if (cut_bin == GFT_DHIST_BINS && run >= a.target) cut_bin = (uint32_t)b;
+        }
+        const uint32_t R = run;
+        uint32_t cut_next = GFT_NO_CUT;
+        // (a cut pays when the near slab is a small part of the frame: with R below 3 x the target too many
+        // quadrants outlive the near slab and the second pass costs more than the first one saved)
+        if (a.target > 0u && R / 3u >= a.target && cut_bin + 1u < GFT_DHIST_BINS)
+            cut_next = __float_as_uint(a.db.near_n * exp2f((float)(cut_bin + 1u) / a.db.scale));
+        const uint32_t flags = __hip_atomic_load(&a.ctrl[GFT_CTRL_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.ctrl[GFT_CTRL_TOTAL] = R;
+        a.ctrl[GFT_CTRL_TOTAL0] = total;
+        a.ctrl[GFT_CTRL_MAXCNT] = longest;
+        a.ctrl[GFT_CTRL_CUTNEXT] = cut_next;
+        if (a.mail) {
+            a.mail[GFT_CTRL_TOTAL] = R;
+            a.mail[GFT_CTRL_FLAGS] = flags;
+            a.mail[GFT_CTRL_MAXCNT] = longest;
+            a.mail[GFT_CTRL_TOTAL0] = total;
+            a.mail[GFT_CTRL_CUTNEXT] = cut_next;
+            __hip_atomic_store(&a.mail[GFT_CTRL_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // MODE 0: global cursors only (tile table too large for LDS)
@@ -153,17 +269,37 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_count(int P, int gx, int T
 //         key array does not stay in the 4 MB L2s: 100 MB of write-backs for 29 MB of keys
 //         (rocprofv3 WRITE_SIZE).  A workgroup with more instances than `stage_cap` writes
 //         directly (MODE 1 behaviour).
-template <int MODE>
-__global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int T, const ushort4* __restrict__ rect,
-                                                            const float* __restrict__ depth,
-                                                            const uint2* __restrict__ ranges,
-                                                            uint32_t* __restrict__ cursor,
-                                                            uint64_t* __restrict__ keys,
-                                                            const uint32_t* __restrict__ ctrl, uint32_t cap,
-                                                            uint32_t stage_cap, const uint16_t* __restrict__ blockhist)
+// PASS 0: near slab (depth bits <= cut); PASS 1: far slab of the flagged tiles (see lazy binning above)
+struct ScatterArgs {
+    int P, gx, T;
+    int items;                      // as in the count pass (the per-workgroup histograms it kept are reused)
+    const ushort4* __restrict__ rect;
+    const float* __restrict__ depth;
+    const uint2* __restrict__ ranges;
+    uint32_t* __restrict__ cursor;
+    uint64_t* __restrict__ keys;
+    const uint32_t* __restrict__ ctrl;
+    uint32_t cap, stage_cap;
+    const uint16_t* __restrict__ blockhist;
+    uint32_t cut_bits;
+    const uint32_t* __restrict__ unit_flag;
+};
+
+template <int MODE, int PASS>
+__global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(ScatterArgs a)
 {
     extern __shared__ uint32_t sh[];
-    if (ctrl[GFT_CTRL_TOTAL] > cap) return;      // binning buffer too small: the host re-runs stage 2
+    __shared__ uint32_t s_flag[BIN_LDS_MAX_TILES / 32];
+    if (a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;      // binning buffer too small: the host re-runs stage 2
+    const int T = a.T, gx = a.gx, P = a.P;
+    if (PASS == 1) {
+        if (a.ctrl[GFT_CTRL_NFLAG] == 0u || a.ctrl[GFT_CTRL_TOTAL] == a.ctrl[GFT_CTRL_TOTAL0] || a.ctrl[GFT_CTRL_TOTAL1] == 0u) return;
+        if (MODE >= 1) load_flagged_tiles(s_flag, T, a.unit_flag);
+    }
+    auto flagged = [&](int t) -> bool {
+        if (MODE >= 1) return ((s_flag[t >> 5] >> (t & 31)) & 1u) != 0u;
+        return (a.unit_flag[4 * t] | a.unit_flag[4 * t + 1] | a.unit_flag[4 * t + 2] | a.unit_flag[4 * t + 3]) != 0u;
+    };
     uint32_t* cnt = sh;          // [T] instances of this block per tile, then running slot
     uint32_t* first = sh + T;    // [T] global position of this block's chunk in the tile segment
     uint32_t* lstart = sh + 2 * T;                                   // [T] MODE 2: chunk start in the LDS stage
@@ -171,22 +307,27 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int
     __shared__ uint32_t s_wave_tot[BIN_THREADS / 64];
     __shared__ uint32_t s_block_tot;
     const int tid = threadIdx.x;
-    const int base = blockIdx.x * BIN_CHUNK;
+    const int base = blockIdx.x * (BIN_THREADS * a.items);
     bool staged = false;
     if (MODE >= 1) {
-        if (blockhist) {
+        if (a.blockhist) {
             // the count kernel kept this workgroup's histogram
-            for (int i = tid; i < T; i += BIN_THREADS) cnt[i] = blockhist[(size_t)blockIdx.x * GFT_BLOCKHIST_TILES + i];
+            for (int i = tid; i < T; i += BIN_THREADS) cnt[i] = a.blockhist[(size_t)blockIdx.x * GFT_BLOCKHIST_TILES + i];
         } else {
             for (int i = tid; i < T; i += BIN_THREADS) cnt[i] = 0;
             __syncthreads();
 #pragma unroll 4
-            for (int k = 0; k < BIN_ITEMS; k++) {
+            for (int k = 0; k < a.items; k++) {
                 const int idx = base + k * BIN_THREADS + tid;
                 if (idx < P) {
-                    const ushort4 r = rect[idx];
+                    const ushort4 r = a.rect[idx];
+                    if (!(r.z > r.x && r.w > r.y)) continue;
+                    if ((PASS == 0) != (__float_as_uint(a.depth[idx]) <= a.cut_bits)) continue;
                     for (int y = r.y; y < r.w; y++)
-                        for (int x = r.x; x < r.z; x++) atomicAdd(&cnt[y * gx + x], 1u);
+                        for (int x = r.x; x < r.z; x++) {
+                            if (PASS == 1 && !flagged(y * gx + x)) continue;
+                            atomicAdd(&cnt[y * gx + x], 1u);
+                        }
                 }
             }
         }
@@ -214,38 +355,49 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int
             for (int k = 0; k < K; k++)
                 if (t0 + k < T) { lstart[t0 + k] = run; run += cnt[t0 + k]; }
             __syncthreads();
-            staged = s_block_tot <= stage_cap;
+            staged = s_block_tot <= a.stage_cap;
         }
         for (int i = tid; i < T; i += BIN_THREADS) {
             const int t = rotated_tile(i, T);
             const uint32_t c = cnt[t];
             if (c) {
-                first[t] = ranges[t].x + atomicAdd(&cursor[t], c);
+                first[t] = a.ranges[t].x + atomicAdd(&a.cursor[t], c);
                 cnt[t] = 0;
             }
         }
         __syncthreads();
     }
-#pragma unroll 2
-    for (int k = 0; k < BIN_ITEMS; k++) {
-        const int idx = base + k * BIN_THREADS + tid;
-        if (idx < P) {
-            const ushort4 r = rect[idx];
-            if (r.z > r.x && r.w > r.y) {
-                const uint64_t key = ((uint64_t)__float_as_uint(depth[idx]) << 32) | (uint32_t)idx;
-                for (int y = r.y; y < r.w; y++)
-                    for (int x = r.x; x < r.z; x++) {
-                        const int t = y * gx + x;
-                        if (MODE == 2 && staged) {
-                            stage[lstart[t] + atomicAdd(&cnt[t], 1u)] = key;
-                        } else {
-                            uint32_t pos;
-                            if (MODE >= 1) pos = first[t] + atomicAdd(&cnt[t], 1u);
-                            else pos = ranges[t].x + atomicAdd(&cursor[t], 1u);
-                            keys[pos] = key;
-                        }
+    for (int k0 = 0; k0 < a.items; k0 += 2) {
+        ushort4 r2[2];
+        uint32_t d2[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int idx = base + (k0 + u) * BIN_THREADS + tid;
+            const bool in = idx < P;
+            r2[u] = in ? a.rect[idx] : make_ushort4(0, 0, 0, 0);
+            d2[u] = in ? __float_as_uint(a.depth[idx]) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const ushort4 r = r2[u];
+            if (!(r.z > r.x && r.w > r.y)) continue;
+            const uint32_t d = d2[u];
+            if ((PASS == 0) != (d <= a.cut_bits)) continue;
+            const uint32_t idx = (uint32_t)(base + (k0 + u) * BIN_THREADS + tid);
+            const uint64_t key = ((uint64_t)d << 32) | idx;
+            for (int y = r.y; y < r.w; y++)
+                for (int x = r.x; x < r.z; x++) {
+                    const int t = y * gx + x;
+                    if (PASS == 1 && !flagged(t)) continue;
+                    if (MODE == 2 && staged) {
+                        stage[lstart[t] + atomicAdd(&cnt[t], 1u)] = key;
+                    } else {
+                        uint32_t pos;
+                        if (MODE >= 1) pos = first[t] + atomicAdd(&cnt[t], 1u);
+                        else pos = a.ranges[t].x + atomicAdd(&a.cursor[t], 1u);
+                        a.keys[pos] = key;
                     }
-            }
+                }
         }
     }
     if (MODE == 2 && staged) {
@@ -256,7 +408,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_scatter(int P, int gx, int
             const uint32_t c = cnt[t];
             if (c == 0) continue;
             const uint32_t src = lstart[t], dst = first[t];
-            for (uint32_t i = lane; i < c; i += 64) keys[dst + i] = stage[src + i];
+            for (uint32_t i = lane; i < c; i += 64) a.keys[dst + i] = stage[src + i];
         }
     }
 }
@@ -705,10 +857,60 @@ __global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_sort_big(int T, const
     }
 }
 
-// Sorts the unsorted tail of the id list of every tile that has a flagged quadrant (lazy sort,
-// see k_tile_front): keys are rebuilt from the ids (depth gather), sorted by 1024 threads with
-// the register-blocked network in LDS (up to 16384 keys) or in place in the key array beyond.
-__global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_tail(int T, const uint2* __restrict__ ranges, uint64_t* keys,
+// Sorts one segment of nt list entries starting at `first` into point_list, by 1024 threads with the register-blocked
+// network in LDS (up to 16384 keys) or in place in the key array beyond.  FROM_IDS: the segment holds unsorted ids in
+// point_list (the tail k_tile_front left) and the keys are rebuilt by a depth gather; else it holds scattered keys.
+template <bool FROM_IDS>
+__device__ __forceinline__ void tail_sort_segment(uint32_t first, uint32_t nt, uint64_t* keys, uint32_t* __restrict__ point_list,
+                                                  const float* __restrict__ depth, uint64_t* sk, int tid)
+{
+    if (nt == 0u) return;
+    auto key_of = [&](uint32_t i) -> uint64_t {
+        if (!FROM_IDS) return keys[first + i];
+        const uint32_t id = point_list[first + i];
+        return ((uint64_t)__float_as_uint(depth[id]) << 32) | id;
+    };
+    if (nt <= SORT_LDS_LARGE_KEYS) {
+        if (nt <= 1024u) {
+            const uint32_t npad = next_pow2(nt < 2u ? 2u : nt);
+            for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) sk[i] = key_of(i);
+            __syncthreads();
+            bitonic_ascending<SORT_BIG_THREADS>(nt, npad, tid, [&](uint32_t i) { return sk[i]; },
+                                                [&](uint32_t i, uint64_t v) { sk[i] = v; }, [] { __syncthreads(); });
+            for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) point_list[first + i] = (uint32_t)sk[i];
+        } else {
+            const uint32_t npad = nt <= 4096u ? 4096u : (nt <= 8192u ? 8192u : 16384u);
+            // all keys are built before any id is overwritten (the ids live in point_list)
+            for (uint32_t i = tid; i < npad; i += SORT_BIG_THREADS) sk[sort_slot(i)] = i < nt ? key_of(i) : ~0ull;
+            __syncthreads();
+            if (npad == 4096u) bitonic_blocked<2, 10>(sk, tid);
+            else if (npad == 8192u) bitonic_blocked<3, 10>(sk, tid);
+            else bitonic_blocked<4, 10>(sk, tid);
+            for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) point_list[first + i] = (uint32_t)sk[sort_slot(i)];
+        }
+        __syncthreads();
+    } else {
+        uint64_t* seg = keys + first;                       // (FROM_IDS: the scattered keys are no longer needed)
+        if (FROM_IDS) {
+            for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) seg[i] = key_of(i);
+        }
+        __threadfence_block();
+        __syncthreads();
+        const uint32_t npad = next_pow2(nt);
+        bitonic_ascending<SORT_BIG_THREADS>(
+            nt, npad, tid,
+            [&](uint32_t i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
+            [&](uint32_t i, uint64_t v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
+            [] { __threadfence_block(); __syncthreads(); });
+        for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) point_list[first + i] = (uint32_t)seg[i];
+        __syncthreads();
+    }
+}
+
+// For every tile that has a flagged quadrant: sorts the unsorted tail of its near-slab id list (lazy sort, see
+// k_tile_front) and, when the far slab was binned for it (lazy binning), its far-slab segment.
+__global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_tail(int T, const uint2* __restrict__ ranges,
+                                                                const uint2* __restrict__ ranges1, uint64_t* keys,
                                                                 uint32_t* __restrict__ point_list,
                                                                 const float* __restrict__ depth,
                                                                 const uint32_t* __restrict__ front_len,
@@ -719,50 +921,17 @@ __global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_tail(int T, const uin
     uint64_t* sk = sk_dyn;
     if (ctrl[GFT_CTRL_TOTAL] > cap) return;
     if (ctrl[GFT_CTRL_NFLAG] == 0u) return;
+    const bool far = ctrl[GFT_CTRL_TOTAL1] != 0u;       // count pass 1 ran and found far-slab instances
     const int tid = threadIdx.x;
     for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
         const uint4 f = reinterpret_cast<const uint4*>(unit_flag)[tile];
         if ((f.x | f.y | f.z | f.w) == 0u) continue;           // uniform per workgroup
         const uint2 r = ranges[tile];
         const uint32_t kf = front_len[tile];
-        const uint32_t first = r.x + kf, nt = (r.y - r.x) - kf;
-        if (nt == 0u) continue;
-        auto key_of = [&](uint32_t i) {
-            const uint32_t id = point_list[first + i];
-            return ((uint64_t)__float_as_uint(depth[id]) << 32) | id;
-        };
-        if (nt <= SORT_LDS_LARGE_KEYS) {
-            if (nt <= 1024u) {
-                const uint32_t npad = next_pow2(nt < 2u ? 2u : nt);
-                for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) sk[i] = key_of(i);
-                __syncthreads();
-                bitonic_ascending<SORT_BIG_THREADS>(nt, npad, tid, [&](uint32_t i) { return sk[i]; },
-                                                    [&](uint32_t i, uint64_t v) { sk[i] = v; }, [] { __syncthreads(); });
-                for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) point_list[first + i] = (uint32_t)sk[i];
-            } else {
-                const uint32_t npad = nt <= 4096u ? 4096u : (nt <= 8192u ? 8192u : 16384u);
-                // all keys are built before any id is overwritten (the ids live in point_list)
-                for (uint32_t i = tid; i < npad; i += SORT_BIG_THREADS) sk[sort_slot(i)] = i < nt ? key_of(i) : ~0ull;
-                __syncthreads();
-                if (npad == 4096u) bitonic_blocked<2, 10>(sk, tid);
-                else if (npad == 8192u) bitonic_blocked<3, 10>(sk, tid);
-                else bitonic_blocked<4, 10>(sk, tid);
-                for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) point_list[first + i] = (uint32_t)sk[sort_slot(i)];
-            }
-            __syncthreads();
-        } else {
-            uint64_t* seg = keys + first;                       // the scattered keys are no longer needed
-            for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) seg[i] = key_of(i);
-            __threadfence_block();
-            __syncthreads();
-            const uint32_t npad = next_pow2(nt);
-            bitonic_ascending<SORT_BIG_THREADS>(
-                nt, npad, tid,
-                [&](uint32_t i) { return __hip_atomic_load(&seg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
-                [&](uint32_t i, uint64_t v) { __hip_atomic_store(&seg[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
-                [] { __threadfence_block(); __syncthreads(); });
-            for (uint32_t i = tid; i < nt; i += SORT_BIG_THREADS) point_list[first + i] = (uint32_t)seg[i];
-            __syncthreads();
+        tail_sort_segment<true>(r.x + kf, (r.y - r.x) - kf, keys, point_list, depth, sk, tid);
+        if (far) {
+            const uint2 r1 = ranges1[tile];
+            tail_sort_segment<false>(r1.x, r1.y - r1.x, keys, point_list, depth, sk, tid);
         }
     }
 }
@@ -773,52 +942,89 @@ __global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_tail(int T, const uin
 #define SORT_LDS_LARGE 16384u     // 128 KB of LDS (+ 4 KB of bank padding)
 #define SORT_LDS_LARGE_BYTES (SORT_SLOTS(SORT_LDS_LARGE) * 8)
 
+// Gaussians per thread of the count / scatter workgroups.  Every workgroup pays for its passes over the tile table
+// (zeroing, scan, one chunk reservation per tile); with a depth cut most Gaussians are skipped, so a workgroup takes
+// more of them while about 200 workgroups remain (5 M Gaussians @ 1080p: 1221 -> 204 workgroups of 8160-entry tables).
+static int bin_items(int P, uint32_t cut_bits)
+{
+    if (cut_bits == GFT_NO_CUT) return BIN_ITEMS;
+    const int by_blocks = P / (BIN_THREADS * 200);
+    const int it = by_blocks < BIN_ITEMS ? BIN_ITEMS : (by_blocks > 60 ? 60 : by_blocks);      // (u16 per-tile counts per workgroup)
+    return it / BIN_ITEMS * BIN_ITEMS;
+}
+
 hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                 uint32_t* mail, uint32_t seq)
+                                 uint32_t* mail, uint32_t seq, uint32_t cut_bits, int pass, uint32_t cap)
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
-    const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
-    if (T <= BIN_LDS_MAX_TILES)
-        hipLaunchKernelGGL(k_tile_count<true>, dim3(blocks), dim3(BIN_THREADS), (size_t)T * 4, s, c.P, gx, T, g.rect,
-                           im.tile_cnt, im.ranges, im.tile_cursor, im.ctrl, mail, seq,
-                           T <= GFT_BLOCKHIST_TILES ? g.blockhist : nullptr);
-    else
-        hipLaunchKernelGGL(k_tile_count<false>, dim3(blocks), dim3(BIN_THREADS), 0, s, c.P, gx, T, g.rect, im.tile_cnt,
-                           im.ranges, im.tile_cursor, im.ctrl, mail, seq, nullptr);
+    CountArgs a;
+    a.items = bin_items(c.P, cut_bits);
+    const int blocks = (c.P + BIN_THREADS * a.items - 1) / (BIN_THREADS * a.items);
+    a.P = c.P; a.gx = gx; a.T = T;
+    a.rect = g.rect; a.depth = g.depth; a.cut_bits = cut_bits;
+    a.tile_cnt = pass == 0 ? im.tile_cnt : im.tile_cnt1;
+    a.ranges = pass == 0 ? im.ranges : im.ranges1;
+    a.cursor = im.tile_cursor; a.ctrl = im.ctrl; a.mail = mail; a.seq = seq;
+    a.blockhist = (T <= BIN_LDS_MAX_TILES && T <= GFT_BLOCKHIST_TILES) ? g.blockhist : nullptr;
+    a.dhist = im.dhist;
+    // log-spaced depth bins between the camera's near and far planes (every visible Gaussian lies between them)
+    const float nr = c.near_n > 1e-6f ? c.near_n : 1e-6f;
+    const float fr = c.far_n > 2.0f * nr ? c.far_n : 2.0f * nr;
+    a.db.near_n = nr; a.db.inv_near = 1.0f / nr; a.db.scale = (float)GFT_DHIST_BINS / log2f(fr / nr);
+    a.target = (uint32_t)(((uint64_t)T * GFT_NEAR_SLAB_PER_TILE) > 0xfffffffeull ? 0xfffffffeull : (uint64_t)T * GFT_NEAR_SLAB_PER_TILE);
+    a.unit_flag = im.unit_flag; a.cap = cap;
+    if (T <= BIN_LDS_MAX_TILES) {
+        if (pass == 0) hipLaunchKernelGGL((k_tile_count<true, 0>), dim3(blocks), dim3(BIN_THREADS), (size_t)T * 4, s, a);
+        else hipLaunchKernelGGL((k_tile_count<true, 1>), dim3(blocks), dim3(BIN_THREADS), (size_t)T * 4, s, a);
+    } else {
+        if (pass == 0) hipLaunchKernelGGL((k_tile_count<false, 0>), dim3(blocks), dim3(BIN_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((k_tile_count<false, 1>), dim3(blocks), dim3(BIN_THREADS), 0, s, a);
+    }
     return hipGetLastError();
 }
 
 hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                   const BinView& b, uint32_t cap)
+                                   const BinView& b, uint32_t cap, uint32_t cut_bits, int pass, int64_t expect_total)
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
-    const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
+    ScatterArgs a;
+    a.items = bin_items(c.P, cut_bits);
+    const int blocks = (c.P + BIN_THREADS * a.items - 1) / (BIN_THREADS * a.items);
+    a.P = c.P; a.gx = gx; a.T = T;
+    a.rect = g.rect; a.depth = g.depth;
+    a.ranges = pass == 0 ? im.ranges : im.ranges1;
+    a.cursor = im.tile_cursor; a.keys = b.keys; a.ctrl = im.ctrl; a.cap = cap; a.stage_cap = 0;
+    a.blockhist = nullptr; a.cut_bits = cut_bits; a.unit_flag = im.unit_flag;
     if (T > BIN_LDS_MAX_TILES) {
-        hipLaunchKernelGGL(k_tile_scatter<0>, dim3(blocks), dim3(BIN_THREADS), 0, s, c.P, gx, T, g.rect, g.depth,
-                           im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, 0u, nullptr);
+        if (pass == 0) hipLaunchKernelGGL((k_tile_scatter<0, 0>), dim3(blocks), dim3(BIN_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((k_tile_scatter<0, 1>), dim3(blocks), dim3(BIN_THREADS), 0, s, a);
         return hipGetLastError();
     }
     {
-        static std::atomic<uint64_t> done1{0}, done2{0};
-        hipError_t e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_tile_scatter<1>), 2 * BIN_LDS_MAX_TILES * 4, done1);
-        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_tile_scatter<2>), BIN_STAGE_LDS_BYTES, done2);
+        static std::atomic<uint64_t> done[4];
+        hipError_t e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_tile_scatter<1, 0>), 2 * BIN_LDS_MAX_TILES * 4, done[0]);
+        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_tile_scatter<2, 0>), BIN_STAGE_LDS_BYTES, done[1]);
+        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_tile_scatter<1, 1>), 2 * BIN_LDS_MAX_TILES * 4, done[2]);
+        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_tile_scatter<2, 1>), BIN_STAGE_LDS_BYTES, done[3]);
         if (e != hipSuccess) return e;
     }
-    // Staging pays when a workgroup's instances (about cap / blocks; cap is R plus the caller's
-    // headroom) fit the LDS that the three per-tile tables leave free; workgroups that exceed it
-    // write directly.  It also pins one workgroup per CU, so it is not used when most would not fit.
+    // Staging pays when a workgroup's instances (about expect_total / blocks: the caller's estimate of the
+    // instances this pass scatters) fit the LDS that the three per-tile tables leave free; workgroups that exceed
+    // it write directly.  It also pins one workgroup per CU, so it is not used when most would not fit.
     const size_t tables = ((size_t)3 * T + (T & 1)) * 4;
     const size_t stage_cap = tables + 4096 * 8 <= BIN_STAGE_LDS_BYTES ? (BIN_STAGE_LDS_BYTES - tables) / 8 : 0;
-    const size_t expect = blocks > 0 ? (size_t)cap / (size_t)blocks : 0;
-    const uint16_t* bh = T <= GFT_BLOCKHIST_TILES ? g.blockhist : nullptr;
-    if (stage_cap > 0 && expect <= stage_cap + stage_cap / 2)
-        hipLaunchKernelGGL(k_tile_scatter<2>, dim3(blocks), dim3(BIN_THREADS), tables + stage_cap * 8, s, c.P, gx, T,
-                           g.rect, g.depth, im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, (uint32_t)stage_cap, bh);
-    else
-        hipLaunchKernelGGL(k_tile_scatter<1>, dim3(blocks), dim3(BIN_THREADS), (size_t)T * 8, s, c.P, gx, T, g.rect,
-                           g.depth, im.ranges, im.tile_cursor, b.keys, im.ctrl, cap, 0u, bh);
+    const size_t expect = blocks > 0 ? (size_t)(expect_total > 0 ? expect_total : 0) / (size_t)blocks : 0;
+    a.blockhist = T <= GFT_BLOCKHIST_TILES ? g.blockhist : nullptr;
+    if (stage_cap > 0 && expect <= stage_cap + stage_cap / 2) {
+        a.stage_cap = (uint32_t)stage_cap;
+        if (pass == 0) hipLaunchKernelGGL((k_tile_scatter<2, 0>), dim3(blocks), dim3(BIN_THREADS), tables + stage_cap * 8, s, a);
+        else hipLaunchKernelGGL((k_tile_scatter<2, 1>), dim3(blocks), dim3(BIN_THREADS), tables + stage_cap * 8, s, a);
+    } else {
+        if (pass == 0) hipLaunchKernelGGL((k_tile_scatter<1, 0>), dim3(blocks), dim3(BIN_THREADS), (size_t)T * 8, s, a);
+        else hipLaunchKernelGGL((k_tile_scatter<1, 1>), dim3(blocks), dim3(BIN_THREADS), (size_t)T * 8, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -856,7 +1062,7 @@ hipError_t gft_launch_tile_tail(hipStream_t s, const gft_config& c, const GeomVi
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_tile_tail, dim3(T < 256 ? T : 256), dim3(SORT_BIG_THREADS), (size_t)SORT_LDS_LARGE_BYTES, s, T,
-                       im.ranges, b.keys, b.point_list, g.depth, im.front_len, im.unit_flag, im.ctrl, cap);
+                       im.ranges, im.ranges1, b.keys, b.point_list, g.depth, im.front_len, im.unit_flag, im.ctrl, cap);
     return hipGetLastError();
 }
 

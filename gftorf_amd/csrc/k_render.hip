@@ -115,6 +115,10 @@ struct RenderFwdArgs {
     float* pixels;
     const uint32_t* __restrict__ ctrl;   // NULL: no instance-count check
     uint32_t cap;
+    // lazy binning (k_binning.hip): the tile's list = its near-slab segment (ranges) + its far-slab segment (ranges1),
+    // the latter binned only after a quadrant of the tile ran out of near-slab entries
+    const uint32_t* __restrict__ totals;      // ctrl words (always set)
+    const uint2* __restrict__ ranges1;
     // lazy sort (k_binning.hip, k_tile_front): only the head of every id list is sorted
     const uint32_t* __restrict__ front_len;   // NULL: lists are sorted whole
     uint32_t* __restrict__ unit_flag;
@@ -144,10 +148,19 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     const uint2 range = a.ranges[tile];
     const int full = (int)(range.y - range.x);
     const int head = a.front_len ? (int)a.front_len[tile] : full;
-    // first pass: list positions [0, head); resume pass: [head, full) of the flagged quadrants
+    // first pass: list positions [0, head); resume pass: [head, full) of the flagged quadrants, then the tile's
+    // far-slab segment (positions full ... full + n1)
     if (a.resume && a.unit_flag[v] == 0u) return;
+    const bool more = a.totals[GFT_CTRL_TOTAL] != a.totals[GFT_CTRL_TOTAL0];      // the frame has a far slab
+    uint32_t r1x = 0;
+    int n1 = 0;
+    if (a.resume && a.totals[GFT_CTRL_TOTAL1] != 0u) {
+        const uint2 r1 = a.ranges1[tile];
+        r1x = r1.x;
+        n1 = (int)(r1.y - r1.x);
+    }
     const int begin = a.resume ? head : 0;
-    const int total = a.resume ? full : head;
+    const int total = a.resume ? full + n1 : head;
     const size_t pix_i = inside ? (size_t)a.W * py + px : 0;
 
     // Predicates are wave-uniform 64-bit lane masks: every ballot below takes a single compare,
@@ -182,7 +195,8 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
         uint32_t cnt = 0;                        // lane j: pixels of this quadrant that blend splat j of the batch
         __syncthreads();                         // previous batch has read LDS
         if (lane < n) {
-            const uint32_t id = a.point_list[range.x + base + lane];
+            const int pos = base + lane;
+            const uint32_t id = a.point_list[pos < full ? range.x + (uint32_t)pos : r1x + (uint32_t)(pos - full)];
             my_id = id;
             reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, (float)qx0, (float)qy0);
         }
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
 
     // The sorted head is used up, pixels are still unsaturated and the list goes on: park the blend
     // state and ask for the tail (k_tile_tail sorts it, the resume pass continues from here).
-    if (!a.resume && head < full && done_m != ~0ull) {
+    if (!a.resume && (head < full || more) && done_m != ~0ull) {
         if (inside) {
             const bool is_done = (done_m >> lane) & 1ull;
             a.resume_state[4 * pix_i] = make_float4(T, C0, C1, C2);
@@ -310,6 +324,7 @@ struct RenderBwdArgs {
     const float4* __restrict__ pix_state;
     const float4* __restrict__ pix_sums;
     int split;                 // 1: deep quadrants are shared by two waves
+    const uint2* __restrict__ ranges1;      // lazy binning: far-slab segments (read only by quadrants that went that deep)
     const uint32_t* __restrict__ quad_max;
     const uint32_t* __restrict__ order;     // tiles, heaviest first
     const float* __restrict__ g_color; const float* __restrict__ g_phasor; const float* __restrict__ g_depth;
@@ -482,7 +497,12 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
-    const uint32_t r0 = a.ranges[tile].x;
+    // list position c -> entry of the id list: the near-slab segment, then (lazy binning) the far-slab segment
+    const uint2 rg = a.ranges[tile];
+    const uint32_t r0 = rg.x, n0 = rg.y - rg.x;
+    uint32_t r1x = 0;
+    if ((uint32_t)tmax > n0) r1x = a.ranges1[tile].x;
+    auto phys = [&](uint32_t c) -> uint32_t { return c < n0 ? r0 + c : r1x + (c - n0); };
     const size_t HW = (size_t)a.H * a.W;
     const size_t pix = inside ? (size_t)a.W * py + px : 0;
 
@@ -542,7 +562,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
             bool reach = false;
             __syncthreads();
             if (lane < n) {
-                const uint32_t id = a.point_list[r0 + (uint32_t)(base + lane)];
+                const uint32_t id = a.point_list[phys((uint32_t)(base + lane))];
                 reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, (float)qx0, (float)qy0);
             }
             uint64_t m = to_sgpr(wave_ballot(reach));
@@ -595,7 +615,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
         bool reach = false;
         __syncthreads();                           // previous batch's flush has read LDS
         if (lane < n) {
-            const uint32_t id = a.point_list[r0 + (uint32_t)(hi - 1 - lane)];
+            const uint32_t id = a.point_list[phys((uint32_t)(hi - 1 - lane))];
             sId[lane] = id;
             reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, (float)qx0, (float)qy0);
         }
@@ -691,6 +711,8 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     RenderFwdArgs a;
     a.ctrl = check_cap ? im.ctrl : nullptr;
     a.cap = cap;
+    a.totals = im.ctrl;
+    a.ranges1 = im.ranges1;
     a.W = c.W; a.H = c.H;
     a.gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X;
     const int gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
@@ -724,6 +746,7 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     const int gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     a.T = a.gx * gy;
     a.ranges = im.ranges; a.point_list = b.point_list; a.rec_a = g.rec_a; a.rec_b = g.rec_b;
+    a.ranges1 = im.ranges1;
     a.bg = io.bg; a.bsc = c.bg_stride_c; a.bsy = c.bg_stride_y; a.bsx = c.bg_stride_x;
     a.dc_offset = c.dc_offset;
     a.pix_state = im.pix_state; a.quad_max = im.tile_max;

@@ -176,8 +176,11 @@ typedef struct gft_layout {
     size_t img_pix_state;     /* float[N][4]  {final_T, n_contrib(bits), w_z, w_z2} */
     size_t img_ranges;        /* uint32[T][2] [first,last) of the tile's list */
     size_t img_tile_max;      /* uint32[T][4] max n_contrib over each 8x8 quadrant of the tile */
-    size_t img_ctrl;          /* uint32[8]    {R, flags, max tile list length, ...}; tile_cnt follows directly */
-    size_t img_tile_cnt;      /* uint32[T]    instances per tile */
+    size_t img_ctrl;          /* uint32[16]   {R, flags, max tile list length, ...}; tile_cnt follows directly */
+    size_t img_tile_cnt;      /* uint32[T]    instances per tile (of the near slab when a depth cut is given) */
+    size_t img_tile_cnt1;     /* uint32[T]    lazy binning: far-slab instances of the tiles that asked for them */
+    size_t img_dhist;         /* uint32[256]  instances per log-depth bin (choice of the next depth cut) */
+    size_t img_ranges1;       /* uint2[T]     lazy binning: [first,last) of every tile's far-slab segment */
     size_t img_tile_cursor;   /* uint32[T]    scatter cursors */
     size_t img_tile_order;    /* uint32[T]    tiles by backward weight (written by gft_backward) */
     size_t img_front_len;     /* uint32[T]    length of the sorted head of the tile's id list (lazy sort) */
@@ -226,22 +229,50 @@ int gft_forward_preprocess(void* hip_stream, const gft_config* cfg,
  * value goes to gft_backward, it fixes the layout inside the buffer. */
 int gft_forward_render(void* hip_stream, const gft_config* cfg,
                        const gft_forward_io* io, int64_t binning_instances,
-                       int64_t max_tile_list /* from stage 1; <= 0 = unknown */);
+                       int64_t max_tile_list /* from stage 1; <= 0 = unknown */,
+                       float depth_cut /* the depth cut the preceding stage 1 ran with: 0 after
+                                          gft_forward_preprocess(), hints->depth_cut after a gft_forward() whose
+                                          buffer was too small */);
+
+/* What a caller knows before the forward (from the previous frame of the same kind), for gft_forward(). */
+typedef struct gft_forward_hints {
+    int64_t binning_instances;   /* instances `io->binning` holds (the caller's guess of R plus headroom) */
+    int64_t max_tile_list;       /* guess of the longest per-tile list (e.g. last frame's, with margin; <= 0 = unknown) */
+    int64_t near_instances;      /* lazy binning: guess of the near slab's instance count (<= 0 = unknown) */
+    float depth_cut;             /* lazy binning: view-space depth of the near slab's far side; <= 0 = bin every instance */
+    float reserved;
+} gft_forward_hints;
+
+/* What the device reported while the forward was running. */
+typedef struct gft_forward_report {
+    int64_t num_rendered;        /* R, the number of (Gaussian, tile) instances of the frame (reference: num_rendered) */
+    int64_t max_tile_list;       /* longest per-tile list that was binned up front */
+    int64_t near_instances;      /* instances binned up front (== num_rendered without a depth cut) */
+    float depth_cut_next;        /* depth cut this frame suggests for the next one (0 = bin every instance) */
+    float reserved;
+} gft_forward_report;
 
 /* The forward in one call, for callers that can guess R (a training loop: R of the
- * previous iteration plus headroom).  `io->binning` holds `binning_instances`
+ * previous iteration plus headroom).  `io->binning` holds `hints->binning_instances`
  * instances.  Both stages are queued back to back, so the device never waits for the
  * host; the call returns as soon as the device has posted R (stage 2 may still run).
- * If *num_rendered > binning_instances the stage-2 kernels have done nothing (they
- * compare the device-side count themselves): allocate for *num_rendered and call
- * gft_forward_render().  `max_tile_list_hint`: the caller's guess of the longest
- * per-tile list (e.g. last frame's, with margin; <= 0 = unknown).  A guess at or below
- * 4096 skips the launches of the long-list sort; if the frame then does have a longer
- * list the library sorts it and renders again before returning.  Results are identical
- * to the two-stage flow in every case. */
+ * If report->num_rendered > hints->binning_instances the stage-2 kernels have done nothing (they
+ * compare the device-side count themselves): allocate for report->num_rendered and call
+ * gft_forward_render().  A `max_tile_list` guess at or below 4096 skips the launches of the long-list
+ * sort (GFT_LAZY_SORT=0 only); if the frame then does have a longer list the library sorts it and renders again
+ * before returning.
+ *
+ * Lazy binning (`hints->depth_cut` > 0): a pixel stops reading its tile's list once its transmittance is below
+ * 1e-4 (reference forward.cu:560-565), so in a dense frame most (Gaussian, tile) instances are never read.  Only
+ * the instances with view-space depth <= depth_cut are counted, scattered and sorted up front; the others are
+ * binned -- for the tiles concerned -- only if a pixel quadrant runs out of entries before all its pixels are
+ * saturated, and those quadrants then continue.  Any cut is valid; report->depth_cut_next is the one that would
+ * have put about 900 instances per tile into the near slab of THIS frame (0 when the frame has too few instances
+ * for a cut to pay).  The binning buffer is still sized for all R instances.
+ *
+ * Results are identical to the two-stage flow in every case (same lists, same arithmetic order). */
 int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
-                int64_t binning_instances, int64_t max_tile_list_hint,
-                int64_t* num_rendered /*host*/, int64_t* max_tile_list /*host, may be NULL*/);
+                const gft_forward_hints* hints, gft_forward_report* report /*host*/);
 
 /* The backward of the forward whose scratch buffers `io` carries.  Gradient sums are added with float atomics
  * (as in the reference), so two runs agree to rounding, not bit for bit.  GFT_BWD_SPLIT=0 in the environment

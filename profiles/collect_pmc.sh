@@ -1,14 +1,15 @@
 #!/bin/bash
 # Collect PMC counters for every kernel of one bench run (separate passes; --pmc is never
-# combined with tracing options other than --kernel-trace).  Usage: collect_pmc.sh <outdir>
+# combined with tracing options other than --kernel-trace).  Usage: collect_pmc.sh <outdir> [workload]
 set -u
 OUT=${1:-gpurun_out/pmc}
+WL=${2:-metric}
 export TMPDIR=/tmp
 mkdir -p "$OUT"
 run() { # name, counters...
   local name=$1; shift
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- \
-      python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/$name.log" 2>&1
+      python3 bench.py --workload "$WL" --steps 3 --warmup 1 --spin-up 0.05 --no-cpu-baseline --no-extras > "$OUT/$name.log" 2>&1
   echo "pass $name rc=$?"
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS

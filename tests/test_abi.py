@@ -54,7 +54,9 @@ def test_header_is_plain_c_and_matches_ctypes(tmp_path, lib):
               "gft_layout": _lib.LAYOUT_FIELDS,
               "gft_profile": _lib.PROFILE_FIELDS + ["forward_calls", "backward_calls"],
               "gft_assemble_io": _lib.ASSEMBLE_FIELDS, "gft_assemble_bwd_io": _lib.ASSEMBLE_BWD_FIELDS,
-              "gft_deform_params": _lib.DEFORM_FIELDS, "gft_deform_grads": _lib.DEFORM_FIELDS}
+              "gft_deform_params": _lib.DEFORM_FIELDS, "gft_deform_grads": _lib.DEFORM_FIELDS,
+              "gft_forward_hints": [f[0] for f in _lib.ForwardHints._fields_],
+              "gft_forward_report": [f[0] for f in _lib.ForwardReport._fields_]}
     body = ['#include <stdio.h>', '#include <stddef.h>', '#include "gftorf_rast.h"', '#include "gftorf_assemble.h"',
             '#include "gftorf_deform.h"', 'int main(void){']
     for s, fl in fields.items():
@@ -69,7 +71,8 @@ def test_header_is_plain_c_and_matches_ctypes(tmp_path, lib):
     mirrors = {"gft_config": _lib.Config, "gft_forward_io": _lib.ForwardIO, "gft_backward_io": _lib.BackwardIO,
                "gft_layout": _lib.Layout, "gft_profile": _lib.Profile,
                "gft_assemble_io": _lib.AssembleIO, "gft_assemble_bwd_io": _lib.AssembleBwdIO,
-               "gft_deform_params": _lib.DeformParams, "gft_deform_grads": _lib.DeformParams}
+               "gft_deform_params": _lib.DeformParams, "gft_deform_grads": _lib.DeformParams,
+               "gft_forward_hints": _lib.ForwardHints, "gft_forward_report": _lib.ForwardReport}
     for s, cls in mirrors.items():
         assert int(out[s]) == C.sizeof(cls), s
         for f in fields[s]:
@@ -85,9 +88,11 @@ def test_size_queries_and_layout_need_no_gpu(lib):
     assert lib.gft_image_bytes(640, 480) >= 640 * 480 * 16 + 1200 * 12
     L = _lib.get_layout(1000, 640, 480, 5000)
     offs = [getattr(L, n) for n in _lib.LAYOUT_FIELDS]
-    # every region is 256-B aligned, except tile_cnt which directly follows the 32-B ctrl block
-    assert all(o % 256 == 0 for n, o in zip(_lib.LAYOUT_FIELDS, offs) if n != "img_tile_cnt")
-    assert L.img_tile_cnt == L.img_ctrl + 32
+    # every region is 256-B aligned, except tile_cnt which directly follows the 64-B ctrl block
+    # (the ctrl words, both slabs' tile counters and the depth histogram are contiguous: one clear)
+    assert all(o % 256 == 0 for n, o in zip(_lib.LAYOUT_FIELDS, offs) if n not in ("img_tile_cnt", "img_tile_cnt1", "img_dhist"))
+    assert L.img_tile_cnt == L.img_ctrl + 64 and L.img_tile_cnt1 == L.img_tile_cnt + 4 * 1200
+    assert L.img_dhist == L.img_tile_cnt1 + 4 * 1200
     assert L.geom_rec_b >= 32 * 1000 and L.bin_point_list >= 8 * 5000 and L.bin_total >= 12 * 5000
     assert lib.gft_binning_bytes(0, 640, 480) >= 0
 

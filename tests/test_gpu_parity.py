@@ -67,7 +67,7 @@ def raw_forward(scene, dev, inputs=None):
     R = int(R.value)
     binning = torch.zeros(lib.gft_binning_bytes(R, W, H), device=dev, dtype=torch.uint8)
     io.binning = p(binning)
-    _lib.check(lib.gft_forward_render(stream, C.byref(c), C.byref(io), R, int(MX.value)))
+    _lib.check(lib.gft_forward_render(stream, C.byref(c), C.byref(io), R, int(MX.value), 0.0))
     torch.cuda.synchronize()
     L = _lib.get_layout(P, W, H, R)
     keep = (T, view, proj, campos, bg)
@@ -376,12 +376,22 @@ def test_one_call_forward_matches_two_stage(oracle, gpu):
     R = api.last_call_stats["num_rendered"]
     assert R > 0 and api.last_call_stats["binning_instances"] == (R + 63) // 64 * 64 and not api.last_call_stats["restarted"]
     key = next(iter(api._instance_hint))
-    for hint, restarted in ((None, False), (R, False), (1, True), (0, True)):
+    # (instance guess, depth cut of the lazy binning, restart expected): the Gaussians lie at view depths 1 .. 5.5
+    for hint, cut, restarted in ((None, 0.0, False), (R, 0.0, False), (1, 0.0, True), (0, 0.0, True),
+                                 (R, 2.5, False), (R, 0.5, False), (R, 50.0, False), (1, 2.5, True)):
         if hint is not None:
-            api._instance_hint[key] = (hint, api._instance_hint[key][1])
+            api._instance_hint[key] = (hint, api._instance_hint[key][1], cut, 0)
         out, grads, _ = Hh.run_gpu(scene, gpu)
         st = api.last_call_stats
         assert st["num_rendered"] == R and st["restarted"] == restarted
+        if hint is not None:
+            assert st["depth_cut"] == cut
+            if cut == 2.5 and not restarted:
+                assert 0 < st["near_instances"] < R
+            elif cut == 0.5:
+                assert st["near_instances"] == 0
+            elif cut in (0.0, 50.0):
+                assert st["near_instances"] == R
         assert st["binning_instances"] >= R
         for k in ref_out:
             np.testing.assert_array_equal(out[k], ref_out[k], err_msg=k)
@@ -430,7 +440,7 @@ def test_one_call_forward_with_wrong_list_guess(oracle, gpu):
     assert longest > 4096
     key = next(iter(api._instance_hint))
     for list_guess in (100, longest):                             # wrong guess, right guess
-        api._instance_hint[key] = (R, list_guess)
+        api._instance_hint[key] = (R, list_guess, 0.0, 0)
         out, grads, _ = Hh.run_gpu(scene, gpu)
         assert api.last_call_stats["num_rendered"] == R and not api.last_call_stats["restarted"]
         for k in ref_out:
@@ -440,6 +450,82 @@ def test_one_call_forward_with_wrong_list_guess(oracle, gpu):
                 Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
     f, b = Hh.run_oracle(oracle, scene)
     check_outputs(f, ref_out)
+
+
+BIN_CASES = {
+    # (scene, depth cuts): frames where no / every / some quadrant outlives the near slab
+    "base": (dict(), (2.0, 3.5)),
+    "deep_lists": (SCENES["deep_lists"], (1.5, 2.5, 4.0)),
+    "opaque_early_exit": (SCENES["opaque_early_exit"], (1.3, 2.0)),             # most quadrants saturate inside the near slab
+    "long_near_and_far": (SCENES["long_lists_lds128k"], (2.0, 3.5)),            # both slabs hold lists of thousands of keys
+    "thin_fog": (dict(P=40000, W=64, H=64, scale_lo=0.01, scale_hi=0.05, opacity=0.02), (1.5, 3.0)),   # nothing saturates
+    "flat_depth": (SCENES["long_lists_flat"], (3.0, 2.9999)),                   # every key on one side of the cut
+}
+
+
+@pytest.mark.parametrize("name", list(BIN_CASES))
+def test_lazy_binning_matches_full_binning(name, oracle, gpu):
+    """Depth-cut binning (near slab up front, far slab on demand for the tiles that ask): every output bit-identical
+    to the run that bins every instance, gradients equal up to the order of the atomic sums, for cuts in front of,
+    inside and behind the Gaussians, and the whole thing against the oracle."""
+    from gftorf_amd import _lib, api
+    kw, cuts = BIN_CASES[name]
+    scene = Hh.small_scene(seed=23, **kw)
+    api._instance_hint.clear()
+    ref_out, ref_grads, _ = Hh.run_gpu(scene, gpu)               # two-stage flow: every instance binned
+    R = api.last_call_stats["num_rendered"]
+    key = next(iter(api._instance_hint))
+    longest = api._instance_hint[key][1]
+    seen_partial = False
+    for cut in cuts:
+        api._instance_hint[key] = (R, longest, cut, 0)
+        out, grads, _ = Hh.run_gpu(scene, gpu)
+        st = api.last_call_stats
+        assert st["num_rendered"] == R and not st["restarted"] and st["depth_cut"] == cut
+        assert 0 <= st["near_instances"] <= R
+        seen_partial |= 0 < st["near_instances"] < R
+        if not _lib.load().gft_lazy_sort():
+            assert st["near_instances"] == R                      # GFT_LAZY_SORT=0: no flags to resume from, no cut
+        for k in ref_out:
+            np.testing.assert_array_equal(out[k], ref_out[k], err_msg="%s cut %g" % (k, cut))
+        for k in ref_grads:
+            if ref_grads[k] is not None:
+                Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
+    if _lib.load().gft_lazy_sort() and name != "flat_depth":
+        assert seen_partial, "no cut of this case split the instances"
+    f, b = Hh.run_oracle(oracle, scene)
+    check_outputs(f, ref_out)
+
+
+def test_lazy_binning_cut_suggestion(gpu):
+    """The forward reports a depth cut for the next frame of the same kind: none for a frame with few instances per
+    tile, one that leaves about 900 instances per tile in the near slab for a dense frame; the frames rendered with
+    it equal the first one bit for bit."""
+    from gftorf_amd import _lib, api
+    if not _lib.load().gft_lazy_sort():
+        pytest.skip("GFT_LAZY_SORT=0")
+    sparse = Hh.small_scene(P=3000, seed=11)
+    api._instance_hint.clear()
+    for _ in range(3):
+        Hh.run_gpu(sparse, gpu, backward=False)
+    assert next(iter(api._instance_hint.values()))[2] == 0.0      # R is far below 1.5 x 896 per tile: no cut
+    dense = Hh.small_scene(seed=29, P=60000, W=64, H=64, scale_lo=0.01, scale_hi=0.06, opacity=0.6)
+    api._instance_hint.clear()
+    first, _, _ = Hh.run_gpu(dense, gpu, backward=False)          # two-stage, no cut, none suggested yet
+    R = api.last_call_stats["num_rendered"]
+    T = 16
+    assert R > 3 * 896 * T
+    Hh.run_gpu(dense, gpu, backward=False)                        # one-call without a cut: measures the depth histogram
+    cut = next(iter(api._instance_hint.values()))[2]
+    assert 1.0 < cut < 5.5
+    for _ in range(2):
+        out, _, _ = Hh.run_gpu(dense, gpu, backward=False)
+        st = api.last_call_stats
+        assert st["depth_cut"] == cut and st["num_rendered"] == R
+        # the near slab holds about 896 instances per tile (one histogram bin of slack)
+        assert 0.8 * 896 * T <= st["near_instances"] <= 1.6 * 896 * T, st
+        for k in first:
+            np.testing.assert_array_equal(out[k], first[k], err_msg=k)
 
 
 LAZY_CASES = {
