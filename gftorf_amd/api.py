@@ -240,12 +240,12 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         planes.zero_()
         binning = torch.empty((0,), device=dev, dtype=torch.uint8)
     else:
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.raw_stream(dev)
         num_rendered = C.c_int64(0)
         hint_key = (dev.index, P, W, H)
         hint, list_hint, cut_hint, near_hint = _instance_hint.get(hint_key, (None, 0, 0.0, 0))
         try:
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 if hint is None:
                     # first frame of this shape: size the buffer after the one blocking
                     # read, like the reference's resize callback
@@ -378,9 +378,9 @@ def native_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii,
                                        (sh, sh_p, s.sh_degree, s.campos, geom, binning, img,
                                         s.debug, s.near_n, s.far_n, s.depth_range, s.use_view_dependent_phase,
                                         ph_off, dc_off))
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = _lib.raw_stream(dev)
     try:
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(lib.gft_backward(stream, C.byref(cfg), C.byref(io), binning_capacity(binning) if P else 0))
     except Exception as ex:
         if s.debug:
@@ -470,8 +470,8 @@ class GaussianRasterizer(nn.Module):
             if P:
                 view = _f32(s.viewmatrix, dev, "viewmatrix")
                 proj = _f32(s.projmatrix, dev, "projmatrix")
-                with torch.cuda.device(dev):
-                    _lib.check(lib.gft_mark_visible(torch.cuda.current_stream(dev).cuda_stream, P, pos.data_ptr(),
+                with _lib.on_device(dev):
+                    _lib.check(lib.gft_mark_visible(_lib.raw_stream(dev), P, pos.data_ptr(),
                                                     view.data_ptr(), proj.data_ptr(), float(s.near_n),
                                                     float(s.far_n), visible.data_ptr()))
         return visible

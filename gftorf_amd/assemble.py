@@ -100,8 +100,8 @@ class _AssembleInputs(torch.autograd.Function):
         io.scratch = scratch.data_ptr()
         io.out_means3D, io.out_means2D, io.out_opacity = _p(means3D), _p(means2D), _p(out_op)
         io.out_scales, io.out_rotations, io.out_shs, io.out_shs_p = _p(scales), _p(rotations), _p(shs), _p(shs_p)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        stream = _lib.raw_stream(dev)
+        with _lib.on_device(dev):
             _lib.check(lib.gft_assemble_forward(stream, P, M, M_p, int(render_static), int(render_dynamic), C.byref(io)))
             if validate:
                 # the reference's masked assignment raises when d_* has another row count
@@ -151,8 +151,8 @@ class _AssembleInputs(torch.autograd.Function):
         io.g_xyz, io.g_screenspace, io.g_opacity_in, io.g_scaling = _p(g_xyz), _p(g_ssp), _p(g_op), _p(g_sc)
         io.g_rotation, io.g_rotation_raw, io.g_feat_color, io.g_feat_phasor = _p(g_rot), _p(g_raw), _p(g_fc), _p(g_fp)
         io.g_d_xyz, io.g_d_rot, io.g_d_sh, io.g_d_sh_p = _p(g_dxyz), _p(g_drot), _p(g_dsh), _p(g_dshp)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        stream = _lib.raw_stream(dev)
+        with _lib.on_device(dev):
             _lib.check(lib.gft_assemble_backward(stream, P, M, M_p, rs, rd, C.byref(io)))
         return (g_xyz, g_ssp, g_op, g_sc, g_rot, g_raw, g_fc, g_fp, None, g_dxyz, g_drot, g_dsh, g_dshp,
                 None, None, None)

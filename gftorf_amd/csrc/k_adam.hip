@@ -53,7 +53,93 @@ __global__ __launch_bounds__(ADAM_BLOCK) void k_adam_step(AdamArgs a)
     }
 }
 
+// Several tensors in ONE launch (own learning rate and step count each; betas, eps, weight decay shared): the
+// reference's optimizers hold 13 one-tensor groups of per-Gaussian parameters and the 36 tensors of the deformation
+// network; at 100 k Gaussians a launch per tensor is bound by launch latency, not by HBM.  Workgroup b serves the
+// tensor whose block range holds b (table in the kernel arguments).
+struct AdamMultiArgs {
+    int count;
+    float one_m_beta1, beta2, one_m_beta2, eps, weight_decay;
+    struct T { float* p; const float* g; float* m; float* v; int64_t n; float step_size, bias2_sqrt; uint32_t first_block; uint32_t pad; } t[GFT_ADAM_MAX_TENSORS];
+};
+
+__global__ __launch_bounds__(ADAM_BLOCK) void k_adam_multi(AdamMultiArgs a)
+{
+    int k = 0;
+#pragma unroll 1
+    for (int q = 1; q < a.count; q++)
+        if (blockIdx.x >= a.t[q].first_block) k = q;
+    AdamArgs s;
+    s.n = a.t[k].n; s.p = a.t[k].p; s.g = a.t[k].g; s.m = a.t[k].m; s.v = a.t[k].v;
+    s.one_m_beta1 = a.one_m_beta1; s.beta2 = a.beta2; s.one_m_beta2 = a.one_m_beta2; s.step_size = a.t[k].step_size;
+    s.bias2_sqrt = a.t[k].bias2_sqrt; s.eps = a.eps; s.weight_decay = a.weight_decay;
+    const uint32_t blk = blockIdx.x - a.t[k].first_block;
+    const int64_t n4 = s.n >> 2;
+    const int64_t i = (int64_t)blk * ADAM_BLOCK + threadIdx.x;
+    if (i < n4) {
+        float4 p = reinterpret_cast<float4*>(s.p)[i];
+        const float4 g = reinterpret_cast<const float4*>(s.g)[i];
+        float4 m = reinterpret_cast<float4*>(s.m)[i];
+        float4 v = reinterpret_cast<float4*>(s.v)[i];
+        adam_one(p.x, g.x, m.x, v.x, s);
+        adam_one(p.y, g.y, m.y, v.y, s);
+        adam_one(p.z, g.z, m.z, v.z, s);
+        adam_one(p.w, g.w, m.w, v.w, s);
+        reinterpret_cast<float4*>(s.p)[i] = p;
+        reinterpret_cast<float4*>(s.m)[i] = m;
+        reinterpret_cast<float4*>(s.v)[i] = v;
+    }
+    const int64_t tail = s.n & 3;
+    if (blk == 0 && (int64_t)threadIdx.x < tail) {
+        const int64_t e = (n4 << 2) + threadIdx.x;
+        float p = s.p[e], m = s.m[e], v = s.v[e];
+        adam_one(p, s.g[e], m, v, s);
+        s.p[e] = p; s.m[e] = m; s.v[e] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int gft_adam_step_multi(void* hip_stream, int32_t count, const gft_adam_tensor* tensors, double beta1,
+                                   double beta2, double eps, double weight_decay)
+{
+    if (count < 0) return gft_fail("gft_adam_step_multi: count < 0");
+    if (count == 0) return 0;
+    if (!tensors) return gft_fail("gft_adam_step_multi: tensors is NULL");
+    for (int32_t c0 = 0; c0 < count; c0 += GFT_ADAM_MAX_TENSORS) {
+        AdamMultiArgs a;
+        a.one_m_beta1 = (float)(1.0 - beta1);
+        a.beta2 = (float)beta2;
+        a.one_m_beta2 = (float)(1.0 - beta2);
+        a.eps = (float)eps;
+        a.weight_decay = (float)weight_decay;
+        int k = 0;
+        uint64_t blocks = 0;
+        for (int32_t c = c0; c < count && c < c0 + GFT_ADAM_MAX_TENSORS; c++) {
+            const gft_adam_tensor& t = tensors[c];
+            if (t.n < 0) return gft_fail("gft_adam_step_multi: tensor %d has n < 0", c);
+            if (t.n == 0) continue;
+            if (t.step < 1) return gft_fail("gft_adam_step_multi: tensor %d: step must be >= 1", c);
+            if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq) return gft_fail("gft_adam_step_multi: tensor %d has a NULL pointer", c);
+            if ((((uintptr_t)t.param | (uintptr_t)t.grad | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq) & 15) != 0)
+                return gft_fail("gft_adam_step_multi: pointers of tensor %d are not 16-byte aligned", c);
+            a.t[k].p = t.param; a.t[k].g = t.grad; a.t[k].m = t.exp_avg; a.t[k].v = t.exp_avg_sq; a.t[k].n = t.n;
+            a.t[k].step_size = (float)(t.lr / (1.0 - pow(beta1, (double)t.step)));
+            a.t[k].bias2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t.step));
+            a.t[k].first_block = (uint32_t)blocks; a.t[k].pad = 0;
+            const int64_t n4 = t.n >> 2;
+            blocks += n4 > 0 ? (uint64_t)((n4 + ADAM_BLOCK - 1) / ADAM_BLOCK) : 1;
+            k++;
+        }
+        if (k == 0) continue;
+        if (blocks > 0x7fffffffull) return gft_fail("gft_adam_step_multi: too many elements for one launch");
+        a.count = k;
+        hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)blocks), dim3(ADAM_BLOCK), 0, (hipStream_t)hip_stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return gft_fail("gft_adam_step_multi: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
 
 extern "C" int gft_adam_step(void* hip_stream, int64_t n, float* param, const float* grad, float* exp_avg,
                              float* exp_avg_sq, double lr, double beta1, double beta2, double eps, double weight_decay,

@@ -76,8 +76,8 @@ class _DeformFn(torch.autograd.Function):
         d_xyz = torch.empty((n, 3), **f32)
         d_sh = torch.empty((n, 16, 3), **f32)
         saved = torch.empty((lib.gft_deform_saved_bytes(n) // 4,), **f32) if (need_bw and n > 0) else None
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        stream = _lib.raw_stream(dev)
+        with _lib.on_device(dev):
             _lib.check(lib.gft_deform_pack(stream, xm, tm, C.byref(_fill(_lib.DeformParams(), ps)), packed.data_ptr()))
             _lib.check(lib.gft_deform_forward(stream, xm, tm, n, x_c.data_ptr() if n else None, t_c.data_ptr() if n else None,
                                               t_stride, packed.data_ptr(), saved.data_ptr() if saved is not None else None,
@@ -102,8 +102,8 @@ class _DeformFn(torch.autograd.Function):
         gx = g_dxyz.float().contiguous() if g_dxyz is not None else None
         gs = g_dsh.float().contiguous() if g_dsh is not None else None
         scratch = torch.empty((lib.gft_deform_scratch_bytes(n) // 4,), **f32)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        stream = _lib.raw_stream(dev)
+        with _lib.on_device(dev):
             _lib.check(lib.gft_deform_backward(stream, ctx.arch[0], ctx.arch[1], n, packed.data_ptr(), saved.data_ptr() if n else None,
                                                gx.data_ptr() if (gx is not None and n) else None,
                                                gs.data_ptr() if (gs is not None and n) else None,

@@ -25,7 +25,7 @@ def distCUDA2(points):
     if P == 0:
         return out
     scratch = torch.empty((lib.gft_knn_scratch_bytes(P),), device=dev, dtype=torch.uint8)
-    with torch.cuda.device(dev):
-        _lib.check(lib.gft_knn_mean_dist2(torch.cuda.current_stream(dev).cuda_stream, P, pts.data_ptr(),
+    with _lib.on_device(dev):
+        _lib.check(lib.gft_knn_mean_dist2(_lib.raw_stream(dev), P, pts.data_ptr(),
                                           out.data_ptr(), scratch.data_ptr()))
     return out

@@ -1,8 +1,9 @@
 """Fused Adam for the Gaussian parameters (optimizer part).
 
 ``FusedAdam`` is a ``torch.optim.Adam`` whose ``step()`` runs one hand-written gfx950 kernel per
-parameter tensor (``csrc/k_adam.hip``, ``include/gftorf_optim.h``) instead of torch's multi-tensor
-path; constructor, ``param_groups``, ``state`` (``step`` / ``exp_avg`` / ``exp_avg_sq``),
+call -- all tensors of all groups that share betas / eps / weight decay in one launch, each with its own learning
+rate and step count (``csrc/k_adam.hip``, ``include/gftorf_optim.h``) --
+instead of torch's multi-tensor path (one kernel per arithmetic operation); constructor, ``param_groups``, ``state`` (``step`` / ``exp_avg`` / ``exp_avg_sq``),
 ``state_dict`` and ``zero_grad`` are torch's own, so the reference's densification code, which
 edits the optimizer state in place (``scene/gaussian_model.py:456-540``), works unchanged.
 Use: replace ``torch.optim.Adam(l, lr=0.0, eps=1e-15)`` at ``scene/gaussian_model.py:274`` by
@@ -28,6 +29,9 @@ class FusedAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        # (parameter, gradient, moments, lr, step tensor) of every tensor that takes a step, bucketed by the settings
+        # one launch shares: (device, betas, eps, weight decay)
+        buckets = {}
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
@@ -48,14 +52,18 @@ class FusedAdam(torch.optim.Adam):
                     state["step"] = torch.tensor(0.0, dtype=torch.float32)
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state["step"] += 1
-                t = int(state["step"])
-                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 m, v = state["exp_avg"], state["exp_avg_sq"]
                 if not (m.is_contiguous() and v.is_contiguous()):
                     raise RuntimeError("gftorf_amd.FusedAdam: optimizer state must be contiguous")
-                with torch.cuda.device(p.device):
-                    _lib.check(lib.gft_adam_step(torch.cuda.current_stream(p.device).cuda_stream, p.numel(),
-                                                 p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                                 float(lr), float(beta1), float(beta2), float(eps), float(wd), t))
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                buckets.setdefault((p.device, float(beta1), float(beta2), float(eps), float(wd)), []).append(
+                    (p, grad, m, v, float(lr), state["step"]))
+        for (dev, beta1, beta2, eps, wd), items in buckets.items():
+            torch._foreach_add_([it[5] for it in items], 1)
+            tab = (_lib.AdamTensor * len(items))()
+            for e, (p, g, m, v, lr, st) in zip(tab, items):
+                e.param, e.grad, e.exp_avg, e.exp_avg_sq, e.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+                e.lr, e.step = lr, int(st)
+            with _lib.on_device(dev):
+                _lib.check(lib.gft_adam_step_multi(_lib.raw_stream(dev), len(items), tab, beta1, beta2, eps, wd))
         return loss

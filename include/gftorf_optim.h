@@ -30,6 +30,23 @@ extern "C" {
 int gft_adam_step(void* hip_stream, int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step);
 
+/* The same update for several tensors in one launch per GFT_ADAM_MAX_TENSORS tensors: every tensor has its own
+ * learning rate and step count (the reference keeps one tensor per parameter group, each with its own lr,
+ * scene/gaussian_model.py:247-272), betas / eps / weight decay are shared. */
+#define GFT_ADAM_MAX_TENSORS 40
+typedef struct gft_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    double lr;
+    int64_t step;      /* 1-based count of this update */
+} gft_adam_tensor;
+
+int gft_adam_step_multi(void* hip_stream, int32_t count, const gft_adam_tensor* tensors /*host*/, double beta1,
+                        double beta2, double eps, double weight_decay);
+
 #ifdef __cplusplus
 }
 #endif

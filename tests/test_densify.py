@@ -128,7 +128,7 @@ def test_prune_and_cat_optimizer_like_the_reference():
     a.load_state_dict(b.state_dict())
     g = torch.Generator().manual_seed(4)
     keep = torch.rand(P, generator=g) < 0.8
-    new_a, sel = densify.prune_optimizer(a, keep.to(dev))
+    new_a = densify.prune_optimizer(a, keep.to(dev))          # {group name: Parameter}, like the reference
     new_b = densify_ref.prune_optimizer_eager(b, keep)
     assert list(new_a) == list(new_b) == list(GROUPS)
     for ga, gb in zip(a.param_groups, b.param_groups):
@@ -156,3 +156,46 @@ def test_prune_and_cat_optimizer_like_the_reference():
     for grp in a.param_groups:                                          # the optimizer is still consistent
         grp["params"][0].grad = torch.zeros_like(grp["params"][0])
     a.step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,max_screen_size", [(20_000, 20), (3_001, None)])
+def test_densify_composites_like_the_reference(P, max_screen_size):
+    """densify_and_clone / densify_and_split / prune_points / densify_and_prune (scene/gaussian_model.py:494-646): the
+    product's functions on a model object against the reference's eager statements on a twin, same device, same torch
+    generator state (the split draws torch.normal samples): every parameter, Adam moment and statistic bit-identical."""
+    from gftorf_amd import FusedAdam, densify
+    dev = torch.device("cuda:0")
+    a = densify_ref.EagerGaussians(P, dev, seed=5)             # driven by gftorf_amd.densify
+    b = densify_ref.EagerGaussians(P, dev, seed=5)             # driven by its own (the reference's) statements
+    for k, v in a.snapshot().items():
+        assert torch.equal(v, b.snapshot()[k]), k
+    extent = 2.0
+    for rnd in range(2):
+        torch.manual_seed(100 + rnd)
+        densify.densify_and_prune(a, 0.0002, 0.005, extent, max_screen_size)
+        torch.manual_seed(100 + rnd)
+        b.densify_and_prune(0.0002, 0.005, extent, max_screen_size)
+        sa, sb = a.snapshot(), b.snapshot()
+        assert sa["_xyz"].shape[0] == sb["_xyz"].shape[0] != P
+        assert set(sa) == set(sb)
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (rnd, k)
+        assert [g["name"] for g in a.optimizer.param_groups] == [g["name"] for g in b.optimizer.param_groups]
+        assert a.optimizer.param_groups[0]["params"][0] is a._xyz
+        # statistics for the next round (densification_postfix zeroed them)
+        g = torch.Generator().manual_seed(7 + rnd)
+        n = a._xyz.shape[0]
+        acc, den = (torch.rand((n, 1), generator=g) * 0.03).to(dev), torch.randint(0, 60, (n, 1), generator=g).float().to(dev)
+        rad = (torch.rand(n, generator=g) * 30).to(dev)
+        for m in (a, b):
+            m.xyz_gradient_accum, m.denom, m.max_radii2D = acc.clone(), den.clone(), rad.clone()
+    # plain pruning (gaussian_model.py:642-646) and one more optimizer step on the result
+    densify.prune(a, 0.3)
+    b.prune_points((b.get_opacity < 0.3).squeeze())
+    sa, sb = a.snapshot(), b.snapshot()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for grp in a.optimizer.param_groups:
+        grp["params"][0].grad = torch.zeros_like(grp["params"][0])
+    a.optimizer.step()
