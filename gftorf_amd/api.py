@@ -58,6 +58,11 @@ last_call_buffers = {}
 # counted (gft_forward: no host round trip in the middle of the forward); a frame that needs
 # more than the guess re-runs stage 2 with the exact size.
 _instance_hint = {}
+# Lazy binning, per the same key: instances per tile wanted in the near slab and the handle of the previous forward's
+# late report (quadrants that outlived the near slab: each costs a second binning pass).  A frame that reports such
+# quadrants widens the next near slab by a quarter; 200 clean frames in a row narrow it again towards the default.
+_slab_state = {}
+_SLAB_DEFAULT, _SLAB_MAX = 896, 8192
 _HINT_HEADROOM = 1.25
 _LIST_HEADROOM = 1.2      # longest tile list of the previous frame -> guess for this one
 
@@ -264,13 +269,26 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
+                    slab = _slab_state.setdefault(hint_key, {"per_tile": _SLAB_DEFAULT, "late": None, "clean": 0})
+                    if slab["late"] is not None:
+                        flagged = C.c_int64(-1)
+                        lib.gft_forward_late(slab["late"][0], slab["late"][1], C.byref(flagged))
+                        if flagged.value > 0:
+                            slab["per_tile"], slab["clean"] = min(_SLAB_MAX, int(slab["per_tile"] * 1.25) + 1), 0
+                        elif flagged.value == 0:
+                            slab["clean"] += 1
+                            if slab["clean"] >= 200 and slab["per_tile"] > _SLAB_DEFAULT:
+                                slab["per_tile"], slab["clean"] = max(_SLAB_DEFAULT, int(slab["per_tile"] * 0.9)), 0
                     hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
-                                              near_instances=int(near_hint), depth_cut=float(cut_hint))
+                                              near_instances=int(near_hint), depth_cut=float(cut_hint),
+                                              near_per_tile=int(slab["per_tile"]))
                     report = _lib.ForwardReport()
                     _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), C.byref(hints), C.byref(report)))
                     R = int(report.num_rendered)
                     max_list.value = int(report.max_tile_list)
                     cut_next, near = float(report.depth_cut_next), int(report.near_instances)
+                    # (without a cut the flags belong to the lazy sort's heads: they say nothing about the slab width)
+                    slab["late"] = (int(report.late_slot), int(report.late_seq)) if cut_hint > 0.0 else None
                     if R > cap:
                         restarted = True
                         cap = _canonical_cap(R)
@@ -294,7 +312,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
 
     last_call_stats.update(num_rendered=R, binning_instances=cap, restarted=restarted,
                            max_tile_list=int(max_list.value) if P else 0, depth_cut=float(cut_hint) if (P and hint is not None) else 0.0,
-                           near_instances=near if P else 0)
+                           near_instances=near if P else 0,
+                           near_per_tile=_slab_state[hint_key]["per_tile"] if (P and hint_key in _slab_state) else _SLAB_DEFAULT)
     if keep_last_buffers:
         last_call_buffers.update(geom=geom, img=img, binning=binning, P=P, W=W, H=H, cap=cap)
     last_call_stats["forwards"] = last_call_stats.get("forwards", 0) + 1

@@ -52,7 +52,8 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->img_ctrl = o;        o += GFT_CTRL_WORDS * 4;          // ctrl words and tile counters are contiguous
     L->img_tile_cnt = o;    o += T * 4;                       // ... and so are the far-slab counters and the depth histogram
     L->img_tile_cnt1 = o;   o += T * 4;
-    L->img_dhist = o;       o = align_up(o + GFT_DHIST_BINS * 4);
+    L->img_dhist = o;       o += GFT_DHIST_BINS * 4;
+    L->img_super_tab = o;   o = align_up(o + 3 * GFT_SUPER_MAX * 4);    // (cleared with them: the supertile counters are accumulated)
     L->img_ranges1 = o;     o = align_up(o + T * 8);
     L->img_tile_cursor = o; o = align_up(o + T * 4);
     L->img_tile_order = o;  o = align_up(o + T * 4);
@@ -96,6 +97,7 @@ ImgView gft_img_view(void* base, const gft_layout& L)
     v.tile_cnt1 = (uint32_t*)(b + L.img_tile_cnt1);
     v.dhist = (uint32_t*)(b + L.img_dhist);
     v.ranges1 = (uint2*)(b + L.img_ranges1);
+    v.super_tab = (uint32_t*)(b + L.img_super_tab);
     v.tile_cursor = (uint32_t*)(b + L.img_tile_cursor);
     v.tile_order = (uint32_t*)(b + L.img_tile_order);
     v.front_len = (uint32_t*)(b + L.img_front_len);
@@ -358,12 +360,12 @@ static uint32_t cut_bits_of(float depth_cut)
 
 // preprocess + tile counting + scan; the totals arrive in the mailbox slot
 static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
-                          const ImgView& im, uint32_t* mail_dev, uint32_t seq, uint32_t cut_bits)
+                          const ImgView& im, uint32_t* mail_dev, uint32_t seq, uint32_t cut_bits, int per_tile = 0)
 {
     {
         // ctrl words, per-tile counters of both slabs and the depth histogram: one clear
         const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
-        GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, (GFT_CTRL_WORDS + 2 * (size_t)gx * gy + GFT_DHIST_BINS) * sizeof(uint32_t), s));
+        GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, (GFT_CTRL_WORDS + 2 * (size_t)gx * gy + GFT_DHIST_BINS + 3 * GFT_SUPER_MAX) * sizeof(uint32_t), s));
     }
     {
         StageTimer t(s, ST_PRE_FWD);
@@ -371,7 +373,14 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
     }
     {
         StageTimer t(s, ST_TILE_COUNT);
-        GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im, mail_dev, seq, cut_bits, 0, 0u));
+        if (cut_bits != GFT_NO_CUT) {
+            // near slab: supertile count (tile-pull binning, k_binning.hip); also totals, depth histogram, mailbox
+            BinView none;
+            none.keys = nullptr; none.point_list = nullptr;
+            GFT_STAGE(s, cfg, "super_count", gft_launch_super_bin(s, *cfg, g, im, none, mail_dev, seq, cut_bits, 0, 0u, per_tile));
+        } else {
+            GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im, mail_dev, seq, cut_bits, 0, 0u, per_tile));
+        }
     }
     return 0;
 }
@@ -391,14 +400,24 @@ extern "C" int gft_lazy_sort(void) { return lazy_sort_enabled() ? 1 : 0; }
 // `cut_bits` as given to stage 1; `expect0`: the caller's estimate of the instances the first scatter moves.
 static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
                           const ImgView& im, const BinView& b, bool binned, int64_t max_tile_list, bool check_cap,
-                          uint32_t cap, uint32_t cut_bits, int64_t expect0)
+                          uint32_t cap, uint32_t cut_bits, int64_t expect0, uint32_t* late_mail = nullptr, uint32_t seq = 0u)
 {
     // The backward's accumulator clear (64 B per Gaussian of pure HBM writes) rides along with the
     // tile sort, whose workgroups are bound by LDS and VALU: each writes a slice of zeros first.
     float* clear = (io->acc && cfg->want_backward && cfg->P > 0) ? io->acc : nullptr;
     const size_t clear_bytes = (size_t)cfg->P * GFT_ACC_STRIDE * sizeof(float);
     const bool lazy = binned && lazy_sort_enabled();
-    if (binned) {
+    if (binned && cut_bits != GFT_NO_CUT) {
+        // near slab by tile-pull binning: ids to supertiles, then every tile collects, sorts and writes its own list
+        {
+            StageTimer t(s, ST_TILE_SCATTER);
+            GFT_STAGE(s, cfg, "super_scatter", gft_launch_super_bin(s, *cfg, g, im, b, nullptr, 0u, cut_bits, 1, cap, 0));
+        }
+        {
+            StageTimer t(s, ST_TILE_SORT);
+            GFT_STAGE(s, cfg, "tile_pull", gft_launch_tile_pull(s, *cfg, g, im, b, cap, clear, clear_bytes));
+        }
+    } else if (binned) {
         {
             StageTimer t(s, ST_TILE_SCATTER);
             GFT_STAGE(s, cfg, "tile_scatter", gft_launch_tile_scatter(s, *cfg, g, im, b, cap, cut_bits, 0, expect0));
@@ -424,7 +443,7 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
         if (cut_bits != GFT_NO_CUT) {
             {
                 StageTimer t(s, ST_TILE_COUNT);
-                GFT_STAGE(s, cfg, "tile_count_far", gft_launch_tile_count(s, *cfg, g, im, nullptr, 0u, cut_bits, 1, cap));
+                GFT_STAGE(s, cfg, "tile_count_far", gft_launch_tile_count(s, *cfg, g, im, nullptr, 0u, cut_bits, 1, cap, 0));
             }
             {
                 StageTimer t(s, ST_TILE_SCATTER);
@@ -433,7 +452,7 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
         }
         {
             StageTimer t(s, ST_TILE_SORT);
-            GFT_STAGE(s, cfg, "tile_tail", gft_launch_tile_tail(s, *cfg, g, im, b, cap));
+            GFT_STAGE(s, cfg, "tile_tail", gft_launch_tile_tail(s, *cfg, g, im, b, cap, late_mail, seq));
         }
         {
             StageTimer t(s, ST_RENDER_FWD);
@@ -496,7 +515,7 @@ extern "C" int gft_forward_render(void* hip_stream, const gft_config* cfg, const
         GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, GFT_CTRL_WORDS * sizeof(uint32_t), s));
     }
     // the cut stage 1 counted with: the near-slab ranges it produced only hold those instances
-    const uint32_t cut_bits = (lazy_sort_enabled() && R > 0) ? cut_bits_of(depth_cut) : GFT_NO_CUT;
+    const uint32_t cut_bits = (lazy_sort_enabled() && R > 0 && gft_tile_pull_ok(*cfg)) ? cut_bits_of(depth_cut) : GFT_NO_CUT;
     return enqueue_stage2(s, cfg, io, g, im, b, R > 0, max_tile_list, cfg->P > 0, (uint32_t)R, cut_bits, R);
 }
 
@@ -522,12 +541,15 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     uint32_t* mail_dev; volatile uint32_t* mail_host; uint32_t seq;
     if (mailbox_acquire(&mail_dev, &mail_host, &seq)) return 1;
     // lazy binning needs the flag / resume protocol of the lazy sort and a binning buffer to work with
-    const uint32_t cut_bits = (lazy_sort_enabled() && binning_instances > 0) ? cut_bits_of(hints->depth_cut) : GFT_NO_CUT;
-    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq, cut_bits)) return 1;
+    const uint32_t cut_bits = (lazy_sort_enabled() && binning_instances > 0 && gft_tile_pull_ok(*cfg)) ? cut_bits_of(hints->depth_cut) : GFT_NO_CUT;
+    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq, cut_bits, hints->near_per_tile)) return 1;
     // stage 2 is queued before R is known; its kernels check R against the buffer themselves
     const uint32_t cap = (uint32_t)binning_instances;
     const int64_t expect0 = (cut_bits != GFT_NO_CUT && hints->near_instances > 0) ? hints->near_instances : binning_instances;
-    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, cap, cut_bits, expect0)) return 1;
+    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, cap, cut_bits, expect0, mail_dev, seq))
+        return 1;
+    report->late_slot = (int32_t)(mail_dev - g_mail.dev) / GFT_CTRL_WORDS;
+    report->late_seq = seq;
     uint32_t host[GFT_CTRL_WORDS];
     if (mailbox_wait(s, mail_host, seq, host)) return 1;
     if (host[GFT_CTRL_FLAGS] & 1u)
@@ -546,6 +568,19 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
         GFT_STAGE(s, cfg, "tile_sort_long", gft_launch_tile_sort_long(s, *cfg, im, b, cap));
         GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, true, cap, 0));
     }
+    return 0;
+}
+
+// The late report of a gft_forward(): quadrants that outlived the near slab / the sorted head.  Never blocks.
+extern "C" int gft_forward_late(int32_t slot, uint32_t seq, int64_t* flagged_quadrants)
+{
+    if (!flagged_quadrants) return gft_fail("gft_forward_late: NULL argument");
+    *flagged_quadrants = -1;
+    std::lock_guard<std::mutex> lk(g_mail.mu);
+    if (!g_mail.host || slot < 0 || slot >= GFT_MAIL_SLOTS) return gft_fail("gft_forward_late: no such report");
+    volatile uint32_t* h = g_mail.host + (size_t)slot * GFT_CTRL_WORDS;
+    // not written yet, or the slot has been reused by a later forward: "unknown"
+    if (__atomic_load_n(&h[GFT_CTRL_SEQ2], __ATOMIC_ACQUIRE) == seq && h[GFT_CTRL_SEQ] == seq) *flagged_quadrants = (int64_t)h[GFT_CTRL_NFLAG];
     return 0;
 }
 

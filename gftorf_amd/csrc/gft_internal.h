@@ -48,6 +48,7 @@ struct ImgView {
     uint32_t* tile_cnt1;  // [T]  lazy binning: instances per flagged tile of the far slab
     uint32_t* dhist;      // [GFT_DHIST_BINS] instances per log-depth bin (picks the next frame's depth cut)
     uint2* ranges1;       // [T]  lazy binning: far-slab segment of every tile (valid once a quadrant was flagged)
+    uint32_t* super_tab;  // [3][256] lazy binning: count, list start and scatter cursor of every supertile
     uint32_t* tile_cursor;// [T]
     uint32_t* tile_order; // [T] tiles by backward weight, heaviest first (written by the backward)
     uint32_t* front_len;  // [T] lazy sort: length of the sorted head of the tile's id list
@@ -71,8 +72,11 @@ struct BinView {
 #define GFT_CTRL_CUTNEXT 6   // lazy binning: float bits of the depth cut suggested for the next frame of this kind
 #define GFT_CTRL_DONE1 7     // finished workgroups of the far-slab count (ticket for its scan)
 #define GFT_CTRL_TOTAL1 8    // lazy binning: far-slab instances binned for the flagged tiles
+#define GFT_CTRL_NEARSUM 9   // tile-pull binning: instances of the near slab as summed by the supertile count pass
+#define GFT_CTRL_SEQ2 10     // host mailbox only: sequence number of the late report (flagged quadrants), written by k_tile_tail
 #define GFT_CTRL_WORDS 16
 #define GFT_DHIST_BINS 256   // log-spaced depth bins between near_n and far_n
+#define GFT_SUPER_MAX 1024   // supertiles (groups of S x S tiles) of the tile-pull binning
 #define GFT_NEAR_SLAB_PER_TILE 896u   // wanted mean list length of the near slab
 #define GFT_NO_CUT 0x7f800000u        // +inf: every instance belongs to the near slab
 #define GFT_BLOCKHIST_TILES 2048
@@ -106,15 +110,20 @@ hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const g
 // pass 0: near slab (view z <= cut; everything with GFT_NO_CUT) + depth histogram + scan + mailbox;
 // pass 1: far slab of the tiles with a flagged quadrant (leaves at once when no quadrant was flagged)
 hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                 uint32_t* mail, uint32_t seq, uint32_t cut_bits, int pass, uint32_t cap);
+                                 uint32_t* mail, uint32_t seq, uint32_t cut_bits, int pass, uint32_t cap, int per_tile);
 hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
                                    const BinView& b, uint32_t cap, uint32_t cut_bits, int pass, int64_t expect);
+bool gft_tile_pull_ok(const gft_config& c);      // the frame's tile grid fits the supertile tables of the lazy binning
+hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
+                                uint32_t* mail, uint32_t seq, uint32_t cut_bits, int pass, uint32_t cap, int per_tile);
+hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
+                                uint32_t cap, float* clear, size_t clear_bytes);
 hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_tile_list, const ImgView& im,
                                 const BinView& b, uint32_t cap, float* clear, size_t clear_bytes);
 hipError_t gft_launch_tile_front(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b, uint32_t cap,
                                  float* clear, size_t clear_bytes);
 hipError_t gft_launch_tile_tail(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                const BinView& b, uint32_t cap);
+                                const BinView& b, uint32_t cap, uint32_t* late_mail, uint32_t seq);
 hipError_t gft_launch_tile_sort_long(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b,
                                      uint32_t cap);
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,

@@ -23,6 +23,8 @@
 // sort makes the final lists deterministic and bit-identical to the reference's.
 #include "gft_internal.h"
 
+#include <cstdlib>
+
 namespace {
 
 // BIN_THREADS / BIN_ITEMS / BIN_CHUNK: gft_internal.h (the geom layout depends on them)
@@ -813,6 +815,276 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_front(const uint2* __restric
     if (tid == 0) front_len[tile] = kf;
 }
 
+// ---- tile-pull binning of the near slab --------------------------------------------------------------------
+// With a depth cut the near slab is small (about 900 instances per tile by construction), and the count / scatter
+// kernels above spend their time on per-workgroup passes over the T-entry tile tables, not on the instances.  The
+// near slab is therefore binned the other way round: the near Gaussians are first dealt to SUPERTILES of S x S tiles
+// (k_super_count, k_super_scatter: two light passes over rect / depth with a <= 256-entry table), then one workgroup
+// per tile pulls its entries out of its supertile's list (a few thousand ids, read from L2), tests the rectangles,
+// collects the (depth, id) keys in LDS, reserves its segment of the id list with one atomic, sorts and writes it
+// (k_tile_pull).  Segments are placed in the order the tiles finish, which nothing depends on.  No per-tile
+// counters, no scan over the tiles, no key array, no separate sort launch.  A tile with more than TPULL_KEYS near
+// entries writes its ids unsorted and leaves an empty sorted head: its quadrants raise the lazy-sort flag at once
+// and k_tile_tail sorts the segment (rare by construction of the cut).
+#define TPULL_KEYS 2048u           // 16 KB of LDS: eight workgroups per CU, a frame's tiles in one round
+#define SUPER_MAX GFT_SUPER_MAX     // supertiles at most (table in LDS and in the image buffer)
+
+struct SuperArgs {
+    int P, gx, gy, T;
+    int sshift, sgx, NS;            // log2 of the supertile side in tiles, supertiles per row, supertile count
+    const ushort4* __restrict__ rect;
+    const float* __restrict__ depth;
+    uint32_t cut_bits;
+    uint32_t* st_cnt;               // [NS] entries per supertile
+    uint32_t* st_start;             // [NS] first entry of every supertile's list
+    uint32_t* st_cursor;            // [NS]
+    uint64_t* sl_ent;               // entries grouped by supertile: id | rectangle relative to the supertile (4 x 5 bits) << 32
+    uint32_t* ctrl;
+    uint32_t* mail; uint32_t seq;
+    uint32_t* dhist;
+    DepthBins db;
+    uint32_t target;
+    uint32_t cap;
+};
+
+template <int PASS>      // 0: count (+ depth histogram, totals, mailbox), 1: scatter
+__global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
+{
+    __shared__ uint32_t s_cnt[SUPER_MAX];
+    __shared__ uint32_t s_first[SUPER_MAX];
+    __shared__ uint32_t s_dh[GFT_DHIST_BINS];
+    __shared__ uint32_t s_last, s_near;
+    const int tid = threadIdx.x;
+    if (PASS == 1 && a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;        // binning buffer too small: the host re-runs stage 2
+    if (tid == 0) s_near = 0;
+    if (tid < SUPER_MAX) s_cnt[tid] = 0;
+    if (PASS == 0 && tid < GFT_DHIST_BINS) s_dh[tid] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * BIN_CHUNK;
+    ushort4 r4[BIN_ITEMS];
+    bool near[BIN_ITEMS];
+#pragma unroll
+    for (int u = 0; u < BIN_ITEMS; u++) {
+        const int idx = base + u * BIN_THREADS + tid;
+        const bool in = idx < a.P;
+        r4[u] = in ? a.rect[idx] : make_ushort4(0, 0, 0, 0);
+        const uint32_t d = in ? __float_as_uint(a.depth[idx]) : 0u;
+        const uint32_t tiles = (uint32_t)(r4[u].z - r4[u].x) * (uint32_t)(r4[u].w - r4[u].y);
+        near[u] = tiles != 0u && d <= a.cut_bits;
+        if (PASS == 0 && tiles != 0u) atomicAdd(&s_dh[depth_bin(d, a.db)], tiles);
+        if (PASS == 0 && near[u]) atomicAdd(&s_near, tiles);
+    }
+#pragma unroll
+    for (int u = 0; u < BIN_ITEMS; u++) {
+        if (!near[u]) continue;
+        const int sx0 = r4[u].x >> a.sshift, sx1 = (r4[u].z - 1) >> a.sshift, sy0 = r4[u].y >> a.sshift, sy1 = (r4[u].w - 1) >> a.sshift;
+        for (int sy = sy0; sy <= sy1; sy++)
+            for (int sx = sx0; sx <= sx1; sx++) atomicAdd(&s_cnt[sy * a.sgx + sx], 1u);
+    }
+    __syncthreads();
+    if (PASS == 0) {
+        if (tid < a.NS) {
+            const uint32_t c = s_cnt[tid];
+            if (c) atomicAdd(&a.st_cnt[tid], c);
+        }
+        static_assert(SUPER_MAX <= BIN_THREADS, "one thread per supertile");
+        if (tid < GFT_DHIST_BINS) {
+            const uint32_t h = s_dh[tid];
+            if (h) atomicAdd(&a.dhist[tid], h);
+        }
+        if (tid == 0 && s_near) atomicAdd(&a.ctrl[GFT_CTRL_NEARSUM], s_near);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(&a.ctrl[GFT_CTRL_DONE], 1u) == gridDim.x - 1 ? 1u : 0u;
+        __syncthreads();
+        if (!s_last) return;
+        // last workgroup: supertile list offsets, frame totals, next cut, mailbox
+        if (tid < GFT_DHIST_BINS) s_dh[tid] = __hip_atomic_load(&a.dhist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < SUPER_MAX) s_cnt[tid] = tid < a.NS ? __hip_atomic_load(&a.st_cnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        __syncthreads();
+        {
+            // exclusive scan of the supertile counts: one thread per supertile
+            __shared__ uint32_t s_wt[BIN_THREADS / 64];
+            const int lane = tid & 63, wave = tid >> 6;
+            const uint32_t v = tid < a.NS ? s_cnt[tid] : 0u;
+            uint32_t x = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if (lane >= d) x += y;
+            }
+            if (lane == 63) s_wt[wave] = x;
+            __syncthreads();
+            uint32_t woff = 0;
+            for (int w = 0; w < wave; w++) woff += s_wt[w];
+            if (tid < a.NS) {
+                a.st_start[tid] = woff + x - v;
+                a.st_cursor[tid] = 0;
+            }
+        }
+        if (tid == 0) {
+            uint32_t R = 0, cut_bin = GFT_DHIST_BINS;
+            for (int b = 0; b < GFT_DHIST_BINS; b++) {
+                R += s_dh[b];
+                if (cut_bin == GFT_DHIST_BINS && R >= a.target) cut_bin = (uint32_t)b;
+            }
+            uint32_t cut_next = GFT_NO_CUT;
+            if (a.target > 0u && R / 3u >= a.target && cut_bin + 1u < GFT_DHIST_BINS)
+                cut_next = __float_as_uint(a.db.near_n * exp2f((float)(cut_bin + 1u) / a.db.scale));
+            const uint32_t flags = __hip_atomic_load(&a.ctrl[GFT_CTRL_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.ctrl[GFT_CTRL_TOTAL] = R;
+            a.ctrl[GFT_CTRL_CUTNEXT] = cut_next;
+            // (TOTAL0, the near slab's instance count, and MAXCNT are accumulated by k_tile_pull)
+            if (a.mail) {
+                a.mail[GFT_CTRL_TOTAL] = R;
+                a.mail[GFT_CTRL_FLAGS] = flags;
+                a.mail[GFT_CTRL_MAXCNT] = 0u;
+                // instances of the near slab (k_tile_pull will arrive at the same sum)
+                a.mail[GFT_CTRL_TOTAL0] = __hip_atomic_load(&a.ctrl[GFT_CTRL_NEARSUM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.mail[GFT_CTRL_CUTNEXT] = cut_next;
+                __hip_atomic_store(&a.mail[GFT_CTRL_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
+    // scatter: one chunk per (workgroup, supertile)
+    if (tid < a.NS) {
+        const uint32_t c = s_cnt[tid];
+        s_first[tid] = c ? a.st_start[tid] + atomicAdd(&a.st_cursor[tid], c) : 0u;
+        s_cnt[tid] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < BIN_ITEMS; u++) {
+        if (!near[u]) continue;
+        const uint32_t idx = (uint32_t)(base + u * BIN_THREADS + tid);
+        const int sx0 = r4[u].x >> a.sshift, sx1 = (r4[u].z - 1) >> a.sshift, sy0 = r4[u].y >> a.sshift, sy1 = (r4[u].w - 1) >> a.sshift;
+        for (int sy = sy0; sy <= sy1; sy++)
+            for (int sx = sx0; sx <= sx1; sx++) {
+                const int q = sy * a.sgx + sx;
+                // the rectangle clipped to this supertile, in tiles from its corner: x0, y0 in [0, S), x1, y1 in (0, S]
+                const int ox = sx << a.sshift, oy = sy << a.sshift, S = 1 << a.sshift;
+                const uint32_t x0 = (uint32_t)max((int)r4[u].x - ox, 0), x1 = (uint32_t)min((int)r4[u].z - ox, S);
+                const uint32_t y0 = (uint32_t)max((int)r4[u].y - oy, 0), y1 = (uint32_t)min((int)r4[u].w - oy, S);
+                const uint32_t rel = x0 | (y0 << 5) | (x1 << 10) | (y1 << 15);
+                a.sl_ent[s_first[q] + atomicAdd(&s_cnt[q], 1u)] = ((uint64_t)rel << 32) | idx;
+            }
+    }
+}
+
+struct PullArgs {
+    int gx, sshift, sgx;
+    const ushort4* __restrict__ rect;
+    const float* __restrict__ depth;
+    const uint32_t* __restrict__ st_cnt;
+    const uint32_t* __restrict__ st_start;
+    const uint64_t* __restrict__ sl_ent;
+    uint2* __restrict__ ranges;
+    uint32_t* __restrict__ point_list;
+    uint32_t* __restrict__ front_len;
+    uint32_t* __restrict__ unit_flag;
+    uint32_t* ctrl;
+    uint32_t cap;
+    float4* __restrict__ clear; size_t clear_vec4;
+};
+
+__global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
+{
+    __shared__ uint64_t sk[SORT_SLOTS(TPULL_KEYS)];
+    __shared__ uint32_t s_n, s_start;
+    if (a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
+    // fire-and-forget zero fill of the backward's accumulator (as k_tile_front does)
+    if (a.clear) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t i = (size_t)blockIdx.x * GFT_BLOCK + threadIdx.x; i < a.clear_vec4; i += (size_t)gridDim.x * GFT_BLOCK)
+            a.clear[i] = z;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tile = blockIdx.x;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const int q = (ty >> a.sshift) * a.sgx + (tx >> a.sshift);
+    const uint32_t ln = a.st_cnt[q];
+    const uint64_t* __restrict__ list = a.sl_ent + a.st_start[q];
+    const uint32_t lx = (uint32_t)(tx & ((1 << a.sshift) - 1)), ly = (uint32_t)(ty & ((1 << a.sshift) - 1));
+    if (tid == 0) s_n = 0;
+    if (tid < 4) a.unit_flag[4 * tile + tid] = 0;
+    __syncthreads();
+    // pass over the supertile's list: keys of the Gaussians whose rectangle covers this tile
+    auto scan = [&](bool store_ids, uint32_t seg) {
+        for (uint32_t i0 = 0; i0 < ln; i0 += 4 * GFT_BLOCK) {
+            uint32_t id4[4];
+            uint64_t e4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * GFT_BLOCK + tid;
+                e4[u] = i < ln ? list[i] : 0ull;                     // (an all-zero rectangle covers no tile)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                id4[u] = (uint32_t)e4[u];
+                const uint32_t rel = (uint32_t)(e4[u] >> 32);
+                const bool hit = lx >= (rel & 31u) && lx < ((rel >> 10) & 31u) && ly >= ((rel >> 5) & 31u) && ly < ((rel >> 15) & 31u);
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+                if (hm == 0ull) continue;
+                uint32_t hb = 0;
+                if (lane == 0) hb = atomicAdd(&s_n, (uint32_t)__popcll(hm));
+                hb = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb);
+                if (hit) {
+                    const uint32_t pos = hb + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+                    if (store_ids) a.point_list[seg + pos] = id4[u];
+                    else if (pos < TPULL_KEYS) sk[pos] = ((uint64_t)__float_as_uint(a.depth[id4[u]]) << 32) | id4[u];
+                }
+            }
+        }
+    };
+    scan(false, 0u);
+    __syncthreads();
+    const uint32_t n = s_n;
+    __syncthreads();
+    if (tid == 0) {
+        s_start = n ? atomicAdd(&a.ctrl[GFT_CTRL_TOTAL0], n) : 0u;
+        if (n) atomicMax(&a.ctrl[GFT_CTRL_MAXCNT], n);
+        s_n = 0;
+    }
+    __syncthreads();
+    const uint32_t start = s_start;
+    if (tid == 0) {
+        a.ranges[tile] = n ? make_uint2(start, start + n) : make_uint2(0u, 0u);
+        a.front_len[tile] = n <= TPULL_KEYS ? n : 0u;         // longer: nothing sorted here, the tail sorter takes the segment
+    }
+    if (n == 0u) return;
+    if (n > TPULL_KEYS) {
+        scan(true, start);                                    // ids in arrival order
+        return;
+    }
+    uint32_t* ids = a.point_list + start;
+    if (n <= 1024u) {
+        const uint32_t npad = next_pow2(n < 2u ? 2u : n);
+        for (uint32_t i = tid + n; i < npad; i += GFT_BLOCK) sk[i] = ~0ull;
+        __syncthreads();
+        head_sort_and_store(sk, n, npad, tid, ids);
+        return;
+    }
+    // 1025 .. 2048 keys: the register-blocked network wants them at their swizzled slots
+    const uint32_t npad = 2048u;
+    static_assert(TPULL_KEYS == 2048u, "k_tile_pull sorts at most 2048 keys");
+    uint64_t mine[TPULL_KEYS / GFT_BLOCK];
+#pragma unroll
+    for (int k = 0; k < (int)(TPULL_KEYS / GFT_BLOCK); k++) {
+        const uint32_t i = tid + k * GFT_BLOCK;
+        mine[k] = i < n ? sk[i] : ~0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (int)(TPULL_KEYS / GFT_BLOCK); k++) {
+        const uint32_t i = tid + k * GFT_BLOCK;
+        if (i < npad) sk[sort_slot(i)] = mine[k];
+    }
+    __syncthreads();
+    bitonic_blocked<3, 8>(sk, tid);
+    for (uint32_t i = tid; i < n; i += GFT_BLOCK) ids[i] = (uint32_t)sk[sort_slot(i)];
+}
+
 // Long lists: 4097..16384 keys are sorted by 1024 threads with the register-blocked network in
 // 132 KB of dynamic LDS (8 or 16 keys per thread), longer ones in place in global memory with the
 // plain network.  Up to one workgroup per CU strides over the tile table.
@@ -915,11 +1187,18 @@ __global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_tail(int T, const uin
                                                                 const float* __restrict__ depth,
                                                                 const uint32_t* __restrict__ front_len,
                                                                 const uint32_t* __restrict__ unit_flag,
-                                                                const uint32_t* __restrict__ ctrl, uint32_t cap)
+                                                                const uint32_t* __restrict__ ctrl, uint32_t cap,
+                                                                uint32_t* late_mail, uint32_t seq)
 {
     extern __shared__ uint64_t sk_dyn[];
     uint64_t* sk = sk_dyn;
     if (ctrl[GFT_CTRL_TOTAL] > cap) return;
+    // late report to the host mailbox (read at the caller's next forward, never waited for): how many quadrants outlived
+    // what was sorted / binned up front -- the caller widens the near slab of the next frame when that happens
+    if (late_mail && blockIdx.x == 0 && threadIdx.x == 0) {
+        late_mail[GFT_CTRL_NFLAG] = ctrl[GFT_CTRL_NFLAG];
+        __hip_atomic_store(&late_mail[GFT_CTRL_SEQ2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (ctrl[GFT_CTRL_NFLAG] == 0u) return;
     const bool far = ctrl[GFT_CTRL_TOTAL1] != 0u;       // count pass 1 ran and found far-slab instances
     const int tid = threadIdx.x;
@@ -942,6 +1221,20 @@ __global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_tail(int T, const uin
 #define SORT_LDS_LARGE 16384u     // 128 KB of LDS (+ 4 KB of bank padding)
 #define SORT_LDS_LARGE_BYTES (SORT_SLOTS(SORT_LDS_LARGE) * 8)
 
+// wanted instances of the near slab (GFT_NEAR_SLAB_PER_TILE per tile; the environment variable of that name overrides
+// it for tuning runs)
+static uint32_t near_slab_target(int T, int per_tile_hint)
+{
+    static const uint32_t env_per_tile = [] {
+        const char* e = getenv("GFT_NEAR_SLAB_PER_TILE");
+        const long v = e ? atol(e) : 0;
+        return v > 0 ? (uint32_t)v : 0u;
+    }();
+    const uint32_t per_tile = env_per_tile ? env_per_tile : (per_tile_hint > 0 ? (uint32_t)per_tile_hint : GFT_NEAR_SLAB_PER_TILE);
+    const uint64_t t = (uint64_t)T * per_tile;
+    return t > 0xfffffffeull ? 0xfffffffeu : (uint32_t)t;
+}
+
 // Gaussians per thread of the count / scatter workgroups.  Every workgroup pays for its passes over the tile table
 // (zeroing, scan, one chunk reservation per tile); with a depth cut most Gaussians are skipped, so a workgroup takes
 // more of them while about 200 workgroups remain (5 M Gaussians @ 1080p: 1221 -> 204 workgroups of 8160-entry tables).
@@ -954,7 +1247,7 @@ static int bin_items(int P, uint32_t cut_bits)
 }
 
 hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                 uint32_t* mail, uint32_t seq, uint32_t cut_bits, int pass, uint32_t cap)
+                                 uint32_t* mail, uint32_t seq, uint32_t cut_bits, int pass, uint32_t cap, int per_tile)
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
@@ -972,7 +1265,7 @@ hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomV
     const float nr = c.near_n > 1e-6f ? c.near_n : 1e-6f;
     const float fr = c.far_n > 2.0f * nr ? c.far_n : 2.0f * nr;
     a.db.near_n = nr; a.db.inv_near = 1.0f / nr; a.db.scale = (float)GFT_DHIST_BINS / log2f(fr / nr);
-    a.target = (uint32_t)(((uint64_t)T * GFT_NEAR_SLAB_PER_TILE) > 0xfffffffeull ? 0xfffffffeull : (uint64_t)T * GFT_NEAR_SLAB_PER_TILE);
+    a.target = near_slab_target(T, per_tile);
     a.unit_flag = im.unit_flag; a.cap = cap;
     if (T <= BIN_LDS_MAX_TILES) {
         if (pass == 0) hipLaunchKernelGGL((k_tile_count<true, 0>), dim3(blocks), dim3(BIN_THREADS), (size_t)T * 4, s, a);
@@ -1028,6 +1321,71 @@ hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const Geo
     return hipGetLastError();
 }
 
+// supertile side: the smallest power of two >= 2 tiles that leaves at most SUPER_MAX supertiles
+static void super_shape(int gx, int gy, int& sshift, int& sgx, int& NS)
+{
+    sshift = 1;
+    for (;;) {
+        const int S = 1 << sshift;
+        sgx = (gx + S - 1) / S;
+        NS = sgx * ((gy + S - 1) / S);
+        if (NS <= SUPER_MAX) return;
+        sshift++;
+    }
+}
+
+// tile-pull binning packs a rectangle relative to its supertile into 4 x 5 bits: supertiles of at most 16 x 16 tiles
+bool gft_tile_pull_ok(const gft_config& c)
+{
+    const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    int sshift, sgx, NS;
+    super_shape(gx, gy, sshift, sgx, NS);
+    return sshift <= 4;
+}
+
+// pass 0: count (+ depth histogram, totals, mailbox); pass 1: scatter of the near Gaussians' ids to their supertiles
+hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
+                                uint32_t* mail, uint32_t seq, uint32_t cut_bits, int pass, uint32_t cap, int per_tile)
+{
+    const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    SuperArgs a;
+    a.P = c.P; a.gx = gx; a.gy = gy; a.T = gx * gy;
+    super_shape(gx, gy, a.sshift, a.sgx, a.NS);
+    a.rect = g.rect; a.depth = g.depth; a.cut_bits = cut_bits;
+    a.st_cnt = im.super_tab; a.st_start = im.super_tab + SUPER_MAX; a.st_cursor = im.super_tab + 2 * SUPER_MAX;
+    // the supertile lists live in the key array, which this path does not use otherwise (`cap` 8-byte entries; there
+    // are at most as many (Gaussian, supertile) pairs as (Gaussian, tile) instances); the far pass reuses it later
+    a.sl_ent = pass == 1 ? b.keys : nullptr;
+    a.ctrl = im.ctrl; a.mail = mail; a.seq = seq; a.dhist = im.dhist;
+    const float nr = c.near_n > 1e-6f ? c.near_n : 1e-6f;
+    const float fr = c.far_n > 2.0f * nr ? c.far_n : 2.0f * nr;
+    a.db.near_n = nr; a.db.inv_near = 1.0f / nr; a.db.scale = (float)GFT_DHIST_BINS / log2f(fr / nr);
+    a.target = near_slab_target(a.T, per_tile);
+    a.cap = cap;
+    const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
+    if (pass == 0) hipLaunchKernelGGL(k_super_bin<0>, dim3(blocks), dim3(BIN_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_super_bin<1>, dim3(blocks), dim3(BIN_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
+                                uint32_t cap, float* clear, size_t clear_bytes)
+{
+    const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    PullArgs a;
+    int NS;
+    a.gx = gx;
+    super_shape(gx, gy, a.sshift, a.sgx, NS);
+    a.rect = g.rect; a.depth = g.depth;
+    a.st_cnt = im.super_tab; a.st_start = im.super_tab + SUPER_MAX;
+    a.sl_ent = b.keys;
+    a.ranges = im.ranges; a.point_list = b.point_list; a.front_len = im.front_len; a.unit_flag = im.unit_flag;
+    a.ctrl = im.ctrl; a.cap = cap;
+    a.clear = reinterpret_cast<float4*>(clear); a.clear_vec4 = clear_bytes / 16;
+    hipLaunchKernelGGL(k_tile_pull, dim3(gx * gy), dim3(GFT_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_tile_list, const ImgView& im,
                                 const BinView& b, uint32_t cap, float* clear, size_t clear_bytes)
 {
@@ -1052,7 +1410,7 @@ hipError_t gft_launch_tile_front(hipStream_t s, const gft_config& c, const ImgVi
 }
 
 hipError_t gft_launch_tile_tail(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                const BinView& b, uint32_t cap)
+                                const BinView& b, uint32_t cap, uint32_t* late_mail, uint32_t seq)
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
@@ -1062,7 +1420,7 @@ hipError_t gft_launch_tile_tail(hipStream_t s, const gft_config& c, const GeomVi
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_tile_tail, dim3(T < 256 ? T : 256), dim3(SORT_BIG_THREADS), (size_t)SORT_LDS_LARGE_BYTES, s, T,
-                       im.ranges, im.ranges1, b.keys, b.point_list, g.depth, im.front_len, im.unit_flag, im.ctrl, cap);
+                       im.ranges, im.ranges1, b.keys, b.point_list, g.depth, im.front_len, im.unit_flag, im.ctrl, cap, late_mail, seq);
     return hipGetLastError();
 }
 

@@ -181,6 +181,7 @@ typedef struct gft_layout {
     size_t img_tile_cnt1;     /* uint32[T]    lazy binning: far-slab instances of the tiles that asked for them */
     size_t img_dhist;         /* uint32[256]  instances per log-depth bin (choice of the next depth cut) */
     size_t img_ranges1;       /* uint2[T]     lazy binning: [first,last) of every tile's far-slab segment */
+    size_t img_super_tab;     /* uint32[3][1024] lazy binning: per supertile (S x S tiles) entry count, list start, cursor */
     size_t img_tile_cursor;   /* uint32[T]    scatter cursors */
     size_t img_tile_order;    /* uint32[T]    tiles by backward weight (written by gft_backward) */
     size_t img_front_len;     /* uint32[T]    length of the sorted head of the tile's id list (lazy sort) */
@@ -240,7 +241,8 @@ typedef struct gft_forward_hints {
     int64_t max_tile_list;       /* guess of the longest per-tile list (e.g. last frame's, with margin; <= 0 = unknown) */
     int64_t near_instances;      /* lazy binning: guess of the near slab's instance count (<= 0 = unknown) */
     float depth_cut;             /* lazy binning: view-space depth of the near slab's far side; <= 0 = bin every instance */
-    float reserved;
+    int32_t near_per_tile;       /* lazy binning: instances per tile the suggested next cut should leave in the near slab
+                                    (<= 0: the default, 896); raise it when gft_forward_late() reports flagged quadrants */
 } gft_forward_hints;
 
 /* What the device reported while the forward was running. */
@@ -249,7 +251,9 @@ typedef struct gft_forward_report {
     int64_t max_tile_list;       /* longest per-tile list that was binned up front */
     int64_t near_instances;      /* instances binned up front (== num_rendered without a depth cut) */
     float depth_cut_next;        /* depth cut this frame suggests for the next one (0 = bin every instance) */
-    float reserved;
+    int32_t late_slot;           /* handle of the late report, see gft_forward_late() */
+    uint32_t late_seq;
+    uint32_t reserved;
 } gft_forward_report;
 
 /* The forward in one call, for callers that can guess R (a training loop: R of the
@@ -273,6 +277,11 @@ typedef struct gft_forward_report {
  * Results are identical to the two-stage flow in every case (same lists, same arithmetic order). */
 int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
                 const gft_forward_hints* hints, gft_forward_report* report /*host*/);
+
+/* Late report of a gft_forward(), written by the device near the end of that forward and never waited for: the
+ * number of pixel quadrants that ran out of up-front sorted / binned entries before saturating (each costs a second
+ * pass).  *flagged_quadrants = -1 while it has not arrived (or after 256 further forwards have reused its slot). */
+int gft_forward_late(int32_t late_slot, uint32_t late_seq, int64_t* flagged_quadrants /*host*/);
 
 /* The backward of the forward whose scratch buffers `io` carries.  Gradient sums are added with float atomics
  * (as in the reference), so two runs agree to rounding, not bit for bit.  GFT_BWD_SPLIT=0 in the environment

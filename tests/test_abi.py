@@ -90,7 +90,7 @@ def test_size_queries_and_layout_need_no_gpu(lib):
     offs = [getattr(L, n) for n in _lib.LAYOUT_FIELDS]
     # every region is 256-B aligned, except tile_cnt which directly follows the 64-B ctrl block
     # (the ctrl words, both slabs' tile counters and the depth histogram are contiguous: one clear)
-    assert all(o % 256 == 0 for n, o in zip(_lib.LAYOUT_FIELDS, offs) if n not in ("img_tile_cnt", "img_tile_cnt1", "img_dhist"))
+    assert all(o % 256 == 0 for n, o in zip(_lib.LAYOUT_FIELDS, offs) if n not in ("img_tile_cnt", "img_tile_cnt1", "img_dhist", "img_super_tab"))
     assert L.img_tile_cnt == L.img_ctrl + 64 and L.img_tile_cnt1 == L.img_tile_cnt + 4 * 1200
     assert L.img_dhist == L.img_tile_cnt1 + 4 * 1200
     assert L.geom_rec_b >= 32 * 1000 and L.bin_point_list >= 8 * 5000 and L.bin_total >= 12 * 5000

@@ -526,6 +526,21 @@ def test_lazy_binning_cut_suggestion(gpu):
         assert 0.8 * 896 * T <= st["near_instances"] <= 1.6 * 896 * T, st
         for k in first:
             np.testing.assert_array_equal(out[k], first[k], err_msg=k)
+    key = next(iter(api._instance_hint))
+    before = api._slab_state[key]["per_tile"]
+    assert before >= 896
+    # a cut that is too shallow: quadrants outlive the near slab; the device reports them late (never waited for), the
+    # frame after reads the report and asks for a wider near slab
+    h = api._instance_hint[key]
+    api._instance_hint[key] = (h[0], h[1], 1.02, 0)
+    out, _, _ = Hh.run_gpu(dense, gpu, backward=False)
+    for k in first:
+        np.testing.assert_array_equal(out[k], first[k], err_msg=k)
+    torch.cuda.synchronize()
+    Hh.run_gpu(dense, gpu, backward=False)
+    assert api._slab_state[key]["per_tile"] > before and api._slab_state[key]["clean"] == 0
+    Hh.run_gpu(dense, gpu, backward=False)
+    assert api.last_call_stats["near_per_tile"] > before
 
 
 LAZY_CASES = {
