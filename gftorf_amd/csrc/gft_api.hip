@@ -53,7 +53,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->img_tile_cnt = o;    o += T * 4;                       // ... and so are the far-slab counters and the depth histogram
     L->img_tile_cnt1 = o;   o += T * 4;
     L->img_dhist = o;       o += GFT_DHIST_BINS * 4;
-    L->img_super_tab = o;   o = align_up(o + 3 * GFT_SUPER_MAX * 4);    // (cleared with them: the supertile counters are accumulated)
+    L->img_super_tab = o;   o = align_up(o + 5 * GFT_SUPER_MAX * 4);    // (cleared with them: the supertile counters are accumulated)
     L->img_ranges1 = o;     o = align_up(o + T * 8);
     L->img_tile_cursor = o; o = align_up(o + T * 4);
     L->img_tile_order = o;  o = align_up(o + T * 4);
@@ -292,6 +292,7 @@ static int mailbox_acquire(uint32_t** dev_slot, volatile uint32_t** host_slot, u
     *seq = g_mail.next;
     *dev_slot = g_mail.dev + (size_t)slot * GFT_CTRL_WORDS;
     *host_slot = g_mail.host + (size_t)slot * GFT_CTRL_WORDS;
+    g_mail.host[(size_t)slot * GFT_CTRL_WORDS + GFT_CTRL_FLAGS] = 0u;     // the preprocess kernel ORs into it
     return 0;
 }
 
@@ -341,6 +342,12 @@ static int check_stage2(const gft_forward_io* io, const char* who)
 }
 
 static bool lazy_sort_enabled();
+// tuning switch: the backward accumulator's zero fill rides with the render kernel instead of the tile-pull kernel
+static bool clear_in_render()
+{
+    static const bool on = [] { const char* e = getenv("GFT_CLEAR_IN_RENDER"); return e ? atoi(e) != 0 : false; }();
+    return on;
+}
 
 // GFT_LAZY_BIN=0 in the environment bins every instance up front (no depth cut); results are identical.
 static bool lazy_bin_enabled()
@@ -363,13 +370,10 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
                           const ImgView& im, uint32_t* mail_dev, uint32_t seq, uint32_t cut_bits, int per_tile = 0)
 {
     {
-        // ctrl words, per-tile counters of both slabs and the depth histogram: one clear
-        const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
-        GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, (GFT_CTRL_WORDS + 2 * (size_t)gx * gy + GFT_DHIST_BINS + 3 * GFT_SUPER_MAX) * sizeof(uint32_t), s));
-    }
-    {
+        // (the preprocess kernel also zeroes the ctrl words, the tile counters of both slabs, the depth histogram and
+        // the supertile table for the binning kernels behind it: no fill launch)
         StageTimer t(s, ST_PRE_FWD);
-        GFT_STAGE(s, cfg, "preprocess_fwd", gft_launch_preprocess_fwd(s, *cfg, *io, g, im));
+        GFT_STAGE(s, cfg, "preprocess_fwd", gft_launch_preprocess_fwd(s, *cfg, *io, g, im, mail_dev));
     }
     {
         StageTimer t(s, ST_TILE_COUNT);
@@ -415,7 +419,8 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
         }
         {
             StageTimer t(s, ST_TILE_SORT);
-            GFT_STAGE(s, cfg, "tile_pull", gft_launch_tile_pull(s, *cfg, g, im, b, cap, clear, clear_bytes));
+            GFT_STAGE(s, cfg, "tile_pull", gft_launch_tile_pull(s, *cfg, g, im, b, cap, clear_in_render() ? nullptr : clear,
+                                                                clear_in_render() ? 0 : clear_bytes));
         }
     } else if (binned) {
         {
@@ -434,7 +439,10 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
     }
     {
         StageTimer t(s, ST_RENDER_FWD);
-        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, check_cap, cap, lazy ? 1 : 0));
+        // (tile-pull path: the accumulator clear rides with the render kernel, whose HBM traffic is small)
+        const bool pull = binned && cut_bits != GFT_NO_CUT && clear_in_render();
+        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, check_cap, cap, lazy ? 1 : 0,
+                                                              pull ? clear : nullptr, pull ? clear_bytes : 0));
     }
     if (lazy) {
         // quadrants that used up the sorted head of their list: sort those tails, continue those quadrants

@@ -48,7 +48,7 @@ struct ImgView {
     uint32_t* tile_cnt1;  // [T]  lazy binning: instances per flagged tile of the far slab
     uint32_t* dhist;      // [GFT_DHIST_BINS] instances per log-depth bin (picks the next frame's depth cut)
     uint2* ranges1;       // [T]  lazy binning: far-slab segment of every tile (valid once a quadrant was flagged)
-    uint32_t* super_tab;  // [3][256] lazy binning: count, list start and scatter cursor of every supertile
+    uint32_t* super_tab;  // [5][GFT_SUPER_MAX] lazy binning: per supertile entry count, list start, scatter cursor, id-list region, cursor
     uint32_t* tile_cursor;// [T]
     uint32_t* tile_order; // [T] tiles by backward weight, heaviest first (written by the backward)
     uint32_t* front_len;  // [T] lazy sort: length of the sorted head of the tile's id list
@@ -106,7 +106,7 @@ int gft_fail(const char* fmt, ...);
 
 // ---- stage launchers (each enqueues on `s`, returns hipError_t) -----------
 hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
-                                     const GeomView& g, const ImgView& im);
+                                     const GeomView& g, const ImgView& im, uint32_t* mail);
 // pass 0: near slab (view z <= cut; everything with GFT_NO_CUT) + depth histogram + scan + mailbox;
 // pass 1: far slab of the tiles with a flagged quadrant (leaves at once when no quadrant was flagged)
 hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
@@ -128,7 +128,7 @@ hipError_t gft_launch_tile_sort_long(hipStream_t s, const gft_config& c, const I
                                      uint32_t cap);
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b, bool check_cap, uint32_t cap,
-                                 int lazy);
+                                 int lazy, float* clear = nullptr, size_t clear_bytes = 0);
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b);
 hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,

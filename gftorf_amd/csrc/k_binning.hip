@@ -65,6 +65,38 @@ __device__ __forceinline__ int depth_bin(uint32_t dbits, const DepthBins& db)
     return i < 0 ? 0 : (i >= GFT_DHIST_BINS ? GFT_DHIST_BINS - 1 : i);
 }
 
+// Total of the depth histogram h[GFT_DHIST_BINS] (LDS) and the first bin at which the running count reaches `target`
+// (GFT_DHIST_BINS when it never does).  Called by all threads of a workgroup of >= GFT_DHIST_BINS threads.
+__device__ void dhist_scan(const uint32_t* h, uint32_t target, uint32_t& total, uint32_t& cut_bin)
+{
+    __shared__ uint32_t s_w[GFT_DHIST_BINS / 64];
+    __shared__ uint32_t s_cut;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t v = 0, x = 0;
+    if (tid < GFT_DHIST_BINS) {
+        v = h[tid];
+        x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_w[wave] = x;
+    }
+    if (tid == 0) s_cut = GFT_DHIST_BINS;
+    __syncthreads();
+    uint32_t tot = 0;
+    for (int w = 0; w < GFT_DHIST_BINS / 64; w++) tot += s_w[w];
+    if (tid < GFT_DHIST_BINS) {
+        uint32_t incl = x;
+        for (int w = 0; w < wave; w++) incl += s_w[w];
+        if (incl >= target && incl - v < target) s_cut = (uint32_t)tid;       // the one bin where the count crosses
+    }
+    __syncthreads();
+    total = tot;
+    cut_bin = s_cut;
+}
+
 // Exclusive scan of tile_cnt by one workgroup (the last one of k_tile_count): ranges (offset by `base`), zeroed
 // cursors; returns the total and the longest list to thread 0.
 __device__ void tile_scan_block(int T, const uint32_t* tile_cnt, uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
@@ -235,26 +267,20 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_count(CountArgs a)
     __shared__ uint32_t s_cum[GFT_DHIST_BINS];
     if (tid < GFT_DHIST_BINS) s_cum[tid] = __hip_atomic_load(&a.dhist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    uint32_t R, cut_bin;
+    dhist_scan(s_cum, a.target, R, cut_bin);
     if (tid == 0) {
-        uint32_t run = 0, cut_bin = GFT_DHIST_BINS;
-        for (int b = 0; b < GFT_DHIST_BINS; b++) {
-            run += s_cum[b];
-            if (cut_bin == GFT_DHIST_BINS && run >= a.target) cut_bin = (uint32_t)b;
-        }
-        const uint32_t R = run;
         uint32_t cut_next = GFT_NO_CUT;
         // (a cut pays when the near slab is a small part of the frame: with R below 3 x the target too many
         // quadrants outlive the near slab and the second pass costs more than the first one saved)
         if (a.target > 0u && R / 3u >= a.target && cut_bin + 1u < GFT_DHIST_BINS)
             cut_next = __float_as_uint(a.db.near_n * exp2f((float)(cut_bin + 1u) / a.db.scale));
-        const uint32_t flags = __hip_atomic_load(&a.ctrl[GFT_CTRL_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.ctrl[GFT_CTRL_TOTAL] = R;
         a.ctrl[GFT_CTRL_TOTAL0] = total;
         a.ctrl[GFT_CTRL_MAXCNT] = longest;
         a.ctrl[GFT_CTRL_CUTNEXT] = cut_next;
         if (a.mail) {
-            a.mail[GFT_CTRL_TOTAL] = R;
-            a.mail[GFT_CTRL_FLAGS] = flags;
+            a.mail[GFT_CTRL_TOTAL] = R;          // (GFT_CTRL_FLAGS of the slot belongs to the preprocess kernel)
             a.mail[GFT_CTRL_MAXCNT] = longest;
             a.mail[GFT_CTRL_TOTAL0] = total;
             a.mail[GFT_CTRL_CUTNEXT] = cut_next;
@@ -838,6 +864,8 @@ struct SuperArgs {
     uint32_t* st_cnt;               // [NS] entries per supertile
     uint32_t* st_start;             // [NS] first entry of every supertile's list
     uint32_t* st_cursor;            // [NS]
+    uint32_t* st_inst;              // [NS] (Gaussian, tile) instances inside the supertile, then the first id-list slot of it
+    uint32_t* st_icur;              // [NS] slots of the supertile's id-list region taken by its tiles
     uint64_t* sl_ent;               // entries grouped by supertile: id | rectangle relative to the supertile (4 x 5 bits) << 32
     uint32_t* ctrl;
     uint32_t* mail; uint32_t seq;
@@ -851,13 +879,13 @@ template <int PASS>      // 0: count (+ depth histogram, totals, mailbox), 1: sc
 __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
 {
     __shared__ uint32_t s_cnt[SUPER_MAX];
-    __shared__ uint32_t s_first[SUPER_MAX];
+    __shared__ uint32_t s_first[SUPER_MAX];         // pass 0: instances per supertile; pass 1: first entry of this workgroup's chunk
     __shared__ uint32_t s_dh[GFT_DHIST_BINS];
     __shared__ uint32_t s_last, s_near;
     const int tid = threadIdx.x;
     if (PASS == 1 && a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;        // binning buffer too small: the host re-runs stage 2
     if (tid == 0) s_near = 0;
-    if (tid < SUPER_MAX) s_cnt[tid] = 0;
+    if (tid < SUPER_MAX) { s_cnt[tid] = 0; s_first[tid] = 0; }
     if (PASS == 0 && tid < GFT_DHIST_BINS) s_dh[tid] = 0;
     __syncthreads();
     const int base = blockIdx.x * BIN_CHUNK;
@@ -879,13 +907,25 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         if (!near[u]) continue;
         const int sx0 = r4[u].x >> a.sshift, sx1 = (r4[u].z - 1) >> a.sshift, sy0 = r4[u].y >> a.sshift, sy1 = (r4[u].w - 1) >> a.sshift;
         for (int sy = sy0; sy <= sy1; sy++)
-            for (int sx = sx0; sx <= sx1; sx++) atomicAdd(&s_cnt[sy * a.sgx + sx], 1u);
+            for (int sx = sx0; sx <= sx1; sx++) {
+                atomicAdd(&s_cnt[sy * a.sgx + sx], 1u);
+                if (PASS == 0) {
+                    // tiles of the rectangle inside this supertile: its tiles reserve their id-list segments in a region
+                    // of exactly that size (no frame-wide counter for 1200 workgroups to queue on)
+                    const int S = 1 << a.sshift;
+                    const int nx = min((int)r4[u].z, (sx + 1) * S) - max((int)r4[u].x, sx * S);
+                    const int ny = min((int)r4[u].w, (sy + 1) * S) - max((int)r4[u].y, sy * S);
+                    atomicAdd(&s_first[sy * a.sgx + sx], (uint32_t)(nx * ny));
+                }
+            }
     }
     __syncthreads();
     if (PASS == 0) {
         if (tid < a.NS) {
             const uint32_t c = s_cnt[tid];
             if (c) atomicAdd(&a.st_cnt[tid], c);
+            const uint32_t ci = s_first[tid];
+            if (ci) atomicAdd(&a.st_inst[tid], ci);
         }
         static_assert(SUPER_MAX <= BIN_THREADS, "one thread per supertile");
         if (tid < GFT_DHIST_BINS) {
@@ -900,47 +940,43 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         if (!s_last) return;
         // last workgroup: supertile list offsets, frame totals, next cut, mailbox
         if (tid < GFT_DHIST_BINS) s_dh[tid] = __hip_atomic_load(&a.dhist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < SUPER_MAX) s_cnt[tid] = tid < a.NS ? __hip_atomic_load(&a.st_cnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        __syncthreads();
         {
-            // exclusive scan of the supertile counts: one thread per supertile
-            __shared__ uint32_t s_wt[BIN_THREADS / 64];
+            // exclusive scans of the supertile entry counts and instance counts: one thread per supertile
+            __shared__ uint32_t s_wt[2][BIN_THREADS / 64];
             const int lane = tid & 63, wave = tid >> 6;
-            const uint32_t v = tid < a.NS ? s_cnt[tid] : 0u;
-            uint32_t x = v;
+            const uint32_t v = tid < a.NS ? __hip_atomic_load(&a.st_cnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const uint32_t vi = tid < a.NS ? __hip_atomic_load(&a.st_inst[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            uint32_t x = v, xi = vi;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d, 64);
-                if (lane >= d) x += y;
+                const uint32_t y = __shfl_up(x, d, 64), yi = __shfl_up(xi, d, 64);
+                if (lane >= d) { x += y; xi += yi; }
             }
-            if (lane == 63) s_wt[wave] = x;
+            if (lane == 63) { s_wt[0][wave] = x; s_wt[1][wave] = xi; }
             __syncthreads();
-            uint32_t woff = 0;
-            for (int w = 0; w < wave; w++) woff += s_wt[w];
+            uint32_t woff = 0, woffi = 0;
+            for (int w = 0; w < wave; w++) { woff += s_wt[0][w]; woffi += s_wt[1][w]; }
             if (tid < a.NS) {
                 a.st_start[tid] = woff + x - v;
                 a.st_cursor[tid] = 0;
+                a.st_inst[tid] = woffi + xi - vi;       // from here on: first id-list slot of the supertile's region
+                a.st_icur[tid] = 0;
             }
         }
+        uint32_t R, cut_bin;
+        dhist_scan(s_dh, a.target, R, cut_bin);
         if (tid == 0) {
-            uint32_t R = 0, cut_bin = GFT_DHIST_BINS;
-            for (int b = 0; b < GFT_DHIST_BINS; b++) {
-                R += s_dh[b];
-                if (cut_bin == GFT_DHIST_BINS && R >= a.target) cut_bin = (uint32_t)b;
-            }
             uint32_t cut_next = GFT_NO_CUT;
             if (a.target > 0u && R / 3u >= a.target && cut_bin + 1u < GFT_DHIST_BINS)
                 cut_next = __float_as_uint(a.db.near_n * exp2f((float)(cut_bin + 1u) / a.db.scale));
-            const uint32_t flags = __hip_atomic_load(&a.ctrl[GFT_CTRL_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t near_total = __hip_atomic_load(&a.ctrl[GFT_CTRL_NEARSUM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.ctrl[GFT_CTRL_TOTAL] = R;
+            a.ctrl[GFT_CTRL_TOTAL0] = near_total;      // instances of the near slab = sum of the supertile regions
             a.ctrl[GFT_CTRL_CUTNEXT] = cut_next;
-            // (TOTAL0, the near slab's instance count, and MAXCNT are accumulated by k_tile_pull)
             if (a.mail) {
                 a.mail[GFT_CTRL_TOTAL] = R;
-                a.mail[GFT_CTRL_FLAGS] = flags;
                 a.mail[GFT_CTRL_MAXCNT] = 0u;
-                // instances of the near slab (k_tile_pull will arrive at the same sum)
-                a.mail[GFT_CTRL_TOTAL0] = __hip_atomic_load(&a.ctrl[GFT_CTRL_NEARSUM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.mail[GFT_CTRL_TOTAL0] = near_total;
                 a.mail[GFT_CTRL_CUTNEXT] = cut_next;
                 __hip_atomic_store(&a.mail[GFT_CTRL_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -972,12 +1008,45 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
     }
 }
 
+// 513 .. 1024 keys in sk[0, 1024) (pads = ~0): every wave sorts its quarter of 256 keys in registers, then the four
+// sorted runs are merged by rank: a key's place in the list = its place in its own run + the number of smaller keys in
+// each of the three other runs (binary searches in LDS; keys are distinct -- the id is their low half).  No merge
+// network: 24 LDS reads per key instead of 19 workgroup-wide compare-exchange stages with a barrier each.
+__device__ __forceinline__ void sort1024_by_rank_and_store(uint64_t* sk, uint32_t n, int tid, uint32_t* __restrict__ ids)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    bitonic_blocked<2, 6, WaveSync>(sk + 256 * wave, lane, WaveSync());
+    __syncthreads();
+    auto at = [&](int run, uint32_t i) { return sk[256 * run + sort_slot(i)]; };     // key i of a sorted run
+#pragma unroll
+    for (int run = 0; run < 4; run++) {
+        const uint64_t key = at(run, (uint32_t)tid);
+        if (key == ~0ull) continue;                      // padding
+        uint32_t rank = (uint32_t)tid;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            if (o == run) continue;
+            // number of keys of run o below `key`
+            uint32_t lo = 0;
+#pragma unroll
+            for (uint32_t step = 128; step > 0; step >>= 1)
+                if (at(o, lo + step - 1) < key) lo += step;
+            if (at(o, lo) < key) lo++;                   // (lo <= 255 here)
+            rank += lo;
+        }
+        ids[rank] = (uint32_t)key;
+    }
+    (void)n;
+}
+
 struct PullArgs {
     int gx, sshift, sgx;
     const ushort4* __restrict__ rect;
     const float* __restrict__ depth;
     const uint32_t* __restrict__ st_cnt;
     const uint32_t* __restrict__ st_start;
+    const uint32_t* __restrict__ st_inst;       // first id-list slot of every supertile's region
+    uint32_t* st_icur;
     const uint64_t* __restrict__ sl_ent;
     uint2* __restrict__ ranges;
     uint32_t* __restrict__ point_list;
@@ -1019,21 +1088,33 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
                 const uint32_t i = i0 + u * GFT_BLOCK + tid;
                 e4[u] = i < ln ? list[i] : 0ull;                     // (an all-zero rectangle covers no tile)
             }
+            // hits of the four entries: one LDS atomic reserves the slots of all of them, the depth gathers of the
+            // hits are issued together
+            bool hit[4];
+            unsigned long long hm[4];
+            uint32_t off[4], cnt = 0;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 id4[u] = (uint32_t)e4[u];
                 const uint32_t rel = (uint32_t)(e4[u] >> 32);
-                const bool hit = lx >= (rel & 31u) && lx < ((rel >> 10) & 31u) && ly >= ((rel >> 5) & 31u) && ly < ((rel >> 15) & 31u);
-                const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
-                if (hm == 0ull) continue;
-                uint32_t hb = 0;
-                if (lane == 0) hb = atomicAdd(&s_n, (uint32_t)__popcll(hm));
-                hb = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb);
-                if (hit) {
-                    const uint32_t pos = hb + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
-                    if (store_ids) a.point_list[seg + pos] = id4[u];
-                    else if (pos < TPULL_KEYS) sk[pos] = ((uint64_t)__float_as_uint(a.depth[id4[u]]) << 32) | id4[u];
-                }
+                hit[u] = lx >= (rel & 31u) && lx < ((rel >> 10) & 31u) && ly >= ((rel >> 5) & 31u) && ly < ((rel >> 15) & 31u);
+                hm[u] = __builtin_amdgcn_ballot_w64(hit[u]);
+                off[u] = cnt;
+                cnt += (uint32_t)__popcll(hm[u]);
+            }
+            if (cnt == 0u) continue;                                 // wave-uniform
+            uint32_t hb = 0;
+            if (lane == 0) hb = atomicAdd(&s_n, cnt);
+            hb = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb);
+            uint32_t d4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) d4[u] = (hit[u] && !store_ids) ? __float_as_uint(a.depth[id4[u]]) : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!hit[u]) continue;
+                const uint32_t pos = hb + off[u] + (uint32_t)__popcll(hm[u] & ((1ull << lane) - 1ull));
+                if (store_ids) a.point_list[seg + pos] = id4[u];
+                else if (pos < TPULL_KEYS) sk[pos] = ((uint64_t)d4[u] << 32) | id4[u];
             }
         }
     };
@@ -1042,8 +1123,8 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
     const uint32_t n = s_n;
     __syncthreads();
     if (tid == 0) {
-        s_start = n ? atomicAdd(&a.ctrl[GFT_CTRL_TOTAL0], n) : 0u;
-        if (n) atomicMax(&a.ctrl[GFT_CTRL_MAXCNT], n);
+        // the tile's segment: inside its supertile's region, in the order its (at most S x S) tiles arrive
+        s_start = n ? a.st_inst[q] + atomicAdd(&a.st_icur[q], n) : 0u;
         s_n = 0;
     }
     __syncthreads();
@@ -1062,7 +1143,8 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
         const uint32_t npad = next_pow2(n < 2u ? 2u : n);
         for (uint32_t i = tid + n; i < npad; i += GFT_BLOCK) sk[i] = ~0ull;
         __syncthreads();
-        head_sort_and_store(sk, n, npad, tid, ids);
+        if (npad == 1024u) sort1024_by_rank_and_store(sk, n, tid, ids);
+        else head_sort_and_store(sk, n, npad, tid, ids);
         return;
     }
     // 1025 .. 2048 keys: the register-blocked network wants them at their swizzled slots
@@ -1238,10 +1320,12 @@ static uint32_t near_slab_target(int T, int per_tile_hint)
 // Gaussians per thread of the count / scatter workgroups.  Every workgroup pays for its passes over the tile table
 // (zeroing, scan, one chunk reservation per tile); with a depth cut most Gaussians are skipped, so a workgroup takes
 // more of them while about 200 workgroups remain (5 M Gaussians @ 1080p: 1221 -> 204 workgroups of 8160-entry tables).
-static int bin_items(int P, uint32_t cut_bits)
+static int bin_items(int P, uint32_t cut_bits, int pass)
 {
     if (cut_bits == GFT_NO_CUT) return BIN_ITEMS;
-    const int by_blocks = P / (BIN_THREADS * 200);
+    // (far pass: it only does something after a quadrant outlived the near slab, which the cut makes rare: about 48 big
+    // workgroups, so that its launches cost little when they find nothing to do)
+    const int by_blocks = P / (BIN_THREADS * (pass == 1 ? 48 : 200));
     const int it = by_blocks < BIN_ITEMS ? BIN_ITEMS : (by_blocks > 60 ? 60 : by_blocks);      // (u16 per-tile counts per workgroup)
     return it / BIN_ITEMS * BIN_ITEMS;
 }
@@ -1252,7 +1336,7 @@ hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomV
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
     CountArgs a;
-    a.items = bin_items(c.P, cut_bits);
+    a.items = bin_items(c.P, cut_bits, pass);
     const int blocks = (c.P + BIN_THREADS * a.items - 1) / (BIN_THREADS * a.items);
     a.P = c.P; a.gx = gx; a.T = T;
     a.rect = g.rect; a.depth = g.depth; a.cut_bits = cut_bits;
@@ -1283,7 +1367,7 @@ hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const Geo
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
     ScatterArgs a;
-    a.items = bin_items(c.P, cut_bits);
+    a.items = bin_items(c.P, cut_bits, pass);
     const int blocks = (c.P + BIN_THREADS * a.items - 1) / (BIN_THREADS * a.items);
     a.P = c.P; a.gx = gx; a.T = T;
     a.rect = g.rect; a.depth = g.depth;
@@ -1353,6 +1437,7 @@ hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomVi
     super_shape(gx, gy, a.sshift, a.sgx, a.NS);
     a.rect = g.rect; a.depth = g.depth; a.cut_bits = cut_bits;
     a.st_cnt = im.super_tab; a.st_start = im.super_tab + SUPER_MAX; a.st_cursor = im.super_tab + 2 * SUPER_MAX;
+    a.st_inst = im.super_tab + 3 * SUPER_MAX; a.st_icur = im.super_tab + 4 * SUPER_MAX;
     // the supertile lists live in the key array, which this path does not use otherwise (`cap` 8-byte entries; there
     // are at most as many (Gaussian, supertile) pairs as (Gaussian, tile) instances); the far pass reuses it later
     a.sl_ent = pass == 1 ? b.keys : nullptr;
@@ -1378,6 +1463,7 @@ hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomVi
     super_shape(gx, gy, a.sshift, a.sgx, NS);
     a.rect = g.rect; a.depth = g.depth;
     a.st_cnt = im.super_tab; a.st_start = im.super_tab + SUPER_MAX;
+    a.st_inst = im.super_tab + 3 * SUPER_MAX; a.st_icur = im.super_tab + 4 * SUPER_MAX;
     a.sl_ent = b.keys;
     a.ranges = im.ranges; a.point_list = b.point_list; a.front_len = im.front_len; a.unit_flag = im.unit_flag;
     a.ctrl = im.ctrl; a.cap = cap;

@@ -415,7 +415,9 @@ struct PreFwdArgs {
     gft_config c;
     gft_forward_io io;
     GeomView g;
-    uint32_t* ctrl;
+    uint32_t* ctrl;            // ctrl words + the counters behind them: cleared here (clear_words), used from the next kernel on
+    uint32_t clear_words;
+    uint32_t* mail;            // host mailbox slot: the "prefiltered point culled" flag goes straight there
     float focal_x, focal_y, dist2phase;
     int gx, gy;
     int stage_sh, stage_shp;   // SH rows staged through LDS (M == 16)
@@ -427,6 +429,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const int P = a.c.P;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the binning kernels' counters (ctrl words, tile counters, depth histogram, supertile table): zeroed here instead
+    // of by a separate fill launch; nothing in this kernel reads or writes them
+    for (uint32_t w = (uint32_t)idx; w < a.clear_words; w += gridDim.x * PRE_BLOCK) a.ctrl[w] = 0u;
     float4* sh_l = lds_rows + wave * ((a.stage_sh ? 64 * SH_ROW_PAD : 0) + (a.stage_shp ? 64 * SHP_ROW_PAD : 0));
     float4* shp_l = sh_l + (a.stage_sh ? 64 * SH_ROW_PAD : 0);
     if (a.stage_sh | a.stage_shp) {
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
         const Mat16 V = load_mat(a.io.viewmatrix);
         const float vz = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
         if (vz < a.c.near_n || vz > a.c.far_n) {
-            if (a.c.prefiltered) atomicOr(&a.ctrl[GFT_CTRL_FLAGS], 1u);
+            if (a.c.prefiltered && a.mail) __hip_atomic_fetch_or(&a.mail[GFT_CTRL_FLAGS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
             const float vx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
             const float vy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
@@ -994,13 +999,19 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_mark_visible(int P, const float* 
 }  // namespace
 
 hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
-                                     const ImgView& im)
+                                     const ImgView& im, uint32_t* mail)
 {
     PreFwdArgs a;
     a.c = c;
     a.io = io;
     a.g = g;
     a.ctrl = im.ctrl;
+    a.mail = mail;
+    {
+        // ctrl | tile_cnt[T] | tile_cnt1[T] | dhist | super_tab are contiguous (gft_compute_layout)
+        const size_t T = (size_t)((c.W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((c.H + GFT_TILE_Y - 1) / GFT_TILE_Y);
+        a.clear_words = (uint32_t)(GFT_CTRL_WORDS + 2 * T + GFT_DHIST_BINS + 5 * GFT_SUPER_MAX);
+    }
     // reference rasterizer_impl.cu:249-250, forward.cu:752
     a.focal_y = c.H / (2.0f * c.tanfovy);
     a.focal_x = c.W / (2.0f * c.tanfovx);

@@ -119,6 +119,7 @@ struct RenderFwdArgs {
     // the latter binned only after a quadrant of the tile ran out of near-slab entries
     const uint32_t* __restrict__ totals;      // ctrl words (always set)
     const uint2* __restrict__ ranges1;
+    float4* __restrict__ clear; size_t clear_vec4;   // backward accumulator to zero (first pass of a tile-pull frame)
     // lazy sort (k_binning.hip, k_tile_front): only the head of every id list is sorted
     const uint32_t* __restrict__ front_len;   // NULL: lists are sorted whole
     uint32_t* __restrict__ unit_flag;
@@ -136,6 +137,12 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     if (a.ctrl && a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
     if (a.resume && *a.nflag == 0u) return;               // no quadrant asked for its tail
     const int V = a.T * 4;
+    // fire-and-forget zero fill of the backward's accumulator: this kernel is bound by its VALU chains and moves
+    // little data, the stores drain underneath
+    if (a.clear) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < a.clear_vec4; i += (size_t)gridDim.x * 64) a.clear[i] = z;
+    }
     const int v = unit_of_block(blockIdx.x, V);
     if (v >= V) return;
     const int tile = v >> 2, quad = v & 3;
@@ -706,9 +713,12 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
 }  // namespace
 
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
-                                 const ImgView& im, const BinView& b, bool check_cap, uint32_t cap, int lazy)
+                                 const ImgView& im, const BinView& b, bool check_cap, uint32_t cap, int lazy, float* clear,
+                                 size_t clear_bytes)
 {
     RenderFwdArgs a;
+    a.clear = reinterpret_cast<float4*>(clear);
+    a.clear_vec4 = clear_bytes / 16;
     a.ctrl = check_cap ? im.ctrl : nullptr;
     a.cap = cap;
     a.totals = im.ctrl;

@@ -181,7 +181,7 @@ typedef struct gft_layout {
     size_t img_tile_cnt1;     /* uint32[T]    lazy binning: far-slab instances of the tiles that asked for them */
     size_t img_dhist;         /* uint32[256]  instances per log-depth bin (choice of the next depth cut) */
     size_t img_ranges1;       /* uint2[T]     lazy binning: [first,last) of every tile's far-slab segment */
-    size_t img_super_tab;     /* uint32[3][1024] lazy binning: per supertile (S x S tiles) entry count, list start, cursor */
+    size_t img_super_tab;     /* uint32[5][1024] lazy binning: per supertile (S x S tiles) entry count, list start, cursor, id-list region, cursor */
     size_t img_tile_cursor;   /* uint32[T]    scatter cursors */
     size_t img_tile_order;    /* uint32[T]    tiles by backward weight (written by gft_backward) */
     size_t img_front_len;     /* uint32[T]    length of the sorted head of the tile's id list (lazy sort) */

@@ -308,6 +308,17 @@ def test_edge_cases(oracle, gpu):
     np.testing.assert_allclose(out["phasor"], scene["bg"][:7], rtol=0, atol=0)
     for k in ["means3D", "shs", "shs_p", "scales", "rotations", "opacities", "means2D"]:
         assert not grads[k].any(), k
+    # prefiltered=True promises that no point is culled; a culled one is an error (device trap in the reference,
+    # auxiliary.h:171-175), in the two-stage flow and in the one-call flow (the flag travels through the host mailbox)
+    from gftorf_amd import api
+    key = (gpu.index, 64, scene["cfg"]["W"], scene["cfg"]["H"])
+    for flow in ("two-stage", "one-call"):
+        api._instance_hint.pop(key, None)
+        if flow == "one-call":
+            api._instance_hint[key] = (1000, 0, 0.0, 0)
+        with pytest.raises(RuntimeError, match="prefiltered"):
+            Hh.run_gpu(far, gpu, backward=False, prefiltered=True)
+    Hh.run_gpu(scene, gpu, backward=False, prefiltered=True)      # nothing culled: fine
     # P == 0: the reference returns zero images (rasterize_points.cu:104)
     empty = dict(scene)
     empty["gaussians"] = {k: (v[:0] if v is not None else None) for k, v in scene["gaussians"].items()}
