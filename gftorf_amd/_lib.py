@@ -51,7 +51,7 @@ BACKWARD_FIELDS = [
 LAYOUT_FIELDS = [
     "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_rect", "geom_dirgrad", "geom_clamped",
     "geom_blockhist", "geom_total",
-    "img_pix_state", "img_ranges", "img_tile_max", "img_ctrl", "img_tile_cnt", "img_tile_cnt1", "img_dhist", "img_ranges1", "img_super_tab", "img_tile_cursor", "img_tile_order", "img_front_len", "img_unit_flag", "img_resume_state", "img_pix_sums", "img_total",
+    "img_pix_state", "img_ranges", "img_tile_max", "img_ctrl", "img_tile_cnt", "img_tile_cnt1", "img_dhist", "img_ranges1", "img_super_tab", "img_tile_cursor", "img_tile_order", "img_front_len", "img_unit_flag", "img_resume_state", "img_pix_sums", "img_snaps", "img_total",
     "bin_keys", "bin_point_list", "bin_total",
 ]
 

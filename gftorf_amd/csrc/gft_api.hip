@@ -61,6 +61,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->img_unit_flag = o;   o = align_up(o + T * 16);
     L->img_resume_state = o; o = align_up(o + n * 64);
     L->img_pix_sums = o;    o = align_up(o + n * 32);
+    L->img_snaps = o;       o = align_up(o + 4 * T * (size_t)(gft_bwd_segments(T) - 1) * GFT_SNAP_F4 * 64 * 16);
     L->img_total = o;
 
     const size_t r = (size_t)(R > 0 ? R : 0);
@@ -104,6 +105,7 @@ ImgView gft_img_view(void* base, const gft_layout& L)
     v.unit_flag = (uint32_t*)(b + L.img_unit_flag);
     v.resume_state = (float4*)(b + L.img_resume_state);
     v.pix_sums = (float4*)(b + L.img_pix_sums);
+    v.snaps = (float4*)(b + L.img_snaps);
     return v;
 }
 
@@ -629,7 +631,7 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     }
     if (num_rendered > 0) {
         StageTimer t(s, ST_RENDER_BWD);
-        GFT_STAGE(s, cfg, "render_bwd", gft_launch_render_bwd(s, *cfg, *io, g, im, b));
+        GFT_STAGE(s, cfg, "render_bwd", gft_launch_render_bwd(s, *cfg, *io, g, im, b, lazy_sort_enabled()));
     }
     {
         StageTimer t(s, ST_PRE_BWD);

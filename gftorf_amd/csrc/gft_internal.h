@@ -6,6 +6,7 @@
 #include "gftorf_rast.h"
 
 #include <atomic>
+#include <cstdlib>
 
 #define GFT_ALIGN 256
 
@@ -41,6 +42,7 @@ struct GeomView {
 struct ImgView {
     float4* pix_state;    // [N] {final_T, n_contrib bits, w_z, w_z2}
     float4* pix_sums;     // [N][2] {C0, C1, C2, R}, {I, Am, dist, A}: final sums of the blend, without background
+    float4* snaps;        // [4T][segments - 1][3][64] blend state of every quadrant in front of list entries 256, 512, ...
     uint2* ranges;        // [T]
     uint32_t* tile_max;   // [T]
     uint32_t* ctrl;       // [8], directly followed by tile_cnt (one memset clears both)
@@ -90,6 +92,23 @@ struct BinView {
 #define BIN_CHUNK (BIN_THREADS * BIN_ITEMS)  // Gaussians per workgroup
 #define GFT_SHORT_LIST_MAX 4096   // tile lists up to this length are sorted by one 256-thread workgroup
 
+// Waves that may share the backward walk of one quadrant: its list is cut every GFT_SEG_LEN entries, where the forward
+// left a snapshot of the blend state (up to 4 segments; fewer on frames with more than 16384 quadrants, where one wave
+// per quadrant already fills the chip).
+#ifndef GFT_SEG_LEN
+#define GFT_SEG_LEN 256
+#endif
+inline int gft_bwd_segments(size_t T)
+{
+    // (2 ... 8 segments measure alike on the metric frame -- the kernel is bound by VALU issue, not by its chains --;
+    // 4 keeps the forward's snapshot traffic low.  GFT_BWD_NSEG overrides for tuning.)
+    static const int cap = [] { const char* e = getenv("GFT_BWD_NSEG"); const int v = e ? atoi(e) : 0; return v > 0 ? (v > 8 ? 8 : v) : 4; }();
+    const size_t v = 4 * (T ? T : 1);
+    const size_t n = 65536 / v;
+    return n < 1 ? 1 : (n > (size_t)cap ? cap : (int)n);
+}
+#define GFT_SNAP_F4 3      // float4 per pixel and snapshot: {T, C0, C1, C2} {PR, PI, PA, Dd} {A, DD_D, DD_D2, -}
+
 void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* L);
 GeomView gft_geom_view(void* base, const gft_layout& L);
 ImgView gft_img_view(void* base, const gft_layout& L);
@@ -130,7 +149,7 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
                                  const GeomView& g, const ImgView& im, const BinView& b, bool check_cap, uint32_t cap,
                                  int lazy, float* clear = nullptr, size_t clear_bytes = 0);
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
-                                 const GeomView& g, const ImgView& im, const BinView& b);
+                                 const GeomView& g, const ImgView& im, const BinView& b, bool lazy);
 hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
                                      const GeomView& g);
 hipError_t gft_launch_mark_visible(hipStream_t s, int32_t P, const float* means3D,

@@ -120,6 +120,8 @@ struct RenderFwdArgs {
     const uint32_t* __restrict__ totals;      // ctrl words (always set)
     const uint2* __restrict__ ranges1;
     float4* __restrict__ clear; size_t clear_vec4;   // backward accumulator to zero (first pass of a tile-pull frame)
+    float4* __restrict__ snaps;               // blend-state snapshots for the backward (NULL: no backward follows)
+    int nsnap;                                // snapshots per quadrant (list positions 256, 512, ...)
     // lazy sort (k_binning.hip, k_tile_front): only the head of every id list is sorted
     const uint32_t* __restrict__ front_len;   // NULL: lists are sorted whole
     uint32_t* __restrict__ unit_flag;
@@ -196,6 +198,14 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     for (int base = begin; base < total; base += RB) {
         // all 64 pixels finished -> the rest of the list is never used
         if (done_m == ~0ull) break;
+        // Blend state in front of list entries 256, 512, ...: the backward cuts a deep quadrant's walk there and gives
+        // every segment to a wave of its own (first pass only: its batches start at multiples of 64 from entry 0)
+        if (a.snaps && !a.resume && base > 0 && (base & (GFT_SEG_LEN - 1)) == 0 && base / GFT_SEG_LEN <= a.nsnap) {
+            float4* sp = a.snaps + ((size_t)v * a.nsnap + (base / GFT_SEG_LEN - 1)) * (GFT_SNAP_F4 * 64) + lane;
+            sp[0] = make_float4(T, C0, C1, C2);
+            sp[64] = make_float4(PR, PI, PA, Dd);
+            sp[128] = make_float4(A, DD_D, DD_D2, 0.f);
+        }
         const int n = min(RB, total - base);
         bool reach = false;
         uint32_t my_id = 0;
@@ -330,7 +340,10 @@ struct RenderBwdArgs {
     float dc_offset;
     const float4* __restrict__ pix_state;
     const float4* __restrict__ pix_sums;
-    int split;                 // 1: deep quadrants are shared by two waves
+    int split;                 // 1: deep quadrants are shared by several waves
+    int nseg;                  // segments (waves) per quadrant at most; snapshots per quadrant = nseg - 1
+    const float4* __restrict__ snaps;
+    const uint32_t* __restrict__ front_len;   // lazy sort / binning: entries the forward's first pass could walk (NULL: all)
     const uint2* __restrict__ ranges1;      // lazy binning: far-slab segments (read only by quadrants that went that deep)
     const uint32_t* __restrict__ quad_max;
     const uint32_t* __restrict__ order;     // tiles, heaviest first
@@ -465,38 +478,35 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     __shared__ float4 sB[RB * 2];
     __shared__ uint32_t sId[RB];
 
-    // block b runs on XCD b & 7; slot b >> 3 of that XCD takes quadrant (slot & 3) of the tile of
-    // weight rank 8 * (slot >> 2) + xcd: heavy tiles first, a tile's quadrants on one XCD
-    // Every quadrant has two workgroups: all quadrant waves are resident from the start (4.7 per SIMD at the
-    // metric size) and each is a serial chain over its list, so the deepest lists (twice the mean) set the
-    // kernel's duration while the SIMDs run empty.  A deep list [0, tmax) is therefore cut at b: segment 0 walks
-    // [b, tmax) back to front from the final state as before, segment 1 first repeats the forward blend over
-    // [0, b) (same operations as k_render_fwd: the same transmittance and partial sums), which gives it the
-    // state the serial walk would have at b -- what lies behind b is (final sums - sums up to b) -- and then
-    // walks [0, b) back to front.
-    // (first all segment-0 workgroups in heavy-first order, then all segment-1 ones: the dispatcher deals
-    // consecutive workgroups round-robin to the CUs, so alternating the two kinds would put them on
-    // alternate CUs)
-    const int half = a.split ? (int)(gridDim.x >> 1) : (int)gridDim.x;
-    const int seg = (int)blockIdx.x >= half ? 1 : 0;
-    const int bid = (int)blockIdx.x - seg * half;
+    // block b of a segment runs on XCD b & 7; slot b >> 3 of that XCD takes quadrant (slot & 3) of the tile of
+    // weight rank 8 * (slot >> 2) + xcd: heavy tiles first, a tile's quadrants on one XCD.
+    // Every quadrant wave is one serial chain over its list and all of them are resident from the start, so the deepest
+    // lists would set the kernel's duration while the SIMDs run empty.  A deep list [0, tmax) is therefore cut every
+    // GFT_SEG_LEN entries: the wave of segment s walks [256 s, 256 (s + 1)) back to front, starting from the blend
+    // state the forward saved in front of entry 256 (s + 1) -- what lies behind it is (final sums - sums up to there) --;
+    // the last segment walks from the final state as a single wave would.  The same arithmetic per (pixel, splat) as
+    // one wave, other summation order of the atomics only.  Workgroups of segment 0 first, then segment 1, ...
+    const int per_seg = (int)gridDim.x / a.nseg;
+    const int seg = (int)blockIdx.x / per_seg;
+    const int bid = (int)blockIdx.x - seg * per_seg;
     const int xcd = bid & 7, qslot = bid >> 3;
     const int rank = 8 * (qslot >> 2) + xcd;
     if (rank >= a.T) return;
     const int v_unit = (int)a.order[rank] * 4 + (qslot & 3);
     const int tmax = (int)a.quad_max[v_unit];
     if (tmax == 0) return;
-    // cut: segment 1 repeats the forward before it can start and is launched behind all segment-0 workgroups
-    int cut = 0;
-    if (a.split && tmax >= 3 * RB) {
-        const int nb = (tmax + RB - 1) / RB;
-        const int kA = (nb * 48 + 32) >> 6;                    // batches of segment 0: 3/4 (measured best of 0.5 ... 0.8)
-        cut = tmax - kA * RB;
-        if (cut < 0) cut = 0;
+    // cuts: at multiples of GFT_SEG_LEN in front of tmax that the forward's first pass walked over (it saved no state
+    // past the sorted head of a lazily sorted list)
+    int ncut = 0;
+    if (a.split) {
+        const int head = a.front_len ? (int)a.front_len[v_unit >> 2] : tmax;
+        const int lim = min(tmax, head);
+        ncut = lim > 0 ? (lim - 1) / GFT_SEG_LEN : 0;                       // cuts at 256, ..., 256 ncut < lim
+        if (ncut > a.nseg - 1) ncut = a.nseg - 1;
     }
-    if (seg == 1 && cut == 0) return;
-    const int hi_first = seg == 0 ? tmax : cut;                // list range [lo_last, hi_first) of this segment
-    const int lo_last = seg == 0 ? cut : 0;
+    if (seg > ncut) return;
+    const int lo_last = seg * GFT_SEG_LEN;                                  // list range [lo_last, hi_first) of this segment
+    const int hi_first = seg == ncut ? tmax : lo_last + GFT_SEG_LEN;
     const int tile = v_unit >> 2, quad = v_unit & 3;
     const int lane = threadIdx.x;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -561,45 +571,12 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     float T = T_final;
     float S1 = 0.f, Sp = 0.f;
 
-    if (seg == 1) {
-        // forward blend over [0, cut), operation for operation as k_render_fwd does it
-        float fT = 1.0f, qC0 = 0, qC1 = 0, qC2 = 0, qPR = 0, qPI = 0, qPA = 0, qDd = 0, qA = 0, qDD_D = 0, qDD_D2 = 0;
-        for (int base = 0; base < cut; base += RB) {
-            const int n = min(RB, cut - base);
-            bool reach = false;
-            __syncthreads();
-            if (lane < n) {
-                const uint32_t id = a.point_list[phys((uint32_t)(base + lane))];
-                reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, (float)qx0, (float)qy0);
-            }
-            uint64_t m = to_sgpr(wave_ballot(reach));
-            __syncthreads();
-            while (m) {
-                const int j = (int)__builtin_ctzll(m);
-                m &= m - 1;
-                const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
-                const float dx = a0.x - pxf, dy = a0.y - pyf;
-                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-                const float alpha = fminf(0.99f, a1.y * gft_exp(power));
-                const bool contrib = (base + j < n_contrib) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                const unsigned long long cm = wave_ballot(contrib);
-                if (cm == 0ull) continue;
-                const float4 b0 = sB[2 * j], b1 = sB[2 * j + 1];
-                const float al = sel_mask(cm, alpha, 0.f);
-                const float w = al * fT;
-                const float w_p = w * fT;
-                qC0 += b0.x * w; qC1 += b0.y * w; qC2 += b0.z * w;
-                qPR += b0.w * w_p; qPI += b1.x * w_p; qPA += b1.y * w_p;
-                const float dist = a1.w;
-                qDd += dist * w;
-                const float z = a1.z;
-                const float wz = w * z;
-                qDD_D += wz;
-                qDD_D2 = fmaf(wz, z, qDD_D2);
-                qA += w;
-                fT = sel_mask(cm, fT * (1 - alpha), fT);
-            }
-        }
+    if (seg < ncut) {
+        // blend state in front of entry `cut`, as the forward left it
+        const float4* sp = a.snaps + ((size_t)v_unit * (a.nseg - 1) + seg) * (GFT_SNAP_F4 * 64) + lane;
+        const float4 s0 = sp[0], s1 = sp[64], s2 = sp[128];
+        const float fT = s0.x, qC0 = s0.y, qC1 = s0.z, qC2 = s0.w, qPR = s1.x, qPI = s1.y, qPA = s1.z, qDd = s1.w;
+        const float qA = s2.x, qDD_D = s2.y, qDD_D2 = s2.z;
         // what the serial walk holds when it arrives at `cut`:
         //   S1 = sum_{k >= cut} w_k D1_k / T_cut,  Sp = sum_{k >= cut} w_k T_k Dp_k / T_cut^2,
         // the sums taken as (whole list) - (entries before cut); a pixel whose list ended before `cut` has equal
@@ -719,6 +696,8 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     RenderFwdArgs a;
     a.clear = reinterpret_cast<float4*>(clear);
     a.clear_vec4 = clear_bytes / 16;
+    a.nsnap = gft_bwd_segments((size_t)((c.W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((c.H + GFT_TILE_Y - 1) / GFT_TILE_Y)) - 1;
+    a.snaps = (c.want_backward && a.nsnap > 0) ? im.snaps : nullptr;
     a.ctrl = check_cap ? im.ctrl : nullptr;
     a.cap = cap;
     a.totals = im.ctrl;
@@ -748,7 +727,7 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
 }
 
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io, const GeomView& g,
-                                 const ImgView& im, const BinView& b)
+                                 const ImgView& im, const BinView& b, bool lazy)
 {
     RenderBwdArgs a;
     a.W = c.W; a.H = c.H;
@@ -767,10 +746,14 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, a.T, im.tile_max, im.tile_order);
     a.pix_sums = im.pix_sums;
     static const int split_on = [] { const char* e = getenv("GFT_BWD_SPLIT"); return e ? atoi(e) != 0 : 1; }();
-    // two waves per deep quadrant only while one wave per quadrant leaves wave slots empty (8 per SIMD = 8192);
-    // with more quadrants than that (5 M @ 1080p: 32640) the repeated forward is only extra work (measured)
-    a.split = split_on && 4 * a.T <= 12288;
-    const int blocks = (a.split ? 64 : 32) * ((a.T + 7) / 8);
+    // segments need the forward's snapshots (written when a backward was announced) and, with a lazily sorted list, the
+    // length of its sorted head
+    a.nseg = gft_bwd_segments((size_t)a.T);
+    a.split = split_on && a.nseg > 1 && c.want_backward;
+    if (!a.split) a.nseg = 1;
+    a.snaps = im.snaps;
+    a.front_len = lazy ? im.front_len : nullptr;
+    const int blocks = a.nseg * 32 * ((a.T + 7) / 8);
     hipLaunchKernelGGL(k_render_bwd, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }

@@ -188,6 +188,8 @@ typedef struct gft_layout {
     size_t img_unit_flag;     /* uint32[4T]   quadrant ran out of sorted ids before saturating (lazy sort) */
     size_t img_resume_state;  /* float[N][16] blend state of such quadrants' pixels */
     size_t img_pix_sums;      /* float[N][8]  final blend sums {C0,C1,C2,R | I,Am,dist,A}: the split backward starts mid-list from them */
+    size_t img_snaps;         /* float[4T][S-1][12][64] blend state of every 8x8 quadrant in front of list entries 256, 512, ...
+                                 (S = up to 8 segments): where the other waves of a split backward walk start */
     size_t img_total;
     /* binning */
     size_t bin_keys;          /* uint64[R]    (depth bits << 32 | Gaussian id), grouped by tile, unsorted */

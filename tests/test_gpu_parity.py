@@ -626,12 +626,16 @@ def synth_pose(rng):
 
 
 @pytest.mark.gpu
-def test_split_backward_matches_one_wave_per_quadrant(tmp_path):
-    """Deep quadrants are walked by two waves; GFT_BWD_SPLIT=0 keeps the serial walk.  Both
-    must give the same gradients up to the rounding of the second wave's starting state."""
+@pytest.mark.parametrize("scene_kw", [SCENES["deep_lists"], SCENES["long_lists_lds128k"],
+                                      dict(P=40000, W=64, H=64, scale_lo=0.01, scale_hi=0.05, opacity=0.02)],
+                         ids=["deep_lists", "thousands_per_tile", "thin_fog_past_the_sorted_head"])
+def test_split_backward_matches_one_wave_per_quadrant(tmp_path, scene_kw):
+    """Deep quadrants are walked by up to 8 waves, one per 256 list entries, each starting from the blend state the
+    forward saved there; GFT_BWD_SPLIT=0 keeps the serial walk.  Both must give the same gradients
+    up to the rounding of the later waves' starting states.  Cases: a few segments; eight segments; lists whose sorted
+    head ends before the deepest contributor (no state is saved past it: the cuts stop there)."""
     import subprocess
     import sys
-    scene_kw = SCENES["deep_lists"]
     child = tmp_path / "serial.py"
     out = tmp_path / "serial.npz"
     child.write_text(
