@@ -236,6 +236,12 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
     acc_buf = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32) if (want_bw and with_acc and P) else None
     io.acc = _ptr(acc_buf)
 
+    # the backward's gradient tensors and argument block, while the device is still busy with earlier work
+    prep = None
+    if want_bw and with_acc and P:
+        prep = prepare_backward(s, means3D_c, opac_c, sh_c, sh_p_c, scales_c, rot_c, cov_c, radii, geom, img,
+                                (bg_c, bsc, bsy, bsx), (view_c, proj_c, campos_c), ph_off, dc_off, acc_buf,
+                                colors_c is not None, cov_c is not None, want_bw)
     R = cap = 0
     restarted = False
     max_list = C.c_int64(0)
@@ -320,17 +326,16 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
     last_call_stats["restarts"] = last_call_stats.get("restarts", 0) + int(restarted)
     return dict(R=R, cap=cap, outputs=(color, phasor, depth, normal, acc, entropy, depth_distortion, amp_distortion,
                                        pixels, distribution, radii),
-                geom=geom, binning=binning, img=img, acc=acc_buf, bg=(bg_c, bsc, bsy, bsx),
+                geom=geom, binning=binning, img=img, acc=acc_buf, prep=prep, bg=(bg_c, bsc, bsy, bsx),
                 consts=(view_c, proj_c, campos_c),
                 inputs=(means3D_c, opac_c, sh_c, sh_p_c, scales_c, rot_c, cov_c, colors_c, phasors_c))
 
 
-def native_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, binning, img, bg, consts,
-                    ph_off, dc_off, grads_out, acc, want_colors, want_cov, want_bw_records=True):
-    """One backward of the native rasterizer (``RasterizeGaussiansBackwardCUDA``, rasterize_points.cu:167-281).
-    ``sh`` ... ``cov3D`` are contiguous tensors or None, ``grads_out`` = (color, phasor, depth, acc, depth_distortion)
-    upstream gradients (None = zeros), ``acc`` the accumulator the forward cleared or None.  Returns a dict of
-    gradient tensors (None where the input is absent)."""
+def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, img, bg, consts, ph_off, dc_off,
+                     acc, want_colors, want_cov, want_bw_records=True):
+    """Everything of a backward that does not depend on the upstream gradients: the gradient tensors, the argument
+    block, the config.  The forward calls it BEFORE it queues its kernels, so that this host work overlaps the device's
+    previous work instead of sitting between the forward's last kernel and the backward's first one."""
     lib = _lib.load()
     dev = means3D.device
     P = means3D.size(0)
@@ -340,35 +345,18 @@ def native_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii,
     has_sh, has_sh_p, has_scales, has_cov = sh is not None, sh_p is not None, scales is not None, cov3D is not None
     M = sh.size(1) if has_sh else 0
     M_p = sh_p.size(1) if has_sh_p else 0
-
-    def gr(t, c, name):
-        # gradients of normal / entropy / amp_distortion / pixels / distribution are
-        # accepted and ignored, as in the reference kernels (backward.cu:609-630)
-        if t is None:
-            return None
-        if tuple(t.shape) != (c, H, W):
-            raise RuntimeError("grad of %s has shape %s, expected %s" % (name, tuple(t.shape), (c, H, W)))
-        return _f32(t, dev, "grad_" + name)
-
-    g_color, g_phasor = gr(grads_out[0], 3, "color"), gr(grads_out[1], 7, "phasor")
-    g_depth, g_acc = gr(grads_out[2], 1, "depth"), gr(grads_out[3], 1, "acc")
-    g_dd = gr(grads_out[4], 1, "depth_distortion")
-
     f32 = dict(device=dev, dtype=torch.float32)
-    grad_means3D = torch.empty((P, 3), **f32)
-    grad_means2D = torch.empty((P, 3), **f32)
-    grad_opacities = torch.empty((P, 1), **f32)
-    grad_colors = torch.empty((P, 3), **f32) if want_colors else None
-    grad_cov3D = torch.empty((P, 6), **f32) if want_cov else None
-    grad_sh = torch.empty((P, M, 3), **f32) if has_sh else None
-    grad_sh_p = torch.empty((P, M_p, 2), **f32) if has_sh_p else None
-    grad_scales = torch.empty((P, 3), **f32) if has_scales else None
-    grad_rotations = torch.empty((P, 4), **f32) if has_scales else None
-    grad_offsets = torch.empty((2,), **f32)
+    g = dict(means3D=torch.empty((P, 3), **f32), means2D=torch.empty((P, 3), **f32), opacities=torch.empty((P, 1), **f32),
+             colors=torch.empty((P, 3), **f32) if want_colors else None,
+             cov3D=torch.empty((P, 6), **f32) if want_cov else None,
+             sh=torch.empty((P, M, 3), **f32) if has_sh else None,
+             sh_p=torch.empty((P, M_p, 2), **f32) if has_sh_p else None,
+             scales=torch.empty((P, 3), **f32) if has_scales else None,
+             rotations=torch.empty((P, 4), **f32) if has_scales else None,
+             offsets=torch.empty((2,), **f32))
     acc_zeroed = acc is not None
     if acc is None:            # second backward through the same forward (retain_graph), or the pybind-level route
         acc = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32)
-
     cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw_records)
     cfg.acc_zeroed = int(acc_zeroed)
     io = _lib.BackwardIO()
@@ -380,35 +368,63 @@ def native_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii,
     io.shs = _ptr(sh) if has_sh else None
     io.shs_p = _ptr(sh_p) if has_sh_p else None
     io.opacities = _ptr(opac) if (P and opac is not None) else None
-    io.dL_dout_color, io.dL_dout_phasor = _ptr(g_color), _ptr(g_phasor)
-    io.dL_dout_depth, io.dL_dout_acc, io.dL_dout_depth_distortion = _ptr(g_depth), _ptr(g_acc), _ptr(g_dd)
-    io.geom, io.img, io.binning = _ptr(geom), _ptr(img), _ptr(binning)
+    io.geom, io.img = _ptr(geom), _ptr(img)
     io.acc = _ptr(acc) if P else None
-    io.dL_dmeans3D, io.dL_dmeans2D = _ptr(grad_means3D) if P else None, _ptr(grad_means2D) if P else None
-    io.dL_dcolors, io.dL_dopacity, io.dL_dcov3D = _ptr(grad_colors), _ptr(grad_opacities) if P else None, _ptr(grad_cov3D)
-    io.dL_dsh, io.dL_dsh_p = _ptr(grad_sh), _ptr(grad_sh_p)
-    io.dL_dscales, io.dL_drotations = _ptr(grad_scales), _ptr(grad_rotations)
-    io.dL_dphase_offset = grad_offsets.data_ptr()
-    io.dL_ddc_offset = grad_offsets.data_ptr() + 4
+    io.dL_dmeans3D, io.dL_dmeans2D = _ptr(g["means3D"]) if P else None, _ptr(g["means2D"]) if P else None
+    io.dL_dcolors, io.dL_dopacity, io.dL_dcov3D = _ptr(g["colors"]), _ptr(g["opacities"]) if P else None, _ptr(g["cov3D"])
+    io.dL_dsh, io.dL_dsh_p = _ptr(g["sh"]), _ptr(g["sh_p"])
+    io.dL_dscales, io.dL_drotations = _ptr(g["scales"]), _ptr(g["rotations"])
+    # the two scalar gradients cost a reduction launch: only when the caller optimises an offset (the reference returns
+    # None for them otherwise, __init__.py:202-203); the pybind-level route always returns them
+    if getattr(s, "optimize_phase_offset", True) or getattr(s, "optimize_dc_offset", True):
+        io.dL_dphase_offset = g["offsets"].data_ptr()
+        io.dL_ddc_offset = g["offsets"].data_ptr() + 4
+    return dict(grads=g, cfg=cfg, io=io, acc=acc, dev=dev, P=P, H=H, W=W,
+                debug_args=(s.bg, means3D, radii, scales, rotations, s.scale_modifier, cov3D, s.viewmatrix, s.projmatrix,
+                            s.tanfovx, s.tanfovy, sh, sh_p, s.sh_degree, s.campos, s.debug, s.near_n, s.far_n, s.depth_range,
+                            s.use_view_dependent_phase, ph_off, dc_off) if s.debug else None)
 
-    if s.debug:
-        cpu_args = cpu_deep_copy_tuple((s.bg, means3D, radii, scales, rotations, s.scale_modifier, cov3D,
-                                        s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy) + tuple(grads_out) +
-                                       (sh, sh_p, s.sh_degree, s.campos, geom, binning, img,
-                                        s.debug, s.near_n, s.far_n, s.depth_range, s.use_view_dependent_phase,
-                                        ph_off, dc_off))
-    stream = _lib.raw_stream(dev)
+
+def run_backward(prep, grads_out, geom, binning, img, debug=False):
+    """The rest of a backward: the upstream gradients (color, phasor, depth, acc, depth_distortion; None = zeros) and the
+    launch (``RasterizeGaussiansBackwardCUDA``, rasterize_points.cu:167-281).  Returns the dict of gradient tensors."""
+    lib = _lib.load()
+    dev, P, H, W, io = prep["dev"], prep["P"], prep["H"], prep["W"], prep["io"]
+
+    def gr(t, c, name):
+        # gradients of normal / entropy / amp_distortion / pixels / distribution are
+        # accepted and ignored, as in the reference kernels (backward.cu:609-630)
+        if t is None:
+            return None
+        if tuple(t.shape) != (c, H, W):
+            raise RuntimeError("grad of %s has shape %s, expected %s" % (name, tuple(t.shape), (c, H, W)))
+        return _f32(t, dev, "grad_" + name)
+
+    keep = (gr(grads_out[0], 3, "color"), gr(grads_out[1], 7, "phasor"), gr(grads_out[2], 1, "depth"),
+            gr(grads_out[3], 1, "acc"), gr(grads_out[4], 1, "depth_distortion"))
+    io.dL_dout_color, io.dL_dout_phasor = _ptr(keep[0]), _ptr(keep[1])
+    io.dL_dout_depth, io.dL_dout_acc, io.dL_dout_depth_distortion = _ptr(keep[2]), _ptr(keep[3]), _ptr(keep[4])
+    io.geom, io.img, io.binning = _ptr(geom), _ptr(img), _ptr(binning)
+    if debug:
+        cpu_args = cpu_deep_copy_tuple(prep["debug_args"] + tuple(grads_out) + (geom, binning, img))
     try:
         with _lib.on_device(dev):
-            _lib.check(lib.gft_backward(stream, C.byref(cfg), C.byref(io), binning_capacity(binning) if P else 0))
+            _lib.check(lib.gft_backward(_lib.raw_stream(dev), C.byref(prep["cfg"]), C.byref(io),
+                                        binning_capacity(binning) if P else 0))
     except Exception as ex:
-        if s.debug:
+        if debug:
             torch.save(cpu_args, "snapshot_bw.dump")
             print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
         raise ex
-    return dict(means3D=grad_means3D, means2D=grad_means2D, opacities=grad_opacities, colors=grad_colors,
-                cov3D=grad_cov3D, sh=grad_sh, sh_p=grad_sh_p, scales=grad_scales, rotations=grad_rotations,
-                offsets=grad_offsets)
+    return prep["grads"]
+
+
+def native_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, binning, img, bg, consts,
+                    ph_off, dc_off, grads_out, acc, want_colors, want_cov, want_bw_records=True):
+    """One backward of the native rasterizer: :func:`prepare_backward` + :func:`run_backward` in one go."""
+    prep = prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, img, bg, consts, ph_off,
+                            dc_off, acc, want_colors, want_cov, want_bw_records)
+    return run_backward(prep, grads_out, geom, binning, img, bool(s.debug))
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -429,6 +445,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.scalars = (ph_off, dc_off)
         ctx.want_bw = want_bw
         ctx.acc = r["acc"]         # zeroed, valid for the first backward of this forward
+        ctx.prep = r["prep"]       # gradient tensors + argument block of that first backward
         ctx.bg = r["bg"]
         ctx.consts = r["consts"]
         ctx.present = (sh_c is not None, sh_p_c is not None, colors_c is not None, phasors_c is not None,
@@ -453,11 +470,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         has_sh, has_sh_p, has_colors, has_phasors, has_scales, has_cov = ctx.present
         ph_off, dc_off = ctx.scalars
         acc, ctx.acc = ctx.acc, None
-        g = native_backward(s, means3D, opac, sh if has_sh else None, sh_p if has_sh_p else None,
-                            scales if has_scales else None, rotations if has_scales else None,
-                            cov3D if has_cov else None, radii, geom, binning, img, ctx.bg, ctx.consts, ph_off, dc_off,
-                            (grad_out_color, grad_out_phasor, grad_out_depth, grad_out_acc, grad_depth_distortion),
-                            acc, has_colors, has_cov, ctx.want_bw)
+        prep, ctx.prep = ctx.prep, None
+        grads_out = (grad_out_color, grad_out_phasor, grad_out_depth, grad_out_acc, grad_depth_distortion)
+        if prep is not None:
+            g = run_backward(prep, grads_out, geom, binning, img, bool(s.debug))
+        else:      # a second backward through the same forward (retain_graph): fresh tensors, own accumulator clear
+            g = native_backward(s, means3D, opac, sh if has_sh else None, sh_p if has_sh_p else None,
+                                scales if has_scales else None, rotations if has_scales else None,
+                                cov3D if has_cov else None, radii, geom, binning, img, ctx.bg, ctx.consts, ph_off, dc_off,
+                                grads_out, None, has_colors, has_cov, ctx.want_bw)
         op_shape, ph_shape, dc_shape = ctx.in_shapes
         grad_phase = grad_dc = None
         if s.optimize_phase_offset and ph_shape is not None:

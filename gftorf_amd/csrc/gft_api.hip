@@ -462,7 +462,7 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
         }
         {
             StageTimer t(s, ST_TILE_SORT);
-            GFT_STAGE(s, cfg, "tile_tail", gft_launch_tile_tail(s, *cfg, g, im, b, cap, late_mail, seq));
+            GFT_STAGE(s, cfg, "tile_tail", gft_launch_tile_tail(s, *cfg, g, im, b, cap, late_mail, seq, cfg->want_backward != 0));
         }
         {
             StageTimer t(s, ST_RENDER_FWD);
@@ -607,9 +607,10 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     }
     if (cfg->P == 0) return 0;
     if (!io->means3D || !io->radii || !io->viewmatrix || !io->projmatrix || !io->campos || !io->geom || !io->img ||
-        !io->bg || !io->acc || !io->dL_dmeans3D || !io->dL_dmeans2D || !io->dL_dopacity || !io->dL_dphase_offset ||
-        !io->dL_ddc_offset)
+        !io->bg || !io->acc || !io->dL_dmeans3D || !io->dL_dmeans2D || !io->dL_dopacity)
         return gft_fail("gft_backward: required pointer is NULL");
+    if ((io->dL_dphase_offset == nullptr) != (io->dL_ddc_offset == nullptr))
+        return gft_fail("gft_backward: dL_dphase_offset and dL_ddc_offset are wanted together or not at all");
     if (num_rendered > 0 && !io->binning) return gft_fail("gft_backward: binning buffer is NULL");
     if ((io->shs != nullptr) != (cfg->M > 0) || (io->shs_p != nullptr) != (cfg->M_p > 0))
         return gft_fail("M / M_p do not match the presence of shs / shs_p");

@@ -76,6 +76,7 @@ struct BinView {
 #define GFT_CTRL_TOTAL1 8    // lazy binning: far-slab instances binned for the flagged tiles
 #define GFT_CTRL_NEARSUM 9   // tile-pull binning: instances of the near slab as summed by the supertile count pass
 #define GFT_CTRL_SEQ2 10     // host mailbox only: sequence number of the late report (flagged quadrants), written by k_tile_tail
+#define GFT_CTRL_ORDER_OK 11 // the forward computed the backward's heavy-first tile order (no quadrant was flagged)
 #define GFT_CTRL_WORDS 16
 #define GFT_DHIST_BINS 256   // log-spaced depth bins between near_n and far_n
 #define GFT_SUPER_MAX 1024   // supertiles (groups of S x S tiles) of the tile-pull binning
@@ -142,7 +143,7 @@ hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_
 hipError_t gft_launch_tile_front(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b, uint32_t cap,
                                  float* clear, size_t clear_bytes);
 hipError_t gft_launch_tile_tail(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                const BinView& b, uint32_t cap, uint32_t* late_mail, uint32_t seq);
+                                const BinView& b, uint32_t cap, uint32_t* late_mail, uint32_t seq, bool want_order);
 hipError_t gft_launch_tile_sort_long(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b,
                                      uint32_t cap);
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
@@ -194,4 +195,45 @@ __device__ __forceinline__ void gft_get_rect(float px, float py, int radius, int
     y0 = min(gy, max(0, (int)((py - r) / 16.0f)));
     x1 = min(gx, max(0, (int)((((px + r) + 16.0f) - 1.0f) / 16.0f)));
     y1 = min(gy, max(0, (int)((((py + r) + 16.0f) - 1.0f) / 16.0f)));
+}
+
+// Heavy-first launch order for the backward: the work of a quadrant is proportional to its
+// deepest contributor (known from the forward) and varies by an order of magnitude, so tiles
+// are bucket-sorted by that weight (64 buckets, descending) and dealt to the XCDs round-robin;
+// the hardware dispatcher then fills free wave slots with the longest remaining units first.
+// One workgroup; the order inside a bucket is arbitrary and only affects scheduling.
+// (called by all 1024 threads of one workgroup)
+__device__ inline void gft_tile_order_block(int T, const uint32_t* __restrict__ quad_max, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_max;
+    __shared__ uint32_t cnt[64], base[64];
+    const int tid = threadIdx.x;
+    if (tid == 0) s_max = 0;
+    if (tid < 64) cnt[tid] = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    for (int t = tid; t < T; t += 1024) {
+        const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
+        m = max(m, max(max(q.x, q.y), max(q.z, q.w)));
+    }
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const uint32_t wmax = s_max + 1;
+    for (int t = tid; t < T; t += 1024) {
+        const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
+        const uint32_t w = max(max(q.x, q.y), max(q.z, q.w));
+        atomicAdd(&cnt[63 - (w * 64u) / wmax], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int b = 0; b < 64; b++) { base[b] = acc; acc += cnt[b]; cnt[b] = 0; }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+        const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
+        const uint32_t w = max(max(q.x, q.y), max(q.z, q.w));
+        const uint32_t b = 63 - (w * 64u) / wmax;
+        order[base[b] + atomicAdd(&cnt[b], 1u)] = (uint32_t)t;
+    }
 }

@@ -1269,12 +1269,19 @@ __global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_tail(int T, const uin
                                                                 const float* __restrict__ depth,
                                                                 const uint32_t* __restrict__ front_len,
                                                                 const uint32_t* __restrict__ unit_flag,
-                                                                const uint32_t* __restrict__ ctrl, uint32_t cap,
-                                                                uint32_t* late_mail, uint32_t seq)
+                                                                uint32_t* ctrl, uint32_t cap,
+                                                                uint32_t* late_mail, uint32_t seq,
+                                                                const uint32_t* __restrict__ quad_max, uint32_t* __restrict__ order)
 {
     extern __shared__ uint64_t sk_dyn[];
     uint64_t* sk = sk_dyn;
     if (ctrl[GFT_CTRL_TOTAL] > cap) return;
+    // No quadrant was flagged (the common case): the deepest contributors of the first render pass are final, and this
+    // otherwise idle launch sorts the tiles by backward weight for k_render_bwd (no separate launch in the backward).
+    if (order && blockIdx.x == 0 && ctrl[GFT_CTRL_NFLAG] == 0u) {
+        gft_tile_order_block(T, quad_max, order);
+        if (threadIdx.x == 0) ctrl[GFT_CTRL_ORDER_OK] = 1u;
+    }
     // late report to the host mailbox (read at the caller's next forward, never waited for): how many quadrants outlived
     // what was sorted / binned up front -- the caller widens the near slab of the next frame when that happens
     if (late_mail && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1496,7 +1503,7 @@ hipError_t gft_launch_tile_front(hipStream_t s, const gft_config& c, const ImgVi
 }
 
 hipError_t gft_launch_tile_tail(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                const BinView& b, uint32_t cap, uint32_t* late_mail, uint32_t seq)
+                                const BinView& b, uint32_t cap, uint32_t* late_mail, uint32_t seq, bool want_order)
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
@@ -1506,7 +1513,8 @@ hipError_t gft_launch_tile_tail(hipStream_t s, const gft_config& c, const GeomVi
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_tile_tail, dim3(T < 256 ? T : 256), dim3(SORT_BIG_THREADS), (size_t)SORT_LDS_LARGE_BYTES, s, T,
-                       im.ranges, im.ranges1, b.keys, b.point_list, g.depth, im.front_len, im.unit_flag, im.ctrl, cap, late_mail, seq);
+                       im.ranges, im.ranges1, b.keys, b.point_list, g.depth, im.front_len, im.unit_flag, im.ctrl, cap, late_mail, seq,
+                       im.tile_max, want_order ? im.tile_order : nullptr);
     return hipGetLastError();
 }
 

@@ -1052,7 +1052,8 @@ hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const g
     const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_PAD : 0) + (a.stage_shp ? SHP_ROW_PAD : 0));
     const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
-    if (io.shs_p != nullptr)
+    // (the two scalar gradients are only reduced when the caller wants them: optimize_phase_offset / optimize_dc_offset)
+    if (io.shs_p != nullptr && io.dL_dphase_offset != nullptr && io.dL_ddc_offset != nullptr)
         hipLaunchKernelGGL(k_offset_reduce, dim3(1), dim3(1024), 0, s, blocks,
                            reinterpret_cast<const float2*>(io.acc + (size_t)c.P * GFT_ACC_STRIDE), io.dL_dphase_offset, io.dL_ddc_offset);
     return hipGetLastError();

@@ -347,6 +347,7 @@ struct RenderBwdArgs {
     const uint2* __restrict__ ranges1;      // lazy binning: far-slab segments (read only by quadrants that went that deep)
     const uint32_t* __restrict__ quad_max;
     const uint32_t* __restrict__ order;     // tiles, heaviest first
+    const uint32_t* __restrict__ order_ok;  // ctrl word: the forward computed `order` (NULL: it is valid)
     const float* __restrict__ g_color; const float* __restrict__ g_phasor; const float* __restrict__ g_depth;
     const float* __restrict__ g_acc; const float* __restrict__ g_dd;
     float* acc;   // [P][GFT_ACC_STRIDE]
@@ -431,45 +432,12 @@ __device__ __forceinline__ float wave_reduce16(v2f L01, v2f L23, v2f L45, v2f L6
     return row_fold4(t01.x, t01.y, t23.x, t23.y);
 }
 
-// Heavy-first launch order for the backward: the work of a quadrant is proportional to its
-// deepest contributor (known from the forward) and varies by an order of magnitude, so tiles
-// are bucket-sorted by that weight (64 buckets, descending) and dealt to the XCDs round-robin;
-// the hardware dispatcher then fills free wave slots with the longest remaining units first.
-// One workgroup; the order inside a bucket is arbitrary and only affects scheduling.
+// Heavy-first launch order for the backward (gft_tile_order_block, gft_internal.h): computed by the forward's
+// k_tile_tail launch when no quadrant was flagged, else (and without the lazy sort) by this kernel in the backward.
 __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint32_t* __restrict__ quad_max,
                                                      uint32_t* __restrict__ order)
 {
-    __shared__ uint32_t s_max;
-    __shared__ uint32_t cnt[64], base[64];
-    const int tid = threadIdx.x;
-    if (tid == 0) s_max = 0;
-    if (tid < 64) cnt[tid] = 0;
-    __syncthreads();
-    uint32_t m = 0;
-    for (int t = tid; t < T; t += 1024) {
-        const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
-        m = max(m, max(max(q.x, q.y), max(q.z, q.w)));
-    }
-    atomicMax(&s_max, m);
-    __syncthreads();
-    const uint32_t wmax = s_max + 1;
-    for (int t = tid; t < T; t += 1024) {
-        const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
-        const uint32_t w = max(max(q.x, q.y), max(q.z, q.w));
-        atomicAdd(&cnt[63 - (w * 64u) / wmax], 1u);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (int b = 0; b < 64; b++) { base[b] = acc; acc += cnt[b]; cnt[b] = 0; }
-    }
-    __syncthreads();
-    for (int t = tid; t < T; t += 1024) {
-        const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
-        const uint32_t w = max(max(q.x, q.y), max(q.z, q.w));
-        const uint32_t b = 63 - (w * 64u) / wmax;
-        order[base[b] + atomicAdd(&cnt[b], 1u)] = (uint32_t)t;
-    }
+    gft_tile_order_block(T, quad_max, order);
 }
 
 __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
@@ -492,7 +460,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     const int xcd = bid & 7, qslot = bid >> 3;
     const int rank = 8 * (qslot >> 2) + xcd;
     if (rank >= a.T) return;
-    const int v_unit = (int)a.order[rank] * 4 + (qslot & 3);
+    const bool ordered = a.order && (a.order_ok == nullptr || *a.order_ok != 0u);
+    const int v_unit = (int)(ordered ? a.order[rank] : (uint32_t)rank) * 4 + (qslot & 3);
     const int tmax = (int)a.quad_max[v_unit];
     if (tmax == 0) return;
     // cuts: at multiples of GFT_SEG_LEN in front of tmax that the forward's first pass walked over (it saved no state
@@ -742,8 +711,12 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     a.g_color = io.dL_dout_color; a.g_phasor = io.dL_dout_phasor; a.g_depth = io.dL_dout_depth;
     a.g_acc = io.dL_dout_acc; a.g_dd = io.dL_dout_depth_distortion;
     a.acc = io.acc;
-    a.order = im.tile_order;
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, a.T, im.tile_max, im.tile_order);
+    static const int order_on = [] { const char* e = getenv("GFT_BWD_ORDER"); return e ? atoi(e) != 0 : 1; }();
+    a.order = order_on ? im.tile_order : nullptr;
+    // with the lazy sort the forward's k_tile_tail launch has computed the order (unless a quadrant was flagged: the
+    // deepest contributors were not final then; those frames walk in tile order)
+    a.order_ok = lazy ? im.ctrl + GFT_CTRL_ORDER_OK : nullptr;
+    if (order_on && !lazy) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, a.T, im.tile_max, im.tile_order);
     a.pix_sums = im.pix_sums;
     static const int split_on = [] { const char* e = getenv("GFT_BWD_SPLIT"); return e ? atoi(e) != 0 : 1; }();
     // segments need the forward's snapshots (written when a backward was announced) and, with a lazily sorted list, the

@@ -153,7 +153,7 @@ typedef struct gft_backward_io {
     float* dL_dsh_p;        /* [P,M_p,2] required iff shs_p != NULL */
     float* dL_dscales;      /* [P,3]  required iff scales != NULL */
     float* dL_drotations;   /* [P,4]  required iff scales != NULL */
-    float* dL_dphase_offset;/* [1] (zeroed + accumulated by the library) */
+    float* dL_dphase_offset;/* [1] (written by the library); NULL together with dL_ddc_offset = not wanted (saves a reduction launch) */
     float* dL_ddc_offset;   /* [1] */
 } gft_backward_io;
 
