@@ -27,6 +27,7 @@ class Config(C.Structure):
         ("use_view_dependent_phase", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("want_backward", C.c_int32),
         ("acc_zeroed", C.c_int32),
+        ("grads_zeroed", C.c_int32),
         ("bg_stride_c", C.c_int64), ("bg_stride_y", C.c_int64), ("bg_stride_x", C.c_int64),
     ]
 
@@ -41,7 +42,7 @@ FORWARD_FIELDS = [
 
 BACKWARD_FIELDS = [
     "bg", "means3D", "radii", "scales", "rotations", "cov3D_precomp", "viewmatrix", "projmatrix",
-    "campos", "shs", "shs_p", "opacities",
+    "campos", "shs", "shs_p", "opacities", "pixels",
     "dL_dout_color", "dL_dout_phasor", "dL_dout_depth", "dL_dout_acc", "dL_dout_depth_distortion",
     "geom", "img", "binning", "acc",
     "dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dcov3D", "dL_dsh", "dL_dsh_p",
@@ -60,7 +61,7 @@ PROFILE_FIELDS = ["preprocess_fwd_ms", "tile_count_ms", "tile_scatter_ms", "tile
 
 
 class ForwardIO(C.Structure):
-    _fields_ = [(n, _fp) for n in FORWARD_FIELDS]
+    _fields_ = [(n, _fp) for n in FORWARD_FIELDS] + [("grads_zero", _fp), ("grads_zero_bytes", C.c_size_t)]
 
 
 class BackwardIO(C.Structure):

@@ -62,6 +62,12 @@ _instance_hint = {}
 # late report (quadrants that outlived the near slab: each costs a second binning pass).  A frame that reports such
 # quadrants widens the next near slab by a quarter; 200 clean frames in a row narrow it again towards the default.
 _slab_state = {}
+# Tuning switch, off: GFT_GRADS_ZERO_FILL=1 makes the forward zero-fill the backward's gradient tensors on a side stream
+# so that the backward writes only the rows of blended Gaussians.  Measured on MI355X (metric frame): the backward's
+# preprocess kernel 108 -> 74 us, but the fill (376 MB) takes whatever runs beside it down with it -- +63 us beside the
+# render kernel, +48 us beside the binning kernels: HBM time is conserved, the fill is not free anywhere.
+import os as _os
+_ZERO_FILL = _os.environ.get("GFT_GRADS_ZERO_FILL", "0") != "0"
 _SLAB_DEFAULT, _SLAB_MAX = 896, 8192
 _HINT_HEADROOM = 1.25
 _LIST_HEADROOM = 1.2      # longest tile list of the previous frame -> guess for this one
@@ -241,7 +247,10 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
     if want_bw and with_acc and P:
         prep = prepare_backward(s, means3D_c, opac_c, sh_c, sh_p_c, scales_c, rot_c, cov_c, radii, geom, img,
                                 (bg_c, bsc, bsy, bsx), (view_c, proj_c, campos_c), ph_off, dc_off, acc_buf,
-                                colors_c is not None, cov_c is not None, want_bw)
+                                colors_c is not None, cov_c is not None, want_bw, pixels, zero_fill=_ZERO_FILL)
+        if prep["zero_buf"] is not None:
+            io.grads_zero = prep["zero_buf"].data_ptr()
+            io.grads_zero_bytes = prep["zero_buf"].numel() * 4
     R = cap = 0
     restarted = False
     max_list = C.c_int64(0)
@@ -332,7 +341,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
 
 
 def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, img, bg, consts, ph_off, dc_off,
-                     acc, want_colors, want_cov, want_bw_records=True):
+                     acc, want_colors, want_cov, want_bw_records=True, pixels=None, zero_fill=False):
     """Everything of a backward that does not depend on the upstream gradients: the gradient tensors, the argument
     block, the config.  The forward calls it BEFORE it queues its kernels, so that this host work overlaps the device's
     previous work instead of sitting between the forward's last kernel and the backward's first one."""
@@ -346,19 +355,32 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
     M = sh.size(1) if has_sh else 0
     M_p = sh_p.size(1) if has_sh_p else 0
     f32 = dict(device=dev, dtype=torch.float32)
-    g = dict(means3D=torch.empty((P, 3), **f32), means2D=torch.empty((P, 3), **f32), opacities=torch.empty((P, 1), **f32),
-             colors=torch.empty((P, 3), **f32) if want_colors else None,
-             cov3D=torch.empty((P, 6), **f32) if want_cov else None,
-             sh=torch.empty((P, M, 3), **f32) if has_sh else None,
-             sh_p=torch.empty((P, M_p, 2), **f32) if has_sh_p else None,
-             scales=torch.empty((P, 3), **f32) if has_scales else None,
-             rotations=torch.empty((P, 4), **f32) if has_scales else None,
-             offsets=torch.empty((2,), **f32))
+    shapes = dict(means3D=(P, 3), means2D=(P, 3), opacities=(P, 1), colors=(P, 3) if want_colors else None,
+                  cov3D=(P, 6) if want_cov else None, sh=(P, M, 3) if has_sh else None,
+                  sh_p=(P, M_p, 2) if has_sh_p else None, scales=(P, 3) if has_scales else None,
+                  rotations=(P, 4) if has_scales else None)
+    zero_buf = None
+    if zero_fill:
+        # One buffer for all per-Gaussian gradients (every tensor a contiguous slice, 16-byte aligned): the forward
+        # zero-fills it beside its render kernel, the backward writes only the rows of blended Gaussians
+        sizes = {k: (int(torch.Size(v).numel()) + 3) // 4 * 4 for k, v in shapes.items() if v is not None}
+        zero_buf = torch.empty((sum(sizes.values()),), **f32)
+        g, o = {}, 0
+        for k, v in shapes.items():
+            if v is None:
+                g[k] = None
+            else:
+                g[k] = zero_buf[o:o + int(torch.Size(v).numel())].view(v)
+                o += sizes[k]
+    else:
+        g = {k: (torch.empty(v, **f32) if v is not None else None) for k, v in shapes.items()}
+    g["offsets"] = torch.empty((2,), **f32)
     acc_zeroed = acc is not None
     if acc is None:            # second backward through the same forward (retain_graph), or the pybind-level route
         acc = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32)
     cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw_records)
     cfg.acc_zeroed = int(acc_zeroed)
+    cfg.grads_zeroed = int(zero_buf is not None)
     io = _lib.BackwardIO()
     io.bg, io.means3D, io.radii = _ptr(bg_c), _ptr(means3D) if P else None, _ptr(radii) if P else None
     io.scales = _ptr(scales) if has_scales else None
@@ -368,6 +390,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
     io.shs = _ptr(sh) if has_sh else None
     io.shs_p = _ptr(sh_p) if has_sh_p else None
     io.opacities = _ptr(opac) if (P and opac is not None) else None
+    io.pixels = _ptr(pixels) if (P and pixels is not None) else None
     io.geom, io.img = _ptr(geom), _ptr(img)
     io.acc = _ptr(acc) if P else None
     io.dL_dmeans3D, io.dL_dmeans2D = _ptr(g["means3D"]) if P else None, _ptr(g["means2D"]) if P else None
@@ -379,7 +402,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
     if getattr(s, "optimize_phase_offset", True) or getattr(s, "optimize_dc_offset", True):
         io.dL_dphase_offset = g["offsets"].data_ptr()
         io.dL_ddc_offset = g["offsets"].data_ptr() + 4
-    return dict(grads=g, cfg=cfg, io=io, acc=acc, dev=dev, P=P, H=H, W=W,
+    return dict(grads=g, cfg=cfg, io=io, acc=acc, pixels=pixels, zero_buf=zero_buf, dev=dev, P=P, H=H, W=W,
                 debug_args=(s.bg, means3D, radii, scales, rotations, s.scale_modifier, cov3D, s.viewmatrix, s.projmatrix,
                             s.tanfovx, s.tanfovy, sh, sh_p, s.sh_degree, s.campos, s.debug, s.near_n, s.far_n, s.depth_range,
                             s.use_view_dependent_phase, ph_off, dc_off) if s.debug else None)

@@ -232,6 +232,35 @@ extern "C" int gft_profile_read(gft_profile* out)
     return 0;
 }
 
+// ---- side stream for the gradient zero fill --------------------------------------------------
+// One non-blocking stream and two events per device.  The forward records `after_main` behind its binning kernels and
+// makes the side stream wait for it (everything queued on the caller's stream so far is then done: the buffer cannot
+// still be in use by earlier work), fills, and records `filled`; the backward makes the caller's stream wait for
+// `filled`.  Re-recording an event does not disturb waits already queued on its earlier record; the latest fill on
+// the in-order side stream implies all earlier ones, so one event per device serves any number of forwards in flight.
+struct SideFill {
+    hipStream_t stream = nullptr;
+    hipEvent_t after_main = nullptr, filled = nullptr;
+    bool pending = false;
+};
+static std::mutex g_side_mu;
+static SideFill g_side[64];
+
+static SideFill* side_of_current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideFill& f = g_side[dev];
+    if (!f.stream) {
+        if (hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking) != hipSuccess) { f.stream = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&f.after_main, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&f.filled, hipEventDisableTiming) != hipSuccess)
+            return nullptr;
+    }
+    return &f;
+}
+
 // ---- helpers -----------------------------------------------------------------
 #define GFT_STAGE(stream, cfg, name, call)                                                   \
     do {                                                                                     \
@@ -375,7 +404,19 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
         // (the preprocess kernel also zeroes the ctrl words, the tile counters of both slabs, the depth histogram and
         // the supertile table for the binning kernels behind it: no fill launch)
         StageTimer t(s, ST_PRE_FWD);
-        GFT_STAGE(s, cfg, "preprocess_fwd", gft_launch_preprocess_fwd(s, *cfg, *io, g, im, mail_dev));
+        GFT_STAGE(s, cfg, "preprocess_fwd", gft_launch_preprocess_fwd(s, *cfg, *io, g, im, mail_dev, cut_bits));
+    }
+    if (io->grads_zero && io->grads_zero_bytes) {
+        // Zero fill of the backward's gradient tensors on the side stream, behind the preprocess kernel: it runs beside
+        // the binning kernels, which wait on latencies and leave HBM and half of every CU's wave slots idle (beside
+        // the render kernel, which is bound by VALU issue, it cost more than it saved: +63 us for 34 us)
+        SideFill* f = side_of_current_device();
+        if (!f) return gft_fail("forward: no side stream for the gradient fill");
+        GFT_CHECK_HIP(hipEventRecord(f->after_main, s));
+        GFT_CHECK_HIP(hipStreamWaitEvent(f->stream, f->after_main, 0));
+        GFT_CHECK_HIP(hipMemsetAsync(io->grads_zero, 0, io->grads_zero_bytes, f->stream));
+        GFT_CHECK_HIP(hipEventRecord(f->filled, f->stream));
+        f->pending = true;
     }
     {
         StageTimer t(s, ST_TILE_COUNT);
@@ -451,6 +492,11 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
         // (all these kernels leave at once when the first pass raised no flag).  With a depth cut the far slab
         // is binned first, for the tiles that have such a quadrant.
         if (cut_bits != GFT_NO_CUT) {
+            {
+                // the far Gaussians were given no appearance (SH colour, phasor) by the preprocess kernel
+                StageTimer t(s, ST_PRE_FWD);
+                GFT_STAGE(s, cfg, "appearance_far", gft_launch_appearance_far(s, *cfg, *io, g, im, cut_bits, cap));
+            }
             {
                 StageTimer t(s, ST_TILE_COUNT);
                 GFT_STAGE(s, cfg, "tile_count_far", gft_launch_tile_count(s, *cfg, g, im, nullptr, 0u, cut_bits, 1, cap, 0));
@@ -626,6 +672,11 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     ImgView im = gft_img_view(const_cast<void*>(io->img), L);
     BinView b = gft_bin_view(const_cast<void*>(io->binning), L);
 
+    if (cfg->grads_zeroed) {
+        SideFill* f = side_of_current_device();
+        if (!f || !f->pending) return gft_fail("gft_backward: grads_zeroed without a forward that filled them");
+        GFT_CHECK_HIP(hipStreamWaitEvent(s, f->filled, 0));
+    }
     if (!cfg->acc_zeroed) {
         StageTimer t(s, ST_MEMSET);
         GFT_CHECK_HIP(hipMemsetAsync(io->acc, 0, (size_t)cfg->P * GFT_ACC_STRIDE * sizeof(float), s));

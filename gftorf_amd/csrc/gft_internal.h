@@ -126,7 +126,9 @@ int gft_fail(const char* fmt, ...);
 
 // ---- stage launchers (each enqueues on `s`, returns hipError_t) -----------
 hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
-                                     const GeomView& g, const ImgView& im, uint32_t* mail);
+                                     const GeomView& g, const ImgView& im, uint32_t* mail, uint32_t cut_bits);
+hipError_t gft_launch_appearance_far(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
+                                     const ImgView& im, uint32_t cut_bits, uint32_t cap);
 // pass 0: near slab (view z <= cut; everything with GFT_NO_CUT) + depth histogram + scan + mailbox;
 // pass 1: far slab of the tiles with a flagged quadrant (leaves at once when no quadrant was flagged)
 hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,

@@ -418,10 +418,138 @@ struct PreFwdArgs {
     uint32_t* ctrl;            // ctrl words + the counters behind them: cleared here (clear_words), used from the next kernel on
     uint32_t clear_words;
     uint32_t* mail;            // host mailbox slot: the "prefiltered point culled" flag goes straight there
+    uint32_t cut_bits;         // lazy binning: float bits of the depth cut (GFT_NO_CUT: every visible Gaussian is "near")
     float focal_x, focal_y, dist2phase;
     int gx, gy;
     int stage_sh, stage_shp;   // SH rows staged through LDS (M == 16)
 };
+
+// Appearance of one visible Gaussian (reference forward.cu:346-407): SH colour, SH (phase, amplitude), the ToF phasor
+// on its (R, I, Am) basis, the direction gradients for the backward and the clamp flags -> rec_b, dirgrad, clamped.
+// Called by k_preprocess_fwd for the Gaussians of the near slab (all of them without a depth cut) and by
+// k_appearance_far for the others when a quadrant asks for the far slab: most far Gaussians are never blended, and
+// their 320 bytes of SH coefficients are then never read.
+__device__ __forceinline__ void appearance_fwd(const PreFwdArgs& a, int idx, int lane, const float4* sh_l, const float4* shp_l,
+                           float px, float py, float pz, float vx, float vy, float vz)
+{
+    const float3 cam = make_float3(a.io.campos[0], a.io.campos[1], a.io.campos[2]);
+    const float dox = px - cam.x, doy = py - cam.y, doz = pz - cam.z;
+    const float dlen = sqrtf(dox * dox + doy * doy + doz * doz);
+    const float dx = dox / dlen, dy = doy / dlen, dz = doz / dlen;
+
+    float rgb[3] = {0.f, 0.f, 0.f};
+    uint32_t clamp_bits = 0;
+    float dgc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // d rgb / d dir
+    float dgp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                  // d (phase, amp) / d dir
+    if (a.io.colors_precomp != nullptr) {
+        rgb[0] = a.io.colors_precomp[3 * idx];
+        rgb[1] = a.io.colors_precomp[3 * idx + 1];
+        rgb[2] = a.io.colors_precomp[3 * idx + 2];
+    }
+    if (a.io.shs != nullptr) {
+        float res[3];
+        if (a.stage_sh) {
+            float v[4 * SH_ROW_F4];
+            lds_row_load<SH_ROW_F4>(v, sh_l + lane * SH_ROW_PAD);
+            sh_eval<3>(a.c.D, dx, dy, dz, v, res);
+            if (a.c.want_backward) sh_dir_grad<3>(a.c.D, dx, dy, dz, v, dgc, dgc + 3, dgc + 6);
+        } else if (a.c.M == 16) {
+            // whole 192-byte row as twelve 16-byte loads (4x fewer TA requests than dwords)
+            float v[4 * SH_ROW_F4];
+            const float4* r4 = reinterpret_cast<const float4*>(a.io.shs) + (size_t)idx * SH_ROW_F4;
+#pragma unroll
+            for (int q = 0; q < SH_ROW_F4; q++) {
+                const float4 t = r4[q];
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+            sh_eval<3>(a.c.D, dx, dy, dz, v, res);
+            if (a.c.want_backward) sh_dir_grad<3>(a.c.D, dx, dy, dz, v, dgc, dgc + 3, dgc + 6);
+        } else {
+            const float* sp3 = a.io.shs + (size_t)idx * a.c.M * 3;
+            sh_eval<3>(a.c.D, dx, dy, dz, sp3, res);
+            if (a.c.want_backward) sh_dir_grad<3>(a.c.D, dx, dy, dz, sp3, dgc, dgc + 3, dgc + 6);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            res[c] += 0.5f;
+            if (res[c] < 0) clamp_bits |= (1u << c);
+            rgb[c] = fmaxf(res[c], 0.0f);
+        }
+    }
+
+    const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float dist_ndc = a.c.far_n / (a.c.far_n - a.c.near_n) * (1 - a.c.near_n / dist);
+    const float factor = 1.0f / (dist * dist);
+
+    // ToF phasor; undefined in the reference when neither input is given -> zeros
+    // The seven ToF planes are linear in three per-splat values (reference
+    // forward.cu:399-406): R = cos(phi) A/d^2, I = sin(phi) A/d^2, Am = A/d^2;
+    // planes 3..6 are (+-R + dc Am), (+-I + dc Am) and are formed by the render kernels.
+    float ph[3] = {0.f, 0.f, 0.f};
+    float phase_sh = 0.f, amplitude = 0.f;
+    bool have_phasor = false;
+    float phase = 0.f;
+    if (a.io.phasors_precomp != nullptr) {
+        phase = dist * a.dist2phase;
+        phase_sh = a.io.phasors_precomp[2 * idx];
+        amplitude = a.io.phasors_precomp[2 * idx + 1];
+        if (a.c.use_view_dependent_phase) phase += phase_sh;
+        have_phasor = true;
+    }
+    if (a.io.shs_p != nullptr) {
+        float res[2];
+        float sp0;
+        if (a.stage_shp) {
+            float v[4 * SHP_ROW_F4];
+            lds_row_load<SHP_ROW_F4>(v, shp_l + lane * SHP_ROW_PAD);
+            sh_eval<2>(a.c.D, dx, dy, dz, v, res);
+            if (a.c.want_backward) sh_dir_grad<2>(a.c.D, dx, dy, dz, v, dgp, dgp + 2, dgp + 4);
+            sp0 = v[0];
+        } else if (a.c.M_p == 16) {
+            float v[4 * SHP_ROW_F4];
+            const float4* r4 = reinterpret_cast<const float4*>(a.io.shs_p) + (size_t)idx * SHP_ROW_F4;
+#pragma unroll
+            for (int q = 0; q < SHP_ROW_F4; q++) {
+                const float4 t = r4[q];
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+            sh_eval<2>(a.c.D, dx, dy, dz, v, res);
+            if (a.c.want_backward) sh_dir_grad<2>(a.c.D, dx, dy, dz, v, dgp, dgp + 2, dgp + 4);
+            sp0 = v[0];
+        } else {
+            const float* sp = a.io.shs_p + (size_t)idx * a.c.M_p * 2;
+            sh_eval<2>(a.c.D, dx, dy, dz, sp, res);
+            if (a.c.want_backward) sh_dir_grad<2>(a.c.D, dx, dy, dz, sp, dgp, dgp + 2, dgp + 4);
+            sp0 = sp[0];
+        }
+        res[0] += 0.5f;
+        res[1] += 0.5f;
+        res[0] = res[0] - 0.5f - SH_C0 * sp0;
+        if (res[1] < 0) {
+            clamp_bits |= 8u;
+            res[1] = 0.0f;
+        }
+        phase_sh = res[0];
+        amplitude = res[1];
+        phase = dist * a.dist2phase + a.c.phase_offset;
+        if (a.c.use_view_dependent_phase) phase += phase_sh;
+        have_phasor = true;
+    }
+    if (have_phasor) {
+        const float cp = cosf(phase), sn = sinf(phase);
+        ph[0] = cp * amplitude * factor;
+        ph[1] = sn * amplitude * factor;
+        ph[2] = amplitude * factor;
+    }
+
+    (void)dist_ndc;
+    a.g.rec_b[2 * idx] = make_float4(rgb[0], rgb[1], rgb[2], ph[0]);
+    a.g.rec_b[2 * idx + 1] = make_float4(ph[1], ph[2], phase_sh, amplitude);
+    if (a.c.want_backward) {
+        dirgrad_store(a.g.dirgrad, idx, dgc, dgp);
+    }
+    a.g.clamped[idx] = (uint8_t)clamp_bits;
+}
 
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
 {
@@ -486,125 +614,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
                 gft_get_rect(pix_x, pix_y, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
                 const uint32_t area = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
                 if (area != 0) {
-                    const float3 cam = make_float3(a.io.campos[0], a.io.campos[1], a.io.campos[2]);
-                    const float dox = px - cam.x, doy = py - cam.y, doz = pz - cam.z;
-                    const float dlen = sqrtf(dox * dox + doy * doy + doz * doz);
-                    const float dx = dox / dlen, dy = doy / dlen, dz = doz / dlen;
-
-                    float rgb[3] = {0.f, 0.f, 0.f};
-                    uint32_t clamp_bits = 0;
-                    float dgc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // d rgb / d dir
-                    float dgp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                  // d (phase, amp) / d dir
-                    if (a.io.colors_precomp != nullptr) {
-                        rgb[0] = a.io.colors_precomp[3 * idx];
-                        rgb[1] = a.io.colors_precomp[3 * idx + 1];
-                        rgb[2] = a.io.colors_precomp[3 * idx + 2];
-                    }
-                    if (a.io.shs != nullptr) {
-                        float res[3];
-                        if (a.stage_sh) {
-                            float v[4 * SH_ROW_F4];
-                            lds_row_load<SH_ROW_F4>(v, sh_l + lane * SH_ROW_PAD);
-                            sh_eval<3>(a.c.D, dx, dy, dz, v, res);
-                            if (a.c.want_backward) sh_dir_grad<3>(a.c.D, dx, dy, dz, v, dgc, dgc + 3, dgc + 6);
-                        } else if (a.c.M == 16) {
-                            // whole 192-byte row as twelve 16-byte loads (4x fewer TA requests than dwords)
-                            float v[4 * SH_ROW_F4];
-                            const float4* r4 = reinterpret_cast<const float4*>(a.io.shs) + (size_t)idx * SH_ROW_F4;
-#pragma unroll
-                            for (int q = 0; q < SH_ROW_F4; q++) {
-                                const float4 t = r4[q];
-                                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-                            }
-                            sh_eval<3>(a.c.D, dx, dy, dz, v, res);
-                            if (a.c.want_backward) sh_dir_grad<3>(a.c.D, dx, dy, dz, v, dgc, dgc + 3, dgc + 6);
-                        } else {
-                            const float* sp3 = a.io.shs + (size_t)idx * a.c.M * 3;
-                            sh_eval<3>(a.c.D, dx, dy, dz, sp3, res);
-                            if (a.c.want_backward) sh_dir_grad<3>(a.c.D, dx, dy, dz, sp3, dgc, dgc + 3, dgc + 6);
-                        }
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            res[c] += 0.5f;
-                            if (res[c] < 0) clamp_bits |= (1u << c);
-                            rgb[c] = fmaxf(res[c], 0.0f);
-                        }
-                    }
-
                     const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
                     const float dist_ndc = a.c.far_n / (a.c.far_n - a.c.near_n) * (1 - a.c.near_n / dist);
-                    const float factor = 1.0f / (dist * dist);
-
-                    // ToF phasor; undefined in the reference when neither input is given -> zeros
-                    // The seven ToF planes are linear in three per-splat values (reference
-                    // forward.cu:399-406): R = cos(phi) A/d^2, I = sin(phi) A/d^2, Am = A/d^2;
-                    // planes 3..6 are (+-R + dc Am), (+-I + dc Am) and are formed by the render kernels.
-                    float ph[3] = {0.f, 0.f, 0.f};
-                    float phase_sh = 0.f, amplitude = 0.f;
-                    bool have_phasor = false;
-                    float phase = 0.f;
-                    if (a.io.phasors_precomp != nullptr) {
-                        phase = dist * a.dist2phase;
-                        phase_sh = a.io.phasors_precomp[2 * idx];
-                        amplitude = a.io.phasors_precomp[2 * idx + 1];
-                        if (a.c.use_view_dependent_phase) phase += phase_sh;
-                        have_phasor = true;
-                    }
-                    if (a.io.shs_p != nullptr) {
-                        float res[2];
-                        float sp0;
-                        if (a.stage_shp) {
-                            float v[4 * SHP_ROW_F4];
-                            lds_row_load<SHP_ROW_F4>(v, shp_l + lane * SHP_ROW_PAD);
-                            sh_eval<2>(a.c.D, dx, dy, dz, v, res);
-                            if (a.c.want_backward) sh_dir_grad<2>(a.c.D, dx, dy, dz, v, dgp, dgp + 2, dgp + 4);
-                            sp0 = v[0];
-                        } else if (a.c.M_p == 16) {
-                            float v[4 * SHP_ROW_F4];
-                            const float4* r4 = reinterpret_cast<const float4*>(a.io.shs_p) + (size_t)idx * SHP_ROW_F4;
-#pragma unroll
-                            for (int q = 0; q < SHP_ROW_F4; q++) {
-                                const float4 t = r4[q];
-                                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-                            }
-                            sh_eval<2>(a.c.D, dx, dy, dz, v, res);
-                            if (a.c.want_backward) sh_dir_grad<2>(a.c.D, dx, dy, dz, v, dgp, dgp + 2, dgp + 4);
-                            sp0 = v[0];
-                        } else {
-                            const float* sp = a.io.shs_p + (size_t)idx * a.c.M_p * 2;
-                            sh_eval<2>(a.c.D, dx, dy, dz, sp, res);
-                            if (a.c.want_backward) sh_dir_grad<2>(a.c.D, dx, dy, dz, sp, dgp, dgp + 2, dgp + 4);
-                            sp0 = sp[0];
-                        }
-                        res[0] += 0.5f;
-                        res[1] += 0.5f;
-                        res[0] = res[0] - 0.5f - SH_C0 * sp0;
-                        if (res[1] < 0) {
-                            clamp_bits |= 8u;
-                            res[1] = 0.0f;
-                        }
-                        phase_sh = res[0];
-                        amplitude = res[1];
-                        phase = dist * a.dist2phase + a.c.phase_offset;
-                        if (a.c.use_view_dependent_phase) phase += phase_sh;
-                        have_phasor = true;
-                    }
-                    if (have_phasor) {
-                        const float cp = cosf(phase), sn = sinf(phase);
-                        ph[0] = cp * amplitude * factor;
-                        ph[1] = sn * amplitude * factor;
-                        ph[2] = amplitude * factor;
-                    }
-
                     a.g.rec_a[2 * idx] = make_float4(pix_x, pix_y, conx, cony);
                     a.g.rec_a[2 * idx + 1] = make_float4(conz, a.io.opacities[idx], dist_ndc, dist);
-                    a.g.rec_b[2 * idx] = make_float4(rgb[0], rgb[1], rgb[2], ph[0]);
-                    a.g.rec_b[2 * idx + 1] = make_float4(ph[1], ph[2], phase_sh, amplitude);
-                    if (a.c.want_backward) {
-                        dirgrad_store(a.g.dirgrad, idx, dgc, dgp);
-                    }
                     a.g.depth[idx] = vz;
-                    a.g.clamped[idx] = (uint8_t)clamp_bits;
+                    // appearance now for the near slab; the far slab's only if a quadrant outlives the near one
+                    if (__float_as_uint(vz) <= a.cut_bits) appearance_fwd(a, idx, lane, sh_l, shp_l, px, py, pz, vx, vy, vz);
                     radius = (int)my_radius;
                     tiles = area;
                     rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
@@ -618,7 +634,48 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
     }
 }
 
-// ---------------------------------------------------------------------------
+// Appearance of the far slab's Gaussians, when a quadrant outlived the near slab (lazy binning, k_binning.hip): leaves at
+// once otherwise.  All visible Gaussians behind the cut get theirs (the flagged tiles' lists are not built yet).
+__global__ __launch_bounds__(PRE_BLOCK) void k_appearance_far(PreFwdArgs a, uint32_t cap)
+{
+    if (a.ctrl[GFT_CTRL_NFLAG] == 0u || a.ctrl[GFT_CTRL_TOTAL] > cap || a.ctrl[GFT_CTRL_TOTAL] == a.ctrl[GFT_CTRL_TOTAL0]) return;
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    if (idx >= a.c.P || a.io.radii[idx] <= 0) return;
+    if (__float_as_uint(a.g.depth[idx]) <= a.cut_bits) return;
+    const float px = a.io.means3D[3 * idx], py = a.io.means3D[3 * idx + 1], pz = a.io.means3D[3 * idx + 2];
+    const Mat16 V = load_mat(a.io.viewmatrix);
+    // the same expressions as in k_preprocess_fwd: the same distance bit for bit
+    const float vz = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
+    const float vx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
+    const float vy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
+    appearance_fwd(a, idx, threadIdx.x & 63, nullptr, nullptr, px, py, pz, vx, vy, vz);
+}
+
+static PreFwdArgs pre_fwd_args(const gft_config& c, const gft_forward_io& io, const GeomView& g, const ImgView& im,
+                               uint32_t* mail, uint32_t cut_bits)
+{
+    PreFwdArgs a;
+    a.c = c;
+    a.io = io;
+    a.g = g;
+    a.ctrl = im.ctrl;
+    a.mail = mail;
+    a.cut_bits = cut_bits;
+    {
+        // ctrl | tile_cnt[T] | tile_cnt1[T] | dhist | super_tab are contiguous (gft_compute_layout)
+        const size_t T = (size_t)((c.W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((c.H + GFT_TILE_Y - 1) / GFT_TILE_Y);
+        a.clear_words = (uint32_t)(GFT_CTRL_WORDS + 2 * T + GFT_DHIST_BINS + 5 * GFT_SUPER_MAX);
+    }
+    // reference rasterizer_impl.cu:249-250, forward.cu:752
+    a.focal_y = c.H / (2.0f * c.tanfovy);
+    a.focal_x = c.W / (2.0f * c.tanfovx);
+    a.dist2phase = 4.0f * 3.14159265358979323846f / c.depth_range;
+    a.gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X;
+    a.gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    a.stage_sh = a.stage_shp = 0;
+    return a;
+}
+
 struct PreBwdArgs {
     gft_config c;
     gft_backward_io io;
@@ -648,7 +705,22 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
     }
 
     if (idx < P) {
-        const bool visible = a.io.radii[idx] > 0;
+        // A Gaussian that no pixel blended has all-zero accumulators and therefore all-zero gradients: they are written
+        // without reading its records (with lazy binning most of the frame's Gaussians are like that, and those behind
+        // the depth cut may not even have an appearance record).  The forward's per-Gaussian pixel count tells; without
+        // it (pybind-level backward) the accumulator row does.
+        bool visible = a.io.radii[idx] > 0;
+        if (visible) {
+            if (a.io.pixels != nullptr) {
+                visible = a.io.pixels[idx] != 0.f;
+            } else {
+                const float4* ap = reinterpret_cast<const float4*>(a.io.acc + (size_t)idx * GFT_ACC_STRIDE);
+                const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+                visible = (a0.x != 0.f) | (a0.y != 0.f) | (a0.z != 0.f) | (a0.w != 0.f) | (a1.x != 0.f) | (a1.y != 0.f) |
+                          (a1.z != 0.f) | (a1.w != 0.f) | (a2.x != 0.f) | (a2.y != 0.f) | (a2.z != 0.f) | (a2.w != 0.f) |
+                          (a3.x != 0.f) | (a3.y != 0.f) | (a3.z != 0.f);
+            }
+        }
         float dmean[3] = {0.f, 0.f, 0.f};
         float dmean2d[2] = {0.f, 0.f};
         float dopac = 0.f;
@@ -891,8 +963,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
                 // reference applies scale_modifier inside s but returns dL/dscale without it
                 // (backward.cu:443-446 dot(Rt, dL_dMt) before the s multiply): keep as is.
             }
-        } else {
-            // culled: every returned gradient row is zero
+        } else if (!a.c.grads_zeroed) {
+            // culled or never blended: every returned gradient row is zero (already so with grads_zeroed)
             if (dsh) for (int k = 0; k < M * 3; k++) dsh[k] = 0.f;
             if (dsh_p) for (int k = 0; k < M_p * 2; k++) dsh_p[k] = 0.f;
             if (a.stage_sh) {
@@ -905,6 +977,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
             }
         }
 
+        if (visible || !a.c.grads_zeroed) {
         a.io.dL_dmeans3D[3 * idx] = dmean[0];
         a.io.dL_dmeans3D[3 * idx + 1] = dmean[1];
         a.io.dL_dmeans3D[3 * idx + 2] = dmean[2];
@@ -926,6 +999,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
             a.io.dL_dscales[3 * idx + 1] = dscale[1];
             a.io.dL_dscales[3 * idx + 2] = dscale[2];
             reinterpret_cast<float4*>(a.io.dL_drotations)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+        }
         }
     }
 
@@ -998,26 +1072,20 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_mark_visible(int P, const float* 
 
 }  // namespace
 
-hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
-                                     const ImgView& im, uint32_t* mail)
+hipError_t gft_launch_appearance_far(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
+                                     const ImgView& im, uint32_t cut_bits, uint32_t cap)
 {
-    PreFwdArgs a;
-    a.c = c;
-    a.io = io;
-    a.g = g;
-    a.ctrl = im.ctrl;
-    a.mail = mail;
-    {
-        // ctrl | tile_cnt[T] | tile_cnt1[T] | dhist | super_tab are contiguous (gft_compute_layout)
-        const size_t T = (size_t)((c.W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((c.H + GFT_TILE_Y - 1) / GFT_TILE_Y);
-        a.clear_words = (uint32_t)(GFT_CTRL_WORDS + 2 * T + GFT_DHIST_BINS + 5 * GFT_SUPER_MAX);
-    }
-    // reference rasterizer_impl.cu:249-250, forward.cu:752
-    a.focal_y = c.H / (2.0f * c.tanfovy);
-    a.focal_x = c.W / (2.0f * c.tanfovx);
-    a.dist2phase = 4.0f * 3.14159265358979323846f / c.depth_range;
-    a.gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X;
-    a.gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    PreFwdArgs a = pre_fwd_args(c, io, g, im, nullptr, cut_bits);
+    a.stage_sh = a.stage_shp = 0;
+    const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;
+    hipLaunchKernelGGL(k_appearance_far, dim3(blocks), dim3(PRE_BLOCK), 0, s, a, cap);
+    return hipGetLastError();
+}
+
+hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
+                                     const ImgView& im, uint32_t* mail, uint32_t cut_bits)
+{
+    PreFwdArgs a = pre_fwd_args(c, io, g, im, mail, cut_bits);
     a.stage_sh = (io.shs != nullptr && c.M == 16) ? 1 : 0;
     a.stage_shp = (io.shs_p != nullptr && c.M_p == 16) ? 1 : 0;
     // Measured on MI355X (1 M Gaussians): staging the forward's SH rows through LDS costs more
@@ -1047,8 +1115,10 @@ hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const g
     a.focal_y = c.H / (2.0f * c.tanfovy);
     a.focal_x = c.W / (2.0f * c.tanfovx);
     a.dist2phase = 4.0f * 3.14159265358979323846f / c.depth_range;
-    a.stage_sh = (io.shs != nullptr && c.M == 16) ? 1 : 0;
-    a.stage_shp = (io.shs_p != nullptr && c.M_p == 16) ? 1 : 0;
+    // (grads_zeroed: only the rows of blended Gaussians are written, straight from the lanes; else whole 64-row blocks
+    // leave through LDS as coalesced stores)
+    a.stage_sh = (io.shs != nullptr && c.M == 16 && !c.grads_zeroed) ? 1 : 0;
+    a.stage_shp = (io.shs_p != nullptr && c.M_p == 16 && !c.grads_zeroed) ? 1 : 0;
     const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_PAD : 0) + (a.stage_shp ? SHP_ROW_PAD : 0));
     const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);

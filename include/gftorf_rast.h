@@ -68,6 +68,8 @@ typedef struct gft_config {
     int32_t want_backward;
     /* backward only: `acc` was cleared by the forward (gft_forward_io.acc), skip the clear */
     int32_t acc_zeroed;
+    int32_t grads_zeroed;   /* gft_backward: the gradient outputs were zeroed by the forward (gft_forward_io.grads_zero):
+                               only the rows of Gaussians that some pixel blended are written */
     /* background [7,H,W] addressed as bg[c*sc + y*sy + x*sx] (element strides), so
      * the reference's expanded constant background (train.py:127) needs no copy */
     int64_t bg_stride_c, bg_stride_y, bg_stride_x;
@@ -110,6 +112,12 @@ typedef struct gft_forward_io {
      * clears it as a side job of the LDS-bound tile sort (64 B/Gaussian of HBM writes that
      * would otherwise be a separate pass of the backward); pass cfg.acc_zeroed to gft_backward. */
     float* acc;
+    /* optional: the buffer that holds the backward's per-Gaussian gradient tensors (any layout, `grads_zero_bytes`
+     * bytes).  The forward zero-fills it on a library-owned side stream while its render kernel (bound by VALU issue,
+     * little HBM traffic) runs; with cfg.grads_zeroed the backward then writes only the rows of the Gaussians that
+     * were blended -- in a dense frame most are not -- instead of streaming ~376 B of zeros per Gaussian. */
+    void* grads_zero;
+    size_t grads_zero_bytes;
 } gft_forward_io;
 
 /* Tensors of the backward call (RAST/rasterize_points.cu:167-198). */
@@ -127,6 +135,8 @@ typedef struct gft_backward_io {
     const float* shs;
     const float* shs_p;
     const float* opacities;                  /* [P] as given to the forward */
+    const float* pixels;                     /* [P] the forward's `pixels` output (contributing pixels per Gaussian), or NULL:
+                                                Gaussians nobody blended get their zero gradients without their records being read */
     /* upstream gradients, contiguous [C,H,W]; NULL = all zeros.  Gradients of
      * normal / entropy / amp_distortion / pixels / distribution are accepted by
      * the reference and ignored by its kernels, so they are not part of the ABI */
