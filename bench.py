@@ -93,30 +93,42 @@ def timed_steps(step_fn, steps, warmup, sync_fn, dist=None):
 # ---------------------------------------------------------------------------
 # algorithmic bytes; P_vis = radii > 0, R = tile instances, N = pixels
 # ---------------------------------------------------------------------------
-def algorithmic_bytes(P, P_vis, R, N, T, R_walked=None, forward_only=False):
-    """per visible Gaussian 1516 B, culled 432 B, per instance 268 B (44 B of binning: keys 12, sort 24,
-    ranges 8; 224 B of rendering: K6 76, K7 148), per pixel 224 B.  With ``R_walked`` the rendering bytes are charged
-    only for the list entries a tile walks (up to its deepest contributor): early termination makes the rest of
-    a list dead data that no implementation of the algorithm has to read, so the all-R figure is not a bound."""
+def algorithmic_bytes(P, P_vis, R, N, T, forward_only=False, units=None):
+    """per visible Gaussian 1516 B (K1 484, K2 8, K3 20, K8 92, K9 836, accumulator clears 76), culled
+    432 B, per instance 268 B (44 B of binning: keys 12, sort 24, ranges 8; 224 B of rendering: K6 76, K7 148), per
+    pixel 224 B.  Without ``units`` this is the formula as written (the reference algorithm: every instance binned and
+    rendered, every visible Gaussian given its appearance and a gradient row).
+
+    With ``units`` the same per-unit constants are charged for the units this implementation's launches PROCESS; the
+    lazy stages make the formula as written an over-count, not a bound (it printed > 8 TB/s at 5 M @ 1080p):
+      P_app   visible Gaussians whose appearance K1 evaluates (SH colour + phasor: 320 B of SH read, 52 B written; the
+              others cost K1 112 B of geometry) -- those in front of the depth cut, all of them without a cut
+      R_bin   instances that are counted, scattered and sorted (the near slab, + the far slab of flagged tiles)
+      R_walk  list entries the render stages walk (per tile up to its deepest contributor: early termination)
+      P_blend Gaussians some pixel blended: K8 + K9 (928 B) run for those, every other Gaussian only gets its 376 B
+              of zero gradient rows (+ 8 B of radii), like a culled one"""
     P_cull = P - P_vis
-    Rr = R if R_walked is None else R_walked
+    u = dict(P_app=P_vis, R_bin=R, R_walk=R, P_blend=P_vis)
+    if units:
+        u.update({k: v for k, v in units.items() if v is not None})
+    P_app, R_bin, R_walk, P_blend = u["P_app"], u["R_bin"], u["R_walk"], u["P_blend"]
     per_kernel = {
-        "preprocess_fwd": 484 * P_vis + 48 * P_cull,
-        "tile_count": 8 * P_vis + 8 * R,        # reference scan (K2) + tile ranges (K5)
-        "tile_scatter": 20 * P_vis + 12 * R,    # reference duplicateWithKeys (K3)
-        "tile_sort": 24 * R,                    # reference key sort (K4), one read + one write of a pair
-        "render_fwd": 76 * Rr + 128 * N,
-        "render_bwd": 148 * Rr + 96 * N,
-        "preprocess_bwd": 928 * P_vis + 384 * P_cull,
+        "preprocess_fwd": 484 * P_app + 112 * (P_vis - P_app) + 48 * P_cull,
+        "tile_count": 8 * P_vis + 8 * R_bin,        # reference scan (K2) + tile ranges (K5)
+        "tile_scatter": 20 * P_vis + 12 * R_bin,    # reference duplicateWithKeys (K3)
+        "tile_sort": 24 * R_bin,                    # reference key sort (K4), one read + one write of a pair
+        "render_fwd": 76 * R_walk + 128 * N,
+        "render_bwd": 148 * R_walk + 96 * N,
+        "preprocess_bwd": 928 * P_blend + 384 * (P - P_blend),
         "memset": 76 * P_vis,
     }
-    whole = 1516 * P_vis + 432 * P_cull + 44 * R + 224 * Rr + 224 * N
     if forward_only:       # SURVEY 8(d): 512 P_vis + 48 P_cull + 120 R + 128 N
-        whole = 512 * P_vis + 48 * P_cull + 44 * R + 76 * Rr + 128 * N
-    return per_kernel, whole
+        for k in ("render_bwd", "preprocess_bwd", "memset"):
+            per_kernel[k] = 0
+    return per_kernel, sum(per_kernel.values())
 
 
-def walked_instances(dev):
+def walked_instances(dev, radii=None):
     """List entries the render stages have to touch: per tile, the deepest contributor over its four 8x8
     quadrants (the backward starts there; the forward stops a little later, when its last pixel saturates),
     read from the scratch of the most recent forward."""
@@ -129,7 +141,11 @@ def walked_instances(dev):
     T = ((b["W"] + 15) // 16) * ((b["H"] + 15) // 16)
     tm = b["img"][L.img_tile_max:L.img_tile_max + T * 16].view(torch.int32).reshape(T, 4)
     ctrl = b["img"][L.img_ctrl:L.img_ctrl + 64].view(torch.int32).cpu().tolist()
+    cut = float(api.last_call_stats.get("depth_cut", 0.0) or 0.0)
+    depth = b["geom"][L.geom_depth:L.geom_depth + 4 * b["P"]].view(torch.float32)
     return {"per_tile_deepest": int(tm.max(dim=1).values.sum().item()), "per_quadrant_sum": int(tm.sum().item()),
+            # Gaussians in front of the depth cut (the preprocess kernel gives only those their appearance); None = all
+            "near_gaussians": int(((depth <= cut) & (radii > 0)).sum().item()) if (cut > 0.0 and radii is not None) else None,
             # lazy binning / lazy sort bookkeeping of that forward (ctrl words, gft_internal.h)
             "near_slab_instances": ctrl[5], "far_slab_instances_binned": ctrl[8], "flagged_quadrants": ctrl[4],
             "depth_cut": api.last_call_stats.get("depth_cut", 0.0)}
@@ -720,8 +736,9 @@ def main():
     radii = state["radii"]
     P_vis = int((radii > 0).sum().item())
     R = int(api.last_call_stats["num_rendered"])
-    walked = walked_instances(dev)
+    walked = walked_instances(dev, radii)
     pairs = float(state["pixels"].double().sum().item())      # (pixel, Gaussian) pairs that were blended
+    P_blend = int((state["pixels"] > 0).sum().item())         # Gaussians with a non-zero gradient row
     restarts = (api.last_call_stats.get("restarts", 0), api.last_call_stats.get("forwards", 0))
 
     exchange = None
@@ -734,29 +751,40 @@ def main():
 
     if env["rank"] == 0:
         fo = bool(cfg.get("forward_only"))
-        per_kernel, whole = algorithmic_bytes(P, P_vis, R, N, T, forward_only=fo)
-        R_walked = walked["per_tile_deepest"] if walked else R
-        per_kernel_w, whole_w = algorithmic_bytes(P, P_vis, R, N, T, R_walked, forward_only=fo)
+        # SURVEY 8(d) as written (reference algorithm) and the same constants on the units the launches process
+        ref_kernel, ref_whole = algorithmic_bytes(P, P_vis, R, N, T, forward_only=fo)
+        units = None
+        if walked:
+            units = {"P_app": walked["near_gaussians"], "R_bin": walked["near_slab_instances"] + walked["far_slab_instances_binned"]
+                     if walked["depth_cut"] > 0.0 else R, "R_walk": walked["per_tile_deepest"],
+                     "P_blend": P_vis if fo else P_blend}
+        per_kernel, whole = algorithmic_bytes(P, P_vis, R, N, T, forward_only=fo, units=units)
         calls = max(prof["forward_calls"], 1)
         stage_ms = {k[:-3]: prof[k] / calls for k in prof if k.endswith("_ms")}
         dom = max(stage_ms, key=lambda k: stage_ms[k])
         dom_ms = stage_ms[dom]
-        achieved = per_kernel[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        achieved = gbs(per_kernel[dom], dom_ms)
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
         cnt = load_counters(dom, args.workload)
         traffic = cnt["hbm_bytes"] if cnt else None
         all_cnt = [load_counters(k, args.workload) for k in stage_ms if k != "memset"]
         path_traffic = sum(c["hbm_bytes"] for c in all_cnt) if all(all_cnt) else None
+        # `achieved` / `frac`: SURVEY 8(d)'s per-unit bytes x the units this launch processes (for the render stages the
+        # list entries walked) / the kernel's mean duration by HIP events.  `traffic`: HBM bytes of one launch by the
+        # committed --pmc passes.  `reference_formula`: the same per-unit bytes x every instance, as the reference
+        # algorithm moves them -- kept for comparison with round 1; it is not a bound for a lazy implementation.
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": per_kernel[dom], "avg_launch_ms": dom_ms,
-                    # what the counters say this kernel really moves, per launch, over the same duration
-                    "counter_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_ms > 0) else None,
+                    "units_processed": units,
+                    "counter_frac": (gbs(traffic, dom_ms) / HBM_PEAK_GBS) if (traffic and dom_ms > 0) else None,
                     "counter_source": cnt["source"] if cnt else None,
-                    # the same stage charged only for the list entries its tiles walk (early termination)
-                    "algorithmic_bytes_walked": per_kernel_w[dom],
-                    "frac_walked": (per_kernel_w[dom] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_ms > 0 else None}
+                    "reference_formula": {"algorithmic_bytes_per_launch": ref_kernel[dom], "achieved": gbs(ref_kernel[dom], dom_ms),
+                                          "frac": gbs(ref_kernel[dom], dom_ms) / HBM_PEAK_GBS,
+                                          "note": "SURVEY 8(d) x all instances (what the reference algorithm moves); early "
+                                                  "termination makes most of it dead data: not a bound"}}
         if dom in FLOPS_PER_PAIR:
             # the render kernels are bound by VALU issue, not by HBM: report that ceiling beside the byte figures
             useful = pairs * FLOPS_PER_PAIR[dom]
@@ -781,20 +809,24 @@ def main():
                                       "measured in deform_exchange)" % world},
             "mpix_per_s": value * N / 1e6,
             "roofline": roofline,
-            # whole step.  `frac` charges the rendering bytes (224 B per instance) for the list entries the tiles
-            # walk; `frac_all_instances` is SURVEY 8(d)'s formula as written (every instance), which early
-            # termination makes an over-count -- it is not a bound (6290 GB/s is the measured copy ceiling).
-            "path_roofline": {"algorithmic_bytes_per_step": whole_w,
-                              "achieved_GBs": whole_w / (ms_per_step * 1e-3) / 1e9,
-                              "frac": whole_w / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "instances": R, "instances_walked": R_walked,
+            # whole step: per-unit bytes of SURVEY 8(d) x units processed (P_app, R_bin, R_walk, P_blend, see
+            # algorithmic_bytes) / step time; `reference_formula_*`: 8(d) as written for the reference algorithm.
+            # 6290 GB/s is the measured copy ceiling of the part.
+            "path_roofline": {"algorithmic_bytes_per_step": whole,
+                              "achieved_GBs": gbs(whole, ms_per_step),
+                              "frac": gbs(whole, ms_per_step) / HBM_PEAK_GBS,
+                              "per_stage_bytes": per_kernel,
+                              "instances": R, "instances_binned": units["R_bin"] if units else R,
+                              "instances_walked": units["R_walk"] if units else R,
                               "instances_walked_per_quadrant_sum": walked["per_quadrant_sum"] if walked else None,
-                              "algorithmic_bytes_all_instances": whole,
-                              "frac_all_instances": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "gaussians_visible": P_vis, "gaussians_with_appearance": (units or {}).get("P_app") or P_vis,
+                              "gaussians_blended": P_blend if not fo else None,
+                              "reference_formula_bytes": ref_whole,
+                              "reference_formula_frac": gbs(ref_whole, ms_per_step) / HBM_PEAK_GBS,
                               "achievable_copy_GBs": 6290.0,
                               # HBM bytes of all stages as the counters saw them (profiles/counters.json)
                               "counter_bytes_per_step": path_traffic,
-                              "counter_frac": (path_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if path_traffic else None,
+                              "counter_frac": (gbs(path_traffic, ms_per_step) / HBM_PEAK_GBS) if path_traffic else None,
                               "gpu_ms_sum_of_stages": sum(stage_ms.values())},
             "binning_restarts": {"restarted_forwards": restarts[0], "forwards": restarts[1]},
             "lazy_binning": {k: walked[k] for k in ("depth_cut", "near_slab_instances", "far_slab_instances_binned",
@@ -854,7 +886,7 @@ def main_loop(args, env, world, dev, dist):
                     for k in prof if k.endswith("_ms")}
         raster_ms_per_it = sum(prof[k] for k in prof if k.endswith("_ms")) / n_prof
         dom = max(stage_ms, key=lambda k: stage_ms[k])
-        per_kernel, whole = algorithmic_bytes(P, P, R, N, T, walked["per_tile_deepest"] if walked else None)
+        per_kernel, whole = algorithmic_bytes(P, P, R, N, T, units={"R_walk": walked["per_tile_deepest"]} if walked else None)
         ms = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
         achieved = per_kernel[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0

@@ -18,7 +18,12 @@ CLOCK_GHZ, SIMDS = 2.4, 1024
 STAGE_OF = {"k_preprocess_fwd": "preprocess_fwd", "k_tile_count": "tile_count", "k_tile_scatter": "tile_scatter",
             "k_tile_sort_small": "tile_sort", "k_tile_sort_big": "tile_sort", "k_tile_front": "tile_sort", "k_tile_tail": "tile_sort",
             "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd", "k_tile_order": "render_bwd",
-            "k_preprocess_bwd": "preprocess_bwd", "k_offset_reduce": "preprocess_bwd"}
+            "k_preprocess_bwd": "preprocess_bwd", "k_offset_reduce": "preprocess_bwd",
+            # tile-pull binning of the near slab (frames with a depth cut).  k_super_bin runs twice per forward (count
+            # pass = stage tile_count, scatter pass = stage tile_scatter): one kernel name, so both launches are booked
+            # under tile_count and tile_scatter holds only k_tile_scatter's (idle) far-slab launch
+            "k_super_bin": "tile_count", "k_tile_pull": "tile_sort", "k_appearance_far": "preprocess_fwd"}
+ALL_STAGES = ("preprocess_fwd", "tile_count", "tile_scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
 
 
 def short(n):
@@ -92,7 +97,12 @@ def main():
         if k in sq:
             s["valu_insts"] += (sq[k]["valu_insts"] or 0.0) * per_step
             s["us_profiled"] += sq[k]["us_profiled"] * per_step
+    for st in ALL_STAGES:
+        stages[st]                       # a stage none of whose kernels ran keeps a zero entry
     for st, s in stages.items():
+        if not s["kernels"]:
+            s["dominant_kernel"] = None
+            continue
         main_k = max(s["kernels"], key=lambda k: sq.get(k, {}).get("us_profiled", 0.0))
         s["dominant_kernel"] = main_k
         for f in ("mean_resident_waves_per_simd", "valu_issue_frac", "valu_issue_slot_frac", "wait_frac", "stall_frac"):
@@ -103,7 +113,7 @@ def main():
     json.dump(doc, open(cpath, "w"), indent=1)
     for st, s in stages.items():
         print("%-15s hbm %8.1f MB  valu insts %11.0f  %7.1f us  waves/SIMD %s  VALU slots %s" % (
-            st, s["hbm_bytes"] / 1e6, s["valu_insts"], s["us_profiled"], s["mean_resident_waves_per_simd"], s["valu_issue_slot_frac"]))
+            st, s["hbm_bytes"] / 1e6, s["valu_insts"], s["us_profiled"], s.get("mean_resident_waves_per_simd"), s.get("valu_issue_slot_frac")))
 
 
 if __name__ == "__main__":

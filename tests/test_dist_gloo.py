@@ -109,3 +109,14 @@ def test_algorithmic_bytes_formula():
     assert abs(whole / 1e9 - 2.29) < 0.05
     # the per-kernel split adds up to the whole-path figure
     assert sum(per.values()) == whole
+    per_f, whole_f = bench.algorithmic_bytes(P=1_000_000, P_vis=910_000, R=3_000_000, N=640 * 480, T=1200, forward_only=True)
+    assert whole_f == 512 * 910_000 + 48 * 90_000 + 120 * 3_000_000 + 128 * 307_200
+    # charged for the units a lazy implementation processes: the same constants, never more than the formula as written,
+    # equal to it when every unit is processed
+    full = dict(P_app=910_000, R_bin=3_000_000, R_walk=3_000_000, P_blend=910_000)
+    assert bench.algorithmic_bytes(1_000_000, 910_000, 3_000_000, 307_200, 1200, units=full)[1] == whole
+    lazy = dict(P_app=300_000, R_bin=1_100_000, R_walk=600_000, P_blend=250_000)
+    per_l, whole_l = bench.algorithmic_bytes(1_000_000, 910_000, 3_000_000, 307_200, 1200, units=lazy)
+    assert whole_l < whole and all(per_l[k] <= per[k] for k in per)
+    assert per_l["render_bwd"] == 148 * 600_000 + 96 * 307_200
+    assert per_l["preprocess_bwd"] == 928 * 250_000 + 384 * 750_000
