@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 DEFORM_MAX_INPUTS = 96          # GFT_DEFORM_MAX_INPUTS (include/gftorf_deform.h)
 ACC_STRIDE = 16
 
@@ -46,7 +46,7 @@ BACKWARD_FIELDS = [
     "dL_dout_color", "dL_dout_phasor", "dL_dout_depth", "dL_dout_acc", "dL_dout_depth_distortion",
     "geom", "img", "binning", "acc",
     "dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dcov3D", "dL_dsh", "dL_dsh_p",
-    "dL_dscales", "dL_drotations", "dL_dphase_offset", "dL_ddc_offset",
+    "dL_dscales", "dL_drotations", "dL_dphase_offset", "dL_ddc_offset", "det_partials",
 ]
 
 LAYOUT_FIELDS = [
@@ -129,7 +129,7 @@ class AdamTensor(C.Structure):
 
 EXPORTS = [
     "gft_abi_version", "gft_lazy_sort", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes", "gft_acc_bytes",
-    "gft_get_layout", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_forward_late", "gft_backward",
+    "gft_det_partials_bytes", "gft_get_layout", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_forward_late", "gft_backward",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
     "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi",
@@ -162,6 +162,8 @@ def load():
     lib.gft_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.gft_acc_bytes.restype = C.c_size_t
     lib.gft_acc_bytes.argtypes = [C.c_int32]
+    lib.gft_det_partials_bytes.restype = C.c_size_t
+    lib.gft_det_partials_bytes.argtypes = [C.c_int64]
     lib.gft_get_layout.restype = C.c_int
     lib.gft_get_layout.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(Layout)]
     lib.gft_forward_preprocess.restype = C.c_int

@@ -68,6 +68,9 @@ _slab_state = {}
 # render kernel, +48 us beside the binning kernels: HBM time is conserved, the fill is not free anywhere.
 import os as _os
 _ZERO_FILL = _os.environ.get("GFT_GRADS_ZERO_FILL", "0") != "0"
+# GFT_BWD_DETERMINISTIC=1: the backward forms its per-Gaussian sums in a fixed order instead of with float atomics
+# (bit-reproducible gradients; several times slower: for tests)
+_DETERMINISTIC = _os.environ.get("GFT_BWD_DETERMINISTIC", "0") != "0"
 _SLAB_DEFAULT, _SLAB_MAX = 896, 8192
 _HINT_HEADROOM = 1.25
 _LIST_HEADROOM = 1.2      # longest tile list of the previous frame -> guess for this one
@@ -428,6 +431,11 @@ def run_backward(prep, grads_out, geom, binning, img, debug=False):
     io.dL_dout_color, io.dL_dout_phasor = _ptr(keep[0]), _ptr(keep[1])
     io.dL_dout_depth, io.dL_dout_acc, io.dL_dout_depth_distortion = _ptr(keep[2]), _ptr(keep[3]), _ptr(keep[4])
     io.geom, io.img, io.binning = _ptr(geom), _ptr(img), _ptr(binning)
+    det = None
+    if _DETERMINISTIC and P and binning_capacity(binning):
+        # test mode: partial rows per (list entry, quadrant), added in a fixed order (gft_backward_io.det_partials)
+        det = torch.empty((lib.gft_det_partials_bytes(binning_capacity(binning)) // 4,), dtype=torch.float32, device=dev)
+        io.det_partials = det.data_ptr()
     if debug:
         cpu_args = cpu_deep_copy_tuple(prep["debug_args"] + tuple(grads_out) + (geom, binning, img))
     try:

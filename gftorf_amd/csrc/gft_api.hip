@@ -24,6 +24,10 @@ int gft_fail(const char* fmt, ...)
 
 extern "C" const char* gft_last_error(void) { return g_err; }
 extern "C" int gft_abi_version(void) { return GFT_ABI_VERSION; }
+extern "C" size_t gft_det_partials_bytes(int64_t binning_instances)
+{
+    return binning_instances > 0 ? (size_t)binning_instances * 4 * GFT_ACC_STRIDE * sizeof(float) : 0;
+}
 
 // ---- layout ------------------------------------------------------------------
 static inline size_t align_up(size_t x) { return (x + GFT_ALIGN - 1) & ~(size_t)(GFT_ALIGN - 1); }
@@ -680,6 +684,11 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     if (!cfg->acc_zeroed) {
         StageTimer t(s, ST_MEMSET);
         GFT_CHECK_HIP(hipMemsetAsync(io->acc, 0, (size_t)cfg->P * GFT_ACC_STRIDE * sizeof(float), s));
+    }
+    if (num_rendered > 0 && io->det_partials) {
+        // deterministic mode: slots of (entry, quadrant) pairs that store no row must read as zero
+        StageTimer t(s, ST_MEMSET);
+        GFT_CHECK_HIP(hipMemsetAsync(io->det_partials, 0, gft_det_partials_bytes(num_rendered), s));
     }
     if (num_rendered > 0) {
         StageTimer t(s, ST_RENDER_BWD);

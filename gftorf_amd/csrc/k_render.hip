@@ -351,6 +351,7 @@ struct RenderBwdArgs {
     const float* __restrict__ g_color; const float* __restrict__ g_phasor; const float* __restrict__ g_depth;
     const float* __restrict__ g_acc; const float* __restrict__ g_dd;
     float* acc;   // [P][GFT_ACC_STRIDE]
+    float* det;   // deterministic mode: [binning instance][quadrant][16] partial rows instead of atomics (NULL: atomics)
 };
 
 __device__ __forceinline__ float swap32_add(float x, float y)
@@ -638,7 +639,12 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
             // 64 pixels -> one partial per value in every fourth lane: 15 of them go straight to the Gaussian's
             // accumulator row (one 64-byte line of float atomics, fire and forget)
             const float tot = wave_reduce16(L01, L23, L45, L67, H01, H23, H45, H67);
-            if ((lane & 3) == 0 && lane < 4 * GFT_NUM_ACC && tot != 0.f)
+            if (a.det) {
+                // deterministic mode: the row of this (list entry, quadrant) is stored; k_acc_reduce_det adds the rows
+                // in a fixed order
+                if ((lane & 3) == 0 && lane < 4 * GFT_NUM_ACC)
+                    a.det[((size_t)phys((uint32_t)(hi - 1 - j)) * 4 + quad) * GFT_ACC_STRIDE + (lane >> 2)] = tot;
+            } else if ((lane & 3) == 0 && lane < 4 * GFT_NUM_ACC && tot != 0.f)
                 atomicAdd(&a.acc[(size_t)sId[j] * GFT_ACC_STRIDE + (lane >> 2)], tot);
         };
 
@@ -653,6 +659,41 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
         }
         // (issuing two splats per iteration in one basic block so that the scheduler can overlap their
         // exp / rcp / DPP latencies was measured: 214 vs 198 us, dropped)
+    }
+}
+
+// Deterministic mode: adds the partial rows k_render_bwd stored, tile by tile; inside a tile every list entry is another
+// Gaussian (no two threads touch one accumulator row), its four quadrant rows are added in the order 0..3, and a
+// barrier separates the tiles: every accumulator value is a sum in one fixed order.  One workgroup (a test mode).
+__global__ __launch_bounds__(1024) void k_acc_reduce_det(int T, const uint2* __restrict__ ranges, const uint2* __restrict__ ranges1,
+                                                         const uint32_t* __restrict__ quad_max,
+                                                         const uint32_t* __restrict__ point_list,
+                                                         const float* __restrict__ det, float* acc)
+{
+    const int tid = threadIdx.x;
+    for (int tile = 0; tile < T; tile++) {
+        const uint4 qm = reinterpret_cast<const uint4*>(quad_max)[tile];
+        const uint32_t walked = max(max(qm.x, qm.y), max(qm.z, qm.w));      // entries some quadrant of the tile walked
+        const uint2 rg = ranges[tile];
+        const uint32_t n0 = rg.y - rg.x;
+        const uint32_t r1x = walked > n0 ? ranges1[tile].x : 0u;
+        for (uint32_t i = (uint32_t)tid; i < walked * GFT_ACC_STRIDE; i += 1024u) {
+            const uint32_t c = i / GFT_ACC_STRIDE, k = i % GFT_ACC_STRIDE;
+            if (k >= GFT_NUM_ACC) continue;
+            const uint32_t p = c < n0 ? rg.x + c : r1x + (c - n0);
+            const float* row = det + (size_t)p * 4 * GFT_ACC_STRIDE + k;
+            float s = row[0];
+            s += row[GFT_ACC_STRIDE];
+            s += row[2 * GFT_ACC_STRIDE];
+            s += row[3 * GFT_ACC_STRIDE];
+            if (s != 0.f) {
+                float* dst = acc + (size_t)point_list[p] * GFT_ACC_STRIDE + k;
+                __hip_atomic_store(dst, __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + s,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __threadfence();
+        __syncthreads();
     }
 }
 
@@ -711,6 +752,7 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     a.g_color = io.dL_dout_color; a.g_phasor = io.dL_dout_phasor; a.g_depth = io.dL_dout_depth;
     a.g_acc = io.dL_dout_acc; a.g_dd = io.dL_dout_depth_distortion;
     a.acc = io.acc;
+    a.det = io.det_partials;
     static const int order_on = [] { const char* e = getenv("GFT_BWD_ORDER"); return e ? atoi(e) != 0 : 1; }();
     a.order = order_on ? im.tile_order : nullptr;
     // with the lazy sort the forward's k_tile_tail launch has computed the order (unless a quadrant was flagged: the
@@ -728,5 +770,8 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     a.front_len = lazy ? im.front_len : nullptr;
     const int blocks = a.nseg * 32 * ((a.T + 7) / 8);
     hipLaunchKernelGGL(k_render_bwd, dim3(blocks), dim3(64), 0, s, a);
+    if (a.det)
+        hipLaunchKernelGGL(k_acc_reduce_det, dim3(1), dim3(1024), 0, s, a.T, im.ranges, im.ranges1, im.tile_max, b.point_list,
+                           a.det, io.acc);
     return hipGetLastError();
 }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GFT_ABI_VERSION 5
+#define GFT_ABI_VERSION 6
 
 /* compile-time constants of the reference (RAST/cuda_rasterizer/config.h:15-23) */
 #define GFT_NUM_CHANNELS 3
@@ -165,6 +165,11 @@ typedef struct gft_backward_io {
     float* dL_drotations;   /* [P,4]  required iff scales != NULL */
     float* dL_dphase_offset;/* [1] (written by the library); NULL together with dL_ddc_offset = not wanted (saves a reduction launch) */
     float* dL_ddc_offset;   /* [1] */
+    /* optional: deterministic reduction (tests).  A buffer of gft_det_partials_bytes(binning_instances) bytes: every
+     * (list entry, pixel quadrant) then stores its 16-float partial row there instead of adding it with float atomics,
+     * and one workgroup adds the rows tile by tile, entries in list order, quadrants 0..3: two runs give bit-identical
+     * gradients (the reference's atomicAdd sums, backward.cu:795-886, have no defined order).  NULL = float atomics. */
+    float* det_partials;
 } gft_backward_io;
 
 /* Byte offsets of the sub-arrays inside the scratch buffers (the forward <->
@@ -223,6 +228,7 @@ size_t gft_geom_bytes(int32_t P);
 size_t gft_image_bytes(int32_t W, int32_t H);
 size_t gft_binning_bytes(int64_t R, int32_t W, int32_t H);
 size_t gft_acc_bytes(int32_t P);
+size_t gft_det_partials_bytes(int64_t binning_instances);   /* gft_backward_io.det_partials */
 int gft_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* out /*host*/);
 
 /* The forward in two stages, shaped like the reference's resize callbacks
@@ -297,7 +303,8 @@ int gft_forward_late(int32_t late_slot, uint32_t late_seq, int64_t* flagged_quad
 
 /* The backward of the forward whose scratch buffers `io` carries.  Gradient sums are added with float atomics
  * (as in the reference), so two runs agree to rounding, not bit for bit.  GFT_BWD_SPLIT=0 in the environment
- * keeps one wave per pixel quadrant (default: deep quadrants are walked by two waves). */
+ * keeps one wave per pixel quadrant (default: deep quadrants are walked by two waves).
+ * With io->det_partials the sums are formed in a fixed order instead (bit-reproducible, slower: a test mode). */
 int gft_backward(void* hip_stream, const gft_config* cfg,
                  const gft_backward_io* io, int64_t binning_instances);
 

@@ -170,3 +170,42 @@ def test_c5_5m_1080p_properties(gpu):
     out1, _, _ = Hh.run_gpu(sc, gpu, backward=False)
     for k in ["color", "phasor", "depth", "acc", "radii", "pixels", "distribution", "depth_distortion"]:
         np.testing.assert_array_equal(out[k], out1[k])
+
+
+def test_metric_config_deterministic_backward_is_bit_reproducible(tmp_path, gpu):
+    """The bench workload through GFT_BWD_DETERMINISTIC=1 (fixed-order sums instead of float atomics, 1.1 GB of partial
+    rows): two runs give bit-identical gradients, and they agree with the atomic mode to summation-order rounding --
+    the element-wise band of test_metric_config_1m_vs_oracle is for splats on the 1/255 alpha edge, not for the atomics."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    child, out = tmp_path / "det_full.py", tmp_path / "det_full.npz"
+    child.write_text(
+        "import sys, zlib, numpy as np, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import helpers\n"
+        "from gftorf_amd import synth\n"
+        "sc = synth.make_scene('metric', seed=1234)\n"
+        "res = {}\n"
+        "for run in (0, 1):\n"
+        "    o, g, t = helpers.run_gpu(sc, torch.device('cuda:0'))\n"
+        "    for k, v in g.items():\n"
+        "        if v is not None:\n"
+        "            res['crc%%d_%%s' %% (run, k)] = np.array(zlib.crc32(np.ascontiguousarray(v).tobytes()), np.uint32)\n"
+        "for k in ('means3D', 'means2D', 'opacities', 'scales', 'rotations'):\n"
+        "    res['g_' + k] = g[k]\n"
+        "res['g_shs'] = g['shs'][::16]; res['g_shs_p'] = g['shs_p'][::16]\n"
+        "np.savez(%r, **res)\n" % (os.path.dirname(here), here, str(out)))
+    subprocess.check_call([sys.executable, str(child)], env=dict(os.environ, GFT_BWD_DETERMINISTIC="1"), timeout=900)
+    det = np.load(out)
+    names = sorted(k[5:] for k in det.files if k.startswith("crc0_"))
+    assert len(names) >= 7
+    for k in names:
+        assert int(det["crc0_" + k]) == int(det["crc1_" + k]), k
+    sc = _scene("metric")
+    _, grads, _ = Hh.run_gpu(sc, gpu)
+    for k in ("means3D", "means2D", "opacities", "scales", "rotations"):
+        Hh.assert_close(k, det["g_" + k], grads[k], rtol_max=2e-5, atol=1e-7)
+    Hh.assert_close("shs", det["g_shs"], grads["shs"][::16], rtol_max=2e-5, atol=1e-7)
+    Hh.assert_close("shs_p", det["g_shs_p"], grads["shs_p"][::16], rtol_max=2e-5, atol=1e-7)

@@ -658,3 +658,46 @@ def test_split_backward_matches_one_wave_per_quadrant(tmp_path, scene_kw):
     assert worst < 2e-5, worst
     # and the split really was in use here: the scene has quadrants deeper than three batches
     assert os.environ.get("GFT_BWD_SPLIT", "1") != "0"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_kw", [SCENES["deep_lists"], SCENES["long_lists_lds128k"],
+                                      dict(P=40000, W=64, H=64, scale_lo=0.01, scale_hi=0.05, opacity=0.02)],
+                         ids=["deep_lists", "thousands_per_tile", "thin_fog_far_segments"])
+def test_deterministic_backward_mode(tmp_path, scene_kw, oracle):
+    """GFT_BWD_DETERMINISTIC=1 (gft_backward_io.det_partials): every (list entry, quadrant) stores its partial row and one
+    workgroup adds the rows in a fixed order instead of the float atomics (reference backward.cu:795-886, whose sums
+    have no defined order).  Two runs must agree bit for bit; the result must agree with the atomic mode to
+    summation-order rounding and with the oracle to the usual tolerance.  Cases: segments of the split walk, lists of
+    thousands of entries, quadrants that go on into lazily sorted / far-slab segments."""
+    import subprocess
+    import sys
+    child = tmp_path / "det.py"
+    out = tmp_path / "det.npz"
+    child.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import helpers\n"
+        "scene = helpers.small_scene(**%r)\n"
+        "res = {}\n"
+        "for run in (0, 1):\n"
+        "    o, g, t = helpers.run_gpu(scene, torch.device('cuda:0'), optimize_offsets=True)\n"
+        "    res.update({'%%d_%%s' %% (run, k): v for k, v in g.items() if v is not None})\n"
+        "np.savez(%r, **res)\n"
+        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+           scene_kw, str(out)))
+    subprocess.check_call([sys.executable, str(child)], env=dict(os.environ, GFT_BWD_DETERMINISTIC="1"), timeout=300)
+    det = np.load(out)
+    keys = sorted(k[2:] for k in det.files if k.startswith("0_"))
+    assert "means3D" in keys and "shs" in keys
+    for k in keys:
+        np.testing.assert_array_equal(det["0_" + k], det["1_" + k], err_msg=k)      # bit-reproducible
+    scene = Hh.small_scene(**scene_kw)
+    _, grads, _ = Hh.run_gpu(scene, torch.device("cuda:0"), optimize_offsets=True)   # float atomics
+    worst = 0.0
+    for k in keys:
+        den = np.abs(grads[k]).max() + 1e-30
+        worst = max(worst, float(np.abs(det["0_" + k] - grads[k]).max() / den))
+    assert worst < 2e-5, worst
+    _, b = Hh.run_oracle(oracle, scene)
+    check_grads(b, {k: det["0_" + k] for k in keys}, scene)
