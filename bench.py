@@ -595,6 +595,78 @@ def train_iteration_extra(dev, scene, steps=10, warmup=3):
             "hip_ms": hip_ms, "hip_it_per_s": 1e3 / hip_ms, "eager_glue_ms": eager_ms, "speedup": eager_ms / hip_ms}
 
 
+def pair_extra(dev, scene, steps=20, warmup=5, which=("two", "pair")):
+    """The colour-camera + ToF-camera calls of one iteration (gaussian_renderer/__init__.py:107-128) at the metric size:
+    two GaussianRasterizer calls whose gradients autograd adds, against one GaussianRasterizerPair call (forward on two
+    streams, one set of gradient tensors that the second view's backward adds its blended rows to).  Forward +
+    backward of both views, the same two cameras a small baseline apart."""
+    import numpy as np
+    import torch
+    from gftorf_amd import GaussianRasterizationSettings, GaussianRasterizer, GaussianRasterizerPair, synth
+    cfg, g = scene["cfg"], scene["gaussians"]
+    P, W, H = cfg["P"], cfg["W"], cfg["H"]
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
+
+    def settings(cam, tof):
+        return GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t(scene["bg"]), scale_modifier=1.0,
+            viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=cfg["D"], campos=t(cam["campos"]),
+            prefiltered=False, debug=False, near_n=cam["znear"], far_n=cam["zfar"], depth_range=scene["depth_range"],
+            use_view_dependent_phase=tof)
+    cam_b = synth.make_camera(W, H, w2c=synth.look_at_w2c(0.0, 0.0, 0.0, (0.03, 0.0, 0.0)))     # ToF sensor beside the colour camera
+    sa, sb = settings(scene["cam"], False), settings(cam_b, True)
+    leaf = {k: t(v).requires_grad_(True) for k, v in g.items() if v is not None}
+    m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+    gr = {k: t(v) for k, v in scene["grads"].items()}
+    kw = dict(means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf["shs"], shs_p=leaf["shs_p"],
+              scales=leaf["scales"], rotations=leaf["rotations"])
+    ph, dc = scene["phase_offset"], scene["dc_offset"]
+    ra, rb, rp = GaussianRasterizer(sa), GaussianRasterizer(sb), GaussianRasterizerPair(sa, sb)
+    ups = [gr["color"], gr["phasor"], gr["depth"], gr["acc"], gr["depth_distortion"]]     # fixed upstream gradients, as in the headline step
+    outs5 = lambda o: [o[0], o[1], o[2], o[4], o[6]]
+
+    def clear():
+        for v in leaf.values():
+            v.grad = None
+        m2.grad = None
+
+    def two_calls():
+        clear()
+        torch.autograd.backward(outs5(ra(**kw)) + outs5(rb(phase_offset=ph, dc_offset=dc, **kw)), ups + ups)
+
+    def pair():
+        clear()
+        oa, ob = rp(phase_offset=(0.0, ph), dc_offset=(0.0, dc), **kw)
+        torch.autograd.backward(outs5(oa) + outs5(ob), ups + ups)
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / steps
+
+    if "two" not in which:                       # (profiling runs time one variant alone)
+        return {"pair_ms": timed(pair)}
+    two_ms = timed(two_calls)
+    g_two = {k: v.grad.clone() for k, v in leaf.items()}
+    if "pair" not in which:
+        return {"two_calls_ms": two_ms}
+    pair_ms = timed(pair)
+    worst = max(float((v.grad - g_two[k]).abs().max() / (g_two[k].abs().max() + 1e-30)) for k, v in leaf.items())
+    blended_b = None
+    return {"what": "colour + ToF camera of one iteration, %d Gaussians, %dx%d, forward + backward of both views" % (P, W, H),
+            "two_calls_ms": two_ms, "pair_ms": pair_ms, "speedup": two_ms / pair_ms, "pairs_per_s": 1e3 / pair_ms,
+            "max_rel_gradient_difference": worst,
+            "bytes_not_moved_per_pair": {"zero_gradient_rows_of_the_second_view": "376 B x (P - Gaussians the second view blended)",
+                                         "autograd_sum_of_two_dense_gradient_sets": 3 * 376 * P}}
+
+
 def knn_extra(dev, P=1_000_000):
     """SURVEY 8(f) row 3 beside the headline metric: distCUDA2 (mean squared distance to the 3
     nearest neighbours, the scale initialisation of scene/gaussian_model.py:194-199) on a
@@ -840,7 +912,9 @@ def main():
             torch.cuda.empty_cache()
             train_extra = train_iteration_extra(dev, scene)
             torch.cuda.empty_cache()
-            out["extras"] = {"assemble_inputs": assemble_extra(dev), "knn": knn_extra(dev),
+            pair_x = pair_extra(dev, scene)
+            torch.cuda.empty_cache()
+            out["extras"] = {"render_pair": pair_x, "assemble_inputs": assemble_extra(dev), "knn": knn_extra(dev),
                              "adam": adam_extra(dev), "deform_network": deform_extra(dev),
                              "densify": densify_extra(dev), "train_iteration": train_extra}
         if world == 1 and not args.no_cpu_baseline:

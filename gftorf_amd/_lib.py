@@ -28,6 +28,7 @@ class Config(C.Structure):
         ("want_backward", C.c_int32),
         ("acc_zeroed", C.c_int32),
         ("grads_zeroed", C.c_int32),
+        ("grads_accumulate", C.c_int32),
         ("bg_stride_c", C.c_int64), ("bg_stride_y", C.c_int64), ("bg_stride_x", C.c_int64),
     ]
 

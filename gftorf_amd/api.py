@@ -184,10 +184,14 @@ class _Settings(NamedTuple):
 
 
 def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
-                   cov3Ds_precomp, ph_off, dc_off, want_bw, with_acc):
+                   cov3Ds_precomp, ph_off, dc_off, want_bw, with_acc, stream=None, hint_slot=0, share_grads=None):
     """One forward of the native rasterizer (``RasterizeGaussiansCUDA``, rasterize_points.cu:42-165): allocates the
     outputs and the three scratch buffers, runs the C ABI on torch's current stream.  ``s`` holds the settings fields
-    (``GaussianRasterizationSettings`` or ``_Settings``), ``ph_off`` / ``dc_off`` are floats.  Returns a dict."""
+    (``GaussianRasterizationSettings`` or ``_Settings``), ``ph_off`` / ``dc_off`` are floats.  Returns a dict.
+
+    For :mod:`gftorf_amd.pair`: ``stream`` = raw hipStream_t to launch on instead of torch's current stream (the caller
+    orders it against the current stream), ``hint_slot`` keeps the binning hints of the two cameras of a pair apart,
+    ``share_grads`` = the ``prep`` of the pair's other view, whose gradient tensors this view's backward adds to."""
     lib = _lib.load()
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -250,7 +254,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
     if want_bw and with_acc and P:
         prep = prepare_backward(s, means3D_c, opac_c, sh_c, sh_p_c, scales_c, rot_c, cov_c, radii, geom, img,
                                 (bg_c, bsc, bsy, bsx), (view_c, proj_c, campos_c), ph_off, dc_off, acc_buf,
-                                colors_c is not None, cov_c is not None, want_bw, pixels, zero_fill=_ZERO_FILL)
+                                colors_c is not None, cov_c is not None, want_bw, pixels,
+                                zero_fill=_ZERO_FILL and share_grads is None, share_grads=share_grads)
         if prep["zero_buf"] is not None:
             io.grads_zero = prep["zero_buf"].data_ptr()
             io.grads_zero_bytes = prep["zero_buf"].numel() * 4
@@ -263,9 +268,10 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         planes.zero_()
         binning = torch.empty((0,), device=dev, dtype=torch.uint8)
     else:
-        stream = _lib.raw_stream(dev)
+        if stream is None:
+            stream = _lib.raw_stream(dev)
         num_rendered = C.c_int64(0)
-        hint_key = (dev.index, P, W, H)
+        hint_key = (dev.index, P, W, H) if not hint_slot else (dev.index, P, W, H, hint_slot)
         hint, list_hint, cut_hint, near_hint = _instance_hint.get(hint_key, (None, 0, 0.0, 0))
         try:
             with _lib.on_device(dev):
@@ -287,16 +293,27 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
-                    slab = _slab_state.setdefault(hint_key, {"per_tile": _SLAB_DEFAULT, "late": None, "clean": 0})
+                    slab = _slab_state.setdefault(hint_key, {"per_tile": _SLAB_DEFAULT, "late": None, "clean": 0, "nocut": 0})
                     if slab["late"] is not None:
                         flagged = C.c_int64(-1)
                         lib.gft_forward_late(slab["late"][0], slab["late"][1], C.byref(flagged))
-                        if flagged.value > 0:
+                        # a few quadrants that outlive the near slab are cheap (only their tiles take the second pass):
+                        # the slab is widened when more than 1 % of the frame's quadrants did
+                        quads = 4 * ((W + 15) // 16) * ((H + 15) // 16)
+                        if flagged.value > max(4, quads // 100):
                             slab["per_tile"], slab["clean"] = min(_SLAB_MAX, int(slab["per_tile"] * 1.25) + 1), 0
-                        elif flagged.value == 0:
+                        elif flagged.value >= 0:
                             slab["clean"] += 1
                             if slab["clean"] >= 200 and slab["per_tile"] > _SLAB_DEFAULT:
                                 slab["per_tile"], slab["clean"] = max(_SLAB_DEFAULT, int(slab["per_tile"] * 0.9)), 0
+                    # A widened slab that no longer leaves out half of the frame gets no cut (and therefore no reports to
+                    # narrow it again): after 50 such frames it starts over at the default width
+                    if cut_hint > 0.0 or slab["per_tile"] == _SLAB_DEFAULT:
+                        slab["nocut"] = 0
+                    else:
+                        slab["nocut"] += 1
+                        if slab["nocut"] >= 50:
+                            slab["per_tile"], slab["nocut"], slab["clean"] = _SLAB_DEFAULT, 0, 0
                     hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
                                               near_instances=int(near_hint), depth_cut=float(cut_hint),
                                               near_per_tile=int(slab["per_tile"]))
@@ -344,7 +361,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
 
 
 def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, img, bg, consts, ph_off, dc_off,
-                     acc, want_colors, want_cov, want_bw_records=True, pixels=None, zero_fill=False):
+                     acc, want_colors, want_cov, want_bw_records=True, pixels=None, zero_fill=False, share_grads=None):
     """Everything of a backward that does not depend on the upstream gradients: the gradient tensors, the argument
     block, the config.  The forward calls it BEFORE it queues its kernels, so that this host work overlaps the device's
     previous work instead of sitting between the forward's last kernel and the backward's first one."""
@@ -363,7 +380,11 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
                   sh_p=(P, M_p, 2) if has_sh_p else None, scales=(P, 3) if has_scales else None,
                   rotations=(P, 4) if has_scales else None)
     zero_buf = None
-    if zero_fill:
+    if share_grads is not None:
+        # second view of a pair (gftorf_amd.pair): its backward adds to the first view's gradient tensors
+        # (cfg.grads_accumulate); only the two scalar offset gradients are its own
+        g = {k: v for k, v in share_grads["grads"].items() if k != "offsets"}
+    elif zero_fill:
         # One buffer for all per-Gaussian gradients (every tensor a contiguous slice, 16-byte aligned): the forward
         # zero-fills it beside its render kernel, the backward writes only the rows of blended Gaussians
         sizes = {k: (int(torch.Size(v).numel()) + 3) // 4 * 4 for k, v in shapes.items() if v is not None}
@@ -384,6 +405,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
     cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw_records)
     cfg.acc_zeroed = int(acc_zeroed)
     cfg.grads_zeroed = int(zero_buf is not None)
+    cfg.grads_accumulate = int(share_grads is not None)
     io = _lib.BackwardIO()
     io.bg, io.means3D, io.radii = _ptr(bg_c), _ptr(means3D) if P else None, _ptr(radii) if P else None
     io.scales = _ptr(scales) if has_scales else None

@@ -669,6 +669,8 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     if ((io->scales == nullptr || io->rotations == nullptr) == (io->cov3D_precomp == nullptr))
         return gft_fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
     if (io->scales && (!io->dL_dscales || !io->dL_drotations)) return gft_fail("gft_backward: dL_dscales/dL_drotations NULL");
+    if (cfg->grads_accumulate && !cfg->want_backward)
+        return gft_fail("gft_backward: grads_accumulate needs the forward's direction-gradient records (want_backward)");
 
     gft_layout L;
     gft_compute_layout(cfg->P, cfg->W, cfg->H, num_rendered, &L);

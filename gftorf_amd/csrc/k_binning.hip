@@ -58,6 +58,15 @@ struct DepthBins {
     float near_n;
 };
 
+// Does a depth cut pay for a frame of R instances?  `target` = wanted near-slab instances (caller's slab width x tiles),
+// `target_min` = the same at the default width.  The frame must be dense (R >= 3 x the default slab: in a sparser one
+// too many quadrants outlive any near slab and the second pass costs more than the first one saved), and the slab the
+// caller asks for -- possibly widened after frames with flagged quadrants -- must still leave out half of the frame.
+__device__ __forceinline__ bool cut_pays(uint32_t R, uint32_t target, uint32_t target_min)
+{
+    return target > 0u && R / 3u >= target_min && R / 2u >= target;
+}
+
 __device__ __forceinline__ int depth_bin(uint32_t dbits, const DepthBins& db)
 {
     const float b = __log2f(__uint_as_float(dbits) * db.inv_near) * db.scale;
@@ -161,6 +170,7 @@ struct CountArgs {
     uint32_t* dhist;                // pass 0 only
     DepthBins db;
     uint32_t target;                // wanted near-slab instances of the next frame
+    uint32_t target_min;            // the same at the default slab width (cut_pays)
     const uint32_t* __restrict__ unit_flag;   // pass 1 only
     uint32_t cap;
 };
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_count(CountArgs a)
         uint32_t cut_next = GFT_NO_CUT;
         // (a cut pays when the near slab is a small part of the frame: with R below 3 x the target too many
         // quadrants outlive the near slab and the second pass costs more than the first one saved)
-        if (a.target > 0u && R / 3u >= a.target && cut_bin + 1u < GFT_DHIST_BINS)
+        if (cut_pays(R, a.target, a.target_min) && cut_bin + 1u < GFT_DHIST_BINS)
             cut_next = __float_as_uint(a.db.near_n * exp2f((float)(cut_bin + 1u) / a.db.scale));
         a.ctrl[GFT_CTRL_TOTAL] = R;
         a.ctrl[GFT_CTRL_TOTAL0] = total;
@@ -871,7 +881,7 @@ struct SuperArgs {
     uint32_t* mail; uint32_t seq;
     uint32_t* dhist;
     DepthBins db;
-    uint32_t target;
+    uint32_t target, target_min;
     uint32_t cap;
 };
 
@@ -967,7 +977,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         dhist_scan(s_dh, a.target, R, cut_bin);
         if (tid == 0) {
             uint32_t cut_next = GFT_NO_CUT;
-            if (a.target > 0u && R / 3u >= a.target && cut_bin + 1u < GFT_DHIST_BINS)
+            if (cut_pays(R, a.target, a.target_min) && cut_bin + 1u < GFT_DHIST_BINS)
                 cut_next = __float_as_uint(a.db.near_n * exp2f((float)(cut_bin + 1u) / a.db.scale));
             const uint32_t near_total = __hip_atomic_load(&a.ctrl[GFT_CTRL_NEARSUM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.ctrl[GFT_CTRL_TOTAL] = R;
@@ -1357,6 +1367,7 @@ hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomV
     const float fr = c.far_n > 2.0f * nr ? c.far_n : 2.0f * nr;
     a.db.near_n = nr; a.db.inv_near = 1.0f / nr; a.db.scale = (float)GFT_DHIST_BINS / log2f(fr / nr);
     a.target = near_slab_target(T, per_tile);
+    a.target_min = near_slab_target(T, 0) < a.target ? near_slab_target(T, 0) : a.target;
     a.unit_flag = im.unit_flag; a.cap = cap;
     if (T <= BIN_LDS_MAX_TILES) {
         if (pass == 0) hipLaunchKernelGGL((k_tile_count<true, 0>), dim3(blocks), dim3(BIN_THREADS), (size_t)T * 4, s, a);
@@ -1453,6 +1464,7 @@ hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomVi
     const float fr = c.far_n > 2.0f * nr ? c.far_n : 2.0f * nr;
     a.db.near_n = nr; a.db.inv_near = 1.0f / nr; a.db.scale = (float)GFT_DHIST_BINS / log2f(fr / nr);
     a.target = near_slab_target(a.T, per_tile);
+    a.target_min = near_slab_target(a.T, 0) < a.target ? near_slab_target(a.T, 0) : a.target;
     a.cap = cap;
     const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
     if (pass == 0) hipLaunchKernelGGL(k_super_bin<0>, dim3(blocks), dim3(BIN_THREADS), 0, s, a);

@@ -275,7 +275,7 @@ __device__ __forceinline__ void sh_dir_grad(int deg, float x, float y, float z, 
 // dL/dsh[k][c] = basis_k(dir) * dres[c] for the active coefficients, zero up to M (no SH data needed)
 template <int NC>
 __device__ __forceinline__ void sh_backward_basis(int deg, int M, float x, float y, float z, const float* dres,
-                                                  float* dsh)
+                                                  float* dsh, bool accumulate = false)
 {
     float d[16];
     d[0] = SH_C0;
@@ -302,7 +302,11 @@ __device__ __forceinline__ void sh_backward_basis(int deg, int M, float x, float
     for (int k = 0; k < 16; k++)
 #pragma unroll
         for (int c = 0; c < NC; c++)
-            if (k < M) dsh[k * NC + c] = d[k] * dres[c];
+            if (k < M) {
+                // (accumulate: the row already holds another view's gradient, cfg.grads_accumulate)
+                const float v = d[k] * dres[c];
+                dsh[k * NC + c] = accumulate ? dsh[k * NC + c] + v : v;
+            }
 }
 
 // ---- coalesced SH rows through LDS ---------------------------------------------
@@ -377,6 +381,35 @@ __device__ __forceinline__ void wave_rows_from_lds(float4* __restrict__ dst, con
     for (int q = 0; q < ROW_F4; q++) {
         const size_t i = g0 + (size_t)(q * 64 + lane);
         if (i < lim) store_stream(&dst[i], src[padded_slot<ROW_F4>(q * 64 + lane)]);
+    }
+}
+
+// cfg.grads_accumulate: the staged rows of the Gaussians in `rows` (bit r = Gaussian first_gaussian + r) are ADDED to
+// what `dst` holds (another view's gradients), as coalesced 16-byte read-modify-writes; the other rows are not touched
+template <int ROW_F4>
+__device__ __forceinline__ void wave_rows_add_from_lds(float4* __restrict__ dst, const float4* src, size_t first_gaussian,
+                                                       size_t P, int lane, unsigned long long rows)
+{
+    const size_t lim = P * ROW_F4;
+    const size_t g0 = first_gaussian * ROW_F4;
+    if (rows == 0ull) return;
+    // all loads of the wave first, then the adds and stores: one memory round trip per tensor, not one per piece
+    float4 o[ROW_F4];
+    bool on[ROW_F4];
+#pragma unroll
+    for (int q = 0; q < ROW_F4; q++) {
+        const int e = q * 64 + lane;
+        const int row = ROW_F4 == 12 ? (e * 43691) >> 19 : e >> 3;
+        on[q] = g0 + (size_t)e < lim && ((rows >> row) & 1ull);
+        o[q] = on[q] ? dst[g0 + (size_t)e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < ROW_F4; q++) {
+        const int e = q * 64 + lane;
+        if (on[q]) {
+            const float4 v = src[padded_slot<ROW_F4>(e)];
+            dst[g0 + (size_t)e] = make_float4(o[q].x + v.x, o[q].y + v.y, o[q].z + v.z, o[q].w + v.w);
+        }
     }
 }
 
@@ -635,13 +668,25 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
 }
 
 // Appearance of the far slab's Gaussians, when a quadrant outlived the near slab (lazy binning, k_binning.hip): leaves at
-// once otherwise.  All visible Gaussians behind the cut get theirs (the flagged tiles' lists are not built yet).
-__global__ __launch_bounds__(PRE_BLOCK) void k_appearance_far(PreFwdArgs a, uint32_t cap)
+// once otherwise.  The visible Gaussians behind the cut whose tile rectangle covers a tile with a flagged quadrant get
+// theirs -- the far pass bins exactly those (k_tile_count / k_tile_scatter pass 1), nobody reads the others' records:
+// one flagged quadrant costs a few thousand appearance evaluations, not the frame's whole far slab.
+__global__ __launch_bounds__(PRE_BLOCK) void k_appearance_far(PreFwdArgs a, uint32_t cap, const uint4* __restrict__ unit_flag)
 {
     if (a.ctrl[GFT_CTRL_NFLAG] == 0u || a.ctrl[GFT_CTRL_TOTAL] > cap || a.ctrl[GFT_CTRL_TOTAL] == a.ctrl[GFT_CTRL_TOTAL0]) return;
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     if (idx >= a.c.P || a.io.radii[idx] <= 0) return;
     if (__float_as_uint(a.g.depth[idx]) <= a.cut_bits) return;
+    {
+        const ushort4 r = a.g.rect[idx];
+        bool wanted = false;
+        for (int y = r.y; y < (int)r.w && !wanted; y++)
+            for (int x = r.x; x < (int)r.z; x++) {
+                const uint4 f = unit_flag[y * a.gx + x];
+                if ((f.x | f.y | f.z | f.w) != 0u) { wanted = true; break; }
+            }
+        if (!wanted) return;
+    }
     const float px = a.io.means3D[3 * idx], py = a.io.means3D[3 * idx + 1], pz = a.io.means3D[3 * idx + 2];
     const Mat16 V = load_mat(a.io.viewmatrix);
     // the same expressions as in k_preprocess_fwd: the same distance bit for bit
@@ -684,6 +729,22 @@ struct PreBwdArgs {
     int stage_sh, stage_shp;
 };
 
+// Is Gaussian idx one that some pixel blended (non-zero accumulators, hence possibly non-zero gradients)?
+__device__ __forceinline__ bool gaussian_blended(const PreBwdArgs& a, int idx)
+{
+    // A Gaussian that no pixel blended has all-zero accumulators and therefore all-zero gradients: they are written
+    // without reading its records (with lazy binning most of the frame's Gaussians are like that, and those behind
+    // the depth cut may not even have an appearance record).  The forward's per-Gaussian pixel count tells; without
+    // it (pybind-level backward) the accumulator row does.
+    if (!(a.io.radii[idx] > 0)) return false;
+    if (a.io.pixels != nullptr) return a.io.pixels[idx] != 0.f;
+    const float4* ap = reinterpret_cast<const float4*>(a.io.acc + (size_t)idx * GFT_ACC_STRIDE);
+    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+    return (a0.x != 0.f) | (a0.y != 0.f) | (a0.z != 0.f) | (a0.w != 0.f) | (a1.x != 0.f) | (a1.y != 0.f) |
+           (a1.z != 0.f) | (a1.w != 0.f) | (a2.x != 0.f) | (a2.y != 0.f) | (a2.z != 0.f) | (a2.w != 0.f) |
+           (a3.x != 0.f) | (a3.y != 0.f) | (a3.z != 0.f);
+}
+
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
 {
     extern __shared__ float4 lds_rows[];
@@ -698,29 +759,17 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
     // with the forward's direction-gradient record no SH coefficient is read here; the LDS rows
     // then only serve to turn the per-lane gradient rows into coalesced 16-byte stores
     const bool have_dg = a.c.want_backward != 0;
+    const bool accum = a.c.grads_accumulate != 0;      // rows of blended Gaussians are added to, the others left alone
     if ((a.stage_sh | a.stage_shp) && !have_dg) {
         if (a.stage_sh) wave_rows_to_lds<SH_ROW_F4>(sh_l, reinterpret_cast<const float4*>(a.io.shs), g0, (size_t)P, lane);
         if (a.stage_shp) wave_rows_to_lds<SHP_ROW_F4>(shp_l, reinterpret_cast<const float4*>(a.io.shs_p), g0, (size_t)P, lane);
         __syncthreads();
     }
 
+    bool blended = false;      // this lane's Gaussian got a non-zero gradient row (cfg.grads_accumulate: the rows that are added)
     if (idx < P) {
-        // A Gaussian that no pixel blended has all-zero accumulators and therefore all-zero gradients: they are written
-        // without reading its records (with lazy binning most of the frame's Gaussians are like that, and those behind
-        // the depth cut may not even have an appearance record).  The forward's per-Gaussian pixel count tells; without
-        // it (pybind-level backward) the accumulator row does.
-        bool visible = a.io.radii[idx] > 0;
-        if (visible) {
-            if (a.io.pixels != nullptr) {
-                visible = a.io.pixels[idx] != 0.f;
-            } else {
-                const float4* ap = reinterpret_cast<const float4*>(a.io.acc + (size_t)idx * GFT_ACC_STRIDE);
-                const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
-                visible = (a0.x != 0.f) | (a0.y != 0.f) | (a0.z != 0.f) | (a0.w != 0.f) | (a1.x != 0.f) | (a1.y != 0.f) |
-                          (a1.z != 0.f) | (a1.w != 0.f) | (a2.x != 0.f) | (a2.y != 0.f) | (a2.z != 0.f) | (a2.w != 0.f) |
-                          (a3.x != 0.f) | (a3.y != 0.f) | (a3.z != 0.f);
-            }
-        }
+        const bool visible = gaussian_blended(a, idx);
+        blended = visible;
         float dmean[3] = {0.f, 0.f, 0.f};
         float dmean2d[2] = {0.f, 0.f};
         float dopac = 0.f;
@@ -850,7 +899,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
                         sh_backward_basis<3>(a.c.D, 16, dx, dy, dz, dres, v);
                         lds_row_store<SH_ROW_F4>(sh_l + lane * SH_ROW_PAD, v);
                     } else {
-                        sh_backward_basis<3>(a.c.D, M, dx, dy, dz, dres, dsh);
+                        sh_backward_basis<3>(a.c.D, M, dx, dy, dz, dres, dsh, accum);
                     }
                 } else if (a.stage_sh) {
                     float v[4 * SH_ROW_F4];
@@ -902,7 +951,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
                         sh_backward_basis<2>(a.c.D, 16, dx, dy, dz, dres, v);
                         lds_row_store<SHP_ROW_F4>(shp_l + lane * SHP_ROW_PAD, v);
                     } else {
-                        sh_backward_basis<2>(a.c.D, M_p, dx, dy, dz, dres, dsh_p);
+                        sh_backward_basis<2>(a.c.D, M_p, dx, dy, dz, dres, dsh_p, accum);
                     }
                 } else if (a.stage_shp) {
                     float v[4 * SHP_ROW_F4];
@@ -963,7 +1012,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
                 // reference applies scale_modifier inside s but returns dL/dscale without it
                 // (backward.cu:443-446 dot(Rt, dL_dMt) before the s multiply): keep as is.
             }
-        } else if (!a.c.grads_zeroed) {
+        } else if (!a.c.grads_zeroed && !accum) {
             // culled or never blended: every returned gradient row is zero (already so with grads_zeroed)
             if (dsh) for (int k = 0; k < M * 3; k++) dsh[k] = 0.f;
             if (dsh_p) for (int k = 0; k < M_p * 2; k++) dsh_p[k] = 0.f;
@@ -977,7 +1026,44 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
             }
         }
 
-        if (visible || !a.c.grads_zeroed) {
+        if (accum) {
+            if (visible) {
+                // loads first, stores after: one round trip for the row's small tensors
+                float* m3 = a.io.dL_dmeans3D + 3 * (size_t)idx;
+                float* m2 = a.io.dL_dmeans2D + 3 * (size_t)idx;
+                float* opp = a.io.dL_dopacity + idx;
+                const float o0 = m3[0], o1 = m3[1], o2 = m3[2], o3 = m2[0], o4 = m2[1], o5 = opp[0];
+                float c0 = 0.f, c1 = 0.f, c2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, v6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.io.dL_dcolors) { c0 = a.io.dL_dcolors[3 * idx]; c1 = a.io.dL_dcolors[3 * idx + 1]; c2 = a.io.dL_dcolors[3 * idx + 2]; }
+                if (a.io.dL_dcov3D) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) v6[i] = a.io.dL_dcov3D[6 * idx + i];
+                }
+                if (a.io.scales != nullptr) {
+                    s0 = a.io.dL_dscales[3 * idx]; s1 = a.io.dL_dscales[3 * idx + 1]; s2 = a.io.dL_dscales[3 * idx + 2];
+                    r4 = reinterpret_cast<const float4*>(a.io.dL_drotations)[idx];
+                }
+                m3[0] = o0 + dmean[0]; m3[1] = o1 + dmean[1]; m3[2] = o2 + dmean[2];
+                m2[0] = o3 + dmean2d[0]; m2[1] = o4 + dmean2d[1];
+                opp[0] = o5 + dopac;
+                if (a.io.dL_dcolors) {
+                    a.io.dL_dcolors[3 * idx] = c0 + dcolor[0];
+                    a.io.dL_dcolors[3 * idx + 1] = c1 + dcolor[1];
+                    a.io.dL_dcolors[3 * idx + 2] = c2 + dcolor[2];
+                }
+                if (a.io.dL_dcov3D) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) a.io.dL_dcov3D[6 * idx + i] = v6[i] + dcov[i];
+                }
+                if (a.io.scales != nullptr) {
+                    a.io.dL_dscales[3 * idx] = s0 + dscale[0];
+                    a.io.dL_dscales[3 * idx + 1] = s1 + dscale[1];
+                    a.io.dL_dscales[3 * idx + 2] = s2 + dscale[2];
+                    reinterpret_cast<float4*>(a.io.dL_drotations)[idx] = make_float4(r4.x + drot[0], r4.y + drot[1], r4.z + drot[2], r4.w + drot[3]);
+                }
+            }
+        } else if (visible || !a.c.grads_zeroed) {
         a.io.dL_dmeans3D[3 * idx] = dmean[0];
         a.io.dL_dmeans3D[3 * idx + 1] = dmean[1];
         a.io.dL_dmeans3D[3 * idx + 2] = dmean[2];
@@ -1006,18 +1092,23 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
     // SH gradient rows leave through LDS as coalesced 16-byte stores
     if (a.stage_sh | a.stage_shp) {
         __syncthreads();
-        if (a.stage_sh) wave_rows_from_lds<SH_ROW_F4>(reinterpret_cast<float4*>(a.io.dL_dsh), sh_l, g0, (size_t)P, lane);
-        if (a.stage_shp) wave_rows_from_lds<SHP_ROW_F4>(reinterpret_cast<float4*>(a.io.dL_dsh_p), shp_l, g0, (size_t)P, lane);
+        if (accum) {
+            const unsigned long long rows = __builtin_amdgcn_ballot_w64(blended);
+            if (a.stage_sh) wave_rows_add_from_lds<SH_ROW_F4>(reinterpret_cast<float4*>(a.io.dL_dsh), sh_l, g0, (size_t)P, lane, rows);
+            if (a.stage_shp) wave_rows_add_from_lds<SHP_ROW_F4>(reinterpret_cast<float4*>(a.io.dL_dsh_p), shp_l, g0, (size_t)P, lane, rows);
+        } else {
+            if (a.stage_sh) wave_rows_from_lds<SH_ROW_F4>(reinterpret_cast<float4*>(a.io.dL_dsh), sh_l, g0, (size_t)P, lane);
+            if (a.stage_shp) wave_rows_from_lds<SHP_ROW_F4>(reinterpret_cast<float4*>(a.io.dL_dsh_p), shp_l, g0, (size_t)P, lane);
+        }
     }
 
     // phase/dc offset gradients (the reference issues two same-address atomics per Gaussian,
-    // backward.cu:556-567): wave sum -> the two pad columns of the accumulator row of the
-    // workgroup's first Gaussian -> fixed-order reduction in k_offset_reduce (deterministic).
-    // (partials live in the tail of the acc scratch, two floats per workgroup)
+    // backward.cu:556-567): wave sums -> the tail of the acc scratch, two floats per wave -> fixed-order
+    // reduction in k_offset_reduce (deterministic).
     const float sp = gft_wave_sum_to_lane63(sum_phase);
     const float sd = gft_wave_sum_to_lane63(sum_dc);
-    if (threadIdx.x == PRE_BLOCK - 1 && a.io.shs_p != nullptr) {
-        float* part = a.io.acc + (size_t)P * GFT_ACC_STRIDE + 2 * (size_t)blockIdx.x;
+    if (lane == 63 && a.io.shs_p != nullptr) {
+        float* part = a.io.acc + (size_t)P * GFT_ACC_STRIDE + 2 * ((size_t)blockIdx.x * (PRE_BLOCK / 64) + wave);     // one per wave
         part[0] = sp;
         part[1] = sd;
     }
@@ -1078,7 +1169,7 @@ hipError_t gft_launch_appearance_far(hipStream_t s, const gft_config& c, const g
     PreFwdArgs a = pre_fwd_args(c, io, g, im, nullptr, cut_bits);
     a.stage_sh = a.stage_shp = 0;
     const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;
-    hipLaunchKernelGGL(k_appearance_far, dim3(blocks), dim3(PRE_BLOCK), 0, s, a, cap);
+    hipLaunchKernelGGL(k_appearance_far, dim3(blocks), dim3(PRE_BLOCK), 0, s, a, cap, reinterpret_cast<const uint4*>(im.unit_flag));
     return hipGetLastError();
 }
 
@@ -1117,10 +1208,13 @@ hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const g
     a.dist2phase = 4.0f * 3.14159265358979323846f / c.depth_range;
     // (grads_zeroed: only the rows of blended Gaussians are written, straight from the lanes; else whole 64-row blocks
     // leave through LDS as coalesced stores)
+    // (grads_zeroed: only the rows of blended Gaussians are written, straight from the lanes; else whole 64-row blocks
+    // leave through LDS as coalesced stores -- with grads_accumulate the write-out adds the blended rows to what the
+    // tensors hold)
     a.stage_sh = (io.shs != nullptr && c.M == 16 && !c.grads_zeroed) ? 1 : 0;
     a.stage_shp = (io.shs_p != nullptr && c.M_p == 16 && !c.grads_zeroed) ? 1 : 0;
     const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_PAD : 0) + (a.stage_shp ? SHP_ROW_PAD : 0));
-    const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;
+    const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;          // = waves = partial sums of the offset gradients
     hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
     // (the two scalar gradients are only reduced when the caller wants them: optimize_phase_offset / optimize_dc_offset)
     if (io.shs_p != nullptr && io.dL_dphase_offset != nullptr && io.dL_ddc_offset != nullptr)

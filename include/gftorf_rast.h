@@ -70,6 +70,12 @@ typedef struct gft_config {
     int32_t acc_zeroed;
     int32_t grads_zeroed;   /* gft_backward: the gradient outputs were zeroed by the forward (gft_forward_io.grads_zero):
                                only the rows of Gaussians that some pixel blended are written */
+    int32_t grads_accumulate; /* gft_backward: the per-Gaussian gradient outputs already hold the gradients of another view
+                               of the same Gaussians (the colour / ToF camera pair of one training iteration,
+                               gaussian_renderer/__init__.py:107-128): the rows of the Gaussians this view blended are
+                               ADDED to, all other rows are left alone -- no second 376 B/Gaussian of zeros, no separate
+                               sum of two dense tensors.  dL_dphase_offset / dL_ddc_offset are written, not added.
+                               Needs the forward's direction-gradient records (want_backward). */
     /* background [7,H,W] addressed as bg[c*sc + y*sy + x*sx] (element strides), so
      * the reference's expanded constant background (train.py:127) needs no copy */
     int64_t bg_stride_c, bg_stride_y, bg_stride_x;

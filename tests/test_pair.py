@@ -1,0 +1,152 @@
+"""GaussianRasterizerPair (gftorf_amd/pair.py): the colour-camera and ToF-camera calls of one iteration
+(gaussian_renderer/__init__.py:107-128) as one autograd node -- forward on two streams, one set of gradient tensors."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from gftorf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _two_views(P=3000, W=96, H=64, seed=5, **kw):
+    """The same Gaussians seen by two cameras a small baseline apart (colour camera / ToF sensor)."""
+    a = Hh.small_scene(P=P, W=W, H=H, seed=seed, w2c=synth.look_at_w2c(0.10, -0.05, 0.02, (0.05, 0.0, 0.1)), **kw)
+    b = Hh.small_scene(P=P, W=W, H=H, seed=seed, w2c=synth.look_at_w2c(0.12, -0.05, 0.02, (0.09, 0.0, 0.1)), **kw)
+    b["gaussians"] = a["gaussians"]
+    b["grads"] = synth.make_pixel_grads(W, H, seed + 100)
+    b["bg"] = synth.make_background(W, H, seed + 100)
+    b["phase_offset"], b["dc_offset"] = 0.25, 0.02
+    a["use_view_dependent_phase"] = False
+    return a, b
+
+
+def _leaves(scene, dev):
+    g = scene["gaussians"]
+    leaf = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for k, v in g.items() if v is not None}
+    m2 = torch.zeros((g["means3D"].shape[0], 3), device=dev, requires_grad=True)
+    return leaf, m2
+
+
+def _loss(outs, scene, dev, keys=Hh.GRAD_KEYS):
+    o = dict(zip(Hh.OUT_NAMES, outs))
+    return sum((o[k] * torch.tensor(scene["grads"][k], device=dev)).sum() for k in keys)
+
+
+def _run_single(a, b, dev, use=(True, True), offsets=False):
+    from gftorf_amd import GaussianRasterizer
+    leaf, m2 = _leaves(a, dev)
+    offs, outs, loss = [], [], 0.0
+    for sc, on in ((a, use[0]), (b, use[1])):
+        ph = torch.tensor([sc["phase_offset"]], device=dev, requires_grad=True) if offsets else sc["phase_offset"]
+        dc = torch.tensor([sc["dc_offset"]], device=dev, requires_grad=True) if offsets else sc["dc_offset"]
+        offs.append((ph, dc))
+        o = GaussianRasterizer(Hh.gpu_settings(sc, dev, optimize_offsets=offsets))(
+            means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf["shs"], shs_p=leaf["shs_p"],
+            scales=leaf["scales"], rotations=leaf["rotations"], phase_offset=ph, dc_offset=dc)
+        outs.append(o)
+        if on:
+            loss = loss + _loss(o, sc, dev)
+    loss.backward()
+    torch.cuda.synchronize()
+    return outs, leaf, m2, offs
+
+
+def _run_pair(a, b, dev, use=(True, True), offsets=False):
+    from gftorf_amd import GaussianRasterizerPair
+    leaf, m2 = _leaves(a, dev)
+    mk = lambda sc, k: torch.tensor([sc[k]], device=dev, requires_grad=True) if offsets else sc[k]
+    offs = [(mk(a, "phase_offset"), mk(a, "dc_offset")), (mk(b, "phase_offset"), mk(b, "dc_offset"))]
+    oa, ob = GaussianRasterizerPair(Hh.gpu_settings(a, dev, optimize_offsets=offsets), Hh.gpu_settings(b, dev, optimize_offsets=offsets))(
+        means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf["shs"], shs_p=leaf["shs_p"],
+        scales=leaf["scales"], rotations=leaf["rotations"], phase_offset=(offs[0][0], offs[1][0]),
+        dc_offset=(offs[0][1], offs[1][1]))
+    assert len(oa) == 11 and len(ob) == 11
+    loss = 0.0
+    if use[0]:
+        loss = loss + _loss(oa, a, dev)
+    if use[1]:
+        loss = loss + _loss(ob, b, dev)
+    loss.backward()
+    torch.cuda.synchronize()
+    return (oa, ob), leaf, m2, offs
+
+
+def _same_grads(l1, m1, l2, m2, tol):
+    for k in l1:
+        x, y = l1[k].grad.cpu().numpy(), l2[k].grad.cpu().numpy()
+        assert np.abs(x - y).max() <= tol * (np.abs(x).max() + 1e-30), k
+    x, y = m1.grad.cpu().numpy(), m2.grad.cpu().numpy()
+    assert np.abs(x - y).max() <= tol * (np.abs(x).max() + 1e-30)
+    assert not y[:, 2].any()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(P=20000, W=64, H=48, scale_lo=0.03, scale_hi=0.15)], ids=["base", "deep_lists"])
+def test_pair_equals_two_single_calls(kw, gpu):
+    a, b = _two_views(**kw)
+    for rep in range(3):         # first frames size their buffers after a blocking read, later ones from hints
+        so, sl, sm, _ = _run_single(a, b, gpu)
+        po, pl, pm, _ = _run_pair(a, b, gpu)
+        for v in range(2):
+            for name, x, y in zip(Hh.OUT_NAMES, so[v], po[v]):
+                np.testing.assert_array_equal(x.detach().cpu().numpy(), y.detach().cpu().numpy(), err_msg="%s view %d" % (name, v))
+        _same_grads(sl, sm, pl, pm, 2e-5)      # float atomics in the render backward: summation order only
+
+
+def test_pair_against_the_oracle(oracle, gpu):
+    a, b = _two_views()
+    (fa, ba), (fb, bb) = Hh.run_oracle(oracle, a), Hh.run_oracle(oracle, b)
+    (oa, ob), leaf, m2, offs = _run_pair(a, b, gpu, offsets=True)
+    for f, o in ((fa, oa), (fb, ob)):
+        o = dict(zip(Hh.OUT_NAMES, o))
+        np.testing.assert_array_equal(o["radii"].cpu().numpy(), f.radii)
+        for k in ["color", "phasor", "depth", "acc", "depth_distortion"]:
+            Hh.assert_close(k, f[k], o[k].detach().cpu().numpy(), rtol_max=2e-4, atol=1e-6, frac_bad=1e-3)
+    for key, name in [("means3D", "dL_dmeans3D"), ("shs", "dL_dsh"), ("shs_p", "dL_dsh_p"), ("scales", "dL_dscales"),
+                      ("rotations", "dL_drotations")]:
+        Hh.assert_close(name, ba[name] + bb[name], leaf[key].grad.cpu().numpy(), rtol_max=3e-4)
+    Hh.assert_close("dL_dopacity", (ba["dL_dopacity"] + bb["dL_dopacity"]).reshape(-1), leaf["opacities"].grad.cpu().numpy().reshape(-1),
+                    rtol_max=3e-4)
+    Hh.assert_close("dL_dmeans2D", ba["dL_dmeans2D"] + bb["dL_dmeans2D"], m2.grad.cpu().numpy(), rtol_max=3e-4)
+    # each view's own scalar offsets
+    for v, bk in ((0, ba), (1, bb)):
+        Hh.assert_close("dL_dphase_offset", bk["dL_dphase_offset"], offs[v][0].grad.cpu().numpy(), rtol_max=3e-4, atol=1e-5)
+        Hh.assert_close("dL_ddc_offset", bk["dL_ddc_offset"], offs[v][1].grad.cpu().numpy(), rtol_max=3e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("use", [(True, False), (False, True)], ids=["only_view_a", "only_view_b"])
+def test_pair_with_one_view_in_the_loss(use, gpu):
+    """torf.json has lambda_color = 0: the colour-camera call reaches no loss and autograd never runs its backward
+    (train.py:206).  The pair then runs only the other view's backward, which writes (not adds) the gradients."""
+    a, b = _two_views()
+    _, sl, sm, _ = _run_single(a, b, gpu, use=use)
+    _, pl, pm, _ = _run_pair(a, b, gpu, use=use)
+    _same_grads(sl, sm, pl, pm, 2e-5)
+
+
+def test_pair_empty_and_forward_only(gpu):
+    from gftorf_amd import GaussianRasterizerPair
+    a, b = _two_views(P=50)
+    z = lambda *s: torch.zeros(s, device=gpu)
+    oa, ob = GaussianRasterizerPair(Hh.gpu_settings(a, gpu), Hh.gpu_settings(b, gpu))(
+        means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1), shs=z(0, 16, 3), shs_p=z(0, 16, 2), scales=z(0, 3), rotations=z(0, 4))
+    assert oa[0].shape == (3, 64, 96) and not oa[0].any() and ob[10].numel() == 0
+    with torch.no_grad():
+        (po, _, _, _) = _run_pair_nograd(a, b, gpu)
+    so = [Hh.run_gpu(sc, gpu, backward=False)[0] for sc in (a, b)]
+    for v in range(2):
+        for name, y in zip(Hh.OUT_NAMES, po[v]):
+            np.testing.assert_array_equal(so[v][name], y.cpu().numpy(), err_msg=name)
+
+
+def _run_pair_nograd(a, b, dev):
+    from gftorf_amd import GaussianRasterizerPair
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=dev)
+    g = a["gaussians"]
+    out = GaussianRasterizerPair(Hh.gpu_settings(a, dev), Hh.gpu_settings(b, dev))(
+        means3D=t(g["means3D"]), means2D=torch.zeros((g["means3D"].shape[0], 3), device=dev), opacities=t(g["opacities"]),
+        shs=t(g["shs"]), shs_p=t(g["shs_p"]), scales=t(g["scales"]), rotations=t(g["rotations"]),
+        phase_offset=(a["phase_offset"], b["phase_offset"]), dc_offset=(a["dc_offset"], b["dc_offset"]))
+    torch.cuda.synchronize()
+    return out, None, None, None
