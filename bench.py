@@ -508,15 +508,15 @@ def densify_extra(dev, P=1_000_000):
 
 def train_iteration_extra(dev, scene, steps=10, warmup=3):
     """One iteration of the reference's loop shape (train.py:164-177, 441-449, 470-474) at the metric size: one
-    deformation-network query for the dynamic 30 %, input assembly and a colour + ToF render pair (two rasterizer
-    forward + backward), densification statistics, Adam on the Gaussians and on the network.  `hip`: every piece
+    deformation-network query for the dynamic 30 %, one input assembly, the colour-camera and the ToF-camera rasterizer
+    call (forward + backward of both), densification statistics, Adam on the Gaussians and on the network.  `hip`: every piece
     from this package; `eager`: the same rasterizer with the reference's eager statements around it
     (oracle/*_ref.py restatements on the device, torch.optim.Adam).  There is no reference rasterizer for
     ROCm, so both columns share ours."""
     import numpy as np
     import torch
-    from gftorf_amd import (reference_network, FusedAdam, GaussianRasterizationSettings, GaussianRasterizer, assemble_inputs,
-                            densify)
+    from gftorf_amd import (reference_network, FusedAdam, GaussianRasterizationSettings, GaussianRasterizer,
+                            GaussianRasterizerPair, assemble_inputs, densify)
     from oracle import assemble_ref, deform_ref, densify_ref
     cam, cfg, g = scene["cam"], scene["cfg"], scene["gaussians"]
     P = cfg["P"]
@@ -532,7 +532,7 @@ def train_iteration_extra(dev, scene, steps=10, warmup=3):
     params = deform_ref.random_params(9, head_std=1e-3)
     gr = {k: t(v) for k, v in scene["grads"].items()}
 
-    def build(fused):
+    def build(fused, pair=False):
         leaf = dict(xyz=t(g["means3D"]), opacity=t(g["opacities"]).reshape(P, 1), scaling=t(g["scales"]),
                     rotation_raw=t(g["rotations"]), fc=t(g["shs"]), fp=t(g["shs_p"]))
         for v in leaf.values():
@@ -551,26 +551,32 @@ def train_iteration_extra(dev, scene, steps=10, warmup=3):
         x_n = (x_n - x_n.min(0).values) / (x_n.max(0).values - x_n.min(0).values)
         stats = [torch.zeros((P, 1), device=dev), torch.zeros((P, 1), device=dev), torch.zeros(P, device=dev)]
 
+        pair_rast = GaussianRasterizerPair(settings, settings) if pair else None
+
         def iteration():
             tt = torch.full((1, 1), 0.4, device=dev).expand(x_n.size(0), -1)
             d = net(x_n, tt) if fused else deform_ref.deform_eager(net, x_n, tt)
-            loss, views = 0.0, []
-            for _ in range(2):                                  # colour camera and ToF camera (train.py:181, 188)
-                ssp = torch.zeros((P, 3), device=dev, requires_grad=True)
-                rot = torch.nn.functional.normalize(leaf["rotation_raw"])
-                args = (leaf["xyz"], ssp, leaf["opacity"], leaf["scaling"], rot, leaf["rotation_raw"], leaf["fc"], leaf["fp"],
-                        mask) + tuple(d)
-                m3, m2, op, sc, ro, shs, shp = assemble_inputs(*args) if fused else assemble_ref.assemble_eager(*args)
-                out = rast(means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro,
-                           phase_offset=scene["phase_offset"], dc_offset=scene["dc_offset"])
-                loss = loss + (out[0] * gr["color"]).sum() + (out[1] * gr["phasor"]).sum() + (out[2] * gr["depth"]).sum()
-                views.append((ssp, out[10], out[8]))
+            # render() (gaussian_renderer/__init__.py:81-128): one input assembly, then the colour-camera and the
+            # ToF-camera rasterizer calls on the same tensors
+            ssp = torch.zeros((P, 3), device=dev, requires_grad=True)
+            rot = torch.nn.functional.normalize(leaf["rotation_raw"])
+            args = (leaf["xyz"], ssp, leaf["opacity"], leaf["scaling"], rot, leaf["rotation_raw"], leaf["fc"], leaf["fp"],
+                    mask) + tuple(d)
+            m3, m2, op, sc, ro, shs, shp = assemble_inputs(*args) if fused else assemble_ref.assemble_eager(*args)
+            kw = dict(means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro)
+            if pair:
+                out_c, out_t = pair_rast(phase_offset=(0.0, scene["phase_offset"]), dc_offset=(0.0, scene["dc_offset"]), **kw)
+            else:
+                out_c = rast(**kw)
+                out_t = rast(phase_offset=scene["phase_offset"], dc_offset=scene["dc_offset"], **kw)
+            loss = ((out_c[0] * gr["color"]).sum() + (out_c[2] * gr["depth"]).sum() +
+                    (out_t[1] * gr["phasor"]).sum() + (out_t[2] * gr["depth"]).sum())
             loss.backward()                                     # one backward for the summed losses (train.py:364-366)
-            for ssp, radii, pixels in views:
-                if fused:
-                    densify.add_densification_stats(stats[0], stats[1], stats[2], ssp.grad, radii > 0, pixels, radii)
-                else:
-                    densify_ref.add_densification_stats_eager(stats[0], stats[1], stats[2], ssp.grad, radii > 0, pixels, radii)
+            radii, pixels = out_t[10], out_t[8]
+            if fused:
+                densify.add_densification_stats(stats[0], stats[1], stats[2], ssp.grad, radii > 0, pixels, radii)
+            else:
+                densify_ref.add_densification_stats_eager(stats[0], stats[1], stats[2], ssp.grad, radii > 0, pixels, radii)
             opt.step(); opt_net.step()
             opt.zero_grad(set_to_none=True); opt_net.zero_grad(set_to_none=True)
         return iteration
@@ -589,10 +595,15 @@ def train_iteration_extra(dev, scene, steps=10, warmup=3):
 
     hip_ms = timed(build(True), steps, warmup)
     torch.cuda.empty_cache()
+    pair_ms = timed(build(True, pair=True), steps, warmup)
+    torch.cuda.empty_cache()
     eager_ms = timed(build(False), max(3, steps // 2), 2)
     return {"what": "one training iteration of the reference's loop shape, %d Gaussians (30 %% dynamic), %dx%d: network query, "
-                    "2 x (assembly + raster fwd/bwd + statistics), Adam" % (P, cfg["W"], cfg["H"]),
-            "hip_ms": hip_ms, "hip_it_per_s": 1e3 / hip_ms, "eager_glue_ms": eager_ms, "speedup": eager_ms / hip_ms}
+                    "input assembly, colour + ToF rasterizer call (fwd/bwd), statistics, Adam" % (P, cfg["W"], cfg["H"]),
+            "hip_ms": hip_ms, "hip_it_per_s": 1e3 / hip_ms,
+            # the same iteration with the two rasterizer calls as one GaussianRasterizerPair (opt-in API)
+            "hip_pair_ms": pair_ms, "hip_pair_it_per_s": 1e3 / pair_ms,
+            "eager_glue_ms": eager_ms, "speedup": eager_ms / hip_ms}
 
 
 def pair_extra(dev, scene, steps=20, warmup=5, which=("two", "pair")):
@@ -745,6 +756,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the fused-assembly measurement")
     ap.add_argument("--spin-up", type=float, default=0.3, help="seconds of untimed steps before the warm-up")
+    ap.add_argument("--pair", action="store_true", help="--workload C3: the two rasterizer calls of an iteration as one "
+                                                         "GaussianRasterizerPair (opt-in API; default: two calls, as the reference)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 7000 if args.workload == "C3" else 50
@@ -938,7 +951,7 @@ def main_loop(args, env, world, dev, dist):
     def region(step_fn, n):
         holder["step"] = step_fn
         return timed_steps(step_fn, n, args.warmup, sync, dist)
-    elapsed, rep, info = bench_loop.run(dev, args.steps, sync, region)
+    elapsed, rep, info = bench_loop.run(dev, args.steps, sync, region, pair=args.pair)
     # roofline leg: per-stage HIP events of the rasterizer calls over 200 more iterations
     _lib.profile_reset()
     _lib.profile_enable(True)
@@ -973,6 +986,7 @@ def main_loop(args, env, world, dev, dist):
                        "step": "one training iteration: LR schedule, random view + background, deform query (after warm-up), "
                                "activations, input assembly, colour + ToF rasterizer forward, ToF loss (L2 + SSIM), backward, "
                                "densification statistics, Adam (Gaussians + network)",
+                       "rasterizer_calls": "GaussianRasterizerPair" if args.pair else "two GaussianRasterizer calls",
                        "parallelism": "replicas x%d" % world},
             "mpix_per_s": value * 2 * N / 1e6,
             "loop": rep,

@@ -65,11 +65,11 @@ C3 = dict(P=100_000, W=320, H=240, views=30, sh_degree=3, warm_up=2000, depth_ra
                 "deform network on after warm_up 2000, colour + ToF rasterizer call per iteration")
 
 
-def build_loop(dev, cfg=C3, seed=1236):
+def build_loop(dev, cfg=C3, seed=1236, pair=False):
     """Returns (iteration_fn, info): iteration_fn(it) runs iteration `it` (1-based) and returns the loss tensor."""
     import torch
-    from gftorf_amd import (FusedAdam, GaussianRasterizationSettings, GaussianRasterizer, assemble_inputs, densify,
-                            reference_network, synth)
+    from gftorf_amd import (FusedAdam, GaussianRasterizationSettings, GaussianRasterizer, GaussianRasterizerPair,
+                            assemble_inputs, densify, reference_network, synth)
     P, W, H, V = cfg["P"], cfg["W"], cfg["H"], cfg["views"]
     t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
 
@@ -177,11 +177,16 @@ def build_loop(dev, cfg=C3, seed=1236):
         m3, m2, op, sc, ro, shs, shp = assemble_inputs(par["xyz"], ssp, opacity, scaling, rotation, par["rotation"], feat_c, feat_p,
                                                       mask, d_xyz, d_rot, d_sh, d_sh_p, render_regions=("dynamic",))
         cc, ct = cams[v]
-        out_c = GaussianRasterizer(settings(cc, bg_map, state["degree"], False))(
-            means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro)
-        out_t = GaussianRasterizer(settings(ct, bg_map, state["degree"], True))(
-            means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro, phase_offset=phase_offset,
-            dc_offset=0.0)
+        if pair:      # opt-in: both calls as one node (gftorf_amd/pair.py); same outputs
+            out_c, out_t = GaussianRasterizerPair(settings(cc, bg_map, state["degree"], False), settings(ct, bg_map, state["degree"], True))(
+                means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro,
+                phase_offset=(0.0, phase_offset), dc_offset=(0.0, 0.0))
+        else:
+            out_c = GaussianRasterizer(settings(cc, bg_map, state["degree"], False))(
+                means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro)
+            out_t = GaussianRasterizer(settings(ct, bg_map, state["degree"], True))(
+                means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro, phase_offset=phase_offset,
+                dc_offset=0.0)
         tof = out_t[1][:cfg["num_phasor_channels"]]
         l2 = ((tof - gt[v]) ** 2).mean()
         loss = cfg["lambda_tof"] * ((1.0 - cfg["lambda_dssim"]) * l2 +
@@ -204,10 +209,10 @@ def build_loop(dev, cfg=C3, seed=1236):
     return iteration, info
 
 
-def run(dev, iters, sync, timed_region, cfg=C3):
+def run(dev, iters, sync, timed_region, cfg=C3, pair=False):
     """Runs `iters` iterations inside timed_region(step_fn, n) -> seconds.  Returns (seconds, report dict)."""
     import torch
-    iteration, info = build_loop(dev, cfg)
+    iteration, info = build_loop(dev, cfg, pair=pair)
     counter = dict(it=0)
     losses = []
 
