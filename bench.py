@@ -678,6 +678,79 @@ def pair_extra(dev, scene, steps=20, warmup=5, which=("two", "pair")):
                                          "autograd_sum_of_two_dense_gradient_sets": 3 * 376 * P}}
 
 
+def views_extra(dev, scene, steps=90, warmup=30, views=30):
+    """The headline step over VARYING views: 30 cameras on an arc around the same Gaussians in shuffled order (a training
+    loop's access pattern), forward + backward each.  The binning buffer and the depth cut of a frame come from the
+    previous frame of the shape -- another view here -- so this is the number that shows what the hints cost when
+    they miss: restarted forwards (instance count above the guess), frames rendered without a depth cut, frames in which
+    a quadrant outlived the near slab (second binning pass)."""
+    import ctypes as C
+    import random
+    import numpy as np
+    import torch
+    from gftorf_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib, api, synth
+    cfg, g = scene["cfg"], scene["gaussians"]
+    P, W, H = cfg["P"], cfg["W"], cfg["H"]
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
+    bg = t(scene["bg"])
+    rasts = []
+    for v in range(views):
+        a = (v / (views - 1) - 0.5) * 0.30
+        cam = synth.make_camera(W, H, w2c=synth.look_at_w2c(yaw=a, pitch=0.04 * np.sin(3 * a), t=(-3.2 * np.sin(a), 0.0, 3.2 * (1 - np.cos(a)))))
+        rasts.append(GaussianRasterizer(GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, scale_modifier=1.0,
+            viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=cfg["D"], campos=t(cam["campos"]),
+            prefiltered=False, debug=False, near_n=cam["znear"], far_n=cam["zfar"], depth_range=scene["depth_range"],
+            use_view_dependent_phase=scene["use_view_dependent_phase"])))
+    leaf = {k: t(v).requires_grad_(True) for k, v in g.items() if v is not None}
+    m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+    gr = {k: t(v) for k, v in scene["grads"].items()}
+    ups = [gr["color"], gr["phasor"], gr["depth"], gr["acc"], gr["depth_distortion"]]
+    rng = random.Random(7)
+    order = []
+    stats = dict(restarted=0, with_cut=0, lates=[])
+    key = (dev.index, P, W, H)
+
+    def step(record=False):
+        if not order:
+            order.extend(rng.sample(range(views), views))
+        for x in leaf.values():
+            x.grad = None
+        m2.grad = None
+        o = rasts[order.pop()](means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf["shs"], shs_p=leaf["shs_p"],
+                               scales=leaf["scales"], rotations=leaf["rotations"], phase_offset=scene["phase_offset"],
+                               dc_offset=scene["dc_offset"])
+        torch.autograd.backward([o[0], o[1], o[2], o[4], o[6]], ups)
+        if record:
+            stats["restarted"] += int(api.last_call_stats["restarted"])
+            stats["with_cut"] += int(api.last_call_stats["depth_cut"] > 0.0)
+            late = api._slab_state.get(key, {}).get("late")
+            if late:
+                stats["lates"].append(late)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    lib = _lib.load()
+    flagged_frames, flagged_quads = 0, 0
+    for slot, seq in stats["lates"][-200:]:
+        n = C.c_int64(-1)
+        lib.gft_forward_late(slot, seq, C.byref(n))
+        if n.value > 0:
+            flagged_frames += 1
+            flagged_quads += int(n.value)
+    return {"what": "headline step over %d views on an arc in shuffled order, %d Gaussians, %dx%d, forward + backward" % (views, P, W, H),
+            "it_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "restarted_forwards": stats["restarted"], "frames_with_depth_cut": stats["with_cut"],
+            "frames_with_flagged_quadrants": flagged_frames, "flagged_quadrants": flagged_quads,
+            "near_slab_per_tile_at_the_end": api._slab_state.get(key, {}).get("per_tile")}
+
+
 def knn_extra(dev, P=1_000_000):
     """SURVEY 8(f) row 3 beside the headline metric: distCUDA2 (mean squared distance to the 3
     nearest neighbours, the scale initialisation of scene/gaussian_model.py:194-199) on a
@@ -927,7 +1000,9 @@ def main():
             torch.cuda.empty_cache()
             pair_x = pair_extra(dev, scene)
             torch.cuda.empty_cache()
-            out["extras"] = {"render_pair": pair_x, "assemble_inputs": assemble_extra(dev), "knn": knn_extra(dev),
+            views_x = views_extra(dev, scene)
+            torch.cuda.empty_cache()
+            out["extras"] = {"render_pair": pair_x, "varying_views": views_x, "assemble_inputs": assemble_extra(dev), "knn": knn_extra(dev),
                              "adam": adam_extra(dev), "deform_network": deform_extra(dev),
                              "densify": densify_extra(dev), "train_iteration": train_extra}
         if world == 1 and not args.no_cpu_baseline:
