@@ -293,19 +293,43 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
-                    slab = _slab_state.setdefault(hint_key, {"per_tile": _SLAB_DEFAULT, "late": None, "clean": 0, "nocut": 0})
+                    slab = _slab_state.setdefault(hint_key, {"per_tile": _SLAB_DEFAULT, "late": None, "clean": 0, "nocut": 0,
+                                                             "off": 0, "backoff": 0})
+                    # late reports of the earlier forwards of this kind, oldest first; one that has not arrived yet (the
+                    # host runs ahead of the device) is asked for again next time
+                    pending = slab.setdefault("pending", [])
                     if slab["late"] is not None:
+                        pending.append(slab["late"])
+                        slab["late"] = None
+                    del pending[:-8]
+                    while pending:
                         flagged = C.c_int64(-1)
-                        lib.gft_forward_late(slab["late"][0], slab["late"][1], C.byref(flagged))
-                        # a few quadrants that outlive the near slab are cheap (only their tiles take the second pass):
-                        # the slab is widened when more than 1 % of the frame's quadrants did
+                        lib.gft_forward_late(pending[0][0], pending[0][1], C.byref(flagged))
+                        if flagged.value < 0:
+                            break
+                        pending.pop(0)
                         quads = 4 * ((W + 15) // 16) * ((H + 15) // 16)
                         if flagged.value > max(4, quads // 100):
+                            # More than 1 % of the quadrants outlived the near slab: the second binning pass (three scans
+                            # over the Gaussians, the tail sort, the resumed quadrants' walk behind everything else) cost
+                            # more than the cut saved -- the frame is not like the one the cut came from (another view of a
+                            # training loop) or its tiles look at very different depths.  Bin whole frames for a while,
+                            # twice as long each time it happens again (at most 64 frames), then try once more.
+                            slab["backoff"] = min(64, 2 * slab["backoff"] + 4)
+                            slab["off"] = slab["backoff"]
+                            slab["per_tile"], slab["clean"] = _SLAB_DEFAULT, 0
+                        elif flagged.value > 0:
+                            # a few: a quarter more slab absorbs them
                             slab["per_tile"], slab["clean"] = min(_SLAB_MAX, int(slab["per_tile"] * 1.25) + 1), 0
-                        elif flagged.value >= 0:
+                        elif flagged.value == 0:
                             slab["clean"] += 1
+                            if slab["clean"] % 16 == 0:
+                                slab["backoff"] //= 2
                             if slab["clean"] >= 200 and slab["per_tile"] > _SLAB_DEFAULT:
                                 slab["per_tile"], slab["clean"] = max(_SLAB_DEFAULT, int(slab["per_tile"] * 0.9)), 0
+                    if slab["off"] > 0:
+                        slab["off"] -= 1
+                        cut_hint = 0.0
                     # A widened slab that no longer leaves out half of the frame gets no cut (and therefore no reports to
                     # narrow it again): after 50 such frames it starts over at the default width
                     if cut_hint > 0.0 or slab["per_tile"] == _SLAB_DEFAULT:

@@ -392,6 +392,7 @@ def test_one_call_forward_matches_two_stage(oracle, gpu):
                                  (R, 2.5, False), (R, 0.5, False), (R, 50.0, False), (1, 2.5, True)):
         if hint is not None:
             api._instance_hint[key] = (hint, api._instance_hint[key][1], cut, 0)
+            api._slab_state.pop(key, None)      # (no pause after the frames whose cut left quadrants unsaturated)
         out, grads, _ = Hh.run_gpu(scene, gpu)
         st = api.last_call_stats
         assert st["num_rendered"] == R and st["restarted"] == restarted
@@ -490,6 +491,7 @@ def test_lazy_binning_matches_full_binning(name, oracle, gpu):
     seen_partial = False
     for cut in cuts:
         api._instance_hint[key] = (R, longest, cut, 0)
+        api._slab_state.pop(key, None)                           # (no pause after a cut that left quadrants unsaturated)
         out, grads, _ = Hh.run_gpu(scene, gpu)
         st = api.last_call_stats
         assert st["num_rendered"] == R and not st["restarted"] and st["depth_cut"] == cut
@@ -530,6 +532,7 @@ def test_lazy_binning_cut_suggestion(gpu):
     cut = next(iter(api._instance_hint.values()))[2]
     assert 1.0 < cut < 5.5
     for _ in range(2):
+        api._slab_state.pop(next(iter(api._instance_hint)), None)     # (the cut itself is tested here, not the policy)
         out, _, _ = Hh.run_gpu(dense, gpu, backward=False)
         st = api.last_call_stats
         assert st["depth_cut"] == cut and st["num_rendered"] == R
@@ -538,20 +541,43 @@ def test_lazy_binning_cut_suggestion(gpu):
         for k in first:
             np.testing.assert_array_equal(out[k], first[k], err_msg=k)
     key = next(iter(api._instance_hint))
-    before = api._slab_state[key]["per_tile"]
-    assert before >= 896
-    # a cut that is too shallow: quadrants outlive the near slab; the device reports them late (never waited for), the
-    # frame after reads the report and asks for a wider near slab
+    api._slab_state.pop(key, None)
+    # a cut that is too shallow: every quadrant outlives the near slab; the device reports them late (never waited for),
+    # the frame after reads the report -- far more than 1 % of the quadrants: whole frames are binned for a while (the
+    # second pass costs more than the cut saves), then the cut is tried again
     h = api._instance_hint[key]
     api._instance_hint[key] = (h[0], h[1], 1.02, 0)
     out, _, _ = Hh.run_gpu(dense, gpu, backward=False)
+    assert api.last_call_stats["depth_cut"] == pytest.approx(1.02)
     for k in first:
         np.testing.assert_array_equal(out[k], first[k], err_msg=k)
     torch.cuda.synchronize()
-    Hh.run_gpu(dense, gpu, backward=False)
-    assert api._slab_state[key]["per_tile"] > before and api._slab_state[key]["clean"] == 0
-    Hh.run_gpu(dense, gpu, backward=False)
-    assert api.last_call_stats["near_per_tile"] > before
+    out, _, _ = Hh.run_gpu(dense, gpu, backward=False)            # reads the report
+    assert api._slab_state[key]["backoff"] == 4 and api.last_call_stats["depth_cut"] == 0.0
+    for k in first:
+        np.testing.assert_array_equal(out[k], first[k], err_msg=k)
+    for _ in range(3):
+        Hh.run_gpu(dense, gpu, backward=False)
+        assert api.last_call_stats["depth_cut"] == 0.0
+    out, _, _ = Hh.run_gpu(dense, gpu, backward=False)            # the pause is over: the suggested cut again
+    assert api.last_call_stats["depth_cut"] == cut
+    for k in first:
+        np.testing.assert_array_equal(out[k], first[k], err_msg=k)
+    # a few flagged quadrants (at most 1 %) only widen the next near slab
+    api._slab_state[key].update(per_tile=896, late=None, off=0)
+    import gftorf_amd.api as A
+    lib = A._lib.load()
+    real = lib.gft_forward_late
+    try:
+        def fake(slot, seq, ref):
+            ref._obj.value = 1
+            return 0
+        api._slab_state[key]["late"] = (0, 0)
+        A._lib.load().gft_forward_late = fake
+        Hh.run_gpu(dense, gpu, backward=False)
+    finally:
+        A._lib.load().gft_forward_late = real
+    assert api._slab_state[key]["per_tile"] > 896 and api._slab_state[key]["off"] == 0
 
 
 LAZY_CASES = {
