@@ -170,6 +170,13 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     }
     const int begin = a.resume ? head : 0;
     const int total = a.resume ? full + n1 : head;
+    // Depth distortion is formed from the sums of w (z - zref) and w (z - zref)^2, zref = NDC depth of the tile's nearest
+    // Gaussian: A D2 - D^2 does not depend on the shift, but its two terms cancel to (depth spread / depth)^2 of their
+    // size -- around zref they are small to begin with (a scene in a narrow depth range kept 1 significant digit
+    // of the plane without the shift, and could go negative).  The backward uses the same shift.
+    // (list position 0 = the tile's nearest Gaussian whatever the slabs: the same zref in every flow, bit-identical sums)
+    const float zref = full > 0 ? a.rec_a[2 * a.point_list[range.x] + 1].z
+                                : (n1 > 0 ? a.rec_a[2 * a.point_list[r1x] + 1].z : 0.0f);
     const size_t pix_i = inside ? (size_t)a.W * py + px : 0;
 
     // Predicates are wave-uniform 64-bit lane masks: every ballot below takes a single compare,
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
                 // depth distortion: the reference adds w (z^2 A - 2 z D + D2) per splat (A, D, D2 = sums
                 // over the splats in front, forward.cu:604-611), which telescopes to
                 // sum_{i>j} w_i w_j (z_i - z_j)^2 = A D2 - D^2 of the final sums: formed once per pixel
-                const float z = a1.z;
+                const float z = a1.z - zref;
                 const float wz = w * z;
                 DD_D += wz;
                 DD_D2 = fmaf(wz, z, DD_D2);
@@ -490,6 +497,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     uint32_t r1x = 0;
     if ((uint32_t)tmax > n0) r1x = a.ranges1[tile].x;
     auto phys = [&](uint32_t c) -> uint32_t { return c < n0 ? r0 + c : r1x + (c - n0); };
+    const float zref = a.rec_a[2 * a.point_list[phys(0u)] + 1].z;                 // the forward's shift of the depth sums (tmax > 0)
     const size_t HW = (size_t)a.H * a.W;
     const size_t pix = inside ? (size_t)a.W * py + px : 0;
 
@@ -601,7 +609,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
             T = T * rcp_1ma;
             const float wc = al * T;             // dchannel_dcolor == dchannel_ddepth
             const float wp = wc * T;             // dchannel_dphasor = alpha*T*T
-            const float dist = a1.w, z = a1.z;
+            const float dist = a1.w, z = a1.z - zref;
             const float t2 = fmaf(A2, z, B2);    // A2 z + B2
             const float dL_dw_ga = fmaf(t2, z, C2);   // g_acc + dL_dw
 

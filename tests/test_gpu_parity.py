@@ -727,3 +727,29 @@ def test_deterministic_backward_mode(tmp_path, scene_kw, oracle):
     assert worst < 2e-5, worst
     _, b = Hh.run_oracle(oracle, scene)
     check_grads(b, {k: det["0_" + k] for k in keys}, scene)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("z_lo,z_hi", [(3.0, 3.05), (4.0, 4.004), (1.0, 5.5)])
+def test_depth_distortion_in_a_narrow_depth_range(z_lo, z_hi, oracle, gpu):
+    """depth_distortion = A D2 - D^2 of the final sums; its two terms cancel to (depth spread / depth)^2 of their size, so
+    the kernels accumulate around the tile's nearest depth.  Against the float64 re-derivation (tests/torch_ref.py) the
+    plane must be as accurate as the oracle's reference-order fp32 sums (relative to the plane's own size, not to 1),
+    and not negative beyond rounding."""
+    import torch_ref
+    sc = Hh.small_scene(P=1500, W=64, H=48, seed=5, scale_lo=0.03, scale_hi=0.15, z_lo=z_lo, z_hi=z_hi, w2c=None)
+    f, _ = Hh.run_oracle(oracle, sc, backward=False)
+    out, grads, _ = Hh.run_gpu(sc, gpu)
+    dt = torch.float64
+    params = {k: torch.tensor(v, dtype=dt, requires_grad=True) for k, v in sc["gaussians"].items() if v is not None}
+    params["phase_offset"] = torch.tensor(sc["phase_offset"], dtype=dt, requires_grad=True)
+    params["dc_offset"] = torch.tensor(sc["dc_offset"], dtype=dt, requires_grad=True)
+    ref = torch_ref.render(params, f, Hh.oracle_kwargs(sc))["depth_distortion"].detach().numpy()
+    size = float(np.abs(ref).max())
+    err_oracle = float(np.abs(f["depth_distortion"] - ref).max())
+    err_dev = float(np.abs(out["depth_distortion"] - ref).max())
+    assert err_dev <= max(2.0 * err_oracle, 2e-3 * size), (err_dev, err_oracle, size)
+    assert float(out["depth_distortion"].min()) >= -1e-3 * size
+    # and the backward uses the same shifted sums: gradients against the oracle as everywhere else
+    _, b = Hh.run_oracle(oracle, sc)
+    check_grads(b, grads, sc)
