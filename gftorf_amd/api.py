@@ -183,6 +183,51 @@ class _Settings(NamedTuple):
     use_view_dependent_phase: bool
 
 
+def new_slab_state():
+    """Per (shape, hint slot): width of the near slab, pause of the depth cut, handles of late reports."""
+    return {"per_tile": _SLAB_DEFAULT, "late": None, "pending": [], "clean": 0, "nocut": 0, "off": 0, "backoff": 0}
+
+
+def slab_report(slab, flagged, quadrants):
+    """Takes the late report of one earlier frame that was rendered with a depth cut: `flagged` of its `quadrants` pixel
+    quadrants outlived the near slab (each tile of such a quadrant took the second binning pass)."""
+    if flagged > max(4, quadrants // 100):
+        # More than 1 % of the quadrants: the second pass (three scans over the Gaussians, the tail sort, the resumed
+        # quadrants' walk behind everything else) cost more than the cut saved -- the frame is not like the one the cut
+        # came from (another view of a training loop) or its tiles look at very different depths.  Bin whole frames for a
+        # while, twice as long each time it happens again (at most 64 frames), then try once more.
+        slab["backoff"] = min(64, 2 * slab["backoff"] + 4)
+        slab["off"] = slab["backoff"]
+        slab["per_tile"], slab["clean"] = _SLAB_DEFAULT, 0
+    elif flagged > 0:
+        # a few: a quarter more slab absorbs them
+        slab["per_tile"], slab["clean"] = min(_SLAB_MAX, int(slab["per_tile"] * 1.25) + 1), 0
+    else:
+        slab["clean"] += 1
+        if slab["clean"] % 16 == 0:
+            slab["backoff"] //= 2
+        if slab["clean"] >= 200 and slab["per_tile"] > _SLAB_DEFAULT:
+            slab["per_tile"], slab["clean"] = max(_SLAB_DEFAULT, int(slab["per_tile"] * 0.9)), 0
+
+
+def slab_next_cut(slab, suggested_cut):
+    """The depth cut the next frame is rendered with: the previous frame's suggestion, or 0 (bin the whole frame) while
+    the cut is paused."""
+    cut = suggested_cut
+    if slab["off"] > 0:
+        slab["off"] -= 1
+        cut = 0.0
+    # A widened slab that no longer leaves out half of the frame gets no cut from the device (and therefore no reports
+    # to narrow it again): after 50 such frames it starts over at the default width
+    if cut > 0.0 or slab["per_tile"] == _SLAB_DEFAULT:
+        slab["nocut"] = 0
+    else:
+        slab["nocut"] += 1
+        if slab["nocut"] >= 50:
+            slab["per_tile"], slab["nocut"], slab["clean"] = _SLAB_DEFAULT, 0, 0
+    return cut
+
+
 def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
                    cov3Ds_precomp, ph_off, dc_off, want_bw, with_acc, stream=None, hint_slot=0, share_grads=None):
     """One forward of the native rasterizer (``RasterizeGaussiansCUDA``, rasterize_points.cu:42-165): allocates the
@@ -293,11 +338,10 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
-                    slab = _slab_state.setdefault(hint_key, {"per_tile": _SLAB_DEFAULT, "late": None, "clean": 0, "nocut": 0,
-                                                             "off": 0, "backoff": 0})
+                    slab = _slab_state.setdefault(hint_key, new_slab_state())
                     # late reports of the earlier forwards of this kind, oldest first; one that has not arrived yet (the
                     # host runs ahead of the device) is asked for again next time
-                    pending = slab.setdefault("pending", [])
+                    pending = slab["pending"]
                     if slab["late"] is not None:
                         pending.append(slab["late"])
                         slab["late"] = None
@@ -308,36 +352,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                         if flagged.value < 0:
                             break
                         pending.pop(0)
-                        quads = 4 * ((W + 15) // 16) * ((H + 15) // 16)
-                        if flagged.value > max(4, quads // 100):
-                            # More than 1 % of the quadrants outlived the near slab: the second binning pass (three scans
-                            # over the Gaussians, the tail sort, the resumed quadrants' walk behind everything else) cost
-                            # more than the cut saved -- the frame is not like the one the cut came from (another view of a
-                            # training loop) or its tiles look at very different depths.  Bin whole frames for a while,
-                            # twice as long each time it happens again (at most 64 frames), then try once more.
-                            slab["backoff"] = min(64, 2 * slab["backoff"] + 4)
-                            slab["off"] = slab["backoff"]
-                            slab["per_tile"], slab["clean"] = _SLAB_DEFAULT, 0
-                        elif flagged.value > 0:
-                            # a few: a quarter more slab absorbs them
-                            slab["per_tile"], slab["clean"] = min(_SLAB_MAX, int(slab["per_tile"] * 1.25) + 1), 0
-                        elif flagged.value == 0:
-                            slab["clean"] += 1
-                            if slab["clean"] % 16 == 0:
-                                slab["backoff"] //= 2
-                            if slab["clean"] >= 200 and slab["per_tile"] > _SLAB_DEFAULT:
-                                slab["per_tile"], slab["clean"] = max(_SLAB_DEFAULT, int(slab["per_tile"] * 0.9)), 0
-                    if slab["off"] > 0:
-                        slab["off"] -= 1
-                        cut_hint = 0.0
-                    # A widened slab that no longer leaves out half of the frame gets no cut (and therefore no reports to
-                    # narrow it again): after 50 such frames it starts over at the default width
-                    if cut_hint > 0.0 or slab["per_tile"] == _SLAB_DEFAULT:
-                        slab["nocut"] = 0
-                    else:
-                        slab["nocut"] += 1
-                        if slab["nocut"] >= 50:
-                            slab["per_tile"], slab["nocut"], slab["clean"] = _SLAB_DEFAULT, 0, 0
+                        slab_report(slab, int(flagged.value), 4 * ((W + 15) // 16) * ((H + 15) // 16))
+                    cut_hint = slab_next_cut(slab, cut_hint)
                     hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
                                               near_instances=int(near_hint), depth_cut=float(cut_hint),
                                               near_per_tile=int(slab["per_tile"]))
