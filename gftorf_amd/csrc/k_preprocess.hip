@@ -786,6 +786,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
             // row = {dcolor[3], ddist | dmean2D.xy', dconic.xy' | XR, XI, X2, XQ | dconic.w', dopacity, dndc, -}
             // (the order the render backward's pairwise wave reduction produces, k_render.hip)
             const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+            // (the forward's records for the chains further down, asked for together with the accumulator row: the wave's
+            // time is its dependent memory round trips, two waves per SIMD do not hide a third one)
+            const uint32_t clamp_bits = a.g.clamped[idx];
+            float dg[16];
+            if (have_dg) dirgrad_load(a.g.dirgrad, idx, dg);
+            const float4 b2 = a.g.rec_b[2 * idx + 1];     // {I, Am, phase_sh, amplitude}
             dcolor[0] = a0.x; dcolor[1] = a0.y; dcolor[2] = a0.z;
             const float ddist_in = a0.w;
             // the five geometric sums arrive without their per-Gaussian factors (k_render_bwd):
@@ -881,9 +887,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
             const float dox = px - a.io.campos[0], doy = py - a.io.campos[1], doz = pz - a.io.campos[2];
             const float dlen = sqrtf(dox * dox + doy * doy + doz * doz);
             const float dx = dox / dlen, dy = doy / dlen, dz = doz / dlen;
-            const uint32_t clamp_bits = a.g.clamped[idx];
-            float dg[16];
-            if (have_dg) dirgrad_load(a.g.dirgrad, idx, dg);
 
             // ---- colour SH (reference backward.cu:20-139) ----
             if (a.io.shs != nullptr) {
@@ -914,7 +917,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
             }
 
             // ---- ToF phasor chain (reference backward.cu:527-587) ----
-            const float4 b2 = a.g.rec_b[2 * idx + 1];     // {I, Am, phase_sh, amplitude}
             // distance to the camera: the forward's expression on the same view-space position (bit-identical;
             // re-reading it from rec_a would cost a 32-byte sector per Gaussian for 4 bytes)
             const float dist = sqrtf(mvx * mvx + mvy * mvy + mvz * mvz);
