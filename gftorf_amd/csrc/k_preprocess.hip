@@ -783,7 +783,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
         if (visible) {
             // accumulators written by the render backward
             const float4* ap = reinterpret_cast<const float4*>(a.io.acc + (size_t)idx * GFT_ACC_STRIDE);
-            // row = {dcolor[3], ddist | dmean2D.xy', dconic.xy' | XR, XI, X2, XQ | dconic.w', dopacity, dndc, -}
+            // row = {dcolor[3], ddist | sum E dx, sum E dy, dconic.xy' | XR, XI, X2, XQ | dconic.w', dopacity, dndc, -}
             // (the order the render backward's pairwise wave reduction produces, k_render.hip)
             const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
             // (the forward's records for the chains further down, asked for together with the accumulator row: the wave's
@@ -798,8 +798,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
             // dL/dmean2D.xy = -o (0.5 W, 0.5 H) * sum,  dL/dconic = -o/2 * sum
             // (the pybind-level backward of the reference has no opacity argument, rasterize_points.h:55-88: the value
             // the forward stored in the geometry record is the same float)
-            const float nop = -(a.io.opacities ? a.io.opacities[idx] : a.g.rec_a[2 * idx + 1].y);
-            dmean2d[0] = a1.x * (nop * 0.5f * (float)a.c.W); dmean2d[1] = a1.y * (nop * 0.5f * (float)a.c.H);
+            const float4 ra0 = a.g.rec_a[2 * idx], ra1 = a.g.rec_a[2 * idx + 1];     // {x, y, conic a, b} {conic c, opacity, ..}
+            const float nop = -(a.io.opacities ? a.io.opacities[idx] : ra1.y);
+            // the render backward reduced sum E dx and sum E dy; the conic is per Gaussian
+            dmean2d[0] = (ra0.z * a1.x + ra0.w * a1.y) * (nop * 0.5f * (float)a.c.W);
+            dmean2d[1] = (ra0.w * a1.x + ra1.x * a1.y) * (nop * 0.5f * (float)a.c.H);
             const float dconx = a1.z * (0.5f * nop), dcony = a1.w * (0.5f * nop), dconw = a3.x * (0.5f * nop);
             dopac = a3.y;
             const float dndc_in = a3.z;

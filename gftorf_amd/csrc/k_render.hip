@@ -597,7 +597,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
         // Gradient contributions of splat j, reduced over the 64 pixels into `row`.  Every lane runs
         // the same arithmetic; lanes that do not blend this splat use alpha = G = 0, which leaves T and
         // the two recurrences unchanged (rcp(1) == 1) and makes all 15 partials exactly zero.
-        // accumulator row = {dcolor[3], ddist | dmean2D.xy, dconic.xy | XR, XI, X2, XQ | dconic.w, dopacity, dndc, -}
+        // accumulator row = {dcolor[3], ddist | sum E dx, sum E dy, dconic.xy | XR, XI, X2, XQ | dconic.w, dopacity, dndc, -}
         auto blend = [&](int j, const float4& a0, const float4& a1, float dx, float dy, float G, float alpha,
                          bool contrib) {
             v2f L01, L23, L45, L67, H01, H23, H45, H67;
@@ -633,11 +633,13 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
 
             // E = G dL/dalpha; the per-splat factors of the five geometric sums (opacity, -1/2,
             // 0.5 W, 0.5 H) are applied once per Gaussian in k_preprocess_bwd:
-            //   dL/dmean2D.x = -o 0.5W sum E (dx a + dy b),  dL/dconic.x = -o/2 sum E dx^2, ...
+            //   dL/dmean2D.x = -o 0.5W (a sum E dx + b sum E dy),  dL/dconic.x = -o/2 sum E dx^2, ...
             const float E = Gm * dL_dalpha;
             const float Edx = E * dx, Edy = E * dy;
-            L45.x = E * fmaf(dy, a0.w, dx * a0.z);    // dmean2D.x / (-o 0.5 W)
-            L45.y = E * fmaf(dx, a0.w, dy * a1.x);    // dmean2D.y / (-o 0.5 H)
+            // dL/dmean2D = -o (0.5 W, 0.5 H) * conic * (sum E dx, sum E dy): the conic is the splat's, so the two plain
+            // sums are reduced and k_preprocess_bwd multiplies (6 VALU less per hit than sum E (a dx + b dy), sum E (b dx + c dy))
+            L45.x = Edx;
+            L45.y = Edy;
             L67.x = Edx * dx;                         // dconic.x / (-o/2)
             L67.y = Edx * dy;                         // dconic.y / (-o/2)
             H45.x = Edy * dy;                         // dconic.w / (-o/2)
