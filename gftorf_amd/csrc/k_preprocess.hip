@@ -584,6 +584,62 @@ __device__ __forceinline__ void appearance_fwd(const PreFwdArgs& a, int idx, int
     a.g.clamped[idx] = (uint8_t)clamp_bits;
 }
 
+// Screen-space geometry of one Gaussian that passed the depth test (reference forward.cu:303-345): pixel centre, conic,
+// radius.  One function for the preprocess kernel and for the far pass, which writes the geometry record of a far
+// Gaussian only when a flagged tile needs it: the same expressions, the same bits.
+struct ScreenGeom {
+    float pix_x, pix_y, conx, cony, conz, my_radius;
+    bool ok;             // false: degenerate 2D covariance (det == 0), the Gaussian is invisible
+};
+__device__ __forceinline__ ScreenGeom screen_geometry(const PreFwdArgs& a, int idx, float px, float py, float pz, const Mat16& V)
+{
+    ScreenGeom o;
+    o.ok = false;
+    o.pix_x = o.pix_y = o.conx = o.cony = o.conz = o.my_radius = 0.f;
+    const Mat16 PV = load_mat(a.io.projmatrix);
+    const float hx = PV.m[0] * px + PV.m[4] * py + PV.m[8] * pz + PV.m[12];
+    const float hy = PV.m[1] * px + PV.m[5] * py + PV.m[9] * pz + PV.m[13];
+    const float hw = PV.m[3] * px + PV.m[7] * py + PV.m[11] * pz + PV.m[15];
+    const float p_w = 1.0f / (hw + 0.0000001f);
+    const float ndc_x = hx * p_w, ndc_y = hy * p_w;
+
+    float cov[6];
+    if (a.io.cov3D_precomp != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov[i] = a.io.cov3D_precomp[6 * idx + i];
+    } else {
+        const float mod = a.c.scale_modifier;
+        const float4 q = reinterpret_cast<const float4*>(a.io.rotations)[idx];
+        cov3d_from_scale_rot(mod * a.io.scales[3 * idx], mod * a.io.scales[3 * idx + 1],
+                             mod * a.io.scales[3 * idx + 2], q, cov);
+    }
+    const Ewa e = ewa_project(px, py, pz, V, a.focal_x, a.focal_y, a.c.tanfovx, a.c.tanfovy, cov);
+    const float ca = e.a + 0.3f, cb = e.b, cc = e.c + 0.3f;
+    const float det = ca * cc - cb * cb;
+    if (det != 0.0f) {
+        const float det_inv = 1.f / det;
+        o.conx = cc * det_inv; o.cony = -cb * det_inv; o.conz = ca * det_inv;
+        const float mid = 0.5f * (ca + cc);
+        const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+        o.my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        // ndc2Pix is evaluated in double in the reference (auxiliary.h:44-47)
+        o.pix_x = (float)(((ndc_x + 1.0) * a.c.W - 1.0) * 0.5);
+        o.pix_y = (float)(((ndc_y + 1.0) * a.c.H - 1.0) * 0.5);
+        o.ok = true;
+    }
+    return o;
+}
+
+// the 32-byte geometry record the render kernels read: {x, y, conic a, b} {conic c, opacity, NDC distance, distance}
+__device__ __forceinline__ void store_rec_a(const PreFwdArgs& a, int idx, const ScreenGeom& sg, float vx, float vy, float vz)
+{
+    const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float dist_ndc = a.c.far_n / (a.c.far_n - a.c.near_n) * (1 - a.c.near_n / dist);
+    a.g.rec_a[2 * idx] = make_float4(sg.pix_x, sg.pix_y, sg.conx, sg.cony);
+    a.g.rec_a[2 * idx + 1] = make_float4(sg.conz, a.io.opacities[idx], dist_ndc, dist);
+}
+
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
 {
     extern __shared__ float4 lds_rows[];
@@ -613,48 +669,20 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
         } else {
             const float vx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
             const float vy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
-            const Mat16 PV = load_mat(a.io.projmatrix);
-            const float hx = PV.m[0] * px + PV.m[4] * py + PV.m[8] * pz + PV.m[12];
-            const float hy = PV.m[1] * px + PV.m[5] * py + PV.m[9] * pz + PV.m[13];
-            const float hw = PV.m[3] * px + PV.m[7] * py + PV.m[11] * pz + PV.m[15];
-            const float p_w = 1.0f / (hw + 0.0000001f);
-            const float ndc_x = hx * p_w, ndc_y = hy * p_w;
-
-            float cov[6];
-            if (a.io.cov3D_precomp != nullptr) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) cov[i] = a.io.cov3D_precomp[6 * idx + i];
-            } else {
-                const float mod = a.c.scale_modifier;
-                const float4 q = reinterpret_cast<const float4*>(a.io.rotations)[idx];
-                cov3d_from_scale_rot(mod * a.io.scales[3 * idx], mod * a.io.scales[3 * idx + 1],
-                                     mod * a.io.scales[3 * idx + 2], q, cov);
-            }
-            const Ewa e = ewa_project(px, py, pz, V, a.focal_x, a.focal_y, a.c.tanfovx, a.c.tanfovy, cov);
-            const float ca = e.a + 0.3f, cb = e.b, cc = e.c + 0.3f;
-            const float det = ca * cc - cb * cb;
-            if (det != 0.0f) {
-                const float det_inv = 1.f / det;
-                const float conx = cc * det_inv, cony = -cb * det_inv, conz = ca * det_inv;
-                const float mid = 0.5f * (ca + cc);
-                const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-                const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-                const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-                // ndc2Pix is evaluated in double in the reference (auxiliary.h:44-47)
-                const float pix_x = (float)(((ndc_x + 1.0) * a.c.W - 1.0) * 0.5);
-                const float pix_y = (float)(((ndc_y + 1.0) * a.c.H - 1.0) * 0.5);
+            const ScreenGeom sg = screen_geometry(a, idx, px, py, pz, V);
+            if (sg.ok) {
                 int x0, y0, x1, y1;
-                gft_get_rect(pix_x, pix_y, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
+                gft_get_rect(sg.pix_x, sg.pix_y, (int)sg.my_radius, a.gx, a.gy, x0, y0, x1, y1);
                 const uint32_t area = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
                 if (area != 0) {
-                    const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
-                    const float dist_ndc = a.c.far_n / (a.c.far_n - a.c.near_n) * (1 - a.c.near_n / dist);
-                    a.g.rec_a[2 * idx] = make_float4(pix_x, pix_y, conx, cony);
-                    a.g.rec_a[2 * idx + 1] = make_float4(conz, a.io.opacities[idx], dist_ndc, dist);
                     a.g.depth[idx] = vz;
-                    // appearance now for the near slab; the far slab's only if a quadrant outlives the near one
-                    if (__float_as_uint(vz) <= a.cut_bits) appearance_fwd(a, idx, lane, sh_l, shp_l, px, py, pz, vx, vy, vz);
-                    radius = (int)my_radius;
+                    // geometry record and appearance now for the near slab; the far slab's only if a quadrant outlives the
+                    // near one (k_appearance_far): the binning kernels need the rectangle and the depth, nothing else
+                    if (__float_as_uint(vz) <= a.cut_bits) {
+                        store_rec_a(a, idx, sg, vx, vy, vz);
+                        appearance_fwd(a, idx, lane, sh_l, shp_l, px, py, pz, vx, vy, vz);
+                    }
+                    radius = (int)sg.my_radius;
                     tiles = area;
                     rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
                 }
@@ -693,6 +721,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_appearance_far(PreFwdArgs a, uint
     const float vz = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
     const float vx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
     const float vy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
+    store_rec_a(a, idx, screen_geometry(a, idx, px, py, pz, V), vx, vy, vz);       // (the preprocess kernel left it out)
     appearance_fwd(a, idx, threadIdx.x & 63, nullptr, nullptr, px, py, pz, vx, vy, vz);
 }
 
