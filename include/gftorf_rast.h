@@ -184,7 +184,8 @@ typedef struct gft_backward_io {
  * tests can inspect intermediate state stage by stage. */
 typedef struct gft_layout {
     /* geom */
-    size_t geom_rec_a;        /* float[P][8]  {x,y, conic a,b,c, opacity, dist_ndc, dist} */
+    size_t geom_rec_a;        /* float[P][8]  {x,y, conic a,b,c, opacity, dist_ndc, dist}; with a depth cut only for the Gaussians in
+                                 front of it and those the far pass binned (like rec_b, dirgrad, clamped) */
     size_t geom_rec_b;        /* float[P][8]  {r,g,b, R,I,Am (ToF phasor basis: cos,sin,1 times A/d^2), phase_sh, amplitude} */
     size_t geom_depth;        /* float[P]     view-space z (sort key bits) */
     size_t geom_tiles;        /* uint32[P]    tiles touched */
