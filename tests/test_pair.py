@@ -150,3 +150,56 @@ def _run_pair_nograd(a, b, dev):
         phase_offset=(a["phase_offset"], b["phase_offset"]), dc_offset=(a["dc_offset"], b["dc_offset"]))
     torch.cuda.synchronize()
     return out, None, None, None
+
+
+@pytest.mark.parametrize("variant", ["colors_cov3d_precomp", "sh_degree1_4coeff"])
+def test_pair_operator_variants(variant, oracle, gpu):
+    """The second view's backward adds to the first one's tensors on every gradient the operator returns: precomputed
+    colours and 3D covariances (dL_dcolors, dL_dcov3D rows), and SH rows that are not whole 16-coefficient rows (the
+    unstaged row path of k_preprocess_bwd)."""
+    from gftorf_amd import GaussianRasterizer, GaussianRasterizerPair
+    if variant == "colors_cov3d_precomp":
+        a, b = _two_views(P=600, tof=False)
+        f0, _ = Hh.run_oracle(oracle, a, backward=False)
+        rng = np.random.default_rng(3)
+        cov = f0.geom["cov3D"].copy()
+        cov[f0.radii <= 0] = np.array([1e-4, 0, 0, 1e-4, 0, 1e-4], np.float32)
+        g = dict(a["gaussians"], shs=None, shs_p=None, scales=None, rotations=None,
+                 colors_precomp=rng.random((600, 3)).astype(np.float32), cov3D_precomp=cov)
+    else:
+        a, b = _two_views(P=600, D=1, sh_coeffs=4)
+        g = dict(a["gaussians"])
+    a["gaussians"] = b["gaussians"] = g
+    keys = [k for k, v in g.items() if v is not None]
+
+    def run(pair):
+        leaf = {k: torch.tensor(g[k], dtype=torch.float32, device=gpu, requires_grad=True) for k in keys}
+        m2 = torch.zeros((600, 3), device=gpu, requires_grad=True)
+        kw = dict(means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf.get("shs"), shs_p=leaf.get("shs_p"),
+                  colors_precomp=leaf.get("colors_precomp"), scales=leaf.get("scales"), rotations=leaf.get("rotations"),
+                  cov3D_precomp=leaf.get("cov3D_precomp"))
+        sa, sb = Hh.gpu_settings(a, gpu), Hh.gpu_settings(b, gpu)
+        if pair:
+            oa, ob = GaussianRasterizerPair(sa, sb)(phase_offset=(a["phase_offset"], b["phase_offset"]),
+                                                    dc_offset=(a["dc_offset"], b["dc_offset"]), **kw)
+        else:
+            oa = GaussianRasterizer(sa)(phase_offset=a["phase_offset"], dc_offset=a["dc_offset"], **kw)
+            ob = GaussianRasterizer(sb)(phase_offset=b["phase_offset"], dc_offset=b["dc_offset"], **kw)
+        (_loss(oa, a, gpu) + _loss(ob, b, gpu)).backward()
+        torch.cuda.synchronize()
+        return (oa, ob), leaf, m2
+
+    so, sl, sm = run(False)
+    po, pl, pm = run(True)
+    for v in range(2):
+        for name, x, y in zip(Hh.OUT_NAMES, so[v], po[v]):
+            np.testing.assert_array_equal(x.detach().cpu().numpy(), y.detach().cpu().numpy(), err_msg="%s view %d" % (name, v))
+    _same_grads(sl, sm, pl, pm, 2e-5)
+    # and against the oracle: the sum of both views' gradients
+    (_, ba), (_, bb) = Hh.run_oracle(oracle, a), Hh.run_oracle(oracle, b)
+    names = dict(means3D="dL_dmeans3D", shs="dL_dsh", shs_p="dL_dsh_p", scales="dL_dscales", rotations="dL_drotations",
+                 colors_precomp="dL_dcolors", cov3D_precomp="dL_dcov3D")
+    for k in keys:
+        if k in names:
+            ref = (ba[names[k]] + bb[names[k]]).reshape(g[k].shape)
+            Hh.assert_close(names[k], ref, pl[k].grad.cpu().numpy(), rtol_max=3e-4)
