@@ -981,7 +981,7 @@ __device__ __forceinline__ void dw_job_bf(const float* A, int lda, int n_base, c
         bf16x8 pa[TN][3], pb[TK][3];
 #pragma unroll
         for (int x = 0; x < TN; x++) {
-            if (BIAS) {
+            if (BIAS && write_bias) {           // (wave-uniform: the waves of the other column half leave the sums out)
 #pragma unroll
                 for (int j = 0; j < 8; j++) bsum[x] += ra[x][j];
             }
