@@ -852,6 +852,7 @@ constexpr int64_t DW_PART_FLOATS = DW_OFF_BIAS + DF_D * DF_W + DF_HEAD;
 struct DwArgs {
     int64_t n_pad;
     int tiles_per_split;    // 64-point tiles per split
+    int shared_split;       // heavy jobs: every operand block split once per workgroup, through LDS (dw_job_bf_shared)
     int splits;
     const float* emb; const float* acts; const float* dz; const float* dzh;
     float* part;            // [splits][DW_PART_FLOATS]
@@ -1017,6 +1018,111 @@ __device__ __forceinline__ void dw_job_bf(const float* A, int lda, int n_base, c
     }
 }
 
+// The 256 x 256 block of a hidden layer's dW by one workgroup, every operand block split ONCE: in dw_job_bf each of the
+// four waves loads and splits both of its 128-column operand blocks, so every block is split by two waves and the
+// splitting takes as long as the multiplies.  Here wave w loads and splits one block (w = 0, 1: columns 0..127 / 128..255
+// of dz; w = 2, 3: of x), leaves the three bf16 planes in LDS in the lanes' MFMA operand layout, and after a barrier
+// every wave reads the planes of its two blocks (16-byte LDS reads, the same lane slot as the writer's).  Two LDS
+// buffers: the planes of step k + 1 are written while the multiplies of step k run; one barrier per 16-point step.  The
+// same products in the same order as dw_job_bf: bit-identical dW.
+constexpr int DW_SH_BLOCK_BYTES = 4 * 3 * 64 * 16;                 // [x 4][plane 3][lane 64] x 16 B
+constexpr int DW_SH_LDS = 2 * 4 * DW_SH_BLOCK_BYTES;               // two buffers of four operand blocks: 98304 B
+__device__ __forceinline__ void dw_job_bf_shared(const float* A, const float* B, float* out, float* bias_out, int64_t p_begin,
+                                                 int64_t p_end, int wave, int lane, char* lds)
+{
+    const int li = lane & 31, hh = lane >> 5;
+    f32x16 acc[4][4];
+    zero_acc(acc);
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    // the block this wave loads and splits
+    const float* S = (wave < 2 ? A : B) + (p_begin + 8 * hh) * DF_W + 128 * (wave & 1) + li;
+    const bool sum_bias = wave < 2;
+    float raw[4][8];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) raw[x][j] = S[(int64_t)j * DF_W + 32 * x];
+        S += 16 * DF_W;
+    };
+    auto split_to = [&](char* buf) {
+        uint4* dst = reinterpret_cast<uint4*>(buf + wave * DW_SH_BLOCK_BYTES) + lane;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            if (sum_bias) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) bsum[x] += raw[x][j];
+            }
+            bf16x8 pl[3];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                __bf16 h, m, l;
+                split3(raw[x][j], h, m, l);
+                pl[0][j] = h; pl[1][j] = m; pl[2][j] = l;
+            }
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                uint4 v;
+                __builtin_memcpy(&v, &pl[q], 16);
+                dst[(x * 3 + q) * 64] = v;
+            }
+        }
+    };
+    const int64_t nsteps = (p_end - p_begin) / 16;
+    if (nsteps > 0) {
+        fetch();
+        split_to(lds);
+        if (nsteps > 1) fetch();
+    }
+    __syncthreads();
+    const int ablk = wave & 1, bblk = 2 + (wave >> 1);
+    for (int64_t k = 0; k < nsteps; k++) {
+        char* cur = lds + (k & 1) * 4 * DW_SH_BLOCK_BYTES;
+        char* nxt = lds + ((k + 1) & 1) * 4 * DW_SH_BLOCK_BYTES;
+        bf16x8 pa[4][3], pb[4][3];
+        {
+            const uint4* sa = reinterpret_cast<const uint4*>(cur + ablk * DW_SH_BLOCK_BYTES) + lane;
+            const uint4* sb = reinterpret_cast<const uint4*>(cur + bblk * DW_SH_BLOCK_BYTES) + lane;
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const uint4 va = sa[(x * 3 + q) * 64], vb = sb[(x * 3 + q) * 64];
+                    __builtin_memcpy(&pa[x][q], &va, 16);
+                    __builtin_memcpy(&pb[x][q], &vb, 16);
+                }
+        }
+        if (k + 1 < nsteps) split_to(nxt);           // (raw holds step k + 1)
+        if (k + 2 < nsteps) fetch();
+#pragma unroll
+        for (int term = 0; term < 6; term++) {
+            const int pw = term == 0 ? 0 : term == 1 ? 1 : term == 2 ? 0 : term == 3 ? 2 : term == 4 ? 0 : 1;
+            const int pv = term == 0 ? 0 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 2 : 1;
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[x][pw], pb[y][pv], acc[x][y], 0, 0, 0);
+        }
+        __syncthreads();      // everyone has read `cur` and written `nxt`
+    }
+    const int n_base = 128 * (wave & 1), k_base = 128 * (wave >> 1);
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                out[(int64_t)(n_base + 32 * x + acc_row(q, hh)) * DF_W + k_base + 32 * y + li] = acc[x][y][q];
+    if (sum_bias) {
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const float tot = bsum[x] + __shfl_xor(bsum[x], 32);
+            if (hh == 0) bias_out[n_base + 32 * x + li] = tot;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_deform_dw_bf(DwArgs a)
 {
     int job, split;
@@ -1036,8 +1142,13 @@ __global__ __launch_bounds__(256) void k_deform_dw_bf(DwArgs a)
     const int64_t plane = a.n_pad * DF_W;
     if (job < 7) {
         const int l = 7 - job;
-        dw_job_bf<4, 4, true>(a.dz + l * plane, DF_W, 128 * (wave & 1), a.acts + (l - 1) * plane, DF_W, 128 * (wave >> 1),
-                              part + DW_OFF_L(l), DF_W, part + DW_OFF_BIAS + l * DF_W, (wave >> 1) == 0, p_begin, p_end, li, hh);
+        extern __shared__ float4 df_lds[];
+        if (a.shared_split)
+            dw_job_bf_shared(a.dz + l * plane, a.acts + (l - 1) * plane, part + DW_OFF_L(l), part + DW_OFF_BIAS + l * DF_W, p_begin,
+                             p_end, wave, lane, reinterpret_cast<char*>(df_lds));
+        else
+            dw_job_bf<4, 4, true>(a.dz + l * plane, DF_W, 128 * (wave & 1), a.acts + (l - 1) * plane, DF_W, 128 * (wave >> 1),
+                                  part + DW_OFF_L(l), DF_W, part + DW_OFF_BIAS + l * DF_W, (wave >> 1) == 0, p_begin, p_end, li, hh);
     } else if (job == 7) {
         dw_job_bf<2, 3, true>(a.dz, DF_W, 64 * wave, a.emb, DF_EMB, 0, part + DW_OFF_L0, DF_EMB, part + DW_OFF_BIAS, true, p_begin,
                               p_end, li, hh);
@@ -1311,8 +1422,13 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
         a.splits = splits;
         a.emb = emb; a.acts = acts; a.dz = dz; a.dzh = dzh;
         a.part = part;
-        if (bf16_planes()) hipLaunchKernelGGL(k_deform_dw_bf, dim3(DW_JOBS * splits), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(k_deform_dw, dim3(DW_JOBS * splits), dim3(256), 0, s, a);
+        static const int shared_split = [] { const char* e = getenv("GFT_DEFORM_DW_SHARED"); return e ? atoi(e) : 1; }();
+        a.shared_split = shared_split;
+        if (bf16_planes()) {
+            static std::atomic<uint64_t> done{0};
+            GFT_CHECK_HIP(gft_lds_opt_in(reinterpret_cast<const void*>(&k_deform_dw_bf), DW_SH_LDS, done));
+            hipLaunchKernelGGL(k_deform_dw_bf, dim3(DW_JOBS * splits), dim3(256), shared_split ? DW_SH_LDS : 0, s, a);
+        } else hipLaunchKernelGGL(k_deform_dw, dim3(DW_JOBS * splits), dim3(256), 0, s, a);
         GFT_CHECK_HIP(hipGetLastError());
     }
     {
