@@ -1069,13 +1069,22 @@ __device__ __forceinline__ void dw_job_bf_shared(const float* A, const float* B,
         }
     };
     const int64_t nsteps = (p_end - p_begin) / 16;
-    if (nsteps > 0) {
+    // (the loop body is one basic block -- the last steps split and fetch a step again instead of branching -- so that
+    // the scheduler can be told to put the VALU work of the next step's split between this step's multiplies: one wave
+    // per SIMD has nobody else to fill the matrix pipe's shadow)
+    const float* S_last = S + (nsteps > 0 ? nsteps - 1 : 0) * 16 * DF_W;
+    auto fetch_clamped = [&]() {
+        if (S > S_last) S = S_last;
         fetch();
+    };
+    if (nsteps > 0) {
+        fetch_clamped();
         split_to(lds);
-        if (nsteps > 1) fetch();
+        fetch_clamped();
     }
     __syncthreads();
     const int ablk = wave & 1, bblk = 2 + (wave >> 1);
+    const bool count_bias = sum_bias;
     for (int64_t k = 0; k < nsteps; k++) {
         char* cur = lds + (k & 1) * 4 * DW_SH_BLOCK_BYTES;
         char* nxt = lds + ((k + 1) & 1) * 4 * DW_SH_BLOCK_BYTES;
@@ -1092,8 +1101,34 @@ __device__ __forceinline__ void dw_job_bf_shared(const float* A, const float* B,
                     __builtin_memcpy(&pb[x][q], &vb, 16);
                 }
         }
-        if (k + 1 < nsteps) split_to(nxt);           // (raw holds step k + 1)
-        if (k + 2 < nsteps) fetch();
+        // raw holds step k + 1 (the last step once more behind the end: its planes are written and never read, its
+        // bias share is left out)
+        const bool live = k + 1 < nsteps;
+        {
+            uint4* dst = reinterpret_cast<uint4*>(nxt + wave * DW_SH_BLOCK_BYTES) + lane;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                float add = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) add += raw[x][j];
+                bsum[x] += (count_bias && live) ? add : 0.f;
+                bf16x8 pl[3];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    __bf16 h, m, l;
+                    split3(raw[x][j], h, m, l);
+                    pl[0][j] = h; pl[1][j] = m; pl[2][j] = l;
+                }
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    uint4 v;
+                    __builtin_memcpy(&v, &pl[q], 16);
+                    dst[(x * 3 + q) * 64] = v;
+                }
+            }
+        }
+        S = S > S_last ? S_last : S;
+        fetch();
 #pragma unroll
         for (int term = 0; term < 6; term++) {
             const int pw = term == 0 ? 0 : term == 1 ? 1 : term == 2 ? 0 : term == 3 ? 2 : term == 4 ? 0 : 1;
@@ -1103,6 +1138,14 @@ __device__ __forceinline__ void dw_job_bf_shared(const float* A, const float* B,
 #pragma unroll
                 for (int y = 0; y < 4; y++)
                     acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[x][pw], pb[y][pv], acc[x][y], 0, 0, 0);
+        }
+        // schedule: one multiply, then a few of the split's VALU instructions, LDS and memory operations in between
+#pragma unroll
+        for (int i = 0; i < 96; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // VALU
+            if ((i & 7) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);   // VMEM read
+            if ((i & 7) == 4) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);   // DS write
         }
         __syncthreads();      // everyone has read `cur` and written `nxt`
     }
