@@ -9,6 +9,7 @@
 // weights are interleaved [k/4][n][4] for 16-byte loads), one 16-k chunk ahead of the multiply; the
 // weight-gradient kernel reads both operands straight from global memory.
 #include "gft_internal.h"
+#include <mutex>
 #include "gftorf_deform.h"
 
 #include <cstdio>
@@ -152,6 +153,18 @@ __device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16&
     const float r1 = x - (float)hi;
     mid = (__bf16)r1;
     lo = (__bf16)(r1 - (float)mid);
+}
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// two floats -> two bf16 (round to nearest even, like the scalar casts of split3) in one dword, the first in the low half
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b)
+{
+    const f32x2_t v = {a, b};
+    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    uint32_t u;
+    __builtin_memcpy(&u, &r, 4);
+    return u;
 }
 
 // fp32 packed streams ([k/4][n][4] per segment) -> bf16 planes ([plane][k/8][n][8] per segment)
@@ -854,6 +867,7 @@ struct DwArgs {
     int tiles_per_split;    // 64-point tiles per split
     int shared_split;       // heavy jobs: every operand block split once per workgroup, through LDS (dw_job_bf_shared)
     int splits;
+    int first_block;        // the launch covers workgroups first_block ... of the job table (heavy jobs, then light ones)
     const float* emb; const float* acts; const float* dz; const float* dzh;
     float* part;            // [splits][DW_PART_FLOATS]
 };
@@ -1038,10 +1052,10 @@ __device__ __forceinline__ void dw_job_bf_shared(const float* A, const float* B,
     const float* S = (wave < 2 ? A : B) + (p_begin + 8 * hh) * DF_W + 128 * (wave & 1) + li;
     const bool sum_bias = wave < 2;
     const int64_t nsteps = (p_end - p_begin) / 16;       // a multiple of 4 (the ranges are multiples of 64 points)
-    // The kernel is bound by its operand reads (4.3 GB of dz and x at 300 k points: with the multiplies taken out it
-    // still takes 1.35 of its 1.9 ms): two steps of loads are kept in flight per wave (rawA / rawB, 16 KB per wave).
-    // The loop body is one basic block -- the steps behind the end split and fetch the last step again instead of
-    // branching -- so that the scheduler can put the split's VALU work between the multiplies.
+    // Measured at 300 k points, hidden layers only: operand loads alone 0.84 ms (4.3 GB of dz and x, 5.1 TB/s), loads +
+    // split + LDS 0.89 ms, everything 1.28 ms; the 96 multiplies of a step are 3072 cycles of the SIMD's matrix pipe.
+    // Two steps of loads are kept in flight per wave (rawA / rawB, 16 KB per wave).  The loop body is one basic block
+    // -- the steps behind the end split and fetch the last step again instead of branching.
     const float* S_last = S + (nsteps > 0 ? nsteps - 1 : 0) * 16 * DF_W;
     float rawA[4][8], rawB[4][8];
     auto fetch = [&](float (&raw)[4][8]) {
@@ -1083,43 +1097,88 @@ __device__ __forceinline__ void dw_job_bf_shared(const float* A, const float* B,
     }
     __syncthreads();
     const int ablk = wave & 1, bblk = 2 + (wave >> 1);
-    // one step: the planes of step k are in buffer k & 1; `raw` holds step k + 1 and is refilled with step k + 3
+    // One step: the planes of step k are in buffer k & 1; `raw` holds step k + 1 and is refilled with step k + 3.
+    // The order is written out and fenced (sched_barrier) chunk by chunk -- left to itself the scheduler puts the 96
+    // multiplies of every other step in one run with the split behind them, and the step takes the sum of the two
+    // instead of the longer one.  A chunk = three multiplies, the split of one raw value per lane, the load that
+    // refills it, and its share of the LDS traffic: the planes of the later terms are read while the earlier terms
+    // multiply, the planes of a finished 32-column block are written as soon as its eighth value is split.
     auto step = [&](int64_t k, float (&raw)[4][8]) {
         char* cur = lds + (k & 1) * 4 * DW_SH_BLOCK_BYTES;
         char* nxt = lds + ((k + 1) & 1) * 4 * DW_SH_BLOCK_BYTES;
+        const uint4* sa = reinterpret_cast<const uint4*>(cur + ablk * DW_SH_BLOCK_BYTES) + lane;
+        const uint4* sb = reinterpret_cast<const uint4*>(cur + bblk * DW_SH_BLOCK_BYTES) + lane;
+        uint4* dst = reinterpret_cast<uint4*>(nxt + wave * DW_SH_BLOCK_BYTES) + lane;
+        const bool live = k + 1 < nsteps;        // (behind the end: planes that are never read, no bias share)
+        S = S > S_last ? S_last : S;
         bf16x8 pa[4][3], pb[4][3];
-        {
-            const uint4* sa = reinterpret_cast<const uint4*>(cur + ablk * DW_SH_BLOCK_BYTES) + lane;
-            const uint4* sb = reinterpret_cast<const uint4*>(cur + bblk * DW_SH_BLOCK_BYTES) + lane;
+        auto read_a = [&](int q) {
 #pragma unroll
-            for (int x = 0; x < 4; x++)
+            for (int x = 0; x < 4; x++) { const uint4 v = sa[(x * 3 + q) * 64]; __builtin_memcpy(&pa[x][q], &v, 16); }
+        };
+        auto read_b = [&](int q) {
 #pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    const uint4 va = sa[(x * 3 + q) * 64], vb = sb[(x * 3 + q) * 64];
-                    __builtin_memcpy(&pa[x][q], &va, 16);
-                    __builtin_memcpy(&pb[x][q], &vb, 16);
-                }
+            for (int x = 0; x < 4; x++) { const uint4 v = sb[(x * 3 + q) * 64]; __builtin_memcpy(&pb[x][q], &v, 16); }
+        };
+        read_a(0);
+        read_b(0);
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t pl[3][4];                       // the three planes of one 32-column block: 8 bf16 per lane each
+        float add = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int x = c >> 2, j = (c & 3) * 2;
+            if (c == 0) read_a(1);               // term 1 (from multiply 16)
+            if (c == 2) read_b(1);               // term 2 (from 32)
+            if (c == 5) read_a(2);               // term 3 (from 48)
+            if (c == 8) read_b(2);               // term 4 (from 64)
+#pragma unroll
+            for (int m = 6 * c; m < 6 * c + 6; m++) {
+                const int term = m >> 4, mx = (m >> 2) & 3, my = m & 3;
+                const int pw = term == 0 ? 0 : term == 1 ? 1 : term == 2 ? 0 : term == 3 ? 2 : term == 4 ? 0 : 1;
+                const int pv = term == 0 ? 0 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 2 : 1;
+                acc[mx][my] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mx][pw], pb[my][pv], acc[mx][my], 0, 0, 0);
+            }
+            {
+                // split3 of two values at once: v_cvt_pk_bf16_f32 rounds both and leaves them packed as the planes
+                // want them (13 VALU instructions per pair, bias sum included)
+                const float v0 = raw[x][j], v1 = raw[x][j + 1];
+                add += v0;
+                add += v1;
+                const uint32_t ph = cvt_pk_bf16(v0, v1);
+                const float r0 = v0 - __uint_as_float(ph << 16), r1 = v1 - __uint_as_float(ph & 0xffff0000u);
+                const uint32_t pm = cvt_pk_bf16(r0, r1);
+                const float s0 = r0 - __uint_as_float(pm << 16), s1 = r1 - __uint_as_float(pm & 0xffff0000u);
+                pl[0][j >> 1] = ph;
+                pl[1][j >> 1] = pm;
+                pl[2][j >> 1] = cvt_pk_bf16(s0, s1);
+                // every use of the old values stays in front of the loads that refill their registers (instruction
+                // selection is free to put them behind otherwise; old and new value then need two registers, and the
+                // copies at the end of the loop body wait for every load in flight)
+                asm volatile("" : "+v"(add), "+v"(pl[0][j >> 1]), "+v"(pl[1][j >> 1]), "+v"(pl[2][j >> 1]) : : "memory");
+                raw[x][j] = S[(int64_t)j * DF_W + 32 * x];
+                raw[x][j + 1] = S[(int64_t)(j + 1) * DF_W + 32 * x];
+            }
+            if (j == 6) {
+                bsum[x] += (sum_bias && live) ? add : 0.f;
+                add = 0.f;
+#pragma unroll
+                for (int q = 0; q < 3; q++) dst[(x * 3 + q) * 64] = make_uint4(pl[q][0], pl[q][1], pl[q][2], pl[q][3]);
+            }
+            // one multiply, then at most three other instructions (a wave alone on its SIMD hides about 24 cycles
+            // of issue behind each 32-cycle multiply)
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // VALU
+                if (i == 1 || i == 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+                if (i == 2 || i == 4) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);   // DS write
+                if (i == 5) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);             // VMEM read
+                if (i == 0 || i == 5) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // VALU
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        split_to(nxt, raw, k + 1 < nsteps);    // (behind the end: planes that are never read, no bias share)
-        fetch(raw);
-#pragma unroll
-        for (int term = 0; term < 6; term++) {
-            const int pw = term == 0 ? 0 : term == 1 ? 1 : term == 2 ? 0 : term == 3 ? 2 : term == 4 ? 0 : 1;
-            const int pv = term == 0 ? 0 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 2 : 1;
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-#pragma unroll
-                for (int y = 0; y < 4; y++)
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[x][pw], pb[y][pv], acc[x][y], 0, 0, 0);
-        }
-        // schedule: one multiply, then a few of the split's VALU instructions, LDS and memory operations in between
-#pragma unroll
-        for (int i = 0; i < 96; i++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // VALU
-            if ((i & 7) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);   // VMEM read
-            if ((i & 7) == 4) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);   // DS write
-        }
+        S += 16 * DF_W;
         __syncthreads();      // everyone has read `cur` and written `nxt`
     };
     for (int64_t k = 0; k < nsteps; k += 2) {
@@ -1146,11 +1205,12 @@ __device__ __forceinline__ void dw_job_bf_shared(const float* A, const float* B,
 __global__ __launch_bounds__(256) void k_deform_dw_bf(DwArgs a)
 {
     int job, split;
-    if ((int)blockIdx.x < 7 * a.splits) {
-        job = blockIdx.x % 7;
-        split = blockIdx.x / 7;
+    const int wg = (int)blockIdx.x + a.first_block;
+    if (wg < 7 * a.splits) {
+        job = wg % 7;
+        split = wg / 7;
     } else {
-        const int r = blockIdx.x - 7 * a.splits;
+        const int r = wg - 7 * a.splits;
         job = 7 + r % 3;
         split = r / 3;
     }
@@ -1253,6 +1313,25 @@ __global__ __launch_bounds__(256) void k_deform_reduce(ReduceArgs a)
 }
 
 int64_t pad_points(int64_t n) { return (n + DF_PAD - 1) / DF_PAD * DF_PAD; }
+
+// one non-blocking side stream and two events per device (the light weight-gradient jobs run there)
+struct DeformSide { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static DeformSide* deform_side()
+{
+    static std::mutex mu;
+    static DeformSide side[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    DeformSide& d = side[dev];
+    if (!d.stream) {
+        if (hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess) { d.stream = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d.join, hipEventDisableTiming) != hipSuccess)
+            return nullptr;
+    }
+    return &d;
+}
 
 int dw_splits(int64_t n_pad, int* tiles_per_split)
 {
@@ -1444,10 +1523,28 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
         a.part = part;
         static const int shared_split = [] { const char* e = getenv("GFT_DEFORM_DW_SHARED"); return e ? atoi(e) : 1; }();
         a.shared_split = shared_split;
-        if (bf16_planes()) {
+        a.first_block = 0;
+        if (bf16_planes() && shared_split) {
+            // The heavy workgroups (7 x splits: one wave per SIMD, 96 KB of LDS) leave no room for a second one of their
+            // kind on a CU, and the light jobs (dW of layer 0, of the encoding rows of layer 5, of the heads: a fifth of
+            // the kernel's time when they run behind the heavy ones) need neither the LDS nor many registers: they go
+            // to a side stream as a launch of their own (no dynamic LDS) and run beside the heavy workgroups.
             static std::atomic<uint64_t> done{0};
             GFT_CHECK_HIP(gft_lds_opt_in(reinterpret_cast<const void*>(&k_deform_dw_bf), DW_SH_LDS, done));
-            hipLaunchKernelGGL(k_deform_dw_bf, dim3(DW_JOBS * splits), dim3(256), shared_split ? DW_SH_LDS : 0, s, a);
+            DeformSide* sd = deform_side();
+            if (!sd) return gft_fail("gft_deform_backward: no side stream");
+            GFT_CHECK_HIP(hipEventRecord(sd->fork, s));
+            GFT_CHECK_HIP(hipStreamWaitEvent(sd->stream, sd->fork, 0));
+            DwArgs light = a;
+            light.first_block = 7 * splits;
+            hipLaunchKernelGGL(k_deform_dw_bf, dim3(3 * splits), dim3(256), 0, sd->stream, light);
+            GFT_CHECK_HIP(hipGetLastError());
+            GFT_CHECK_HIP(hipEventRecord(sd->join, sd->stream));
+            hipLaunchKernelGGL(k_deform_dw_bf, dim3(7 * splits), dim3(256), DW_SH_LDS, s, a);
+            GFT_CHECK_HIP(hipGetLastError());
+            GFT_CHECK_HIP(hipStreamWaitEvent(s, sd->join, 0));
+        } else if (bf16_planes()) {
+            hipLaunchKernelGGL(k_deform_dw_bf, dim3(DW_JOBS * splits), dim3(256), 0, s, a);
         } else hipLaunchKernelGGL(k_deform_dw, dim3(DW_JOBS * splits), dim3(256), 0, s, a);
         GFT_CHECK_HIP(hipGetLastError());
     }
