@@ -482,11 +482,13 @@ __device__ __forceinline__ bf16x8 as_bf(const uint4& v)
     return r;
 }
 
-// acc[rt][ct] += (A[64 x 16 nchunks] W)^T; a_lane: this lane's row of plane 0 at k = 8 hh (bytes); wcur: chunk 0 of
-// `cur`, already loaded; `nxt`: the segment that follows (its chunk 0 is prefetched into wcur), or null.
+// acc[rt][ct] += (A[64 x 16 nchunks] W)^T; a_lane: this lane's row of plane 0 at k = 8 hh (bytes); w0, w1: chunks 0 and 1
+// of `cur`, already loaded; `nxt`: the segment that follows (its chunks 0 and 1 are prefetched into w0, w1), or null.
+// The weights come from L2 (every workgroup streams all of them): two chunks = 48 multiplies of lead.
 template <int NR, int NC, int NCOL>
 __device__ __forceinline__ void stream_gemm_bf(f32x16 (&acc)[NR][NC], const char* a_lane, int a_row_bytes, size_t a_plane_bytes,
-                                               int nchunks, const WSeg& cur, const WSeg* nxt, uint4 (&wcur)[3][NC])
+                                               int nchunks, const WSeg& cur, const WSeg* nxt, uint4 (&w0)[3][NC],
+                                               uint4 (&w1)[3][NC])
 {
     uint4 acur[3][NR];
 #pragma unroll
@@ -496,17 +498,16 @@ __device__ __forceinline__ void stream_gemm_bf(f32x16 (&acc)[NR][NC], const char
             acur[pl][rt] = *reinterpret_cast<const uint4*>(a_lane + pl * a_plane_bytes + (size_t)rt * 32 * a_row_bytes);
     for (int c = 0; c < nchunks; c++) {
         const bool last = c + 1 >= nchunks;
-        uint4 wnxt[3][NC], anxt[3][NR];
+        uint4 w2[3][NC], anxt[3][NR];
         // (unconditional loads from valid addresses: conditionally filled arrays end up in scratch)
-        if (!last) load_wbf<NC, NCOL>(wnxt, cur, c + 1);
-        else load_wbf<NC, NCOL>(wnxt, nxt ? *nxt : cur, 0);
+        if (c + 2 < nchunks) load_wbf<NC, NCOL>(w2, cur, c + 2);
+        else load_wbf<NC, NCOL>(w2, nxt ? *nxt : cur, c + 2 - nchunks);
         const int cn = last ? c : c + 1;
 #pragma unroll
         for (int pl = 0; pl < 3; pl++)
 #pragma unroll
             for (int rt = 0; rt < NR; rt++)
                 anxt[pl][rt] = *reinterpret_cast<const uint4*>(a_lane + pl * a_plane_bytes + (size_t)rt * 32 * a_row_bytes + cn * 32);
-        __builtin_amdgcn_sched_barrier(0);
         // weights are the MFMA's A operand, activations its B operand (point on the lane, see stream_gemm)
 #pragma unroll
         for (int term = 0; term < 6; term++) {
@@ -516,13 +517,21 @@ __device__ __forceinline__ void stream_gemm_bf(f32x16 (&acc)[NR][NC], const char
             for (int rt = 0; rt < NR; rt++)
 #pragma unroll
                 for (int ct = 0; ct < NC; ct++)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(wcur[pw][ct]), as_bf(acur[pa][rt]), acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w0[pw][ct]), as_bf(acur[pa][rt]), acc[rt][ct], 0, 0, 0);
+        }
+        // the loads of the chunks to come go between the multiplies, one per gap (issued in a run in front of them
+        // they hold the wave for their issue time with the matrix pipe idle)
+#pragma unroll
+        for (int i = 0; i < 3 * NC + 3 * NR; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+            if (i < 3 * NC) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   // VMEM read
+            else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                              // DS read
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pl = 0; pl < 3; pl++) {
 #pragma unroll
-            for (int ct = 0; ct < NC; ct++) wcur[pl][ct] = wnxt[pl][ct];
+            for (int ct = 0; ct < NC; ct++) { w0[pl][ct] = w1[pl][ct]; w1[pl][ct] = w2[pl][ct]; }
 #pragma unroll
             for (int rt = 0; rt < NR; rt++) acur[pl][rt] = anxt[pl][rt];
         }
@@ -554,8 +563,9 @@ __global__ __launch_bounds__(256) void k_deform_fwd_bf(FwdArgs a)
     const int n0 = wave * 64;
     const __bf16* bf = reinterpret_cast<const __bf16*>(a.packed + DF_PACKED_FLOATS);
     WSeg seg = wseg(bf, 0, n0 + li, hh);
-    uint4 wcur[3][2];
+    uint4 wcur[3][2], wnx1[3][2];
     load_wbf<2, DF_W>(wcur, seg, 0);
+    load_wbf<2, DF_W>(wnx1, seg, 1);
     for (int q = tid; q < DF_BIAS_FLOATS; q += 256) bL[q] = a.packed[DF_BIAS_BASE + q];
 
     // positional encoding (time_utils.py:24-53), split into the three planes; the fp32 values are saved for the
@@ -603,23 +613,23 @@ __global__ __launch_bounds__(256) void k_deform_fwd_bf(FwdArgs a)
         zero_acc(acc);
         if (l == 0) {
             const WSeg nx = wseg(bf, 1, n0 + li, hh);
-            stream_gemm_bf<2, 2, DF_W>(acc, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur);
+            stream_gemm_bf<2, 2, DF_W>(acc, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur, wnx1);
             seg = nx;
         } else {
             if (l == 5) {
                 // after layer 4 the encoding is concatenated in front (time_utils.py:112-113)
                 const WSeg nx = wseg(bf, 6, n0 + li, hh);
-                stream_gemm_bf<2, 2, DF_W>(acc, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur);
+                stream_gemm_bf<2, 2, DF_W>(acc, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur, wnx1);
                 seg = nx;
             }
             // segments: layers 1..4 -> 1..4, encoding rows of 5 -> 5, hidden rows of 5, 6, 7 -> 6, 7, 8
             const int s_next = l < 4 ? l + 1 : l == 4 ? 5 : l < 7 ? l + 2 : -1;
             if (s_next >= 0) {
                 const WSeg nx = wseg(bf, s_next, n0 + li, hh);
-                stream_gemm_bf<2, 2, DF_W>(acc, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, &nx, wcur);
+                stream_gemm_bf<2, 2, DF_W>(acc, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, &nx, wcur, wnx1);
                 seg = nx;
             } else {
-                stream_gemm_bf<2, 2, DF_W>(acc, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur);
+                stream_gemm_bf<2, 2, DF_W>(acc, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur, wnx1);
             }
         }
         float4 bv[2][4];
@@ -660,12 +670,13 @@ __global__ __launch_bounds__(256) void k_deform_fwd_bf(FwdArgs a)
     {
         const int ct = wave & 1, r0 = 32 * (wave >> 1);
         const WSeg hs = wseg(bf, 9, 32 * ct + li, hh);
-        uint4 hw[3][1];
+        uint4 hw[3][1], hw1[3][1];
         load_wbf<1, DF_HEAD>(hw, hs, 0);
+        load_wbf<1, DF_HEAD>(hw1, hs, 1);
         f32x16 hacc[1][1];
         zero_acc(hacc);
         stream_gemm_bf<1, 1, DF_HEAD>(hacc, hP + (size_t)(r0 + li) * DF_BH * 2 + 16 * hh, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, hs,
-                                      nullptr, hw);
+                                      nullptr, hw, hw1);
         const int64_t p = p0 + r0 + li;
         if (p < a.n) {
 #pragma unroll
@@ -778,8 +789,9 @@ __global__ __launch_bounds__(256) void k_deform_bwd_bf(BwdArgs a)
     const int n0 = wave * 64;
     const __bf16* bf = reinterpret_cast<const __bf16*>(a.packed + DF_PACKED_FLOATS);
     WSeg seg = wseg(bf, 10, n0 + li, hh);
-    uint4 wcur[3][2];
+    uint4 wcur[3][2], wnx1[3][2];
     load_wbf<2, DF_W>(wcur, seg, 0);
+    load_wbf<2, DF_W>(wnx1, seg, 1);
 
     // upstream gradients as the head's output tile: [d_sh (48) | d_xyz (3) | 0], in the first 64 columns
     for (int q = tid; q < 64 * (DF_HEAD / 4); q += 256) {
@@ -810,7 +822,7 @@ __global__ __launch_bounds__(256) void k_deform_bwd_bf(BwdArgs a)
     zero_acc(acc);
     {
         const WSeg nx = wseg(bf, 11, n0 + li, hh);
-        stream_gemm_bf<2, 2, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_HEAD / 16, seg, &nx, wcur);   // dh_7
+        stream_gemm_bf<2, 2, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_HEAD / 16, seg, &nx, wcur, wnx1);   // dh_7
         seg = nx;
     }
     for (int l = DF_D - 1; l >= 0; l--) {
@@ -841,10 +853,10 @@ __global__ __launch_bounds__(256) void k_deform_bwd_bf(BwdArgs a)
         // segment of W_l in the backward stream: 11 + (7 - l); the walk ends with W_1
         if (l > 1) {
             const WSeg nx = wseg(bf, 11 + (7 - l) + 1, n0 + li, hh);
-            stream_gemm_bf<2, 2, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, &nx, wcur);   // dh_{l-1}
+            stream_gemm_bf<2, 2, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, &nx, wcur, wnx1);   // dh_{l-1}
             seg = nx;
         } else {
-            stream_gemm_bf<2, 2, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur);
+            stream_gemm_bf<2, 2, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur, wnx1);
         }
     }
 }
