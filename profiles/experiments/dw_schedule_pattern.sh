@@ -1,7 +1,7 @@
 #!/bin/bash
 # compile k_deform.hip to gfx950 assembly and print the instruction mix of k_deform_dw_bf's main loop
 # (M = MFMA, . = VALU, G = global load, r / w = LDS read / write, | = s_waitcnt, B = s_barrier)
-cd /root/repo
+cd "$(dirname "$0")/../.."
 /opt/rocm/bin/hipcc $(python -c "from gftorf_amd import build; print(' '.join(build.flags()+build.FILE_FLAGS.get('k_deform.hip',[])))") $EXTRA --cuda-device-only -S gftorf_amd/csrc/k_deform.hip -o /tmp/k_deform_dev.s || exit 1
 awk '/^_ZN12_GLOBAL__N_114k_deform_dw_bfENS_6DwArgsE:/,/\.set _ZN12_GLOBAL__N_114k_deform_dw_bfENS_6DwArgsE.num_vgpr/' /tmp/k_deform_dev.s > /tmp/dw.s
 grep "num_vgpr\|num_agpr" /tmp/dw.s
