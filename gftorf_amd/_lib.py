@@ -133,7 +133,7 @@ EXPORTS = [
     "gft_det_partials_bytes", "gft_get_layout", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_forward_late", "gft_backward",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
-    "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi",
+    "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi", "gft_adam_step_rows",
     "gft_deform_inputs", "gft_deform_packed_bytes", "gft_deform_saved_bytes", "gft_deform_scratch_bytes", "gft_deform_pack",
     "gft_deform_forward", "gft_deform_backward",
     "gft_densify_stats", "gft_rows_rank_scratch_bytes", "gft_rows_rank", "gft_rows_gather",
@@ -177,6 +177,9 @@ def load():
     lib.gft_adam_step_multi.restype = C.c_int
     lib.gft_adam_step_multi.argtypes = [C.c_void_p, C.c_int32, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double,
                                         C.c_double]
+    lib.gft_adam_step_rows.restype = C.c_int
+    lib.gft_adam_step_rows.argtypes = [C.c_void_p, C.c_int32, C.POINTER(AdamTensor), C.c_int64, C.c_void_p, C.c_double, C.c_double,
+                                       C.c_double, C.c_double]
     lib.gft_deform_packed_bytes.restype = C.c_size_t
     lib.gft_deform_packed_bytes.argtypes = []
     lib.gft_deform_saved_bytes.restype = C.c_size_t

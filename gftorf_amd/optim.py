@@ -8,6 +8,12 @@ instead of torch's multi-tensor path (one kernel per arithmetic operation); cons
 edits the optimizer state in place (``scene/gaussian_model.py:456-540``), works unchanged.
 Use: replace ``torch.optim.Adam(l, lr=0.0, eps=1e-15)`` at ``scene/gaussian_model.py:274`` by
 ``gftorf_amd.FusedAdam(l, lr=0.0, eps=1e-15)``.
+
+Opt-in, not the reference's behaviour: ``step(visibility=mask)`` ("sparse Adam on visible
+Gaussians") updates only the rows ``mask`` selects in every parameter whose first dimension is ``mask.numel()`` -- with
+``visibility_filter`` of the iteration's render (``train.py:181``) that is the 10-20 % of the Gaussians that received a
+gradient at all.  The other rows keep parameter AND moments (a dense Adam lets their moments decay and still moves
+them by the decaying first moment); parameters of other shapes (the deformation network) take the dense step.
 """
 import torch
 
@@ -23,8 +29,15 @@ class FusedAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, **kw)
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, visibility=None):
         loss = None
+        rows = None
+        if visibility is not None:
+            if visibility.dim() != 1 or visibility.dtype not in (torch.bool, torch.uint8):
+                raise RuntimeError("gftorf_amd.FusedAdam: visibility must be a 1-D bool / uint8 tensor (one entry per Gaussian)")
+            rows = visibility.numel()
+            visibility = visibility.contiguous()
+            mask_u8 = visibility.view(torch.uint8) if visibility.dtype == torch.bool else visibility
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
@@ -56,14 +69,21 @@ class FusedAdam(torch.optim.Adam):
                 if not (m.is_contiguous() and v.is_contiguous()):
                     raise RuntimeError("gftorf_amd.FusedAdam: optimizer state must be contiguous")
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                buckets.setdefault((p.device, float(beta1), float(beta2), float(eps), float(wd)), []).append(
+                by_rows = rows is not None and p.dim() >= 1 and p.shape[0] == rows and rows > 0
+                if by_rows and visibility.device != p.device:
+                    raise RuntimeError("gftorf_amd.FusedAdam: visibility is on %s, the parameter on %s" % (visibility.device, p.device))
+                buckets.setdefault((p.device, float(beta1), float(beta2), float(eps), float(wd), by_rows), []).append(
                     (p, grad, m, v, float(lr), state["step"]))
-        for (dev, beta1, beta2, eps, wd), items in buckets.items():
+        for (dev, beta1, beta2, eps, wd, by_rows), items in buckets.items():
             torch._foreach_add_([it[5] for it in items], 1)
             tab = (_lib.AdamTensor * len(items))()
             for e, (p, g, m, v, lr, st) in zip(tab, items):
                 e.param, e.grad, e.exp_avg, e.exp_avg_sq, e.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
                 e.lr, e.step = lr, int(st)
             with _lib.on_device(dev):
-                _lib.check(lib.gft_adam_step_multi(_lib.raw_stream(dev), len(items), tab, beta1, beta2, eps, wd))
+                if by_rows:
+                    _lib.check(lib.gft_adam_step_rows(_lib.raw_stream(dev), len(items), tab, rows, mask_u8.data_ptr(), beta1, beta2,
+                                                      eps, wd))
+                else:
+                    _lib.check(lib.gft_adam_step_multi(_lib.raw_stream(dev), len(items), tab, beta1, beta2, eps, wd))
         return loss

@@ -47,6 +47,14 @@ typedef struct gft_adam_tensor {
 int gft_adam_step_multi(void* hip_stream, int32_t count, const gft_adam_tensor* tensors /*host*/, double beta1,
                         double beta2, double eps, double weight_decay);
 
+/* Opt-in, NOT the reference's optimizer (which is dense): the same update restricted to the rows of a mask -- SURVEY
+ * section 8(f) row 4, "sparse Adam on visible Gaussians".  Every tensor has `rows` rows (n = rows x floats per row);
+ * row r takes the step when row_mask[r] != 0 (device pointer, one byte per row: e.g. `radii > 0` of the iteration's
+ * render, reference train.py:181 `visibility_filter`); the other rows' parameter and moments are left as they are
+ * (their moments do not decay).  16-byte groups without a masked-in element are neither read nor written. */
+int gft_adam_step_rows(void* hip_stream, int32_t count, const gft_adam_tensor* tensors /*host*/, int64_t rows,
+                       const uint8_t* row_mask, double beta1, double beta2, double eps, double weight_decay);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,3 +73,49 @@ def test_fused_adam_state_is_torch_compatible(gpu):
     other = torch.optim.Adam(groups(gpu), lr=0.0, eps=1e-15)
     other.load_state_dict(sd)
     assert set(other.state[other.param_groups[0]["params"][0]].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frac", [0.0, 0.14, 1.0])
+def test_step_on_visible_rows_only(frac, gpu):
+    """Opt-in `step(visibility=mask)` (sparse Adam on visible Gaussians): rows of the mask take exactly
+    the dense step (bit for bit), the other rows keep parameter and moments; parameters that are not per-Gaussian (the
+    odd 7-element one) take the dense step."""
+    from gftorf_amd import FusedAdam
+    gen = torch.Generator().manual_seed(99)
+    vis = (torch.rand(1001, generator=gen) < frac).to(gpu)
+    dense, rows = FusedAdam(groups(gpu), lr=0.0, eps=1e-15), FusedAdam(groups(gpu), lr=0.0, eps=1e-15)
+    ggen = torch.Generator().manual_seed(5)
+    for it in range(4):
+        for gd, gr in zip(dense.param_groups, rows.param_groups):
+            pd, pr = gd["params"][0], gr["params"][0]
+            pd.grad = torch.randn(pd.shape, generator=ggen).to(gpu)
+            pr.grad = pd.grad.clone()
+            # the dense optimizer starts every step from the row-wise one's state: one step is compared at a time
+            pd.data.copy_(pr.data)
+            if pr in rows.state:
+                if pd not in dense.state:
+                    dense.state[pd] = {"step": rows.state[pr]["step"].clone(), "exp_avg": rows.state[pr]["exp_avg"].clone(),
+                                       "exp_avg_sq": rows.state[pr]["exp_avg_sq"].clone()}
+                for k in ("step", "exp_avg", "exp_avg_sq"):
+                    dense.state[pd][k].copy_(rows.state[pr][k])
+        old = [(g["params"][0].detach().clone(),
+                rows.state[g["params"][0]]["exp_avg"].clone() if g["params"][0] in rows.state else None,
+                rows.state[g["params"][0]]["exp_avg_sq"].clone() if g["params"][0] in rows.state else None) for g in rows.param_groups]
+        dense.step()
+        rows.step(visibility=vis if it % 2 == 0 else vis.to(torch.uint8))
+        for (p0, m0, v0), gd, gr in zip(old, dense.param_groups, rows.param_groups):
+            pd, pr = gd["params"][0], gr["params"][0]
+            sd, sr = dense.state[pd], rows.state[pr]
+            assert float(sd["step"]) == float(sr["step"]) == it + 1
+            m0 = torch.zeros_like(p0) if m0 is None else m0
+            v0 = torch.zeros_like(p0) if v0 is None else v0
+            if pr.shape[0] == 1001:
+                sel = vis.view(-1, *([1] * (pr.dim() - 1)))
+                want = (torch.where(sel, pd.detach(), p0), torch.where(sel, sd["exp_avg"], m0), torch.where(sel, sd["exp_avg_sq"], v0))
+            else:
+                want = (pd.detach(), sd["exp_avg"], sd["exp_avg_sq"])
+            for name, w, g in zip(("param", "exp_avg", "exp_avg_sq"), want, (pr.detach(), sr["exp_avg"], sr["exp_avg_sq"])):
+                assert torch.equal(w, g), "%s of group %s, step %d" % (name, gr["name"], it)
+    with pytest.raises(RuntimeError, match="visibility"):
+        rows.step(visibility=torch.zeros(1001, device=gpu))
