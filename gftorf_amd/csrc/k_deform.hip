@@ -9,7 +9,6 @@
 // weights are interleaved [k/4][n][4] for 16-byte loads), one 16-k chunk ahead of the multiply; the
 // weight-gradient kernel reads both operands straight from global memory.
 #include "gft_internal.h"
-#include <mutex>
 #include "gftorf_deform.h"
 
 #include <cstdio>
@@ -538,14 +537,19 @@ __device__ __forceinline__ void stream_gemm_bf(f32x16 (&acc)[NR][NC], const char
     }
 }
 
-// four consecutive fp32 values of one point -> 4 bf16 in each of the three planes
+// four consecutive fp32 values of one point -> 4 bf16 in each of the three planes (split3 of each value; two values
+// per v_cvt_pk_bf16_f32, which leaves them packed as the planes store them)
 __device__ __forceinline__ void store_split4(char* plane0, size_t plane_bytes, size_t byte_off, const float4& v)
 {
-    __bf16 h[4], m[4], l[4];
-    split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]);
-    split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
     uint2 ph, pm, pl;
-    __builtin_memcpy(&ph, h, 8); __builtin_memcpy(&pm, m, 8); __builtin_memcpy(&pl, l, 8);
+    ph.x = cvt_pk_bf16(v.x, v.y);
+    ph.y = cvt_pk_bf16(v.z, v.w);
+    const float r0 = v.x - __uint_as_float(ph.x << 16), r1 = v.y - __uint_as_float(ph.x & 0xffff0000u);
+    const float r2 = v.z - __uint_as_float(ph.y << 16), r3 = v.w - __uint_as_float(ph.y & 0xffff0000u);
+    pm.x = cvt_pk_bf16(r0, r1);
+    pm.y = cvt_pk_bf16(r2, r3);
+    pl.x = cvt_pk_bf16(r0 - __uint_as_float(pm.x << 16), r1 - __uint_as_float(pm.x & 0xffff0000u));
+    pl.y = cvt_pk_bf16(r2 - __uint_as_float(pm.y << 16), r3 - __uint_as_float(pm.y & 0xffff0000u));
     *reinterpret_cast<uint2*>(plane0 + byte_off) = ph;
     *reinterpret_cast<uint2*>(plane0 + plane_bytes + byte_off) = pm;
     *reinterpret_cast<uint2*>(plane0 + 2 * plane_bytes + byte_off) = pl;
@@ -877,7 +881,6 @@ constexpr int64_t DW_PART_FLOATS = DW_OFF_BIAS + DF_D * DF_W + DF_HEAD;
 struct DwArgs {
     int64_t n_pad;
     int tiles_per_split;    // 64-point tiles per split
-    int shared_split;       // heavy jobs: every operand block split once per workgroup, through LDS (dw_job_bf_shared)
     int splits;
     int first_block;        // the launch covers workgroups first_block ... of the job table (heavy jobs, then light ones)
     const float* emb; const float* acts; const float* dz; const float* dzh;
@@ -976,57 +979,94 @@ template <int TN, int TK, bool BIAS>
 __device__ __forceinline__ void dw_job_bf(const float* A, int lda, int n_base, const float* B, int ldb, int k_base, float* out,
                                           int out_ld, float* bias_out, bool write_bias, int64_t p_begin, int64_t p_end, int li, int hh)
 {
+    // The light jobs (first layer, encoding rows of layer 5, heads): every wave loads and splits the blocks of both
+    // operands it multiplies.  Same pipeline as dw_job_bf_shared, in registers: two steps of loads in flight (rawA /
+    // rawB), the planes of step k + 1 are split (two values per v_cvt_pk_bf16_f32) between the multiplies of step k,
+    // and every use of a raw value stays in front of the load that refills its register -- before, the copies at the
+    // end of the loop body waited for the loads of the step that had just been requested, every step.
+    constexpr int NB = TN + TK;                      // 32-column blocks of both operands
+    constexpr int NPAIR = NB * 4, NMUL = 6 * TN * TK;
     f32x16 acc[TN][TK];
     zero_acc(acc);
     float bsum[TN];
 #pragma unroll
     for (int x = 0; x < TN; x++) bsum[x] = 0.f;
+    const int64_t nsteps = (p_end - p_begin) / 16;   // a multiple of 4 (the ranges are multiples of 64 points)
     const float* Ap = A + (p_begin + 8 * hh) * lda + n_base + li;
     const float* Bp = B + (p_begin + 8 * hh) * ldb + k_base + li;
-    float ra[TN][8], rb[TK][8];                     // raw values of the next step
-    auto fetch = [&]() {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-#pragma unroll
-            for (int x = 0; x < TN; x++) ra[x][j] = Ap[(int64_t)j * lda + 32 * x];
-#pragma unroll
-            for (int y = 0; y < TK; y++) rb[y][j] = Bp[(int64_t)j * ldb + 32 * y];
-        }
+    const float* Ap_last = Ap + (nsteps > 0 ? nsteps - 1 : 0) * 16 * lda;
+    const float* Bp_last = Bp + (nsteps > 0 ? nsteps - 1 : 0) * 16 * ldb;
+    float rawA[NB][8], rawB[NB][8];
+    uint32_t plA[NB][3][4], plB[NB][3][4];           // the planes of an even / odd step: 8 bf16 per lane, block and plane
+    auto load1 = [&](int blk, int j) -> float {
+        return blk < TN ? Ap[(int64_t)j * lda + 32 * blk] : Bp[(int64_t)j * ldb + 32 * (blk - TN)];
+    };
+    auto advance = [&]() {
         Ap += 16 * lda;
         Bp += 16 * ldb;
+        Ap = Ap > Ap_last ? Ap_last : Ap;
+        Bp = Bp > Bp_last ? Bp_last : Bp;
     };
-    auto split8 = [&](const float (&v)[8], bf16x8 (&pl)[3]) {
+    auto fetch = [&](float (&raw)[NB][8]) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            __bf16 h, m, l;
-            split3(v[j], h, m, l);
-            pl[0][j] = h; pl[1][j] = m; pl[2][j] = l;
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int blk = 0; blk < NB; blk++) raw[blk][j] = load1(blk, j);
+        advance();
+    };
+    // splits the pair (j, j + 1) of block blk into the planes `pf`; refill: loads the pair of the step Ap / Bp point at
+    auto split_pair = [&](float (&raw)[NB][8], uint32_t (&pf)[NB][3][4], int blk, int j, bool live, bool refill) {
+        const float v0 = raw[blk][j], v1 = raw[blk][j + 1];
+        if (BIAS && blk < TN && write_bias) {          // (wave-uniform: the waves of the other column half leave the sums out)
+            bsum[blk < TN ? blk : 0] += live ? v0 : 0.f;
+            bsum[blk < TN ? blk : 0] += live ? v1 : 0.f;
+        }
+        const uint32_t ph = cvt_pk_bf16(v0, v1);
+        const float r0 = v0 - __uint_as_float(ph << 16), r1 = v1 - __uint_as_float(ph & 0xffff0000u);
+        const uint32_t pm = cvt_pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(pm << 16), s1 = r1 - __uint_as_float(pm & 0xffff0000u);
+        pf[blk][0][j >> 1] = ph;
+        pf[blk][1][j >> 1] = pm;
+        pf[blk][2][j >> 1] = cvt_pk_bf16(s0, s1);
+        if (refill) {
+            asm volatile("" : "+v"(pf[blk][0][j >> 1]), "+v"(pf[blk][1][j >> 1]), "+v"(pf[blk][2][j >> 1]), "+v"(bsum[blk < TN ? blk : 0])
+                         : : "memory");
+            raw[blk][j] = load1(blk, j);
+            raw[blk][j + 1] = load1(blk, j + 1);
         }
     };
-    if (p_begin < p_end) fetch();
-    for (int64_t p = p_begin; p < p_end; p += 16) {
-        bf16x8 pa[TN][3], pb[TK][3];
+    auto plane = [&](const uint32_t (&pl)[NB][3][4], int blk, int q) -> bf16x8 {
+        const uint4 v = make_uint4(pl[blk][q][0], pl[blk][q][1], pl[blk][q][2], pl[blk][q][3]);
+        return as_bf(v);
+    };
+    if (nsteps > 0) {
+        fetch(rawA);                                   // step 0
 #pragma unroll
-        for (int x = 0; x < TN; x++) {
-            if (BIAS && write_bias) {           // (wave-uniform: the waves of the other column half leave the sums out)
+        for (int c = 0; c < NPAIR; c++) split_pair(rawA, plA, c >> 2, (c & 3) * 2, true, false);
+        fetch(rawA);                                   // step 1
+        fetch(rawB);                                   // step 2; Ap / Bp now at step 3
+    }
+    // one step: multiplies with the planes `pu` of step k; `raw` holds step k + 1, is split into `pf` and refilled
+    // with step k + 3
+    auto step = [&](int64_t k, float (&raw)[NB][8], const uint32_t (&pu)[NB][3][4], uint32_t (&pf)[NB][3][4]) {
+        const bool live = k + 1 < nsteps;              // (behind the end: planes that are never used, no bias share)
 #pragma unroll
-                for (int j = 0; j < 8; j++) bsum[x] += ra[x][j];
+        for (int c = 0; c < NPAIR; c++) {
+#pragma unroll
+            for (int m = c * NMUL / NPAIR; m < (c + 1) * NMUL / NPAIR; m++) {
+                const int term = m / (TN * TK), x = (m / TK) % TN, y = m % TK;
+                const int pw = term == 0 ? 0 : term == 1 ? 1 : term == 2 ? 0 : term == 3 ? 2 : term == 4 ? 0 : 1;
+                const int pv = term == 0 ? 0 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 2 : 1;
+                acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(plane(pu, x, pw), plane(pu, TN + y, pv), acc[x][y], 0, 0, 0);
             }
-            split8(ra[x], pa[x]);
+            split_pair(raw, pf, c >> 2, (c & 3) * 2, live, true);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int y = 0; y < TK; y++) split8(rb[y], pb[y]);
-        if (p + 16 < p_end) fetch();                 // next step's loads fly during the multiplies
-#pragma unroll
-        for (int term = 0; term < 6; term++) {
-            const int pw = term == 0 ? 0 : term == 1 ? 1 : term == 2 ? 0 : term == 3 ? 2 : term == 4 ? 0 : 1;
-            const int pv = term == 0 ? 0 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 2 : 1;
-#pragma unroll
-            for (int x = 0; x < TN; x++)
-#pragma unroll
-                for (int y = 0; y < TK; y++)
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[x][pw], pb[y][pv], acc[x][y], 0, 0, 0);
-        }
+        advance();
+    };
+    for (int64_t k = 0; k < nsteps; k += 2) {
+        step(k, rawA, plA, plB);
+        step(k + 1, rawB, plB, plA);
     }
 #pragma unroll
     for (int x = 0; x < TN; x++)
@@ -1235,12 +1275,8 @@ __global__ __launch_bounds__(256) void k_deform_dw_bf(DwArgs a)
     if (job < 7) {
         const int l = 7 - job;
         extern __shared__ float4 df_lds[];
-        if (a.shared_split)
-            dw_job_bf_shared(a.dz + l * plane, a.acts + (l - 1) * plane, part + DW_OFF_L(l), part + DW_OFF_BIAS + l * DF_W, p_begin,
-                             p_end, wave, lane, reinterpret_cast<char*>(df_lds));
-        else
-            dw_job_bf<4, 4, true>(a.dz + l * plane, DF_W, 128 * (wave & 1), a.acts + (l - 1) * plane, DF_W, 128 * (wave >> 1),
-                                  part + DW_OFF_L(l), DF_W, part + DW_OFF_BIAS + l * DF_W, (wave >> 1) == 0, p_begin, p_end, li, hh);
+        dw_job_bf_shared(a.dz + l * plane, a.acts + (l - 1) * plane, part + DW_OFF_L(l), part + DW_OFF_BIAS + l * DF_W, p_begin,
+                         p_end, wave, lane, reinterpret_cast<char*>(df_lds));
     } else if (job == 7) {
         dw_job_bf<2, 3, true>(a.dz, DF_W, 64 * wave, a.emb, DF_EMB, 0, part + DW_OFF_L0, DF_EMB, part + DW_OFF_BIAS, true, p_begin,
                               p_end, li, hh);
@@ -1325,25 +1361,6 @@ __global__ __launch_bounds__(256) void k_deform_reduce(ReduceArgs a)
 }
 
 int64_t pad_points(int64_t n) { return (n + DF_PAD - 1) / DF_PAD * DF_PAD; }
-
-// one non-blocking side stream and two events per device (the light weight-gradient jobs run there)
-struct DeformSide { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-static DeformSide* deform_side()
-{
-    static std::mutex mu;
-    static DeformSide side[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    DeformSide& d = side[dev];
-    if (!d.stream) {
-        if (hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess) { d.stream = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&d.join, hipEventDisableTiming) != hipSuccess)
-            return nullptr;
-    }
-    return &d;
-}
 
 int dw_splits(int64_t n_pad, int* tiles_per_split)
 {
@@ -1533,30 +1550,20 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
         a.splits = splits;
         a.emb = emb; a.acts = acts; a.dz = dz; a.dzh = dzh;
         a.part = part;
-        static const int shared_split = [] { const char* e = getenv("GFT_DEFORM_DW_SHARED"); return e ? atoi(e) : 1; }();
-        a.shared_split = shared_split;
         a.first_block = 0;
-        if (bf16_planes() && shared_split) {
-            // The heavy workgroups (7 x splits: one wave per SIMD, 96 KB of LDS) leave no room for a second one of their
-            // kind on a CU, and the light jobs (dW of layer 0, of the encoding rows of layer 5, of the heads: a fifth of
-            // the kernel's time when they run behind the heavy ones) need neither the LDS nor many registers: they go
-            // to a side stream as a launch of their own (no dynamic LDS) and run beside the heavy workgroups.
+        if (bf16_planes()) {
+            // Two launches of the same kernel: the hidden-layer jobs (7 x splits workgroups, one wave per SIMD, 96 KB
+            // of LDS), then the light jobs (dW of layer 0, of the encoding rows of layer 5, of the heads), which need no
+            // LDS and get the CUs to themselves.  Measured at 300 k points: 1.21 + 0.29 ms back to back; with the
+            // light jobs on a side stream beside the heavy ones 1.53 ms (the two share the CUs' issue slots and the
+            // heavy waves' hand-placed schedule has no room for a guest), light first 1.54 ms.
             static std::atomic<uint64_t> done{0};
             GFT_CHECK_HIP(gft_lds_opt_in(reinterpret_cast<const void*>(&k_deform_dw_bf), DW_SH_LDS, done));
-            DeformSide* sd = deform_side();
-            if (!sd) return gft_fail("gft_deform_backward: no side stream");
-            GFT_CHECK_HIP(hipEventRecord(sd->fork, s));
-            GFT_CHECK_HIP(hipStreamWaitEvent(sd->stream, sd->fork, 0));
-            DwArgs light = a;
-            light.first_block = 7 * splits;
-            hipLaunchKernelGGL(k_deform_dw_bf, dim3(3 * splits), dim3(256), 0, sd->stream, light);
-            GFT_CHECK_HIP(hipGetLastError());
-            GFT_CHECK_HIP(hipEventRecord(sd->join, sd->stream));
             hipLaunchKernelGGL(k_deform_dw_bf, dim3(7 * splits), dim3(256), DW_SH_LDS, s, a);
             GFT_CHECK_HIP(hipGetLastError());
-            GFT_CHECK_HIP(hipStreamWaitEvent(s, sd->join, 0));
-        } else if (bf16_planes()) {
-            hipLaunchKernelGGL(k_deform_dw_bf, dim3(DW_JOBS * splits), dim3(256), 0, s, a);
+            DwArgs light = a;
+            light.first_block = 7 * splits;
+            hipLaunchKernelGGL(k_deform_dw_bf, dim3(3 * splits), dim3(256), 0, s, light);
         } else hipLaunchKernelGGL(k_deform_dw, dim3(DW_JOBS * splits), dim3(256), 0, s, a);
         GFT_CHECK_HIP(hipGetLastError());
     }
