@@ -555,8 +555,13 @@ __device__ __forceinline__ void store_split4(char* plane0, size_t plane_bytes, s
     *reinterpret_cast<uint2*>(plane0 + 2 * plane_bytes + byte_off) = pl;
 }
 
+// DF_FWD_WAVES waves per workgroup: 4 (a wave owns 64 output columns, one wave per SIMD) or 8 (32 columns, two waves per
+// SIMD: the other wave multiplies while one waits for its weights or its LDS reads; 256 registers per wave).  Measured at
+// 300 k points: 2.15-2.2 ms with 4, 1.96-2.02 ms with 8.
+constexpr int DF_FWD_WAVES = 8;
+constexpr int DF_FWD_NC = 8 / DF_FWD_WAVES;            // 32-column tiles per wave
 template <bool SAVE>
-__global__ __launch_bounds__(256) void k_deform_fwd_bf(FwdArgs a)
+__global__ __launch_bounds__(64 * DF_FWD_WAVES) void k_deform_fwd_bf(FwdArgs a)
 {
     extern __shared__ float4 df_lds[];
     char* hP = reinterpret_cast<char*>(df_lds);                  // activation planes [3][64][264] bf16
@@ -564,13 +569,14 @@ __global__ __launch_bounds__(256) void k_deform_fwd_bf(FwdArgs a)
     float* bL = reinterpret_cast<float*>(eP + 3 * DF_BF_ENC_PLANE);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * 64;
-    const int n0 = wave * 64;
+    constexpr int NC = DF_FWD_NC, NT = 64 * DF_FWD_WAVES;
+    const int n0 = wave * 32 * NC;
     const __bf16* bf = reinterpret_cast<const __bf16*>(a.packed + DF_PACKED_FLOATS);
     WSeg seg = wseg(bf, 0, n0 + li, hh);
-    uint4 wcur[3][2], wnx1[3][2];
-    load_wbf<2, DF_W>(wcur, seg, 0);
-    load_wbf<2, DF_W>(wnx1, seg, 1);
-    for (int q = tid; q < DF_BIAS_FLOATS; q += 256) bL[q] = a.packed[DF_BIAS_BASE + q];
+    uint4 wcur[3][NC], wnx1[3][NC];
+    load_wbf<NC, DF_W>(wcur, seg, 0);
+    load_wbf<NC, DF_W>(wnx1, seg, 1);
+    for (int q = tid; q < DF_BIAS_FLOATS; q += NT) bL[q] = a.packed[DF_BIAS_BASE + q];
 
     // positional encoding (time_utils.py:24-53), split into the three planes; the fp32 values are saved for the
     // weight-gradient GEMMs
@@ -586,7 +592,8 @@ __global__ __launch_bounds__(256) void k_deform_fwd_bf(FwdArgs a)
             e[DF_BF_ENC_PLANE] = l;
             if (SAVE) a.emb[p * DF_EMB + col] = v;
         };
-        if (grp < 3) {
+        if (grp > 3) {
+        } else if (grp < 3) {
             const float v = p < a.n ? a.xyz[3 * p + grp] : 0.f;
             put(grp, v);
             for (int f = 0; f < a.xm; f++) {
@@ -612,33 +619,33 @@ __global__ __launch_bounds__(256) void k_deform_fwd_bf(FwdArgs a)
 
     const char* h_lane = hP + (size_t)li * DF_BH * 2 + 16 * hh;
     const char* e_lane = eP + (size_t)li * DF_BE * 2 + 16 * hh;
-    f32x16 acc[2][2];
+    f32x16 acc[2][NC];
     for (int l = 0; l < DF_D; l++) {
         zero_acc(acc);
         if (l == 0) {
             const WSeg nx = wseg(bf, 1, n0 + li, hh);
-            stream_gemm_bf<2, 2, DF_W>(acc, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur, wnx1);
+            stream_gemm_bf<2, NC, DF_W>(acc, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur, wnx1);
             seg = nx;
         } else {
             if (l == 5) {
                 // after layer 4 the encoding is concatenated in front (time_utils.py:112-113)
                 const WSeg nx = wseg(bf, 6, n0 + li, hh);
-                stream_gemm_bf<2, 2, DF_W>(acc, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur, wnx1);
+                stream_gemm_bf<2, NC, DF_W>(acc, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur, wnx1);
                 seg = nx;
             }
             // segments: layers 1..4 -> 1..4, encoding rows of 5 -> 5, hidden rows of 5, 6, 7 -> 6, 7, 8
             const int s_next = l < 4 ? l + 1 : l == 4 ? 5 : l < 7 ? l + 2 : -1;
             if (s_next >= 0) {
                 const WSeg nx = wseg(bf, s_next, n0 + li, hh);
-                stream_gemm_bf<2, 2, DF_W>(acc, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, &nx, wcur, wnx1);
+                stream_gemm_bf<2, NC, DF_W>(acc, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, &nx, wcur, wnx1);
                 seg = nx;
             } else {
-                stream_gemm_bf<2, 2, DF_W>(acc, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur, wnx1);
+                stream_gemm_bf<2, NC, DF_W>(acc, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur, wnx1);
             }
         }
-        float4 bv[2][4];
+        float4 bv[NC][4];
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++)
+        for (int ct = 0; ct < NC; ct++)
 #pragma unroll
             for (int g = 0; g < 4; g++)
                 bv[ct][g] = *reinterpret_cast<const float4*>(bL + l * DF_W + n0 + 32 * ct + acc_col4(g, hh));
@@ -646,7 +653,7 @@ __global__ __launch_bounds__(256) void k_deform_fwd_bf(FwdArgs a)
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-            for (int ct = 0; ct < 2; ct++) {
+            for (int ct = 0; ct < NC; ct++) {
                 uint32_t bits = 0;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
@@ -665,13 +672,13 @@ __global__ __launch_bounds__(256) void k_deform_fwd_bf(FwdArgs a)
                 }
                 if (SAVE) {
                     bits |= (uint32_t)__shfl_xor((int)bits, 32);
-                    if (hh == 0) a.signs[((int64_t)l * a.n_pad + p0 + 32 * rt + li) * DF_SIGN_WORDS + 2 * wave + ct] = bits;
+                    if (hh == 0) a.signs[((int64_t)l * a.n_pad + p0 + 32 * rt + li) * DF_SIGN_WORDS + NC * wave + ct] = bits;
                 }
             }
         __syncthreads();
     }
-    // heads: 64 columns, one 32 x 32 tile per wave
-    {
+    // heads: 64 columns, one 32 x 32 tile per wave (of the first four)
+    if (wave < 4) {
         const int ct = wave & 1, r0 = 32 * (wave >> 1);
         const WSeg hs = wseg(bf, 9, 32 * ct + li, hh);
         uint4 hw[3][1], hw1[3][1];
@@ -784,21 +791,24 @@ __global__ __launch_bounds__(256) void k_deform_bwd(BwdArgs a)
 // as hi / mid / lo planes and the weights from the bf16 copy of the backward stream
 constexpr size_t DF_BWD_BF_LDS = 3 * DF_BF_ACT_PLANE;   // 101376
 
-__global__ __launch_bounds__(256) void k_deform_bwd_bf(BwdArgs a)
+constexpr int DF_BWD_WAVES = 4;                        // as DF_FWD_WAVES; measured at 300 k points: 1.64 ms with 4, 1.76 ms with 8
+constexpr int DF_BWD_NC = 8 / DF_BWD_WAVES;
+__global__ __launch_bounds__(64 * DF_BWD_WAVES) void k_deform_bwd_bf(BwdArgs a)
 {
     extern __shared__ float4 df_lds[];
     char* gP = reinterpret_cast<char*>(df_lds);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * 64;
-    const int n0 = wave * 64;
+    constexpr int NC = DF_BWD_NC, NT = 64 * DF_BWD_WAVES;
+    const int n0 = wave * 32 * NC;
     const __bf16* bf = reinterpret_cast<const __bf16*>(a.packed + DF_PACKED_FLOATS);
     WSeg seg = wseg(bf, 10, n0 + li, hh);
-    uint4 wcur[3][2], wnx1[3][2];
-    load_wbf<2, DF_W>(wcur, seg, 0);
-    load_wbf<2, DF_W>(wnx1, seg, 1);
+    uint4 wcur[3][NC], wnx1[3][NC];
+    load_wbf<NC, DF_W>(wcur, seg, 0);
+    load_wbf<NC, DF_W>(wnx1, seg, 1);
 
     // upstream gradients as the head's output tile: [d_sh (48) | d_xyz (3) | 0], in the first 64 columns
-    for (int q = tid; q < 64 * (DF_HEAD / 4); q += 256) {
+    for (int q = tid; q < 64 * (DF_HEAD / 4); q += NT) {
         const int row = q >> 4, col = (q & 15) * 4;
         const int64_t p = p0 + row;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -815,18 +825,20 @@ __global__ __launch_bounds__(256) void k_deform_bwd_bf(BwdArgs a)
     __syncthreads();
 
     const char* g_lane = gP + (size_t)li * DF_BH * 2 + 16 * hh;
-    f32x16 acc[2][2];
-    uint2 sg[2];
+    f32x16 acc[2][NC];
+    uint32_t sg[2][NC];
     auto load_signs = [&](int l) {
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
-            sg[rt] = *reinterpret_cast<const uint2*>(a.signs + ((int64_t)l * a.n_pad + p0 + 32 * rt + li) * DF_SIGN_WORDS + 2 * wave);
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++)
+                sg[rt][ct] = a.signs[((int64_t)l * a.n_pad + p0 + 32 * rt + li) * DF_SIGN_WORDS + NC * wave + ct];
     };
     load_signs(DF_D - 1);
     zero_acc(acc);
     {
         const WSeg nx = wseg(bf, 11, n0 + li, hh);
-        stream_gemm_bf<2, 2, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_HEAD / 16, seg, &nx, wcur, wnx1);   // dh_7
+        stream_gemm_bf<2, NC, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_HEAD / 16, seg, &nx, wcur, wnx1);   // dh_7
         seg = nx;
     }
     for (int l = DF_D - 1; l >= 0; l--) {
@@ -834,9 +846,9 @@ __global__ __launch_bounds__(256) void k_deform_bwd_bf(BwdArgs a)
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-            for (int ct = 0; ct < 2; ct++) {
+            for (int ct = 0; ct < NC; ct++) {
                 const int row = 32 * rt + li;
-                const uint32_t word = ct == 0 ? sg[rt].x : sg[rt].y;
+                const uint32_t word = sg[rt][ct];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const int col = n0 + 32 * ct + acc_col4(g, hh);
@@ -857,10 +869,10 @@ __global__ __launch_bounds__(256) void k_deform_bwd_bf(BwdArgs a)
         // segment of W_l in the backward stream: 11 + (7 - l); the walk ends with W_1
         if (l > 1) {
             const WSeg nx = wseg(bf, 11 + (7 - l) + 1, n0 + li, hh);
-            stream_gemm_bf<2, 2, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, &nx, wcur, wnx1);   // dh_{l-1}
+            stream_gemm_bf<2, NC, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, &nx, wcur, wnx1);   // dh_{l-1}
             seg = nx;
         } else {
-            stream_gemm_bf<2, 2, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur, wnx1);
+            stream_gemm_bf<2, NC, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur, wnx1);
         }
     }
 }
@@ -1481,8 +1493,8 @@ extern "C" int gft_deform_forward(void* hip_stream, int xyz_multires, int t_mult
     // all padded rows are computed and saved: the weight-gradient GEMMs multiply them (by zero gradients)
     const dim3 grid((unsigned)(a.n_pad / (32 * DF_NR_FWD)));
     if (bf16_planes()) {
-        if (saved) hipLaunchKernelGGL(k_deform_fwd_bf<true>, grid, dim3(256), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);
-        else hipLaunchKernelGGL(k_deform_fwd_bf<false>, grid, dim3(256), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);
+        if (saved) hipLaunchKernelGGL(k_deform_fwd_bf<true>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);
+        else hipLaunchKernelGGL(k_deform_fwd_bf<false>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);
     } else {
         if (saved) hipLaunchKernelGGL(k_deform_fwd<true>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
         else hipLaunchKernelGGL(k_deform_fwd<false>, grid, dim3(256), DF_FWD_LDS, (hipStream_t)hip_stream, a);
@@ -1537,7 +1549,7 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
         a.signs = reinterpret_cast<const uint32_t*>(acts + n_pad * DF_D * DF_W);
         a.g_dxyz = g_d_xyz; a.g_dsh = g_d_sh;
         a.dz = dz; a.dzh = dzh;
-        if (bf16_planes()) hipLaunchKernelGGL(k_deform_bwd_bf, dim3((unsigned)(n_pad / 64)), dim3(256), DF_BWD_BF_LDS, s, a);
+        if (bf16_planes()) hipLaunchKernelGGL(k_deform_bwd_bf, dim3((unsigned)(n_pad / 64)), dim3(64 * DF_BWD_WAVES), DF_BWD_BF_LDS, s, a);
         else hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(n_pad / (32 * DF_NR_BWD))), dim3(256), DF_BWD_LDS, s, a);
         GFT_CHECK_HIP(hipGetLastError());
     }
