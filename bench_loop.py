@@ -18,7 +18,6 @@ FusedAdam); the losses and activations are stock torch, as in the reference.
 """
 import math
 import random
-import time
 
 import numpy as np
 

@@ -19,7 +19,6 @@ calls (``gaussian_renderer/__init__.py:29-34``).
 import torch
 import torch.nn as nn
 
-from . import _lib
 from .api import (_scalar, native_forward, native_backward, run_backward)
 
 _side_streams = {}
