@@ -227,15 +227,13 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
         uint64_t m = to_sgpr(wave_ballot(reach));
         __syncthreads();
 
-        while (m) {
-            const int j = (int)__builtin_ctzll(m);
-            m &= m - 1;
-            const float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
+        // one list entry (splat j of the batch, its two LDS records already in registers)
+        auto blend = [&](const int j, const float4& a0, const float4& a1, const float4& b0, const float4& b1) {
             const float dx = a0.x - pxf, dy = a0.y - pyf;
             const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
             const float alpha = fminf(0.99f, a1.y * gft_exp(power));
             const unsigned long long vm = wave_ballot(!(power > 0.0f)) & wave_ballot(!(alpha < 1.0f / 255.0f)) & ~done_m;
-            if (vm == 0ull) continue;                        // wave-uniform skip
+            if (vm == 0ull) return;                          // wave-uniform skip
             const float test_T = T * (1 - alpha);
             const unsigned long long tm = vm & wave_ballot(test_T < 0.0001f);   // saturated here: splat not blended
             const unsigned long long cm = vm & ~tm;
@@ -243,7 +241,6 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
             if (cm != 0ull) {
                 // Branch-free blend: lanes that do not take this splat use alpha = 0, which adds
                 // exact zeros and leaves T unchanged.
-                const float4 b0 = sB[2 * j], b1 = sB[2 * j + 1];
                 const float al = sel_mask(cm, alpha, 0.f);
                 const float w = al * T;
                 const float w_p = w * T;
@@ -274,7 +271,27 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
                                  : "+v"(cnt), "=&s"(m0_keep) : "s"(pc), "s"(j));
                 }
             }
-            if (done_m == ~0ull) break;
+        };
+        // The records of the NEXT entry are read from LDS while the current one is blended (a wave's time per entry is its
+        // dependent chain: LDS read -> alpha -> test -> LDS read -> sums; two entries alternate between two register sets)
+        if (m) {
+            int j0 = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            float4 p0 = sA[2 * j0], p1 = sA[2 * j0 + 1], q0 = sB[2 * j0], q1 = sB[2 * j0 + 1];
+            for (;;) {
+                const bool more1 = m != 0;
+                int j1 = j0;
+                if (more1) { j1 = (int)__builtin_ctzll(m); m &= m - 1; }
+                const float4 r0 = sA[2 * j1], r1 = sA[2 * j1 + 1], t0 = sB[2 * j1], t1 = sB[2 * j1 + 1];
+                blend(j0, p0, p1, q0, q1);
+                if (!more1 || done_m == ~0ull) break;
+                const bool more0 = m != 0;
+                j0 = j1;
+                if (more0) { j0 = (int)__builtin_ctzll(m); m &= m - 1; }
+                p0 = sA[2 * j0]; p1 = sA[2 * j0 + 1]; q0 = sB[2 * j0]; q1 = sB[2 * j0 + 1];
+                blend(j1, r0, r1, t0, t1);
+                if (!more0 || done_m == ~0ull) break;
+            }
         }
         if (cnt) atomicAdd(&a.pixels[my_id], (float)cnt);
     }
