@@ -602,9 +602,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
         __syncthreads();
 
         // alpha of splat j for this pixel and whether the pixel blended it in the forward
-        auto eval = [&](int j, float4& a0, float4& a1, float& dx, float& dy, float& G, float& alpha) -> bool {
+        auto eval = [&](int j, const float4& a0, const float4& a1, float& dx, float& dy, float& G, float& alpha) -> bool {
             const int c = hi - 1 - j;               // list position of this splat
-            a0 = sA[2 * j]; a1 = sA[2 * j + 1];
             dx = a0.x - pxf; dy = a0.y - pyf;
             const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
             G = gft_exp(power);
@@ -615,10 +614,9 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
         // the same arithmetic; lanes that do not blend this splat use alpha = G = 0, which leaves T and
         // the two recurrences unchanged (rcp(1) == 1) and makes all 15 partials exactly zero.
         // accumulator row = {dcolor[3], ddist | sum E dx, sum E dy, dconic.xy | XR, XI, X2, XQ | dconic.w, dopacity, dndc, -}
-        auto blend = [&](int j, const float4& a0, const float4& a1, float dx, float dy, float G, float alpha,
-                         bool contrib) {
+        auto blend = [&](int j, const float4& a0, const float4& a1, const float4& b0, const float4& b1, float dx, float dy,
+                         float G, float alpha, bool contrib) {
             v2f L01, L23, L45, L67, H01, H23, H45, H67;
-            const float4 b0 = sB[2 * j], b1 = sB[2 * j + 1];
             const float al = contrib ? alpha : 0.f;
             const float Gm = contrib ? G : 0.f;
             const float one_m_a = 1.f - al;
@@ -675,14 +673,31 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
                 atomicAdd(&a.acc[(size_t)sId[j] * GFT_ACC_STRIDE + (lane >> 2)], tot);
         };
 
-        while (m) {
-            const int j = (int)__builtin_ctzll(m);
-            m &= m - 1;
-            float4 a0, a1;
+        // (as in k_render_fwd: the next entry's LDS records are read while the current one is worked on)
+        auto entry = [&](int j, const float4& a0, const float4& a1, const float4& b0, const float4& b1) {
             float dx, dy, G, alpha;
             const bool contrib = eval(j, a0, a1, dx, dy, G, alpha);
-            if (wave_ballot(contrib) == 0ull) continue;   // wave-uniform skip
-            blend(j, a0, a1, dx, dy, G, alpha, contrib);
+            if (wave_ballot(contrib) == 0ull) return;     // wave-uniform skip
+            blend(j, a0, a1, b0, b1, dx, dy, G, alpha, contrib);
+        };
+        if (m) {
+            int j0 = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            float4 p0 = sA[2 * j0], p1 = sA[2 * j0 + 1], q0 = sB[2 * j0], q1 = sB[2 * j0 + 1];
+            for (;;) {
+                const bool more1 = m != 0;
+                int j1 = j0;
+                if (more1) { j1 = (int)__builtin_ctzll(m); m &= m - 1; }
+                const float4 r0 = sA[2 * j1], r1 = sA[2 * j1 + 1], t0 = sB[2 * j1], t1 = sB[2 * j1 + 1];
+                entry(j0, p0, p1, q0, q1);
+                if (!more1) break;
+                const bool more0 = m != 0;
+                j0 = j1;
+                if (more0) { j0 = (int)__builtin_ctzll(m); m &= m - 1; }
+                p0 = sA[2 * j0]; p1 = sA[2 * j0 + 1]; q0 = sB[2 * j0]; q1 = sB[2 * j0 + 1];
+                entry(j1, r0, r1, t0, t1);
+                if (!more0) break;
+            }
         }
         // (issuing two splats per iteration in one basic block so that the scheduler can overlap their
         // exp / rcp / DPP latencies was measured: 214 vs 198 us, dropped)
