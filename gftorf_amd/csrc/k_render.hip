@@ -202,6 +202,10 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
         done_m = wave_ballot(was_done);
     }
 
+    // (zref and a resumed blend state are waited for HERE: left to their first use the waits sit inside the entry loop,
+    // where the in-order counter of outstanding memory operations makes them wait for the previous batch's pixel-count
+    // atomics and snapshot stores as well)
+    asm volatile("" : : "v"(zref), "v"(T), "v"(C0), "v"(WD1));
     for (int base = begin; base < total; base += RB) {
         // all 64 pixels finished -> the rest of the list is never used
         if (done_m == ~0ull) break;
