@@ -618,8 +618,8 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
         // the same arithmetic; lanes that do not blend this splat use alpha = G = 0, which leaves T and
         // the two recurrences unchanged (rcp(1) == 1) and makes all 15 partials exactly zero.
         // accumulator row = {dcolor[3], ddist | sum E dx, sum E dy, dconic.xy | XR, XI, X2, XQ | dconic.w, dopacity, dndc, -}
-        auto blend = [&](int j, const float4& a0, const float4& a1, const float4& b0, const float4& b1, float dx, float dy,
-                         float G, float alpha, bool contrib) {
+        auto blend = [&](int j, uint32_t gid, const float4& a0, const float4& a1, const float4& b0, const float4& b1, float dx,
+                         float dy, float G, float alpha, bool contrib) {
             v2f L01, L23, L45, L67, H01, H23, H45, H67;
             const float al = contrib ? alpha : 0.f;
             const float Gm = contrib ? G : 0.f;
@@ -674,32 +674,37 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
                 if ((lane & 3) == 0 && lane < 4 * GFT_NUM_ACC)
                     a.det[((size_t)phys((uint32_t)(hi - 1 - j)) * 4 + quad) * GFT_ACC_STRIDE + (lane >> 2)] = tot;
             } else if ((lane & 3) == 0 && lane < 4 * GFT_NUM_ACC && tot != 0.f)
-                atomicAdd(&a.acc[(size_t)sId[j] * GFT_ACC_STRIDE + (lane >> 2)], tot);
+                atomicAdd(&a.acc[(size_t)gid * GFT_ACC_STRIDE + (lane >> 2)], tot);
         };
 
         // (as in k_render_fwd: the next entry's LDS records are read while the current one is worked on)
-        auto entry = [&](int j, const float4& a0, const float4& a1, const float4& b0, const float4& b1) {
+        // (the Gaussian's id for the accumulator row's address comes along: read where it is needed, every entry waits
+        // for that LDS read in front of its atomics)
+        auto entry = [&](int j, uint32_t gid, const float4& a0, const float4& a1, const float4& b0, const float4& b1) {
             float dx, dy, G, alpha;
             const bool contrib = eval(j, a0, a1, dx, dy, G, alpha);
             if (wave_ballot(contrib) == 0ull) return;     // wave-uniform skip
-            blend(j, a0, a1, b0, b1, dx, dy, G, alpha, contrib);
+            blend(j, gid, a0, a1, b0, b1, dx, dy, G, alpha, contrib);
         };
         if (m) {
             int j0 = (int)__builtin_ctzll(m);
             m &= m - 1;
             float4 p0 = sA[2 * j0], p1 = sA[2 * j0 + 1], q0 = sB[2 * j0], q1 = sB[2 * j0 + 1];
+            uint32_t g0 = sId[j0];
             for (;;) {
                 const bool more1 = m != 0;
                 int j1 = j0;
                 if (more1) { j1 = (int)__builtin_ctzll(m); m &= m - 1; }
                 const float4 r0 = sA[2 * j1], r1 = sA[2 * j1 + 1], t0 = sB[2 * j1], t1 = sB[2 * j1 + 1];
-                entry(j0, p0, p1, q0, q1);
+                const uint32_t g1 = sId[j1];
+                entry(j0, g0, p0, p1, q0, q1);
                 if (!more1) break;
                 const bool more0 = m != 0;
                 j0 = j1;
                 if (more0) { j0 = (int)__builtin_ctzll(m); m &= m - 1; }
                 p0 = sA[2 * j0]; p1 = sA[2 * j0 + 1]; q0 = sB[2 * j0]; q1 = sB[2 * j0 + 1];
-                entry(j1, r0, r1, t0, t1);
+                g0 = sId[j0];
+                entry(j1, g1, r0, r1, t0, t1);
                 if (!more0) break;
             }
         }
