@@ -774,8 +774,21 @@ __device__ __forceinline__ bool gaussian_blended(const PreBwdArgs& a, int idx)
            (a3.x != 0.f) | (a3.y != 0.f) | (a3.z != 0.f);
 }
 
-__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
+// COMMON = the call a training loop makes (SH colour and SH phasor of 16 coefficients, scales + rotations, the forward's
+// direction-gradient record, whole gradient tensors written): the switches below are constants there and the other paths
+// are not compiled in; every other combination runs the general kernel.
+template <bool COMMON>
+__device__ __forceinline__ void preprocess_bwd_body(PreBwdArgs a)
 {
+    if (COMMON) {
+        a.stage_sh = 1; a.stage_shp = 1;
+        a.c.want_backward = 1; a.c.grads_accumulate = 0; a.c.grads_zeroed = 0;
+        a.c.M = 16; a.c.M_p = 16;
+        a.io.cov3D_precomp = nullptr; a.io.dL_dcolors = nullptr; a.io.dL_dcov3D = nullptr;
+        __builtin_assume(a.io.shs != nullptr);
+        __builtin_assume(a.io.shs_p != nullptr);
+        __builtin_assume(a.io.scales != nullptr);
+    }
     extern __shared__ float4 lds_rows[];
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const int P = a.c.P;
@@ -1148,6 +1161,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a)
     }
 }
 
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a) { preprocess_bwd_body<false>(a); }
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd_common(PreBwdArgs a) { preprocess_bwd_body<true>(a); }
+
 __global__ __launch_bounds__(1024) void k_offset_reduce(int nblocks, const float2* __restrict__ part,
                                                         float* __restrict__ out_phase, float* __restrict__ out_dc)
 {
@@ -1249,7 +1265,10 @@ hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const g
     a.stage_shp = (io.shs_p != nullptr && c.M_p == 16 && !c.grads_zeroed) ? 1 : 0;
     const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_PAD : 0) + (a.stage_shp ? SHP_ROW_PAD : 0));
     const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;          // = waves = partial sums of the offset gradients
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
+    const bool common = c.want_backward && !c.grads_accumulate && !c.grads_zeroed && io.shs && c.M == 16 && io.shs_p && c.M_p == 16 &&
+                        !io.cov3D_precomp && io.scales && io.rotations && !io.dL_dcolors && !io.dL_dcov3D;
+    if (common) hipLaunchKernelGGL(k_preprocess_bwd_common, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
+    else hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
     // (the two scalar gradients are only reduced when the caller wants them: optimize_phase_offset / optimize_dc_offset)
     if (io.shs_p != nullptr && io.dL_dphase_offset != nullptr && io.dL_ddc_offset != nullptr)
         hipLaunchKernelGGL(k_offset_reduce, dim3(1), dim3(1024), 0, s, blocks,
