@@ -11,7 +11,7 @@ from collections import defaultdict
 
 STAGE_OF = {"k_preprocess_fwd": "preprocess_fwd", "k_tile_count": "tile_count", "k_tile_scatter": "tile_scatter",
             "k_tile_sort_small": "tile_sort", "k_tile_front": "tile_sort", "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd",
-            "k_preprocess_bwd": "preprocess_bwd"}
+            "k_preprocess_bwd": "preprocess_bwd", "k_preprocess_bwd_common": "preprocess_bwd"}
 
 
 def short(n):
