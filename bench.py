@@ -206,7 +206,7 @@ def gpu_step_fn(scene, dev):
     return step, state, leaf
 
 
-def cpu_baseline(scene, budget_s=20.0, max_iters=5, forward_only=False):
+def cpu_baseline(scene, budget_s=20.0, max_iters=5, forward_only=False, one_core=True, one_core_budget_s=35.0):
     """The CPU oracle (a port of the reference algorithm; the reference itself has no CPU
     rasterizer) timed on this host: full forward+backward of the same frame."""
     from oracle import oracle
@@ -225,9 +225,25 @@ def cpu_baseline(scene, budget_s=20.0, max_iters=5, forward_only=False):
         t_all = [warm]
     t_all.sort()
     med = t_all[len(t_all) // 2]
-    return dict(value=1.0 / med, unit="it/s", cores=oracle.num_threads(), kind="port",
-                sample="%d full %s iterations of the same frame (median %.3f s)" % (
-                    len(t_all), "forward" if forward_only else "forward+backward", med))
+    cores = oracle.num_threads()
+    out = dict(value=1.0 / med, unit="it/s", cores=cores, kind="port",
+               sample="%d full %s iterations of the same frame (median %.3f s)" % (
+                   len(t_all), "forward" if forward_only else "forward+backward", med))
+    if one_core and cores > 1:
+        # "with all cores ... and with 1 core".  One thread takes ~15 s per 1 M frame: a single full iteration
+        # (a second one while the budget lasts), no warm-up run -- the pages are warm from the runs above
+        oracle.set_num_threads(1)
+        try:
+            t1, t_start = [], time.perf_counter()
+            while len(t1) < 2 and (not t1 or time.perf_counter() - t_start + t1[0] < one_core_budget_s):
+                t0 = time.perf_counter()
+                Hh.run_oracle(oracle, scene, backward=not forward_only)
+                t1.append(time.perf_counter() - t0)
+        finally:
+            oracle.set_num_threads(cores)
+        out["one_core"] = dict(value=1.0 / min(t1), unit="it/s", cores=1, kind="port",
+                               sample="%d full iteration(s) of the same frame on one thread (best %.2f s)" % (len(t1), min(t1)))
+    return out
 
 
 def load_counters(stage, workload):
@@ -736,6 +752,22 @@ def views_extra(dev, scene, steps=90, warmup=30, views=30):
         step(True)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    # per-stage HIP events over the same number of steps (second leg, as for the headline step)
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    R_sum = walk_sum = blend_sum = vis_sum = 0
+    for i in range(steps):
+        step()
+        if i % 10 == 0:                      # units of every tenth frame (each read is a device synchronisation)
+            w = walked_instances(dev)
+            R_sum += int(api.last_call_stats["num_rendered"])
+            walk_sum += w["per_tile_deepest"] if w else 0
+    torch.cuda.synchronize(dev)
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    n_units = (steps + 9) // 10
+    calls = max(prof["forward_calls"], 1)
+    stage_ms = {k[:-3]: prof[k] / calls for k in prof if k.endswith("_ms")}
     lib = _lib.load()
     flagged_frames, flagged_quads = 0, 0
     for slot, seq in stats["lates"][-200:]:
@@ -748,7 +780,21 @@ def views_extra(dev, scene, steps=90, warmup=30, views=30):
             "it_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
             "restarted_forwards": stats["restarted"], "frames_with_depth_cut": stats["with_cut"],
             "frames_with_flagged_quadrants": flagged_frames, "flagged_quadrants": flagged_quads,
-            "near_slab_per_tile_at_the_end": api._slab_state.get(key, {}).get("per_tile")}
+            "near_slab_per_tile_at_the_end": api._slab_state.get(key, {}).get("per_tile"),
+            "stage_ms": stage_ms, "gpu_ms_sum_of_stages": sum(stage_ms.values()),
+            "roofline": views_roofline(stage_ms, P, W * H, ((W + 15) // 16) * ((H + 15) // 16), R_sum / n_units, walk_sum / n_units)}
+
+
+def views_roofline(stage_ms, P, N, T, R, R_walk):
+    """`roofline` object of the varying-view step: dominant stage by HIP events, SURVEY 8(d) bytes x units processed
+    (mean instance count / walked entries over the sampled frames; every visible Gaussian charged as P)."""
+    dom = max(stage_ms, key=lambda k: stage_ms[k])
+    per_kernel, whole = algorithmic_bytes(P, P, int(R), N, T, units={"R_walk": int(R_walk)})
+    ms = stage_ms[dom]
+    ach = per_kernel[dom] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": None, "algorithmic_bytes_per_launch": per_kernel[dom], "avg_launch_ms": ms,
+            "mean_instances": R, "mean_walked_entries": R_walk}
 
 
 def knn_extra(dev, P=1_000_000):
@@ -830,6 +876,51 @@ def adam_extra(dev, P=1_000_000, steps=10):
                                   "ms": vis_ms, "algorithmic_bytes": 28 * nv + P, "achieved_GBs": (28 * nv + P) / (vis_ms * 1e-3) / 1e9}}
 
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a child process (never an exec: this process stays the parent and has touched no GPU), pass the
+    ranks' output through (rank 0 prints the JSON line) and return the launcher's exit code -- non-zero when any rank
+    failed."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    envc = dict(os.environ)
+    envc.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    envc.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=envc).returncode
+
+
+def main_cpu_rehearsal(args, env, world):
+    """GFT_BENCH_REHEARSAL=cpu: the launch / rendezvous / timing plumbing of the N > 1 run without a GPU (gloo ranks, a
+    host-side stand-in step, no rasterizer call): what tests/test_dist_gloo.py starts to check that `--gpus N` really
+    runs N ranks.  The line it prints is marked as a rehearsal and carries no metric value."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    frames = []
+
+    def step():
+        frames.append(frame_of_rank(env["rank"], len(frames), world))
+        time.sleep(0.001)
+    steps = min(args.steps, 20)
+    elapsed = timed_steps(step, steps, min(args.warmup, 2), lambda: None, dist if world > 1 else None)
+    if env["rank"] == 0:
+        print(json.dumps({"rehearsal": "cpu: gloo ranks, host-side stand-in step, no rasterizer call", "metric": None, "value": None,
+                          "n_gpus": world, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "rccl_ranks": 0,
+                          "process_group": ("gloo x%d" % dist.get_world_size()) if world > 1 else "none",
+                          "frames_of_rank0": frames[-3:]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -838,7 +929,9 @@ def main():
     ap.add_argument("--workload", default="metric", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--no-extras", action="store_true", help="skip the fused-assembly measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the measurements beside the headline step")
+    ap.add_argument("--extras", default="all", help="comma list of extras to run (render_pair, varying_views, assemble_inputs, knn, "
+                                                    "adam, deform_network, densify, train_iteration) or `all`")
     ap.add_argument("--spin-up", type=float, default=0.3, help="seconds of untimed steps before the warm-up")
     ap.add_argument("--pair", action="store_true", help="--workload C3: the two rasterizer calls of an iteration as one "
                                                          "GaussianRasterizerPair (opt-in API; default: two calls, as the reference)")
@@ -846,18 +939,26 @@ def main():
     if args.steps is None:
         args.steps = 7000 if args.workload == "C3" else 50
 
-    import torch
     env = dist_env()
     world = max(env["world"], 1)
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher (`python3 bench.py --gpus N`, the way the driver starts --gpus 1): this parent has
+        # made no GPU call (torch is not even imported yet) and spawns the N ranks as fresh child processes
+        sys.exit(spawn_ranks(args.gpus))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU (start through torch.distributed.run, or "
+                         "without WORLD_SIZE in the environment to let bench.py spawn the ranks)" % (args.gpus, world))
+    rehearsal_mode = os.environ.get("GFT_BENCH_REHEARSAL", "")
+    if rehearsal_mode == "cpu":
+        return main_cpu_rehearsal(args, env, world)
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the rasterizer has no CPU path)")
     from gftorf_amd import _lib
     _lib.load()
     # GFT_BENCH_REHEARSAL=1: all ranks on device 0 with the gloo backend, to rehearse the N > 1 code path on
     # a one-GPU box (RCCL refuses two ranks on one device); never set by the driver
-    rehearsal = os.environ.get("GFT_BENCH_REHEARSAL") == "1"
+    rehearsal = rehearsal_mode == "1"
     local = 0 if rehearsal else env["local_rank"]
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -870,6 +971,8 @@ def main():
         else:
             dist_mod.init_process_group(backend="nccl", device_id=dev)
         dist = dist_mod
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
     from gftorf_amd import api
     api.keep_last_buffers = True          # the walked-entries figure of path_roofline is read from the last forward's scratch
@@ -971,6 +1074,9 @@ def main():
             "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            # ranks of the process group the timed region's barriers ran on (backend nccl = RCCL; gloo in a rehearsal)
+            "rccl_ranks": dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else (1 if dist is None else 0),
+            "process_group": ("%s x%d" % (dist.get_backend(), dist.get_world_size())) if dist is not None else "none",
             "config": {"workload": scene["label"], "P": P, "W": W, "H": H, "sh_degree": cfg["D"],
                        "P_visible": P_vis, "num_rendered": R,
                        "longest_tile_list": int(api.last_call_stats["max_tile_list"]), "frames_per_step": world,
@@ -1004,18 +1110,21 @@ def main():
         }
         if exchange is not None:
             out["deform_exchange"] = exchange
-        if world == 1 and not args.no_extras and args.workload == "metric":
+        # (the measurements beside the headline belong to the metric workload; named explicitly they run on any workload's
+        # scene, e.g. `--workload C5 --extras varying_views`)
+        if world == 1 and not args.no_extras and (args.workload == "metric" or args.extras != "all"):
             del state, step
             torch.cuda.empty_cache()
-            train_extra = train_iteration_extra(dev, scene)
-            torch.cuda.empty_cache()
-            pair_x = pair_extra(dev, scene)
-            torch.cuda.empty_cache()
-            views_x = views_extra(dev, scene)
-            torch.cuda.empty_cache()
-            out["extras"] = {"render_pair": pair_x, "varying_views": views_x, "assemble_inputs": assemble_extra(dev), "knn": knn_extra(dev),
-                             "adam": adam_extra(dev), "deform_network": deform_extra(dev),
-                             "densify": densify_extra(dev), "train_iteration": train_extra}
+            table = [("train_iteration", lambda: train_iteration_extra(dev, scene)), ("render_pair", lambda: pair_extra(dev, scene)),
+                     ("varying_views", lambda: views_extra(dev, scene)), ("assemble_inputs", lambda: assemble_extra(dev)),
+                     ("knn", lambda: knn_extra(dev)), ("adam", lambda: adam_extra(dev)), ("deform_network", lambda: deform_extra(dev)),
+                     ("densify", lambda: densify_extra(dev))]
+            want = None if args.extras == "all" else set(args.extras.split(","))
+            out["extras"] = {}
+            for name, fn in table:
+                if want is None or name in want:
+                    out["extras"][name] = fn()
+                    torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, budget_s=args.cpu_budget, forward_only=fo)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]

@@ -229,14 +229,18 @@ def slab_next_cut(slab, suggested_cut):
 
 
 def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
-                   cov3Ds_precomp, ph_off, dc_off, want_bw, with_acc, stream=None, hint_slot=0, share_grads=None):
+                   cov3Ds_precomp, ph_off, dc_off, want_bw, with_acc, stream=None, hint_slot=0, share_grads=None,
+                   pre_launch=None):
     """One forward of the native rasterizer (``RasterizeGaussiansCUDA``, rasterize_points.cu:42-165): allocates the
     outputs and the three scratch buffers, runs the C ABI on torch's current stream.  ``s`` holds the settings fields
     (``GaussianRasterizationSettings`` or ``_Settings``), ``ph_off`` / ``dc_off`` are floats.  Returns a dict.
 
     For :mod:`gftorf_amd.pair`: ``stream`` = raw hipStream_t to launch on instead of torch's current stream (the caller
     orders it against the current stream), ``hint_slot`` keeps the binning hints of the two cameras of a pair apart,
-    ``share_grads`` = the ``prep`` of the pair's other view, whose gradient tensors this view's backward adds to."""
+    ``share_grads`` = the ``prep`` of the pair's other view, whose gradient tensors this view's backward adds to,
+    ``pre_launch`` = called after every host-side tensor preparation of this call (contiguous / aligned copies of the
+    inputs and camera constants, queued on torch's CURRENT stream) and before its first kernel launch: a caller that
+    launches on another stream orders that stream behind those copies there."""
     lib = _lib.load()
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -315,6 +319,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
     else:
         if stream is None:
             stream = _lib.raw_stream(dev)
+        if pre_launch is not None:
+            pre_launch()
         num_rendered = C.c_int64(0)
         hint_key = (dev.index, P, W, H) if not hint_slot else (dev.index, P, W, H, hint_slot)
         hint, list_hint, cut_hint, near_hint = _instance_hint.get(hint_key, (None, 0, 0.0, 0))
@@ -551,7 +557,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D_c, opac_c if opac_c is not None else dummy,
                               sh_c if sh_c is not None else dummy, sh_p_c if sh_p_c is not None else dummy,
                               scales_c if scales_c is not None else dummy, rot_c if rot_c is not None else dummy,
-                              cov_c if cov_c is not None else dummy, radii, r["geom"], r["binning"], r["img"])
+                              cov_c if cov_c is not None else dummy, radii, r["geom"], r["binning"], r["img"],
+                              r["outputs"][8])     # `pixels`: the backward reads it (which Gaussians were blended), so an
+                                                   # in-place edit between forward and backward must raise, not zero rows
         ctx.mark_non_differentiable(radii)
         return r["outputs"]
 
@@ -559,7 +567,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, grad_out_phasor, grad_out_depth, grad_out_normal, grad_out_acc,
                  grad_entropy, grad_depth_distortion, grad_amp_distortion, grad_pixels, grad_distribution, _):
         s = ctx.raster_settings
-        means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, binning, img = ctx.saved_tensors
+        means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, binning, img, _pixels = ctx.saved_tensors
         has_sh, has_sh_p, has_colors, has_phasors, has_scales, has_cov = ctx.present
         ph_off, dc_off = ctx.scalars
         acc, ctx.acc = ctx.acc, None

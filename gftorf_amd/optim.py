@@ -29,9 +29,16 @@ class FusedAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, **kw)
 
     @torch.no_grad()
-    def step(self, closure=None, visibility=None):
+    def step(self, closure=None, visibility=None, row_params=None):
+        """``visibility``: opt-in row mask (see the module docstring).  ``row_params``: the parameters the mask applies to
+        (an iterable of tensors; default: every parameter whose first dimension equals ``visibility.numel()`` -- name
+        them when another parameter, e.g. a network weight, could have that many rows by coincidence).  A row that is
+        skipped keeps its moments, and the bias correction uses the tensor's one step count: a row that was skipped
+        k times is corrected as if it had taken those k steps (dense Adam differs there as well as in the decay)."""
         loss = None
         rows = None
+        if row_params is not None:
+            row_params = {id(t) for t in row_params}
         if visibility is not None:
             if visibility.dim() != 1 or visibility.dtype not in (torch.bool, torch.uint8):
                 raise RuntimeError("gftorf_amd.FusedAdam: visibility must be a 1-D bool / uint8 tensor (one entry per Gaussian)")
@@ -69,21 +76,31 @@ class FusedAdam(torch.optim.Adam):
                 if not (m.is_contiguous() and v.is_contiguous()):
                     raise RuntimeError("gftorf_amd.FusedAdam: optimizer state must be contiguous")
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                by_rows = rows is not None and p.dim() >= 1 and p.shape[0] == rows and rows > 0
+                # the kernels move 16-byte pieces: a gradient that is a view at an odd offset (e.g. the rasterizer's
+                # dc_offset gradient, element 1 of a two-float tensor) is copied once; parameter and moments are the
+                # caller's own allocations and must be aligned as torch allocates them
+                if grad.data_ptr() % 16:
+                    grad = grad.clone()
+                if p.data_ptr() % 16 or m.data_ptr() % 16 or v.data_ptr() % 16:
+                    raise RuntimeError("gftorf_amd.FusedAdam: parameters and optimizer state must be 16-byte aligned")
+                by_rows = rows is not None and p.dim() >= 1 and p.shape[0] == rows and rows > 0 and (
+                    row_params is None or id(p) in row_params)
                 if by_rows and visibility.device != p.device:
                     raise RuntimeError("gftorf_amd.FusedAdam: visibility is on %s, the parameter on %s" % (visibility.device, p.device))
                 buckets.setdefault((p.device, float(beta1), float(beta2), float(eps), float(wd), by_rows), []).append(
                     (p, grad, m, v, float(lr), state["step"]))
         for (dev, beta1, beta2, eps, wd, by_rows), items in buckets.items():
-            torch._foreach_add_([it[5] for it in items], 1)
             tab = (_lib.AdamTensor * len(items))()
             for e, (p, g, m, v, lr, st) in zip(tab, items):
                 e.param, e.grad, e.exp_avg, e.exp_avg_sq, e.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
-                e.lr, e.step = lr, int(st)
+                e.lr, e.step = lr, int(st) + 1
             with _lib.on_device(dev):
                 if by_rows:
                     _lib.check(lib.gft_adam_step_rows(_lib.raw_stream(dev), len(items), tab, rows, mask_u8.data_ptr(), beta1, beta2,
                                                       eps, wd))
                 else:
                     _lib.check(lib.gft_adam_step_multi(_lib.raw_stream(dev), len(items), tab, beta1, beta2, eps, wd))
+            # the step counters advance only once the launch was accepted (a rejected table leaves every tensor of the
+            # bucket and its counter as they were)
+            torch._foreach_add_([it[5] for it in items], 1)
         return loss

@@ -46,16 +46,22 @@ class _RasterizePair(torch.autograd.Function):
         if overlap:
             main = torch.cuda.current_stream(dev)
             side = _side_stream(dev)
-            fork = torch.cuda.Event()
-            fork.record(main)
-            side.wait_event(fork)                     # B starts behind everything already queued (its inputs)
+
+            def fork():
+                # B's kernels start behind everything queued on the main stream so far: the producers of its inputs AND
+                # the contiguous / aligned copies native_forward has just made of them on the main stream (the
+                # reference's camera matrices are `.transpose(0, 1)` views, copied on every call)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
         ra = native_forward(settings_a, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
                             cov3Ds_precomp, offs[0][0], offs[0][1], want_bw, True, hint_slot=1)
         # (B's buffers come from the current stream's pool like A's: it is joined below before anything is returned,
         # and A's call frees nothing that B could be handed while A's kernels still use it)
         rb = native_forward(settings_b, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
                             cov3Ds_precomp, offs[1][0], offs[1][1], want_bw, True,
-                            stream=side.cuda_stream if overlap else None, hint_slot=2, share_grads=ra["prep"])
+                            stream=side.cuda_stream if overlap else None, hint_slot=2, share_grads=ra["prep"],
+                            pre_launch=fork if overlap else None)
         if overlap:
             join = torch.cuda.Event()
             join.record(side)
@@ -75,14 +81,15 @@ class _RasterizePair(torch.autograd.Function):
         opt = lambda t: t if t is not None else dummy
         ctx.save_for_backward(means3D_c, opt(opac_c), opt(sh_c), opt(sh_p_c), opt(scales_c), opt(rot_c), opt(cov_c),
                               ra["outputs"][10], ra["geom"], ra["binning"], ra["img"],
-                              rb["outputs"][10], rb["geom"], rb["binning"], rb["img"])
+                              rb["outputs"][10], rb["geom"], rb["binning"], rb["img"],
+                              ra["outputs"][8], rb["outputs"][8])       # `pixels` of both views (read by the backward)
         ctx.mark_non_differentiable(ra["outputs"][10], rb["outputs"][10])
         return tuple(ra["outputs"]) + tuple(rb["outputs"])
 
     @staticmethod
     def backward(ctx, *grads):
         (means3D, opac, sh, sh_p, scales, rotations, cov3D, radii_a, geom_a, bin_a, img_a,
-         radii_b, geom_b, bin_b, img_b) = ctx.saved_tensors
+         radii_b, geom_b, bin_b, img_b, _pix_a, _pix_b) = ctx.saved_tensors
         has_sh, has_sh_p, has_colors, has_phasors, has_scales, has_cov = ctx.present
         views = [(ctx.settings[0], radii_a, geom_a, bin_a, img_a, grads[0:11]),
                  (ctx.settings[1], radii_b, geom_b, bin_b, img_b, grads[11:22])]

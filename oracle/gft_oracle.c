@@ -38,6 +38,18 @@ int gfto_num_threads(void)
 #endif
 }
 
+/* threads of the following calls (bench.py times the oracle on all host cores and on one); returns the count in effect */
+int gfto_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 /* ---- tiny column-major 3x3 (GLM semantics: m[c][r]) ---------------------- */
 typedef struct { float m[3][3]; } m3;
 

@@ -53,6 +53,8 @@ def lib():
         _lib.gfto_scan.restype = C.c_uint32
         _lib.gfto_preprocess_fwd.restype = C.c_int
         _lib.gfto_num_threads.restype = C.c_int
+        _lib.gfto_set_num_threads.restype = C.c_int
+        _lib.gfto_set_num_threads.argtypes = [C.c_int]
     return _lib
 
 
@@ -74,6 +76,11 @@ def get_higher_msb(n):
 
 def num_threads():
     return int(lib().gfto_num_threads())
+
+
+def set_num_threads(n):
+    """OpenMP threads of the following oracle calls; returns the count in effect."""
+    return int(lib().gfto_set_num_threads(int(n)))
 
 
 def mark_visible(means3D, viewmatrix, projmatrix, near_n, far_n):

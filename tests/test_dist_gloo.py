@@ -120,3 +120,23 @@ def test_algorithmic_bytes_formula():
     assert whole_l < whole and all(per_l[k] <= per[k] for k in per)
     assert per_l["render_bwd"] == 148 * 600_000 + 96 * 307_200
     assert per_l["preprocess_bwd"] == 928 * 250_000 + 384 * 750_000
+
+
+def test_bare_bench_gpus2_spawns_two_ranks():
+    """`python3 bench.py --gpus 2` started the way the driver starts `--gpus 1` (no launcher, no WORLD_SIZE): the
+    parent spawns 2 ranks as child processes and relays rank 0's line, which says n_gpus 2 -- it must never run one
+    rank and call it two.  GFT_BENCH_REHEARSAL=cpu: gloo ranks and a host-side stand-in step (no GPU here)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["GFT_BENCH_REHEARSAL"] = "cpu"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert lines[0]["n_gpus"] == 2 and lines[0]["process_group"] == "gloo x2" and lines[0]["steps"] == 5
+    # a world size that contradicts --gpus is refused, not silently accepted
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stdout + r2.stderr)

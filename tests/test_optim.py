@@ -119,3 +119,32 @@ def test_step_on_visible_rows_only(frac, gpu):
                 assert torch.equal(w, g), "%s of group %s, step %d" % (name, gr["name"], it)
     with pytest.raises(RuntimeError, match="visibility"):
         rows.step(visibility=torch.zeros(1001, device=gpu))
+
+
+@pytest.mark.gpu
+def test_gradient_view_at_an_odd_offset_and_row_params(gpu):
+    """The rasterizer returns the dc_offset gradient as element 1 of a two-float tensor (api.py: `g["offsets"][1:2]`): a
+    contiguous view 4 bytes into its allocation, which autograd may adopt as `.grad`.  The step copies such a gradient
+    instead of rejecting the whole table, and step counters only advance with a step that was taken.  `row_params` names
+    the tensors a visibility mask applies to."""
+    from gftorf_amd import FusedAdam
+    p = torch.nn.Parameter(torch.tensor([0.5], device=gpu))
+    q = torch.nn.Parameter(torch.tensor([0.5], device=gpu))
+    two = torch.tensor([9.0, 0.25], device=gpu)
+    p.grad = two[1:2]
+    q.grad = torch.tensor([0.25], device=gpu)
+    assert p.grad.data_ptr() % 16 == 4
+    a, b = FusedAdam([p], lr=1e-2), FusedAdam([q], lr=1e-2)
+    for _ in range(3):
+        a.step()
+        b.step()
+    assert torch.equal(p.detach(), q.detach()) and float(a.state[p]["step"]) == 3.0
+    # a 7-row weight is not a per-Gaussian tensor although a 7-entry mask fits it: named row parameters only
+    w = torch.nn.Parameter(torch.ones(7, 3, device=gpu))
+    x = torch.nn.Parameter(torch.ones(7, 3, device=gpu))
+    w.grad, x.grad = torch.ones_like(w), torch.ones_like(x)
+    opt = FusedAdam([w, x], lr=1e-2)
+    vis = torch.tensor([1, 0, 0, 0, 0, 0, 1], dtype=torch.bool, device=gpu)
+    opt.step(visibility=vis, row_params=[x])
+    assert (w.detach() != 1.0).all()                                  # dense step
+    assert (x.detach()[1:6] == 1.0).all() and (x.detach()[0] != 1.0).all()

@@ -203,3 +203,39 @@ def test_pair_operator_variants(variant, oracle, gpu):
         if k in names:
             ref = (ba[names[k]] + bb[names[k]]).reshape(g[k].shape)
             Hh.assert_close(names[k], ref, pl[k].grad.cpu().numpy(), rtol_max=3e-4)
+
+
+def test_pair_with_strided_camera_matrices_and_a_noncontiguous_input(gpu):
+    """The reference builds its camera matrices as `.transpose(0, 1)` views (scene/cameras.py:121-129), which the
+    forward copies on every call, on torch's current stream: view B's kernels (side stream) must be ordered behind those
+    copies, not only behind what was queued before the pair call.  Large inputs make the window wide enough to see."""
+    from gftorf_amd import GaussianRasterizer, GaussianRasterizerPair
+    a, b = _two_views(P=60000, W=128, H=96, scale_lo=0.01, scale_hi=0.05)
+    dev = gpu
+
+    def strided(sc):
+        s = Hh.gpu_settings(sc, dev)
+        # the same values with strides (1, 4): what `torch.tensor(M).transpose(0, 1).cuda()` keeps
+        return s._replace(viewmatrix=s.viewmatrix.t().contiguous().t(), projmatrix=s.projmatrix.t().contiguous().t())
+    sa, sb = strided(a), strided(b)
+    assert not sa.viewmatrix.is_contiguous() and not sb.projmatrix.is_contiguous()
+    g = a["gaussians"]
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=dev)
+    # opacities as a column of a wider tensor, SH rows as a slice of a longer tensor: both are copied by the forward
+    wide = torch.cat([t(g["opacities"]), torch.zeros((g["opacities"].shape[0], 3), device=dev)], 1)
+    kw = dict(means3D=t(g["means3D"]), means2D=torch.zeros((g["means3D"].shape[0], 3), device=dev), opacities=wide[:, 0:1],
+              shs=t(np.concatenate([g["shs"], g["shs"]], 1))[:, :16], shs_p=t(g["shs_p"]), scales=t(g["scales"]),
+              rotations=t(g["rotations"]))
+    assert not kw["opacities"].is_contiguous() and not kw["shs"].is_contiguous()
+    for rep in range(4):
+        with torch.no_grad():
+            # keep the main stream busy in front of the pair call so that the copies sit behind real work
+            junk = torch.randn(4096, 4096, device=dev) @ torch.randn(4096, 4096, device=dev)
+            oa, ob = GaussianRasterizerPair(sa, sb)(phase_offset=(a["phase_offset"], b["phase_offset"]),
+                                                    dc_offset=(a["dc_offset"], b["dc_offset"]), **kw)
+            ra = GaussianRasterizer(sa)(phase_offset=a["phase_offset"], dc_offset=a["dc_offset"], **kw)
+            rb = GaussianRasterizer(sb)(phase_offset=b["phase_offset"], dc_offset=b["dc_offset"], **kw)
+        torch.cuda.synchronize()
+        del junk
+        for name, x, y in zip(Hh.OUT_NAMES, tuple(ra) + tuple(rb), tuple(oa) + tuple(ob)):
+            np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy(), err_msg="%s (repetition %d)" % (name, rep))
