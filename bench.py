@@ -101,9 +101,9 @@ def algorithmic_bytes(P, P_vis, R, N, T, forward_only=False, units=None):
 
     With ``units`` the same per-unit constants are charged for the units this implementation's launches PROCESS; the
     lazy stages make the formula as written an over-count, not a bound (it printed > 8 TB/s at 5 M @ 1080p):
-      P_app   visible Gaussians whose appearance K1 evaluates (SH colour + phasor: 320 B of SH read, 52 B written; the
-              others cost K1 112 B of geometry) -- those in front of the depth cut, all of them without a cut
-      R_bin   instances that are counted, scattered and sorted (the near slab, + the far slab of flagged tiles)
+      P_app   visible Gaussians whose appearance is evaluated (SH colour + phasor: 320 B of SH read, 52 B written; the
+              others cost K1 112 B of geometry) -- those that stand in the sorted part of some tile list
+      R_bin   ids that are sorted into tile lists (the list heads, + the lists completed for flagged quadrants)
       R_walk  list entries the render stages walk (per tile up to its deepest contributor: early termination)
       P_blend Gaussians some pixel blended: K8 + K9 (928 B) run for those, every other Gaussian only gets its 376 B
               of zero gradient rows (+ 8 B of radii), like a culled one"""
@@ -141,14 +141,17 @@ def walked_instances(dev, radii=None):
     T = ((b["W"] + 15) // 16) * ((b["H"] + 15) // 16)
     tm = b["img"][L.img_tile_max:L.img_tile_max + T * 16].view(torch.int32).reshape(T, 4)
     ctrl = b["img"][L.img_ctrl:L.img_ctrl + 64].view(torch.int32).cpu().tolist()
-    cut = float(api.last_call_stats.get("depth_cut", 0.0) or 0.0)
-    depth = b["geom"][L.geom_depth:L.geom_depth + 4 * b["P"]].view(torch.float32)
+    need = b["geom"][L.geom_need:L.geom_need + b["P"]]
+    heads = b["img"][L.img_front_len:L.img_front_len + 4 * T].view(torch.int32)
+    pull = bool(ctrl[5])          # (Gaussian, supertile) entries: only the tile-pull count pass writes them
     return {"per_tile_deepest": int(tm.max(dim=1).values.sum().item()), "per_quadrant_sum": int(tm.sum().item()),
-            # Gaussians in front of the depth cut (the preprocess kernel gives only those their appearance); None = all
-            "near_gaussians": int(((depth <= cut) & (radii > 0)).sum().item()) if (cut > 0.0 and radii is not None) else None,
-            # lazy binning / lazy sort bookkeeping of that forward (ctrl words, gft_internal.h)
-            "near_slab_instances": ctrl[5], "far_slab_instances_binned": ctrl[8], "flagged_quadrants": ctrl[4],
-            "depth_cut": api.last_call_stats.get("depth_cut", 0.0)}
+            "tile_pull": pull,
+            # Gaussians that stand in the sorted part of some tile list and were given an appearance; None = all visible ones
+            "gaussians_with_appearance": int((need != 0).sum().item()) if pull else None,
+            # bookkeeping of that forward (ctrl words, gft_internal.h): entries dealt to supertiles, ids sorted into list
+            # heads, quadrants that walked past their head, ids in the lists that were completed for them
+            "supertile_entries": ctrl[5] if pull else None, "head_ids": int(heads.sum().item()) if pull else None,
+            "flagged_quadrants": ctrl[4], "completed_list_ids": ctrl[6] if pull else None}
 
 
 def build_scene(workload, rank, world):
@@ -696,10 +699,9 @@ def pair_extra(dev, scene, steps=20, warmup=5, which=("two", "pair")):
 
 def views_extra(dev, scene, steps=90, warmup=30, views=30):
     """The headline step over VARYING views: 30 cameras on an arc around the same Gaussians in shuffled order (a training
-    loop's access pattern), forward + backward each.  The binning buffer and the depth cut of a frame come from the
-    previous frame of the shape -- another view here -- so this is the number that shows what the hints cost when
-    they miss: restarted forwards (instance count above the guess), frames rendered without a depth cut, frames in which
-    a quadrant outlived the near slab (second binning pass)."""
+    loop's access pattern), forward + backward each.  Only the size of the binning buffer comes from the previous
+    frames of the shape -- other views here: restarted forwards (instance count above the guess), frames in which
+    a quadrant walked past the sorted head of its list (that tile's list is completed on demand)."""
     import ctypes as C
     import random
     import numpy as np
@@ -724,8 +726,7 @@ def views_extra(dev, scene, steps=90, warmup=30, views=30):
     ups = [gr["color"], gr["phasor"], gr["depth"], gr["acc"], gr["depth_distortion"]]
     rng = random.Random(7)
     order = []
-    stats = dict(restarted=0, with_cut=0, lates=[])
-    key = (dev.index, P, W, H)
+    stats = dict(restarted=0)
 
     def step(record=False):
         if not order:
@@ -739,10 +740,6 @@ def views_extra(dev, scene, steps=90, warmup=30, views=30):
         torch.autograd.backward([o[0], o[1], o[2], o[4], o[6]], ups)
         if record:
             stats["restarted"] += int(api.last_call_stats["restarted"])
-            stats["with_cut"] += int(api.last_call_stats["depth_cut"] > 0.0)
-            late = api._slab_state.get(key, {}).get("late")
-            if late:
-                stats["lates"].append(late)
 
     for _ in range(warmup):
         step()
@@ -755,32 +752,31 @@ def views_extra(dev, scene, steps=90, warmup=30, views=30):
     # per-stage HIP events over the same number of steps (second leg, as for the headline step)
     _lib.profile_reset()
     _lib.profile_enable(True)
-    R_sum = walk_sum = blend_sum = vis_sum = 0
+    R_sum = walk_sum = flag_frames = flag_quads = app_sum = done_sum = 0
     for i in range(steps):
         step()
         if i % 10 == 0:                      # units of every tenth frame (each read is a device synchronisation)
             w = walked_instances(dev)
             R_sum += int(api.last_call_stats["num_rendered"])
             walk_sum += w["per_tile_deepest"] if w else 0
+            flag_frames += int(bool(w and w["flagged_quadrants"]))
+            flag_quads += w["flagged_quadrants"] if w else 0
+            app_sum += (w["gaussians_with_appearance"] or 0) if w else 0
+            done_sum += (w["completed_list_ids"] or 0) if w else 0
     torch.cuda.synchronize(dev)
     prof = _lib.profile_read()
     _lib.profile_enable(False)
     n_units = (steps + 9) // 10
     calls = max(prof["forward_calls"], 1)
     stage_ms = {k[:-3]: prof[k] / calls for k in prof if k.endswith("_ms")}
-    lib = _lib.load()
-    flagged_frames, flagged_quads = 0, 0
-    for slot, seq in stats["lates"][-200:]:
-        n = C.c_int64(-1)
-        lib.gft_forward_late(slot, seq, C.byref(n))
-        if n.value > 0:
-            flagged_frames += 1
-            flagged_quads += int(n.value)
     return {"what": "headline step over %d views on an arc in shuffled order, %d Gaussians, %dx%d, forward + backward" % (views, P, W, H),
             "it_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "restarted_forwards": stats["restarted"], "frames_with_depth_cut": stats["with_cut"],
-            "frames_with_flagged_quadrants": flagged_frames, "flagged_quadrants": flagged_quads,
-            "near_slab_per_tile_at_the_end": api._slab_state.get(key, {}).get("per_tile"),
+            "restarted_forwards": stats["restarted"],
+            # of the sampled frames (every tenth): frames in which a quadrant walked past the sorted head of its list (the
+            # silhouette quadrants of a view: their lists are completed on demand), and the means per sampled frame
+            "sampled_frames": n_units, "sampled_frames_with_flagged_quadrants": flag_frames,
+            "flagged_quadrants_per_frame": flag_quads / n_units, "completed_list_ids_per_frame": done_sum / n_units,
+            "gaussians_with_appearance_per_frame": app_sum / n_units,
             "stage_ms": stage_ms, "gpu_ms_sum_of_stages": sum(stage_ms.values()),
             "roofline": views_roofline(stage_ms, P, W * H, ((W + 15) // 16) * ((H + 15) // 16), R_sum / n_units, walk_sum / n_units)}
 
@@ -1027,9 +1023,11 @@ def main():
         ref_kernel, ref_whole = algorithmic_bytes(P, P_vis, R, N, T, forward_only=fo)
         units = None
         if walked:
-            units = {"P_app": walked["near_gaussians"], "R_bin": walked["near_slab_instances"] + walked["far_slab_instances_binned"]
-                     if walked["depth_cut"] > 0.0 else R, "R_walk": walked["per_tile_deepest"],
-                     "P_blend": P_vis if fo else P_blend}
+            # tile-pull binning: the supertile entries are what is counted and scattered, the list heads (+ completed lists)
+            # what is sorted; R_bin charges the larger of the two per instance-equivalent
+            units = {"P_app": walked["gaussians_with_appearance"],
+                     "R_bin": (walked["head_ids"] + walked["completed_list_ids"]) if walked["tile_pull"] else R,
+                     "R_walk": walked["per_tile_deepest"], "P_blend": P_vis if fo else P_blend}
         per_kernel, whole = algorithmic_bytes(P, P_vis, R, N, T, forward_only=fo, units=units)
         calls = max(prof["forward_calls"], 1)
         stage_ms = {k[:-3]: prof[k] / calls for k in prof if k.endswith("_ms")}
@@ -1104,8 +1102,8 @@ def main():
                               "counter_frac": (gbs(path_traffic, ms_per_step) / HBM_PEAK_GBS) if path_traffic else None,
                               "gpu_ms_sum_of_stages": sum(stage_ms.values())},
             "binning_restarts": {"restarted_forwards": restarts[0], "forwards": restarts[1]},
-            "lazy_binning": {k: walked[k] for k in ("depth_cut", "near_slab_instances", "far_slab_instances_binned",
-                                                    "flagged_quadrants")} if walked else None,
+            "tile_pull_binning": {k: walked[k] for k in ("tile_pull", "supertile_entries", "head_ids", "flagged_quadrants",
+                                                         "completed_list_ids", "gaussians_with_appearance")} if walked else None,
             "stage_ms": stage_ms,
         }
         if exchange is not None:

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 DEFORM_MAX_INPUTS = 96          # GFT_DEFORM_MAX_INPUTS (include/gftorf_deform.h)
 ACC_STRIDE = 16
 
@@ -51,9 +51,10 @@ BACKWARD_FIELDS = [
 ]
 
 LAYOUT_FIELDS = [
-    "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_rect", "geom_dirgrad", "geom_clamped",
+    "geom_rec_a", "geom_rec_b", "geom_depth", "geom_tiles", "geom_rect", "geom_dirgrad", "geom_clamped", "geom_need",
     "geom_blockhist", "geom_total",
-    "img_pix_state", "img_ranges", "img_tile_max", "img_ctrl", "img_tile_cnt", "img_tile_cnt1", "img_dhist", "img_ranges1", "img_super_tab", "img_tile_cursor", "img_tile_order", "img_front_len", "img_unit_flag", "img_resume_state", "img_pix_sums", "img_snaps", "img_total",
+    "img_pix_state", "img_ranges", "img_tile_max", "img_ctrl", "img_tile_cnt", "img_tile_cut", "img_super_tab", "img_tile_cursor",
+    "img_tile_order", "img_front_len", "img_unit_flag", "img_resume_state", "img_pix_sums", "img_snaps", "img_total",
     "bin_keys", "bin_point_list", "bin_total",
 ]
 
@@ -75,14 +76,12 @@ class Layout(C.Structure):
 
 class ForwardHints(C.Structure):
     """gft_forward_hints"""
-    _fields_ = [("binning_instances", C.c_int64), ("max_tile_list", C.c_int64), ("near_instances", C.c_int64),
-                ("depth_cut", C.c_float), ("near_per_tile", C.c_int32)]
+    _fields_ = [("binning_instances", C.c_int64), ("max_tile_list", C.c_int64)]
 
 
 class ForwardReport(C.Structure):
     """gft_forward_report"""
-    _fields_ = [("num_rendered", C.c_int64), ("max_tile_list", C.c_int64), ("near_instances", C.c_int64),
-                ("depth_cut_next", C.c_float), ("late_slot", C.c_int32), ("late_seq", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("num_rendered", C.c_int64), ("max_tile_list", C.c_int64), ("list_entries", C.c_int64)]
 
 
 class Profile(C.Structure):
@@ -130,7 +129,7 @@ class AdamTensor(C.Structure):
 
 EXPORTS = [
     "gft_abi_version", "gft_lazy_sort", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes", "gft_acc_bytes",
-    "gft_det_partials_bytes", "gft_get_layout", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_forward_late", "gft_backward",
+    "gft_det_partials_bytes", "gft_get_layout", "gft_binning_capacity", "gft_set_binning_mode", "gft_binning_mode", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_backward",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
     "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi", "gft_adam_step_rows",
@@ -164,7 +163,13 @@ def load():
     lib.gft_acc_bytes.restype = C.c_size_t
     lib.gft_acc_bytes.argtypes = [C.c_int32]
     lib.gft_det_partials_bytes.restype = C.c_size_t
-    lib.gft_det_partials_bytes.argtypes = [C.c_int64]
+    lib.gft_det_partials_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    lib.gft_binning_capacity.restype = C.c_int64
+    lib.gft_binning_capacity.argtypes = [C.c_size_t, C.c_int32, C.c_int32]
+    lib.gft_set_binning_mode.restype = C.c_int
+    lib.gft_set_binning_mode.argtypes = [C.c_int]
+    lib.gft_binning_mode.restype = C.c_int
+    lib.gft_binning_mode.argtypes = [C.POINTER(Config)]
     lib.gft_get_layout.restype = C.c_int
     lib.gft_get_layout.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(Layout)]
     lib.gft_forward_preprocess.restype = C.c_int
@@ -221,9 +226,7 @@ def load():
     lib.gft_forward.restype = C.c_int
     lib.gft_forward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.POINTER(ForwardHints),
                                 C.POINTER(ForwardReport)]
-    lib.gft_forward_render.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64, C.c_int64, C.c_float]
-    lib.gft_forward_late.restype = C.c_int
-    lib.gft_forward_late.argtypes = [C.c_int32, C.c_uint32, C.POINTER(C.c_int64)]
+    lib.gft_forward_render.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64, C.c_int64]
     lib.gft_backward.restype = C.c_int
     lib.gft_backward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(BackwardIO), C.c_int64]
     lib.gft_mark_visible.restype = C.c_int

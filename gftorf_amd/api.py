@@ -54,14 +54,11 @@ keep_last_buffers = False
 last_call_buffers = {}
 
 # Instance count (and longest tile list) of the recent forwards per (device, P, W, H).  A training loop renders
-# similar frames back to back, so the binning buffer can be sized before the device has
+# frames of similar size back to back, so the binning buffer can be sized before the device has
 # counted (gft_forward: no host round trip in the middle of the forward); a frame that needs
-# more than the guess re-runs stage 2 with the exact size.
+# more than the guess re-runs stage 2 with the exact size.  Nothing else is taken from earlier frames: what is
+# binned, sorted and given an appearance is decided by the device from the frame itself (tile-pull binning).
 _instance_hint = {}
-# Lazy binning, per the same key: instances per tile wanted in the near slab and the handle of the previous forward's
-# late report (quadrants that outlived the near slab: each costs a second binning pass).  A frame that reports such
-# quadrants widens the next near slab by a quarter; 200 clean frames in a row narrow it again towards the default.
-_slab_state = {}
 # Tuning switch, off: GFT_GRADS_ZERO_FILL=1 makes the forward zero-fill the backward's gradient tensors on a side stream
 # so that the backward writes only the rows of blended Gaussians.  Measured on MI355X (metric frame): the backward's
 # preprocess kernel 108 -> 74 us, but the fill (376 MB) takes whatever runs beside it down with it -- +63 us beside the
@@ -71,7 +68,6 @@ _ZERO_FILL = _os.environ.get("GFT_GRADS_ZERO_FILL", "0") != "0"
 # GFT_BWD_DETERMINISTIC=1: the backward forms its per-Gaussian sums in a fixed order instead of with float atomics
 # (bit-reproducible gradients; several times slower: for tests)
 _DETERMINISTIC = _os.environ.get("GFT_BWD_DETERMINISTIC", "0") != "0"
-_SLAB_DEFAULT, _SLAB_MAX = 896, 8192
 _HINT_HEADROOM = 1.25
 _LIST_HEADROOM = 1.2      # longest tile list of the previous frame -> guess for this one
 
@@ -158,9 +154,9 @@ def _canonical_cap(n):
     return (int(n) + 63) // 64 * 64
 
 
-def binning_capacity(binning):
-    """Instances a binning buffer allocated by :func:`native_forward` holds."""
-    return max(0, (binning.numel() - 256) // 12)
+def binning_capacity(binning, W, H):
+    """Instances a binning buffer allocated by :func:`native_forward` for a W x H frame holds."""
+    return int(_lib.load().gft_binning_capacity(binning.numel(), int(W), int(H)))
 
 
 class _Settings(NamedTuple):
@@ -183,51 +179,6 @@ class _Settings(NamedTuple):
     use_view_dependent_phase: bool
 
 
-def new_slab_state():
-    """Per (shape, hint slot): width of the near slab, pause of the depth cut, handles of late reports."""
-    return {"per_tile": _SLAB_DEFAULT, "late": None, "pending": [], "clean": 0, "nocut": 0, "off": 0, "backoff": 0}
-
-
-def slab_report(slab, flagged, quadrants):
-    """Takes the late report of one earlier frame that was rendered with a depth cut: `flagged` of its `quadrants` pixel
-    quadrants outlived the near slab (each tile of such a quadrant took the second binning pass)."""
-    if flagged > max(4, quadrants // 100):
-        # More than 1 % of the quadrants: the second pass (three scans over the Gaussians, the tail sort, the resumed
-        # quadrants' walk behind everything else) cost more than the cut saved -- the frame is not like the one the cut
-        # came from (another view of a training loop) or its tiles look at very different depths.  Bin whole frames for a
-        # while, twice as long each time it happens again (at most 64 frames), then try once more.
-        slab["backoff"] = min(64, 2 * slab["backoff"] + 4)
-        slab["off"] = slab["backoff"]
-        slab["per_tile"], slab["clean"] = _SLAB_DEFAULT, 0
-    elif flagged > 0:
-        # a few: a quarter more slab absorbs them
-        slab["per_tile"], slab["clean"] = min(_SLAB_MAX, int(slab["per_tile"] * 1.25) + 1), 0
-    else:
-        slab["clean"] += 1
-        if slab["clean"] % 16 == 0:
-            slab["backoff"] //= 2
-        if slab["clean"] >= 200 and slab["per_tile"] > _SLAB_DEFAULT:
-            slab["per_tile"], slab["clean"] = max(_SLAB_DEFAULT, int(slab["per_tile"] * 0.9)), 0
-
-
-def slab_next_cut(slab, suggested_cut):
-    """The depth cut the next frame is rendered with: the previous frame's suggestion, or 0 (bin the whole frame) while
-    the cut is paused."""
-    cut = suggested_cut
-    if slab["off"] > 0:
-        slab["off"] -= 1
-        cut = 0.0
-    # A widened slab that no longer leaves out half of the frame gets no cut from the device (and therefore no reports
-    # to narrow it again): after 50 such frames it starts over at the default width
-    if cut > 0.0 or slab["per_tile"] == _SLAB_DEFAULT:
-        slab["nocut"] = 0
-    else:
-        slab["nocut"] += 1
-        if slab["nocut"] >= 50:
-            slab["per_tile"], slab["nocut"], slab["clean"] = _SLAB_DEFAULT, 0, 0
-    return cut
-
-
 def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
                    cov3Ds_precomp, ph_off, dc_off, want_bw, with_acc, stream=None, hint_slot=0, share_grads=None,
                    pre_launch=None):
@@ -236,7 +187,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
     (``GaussianRasterizationSettings`` or ``_Settings``), ``ph_off`` / ``dc_off`` are floats.  Returns a dict.
 
     For :mod:`gftorf_amd.pair`: ``stream`` = raw hipStream_t to launch on instead of torch's current stream (the caller
-    orders it against the current stream), ``hint_slot`` keeps the binning hints of the two cameras of a pair apart,
+    orders it against the current stream), ``hint_slot`` keeps the buffer-size hints of the two cameras of a pair apart,
     ``share_grads`` = the ``prep`` of the pair's other view, whose gradient tensors this view's backward adds to,
     ``pre_launch`` = called after every host-side tensor preparation of this call (contiguous / aligned copies of the
     inputs and camera constants, queued on torch's CURRENT stream) and before its first kernel launch: a caller that
@@ -323,7 +274,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
             pre_launch()
         num_rendered = C.c_int64(0)
         hint_key = (dev.index, P, W, H) if not hint_slot else (dev.index, P, W, H, hint_slot)
-        hint, list_hint, cut_hint, near_hint = _instance_hint.get(hint_key, (None, 0, 0.0, 0))
+        hint, list_hint = _instance_hint.get(hint_key, (None, 0))
         try:
             with _lib.on_device(dev):
                 if hint is None:
@@ -336,52 +287,28 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     cap = _canonical_cap(R)
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
-                    _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, int(max_list.value), 0.0))
-                    # the first frame of a shape bins every instance and leaves no depth cut for the next one: the
-                    # second frame measures the depth distribution (gft_forward reports it), the third uses it
-                    cut_next, near = 0.0, R
+                    _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, int(max_list.value)))
                 else:
+                    # later frames: the buffer is sized from the recent frames' instance counts (the only thing taken
+                    # from earlier frames), both stages are queued back to back
                     cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
-                    slab = _slab_state.setdefault(hint_key, new_slab_state())
-                    # late reports of the earlier forwards of this kind, oldest first; one that has not arrived yet (the
-                    # host runs ahead of the device) is asked for again next time
-                    pending = slab["pending"]
-                    if slab["late"] is not None:
-                        pending.append(slab["late"])
-                        slab["late"] = None
-                    del pending[:-8]
-                    while pending:
-                        flagged = C.c_int64(-1)
-                        lib.gft_forward_late(pending[0][0], pending[0][1], C.byref(flagged))
-                        if flagged.value < 0:
-                            break
-                        pending.pop(0)
-                        slab_report(slab, int(flagged.value), 4 * ((W + 15) // 16) * ((H + 15) // 16))
-                    cut_hint = slab_next_cut(slab, cut_hint)
-                    hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
-                                              near_instances=int(near_hint), depth_cut=float(cut_hint),
-                                              near_per_tile=int(slab["per_tile"]))
+                    hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1)
                     report = _lib.ForwardReport()
                     _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), C.byref(hints), C.byref(report)))
                     R = int(report.num_rendered)
                     max_list.value = int(report.max_tile_list)
-                    cut_next, near = float(report.depth_cut_next), int(report.near_instances)
-                    # (without a cut the flags belong to the lazy sort's heads: they say nothing about the slab width)
-                    slab["late"] = (int(report.late_slot), int(report.late_seq)) if cut_hint > 0.0 else None
                     if R > cap:
                         restarted = True
                         cap = _canonical_cap(R)
                         binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                         io.binning = binning.data_ptr()
-                        _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap,
-                                                          int(max_list.value), float(cut_hint)))
+                        _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, int(max_list.value)))
                 # slowly decaying maximum: alternating views of one scene (colour / ToF camera,
                 # random training views) keep the larger count as the guess
-                prev_r, prev_l = _instance_hint.get(hint_key, (0, 0, 0.0, 0))[:2]
-                _instance_hint[hint_key] = (max(R, int((prev_r or 0) * 0.95)),
-                                            max(int(max_list.value), int(prev_l * 0.95)), cut_next, near)
+                prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
+                _instance_hint[hint_key] = (max(R, int((prev_r or 0) * 0.95)), max(int(max_list.value), int(prev_l * 0.95)))
                 if len(_instance_hint) > 64:
                     _instance_hint.pop(next(iter(_instance_hint)))
         except Exception as ex:
@@ -389,12 +316,10 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
             raise ex
-        assert binning_capacity(binning) == cap
+        assert binning_capacity(binning, W, H) == cap
 
     last_call_stats.update(num_rendered=R, binning_instances=cap, restarted=restarted,
-                           max_tile_list=int(max_list.value) if P else 0, depth_cut=float(cut_hint) if (P and hint is not None) else 0.0,
-                           near_instances=near if P else 0,
-                           near_per_tile=_slab_state[hint_key]["per_tile"] if (P and hint_key in _slab_state) else _SLAB_DEFAULT)
+                           max_tile_list=int(max_list.value) if P else 0)
     if keep_last_buffers:
         last_call_buffers.update(geom=geom, img=img, binning=binning, P=P, W=W, H=H, cap=cap)
     last_call_stats["forwards"] = last_call_stats.get("forwards", 0) + 1
@@ -500,16 +425,16 @@ def run_backward(prep, grads_out, geom, binning, img, debug=False):
     io.dL_dout_depth, io.dL_dout_acc, io.dL_dout_depth_distortion = _ptr(keep[2]), _ptr(keep[3]), _ptr(keep[4])
     io.geom, io.img, io.binning = _ptr(geom), _ptr(img), _ptr(binning)
     det = None
-    if _DETERMINISTIC and P and binning_capacity(binning):
+    cap = binning_capacity(binning, W, H) if P else 0
+    if _DETERMINISTIC and P and cap:
         # test mode: partial rows per (list entry, quadrant), added in a fixed order (gft_backward_io.det_partials)
-        det = torch.empty((lib.gft_det_partials_bytes(binning_capacity(binning)) // 4,), dtype=torch.float32, device=dev)
+        det = torch.empty((lib.gft_det_partials_bytes(cap, W, H) // 4,), dtype=torch.float32, device=dev)
         io.det_partials = det.data_ptr()
     if debug:
         cpu_args = cpu_deep_copy_tuple(prep["debug_args"] + tuple(grads_out) + (geom, binning, img))
     try:
         with _lib.on_device(dev):
-            _lib.check(lib.gft_backward(_lib.raw_stream(dev), C.byref(prep["cfg"]), C.byref(io),
-                                        binning_capacity(binning) if P else 0))
+            _lib.check(lib.gft_backward(_lib.raw_stream(dev), C.byref(prep["cfg"]), C.byref(io), cap))
     except Exception as ex:
         if debug:
             torch.save(cpu_args, "snapshot_bw.dump")

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libgftorf_rast.so")
-SOURCES = ["gft_api.hip", "k_preprocess.hip", "k_binning.hip", "k_render.hip", "k_assemble.hip", "k_knn.hip", "k_adam.hip", "k_deform.hip", "k_densify.hip"]
+SOURCES = ["gft_api.hip", "k_preprocess.hip", "k_binning.hip", "k_pull.hip", "k_render.hip", "k_assemble.hip", "k_knn.hip", "k_adam.hip", "k_deform.hip", "k_densify.hip"]
 ARCH = "gfx950"
 # The SLP vectoriser packs the render kernels' scalar fp32 maths into v_pk_* ops that need extra
 # v_mov to pair registers: measured +12 us per render kernel on the metric frame.
@@ -44,9 +44,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False, save_temps=False):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "gft_internal.h"), os.path.join(ROOT, "include", "gftorf_rast.h"),
-               os.path.join(ROOT, "include", "gftorf_assemble.h"), os.path.join(ROOT, "include", "gftorf_knn.h"), os.path.join(ROOT, "include", "gftorf_optim.h"), os.path.join(ROOT, "include", "gftorf_deform.h"), os.path.join(ROOT, "include", "gftorf_densify.h"),
-               os.path.abspath(__file__)]
+    import glob
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))) + [os.path.abspath(__file__)]
     cc = hipcc()
     jobs = []
     for src in SOURCES:

@@ -24,9 +24,25 @@ int gft_fail(const char* fmt, ...)
 
 extern "C" const char* gft_last_error(void) { return g_err; }
 extern "C" int gft_abi_version(void) { return GFT_ABI_VERSION; }
-extern "C" size_t gft_det_partials_bytes(int64_t binning_instances)
+// ids a point_list sized for `binning_instances` holds: one head slot per tile + the pool (tile-pull binning), which
+// is also what whole-frame binning needs (binning_instances ids)
+static size_t point_list_slots(int64_t binning_instances, int32_t W, int32_t H)
 {
-    return binning_instances > 0 ? (size_t)binning_instances * 4 * GFT_ACC_STRIDE * sizeof(float) : 0;
+    if (binning_instances <= 0) return 0;
+    const size_t T = (size_t)((W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((H + GFT_TILE_Y - 1) / GFT_TILE_Y);
+    return T * (size_t)GFT_HEAD_SLOT + (size_t)binning_instances;
+}
+extern "C" size_t gft_det_partials_bytes(int64_t binning_instances, int32_t W, int32_t H)
+{
+    return point_list_slots(binning_instances, W, H) * 4 * GFT_ACC_STRIDE * sizeof(float);
+}
+// inverse of gft_binning_bytes for capacities that are multiples of 64 (what a caller that only holds the buffer needs)
+extern "C" int64_t gft_binning_capacity(size_t bytes, int32_t W, int32_t H)
+{
+    const size_t T = (size_t)((W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((H + GFT_TILE_Y - 1) / GFT_TILE_Y);
+    const size_t fixed = T * (size_t)GFT_HEAD_SLOT * 4 + GFT_ALIGN;
+    if (bytes <= fixed) return 0;
+    return (int64_t)((bytes - fixed) / 12);
 }
 
 // ---- layout ------------------------------------------------------------------
@@ -44,6 +60,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->geom_rect = o;     o = align_up(o + p * 8);
     L->geom_dirgrad = o;  o = align_up(o + p * 64);
     L->geom_clamped = o;  o = align_up(o + p);
+    L->geom_need = o;     o = align_up(o + p);
     L->geom_blockhist = o; o = align_up(o + ((p + BIN_CHUNK - 1) / BIN_CHUNK) * GFT_BLOCKHIST_TILES * 2);
     L->geom_total = o;
 
@@ -53,12 +70,10 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->img_pix_state = o;   o = align_up(o + n * 16);
     L->img_ranges = o;      o = align_up(o + T * 8);
     L->img_tile_max = o;    o = align_up(o + T * 4 * 4);   // one entry per 8x8 quadrant
-    L->img_ctrl = o;        o += GFT_CTRL_WORDS * 4;          // ctrl words and tile counters are contiguous
-    L->img_tile_cnt = o;    o += T * 4;                       // ... and so are the far-slab counters and the depth histogram
-    L->img_tile_cnt1 = o;   o += T * 4;
-    L->img_dhist = o;       o += GFT_DHIST_BINS * 4;
-    L->img_super_tab = o;   o = align_up(o + 5 * GFT_SUPER_MAX * 4);    // (cleared with them: the supertile counters are accumulated)
-    L->img_ranges1 = o;     o = align_up(o + T * 8);
+    L->img_ctrl = o;        o += GFT_CTRL_WORDS * 4;          // ctrl words, tile counters, tile cuts and the supertile tables are
+    L->img_tile_cnt = o;    o += T * 4;                       // contiguous: k_preprocess_fwd clears them in one sweep
+    L->img_tile_cut = o;    o += T * 4;
+    L->img_super_tab = o;   o = align_up(o + 3 * (size_t)GFT_SUPER_CELLS * 4);
     L->img_tile_cursor = o; o = align_up(o + T * 4);
     L->img_tile_order = o;  o = align_up(o + T * 4);
     L->img_front_len = o;   o = align_up(o + T * 4);
@@ -71,7 +86,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     const size_t r = (size_t)(R > 0 ? R : 0);
     o = 0;
     L->bin_keys = o;        o = align_up(o + r * 8);
-    L->bin_point_list = o;  o = align_up(o + r * 4);
+    L->bin_point_list = o;  o = align_up(o + (r ? T * (size_t)GFT_HEAD_SLOT + r : 0) * 4);
     L->bin_total = o + GFT_ALIGN;
 }
 
@@ -86,6 +101,7 @@ GeomView gft_geom_view(void* base, const gft_layout& L)
     g.rect = (ushort4*)(b + L.geom_rect);
     g.dirgrad = (float4*)(b + L.geom_dirgrad);
     g.clamped = (uint8_t*)(b + L.geom_clamped);
+    g.need = (uint8_t*)(b + L.geom_need);
     g.blockhist = (uint16_t*)(b + L.geom_blockhist);
     return g;
 }
@@ -99,9 +115,7 @@ ImgView gft_img_view(void* base, const gft_layout& L)
     v.tile_max = (uint32_t*)(b + L.img_tile_max);
     v.ctrl = (uint32_t*)(b + L.img_ctrl);
     v.tile_cnt = (uint32_t*)(b + L.img_tile_cnt);
-    v.tile_cnt1 = (uint32_t*)(b + L.img_tile_cnt1);
-    v.dhist = (uint32_t*)(b + L.img_dhist);
-    v.ranges1 = (uint2*)(b + L.img_ranges1);
+    v.tile_cut = (uint32_t*)(b + L.img_tile_cut);
     v.super_tab = (uint32_t*)(b + L.img_super_tab);
     v.tile_cursor = (uint32_t*)(b + L.img_tile_cursor);
     v.tile_order = (uint32_t*)(b + L.img_tile_order);
@@ -376,44 +390,53 @@ static int check_stage2(const gft_forward_io* io, const char* who)
     return 0;
 }
 
-static bool lazy_sort_enabled();
-// tuning switch: the backward accumulator's zero fill rides with the render kernel instead of the tile-pull kernel
-static bool clear_in_render()
+// GFT_LAZY_SORT=0 in the environment sorts every tile list whole (k_tile_sort_small / _big) instead of
+// head first, tail on demand; results are identical.  (Whole-frame binning only: tile-pull binning needs the flag /
+// resume protocol of the lazy sort.)
+static bool lazy_sort_enabled()
 {
-    static const bool on = [] { const char* e = getenv("GFT_CLEAR_IN_RENDER"); return e ? atoi(e) != 0 : false; }();
+    static const bool on = [] { const char* e = getenv("GFT_LAZY_SORT"); return e ? atoi(e) != 0 : true; }();
     return on;
 }
 
-// GFT_LAZY_BIN=0 in the environment bins every instance up front (no depth cut); results are identical.
-static bool lazy_bin_enabled()
-{
-    static const bool on = [] { const char* e = getenv("GFT_LAZY_BIN"); return e ? atoi(e) != 0 : true; }();
-    return on;
-}
+extern "C" int gft_lazy_sort(void) { return lazy_sort_enabled() ? 1 : 0; }
 
-// depth cut of the caller -> float bits the kernels compare depth bits with (positive floats order like their bits)
-static uint32_t cut_bits_of(float depth_cut)
+// Binning mode: 1 = tile pull (k_pull.hip, the default), 0 = whole frame (k_binning.hip: every instance counted,
+// scattered and sorted, the structure of the reference).  Results are identical; GFT_LAZY_BIN=0 in the environment or
+// gft_set_binning_mode(0) select the whole-frame path (tests compare the two bit for bit).
+static std::atomic<int> g_binning_mode{-1};
+extern "C" int gft_set_binning_mode(int mode)
 {
-    if (!(depth_cut > 0.0f) || !lazy_bin_enabled()) return GFT_NO_CUT;      // <= 0, NaN: no cut
-    uint32_t b;
-    memcpy(&b, &depth_cut, 4);
-    return b < GFT_NO_CUT ? b : GFT_NO_CUT;
+    g_binning_mode.store(mode < 0 ? -1 : (mode ? 1 : 0));      // (< 0: back to the environment's choice)
+    return 0;
 }
+static bool pull_enabled(const gft_config* cfg)
+{
+    int m = g_binning_mode.load();
+    if (m < 0) {
+        const char* e = getenv("GFT_LAZY_BIN");
+        m = e ? (atoi(e) != 0) : 1;
+        g_binning_mode.store(m);
+    }
+    return m != 0 && lazy_sort_enabled() && gft_tile_pull_ok(*cfg);
+}
+extern "C" int gft_binning_mode(const gft_config* cfg) { return (cfg && pull_enabled(cfg)) ? 1 : 0; }
 
-// preprocess + tile counting + scan; the totals arrive in the mailbox slot
+// preprocess + instance counting; the totals arrive in the mailbox slot
 static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
-                          const ImgView& im, uint32_t* mail_dev, uint32_t seq, uint32_t cut_bits, int per_tile = 0)
+                          const ImgView& im, uint32_t* mail_dev, uint32_t seq, bool pull)
 {
     {
-        // (the preprocess kernel also zeroes the ctrl words, the tile counters of both slabs, the depth histogram and
-        // the supertile table for the binning kernels behind it: no fill launch)
+        // (the preprocess kernel also zeroes the ctrl words, the tile counters and the supertile tables for the binning
+        // kernels behind it: no fill launch)
         StageTimer t(s, ST_PRE_FWD);
-        GFT_STAGE(s, cfg, "preprocess_fwd", gft_launch_preprocess_fwd(s, *cfg, *io, g, im, mail_dev, cut_bits));
+        GFT_STAGE(s, cfg, "preprocess_fwd", gft_launch_preprocess_fwd(s, *cfg, *io, g, im, mail_dev, pull));
     }
     if (io->grads_zero && io->grads_zero_bytes) {
-        // Zero fill of the backward's gradient tensors on the side stream, behind the preprocess kernel: it runs beside
-        // the binning kernels, which wait on latencies and leave HBM and half of every CU's wave slots idle (beside
-        // the render kernel, which is bound by VALU issue, it cost more than it saved: +63 us for 34 us)
+        // Test / tuning switch (GFT_GRADS_ZERO_FILL=1 in api.py, off by default): zero fill of the backward's gradient
+        // tensors on the side stream, behind the preprocess kernel.  HAZARD, which is why it stays a switch: only
+        // gft_backward makes the caller's stream wait for the fill; a caller that drops the graph without running the
+        // backward may hand the buffer to other work while the fill is still pending.
         SideFill* f = side_of_current_device();
         if (!f) return gft_fail("forward: no side stream for the gradient fill");
         GFT_CHECK_HIP(hipEventRecord(f->after_main, s));
@@ -424,55 +447,48 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
     }
     {
         StageTimer t(s, ST_TILE_COUNT);
-        if (cut_bits != GFT_NO_CUT) {
-            // near slab: supertile count (tile-pull binning, k_binning.hip); also totals, depth histogram, mailbox
+        if (pull) {
             BinView none;
             none.keys = nullptr; none.point_list = nullptr;
-            GFT_STAGE(s, cfg, "super_count", gft_launch_super_bin(s, *cfg, g, im, none, mail_dev, seq, cut_bits, 0, 0u, per_tile));
+            GFT_STAGE(s, cfg, "super_count", gft_launch_super_bin(s, *cfg, g, im, none, mail_dev, seq, 0, 0u));
         } else {
-            GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im, mail_dev, seq, cut_bits, 0, 0u, per_tile));
+            GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im, mail_dev, seq));
         }
     }
     return 0;
 }
 
-// GFT_LAZY_SORT=0 in the environment sorts every tile list whole (k_tile_sort_small / _big) instead of
-// head first, tail on demand (k_tile_front / k_tile_tail); results are identical.
-static bool lazy_sort_enabled()
-{
-    static const bool on = [] { const char* e = getenv("GFT_LAZY_SORT"); return e ? atoi(e) != 0 : true; }();
-    return on;
-}
-
-extern "C" int gft_lazy_sort(void) { return lazy_sort_enabled() ? 1 : 0; }
-
-// scatter + per-tile sort + render; `cap` = instances the binning buffer holds.  With
-// check_cap the kernels compare the device-side count against it and do nothing on overflow.
-// `cut_bits` as given to stage 1; `expect0`: the caller's estimate of the instances the first scatter moves.
+// binning + render; `cap` = instances the binning buffer holds.  With check_cap the kernels compare the device-side
+// count against it and do nothing on overflow.
 static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
                           const ImgView& im, const BinView& b, bool binned, int64_t max_tile_list, bool check_cap,
-                          uint32_t cap, uint32_t cut_bits, int64_t expect0, uint32_t* late_mail = nullptr, uint32_t seq = 0u)
+                          uint32_t cap, bool pull)
 {
     // The backward's accumulator clear (64 B per Gaussian of pure HBM writes) rides along with the
-    // tile sort, whose workgroups are bound by LDS and VALU: each writes a slice of zeros first.
+    // per-tile sort kernels, whose workgroups are bound by LDS and VALU: each writes a slice of zeros first.
     float* clear = (io->acc && cfg->want_backward && cfg->P > 0) ? io->acc : nullptr;
     const size_t clear_bytes = (size_t)cfg->P * GFT_ACC_STRIDE * sizeof(float);
     const bool lazy = binned && lazy_sort_enabled();
-    if (binned && cut_bits != GFT_NO_CUT) {
-        // near slab by tile-pull binning: ids to supertiles, then every tile collects, sorts and writes its own list
+    pull = pull && binned;
+    if (pull) {
+        // tile-pull binning: ids to supertiles, every tile collects, sorts and writes the head of its own list, the
+        // Gaussians in a head get their appearance
         {
             StageTimer t(s, ST_TILE_SCATTER);
-            GFT_STAGE(s, cfg, "super_scatter", gft_launch_super_bin(s, *cfg, g, im, b, nullptr, 0u, cut_bits, 1, cap, 0));
+            GFT_STAGE(s, cfg, "super_scatter", gft_launch_super_bin(s, *cfg, g, im, b, nullptr, 0u, 1, cap));
         }
         {
             StageTimer t(s, ST_TILE_SORT);
-            GFT_STAGE(s, cfg, "tile_pull", gft_launch_tile_pull(s, *cfg, g, im, b, cap, clear_in_render() ? nullptr : clear,
-                                                                clear_in_render() ? 0 : clear_bytes));
+            GFT_STAGE(s, cfg, "tile_pull", gft_launch_tile_pull(s, *cfg, g, im, b, cap, clear, clear_bytes));
+        }
+        {
+            StageTimer t(s, ST_PRE_FWD);
+            GFT_STAGE(s, cfg, "appearance", gft_launch_appearance(s, *cfg, *io, g, im, cap));
         }
     } else if (binned) {
         {
             StageTimer t(s, ST_TILE_SCATTER);
-            GFT_STAGE(s, cfg, "tile_scatter", gft_launch_tile_scatter(s, *cfg, g, im, b, cap, cut_bits, 0, expect0));
+            GFT_STAGE(s, cfg, "tile_scatter", gft_launch_tile_scatter(s, *cfg, g, im, b, cap, (int64_t)cap));
         }
         {
             StageTimer t(s, ST_TILE_SORT);
@@ -486,37 +502,21 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
     }
     {
         StageTimer t(s, ST_RENDER_FWD);
-        // (tile-pull path: the accumulator clear rides with the render kernel, whose HBM traffic is small)
-        const bool pull = binned && cut_bits != GFT_NO_CUT && clear_in_render();
-        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, check_cap, cap, lazy ? 1 : 0,
-                                                              pull ? clear : nullptr, pull ? clear_bytes : 0));
+        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, check_cap, cap, lazy ? 1 : 0, pull));
     }
     if (lazy) {
-        // quadrants that used up the sorted head of their list: sort those tails, continue those quadrants
-        // (all these kernels leave at once when the first pass raised no flag).  With a depth cut the far slab
-        // is binned first, for the tiles that have such a quadrant.
-        if (cut_bits != GFT_NO_CUT) {
-            {
-                // the far Gaussians were given no appearance (SH colour, phasor) by the preprocess kernel
-                StageTimer t(s, ST_PRE_FWD);
-                GFT_STAGE(s, cfg, "appearance_far", gft_launch_appearance_far(s, *cfg, *io, g, im, cut_bits, cap));
-            }
-            {
-                StageTimer t(s, ST_TILE_COUNT);
-                GFT_STAGE(s, cfg, "tile_count_far", gft_launch_tile_count(s, *cfg, g, im, nullptr, 0u, cut_bits, 1, cap, 0));
-            }
-            {
-                StageTimer t(s, ST_TILE_SCATTER);
-                GFT_STAGE(s, cfg, "tile_scatter_far", gft_launch_tile_scatter(s, *cfg, g, im, b, cap, cut_bits, 1, (int64_t)cap));
-            }
-        }
+        // quadrants that used up the sorted head of their list with unsaturated pixels: complete those lists, continue
+        // those quadrants (both launches leave at once when the first pass raised no flag)
         {
             StageTimer t(s, ST_TILE_SORT);
-            GFT_STAGE(s, cfg, "tile_tail", gft_launch_tile_tail(s, *cfg, g, im, b, cap, late_mail, seq, cfg->want_backward != 0));
+            if (pull)
+                GFT_STAGE(s, cfg, "tail_build", gft_launch_tail_build(s, *cfg, *io, g, im, b, cap, cfg->want_backward != 0));
+            else
+                GFT_STAGE(s, cfg, "tile_tail", gft_launch_tile_tail(s, *cfg, g, im, b, cap, cfg->want_backward != 0));
         }
         {
             StageTimer t(s, ST_RENDER_FWD);
-            GFT_STAGE(s, cfg, "render_resume", gft_launch_render_fwd(s, *cfg, *io, g, im, b, check_cap, cap, 2));
+            GFT_STAGE(s, cfg, "render_resume", gft_launch_render_fwd(s, *cfg, *io, g, im, b, check_cap, cap, 2, pull));
         }
     }
     if (g_prof.on) { std::lock_guard<std::mutex> lk(g_prof.mu); g_prof.fwd++; }
@@ -540,7 +540,7 @@ extern "C" int gft_forward_preprocess(void* hip_stream, const gft_config* cfg, c
     ImgView im = gft_img_view(io->img, L);
     uint32_t* mail_dev; volatile uint32_t* mail_host; uint32_t seq;
     if (mailbox_acquire(&mail_dev, &mail_host, &seq)) return 1;
-    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq, GFT_NO_CUT)) return 1;
+    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq, pull_enabled(cfg))) return 1;
     // the one blocking read of the forward (reference rasterizer_impl.cu:311)
     uint32_t host[GFT_CTRL_WORDS];
     if (mailbox_wait(s, mail_host, seq, host)) return 1;
@@ -553,7 +553,7 @@ extern "C" int gft_forward_preprocess(void* hip_stream, const gft_config* cfg, c
 
 // ---- forward, stage 2 -----------------------------------------------------------
 extern "C" int gft_forward_render(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
-                                  int64_t binning_instances, int64_t max_tile_list, float depth_cut)
+                                  int64_t binning_instances, int64_t max_tile_list)
 {
     if (check_config(cfg)) return 1;
     if (!io) return gft_fail("gft_forward_render: io is NULL");
@@ -568,15 +568,15 @@ extern "C" int gft_forward_render(void* hip_stream, const gft_config* cfg, const
     GeomView g = gft_geom_view(io->geom, L);
     ImgView im = gft_img_view(io->img, L);
     BinView b = gft_bin_view(io->binning, L);
-    if (cfg->P == 0) {
-        // no stage 1 ran: every tile list is empty, all totals are zero
+    const bool pull = cfg->P > 0 && pull_enabled(cfg);
+    if (cfg->P == 0 || (pull && R == 0)) {
+        // no stage 1 ran (or its tile-pull count pass, which leaves the per-tile tables to the pull kernel): every tile
+        // list is empty, all totals are zero
         const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
         GFT_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s));
-        GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, GFT_CTRL_WORDS * sizeof(uint32_t), s));
+        if (cfg->P == 0) GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, GFT_CTRL_WORDS * sizeof(uint32_t), s));
     }
-    // the cut stage 1 counted with: the near-slab ranges it produced only hold those instances
-    const uint32_t cut_bits = (lazy_sort_enabled() && R > 0 && gft_tile_pull_ok(*cfg)) ? cut_bits_of(depth_cut) : GFT_NO_CUT;
-    return enqueue_stage2(s, cfg, io, g, im, b, R > 0, max_tile_list, cfg->P > 0, (uint32_t)R, cut_bits, R);
+    return enqueue_stage2(s, cfg, io, g, im, b, R > 0, max_tile_list, cfg->P > 0, (uint32_t)R, pull);
 }
 
 // ---- forward, one call ------------------------------------------------------------
@@ -589,7 +589,7 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     if (check_stage2(io, "gft_forward")) return 1;
     const int64_t binning_instances = hints->binning_instances;
     if (binning_instances < 0 || binning_instances > 0xffffffffll) return gft_fail("gft_forward: bad instance count");
-    if (cfg->P == 0) return gft_forward_render(hip_stream, cfg, io, 0, 0, 0.0f);
+    if (cfg->P == 0) return gft_forward_render(hip_stream, cfg, io, 0, 0);
     if (check_stage1(cfg, io, "gft_forward")) return 1;
     if (binning_instances > 0 && !io->binning) return gft_fail("gft_forward: binning buffer is NULL");
     hipStream_t s = (hipStream_t)hip_stream;
@@ -600,25 +600,24 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     BinView b = gft_bin_view(io->binning, L);
     uint32_t* mail_dev; volatile uint32_t* mail_host; uint32_t seq;
     if (mailbox_acquire(&mail_dev, &mail_host, &seq)) return 1;
-    // lazy binning needs the flag / resume protocol of the lazy sort and a binning buffer to work with
-    const uint32_t cut_bits = (lazy_sort_enabled() && binning_instances > 0 && gft_tile_pull_ok(*cfg)) ? cut_bits_of(hints->depth_cut) : GFT_NO_CUT;
-    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq, cut_bits, hints->near_per_tile)) return 1;
+    const bool pull = pull_enabled(cfg);
+    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq, pull)) return 1;
+    if (pull && binning_instances == 0) {
+        // (no buffer: stage 2 renders empty lists, which is right only if R turns out to be 0 -- else the caller re-runs it)
+        const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+        GFT_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s));
+    }
     // stage 2 is queued before R is known; its kernels check R against the buffer themselves
     const uint32_t cap = (uint32_t)binning_instances;
-    const int64_t expect0 = (cut_bits != GFT_NO_CUT && hints->near_instances > 0) ? hints->near_instances : binning_instances;
-    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, cap, cut_bits, expect0, mail_dev, seq))
+    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, cap, pull))
         return 1;
-    report->late_slot = (int32_t)(mail_dev - g_mail.dev) / GFT_CTRL_WORDS;
-    report->late_seq = seq;
     uint32_t host[GFT_CTRL_WORDS];
     if (mailbox_wait(s, mail_host, seq, host)) return 1;
     if (host[GFT_CTRL_FLAGS] & 1u)
         return gft_fail("Point is filtered although prefiltered is set. This shouldn't happen!");
     report->num_rendered = (int64_t)host[GFT_CTRL_TOTAL];
     report->max_tile_list = (int64_t)host[GFT_CTRL_MAXCNT];
-    report->near_instances = (int64_t)host[GFT_CTRL_TOTAL0];
-    memcpy(&report->depth_cut_next, &host[GFT_CTRL_CUTNEXT], 4);
-    if (host[GFT_CTRL_CUTNEXT] >= GFT_NO_CUT || !lazy_bin_enabled()) report->depth_cut_next = 0.0f;    // "bin everything"
+    report->list_entries = pull ? (int64_t)host[GFT_CTRL_ENTRIES] : (int64_t)host[GFT_CTRL_TOTAL];
     // The hint said "no tile list longer than the short-sort limit" and the frame has one: its
     // tiles were rendered unsorted.  Sort them and render again (the contributing-pixel counters
     // are the only accumulated output).
@@ -626,21 +625,8 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
         host[GFT_CTRL_MAXCNT] > GFT_SHORT_LIST_MAX && host[GFT_CTRL_TOTAL] <= cap && binning_instances > 0) {
         GFT_CHECK_HIP(hipMemsetAsync(io->pixels, 0, (size_t)cfg->P * sizeof(float), s));
         GFT_STAGE(s, cfg, "tile_sort_long", gft_launch_tile_sort_long(s, *cfg, im, b, cap));
-        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, true, cap, 0));
+        GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, true, cap, 0, false));
     }
-    return 0;
-}
-
-// The late report of a gft_forward(): quadrants that outlived the near slab / the sorted head.  Never blocks.
-extern "C" int gft_forward_late(int32_t slot, uint32_t seq, int64_t* flagged_quadrants)
-{
-    if (!flagged_quadrants) return gft_fail("gft_forward_late: NULL argument");
-    *flagged_quadrants = -1;
-    std::lock_guard<std::mutex> lk(g_mail.mu);
-    if (!g_mail.host || slot < 0 || slot >= GFT_MAIL_SLOTS) return gft_fail("gft_forward_late: no such report");
-    volatile uint32_t* h = g_mail.host + (size_t)slot * GFT_CTRL_WORDS;
-    // not written yet, or the slot has been reused by a later forward: "unknown"
-    if (__atomic_load_n(&h[GFT_CTRL_SEQ2], __ATOMIC_ACQUIRE) == seq && h[GFT_CTRL_SEQ] == seq) *flagged_quadrants = (int64_t)h[GFT_CTRL_NFLAG];
     return 0;
 }
 
@@ -690,7 +676,7 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     if (num_rendered > 0 && io->det_partials) {
         // deterministic mode: slots of (entry, quadrant) pairs that store no row must read as zero
         StageTimer t(s, ST_MEMSET);
-        GFT_CHECK_HIP(hipMemsetAsync(io->det_partials, 0, gft_det_partials_bytes(num_rendered), s));
+        GFT_CHECK_HIP(hipMemsetAsync(io->det_partials, 0, gft_det_partials_bytes(num_rendered, cfg->W, cfg->H), s));
     }
     if (num_rendered > 0) {
         StageTimer t(s, ST_RENDER_BWD);

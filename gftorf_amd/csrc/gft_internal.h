@@ -29,13 +29,14 @@ inline hipError_t gft_lds_opt_in(const void* kernel, size_t bytes, std::atomic<u
 
 // ---- scratch views -------------------------------------------------------
 struct GeomView {
-    float4* rec_a;      // [P][2]  {x,y,ca,cb} {cc,opacity,dist_ndc,dist}
-    float4* rec_b;      // [P][2]  {r,g,b,R} {I,Am,phase_sh,amp}
+    float4* rec_a;      // [P][2]  {x,y,ca,cb} {cc,opacity,dist_ndc,dist}: every visible Gaussian
+    float4* rec_b;      // [P][2]  {r,g,b,R} {I,Am,phase_sh,amp}: the Gaussians marked in `need` (all visible ones in the whole-frame binning mode)
     float* depth;       // [P]
     uint32_t* tiles;    // [P]
     ushort4* rect;      // [P] tile rectangle {x0,y0,x1,y1}; all zero when culled
-    float4* dirgrad;    // [P][4] d(rgb)/d(dir) 9, d(phase,amp)/d(dir) 6, pad (forward with want_backward)
-    uint8_t* clamped;   // [P]
+    float4* dirgrad;    // [P][4] d(rgb)/d(dir) 9, d(phase,amp)/d(dir) 6, pad (forward with want_backward; as rec_b)
+    uint8_t* clamped;   // [P]   (as rec_b)
+    uint8_t* need;      // [P]   tile-pull binning: 1 = the Gaussian is in the sorted part of some tile list, its appearance records exist
     uint16_t* blockhist; // [ceil(P/4096)][GFT_BLOCKHIST_TILES] tile hits of every 4096-Gaussian block (T <= GFT_BLOCKHIST_TILES)
 };
 
@@ -43,45 +44,44 @@ struct ImgView {
     float4* pix_state;    // [N] {final_T, n_contrib bits, w_z, w_z2}
     float4* pix_sums;     // [N][2] {C0, C1, C2, R}, {I, Am, dist, A}: final sums of the blend, without background
     float4* snaps;        // [4T][segments - 1][3][64] blend state of every quadrant in front of list entries 256, 512, ...
-    uint2* ranges;        // [T]
-    uint32_t* tile_max;   // [T]
-    uint32_t* ctrl;       // [8], directly followed by tile_cnt (one memset clears both)
-    uint32_t* tile_cnt;   // [T]  instances per tile of the near slab (all instances without a depth cut)
-    uint32_t* tile_cnt1;  // [T]  lazy binning: instances per flagged tile of the far slab
-    uint32_t* dhist;      // [GFT_DHIST_BINS] instances per log-depth bin (picks the next frame's depth cut)
-    uint2* ranges1;       // [T]  lazy binning: far-slab segment of every tile (valid once a quadrant was flagged)
-    uint32_t* super_tab;  // [5][GFT_SUPER_MAX] lazy binning: per supertile entry count, list start, scatter cursor, id-list region, cursor
+    uint2* ranges;        // [T]  the tile's id list [first, last) inside point_list
+    uint32_t* tile_max;   // [T][4] deepest contributor per 8x8 quadrant
+    uint32_t* ctrl;       // [GFT_CTRL_WORDS], directly followed by tile_cnt, tile_cut, super_tab (cleared together by k_preprocess_fwd)
+    uint32_t* tile_cnt;   // [T]  instances per tile
+    uint32_t* tile_cut;   // [T]  tile-pull binning: last depth bin inside the sorted head; GFT_NO_TAIL when the head is the whole list
+    uint32_t* super_tab;  // [3][GFT_SUPER_CELLS] tile-pull binning: per (supertile, depth slab) entry count, list start, scatter cursor
     uint32_t* tile_cursor;// [T]
-    uint32_t* tile_order; // [T] tiles by backward weight, heaviest first (written by the backward)
-    uint32_t* front_len;  // [T] lazy sort: length of the sorted head of the tile's id list
-    uint32_t* unit_flag;  // [4T] lazy sort: quadrant reached the end of the head unsaturated
-    float4* resume_state; // [N][4] lazy sort: blend state of the pixels of flagged quadrants
+    uint32_t* tile_order; // [T] tiles by backward weight, heaviest first
+    uint32_t* front_len;  // [T] length of the sorted head of the tile's id list
+    uint32_t* unit_flag;  // [4T] quadrant reached the end of the head unsaturated
+    float4* resume_state; // [N][4] blend state of the pixels of flagged quadrants
 };
 
 struct BinView {
-    uint64_t* keys;        // [R] (depth bits << 32 | id), grouped by tile
-    uint32_t* point_list;  // [R]
+    uint64_t* keys;        // [cap] whole-frame binning: (depth bits << 32 | id) grouped by tile; tile-pull binning: the supertile entry lists
+    uint32_t* point_list;  // [T * GFT_HEAD_SLOT + cap] whole-frame binning: ids per tile in [0, R); tile-pull binning: one head slot per
+                           // tile, then the pool of the lists that were completed on demand (head copy + culled tail)
 };
 
 // ctrl words (uint32)
 #define GFT_CTRL_TOTAL 0     // R = number of (Gaussian, tile) instances
 #define GFT_CTRL_FLAGS 1     // bit0: prefiltered point culled
-#define GFT_CTRL_MAXCNT 2    // longest tile list
-#define GFT_CTRL_NFLAG 4     // lazy sort: number of flagged quadrants
-#define GFT_CTRL_DONE 3      // finished k_tile_count workgroups (ticket for the fused scan)
+#define GFT_CTRL_MAXCNT 2    // longest tile list (whole-frame binning; 0 with tile-pull binning, which never forms the lists)
+#define GFT_CTRL_NFLAG 4     // number of flagged quadrants (ran out of sorted entries before saturating)
+#define GFT_CTRL_DONE 3      // finished workgroups of the count kernel (ticket for its fused scan)
 #define GFT_CTRL_SEQ 3       // host mailbox only: sequence number, written last
-#define GFT_CTRL_TOTAL0 5    // lazy binning: instances of the near slab (view z <= depth cut), binned up front
-#define GFT_CTRL_CUTNEXT 6   // lazy binning: float bits of the depth cut suggested for the next frame of this kind
-#define GFT_CTRL_DONE1 7     // finished workgroups of the far-slab count (ticket for its scan)
-#define GFT_CTRL_TOTAL1 8    // lazy binning: far-slab instances binned for the flagged tiles
-#define GFT_CTRL_NEARSUM 9   // tile-pull binning: instances of the near slab as summed by the supertile count pass
-#define GFT_CTRL_SEQ2 10     // host mailbox only: sequence number of the late report (flagged quadrants), written by k_tile_tail
-#define GFT_CTRL_ORDER_OK 11 // the forward computed the backward's heavy-first tile order (no quadrant was flagged)
+#define GFT_CTRL_ENTRIES 5   // tile-pull binning: (Gaussian, supertile) entries
+#define GFT_CTRL_POOLCUR 6   // tile-pull binning: ids taken from the pool of completed lists
+#define GFT_CTRL_DONE2 7     // finished workgroups of k_tail_build (ticket for the backward's tile order)
+#define GFT_CTRL_RSUM 9      // tile-pull binning: R as summed by the supertile count pass
+#define GFT_CTRL_ORDER_OK 11 // the forward computed the backward's heavy-first tile order
 #define GFT_CTRL_WORDS 16
-#define GFT_DHIST_BINS 256   // log-spaced depth bins between near_n and far_n
 #define GFT_SUPER_MAX 1024   // supertiles (groups of S x S tiles) of the tile-pull binning
-#define GFT_NEAR_SLAB_PER_TILE 896u   // wanted mean list length of the near slab
-#define GFT_NO_CUT 0x7f800000u        // +inf: every instance belongs to the near slab
+#define GFT_SLAB_MAX 16      // depth slabs per supertile list
+#define GFT_SUPER_CELLS (GFT_SUPER_MAX * GFT_SLAB_MAX)
+#define GFT_DEPTH_BINS 4096  // depth bins a supertile entry carries (12 bits); slab = top bits of the bin
+#define GFT_HEAD_SLOT 2048u  // ids per tile head slot = longest sorted head
+#define GFT_NO_TAIL 0xffffffffu
 #define GFT_BLOCKHIST_TILES 2048
 // binning workgroup shape (k_binning.hip): 16 waves per workgroup keep one CU busy on their own
 #ifndef BIN_THREADS
@@ -125,32 +125,40 @@ int gft_fail(const char* fmt, ...);
     } while (0)
 
 // ---- stage launchers (each enqueues on `s`, returns hipError_t) -----------
+// defer_appearance: geometry only (rectangle, depth, radius, geometry record); the appearance records follow from
+// gft_launch_appearance for the Gaussians the tile-pull binning marks in `need`
 hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
-                                     const GeomView& g, const ImgView& im, uint32_t* mail, uint32_t cut_bits);
-hipError_t gft_launch_appearance_far(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
-                                     const ImgView& im, uint32_t cut_bits, uint32_t cap);
-// pass 0: near slab (view z <= cut; everything with GFT_NO_CUT) + depth histogram + scan + mailbox;
-// pass 1: far slab of the tiles with a flagged quadrant (leaves at once when no quadrant was flagged)
+                                     const GeomView& g, const ImgView& im, uint32_t* mail, bool defer_appearance);
+hipError_t gft_launch_appearance(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
+                                 const ImgView& im, uint32_t cap);
+// whole-frame binning (reference structure: every instance counted, scattered and sorted)
 hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                 uint32_t* mail, uint32_t seq, uint32_t cut_bits, int pass, uint32_t cap, int per_tile);
+                                 uint32_t* mail, uint32_t seq);
 hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                   const BinView& b, uint32_t cap, uint32_t cut_bits, int pass, int64_t expect);
-bool gft_tile_pull_ok(const gft_config& c);      // the frame's tile grid fits the supertile tables of the lazy binning
-hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
-                                uint32_t* mail, uint32_t seq, uint32_t cut_bits, int pass, uint32_t cap, int per_tile);
-hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
-                                uint32_t cap, float* clear, size_t clear_bytes);
+                                   const BinView& b, uint32_t cap, int64_t expect);
 hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_tile_list, const ImgView& im,
                                 const BinView& b, uint32_t cap, float* clear, size_t clear_bytes);
 hipError_t gft_launch_tile_front(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b, uint32_t cap,
                                  float* clear, size_t clear_bytes);
 hipError_t gft_launch_tile_tail(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                const BinView& b, uint32_t cap, uint32_t* late_mail, uint32_t seq, bool want_order);
+                                const BinView& b, uint32_t cap, bool want_order);
 hipError_t gft_launch_tile_sort_long(hipStream_t s, const gft_config& c, const ImgView& im, const BinView& b,
                                      uint32_t cap);
+// tile-pull binning (k_binning.hip, k_tail.hip): ids to supertiles, every tile pulls and sorts the head of its list,
+// lists are completed on demand for the tiles with a flagged quadrant
+bool gft_tile_pull_ok(const gft_config& c);      // the frame's tile grid fits the supertile tables
+struct SuperShape { int gx, gy, T, sshift, sgx, sgy, NS, K, kshift; uint32_t near_bits; int bin_shift; };
+SuperShape gft_super_shape(const gft_config& c);
+hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
+                                uint32_t* mail, uint32_t seq, int pass, uint32_t cap);
+hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
+                                uint32_t cap, float* clear, size_t clear_bytes);
+hipError_t gft_launch_tail_build(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
+                                 const ImgView& im, const BinView& b, uint32_t cap, bool want_order);
+// lazy: 0 = lists sorted whole, 1 = first pass over the sorted heads, 2 = resume pass of the flagged quadrants
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b, bool check_cap, uint32_t cap,
-                                 int lazy, float* clear = nullptr, size_t clear_bytes = 0);
+                                 int lazy, bool pull);
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b, bool lazy);
 hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
@@ -199,13 +207,39 @@ __device__ __forceinline__ void gft_get_rect(float px, float py, int radius, int
     y1 = min(gy, max(0, (int)((((py + r) + 16.0f) - 1.0f) / 16.0f)));
 }
 
+// Can a splat reach the 8x8 pixel quadrant whose first pixel centre is (qx0, qy0)?  a0 = {x, y, conic a, b},
+// a1 = {conic c, opacity, ..}.  alpha = min(0.99, o*exp(power)) >= 1/255  <=>  power >= -tau, tau = ln(255 o), i.e. the
+// pixels that can blend this splat lie in the ellipse q(u) = a ux^2 + 2 b ux uy + c uy^2 <= 2 tau around the centre.
+// The quadrant's pixel centres span a rectangle; q is convex with its minimum at the centre, so its minimum over the
+// rectangle sits on an edge facing the centre: two 1-D clamped minimisations.  (A bounding-box test passes 195 of 429
+// walked splats per quadrant on the metric frame, this one 154; 144 really touch a pixel.)  Conservative: a splat that
+// fails can blend into no pixel of the quadrant (forward.cu:536-548).
+__device__ __forceinline__ bool gft_splat_reaches_quadrant(const float4& a0, const float4& a1, float qx0, float qy0)
+{
+    const float ca = a0.z, cb = a0.w, cc = a1.x, op = a1.y;
+    const float det = ca * cc - cb * cb;
+    const float tau = __logf(255.0f * op);
+    if (!(tau > 0.0f)) return false;            // opacity <= 1/255: can never pass the alpha test
+    if (!(det > 0.0f && ca > 0.0f && cc > 0.0f)) return true;   // degenerate conic: let the pixel test decide
+    const float ux0 = qx0 - a0.x, ux1 = ux0 + 7.0f;
+    const float uy0 = qy0 - a0.y, uy1 = uy0 + 7.0f;
+    const float X = fminf(fmaxf(0.0f, ux0), ux1), Y = fminf(fmaxf(0.0f, uy0), uy1);   // rectangle point nearest the centre, per axis
+    const float ys = fminf(fmaxf(-cb * X * __frcp_rn(cc), uy0), uy1);
+    const float xs = fminf(fmaxf(-cb * Y * __frcp_rn(ca), ux0), ux1);
+    const float q1 = ca * X * X + 2.0f * cb * X * ys + cc * ys * ys;
+    const float q2 = ca * xs * xs + 2.0f * cb * xs * Y + cc * Y * Y;
+    return fminf(q1, q2) <= 2.0f * tau * 1.0005f + 0.01f;       // margins keep the test conservative
+}
+
 // Heavy-first launch order for the backward: the work of a quadrant is proportional to its
 // deepest contributor (known from the forward) and varies by an order of magnitude, so tiles
 // are bucket-sorted by that weight (64 buckets, descending) and dealt to the XCDs round-robin;
 // the hardware dispatcher then fills free wave slots with the longest remaining units first.
 // One workgroup; the order inside a bucket is arbitrary and only affects scheduling.
-// (called by all 1024 threads of one workgroup)
-__device__ inline void gft_tile_order_block(int T, const uint32_t* __restrict__ quad_max, uint32_t* __restrict__ order)
+// (called by all threads of one workgroup).  `flag` (may be NULL): quadrants that will walk further than quad_max
+// says (their lists are completed after this order is taken): their tiles go first.
+__device__ inline void gft_tile_order_block(int T, const uint32_t* __restrict__ quad_max, uint32_t* __restrict__ order,
+                                            const uint32_t* __restrict__ flag = nullptr)
 {
     __shared__ uint32_t s_max;
     __shared__ uint32_t cnt[64], base[64];
@@ -213,29 +247,30 @@ __device__ inline void gft_tile_order_block(int T, const uint32_t* __restrict__ 
     if (tid == 0) s_max = 0;
     if (tid < 64) cnt[tid] = 0;
     __syncthreads();
-    uint32_t m = 0;
-    for (int t = tid; t < T; t += 1024) {
+    // weight of a tile: its deepest quadrant walk; a flagged quadrant's walk is not over: the tile counts as the heaviest
+    auto weight = [&](int t) -> uint32_t {
         const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
-        m = max(m, max(max(q.x, q.y), max(q.z, q.w)));
-    }
+        return max(max(q.x, q.y), max(q.z, q.w));
+    };
+    auto flagged = [&](int t) -> bool {
+        if (!flag) return false;
+        const uint4 f = reinterpret_cast<const uint4*>(flag)[t];
+        return (f.x | f.y | f.z | f.w) != 0u;
+    };
+    uint32_t m = 0;
+    for (int t = tid; t < T; t += (int)blockDim.x) m = max(m, weight(t));
     atomicMax(&s_max, m);
     __syncthreads();
     const uint32_t wmax = s_max + 1;
-    for (int t = tid; t < T; t += 1024) {
-        const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
-        const uint32_t w = max(max(q.x, q.y), max(q.z, q.w));
-        atomicAdd(&cnt[63 - (w * 64u) / wmax], 1u);
-    }
+    for (int t = tid; t < T; t += (int)blockDim.x) atomicAdd(&cnt[flagged(t) ? 0u : 63 - (weight(t) * 64u) / wmax], 1u);
     __syncthreads();
     if (tid == 0) {
         uint32_t acc = 0;
         for (int b = 0; b < 64; b++) { base[b] = acc; acc += cnt[b]; cnt[b] = 0; }
     }
     __syncthreads();
-    for (int t = tid; t < T; t += 1024) {
-        const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
-        const uint32_t w = max(max(q.x, q.y), max(q.z, q.w));
-        const uint32_t b = 63 - (w * 64u) / wmax;
+    for (int t = tid; t < T; t += (int)blockDim.x) {
+        const uint32_t b = flagged(t) ? 0u : 63 - (weight(t) * 64u) / wmax;
         order[base[b] + atomicAdd(&cnt[b], 1u)] = (uint32_t)t;
     }
 }

@@ -1,0 +1,736 @@
+// k_pull.hip -- tile-pull instance binning (gfx950): what is binned, sorted and given an appearance is what
+// can be seen, decided from THIS frame (no hints from earlier frames: a training loop draws another camera
+// every iteration, train.py:155-163).
+//
+// A pixel stops reading its tile list once its transmittance is below 1e-4 (reference forward.cu:560-565), so
+// in a dense frame most (Gaussian, tile) instances are never read (1 M metric frame: 3.6 M instances, 0.6 M up
+// to the deepest contributor of every tile).  The reference duplicates every Gaussian into 64-bit (tile, depth)
+// keys and radix-sorts all R of them (rasterizer_impl.cu:72-140,307-348).  Here:
+//
+//   k_super_bin<0/1> : every visible Gaussian is dealt to the SUPERTILES (S x S tiles) its rectangle touches: one
+//                      8-byte entry `id | rectangle relative to the supertile (4 x 5 bits) | depth bin (12 bits)`
+//                      per (Gaussian, supertile); count pass (+ R, mailbox), then scatter with one reserved chunk
+//                      per (workgroup, supertile, depth slab)                      [8 B per entry, ~0.5 per instance]
+//   k_tile_pull      : one workgroup per tile scans its supertile's entries (L2), histograms its hits over the
+//                      depth bins, takes the nearest ~940 (whole bins) as the HEAD of its list: gathers their
+//                      depths, sorts the (depth bits, id) keys in LDS, writes the ids into the tile's head slot
+//                      and marks those Gaussians as needed (appearance on demand, k_preprocess.hip).  The rest
+//                      of the list is never formed unless somebody walks that far.
+//   k_tail_build     : for the tiles with a FLAGGED quadrant (walked its whole head with unsaturated pixels --
+//                      the silhouette quadrants of a scene, whose pixels never saturate): pulls the rest of the
+//                      list, CULLS it against the flagged quadrants (most entries of a tile do not reach a given
+//                      8x8 quadrant), gives the survivors their appearance, sorts them and writes head + culled
+//                      tail as one list into the pool; the render kernel's resume pass and the backward walk
+//                      that list.  Non-reaching entries contribute nothing to any pixel of those quadrants, so
+//                      the blend is the same arithmetic sequence as over the reference's full list: images,
+//                      pixel counts and gradients are bit-identical to whole-frame binning (k_binning.hip).
+//
+// Depth bins are a monotone integer function of the depth bits (no transcendental): keys of a lower bin are
+// smaller than keys of a higher bin, so "all entries of the first bins, sorted" is a prefix of the reference's
+// sorted list.
+#include "gft_internal.h"
+#include "gft_sort.h"
+#include "gft_appearance.h"      // (floating-point contraction is off from here on)
+
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+#define TPULL_KEYS GFT_HEAD_SLOT    // 16 KB of LDS for the head's keys
+#define HEAD_DIRECT 1024u           // lists (scanned hits) up to this length are sorted whole
+#define HEAD_TARGET 940u            // wanted length of the sorted head of a longer list
+#define TAIL_LDS_KEYS 4096u         // culled tails are sorted in LDS in runs of at most this many keys (whole depth bins)
+#define TAIL_THREADS 512              // (1024 threads leave 128 registers per lane: the appearance evaluation then spills)
+
+__device__ __forceinline__ uint32_t depth_bin(uint32_t dbits, uint32_t near_bits, int shift)
+{
+    const uint32_t d = dbits > near_bits ? dbits - near_bits : 0u;
+    const uint32_t b = d >> shift;
+    return b < GFT_DEPTH_BINS ? b : GFT_DEPTH_BINS - 1u;
+}
+
+// entry = id | rel << 32 | bin << 52;  rel = x0 | y0 << 5 | x1 << 10 | y1 << 15 (tiles from the supertile's corner)
+__device__ __forceinline__ bool entry_hits(uint64_t e, uint32_t lx, uint32_t ly)
+{
+    const uint32_t rel = (uint32_t)(e >> 32);
+    return lx >= (rel & 31u) && lx < ((rel >> 10) & 31u) && ly >= ((rel >> 5) & 31u) && ly < ((rel >> 15) & 31u);
+}
+__device__ __forceinline__ uint32_t entry_bin(uint64_t e) { return (uint32_t)(e >> 52); }
+
+struct SuperArgs {
+    int P;
+    SuperShape sh;
+    const ushort4* __restrict__ rect;
+    const float* __restrict__ depth;
+    uint32_t* st_cnt;               // [NS * K] entries per (supertile, slab)
+    uint32_t* st_start;             // [NS * K] first entry of every list
+    uint32_t* st_cursor;            // [NS * K]
+    uint64_t* sl_ent;               // entries grouped by (supertile, slab)
+    uint32_t* ctrl;
+    uint32_t* mail; uint32_t seq;
+    uint32_t cap;
+};
+
+template <int PASS>      // 0: count (+ R, mailbox), 1: scatter
+__global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
+{
+    extern __shared__ uint32_t sb_dyn[];
+    const int cells = a.sh.NS * a.sh.K;
+    uint32_t* s_cnt = sb_dyn;                 // [cells]
+    uint32_t* s_first = sb_dyn + cells;       // [cells] pass 1: first entry of this workgroup's chunk
+    __shared__ uint32_t s_last, s_sum, s_carry;
+    __shared__ uint32_t s_wt[BIN_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (PASS == 1 && a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;        // binning buffer too small: the host re-runs stage 2
+    for (int i = tid; i < cells; i += BIN_THREADS) s_cnt[i] = 0;
+    if (tid == 0) s_sum = 0;
+    __syncthreads();
+    const int base = blockIdx.x * BIN_CHUNK;
+    const int K = a.sh.K, sgx = a.sh.sgx, ss = a.sh.sshift;
+    ushort4 r4[BIN_ITEMS];
+    uint32_t bin[BIN_ITEMS];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < BIN_ITEMS; u++) {
+        const int idx = base + u * BIN_THREADS + tid;
+        const bool in = idx < a.P;
+        r4[u] = in ? a.rect[idx] : make_ushort4(0, 0, 0, 0);
+        const uint32_t tiles = (uint32_t)(r4[u].z - r4[u].x) * (uint32_t)(r4[u].w - r4[u].y);
+        // (the depth is not written for culled Gaussians and not used for them either)
+        bin[u] = (in && tiles) ? depth_bin(__float_as_uint(a.depth[idx]), a.sh.near_bits, a.sh.bin_shift) : 0u;
+        mine += tiles;
+    }
+    if (PASS == 0) {
+        mine = gft_wave_sum_u32_to_lane63(mine);
+        if (lane == 63 && mine) atomicAdd(&s_sum, mine);
+    }
+#pragma unroll
+    for (int u = 0; u < BIN_ITEMS; u++) {
+        if (!(r4[u].z > r4[u].x && r4[u].w > r4[u].y)) continue;
+        const int sx0 = r4[u].x >> ss, sx1 = (r4[u].z - 1) >> ss, sy0 = r4[u].y >> ss, sy1 = (r4[u].w - 1) >> ss;
+        const int slab = (int)(bin[u] >> a.sh.kshift);
+        for (int sy = sy0; sy <= sy1; sy++)
+            for (int sx = sx0; sx <= sx1; sx++) atomicAdd(&s_cnt[(sy * sgx + sx) * K + slab], 1u);
+    }
+    __syncthreads();
+    if (PASS == 0) {
+        // (every workgroup walks the table from another start: they do not queue up on the same counters)
+        const int rot = (int)(((uint64_t)blockIdx.x * (uint64_t)cells) / gridDim.x);
+        for (int i = tid; i < cells; i += BIN_THREADS) {
+            const int cidx = i + rot >= cells ? i + rot - cells : i + rot;
+            const uint32_t c = s_cnt[cidx];
+            if (c) atomicAdd(&a.st_cnt[cidx], c);
+        }
+        if (tid == 0 && s_sum) atomicAdd(&a.ctrl[GFT_CTRL_RSUM], s_sum);
+        // The workgroup that draws the last ticket scans.  Every counter update above is a device-scope atomic, complete
+        // once vmcnt drains, and the scan reads the counters with device-scope loads: no cache write-back is needed.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(&a.ctrl[GFT_CTRL_DONE], 1u) == gridDim.x - 1 ? 1u : 0u;
+        __syncthreads();
+        if (!s_last) return;
+        // last workgroup: exclusive scan of the entry counts -> list starts; frame totals -> ctrl + host mailbox
+        if (tid == 0) s_carry = 0;
+        __syncthreads();
+        for (int b0 = 0; b0 < cells; b0 += BIN_THREADS) {
+            const int i = b0 + tid;
+            const uint32_t v = i < cells ? __hip_atomic_load(&a.st_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            uint32_t x = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if (lane >= d) x += y;
+            }
+            if (lane == 63) s_wt[wave] = x;
+            __syncthreads();
+            uint32_t woff = 0;
+            for (int w = 0; w < wave; w++) woff += s_wt[w];
+            const uint32_t carry = s_carry;
+            if (i < cells) {
+                a.st_start[i] = carry + woff + x - v;
+                a.st_cursor[i] = 0;
+            }
+            __syncthreads();
+            if (tid == BIN_THREADS - 1) s_carry = carry + woff + x;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const uint32_t R = __hip_atomic_load(&a.ctrl[GFT_CTRL_RSUM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.ctrl[GFT_CTRL_TOTAL] = R;
+            a.ctrl[GFT_CTRL_ENTRIES] = s_carry;
+            a.ctrl[GFT_CTRL_MAXCNT] = 0u;              // (the tile lists are never formed)
+            if (a.mail) {
+                a.mail[GFT_CTRL_TOTAL] = R;            // (GFT_CTRL_FLAGS of the slot belongs to the preprocess kernel)
+                a.mail[GFT_CTRL_MAXCNT] = 0u;
+                a.mail[GFT_CTRL_ENTRIES] = s_carry;
+                __hip_atomic_store(&a.mail[GFT_CTRL_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
+    // scatter: one chunk per (workgroup, supertile, slab)
+    for (int i = tid; i < cells; i += BIN_THREADS) {
+        const uint32_t c = s_cnt[i];
+        s_first[i] = c ? a.st_start[i] + atomicAdd(&a.st_cursor[i], c) : 0u;
+        s_cnt[i] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < BIN_ITEMS; u++) {
+        if (!(r4[u].z > r4[u].x && r4[u].w > r4[u].y)) continue;
+        const uint32_t idx = (uint32_t)(base + u * BIN_THREADS + tid);
+        const int sx0 = r4[u].x >> ss, sx1 = (r4[u].z - 1) >> ss, sy0 = r4[u].y >> ss, sy1 = (r4[u].w - 1) >> ss;
+        const int slab = (int)(bin[u] >> a.sh.kshift);
+        for (int sy = sy0; sy <= sy1; sy++)
+            for (int sx = sx0; sx <= sx1; sx++) {
+                const int cell = (sy * sgx + sx) * K + slab;
+                // the rectangle clipped to this supertile, in tiles from its corner: x0, y0 in [0, S), x1, y1 in (0, S]
+                const int ox = sx << ss, oy = sy << ss, S = 1 << ss;
+                const uint32_t x0 = (uint32_t)max((int)r4[u].x - ox, 0), x1 = (uint32_t)min((int)r4[u].z - ox, S);
+                const uint32_t y0 = (uint32_t)max((int)r4[u].y - oy, 0), y1 = (uint32_t)min((int)r4[u].w - oy, S);
+                const uint32_t hi = x0 | (y0 << 5) | (x1 << 10) | (y1 << 15) | (bin[u] << 20);
+                a.sl_ent[s_first[cell] + atomicAdd(&s_cnt[cell], 1u)] = ((uint64_t)hi << 32) | idx;
+            }
+    }
+}
+
+struct PullArgs {
+    SuperShape sh;
+    const float* __restrict__ depth;
+    const uint32_t* __restrict__ st_cnt;
+    const uint32_t* __restrict__ st_start;
+    const uint64_t* __restrict__ sl_ent;
+    uint2* __restrict__ ranges;
+    uint32_t* __restrict__ heads;            // point_list: head slot of tile t at [t * GFT_HEAD_SLOT, ...)
+    uint32_t* __restrict__ front_len;
+    uint32_t* __restrict__ unit_flag;
+    uint32_t* __restrict__ tile_cnt;
+    uint32_t* __restrict__ tile_cut;
+    uint8_t* __restrict__ need;
+    const uint32_t* __restrict__ ctrl;
+    uint32_t cap;
+    float4* __restrict__ clear; size_t clear_vec4;
+};
+
+// block -> tile: blocks are dealt round-robin to the 8 XCDs; every XCD gets one contiguous run of the tiles in
+// supertile-major order, so the S x S tiles that scan the same entry lists run on one XCD (one L2) at about the same time
+__device__ __forceinline__ bool pull_tile_of_block(const SuperShape& sh, int b, int& tile, int& q, uint32_t& lx, uint32_t& ly)
+{
+    const int S2 = 1 << (2 * sh.sshift);
+    const int Np = sh.NS * S2;
+    const int chunk = (Np + 7) >> 3;
+    const int pos = (b & 7) * chunk + (b >> 3);
+    if (pos >= Np) return false;
+    q = pos >> (2 * sh.sshift);
+    const int local = pos & (S2 - 1);
+    lx = (uint32_t)(local & ((1 << sh.sshift) - 1));
+    ly = (uint32_t)(local >> sh.sshift);
+    const int tx = ((q % sh.sgx) << sh.sshift) + (int)lx, ty = ((q / sh.sgx) << sh.sshift) + (int)ly;
+    if (tx >= sh.gx || ty >= sh.gy) return false;
+    tile = ty * sh.gx + tx;
+    return true;
+}
+
+__global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
+{
+    // the depth-bin histogram of pass A and the keys of pass B share 16 KB of LDS (the histogram is done with once the head
+    // is chosen): nine workgroups per CU instead of four -- a frame's tiles are resident in one round
+    __shared__ uint64_t sk[SORT_SLOTS(TPULL_KEYS)];
+    static_assert(sizeof(uint64_t) * SORT_SLOTS(TPULL_KEYS) >= sizeof(uint32_t) * GFT_DEPTH_BINS, "histogram fits the key buffer");
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(sk);
+    __shared__ uint32_t s_n, s_cut, s_kf;
+    __shared__ uint32_t s_wt[GFT_BLOCK / 64];
+    if (a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
+    // fire-and-forget zero fill of the backward's accumulator: the stores drain while this workgroup works in LDS
+    if (a.clear) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t i = (size_t)blockIdx.x * GFT_BLOCK + threadIdx.x; i < a.clear_vec4; i += (size_t)gridDim.x * GFT_BLOCK)
+            a.clear[i] = z;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tile, q;
+    uint32_t lx, ly;
+    if (!pull_tile_of_block(a.sh, (int)blockIdx.x, tile, q, lx, ly)) return;
+    const int K = a.sh.K;
+    for (int i = tid; i < GFT_DEPTH_BINS; i += GFT_BLOCK) s_hist[i] = 0;
+    if (tid == 0) s_n = 0;
+    if (tid < 4) a.unit_flag[4 * tile + tid] = 0;
+    __syncthreads();
+
+    // pass over one entry list of the supertile.  MODE 0: count the tile's hits and histogram them over the depth bins;
+    // MODE 1: keys (gathered depth bits, id) of the hits in front of bin `first_tail` -> LDS, Gaussians marked as needed
+    auto scan = [&](const uint64_t* __restrict__ list, uint32_t ln, int mode, uint32_t first_tail) {
+        for (uint32_t i0 = 0; i0 < ln; i0 += 4 * GFT_BLOCK) {
+            uint64_t e4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * GFT_BLOCK + tid;
+                e4[u] = i < ln ? list[i] : 0ull;                     // (an all-zero rectangle covers no tile)
+            }
+            bool hit[4];
+            unsigned long long hm[4];
+            uint32_t off[4], cnt = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                hit[u] = entry_hits(e4[u], lx, ly) && (mode == 0 || entry_bin(e4[u]) < first_tail);
+                hm[u] = __builtin_amdgcn_ballot_w64(hit[u]);
+                off[u] = cnt;
+                cnt += (uint32_t)__popcll(hm[u]);
+            }
+            if (cnt == 0u) continue;                                 // wave-uniform
+            // one LDS atomic per wave reserves the slots of all four entries
+            uint32_t hb = 0;
+            if (lane == 0) hb = atomicAdd(&s_n, cnt);
+            if (mode == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (hit[u]) atomicAdd(&s_hist[entry_bin(e4[u])], 1u);
+                continue;
+            }
+            hb = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb);
+            // the depth gathers of the hits are issued together
+            uint32_t d4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) d4[u] = hit[u] ? __float_as_uint(a.depth[(uint32_t)e4[u]]) : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!hit[u]) continue;
+                const uint32_t id = (uint32_t)e4[u];
+                const uint32_t pos = hb + off[u] + (uint32_t)__popcll(hm[u] & ((1ull << lane) - 1ull));
+                if (pos < TPULL_KEYS) sk[pos] = ((uint64_t)d4[u] << 32) | id;
+                a.need[id] = 1;                                      // its appearance is wanted (k_appearance)
+            }
+        }
+    };
+
+    // pass A: slabs front to back until the head is covered (one slab = the whole list when K == 1)
+    int kstop = K - 1;
+    uint32_t n = 0;                                      // hits in the slabs that were scanned
+    for (int k = 0; k < K; k++) {
+        const uint32_t ln = a.st_cnt[q * K + k];
+        if (ln) scan(a.sl_ent + a.st_start[q * K + k], ln, 0, 0u);
+        __syncthreads();
+        n = s_n;
+        __syncthreads();                                 // (everybody has read the count before the next slab adds to it)
+        if (n >= HEAD_TARGET) { kstop = k; break; }
+    }
+    bool more_slabs = false;
+    for (int k = kstop + 1; k < K; k++) more_slabs |= a.st_cnt[q * K + k] != 0u;
+    // the head: whole bins up to the one where the running count reaches HEAD_TARGET.  That bin is taken if the head then
+    // still sorts as one 1024-key unit; a bin that overshoots is left out unless the head would otherwise be shorter than
+    // 512 and the bin fits the 2048-key sorter.  first_tail = first bin outside the head.
+    uint32_t first_tail = (uint32_t)(kstop + 1) << a.sh.kshift, kf = n;
+    if (n > HEAD_DIRECT) {
+        uint32_t h[16], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { h[k] = s_hist[16 * tid + k]; sum += h[k]; }
+        uint32_t x = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_wt[wave] = x;
+        __syncthreads();
+        for (int w = 0; w < wave; w++) x += s_wt[w];
+        uint32_t run = x - sum;
+        if (run < HEAD_TARGET && x >= HEAD_TARGET) {                 // exactly one thread: the crossing lies in its 16 bins
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t before = run;
+                run += h[k];
+                if (before < HEAD_TARGET && run >= HEAD_TARGET) {
+                    const bool take = run <= HEAD_DIRECT || (before < 512u && run <= TPULL_KEYS);
+                    s_cut = (uint32_t)(16 * tid + k) + (take ? 1u : 0u);
+                    s_kf = take ? run : before;
+                }
+            }
+        }
+        __syncthreads();
+        first_tail = s_cut;
+        kf = s_kf;
+    }
+    __syncthreads();
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    // pass B: the head's keys
+    if (kf) {
+        for (int k = 0; k <= kstop; k++) {
+            if (((uint32_t)k << a.sh.kshift) >= first_tail) break;
+            const uint32_t ln = a.st_cnt[q * K + k];
+            if (ln) scan(a.sl_ent + a.st_start[q * K + k], ln, 1, first_tail);
+        }
+    }
+    const bool has_tail = kf < n || more_slabs;
+    const uint32_t start = (uint32_t)tile * GFT_HEAD_SLOT;
+    if (tid == 0) {
+        a.ranges[tile] = kf ? make_uint2(start, start + kf) : make_uint2(0u, 0u);     // (empty: (0,0) like the reference)
+        a.front_len[tile] = kf;
+        a.tile_cnt[tile] = n;
+        a.tile_cut[tile] = has_tail ? first_tail : GFT_NO_TAIL;
+    }
+    __syncthreads();
+    if (kf == 0u) return;
+    uint32_t* ids = a.heads + start;
+    if (kf <= 1024u) {
+        const uint32_t npad = next_pow2(kf < 2u ? 2u : kf);
+        for (uint32_t i = tid + kf; i < npad; i += GFT_BLOCK) sk[i] = ~0ull;
+        __syncthreads();
+        if (npad == 1024u) sort1024_by_rank_and_store(sk, kf, tid, ids);
+        else head_sort_and_store(sk, kf, npad, tid, ids);
+        return;
+    }
+    // 1025 .. 2048 keys: the register-blocked network wants them at their swizzled slots
+    static_assert(TPULL_KEYS == 2048u, "k_tile_pull sorts at most 2048 keys");
+    uint64_t mine[TPULL_KEYS / GFT_BLOCK];
+#pragma unroll
+    for (int k = 0; k < (int)(TPULL_KEYS / GFT_BLOCK); k++) {
+        const uint32_t i = tid + k * GFT_BLOCK;
+        mine[k] = i < kf ? sk[i] : ~0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (int)(TPULL_KEYS / GFT_BLOCK); k++) sk[sort_slot(tid + k * GFT_BLOCK)] = mine[k];
+    __syncthreads();
+    bitonic_blocked<3, 8>(sk, tid);
+    for (uint32_t i = tid; i < kf; i += GFT_BLOCK) ids[i] = (uint32_t)sk[sort_slot(i)];
+}
+
+// ---- lists completed on demand --------------------------------------------------------------------------------
+struct TailArgs {
+    PreFwdArgs pre;                          // inputs of the appearance evaluation
+    SuperShape sh;
+    const uint32_t* __restrict__ st_cnt;
+    const uint32_t* __restrict__ st_start;
+    const uint64_t* __restrict__ sl_ent;
+    uint2* __restrict__ ranges;
+    uint32_t* point_list;
+    uint32_t pool_base;                      // first pool slot inside point_list (= T * GFT_HEAD_SLOT)
+    const uint32_t* __restrict__ front_len;
+    const uint32_t* __restrict__ unit_flag;
+    const uint32_t* __restrict__ tile_cut;
+    uint32_t* ctrl;
+    uint32_t cap;
+    const uint32_t* __restrict__ quad_max;
+    uint32_t* __restrict__ order;
+};
+
+__device__ __forceinline__ void tail_appearance(const TailArgs& a, uint32_t id)
+{
+    if (a.pre.g.need[id]) return;            // (another tile may do the same at the same time: the same bits are written)
+    a.pre.g.need[id] = 1;
+    const float px = a.pre.io.means3D[3 * id], py = a.pre.io.means3D[3 * id + 1], pz = a.pre.io.means3D[3 * id + 2];
+    const Mat16 V = load_mat(a.pre.io.viewmatrix);
+    // the same expressions as in k_preprocess_fwd / k_appearance: the same distance bit for bit
+    const float vz = V.m[2] * px + V.m[6] * py + V.m[10] * pz + V.m[14];
+    const float vx = V.m[0] * px + V.m[4] * py + V.m[8] * pz + V.m[12];
+    const float vy = V.m[1] * px + V.m[5] * py + V.m[9] * pz + V.m[13];
+    appearance_fwd(a.pre, (int)id, threadIdx.x & 63, nullptr, nullptr, px, py, pz, vx, vy, vz);
+}
+
+__global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
+{
+    extern __shared__ uint64_t sk_dyn[];
+    uint64_t* sk = sk_dyn;                                   // TAIL_LDS_KEYS keys at their swizzled slots
+    __shared__ uint32_t s_hist[GFT_DEPTH_BINS];
+    __shared__ uint32_t s_m, s_pool, s_hi, s_chunk;
+    __shared__ unsigned long long s_nearest;
+    if (a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
+    const uint32_t nflag = a.ctrl[GFT_CTRL_NFLAG];
+    const int T = a.sh.T;
+    // The backward's heavy-first tile order rides on this launch (no separate launch in the backward): by the deepest
+    // contributors of the first render pass; a tile with a flagged quadrant, whose walk goes on, counts as heaviest.
+    if (a.order && blockIdx.x == 0) {
+        gft_tile_order_block(T, a.quad_max, a.order, nflag ? a.unit_flag : nullptr);
+        if (threadIdx.x == 0) a.ctrl[GFT_CTRL_ORDER_OK] = 1u;
+    }
+    if (nflag == 0u) return;                                 // the common case: every quadrant saturated inside its head
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int K = a.sh.K;
+    // one workgroup per tile (three are resident per CU): the flagged tiles of a frame -- a few dozen silhouette tiles --
+    // are completed side by side; with a tile loop over 256 workgroups two or three of them met in one workgroup on most
+    // frames and the kernel took that chain (54 -> 2x us)
+    {
+        const int tile = (int)blockIdx.x;
+        const uint4 f = reinterpret_cast<const uint4*>(a.unit_flag)[tile];
+        if ((f.x | f.y | f.z | f.w) == 0u) return;           // uniform per workgroup
+        const uint32_t first_tail = a.tile_cut[tile];
+        if (first_tail == GFT_NO_TAIL) return;               // (its head is its whole list: nothing to complete)
+        const uint32_t kf = a.front_len[tile];
+        const int tx = tile % a.sh.gx, ty = tile / a.sh.gx;
+        const int q = (ty >> a.sh.sshift) * a.sh.sgx + (tx >> a.sh.sshift);
+        const uint32_t lx = (uint32_t)(tx & ((1 << a.sh.sshift) - 1)), ly = (uint32_t)(ty & ((1 << a.sh.sshift) - 1));
+        const float qx = (float)(tx * GFT_TILE_X), qy = (float)(ty * GFT_TILE_Y);
+        for (int i = tid; i < GFT_DEPTH_BINS; i += TAIL_THREADS) s_hist[i] = 0;
+        if (tid == 0) { s_m = 0; s_nearest = ~0ull; }
+        __syncthreads();
+        // An empty head (every key of the tile in one depth bin too large to sort up front): list position 0, whose depth
+        // the render kernels take as the reference of their depth sums, must be the tile's nearest Gaussian as in every
+        // other flow -- it is kept whether it reaches a flagged quadrant or not.
+        uint32_t keep_id = 0xffffffffu;
+        if (kf == 0u) {
+            for (int k = 0; k < K; k++) {
+                const uint32_t ln = a.st_cnt[q * K + k];
+                const uint64_t* __restrict__ list = a.sl_ent + a.st_start[q * K + k];
+                for (uint32_t i = tid; i < ln; i += TAIL_THREADS) {
+                    const uint64_t e = list[i];
+                    if (entry_hits(e, lx, ly) && entry_bin(e) >= first_tail)
+                        atomicMin(&s_nearest, ((unsigned long long)__float_as_uint(a.pre.g.depth[(uint32_t)e]) << 32) | (uint32_t)e);
+                }
+            }
+            __syncthreads();
+            keep_id = (uint32_t)s_nearest;               // (0xffffffff when the tile has no entry at all)
+        }
+        // Entries of the supertile behind the head that cover this tile AND reach one of its flagged quadrants.
+        // MODE 0: count them, histogram them over the bins, keep the keys of the first TAIL_LDS_KEYS in LDS;
+        // MODE 1: keys of those with bin in [lo, hi] -> LDS;  MODE 2: their ids -> dst[0, ...) (one bin too large for LDS)
+        auto scan = [&](int mode, uint32_t lo, uint32_t hi, uint32_t* dst) {
+            for (int k = 0; k < K; k++) {
+                if ((((uint32_t)k + 1u) << a.sh.kshift) <= lo || ((uint32_t)k << a.sh.kshift) > hi) continue;   // slab outside [lo, hi]
+                const uint32_t ln = a.st_cnt[q * K + k];
+                const uint64_t* __restrict__ list = a.sl_ent + a.st_start[q * K + k];
+                // four entries per thread and trip: their loads, then the geometry records of the hits, are in flight together
+                // (a trip is two dependent memory round trips)
+                for (uint32_t i0 = 0; i0 < ln; i0 += 4 * TAIL_THREADS) {
+                    uint64_t e4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t i = i0 + u * TAIL_THREADS + tid;
+                        e4[u] = i < ln ? list[i] : 0ull;
+                    }
+                    bool s4[4];
+                    float4 ra[4], rb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t b = entry_bin(e4[u]);
+                        s4[u] = entry_hits(e4[u], lx, ly) && b >= lo && b <= hi;
+                        const uint32_t id = s4[u] ? (uint32_t)e4[u] : 0u;
+                        ra[u] = s4[u] ? a.pre.g.rec_a[2 * id] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        rb[u] = s4[u] ? a.pre.g.rec_a[2 * id + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t id = (uint32_t)e4[u], b = entry_bin(e4[u]);
+                        bool sv = s4[u];
+                        if (sv)
+                            sv = (f.x && gft_splat_reaches_quadrant(ra[u], rb[u], qx, qy)) || (f.y && gft_splat_reaches_quadrant(ra[u], rb[u], qx + 8.f, qy)) ||
+                                 (f.z && gft_splat_reaches_quadrant(ra[u], rb[u], qx, qy + 8.f)) || (f.w && gft_splat_reaches_quadrant(ra[u], rb[u], qx + 8.f, qy + 8.f)) ||
+                                 id == keep_id;
+                        const unsigned long long sm = __builtin_amdgcn_ballot_w64(sv);
+                        if (sm == 0ull) continue;                // wave-uniform
+                        uint32_t hb = 0;
+                        if (lane == 0) hb = atomicAdd(&s_m, (uint32_t)__popcll(sm));
+                        hb = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb);
+                        if (!sv) continue;
+                        const uint32_t pos = hb + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+                        if (mode == 0) atomicAdd(&s_hist[b], 1u);
+                        if (mode == 2) dst[pos] = id;
+                        else if (pos < TAIL_LDS_KEYS) sk[sort_slot(pos)] = ((uint64_t)__float_as_uint(a.pre.g.depth[id]) << 32) | id;
+                    }
+                }
+            }
+        };
+        // sorts the n keys in LDS (n <= TAIL_LDS_KEYS), gives their Gaussians an appearance, writes the ids
+        auto finish_lds = [&](uint32_t n, uint32_t* dst) {
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += TAIL_THREADS) tail_appearance(a, (uint32_t)sk[sort_slot(i)]);
+            if (n <= 1024u) {
+                // a short tail (the usual case: a few hundred survivors): runs of 256 keys are sorted by one wave each in
+                // registers (no workgroup barrier), the runs are merged by rank -- a key's place = its place in its own run +
+                // the number of smaller keys in the other runs (binary searches; the keys are distinct: the id is their
+                // low half).  sort_slot() permutes inside 32-key blocks, so run r occupies slots [256 r, 256 r + 256).
+                const uint32_t runs = (n + 255u) >> 8;
+                for (uint32_t i = tid + n; i < 256u * runs; i += TAIL_THREADS) sk[sort_slot(i)] = ~0ull;
+                __syncthreads();
+                const int wave = tid >> 6;
+                if ((uint32_t)wave < runs) bitonic_blocked<2, 6, WaveSync>(sk + 256 * wave, lane, WaveSync());
+                __syncthreads();
+                for (uint32_t i = tid; i < 256u * runs; i += TAIL_THREADS) {
+                    const uint32_t run = i >> 8, pos = i & 255u;
+                    const uint64_t key = sk[256u * run + sort_slot(pos)];
+                    if (key == ~0ull) continue;                  // padding
+                    uint32_t rank = pos;
+                    for (uint32_t o = 0; o < runs; o++) {
+                        if (o == run) continue;
+                        const uint64_t* r = sk + 256u * o;
+                        uint32_t lo = 0;                         // number of keys of run o below `key`
+#pragma unroll
+                        for (uint32_t step = 128; step > 0; step >>= 1)
+                            if (r[sort_slot(lo + step - 1)] < key) lo += step;
+                        if (r[sort_slot(lo)] < key) lo++;        // (lo <= 255 here)
+                        rank += lo;
+                    }
+                    dst[rank] = (uint32_t)key;
+                }
+                __syncthreads();
+                return;
+            } else {
+                // (larger register-blocked networks -- 16 or 32 keys per thread -- would push this kernel into scratch memory,
+                // which costs every launch, also the idle ones, tens of microseconds: longer tails go in runs of bins)
+                static_assert(TAIL_LDS_KEYS == 4096u && TAIL_THREADS == 512, "one 4096-key network: 8 keys per thread");
+                for (uint32_t i = tid + n; i < TAIL_LDS_KEYS; i += TAIL_THREADS) sk[sort_slot(i)] = ~0ull;
+                __syncthreads();
+                bitonic_blocked<3, 9>(sk, tid);
+            }
+            for (uint32_t i = tid; i < n; i += TAIL_THREADS) dst[i] = (uint32_t)sk[sort_slot(i)];
+            __syncthreads();
+        };
+        scan(0, first_tail, GFT_DEPTH_BINS - 1u, nullptr);
+        __syncthreads();
+        const uint32_t m = s_m;
+        // the completed list (head copy + culled tail) takes kf + m pool slots; over all tiles that is at most R <= cap
+        if (tid == 0) s_pool = atomicAdd(&a.ctrl[GFT_CTRL_POOLCUR], kf + m);
+        __syncthreads();
+        uint32_t* list = a.point_list + a.pool_base + s_pool;
+        const uint32_t* head = a.point_list + (size_t)tile * GFT_HEAD_SLOT;
+        for (uint32_t i = tid; i < kf; i += TAIL_THREADS) list[i] = head[i];
+        if (m <= TAIL_LDS_KEYS) {
+            finish_lds(m, list + kf);
+        } else {
+            // more survivors than LDS holds: bin ranges of at most TAIL_LDS_KEYS survivors, front to back
+            uint32_t done = 0, lo = first_tail;
+            while (done < m) {
+                if (tid == 0) {
+                    uint32_t hi = lo, c = s_hist[lo];
+                    while (hi + 1u < GFT_DEPTH_BINS && c + s_hist[hi + 1u] <= TAIL_LDS_KEYS) c += s_hist[++hi];
+                    s_hi = hi; s_chunk = c; s_m = 0;
+                }
+                __syncthreads();
+                const uint32_t hi = s_hi, c = s_chunk;
+                uint32_t* dst = list + kf + done;
+                if (c <= TAIL_LDS_KEYS) {
+                    if (c) { scan(1, lo, hi, nullptr); finish_lds(c, dst); }
+                } else {
+                    // one depth bin with more survivors than LDS holds (thousands of Gaussians within 1e-3 of one depth, all
+                    // on one tile): ids to the list, sorted in place by (gathered depth bits, id) -- slow, never seen in practice
+                    scan(2, lo, hi, dst);
+                    __threadfence_block();
+                    __syncthreads();
+                    for (uint32_t i = tid; i < c; i += TAIL_THREADS) tail_appearance(a, dst[i]);
+                    auto ld = [&](uint32_t i) {
+                        const uint32_t id = __hip_atomic_load(&dst[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        return ((uint64_t)__float_as_uint(a.pre.g.depth[id]) << 32) | id;
+                    };
+                    bitonic_ascending<TAIL_THREADS>(c, next_pow2(c), tid, ld,
+                        [&](uint32_t i, uint64_t v) { __hip_atomic_store(&dst[i], (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
+                        [] { __threadfence_block(); __syncthreads(); });
+                }
+                done += c;
+                lo = hi + 1u;
+                __syncthreads();
+            }
+        }
+        if (tid == 0) a.ranges[tile] = make_uint2(a.pool_base + s_pool, a.pool_base + s_pool + kf + m);
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// supertile side: the smallest power of two >= 2 tiles that leaves at most GFT_SUPER_MAX supertiles; depth slabs per
+// supertile list: 4 on big tile grids (S >= 4: sixteen tiles share a list several times their own length; a tile then
+// scans the slabs front to back only until its head is covered), one otherwise.  Measured at 5 M @ 1080p, count +
+// scatter + pull: 1 slab 48 + 100 + 476 us, 4 slabs 53 + 157 + 245, 16 slabs 70 + 194 + 197 (the scatter's chunks per
+// (workgroup, supertile, slab) shrink to single 8-byte writes)
+SuperShape gft_super_shape(const gft_config& c)
+{
+    static const int env_slabs = [] { const char* e = getenv("GFT_SLABS"); return e ? atoi(e) : 0; }();
+    SuperShape sh;
+    sh.gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X;
+    sh.gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+    sh.T = sh.gx * sh.gy;
+    sh.sshift = 1;
+    for (;;) {
+        const int S = 1 << sh.sshift;
+        sh.sgx = (sh.gx + S - 1) / S;
+        sh.sgy = (sh.gy + S - 1) / S;
+        sh.NS = sh.sgx * sh.sgy;
+        if (sh.NS <= GFT_SUPER_MAX) break;
+        sh.sshift++;
+    }
+    int K = sh.sshift >= 2 ? 4 : 1;
+    if (env_slabs == 1 || env_slabs == 2 || env_slabs == 4 || env_slabs == 8 || env_slabs == 16) K = env_slabs;
+    sh.K = K;
+    sh.kshift = 12;
+    for (int k = K; k > 1; k >>= 1) sh.kshift--;
+    // depth bins: 4096 equal steps of the float bits between the near and the far plane (log-spaced inside an octave's
+    // mantissa steps, i.e. monotone in the depth bits: positive floats order like their bits)
+    const float nr = c.near_n > 1e-6f ? c.near_n : 1e-6f;
+    const float fr = c.far_n > nr ? c.far_n : 2.0f * nr;
+    uint32_t nb, fb;
+    memcpy(&nb, &nr, 4);
+    memcpy(&fb, &fr, 4);
+    sh.near_bits = nb;
+    sh.bin_shift = 0;
+    while (((fb - nb) >> sh.bin_shift) >= (uint32_t)GFT_DEPTH_BINS - 1u) sh.bin_shift++;
+    return sh;
+}
+
+// the rectangle of an entry relative to its supertile is packed into 4 x 5 bits: supertiles of at most 16 x 16 tiles
+bool gft_tile_pull_ok(const gft_config& c) { return gft_super_shape(c).sshift <= 4; }
+
+// pass 0: count (+ R, mailbox); pass 1: scatter of the entries to their (supertile, slab) lists
+hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
+                                uint32_t* mail, uint32_t seq, int pass, uint32_t cap)
+{
+    SuperArgs a;
+    a.P = c.P;
+    a.sh = gft_super_shape(c);
+    a.rect = g.rect; a.depth = g.depth;
+    a.st_cnt = im.super_tab; a.st_start = im.super_tab + GFT_SUPER_CELLS; a.st_cursor = im.super_tab + 2 * GFT_SUPER_CELLS;
+    // the entry lists live in the key array (`cap` 8-byte slots: there are at most as many (Gaussian, supertile) pairs as
+    // (Gaussian, tile) instances)
+    a.sl_ent = pass == 1 ? b.keys : nullptr;
+    a.ctrl = im.ctrl; a.mail = mail; a.seq = seq; a.cap = cap;
+    const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
+    const size_t lds = (size_t)a.sh.NS * a.sh.K * 2 * sizeof(uint32_t);
+    {
+        static std::atomic<uint64_t> done[2];
+        hipError_t e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<0>), (size_t)GFT_SUPER_CELLS * 8, done[0]);
+        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<1>), (size_t)GFT_SUPER_CELLS * 8, done[1]);
+        if (e != hipSuccess) return e;
+    }
+    if (pass == 0) hipLaunchKernelGGL(k_super_bin<0>, dim3(blocks), dim3(BIN_THREADS), lds, s, a);
+    else hipLaunchKernelGGL(k_super_bin<1>, dim3(blocks), dim3(BIN_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
+                                uint32_t cap, float* clear, size_t clear_bytes)
+{
+    PullArgs a;
+    a.sh = gft_super_shape(c);
+    a.depth = g.depth;
+    a.st_cnt = im.super_tab; a.st_start = im.super_tab + GFT_SUPER_CELLS;
+    a.sl_ent = b.keys;
+    a.ranges = im.ranges; a.heads = b.point_list; a.front_len = im.front_len; a.unit_flag = im.unit_flag;
+    a.tile_cnt = im.tile_cnt; a.tile_cut = im.tile_cut; a.need = g.need;
+    a.ctrl = im.ctrl; a.cap = cap;
+    a.clear = reinterpret_cast<float4*>(clear); a.clear_vec4 = clear_bytes / 16;
+    const int Np = a.sh.NS << (2 * a.sh.sshift);
+    hipLaunchKernelGGL(k_tile_pull, dim3(8 * ((Np + 7) / 8)), dim3(GFT_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t gft_launch_tail_build(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
+                                 const ImgView& im, const BinView& b, uint32_t cap, bool want_order)
+{
+    TailArgs a;
+    a.pre = gft_pre_fwd_args(c, io, g, im, nullptr, true);
+    a.sh = gft_super_shape(c);
+    a.st_cnt = im.super_tab; a.st_start = im.super_tab + GFT_SUPER_CELLS;
+    a.sl_ent = b.keys;
+    a.ranges = im.ranges; a.point_list = b.point_list; a.pool_base = (uint32_t)a.sh.T * GFT_HEAD_SLOT;
+    a.front_len = im.front_len; a.unit_flag = im.unit_flag; a.tile_cut = im.tile_cut;
+    a.ctrl = im.ctrl; a.cap = cap;
+    a.quad_max = im.tile_max; a.order = want_order ? im.tile_order : nullptr;
+    const size_t lds = (size_t)SORT_SLOTS(TAIL_LDS_KEYS) * 8;
+    {
+        static std::atomic<uint64_t> done{0};
+        const hipError_t e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_tail_build), lds, done);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_tail_build, dim3(a.sh.T), dim3(TAIL_THREADS), lds, s, a);
+    return hipGetLastError();
+}

@@ -77,25 +77,7 @@ __device__ __forceinline__ bool stage_splat(uint32_t id, int slot, const float4*
     sA[2 * slot + 1] = a1;
     sB[2 * slot] = rec_b[2 * id];
     sB[2 * slot + 1] = rec_b[2 * id + 1];
-    // alpha = min(0.99, o*exp(power)) >= 1/255  <=>  power >= -tau, tau = ln(255 o), i.e. the
-    // pixels that can blend this splat lie in the ellipse q(u) = a ux^2 + 2 b ux uy + c uy^2 <= 2 tau
-    // around the centre.  The quadrant's pixel centres span a rectangle; q is convex with its
-    // minimum at the centre, so its minimum over the rectangle sits on an edge facing the centre:
-    // two 1-D clamped minimisations.  (A bounding-box test passes 195 of 429 walked splats per
-    // quadrant on the metric frame, this one 154; 144 really touch a pixel.)
-    const float ca = a0.z, cb = a0.w, cc = a1.x, op = a1.y;
-    const float det = ca * cc - cb * cb;
-    const float tau = __logf(255.0f * op);
-    if (!(tau > 0.0f)) return false;            // opacity <= 1/255: can never pass the alpha test
-    if (!(det > 0.0f && ca > 0.0f && cc > 0.0f)) return true;   // degenerate conic: let the pixel test decide
-    const float ux0 = qx0 - a0.x, ux1 = ux0 + 7.0f;
-    const float uy0 = qy0 - a0.y, uy1 = uy0 + 7.0f;
-    const float X = fminf(fmaxf(0.0f, ux0), ux1), Y = fminf(fmaxf(0.0f, uy0), uy1);   // rectangle point nearest the centre, per axis
-    const float ys = fminf(fmaxf(-cb * X * __frcp_rn(cc), uy0), uy1);
-    const float xs = fminf(fmaxf(-cb * Y * __frcp_rn(ca), ux0), ux1);
-    const float q1 = ca * X * X + 2.0f * cb * X * ys + cc * ys * ys;
-    const float q2 = ca * xs * xs + 2.0f * cb * xs * Y + cc * Y * Y;
-    return fminf(q1, q2) <= 2.0f * tau * 1.0005f + 0.01f;       // margins keep the test conservative
+    return gft_splat_reaches_quadrant(a0, a1, qx0, qy0);
 }
 
 struct RenderFwdArgs {
@@ -115,11 +97,9 @@ struct RenderFwdArgs {
     float* pixels;
     const uint32_t* __restrict__ ctrl;   // NULL: no instance-count check
     uint32_t cap;
-    // lazy binning (k_binning.hip): the tile's list = its near-slab segment (ranges) + its far-slab segment (ranges1),
-    // the latter binned only after a quadrant of the tile ran out of near-slab entries
-    const uint32_t* __restrict__ totals;      // ctrl words (always set)
-    const uint2* __restrict__ ranges1;
-    float4* __restrict__ clear; size_t clear_vec4;   // backward accumulator to zero (first pass of a tile-pull frame)
+    // tile-pull binning (k_pull.hip): `ranges` holds the sorted head of the tile's list; tile_cut[tile] != GFT_NO_TAIL: the
+    // list goes on behind it (completed by k_tail_build for the tiles with a flagged quadrant).  NULL: whole-frame binning
+    const uint32_t* __restrict__ tile_cut;
     float4* __restrict__ snaps;               // blend-state snapshots for the backward (NULL: no backward follows)
     int nsnap;                                // snapshots per quadrant (list positions 256, 512, ...)
     // lazy sort (k_binning.hip, k_tile_front): only the head of every id list is sorted
@@ -139,12 +119,6 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     if (a.ctrl && a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
     if (a.resume && *a.nflag == 0u) return;               // no quadrant asked for its tail
     const int V = a.T * 4;
-    // fire-and-forget zero fill of the backward's accumulator: this kernel is bound by its VALU chains and moves
-    // little data, the stores drain underneath
-    if (a.clear) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < a.clear_vec4; i += (size_t)gridDim.x * 64) a.clear[i] = z;
-    }
     const int v = unit_of_block(blockIdx.x, V);
     if (v >= V) return;
     const int tile = v >> 2, quad = v & 3;
@@ -157,26 +131,19 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     const uint2 range = a.ranges[tile];
     const int full = (int)(range.y - range.x);
     const int head = a.front_len ? (int)a.front_len[tile] : full;
-    // first pass: list positions [0, head); resume pass: [head, full) of the flagged quadrants, then the tile's
-    // far-slab segment (positions full ... full + n1)
+    // first pass: list positions [0, head); resume pass: [head, full) of the flagged quadrants (whole-frame binning: the
+    // tail k_tile_tail has sorted; tile-pull binning: the culled tail k_tail_build has appended, `ranges` now names the
+    // completed list)
     if (a.resume && a.unit_flag[v] == 0u) return;
-    const bool more = a.totals[GFT_CTRL_TOTAL] != a.totals[GFT_CTRL_TOTAL0];      // the frame has a far slab
-    uint32_t r1x = 0;
-    int n1 = 0;
-    if (a.resume && a.totals[GFT_CTRL_TOTAL1] != 0u) {
-        const uint2 r1 = a.ranges1[tile];
-        r1x = r1.x;
-        n1 = (int)(r1.y - r1.x);
-    }
+    const bool more = a.tile_cut != nullptr && a.tile_cut[tile] != GFT_NO_TAIL;   // the list goes on behind what `ranges` holds
     const int begin = a.resume ? head : 0;
-    const int total = a.resume ? full + n1 : head;
+    const int total = a.resume ? full : head;
     // Depth distortion is formed from the sums of w (z - zref) and w (z - zref)^2, zref = NDC depth of the tile's nearest
     // Gaussian: A D2 - D^2 does not depend on the shift, but its two terms cancel to (depth spread / depth)^2 of their
     // size -- around zref they are small to begin with (a scene in a narrow depth range kept 1 significant digit
     // of the plane without the shift, and could go negative).  The backward uses the same shift.
-    // (list position 0 = the tile's nearest Gaussian whatever the slabs: the same zref in every flow, bit-identical sums)
-    const float zref = full > 0 ? a.rec_a[2 * a.point_list[range.x] + 1].z
-                                : (n1 > 0 ? a.rec_a[2 * a.point_list[r1x] + 1].z : 0.0f);
+    // (list position 0 = the tile's nearest Gaussian in every flow: the same zref, bit-identical sums)
+    const float zref = full > 0 ? a.rec_a[2 * a.point_list[range.x] + 1].z : 0.0f;
     const size_t pix_i = inside ? (size_t)a.W * py + px : 0;
 
     // Predicates are wave-uniform 64-bit lane masks: every ballot below takes a single compare,
@@ -224,7 +191,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
         __syncthreads();                         // previous batch has read LDS
         if (lane < n) {
             const int pos = base + lane;
-            const uint32_t id = a.point_list[pos < full ? range.x + (uint32_t)pos : r1x + (uint32_t)(pos - full)];
+            const uint32_t id = a.point_list[range.x + (uint32_t)pos];
             my_id = id;
             reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, (float)qx0, (float)qy0);
         }
@@ -371,8 +338,7 @@ struct RenderBwdArgs {
     int split;                 // 1: deep quadrants are shared by several waves
     int nseg;                  // segments (waves) per quadrant at most; snapshots per quadrant = nseg - 1
     const float4* __restrict__ snaps;
-    const uint32_t* __restrict__ front_len;   // lazy sort / binning: entries the forward's first pass could walk (NULL: all)
-    const uint2* __restrict__ ranges1;      // lazy binning: far-slab segments (read only by quadrants that went that deep)
+    const uint32_t* __restrict__ front_len;   // lazy sort / tile-pull binning: entries the forward's first pass could walk (NULL: all)
     const uint32_t* __restrict__ quad_max;
     const uint32_t* __restrict__ order;     // tiles, heaviest first
     const uint32_t* __restrict__ order_ok;  // ctrl word: the forward computed `order` (NULL: it is valid)
@@ -512,12 +478,9 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
-    // list position c -> entry of the id list: the near-slab segment, then (lazy binning) the far-slab segment
-    const uint2 rg = a.ranges[tile];
-    const uint32_t r0 = rg.x, n0 = rg.y - rg.x;
-    uint32_t r1x = 0;
-    if ((uint32_t)tmax > n0) r1x = a.ranges1[tile].x;
-    auto phys = [&](uint32_t c) -> uint32_t { return c < n0 ? r0 + c : r1x + (c - n0); };
+    // list position c -> entry of the id list
+    const uint32_t r0 = a.ranges[tile].x;
+    auto phys = [&](uint32_t c) -> uint32_t { return r0 + c; };
     const float zref = a.rec_a[2 * a.point_list[phys(0u)] + 1].z;                 // the forward's shift of the depth sums (tmax > 0)
     const size_t HW = (size_t)a.H * a.W;
     const size_t pix = inside ? (size_t)a.W * py + px : 0;
@@ -716,7 +679,7 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
 // Deterministic mode: adds the partial rows k_render_bwd stored, tile by tile; inside a tile every list entry is another
 // Gaussian (no two threads touch one accumulator row), its four quadrant rows are added in the order 0..3, and a
 // barrier separates the tiles: every accumulator value is a sum in one fixed order.  One workgroup (a test mode).
-__global__ __launch_bounds__(1024) void k_acc_reduce_det(int T, const uint2* __restrict__ ranges, const uint2* __restrict__ ranges1,
+__global__ __launch_bounds__(1024) void k_acc_reduce_det(int T, const uint2* __restrict__ ranges,
                                                          const uint32_t* __restrict__ quad_max,
                                                          const uint32_t* __restrict__ point_list,
                                                          const float* __restrict__ det, float* acc)
@@ -726,12 +689,10 @@ __global__ __launch_bounds__(1024) void k_acc_reduce_det(int T, const uint2* __r
         const uint4 qm = reinterpret_cast<const uint4*>(quad_max)[tile];
         const uint32_t walked = max(max(qm.x, qm.y), max(qm.z, qm.w));      // entries some quadrant of the tile walked
         const uint2 rg = ranges[tile];
-        const uint32_t n0 = rg.y - rg.x;
-        const uint32_t r1x = walked > n0 ? ranges1[tile].x : 0u;
         for (uint32_t i = (uint32_t)tid; i < walked * GFT_ACC_STRIDE; i += 1024u) {
             const uint32_t c = i / GFT_ACC_STRIDE, k = i % GFT_ACC_STRIDE;
             if (k >= GFT_NUM_ACC) continue;
-            const uint32_t p = c < n0 ? rg.x + c : r1x + (c - n0);
+            const uint32_t p = rg.x + c;
             const float* row = det + (size_t)p * 4 * GFT_ACC_STRIDE + k;
             float s = row[0];
             s += row[GFT_ACC_STRIDE];
@@ -751,18 +712,14 @@ __global__ __launch_bounds__(1024) void k_acc_reduce_det(int T, const uint2* __r
 }  // namespace
 
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
-                                 const ImgView& im, const BinView& b, bool check_cap, uint32_t cap, int lazy, float* clear,
-                                 size_t clear_bytes)
+                                 const ImgView& im, const BinView& b, bool check_cap, uint32_t cap, int lazy, bool pull)
 {
     RenderFwdArgs a;
-    a.clear = reinterpret_cast<float4*>(clear);
-    a.clear_vec4 = clear_bytes / 16;
     a.nsnap = gft_bwd_segments((size_t)((c.W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((c.H + GFT_TILE_Y - 1) / GFT_TILE_Y)) - 1;
     a.snaps = (c.want_backward && a.nsnap > 0) ? im.snaps : nullptr;
     a.ctrl = check_cap ? im.ctrl : nullptr;
     a.cap = cap;
-    a.totals = im.ctrl;
-    a.ranges1 = im.ranges1;
+    a.tile_cut = pull ? im.tile_cut : nullptr;
     a.W = c.W; a.H = c.H;
     a.gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X;
     const int gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
@@ -796,7 +753,6 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     const int gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     a.T = a.gx * gy;
     a.ranges = im.ranges; a.point_list = b.point_list; a.rec_a = g.rec_a; a.rec_b = g.rec_b;
-    a.ranges1 = im.ranges1;
     a.bg = io.bg; a.bsc = c.bg_stride_c; a.bsy = c.bg_stride_y; a.bsx = c.bg_stride_x;
     a.dc_offset = c.dc_offset;
     a.pix_state = im.pix_state; a.quad_max = im.tile_max;
@@ -822,7 +778,7 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     const int blocks = a.nseg * 32 * ((a.T + 7) / 8);
     hipLaunchKernelGGL(k_render_bwd, dim3(blocks), dim3(64), 0, s, a);
     if (a.det)
-        hipLaunchKernelGGL(k_acc_reduce_det, dim3(1), dim3(1024), 0, s, a.T, im.ranges, im.ranges1, im.tile_max, b.point_list,
+        hipLaunchKernelGGL(k_acc_reduce_det, dim3(1), dim3(1024), 0, s, a.T, im.ranges, im.tile_max, b.point_list,
                            a.det, io.acc);
     return hipGetLastError();
 }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GFT_ABI_VERSION 6
+#define GFT_ABI_VERSION 7
 
 /* compile-time constants of the reference (RAST/cuda_rasterizer/config.h:15-23) */
 #define GFT_NUM_CHANNELS 3
@@ -184,38 +184,43 @@ typedef struct gft_backward_io {
  * tests can inspect intermediate state stage by stage. */
 typedef struct gft_layout {
     /* geom */
-    size_t geom_rec_a;        /* float[P][8]  {x,y, conic a,b,c, opacity, dist_ndc, dist}; with a depth cut only for the Gaussians in
-                                 front of it and those the far pass binned (like rec_b, dirgrad, clamped) */
-    size_t geom_rec_b;        /* float[P][8]  {r,g,b, R,I,Am (ToF phasor basis: cos,sin,1 times A/d^2), phase_sh, amplitude} */
+    size_t geom_rec_a;        /* float[P][8]  {x,y, conic a,b,c, opacity, dist_ndc, dist} of every visible Gaussian */
+    size_t geom_rec_b;        /* float[P][8]  {r,g,b, R,I,Am (ToF phasor basis: cos,sin,1 times A/d^2), phase_sh, amplitude}; with
+                                 tile-pull binning only for the Gaussians marked in geom_need (like dirgrad, clamped) */
     size_t geom_depth;        /* float[P]     view-space z (sort key bits) */
     size_t geom_tiles;        /* uint32[P]    tiles touched */
     size_t geom_rect;         /* uint16[P][4] tile rectangle {x0,y0,x1,y1} (all 0 when culled) */
     size_t geom_dirgrad;      /* float[P][16] d rgb/d dir (9), d (phase,amp)/d dir (6), pad; only with want_backward */
     size_t geom_clamped;      /* uint8[P]     bit0..2 rgb clamped, bit3 amplitude clamped */
-    size_t geom_blockhist;    /* uint16[ceil(P/4096)][2048] instances per (4096-Gaussian block, tile); used when T <= 2048 */
+    size_t geom_need;         /* uint8[P]     tile-pull binning: 1 = the Gaussian stands in the sorted part of a tile list and has
+                                 its appearance records */
+    size_t geom_blockhist;    /* uint16[ceil(P/4096)][2048] instances per (4096-Gaussian block, tile); whole-frame binning, T <= 2048 */
     size_t geom_total;
     /* img */
     size_t img_pix_state;     /* float[N][4]  {final_T, n_contrib(bits), w_z, w_z2} */
     size_t img_ranges;        /* uint32[T][2] [first,last) of the tile's list */
     size_t img_tile_max;      /* uint32[T][4] max n_contrib over each 8x8 quadrant of the tile */
-    size_t img_ctrl;          /* uint32[16]   {R, flags, max tile list length, ...}; tile_cnt follows directly */
-    size_t img_tile_cnt;      /* uint32[T]    instances per tile (of the near slab when a depth cut is given) */
-    size_t img_tile_cnt1;     /* uint32[T]    lazy binning: far-slab instances of the tiles that asked for them */
-    size_t img_dhist;         /* uint32[256]  instances per log-depth bin (choice of the next depth cut) */
-    size_t img_ranges1;       /* uint2[T]     lazy binning: [first,last) of every tile's far-slab segment */
-    size_t img_super_tab;     /* uint32[5][1024] lazy binning: per supertile (S x S tiles) entry count, list start, cursor, id-list region, cursor */
+    size_t img_ctrl;          /* uint32[16]   {R, flags, max tile list length, ...}; tile_cnt, tile_cut, super_tab follow directly */
+    size_t img_tile_cnt;      /* uint32[T]    instances per tile (tile-pull binning with depth slabs: of the slabs a tile scanned) */
+    size_t img_tile_cut;      /* uint32[T]    tile-pull binning: first depth bin behind the sorted head of the tile's list;
+                                 0xffffffff: the head is the whole list */
+    size_t img_super_tab;     /* uint32[3][16384] tile-pull binning: per (supertile of S x S tiles, depth slab) entry count, list
+                                 start, scatter cursor */
     size_t img_tile_cursor;   /* uint32[T]    scatter cursors */
-    size_t img_tile_order;    /* uint32[T]    tiles by backward weight (written by gft_backward) */
-    size_t img_front_len;     /* uint32[T]    length of the sorted head of the tile's id list (lazy sort) */
-    size_t img_unit_flag;     /* uint32[4T]   quadrant ran out of sorted ids before saturating (lazy sort) */
+    size_t img_tile_order;    /* uint32[T]    tiles by backward weight, heaviest first */
+    size_t img_front_len;     /* uint32[T]    length of the sorted head of the tile's id list */
+    size_t img_unit_flag;     /* uint32[4T]   quadrant ran out of sorted ids before saturating */
     size_t img_resume_state;  /* float[N][16] blend state of such quadrants' pixels */
     size_t img_pix_sums;      /* float[N][8]  final blend sums {C0,C1,C2,R | I,Am,dist,A}: the split backward starts mid-list from them */
     size_t img_snaps;         /* float[4T][S-1][12][64] blend state of every 8x8 quadrant in front of list entries 256, 512, ...
                                  (S = up to 8 segments): where the other waves of a split backward walk start */
     size_t img_total;
     /* binning */
-    size_t bin_keys;          /* uint64[R]    (depth bits << 32 | Gaussian id), grouped by tile, unsorted */
-    size_t bin_point_list;    /* uint32[R]    Gaussian ids, per tile ascending (depth bits, id) */
+    size_t bin_keys;          /* uint64[R]    whole-frame binning: (depth bits << 32 | Gaussian id) grouped by tile, unsorted;
+                                 tile-pull binning: (Gaussian, supertile) entries id | rectangle << 32 | depth bin << 52 */
+    size_t bin_point_list;    /* uint32[2048 T + R] Gaussian ids, per tile ascending (depth bits, id).  Whole-frame binning: [0, R);
+                                 tile-pull binning: the sorted head of tile t at [2048 t, ...), lists completed on demand
+                                 (head + the part of the tail that reaches a quadrant that asked) from 2048 T on */
     size_t bin_total;
 } gft_layout;
 
@@ -235,7 +240,14 @@ size_t gft_geom_bytes(int32_t P);
 size_t gft_image_bytes(int32_t W, int32_t H);
 size_t gft_binning_bytes(int64_t R, int32_t W, int32_t H);
 size_t gft_acc_bytes(int32_t P);
-size_t gft_det_partials_bytes(int64_t binning_instances);   /* gft_backward_io.det_partials */
+size_t gft_det_partials_bytes(int64_t binning_instances, int32_t W, int32_t H);   /* gft_backward_io.det_partials */
+/* instances a binning buffer of `bytes` bytes holds (inverse of gft_binning_bytes for multiples of 64) */
+int64_t gft_binning_capacity(size_t bytes, int32_t W, int32_t H);
+/* 1: tile-pull binning (default): ids to supertiles, every tile pulls and sorts the head of its own list, lists are
+ * completed on demand.  0: whole-frame binning, the structure of the reference (every instance counted, keyed, sorted);
+ * also GFT_LAZY_BIN=0 in the environment.  Results are identical.  Process-wide; meant for tests and tuning. */
+int gft_set_binning_mode(int mode);
+int gft_binning_mode(const gft_config* cfg);   /* the mode a forward with this config runs in */
 int gft_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* out /*host*/);
 
 /* The forward in two stages, shaped like the reference's resize callbacks
@@ -255,30 +267,19 @@ int gft_forward_preprocess(void* hip_stream, const gft_config* cfg,
  * value goes to gft_backward, it fixes the layout inside the buffer. */
 int gft_forward_render(void* hip_stream, const gft_config* cfg,
                        const gft_forward_io* io, int64_t binning_instances,
-                       int64_t max_tile_list /* from stage 1; <= 0 = unknown */,
-                       float depth_cut /* the depth cut the preceding stage 1 ran with: 0 after
-                                          gft_forward_preprocess(), hints->depth_cut after a gft_forward() whose
-                                          buffer was too small */);
+                       int64_t max_tile_list /* from stage 1; <= 0 = unknown */);
 
 /* What a caller knows before the forward (from the previous frame of the same kind), for gft_forward(). */
 typedef struct gft_forward_hints {
     int64_t binning_instances;   /* instances `io->binning` holds (the caller's guess of R plus headroom) */
-    int64_t max_tile_list;       /* guess of the longest per-tile list (e.g. last frame's, with margin; <= 0 = unknown) */
-    int64_t near_instances;      /* lazy binning: guess of the near slab's instance count (<= 0 = unknown) */
-    float depth_cut;             /* lazy binning: view-space depth of the near slab's far side; <= 0 = bin every instance */
-    int32_t near_per_tile;       /* lazy binning: instances per tile the suggested next cut should leave in the near slab
-                                    (<= 0: the default, 896); raise it when gft_forward_late() reports flagged quadrants */
+    int64_t max_tile_list;       /* whole-frame binning without the lazy sort: guess of the longest per-tile list (<= 0 = unknown) */
 } gft_forward_hints;
 
 /* What the device reported while the forward was running. */
 typedef struct gft_forward_report {
     int64_t num_rendered;        /* R, the number of (Gaussian, tile) instances of the frame (reference: num_rendered) */
-    int64_t max_tile_list;       /* longest per-tile list that was binned up front */
-    int64_t near_instances;      /* instances binned up front (== num_rendered without a depth cut) */
-    float depth_cut_next;        /* depth cut this frame suggests for the next one (0 = bin every instance) */
-    int32_t late_slot;           /* handle of the late report, see gft_forward_late() */
-    uint32_t late_seq;
-    uint32_t reserved;
+    int64_t max_tile_list;       /* longest per-tile list (whole-frame binning; 0 with tile-pull binning) */
+    int64_t list_entries;        /* entries that were scattered: (Gaussian, supertile) pairs with tile-pull binning, else R */
 } gft_forward_report;
 
 /* The forward in one call, for callers that can guess R (a training loop: R of the
@@ -287,26 +288,12 @@ typedef struct gft_forward_report {
  * host; the call returns as soon as the device has posted R (stage 2 may still run).
  * If report->num_rendered > hints->binning_instances the stage-2 kernels have done nothing (they
  * compare the device-side count themselves): allocate for report->num_rendered and call
- * gft_forward_render().  A `max_tile_list` guess at or below 4096 skips the launches of the long-list
- * sort (GFT_LAZY_SORT=0 only); if the frame then does have a longer list the library sorts it and renders again
- * before returning.
- *
- * Lazy binning (`hints->depth_cut` > 0): a pixel stops reading its tile's list once its transmittance is below
- * 1e-4 (reference forward.cu:560-565), so in a dense frame most (Gaussian, tile) instances are never read.  Only
- * the instances with view-space depth <= depth_cut are counted, scattered and sorted up front; the others are
- * binned -- for the tiles concerned -- only if a pixel quadrant runs out of entries before all its pixels are
- * saturated, and those quadrants then continue.  Any cut is valid; report->depth_cut_next is the one that would
- * have put about 900 instances per tile into the near slab of THIS frame (0 when the frame has too few instances
- * for a cut to pay).  The binning buffer is still sized for all R instances.
+ * gft_forward_render().  The size of the buffer is the only thing taken from earlier frames: what is binned,
+ * sorted and given an appearance is decided from the frame itself (tile-pull binning).
  *
  * Results are identical to the two-stage flow in every case (same lists, same arithmetic order). */
 int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
                 const gft_forward_hints* hints, gft_forward_report* report /*host*/);
-
-/* Late report of a gft_forward(), written by the device near the end of that forward and never waited for: the
- * number of pixel quadrants that ran out of up-front sorted / binned entries before saturating (each costs a second
- * pass).  *flagged_quadrants = -1 while it has not arrived (or after 256 further forwards have reused its slot). */
-int gft_forward_late(int32_t late_slot, uint32_t late_seq, int64_t* flagged_quadrants /*host*/);
 
 /* The backward of the forward whose scratch buffers `io` carries.  Gradient sums are added with float atomics
  * (as in the reference), so two runs agree to rounding, not bit for bit.  GFT_BWD_SPLIT=0 in the environment

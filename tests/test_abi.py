@@ -88,13 +88,16 @@ def test_size_queries_and_layout_need_no_gpu(lib):
     assert lib.gft_image_bytes(640, 480) >= 640 * 480 * 16 + 1200 * 12
     L = _lib.get_layout(1000, 640, 480, 5000)
     offs = [getattr(L, n) for n in _lib.LAYOUT_FIELDS]
-    # every region is 256-B aligned, except tile_cnt which directly follows the 64-B ctrl block
-    # (the ctrl words, both slabs' tile counters and the depth histogram are contiguous: one clear)
-    assert all(o % 256 == 0 for n, o in zip(_lib.LAYOUT_FIELDS, offs) if n not in ("img_tile_cnt", "img_tile_cnt1", "img_dhist", "img_super_tab"))
-    assert L.img_tile_cnt == L.img_ctrl + 64 and L.img_tile_cnt1 == L.img_tile_cnt + 4 * 1200
-    assert L.img_dhist == L.img_tile_cnt1 + 4 * 1200
-    assert L.geom_rec_b >= 32 * 1000 and L.bin_point_list >= 8 * 5000 and L.bin_total >= 12 * 5000
+    # every region is 256-B aligned, except those that directly follow the 64-B ctrl block
+    # (the ctrl words, the tile counters, the tile cuts and the supertile tables are contiguous: one clear)
+    assert all(o % 256 == 0 for n, o in zip(_lib.LAYOUT_FIELDS, offs) if n not in ("img_tile_cnt", "img_tile_cut", "img_super_tab"))
+    assert L.img_tile_cnt == L.img_ctrl + 64 and L.img_tile_cut == L.img_tile_cnt + 4 * 1200
+    assert L.img_super_tab == L.img_tile_cut + 4 * 1200
+    assert L.geom_rec_b >= 32 * 1000 and L.bin_point_list >= 8 * 5000 and L.bin_total >= 12 * 5000 + 1200 * 2048 * 4
     assert lib.gft_binning_bytes(0, 640, 480) >= 0
+    # capacity <-> bytes (what the pybind-level backward reads back from the buffer it is handed)
+    for cap in (0, 64, 5056, 3_638_528):
+        assert lib.gft_binning_capacity(lib.gft_binning_bytes(cap, 640, 480), 640, 480) == cap
 
 
 def test_argument_errors_are_reported(lib):

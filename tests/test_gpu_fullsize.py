@@ -16,26 +16,53 @@ def _scene(name, P=None):
     return sc
 
 
+def _head_ids(P, W, H):
+    """ids sorted into tile-list heads by the most recent forward, and ids in lists that were completed on demand"""
+    from gftorf_amd import _lib, api
+    b = api.last_call_buffers
+    L = _lib.get_layout(P, W, H, b["cap"])
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    heads = int(b["img"][L.img_front_len:L.img_front_len + 4 * T].view(torch.int32).sum().item())
+    ctrl = b["img"][L.img_ctrl:L.img_ctrl + 64].view(torch.int32).cpu().tolist()
+    return heads, ctrl[6], ctrl[4]
+
+
 def test_metric_config_1m_vs_oracle(oracle, gpu):
-    """1 M Gaussians @ 640x480, SH deg 3, RGB + ToF, forward + backward: the bench workload."""
+    """1 M Gaussians @ 640x480, SH deg 3, RGB + ToF, forward + backward: the bench workload, in the flow of the first
+    frame of a shape (two stages, one blocking read) AND in the flow every later frame runs (one call, buffer sized from
+    the previous frame) -- the frames bench.py times.  Both through tile-pull binning: about a third of the frame's
+    instances are ever sorted, the rest is never formed."""
+    from gftorf_amd import _lib, api
     sc = _scene("metric")
     f, b = Hh.run_oracle(oracle, sc)
-    out, grads, _ = Hh.run_gpu(sc, gpu, optimize_offsets=True)
-    # integer decisions made per Gaussian: bit-exact
-    np.testing.assert_array_equal(out["radii"], f.radii)
-    for k in ["color", "phasor", "depth", "acc", "depth_distortion"]:
-        l1 = float(np.abs(out[k].astype(np.float64) - f[k]).mean())
-        assert l1 < 1e-5 * max(1.0, float(np.abs(f[k]).max())), (k, l1)
-    mism = float((out["pixels"] != f.pixels).mean())
-    assert mism < 2e-3, mism
-    for name, ref, got in [("means3D", b["dL_dmeans3D"], grads["means3D"]), ("means2D", b["dL_dmeans2D"], grads["means2D"]),
-                           ("opacity", b["dL_dopacity"], grads["opacities"]), ("sh", b["dL_dsh"], grads["shs"]),
-                           ("sh_p", b["dL_dsh_p"], grads["shs_p"]), ("scales", b["dL_dscales"], grads["scales"]),
-                           ("rot", b["dL_drotations"], grads["rotations"])]:
-        # element-wise band: a handful of splats sit on the 1/255 alpha edge of one pixel
-        Hh.assert_close(name, ref, got, rtol_max=5e-4, atol=1e-6, frac_bad=1e-5)
-    Hh.assert_close("phase_offset", b["dL_dphase_offset"], grads["phase_offset"], rtol_max=1e-3, atol=1e-3)
-    Hh.assert_close("dc_offset", b["dL_ddc_offset"], grads["dc_offset"], rtol_max=1e-3, atol=1e-3)
+    api._instance_hint.clear()
+    api.keep_last_buffers = True
+    try:
+        for frame in range(3):
+            out, grads, _ = Hh.run_gpu(sc, gpu, optimize_offsets=True)
+            st = api.last_call_stats
+            assert st["num_rendered"] == f.num_rendered and not st["restarted"]
+            if _lib.load().gft_lazy_sort():
+                heads, completed, flagged = _head_ids(sc["cfg"]["P"], sc["cfg"]["W"], sc["cfg"]["H"])
+                assert 0 < heads + completed < f.num_rendered // 2, (heads, completed, flagged)
+            # integer decisions made per Gaussian: bit-exact
+            np.testing.assert_array_equal(out["radii"], f.radii)
+            for k in ["color", "phasor", "depth", "acc", "depth_distortion"]:
+                l1 = float(np.abs(out[k].astype(np.float64) - f[k]).mean())
+                assert l1 < 1e-5 * max(1.0, float(np.abs(f[k]).max())), (k, l1, frame)
+            mism = float((out["pixels"] != f.pixels).mean())
+            assert mism < 2e-3, mism
+            for name, ref, got in [("means3D", b["dL_dmeans3D"], grads["means3D"]), ("means2D", b["dL_dmeans2D"], grads["means2D"]),
+                                   ("opacity", b["dL_dopacity"], grads["opacities"]), ("sh", b["dL_dsh"], grads["shs"]),
+                                   ("sh_p", b["dL_dsh_p"], grads["shs_p"]), ("scales", b["dL_dscales"], grads["scales"]),
+                                   ("rot", b["dL_drotations"], grads["rotations"])]:
+                # element-wise band: a handful of splats sit on the 1/255 alpha edge of one pixel
+                Hh.assert_close(name, ref, got, rtol_max=5e-4, atol=1e-6, frac_bad=1e-5)
+            Hh.assert_close("phase_offset", b["dL_dphase_offset"], grads["phase_offset"], rtol_max=1e-3, atol=1e-3)
+            Hh.assert_close("dc_offset", b["dL_ddc_offset"], grads["dc_offset"], rtol_max=1e-3, atol=1e-3)
+    finally:
+        api.keep_last_buffers = False
+        api.last_call_buffers.clear()
 
 
 def test_c2_500k_forward_backward_vs_oracle(oracle, gpu):
@@ -73,13 +100,13 @@ def test_c1_10k_256_deg0_rgb_forward_vs_oracle(oracle, gpu):
         assert not out[k].any()
 
 
-def test_c5_5m_1080p_with_deform_offsets_and_lazy_binning(gpu):
+def test_c5_5m_1080p_with_deform_offsets_tile_pull_vs_whole_frame(gpu):
     """BASELINE.json config 5 as it is named: 5 M Gaussians @ 1920x1080, ToF + dynamic deform -- d_xyz / d_sh of the
     deformation network (the architecture the reference constructs) for the 30 % dynamic Gaussians, composed in by the
     fused input assembly, forward + backward through all three pieces.  Size-independent properties: the frame rendered
-    with the near-slab binning (depth cut suggested by the previous frame) equals the frame with every instance binned
-    bit for bit, gradients reach the network, and the raster gradients equal those of feeding the assembled tensors."""
-    from gftorf_amd import GaussianRasterizer, api, assemble_inputs, reference_network
+    with tile-pull binning (the production path: depth slabs, list heads, appearance on demand) equals the frame with
+    every instance binned bit for bit, gradients reach the network, and the raster gradients agree."""
+    from gftorf_amd import GaussianRasterizer, _lib, api, assemble_inputs, reference_network
     from oracle import deform_ref
     sc = _scene("C5")
     P, W, H = sc["cfg"]["P"], sc["cfg"]["W"], sc["cfg"]["H"]
@@ -117,12 +144,16 @@ def test_c5_5m_1080p_with_deform_offsets_and_lazy_binning(gpu):
         return [o.detach().clone() for o in out], {k: v.grad.clone() for k, v in leaf.items()}, \
             {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, ssp.grad.clone(), st
 
-    o1, g1, n1, s1, st1 = frame()          # two-stage flow: every instance binned
-    o2, g2, n2, s2, st2 = frame()          # one-call flow, no cut yet: measures the depth histogram
-    o3, g3, n3, s3, st3 = frame()          # near-slab binning with the suggested cut
+    _lib.load().gft_set_binning_mode(0)
+    try:
+        o1, g1, n1, s1, st1 = frame()      # whole-frame binning (two-stage flow): every instance counted, keyed, sorted
+    finally:
+        _lib.load().gft_set_binning_mode(-1)
+    api._instance_hint.clear()
+    o2, g2, n2, s2, st2 = frame()          # tile-pull binning, two-stage flow (first frame of the shape)
+    o3, g3, n3, s3, st3 = frame()          # tile-pull binning, one call (buffer sized from the previous frame)
     R = st1["num_rendered"]
-    assert st1["near_instances"] == R and st2["near_instances"] == R and st3["num_rendered"] == R
-    assert st3["depth_cut"] > 0 and st3["near_instances"] < R // 3, st3
+    assert st2["num_rendered"] == R and st3["num_rendered"] == R and not st3["restarted"]
     for a, b, c in zip(o1, o2, o3):
         assert torch.equal(a, b) and torch.equal(a, c)
     assert all(torch.isfinite(v).all() for v in o1)
@@ -209,3 +240,61 @@ def test_metric_config_deterministic_backward_is_bit_reproducible(tmp_path, gpu)
         Hh.assert_close(k, det["g_" + k], grads[k], rtol_max=2e-5, atol=1e-7)
     Hh.assert_close("shs", det["g_shs"], grads["shs"][::16], rtol_max=2e-5, atol=1e-7)
     Hh.assert_close("shs_p", det["g_shs_p"], grads["shs_p"][::16], rtol_max=2e-5, atol=1e-7)
+
+
+def test_c3_shaped_view_sequence_vs_oracle(oracle, gpu):
+    """BASELINE.json config 3 at its named shape (configs/torf.json:15-23: 100 k Gaussians, 320x240; train.py:118-279): a
+    SEQUENCE of different views -- 8 of the 30 arc views in shuffled order, each as the colour-camera call and the
+    ToF-camera call of one iteration (gaussian_renderer/__init__.py:107-128), the active SH degree raised 0 -> 3 along the
+    way (train.py:143-145) -- through two long-lived GaussianRasterizer modules, so that every call but the first of
+    each kind runs the one-call flow with a buffer sized by another view's frame.  Every frame's images, counters and
+    gradients against the oracle."""
+    import math
+    import random
+    from gftorf_amd import GaussianRasterizer, api
+    P, W, H, V = 100_000, 320, 240, 30
+    base = synth.make_camera(W, H)
+    g = synth.make_gaussians(P, base, 1236, sh_coeffs=16, scale_lo=0.004, scale_hi=0.04)
+    bg, grads = synth.make_background(W, H, 5), synth.make_pixel_grads(W, H, 5)
+    order = list(range(V))
+    random.Random(3).shuffle(order)
+    api._instance_hint.clear()
+    leaf = {k: torch.tensor(v, dtype=torch.float32, device=gpu, requires_grad=True) for k, v in g.items()}
+    m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+    up = {k: torch.tensor(v, device=gpu) for k, v in grads.items()}
+    restarts = 0
+    for it, v in enumerate(order[:8]):
+        a = (v / (V - 1) - 0.5) * 0.30
+        pose = dict(yaw=a, pitch=0.04 * math.sin(3 * a))
+        degree = min(3, it // 2)
+        for tof in (False, True):
+            # the ToF sensor sits beside the colour camera (its own pose, scene/cameras.py:121-146)
+            w2c = synth.look_at_w2c(t=(-3.2 * math.sin(a) + (0.03 if tof else 0.0), 0.0, 3.2 * (1 - math.cos(a))), **pose)
+            sc = dict(cfg=dict(P=P, W=W, H=H, D=degree, sh_coeffs=16, tof=True), cam=synth.make_camera(W, H, w2c=w2c), gaussians=g,
+                      bg=bg, grads=grads, depth_range=10.0 if tof else 100.0, phase_offset=0.1 if tof else 0.0,
+                      dc_offset=0.02 if tof else 0.0, use_view_dependent_phase=tof)
+            f, b = Hh.run_oracle(oracle, sc)
+            for x in list(leaf.values()) + [m2]:
+                x.grad = None
+            out = GaussianRasterizer(Hh.gpu_settings(sc, gpu))(
+                means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf["shs"], shs_p=leaf["shs_p"],
+                scales=leaf["scales"], rotations=leaf["rotations"], phase_offset=sc["phase_offset"], dc_offset=sc["dc_offset"])
+            o = dict(zip(Hh.OUT_NAMES, out))
+            sum((o[k] * up[k]).sum() for k in Hh.GRAD_KEYS).backward()
+            st = api.last_call_stats
+            restarts += int(st["restarted"])
+            assert st["num_rendered"] == f.num_rendered, (it, tof)
+            np.testing.assert_array_equal(o["radii"].cpu().numpy(), f.radii)
+            for k in Hh.GRAD_KEYS + ["distribution"]:
+                got = o[k].detach().cpu().numpy()
+                l1 = float(np.abs(got.astype(np.float64) - f[k]).mean())
+                assert l1 < 1e-5 * max(1.0, float(np.abs(f[k]).max())), (k, l1, it, tof)
+                Hh.assert_close(k, f[k], got, rtol_max=2e-4, atol=1e-6, frac_bad=1e-3)
+            assert float((o["pixels"].detach().cpu().numpy() != f.pixels).mean()) < 2e-3
+            for name, ref, got in [("means3D", b["dL_dmeans3D"], leaf["means3D"].grad), ("means2D", b["dL_dmeans2D"], m2.grad),
+                                   ("opacity", b["dL_dopacity"], leaf["opacities"].grad), ("sh", b["dL_dsh"], leaf["shs"].grad),
+                                   ("sh_p", b["dL_dsh_p"], leaf["shs_p"].grad), ("scales", b["dL_dscales"], leaf["scales"].grad),
+                                   ("rot", b["dL_drotations"], leaf["rotations"].grad)]:
+                Hh.assert_close("%s (iteration %d, %s call)" % (name, it, "ToF" if tof else "colour"), ref, got.cpu().numpy(),
+                                rtol_max=5e-4, atol=1e-6, frac_bad=1e-5)
+    assert restarts <= 2          # the buffer guess (decaying maximum of the recent frames + 25 %) rarely misses

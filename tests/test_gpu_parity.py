@@ -2,6 +2,7 @@
 identical seeded inputs.  Integer/index stages bit-exact, fp32 stages within the
 tolerances written below (north star: rendered L1 < 1e-5, bit-exact tile/key
 indexing)."""
+import contextlib
 import ctypes as C
 import os
 
@@ -20,8 +21,9 @@ GRAD_RTOL = 3e-4       # gradients: fp32 atomics/reduction order + T recovered b
 
 
 # ---------------------------------------------------------------------------
-def raw_forward(scene, dev, inputs=None):
-    """Drive the C ABI directly so the scratch buffers can be inspected."""
+def raw_forward(scene, dev, inputs=None, mode=None):
+    """Drive the C ABI directly so the scratch buffers can be inspected.  mode: 1 = tile-pull binning, 0 = whole-frame
+    binning (gft_set_binning_mode), None = the library's default."""
     from gftorf_amd import _lib
     lib = _lib.load()
     g = dict(scene["gaussians"])
@@ -63,12 +65,19 @@ def raw_forward(scene, dev, inputs=None):
     R = C.c_int64(0)
     MX = C.c_int64(0)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    _lib.check(lib.gft_forward_preprocess(stream, C.byref(c), C.byref(io), C.byref(R), C.byref(MX)))
-    R = int(R.value)
-    binning = torch.zeros(lib.gft_binning_bytes(R, W, H), device=dev, dtype=torch.uint8)
-    io.binning = p(binning)
-    _lib.check(lib.gft_forward_render(stream, C.byref(c), C.byref(io), R, int(MX.value), 0.0))
-    torch.cuda.synchronize()
+    if mode is not None:
+        lib.gft_set_binning_mode(int(mode))
+    try:
+        pull = bool(lib.gft_binning_mode(C.byref(c)))
+        _lib.check(lib.gft_forward_preprocess(stream, C.byref(c), C.byref(io), C.byref(R), C.byref(MX)))
+        R = int(R.value)
+        binning = torch.zeros(lib.gft_binning_bytes(R, W, H), device=dev, dtype=torch.uint8)
+        io.binning = p(binning)
+        _lib.check(lib.gft_forward_render(stream, C.byref(c), C.byref(io), R, int(MX.value)))
+        torch.cuda.synchronize()
+    finally:
+        if mode is not None:
+            lib.gft_set_binning_mode(-1)
     L = _lib.get_layout(P, W, H, R)
     keep = (T, view, proj, campos, bg)
 
@@ -78,25 +87,33 @@ def raw_forward(scene, dev, inputs=None):
 
     Tn = ((W + 15) // 16) * ((H + 15) // 16)
     st = dict(
-        R=R, radii=radii.cpu().numpy(), pixels=pixels.cpu().numpy(), planes=planes.cpu().numpy(),
+        R=R, radii=radii.cpu().numpy(), pixels=pixels.cpu().numpy(), planes=planes.cpu().numpy(), pull=pull,
         rec_a=view_of(geom, L.geom_rec_a, P * 8, torch.float32).reshape(P, 8),
         rec_b=view_of(geom, L.geom_rec_b, P * 8, torch.float32).reshape(P, 8),
         depth=view_of(geom, L.geom_depth, P, torch.float32),
         tiles=view_of(geom, L.geom_tiles, P, torch.int32).astype(np.uint32),
         rect=view_of(geom, L.geom_rect, P * 4, torch.int16).astype(np.uint16).reshape(P, 4),
         clamped=view_of(geom, L.geom_clamped, P, torch.uint8),
-        ctrl=view_of(img, L.img_ctrl, 8, torch.int32).astype(np.uint32),
+        need=view_of(geom, L.geom_need, P, torch.uint8),
+        ctrl=view_of(img, L.img_ctrl, 16, torch.int32).astype(np.uint32),
         pix_state=view_of(img, L.img_pix_state, W * H * 4, torch.float32).reshape(H * W, 4),
         ranges=view_of(img, L.img_ranges, Tn * 2, torch.int32).astype(np.uint32).reshape(Tn, 2),
         tile_max=view_of(img, L.img_tile_max, Tn * 4, torch.int32).astype(np.uint32).reshape(Tn, 4),
         tile_cnt=view_of(img, L.img_tile_cnt, Tn, torch.int32).astype(np.uint32),
+        tile_cut=view_of(img, L.img_tile_cut, Tn, torch.int32).astype(np.uint32),
         front_len=view_of(img, L.img_front_len, Tn, torch.int32).astype(np.uint32),
         unit_flag=view_of(img, L.img_unit_flag, Tn * 4, torch.int32).astype(np.uint32).reshape(Tn, 4),
         lazy=bool(lib.gft_lazy_sort()),
-        point_list=view_of(binning, L.bin_point_list, R, torch.int32).astype(np.uint32) if R else np.zeros(0, np.uint32),
+        point_list=view_of(binning, L.bin_point_list, Tn * 2048 + R, torch.int32).astype(np.uint32) if R else np.zeros(0, np.uint32),
     )
     del keep
     return st
+
+
+def is_subsequence(sub, full):
+    """every element of `sub` occurs in `full`, in the same order"""
+    it = iter(full.tolist())
+    return all(any(x == y for y in it) for x in sub.tolist())
 
 
 SCENES = {
@@ -114,20 +131,24 @@ SCENES = {
 }
 
 
+@pytest.mark.parametrize("mode", [1, 0], ids=["tile_pull", "whole_frame"])
 @pytest.mark.parametrize("name", list(SCENES))
-def test_preprocess_and_binning_bit_exact(name, oracle, gpu):
+def test_preprocess_and_binning_bit_exact(name, mode, oracle, gpu):
     scene = Hh.small_scene(**SCENES[name])
     f, _ = Hh.run_oracle(oracle, scene, backward=False)
-    st = raw_forward(scene, gpu)
+    st = raw_forward(scene, gpu, mode=mode)
     og = f.geom
     vis = og["radii"] > 0
+    pull = st["pull"]
+    assert pull == (mode == 1 and st["lazy"])
     # integer decisions
     np.testing.assert_array_equal(st["radii"], og["radii"])
     np.testing.assert_array_equal(st["tiles"], og["tiles_touched"])
     assert st["R"] == f.num_rendered == int(st["ctrl"][0])
     lens = f.ranges[:, 1] - f.ranges[:, 0]
-    np.testing.assert_array_equal(st["tile_cnt"], lens)
-    assert int(st["ctrl"][2]) == int(lens.max())
+    np.testing.assert_array_equal(st["tile_cnt"], lens)          # (small frames: one depth slab, every tile scans its whole list)
+    if not pull:
+        assert int(st["ctrl"][2]) == int(lens.max())
     W, H = scene["cfg"]["W"], scene["cfg"]["H"]
     np.testing.assert_array_equal(
         (st["rect"][:, 2].astype(np.int64) - st["rect"][:, 0]) * (st["rect"][:, 3].astype(np.int64) - st["rect"][:, 1]),
@@ -139,20 +160,60 @@ def test_preprocess_and_binning_bit_exact(name, oracle, gpu):
     np.testing.assert_array_equal(st["rec_a"][vis, 4:6], og["conic_opacity"][vis, 2:4])
     np.testing.assert_array_equal(st["rec_a"][vis, 6], og["dists_ndc"][vis])
     np.testing.assert_array_equal(st["rec_a"][vis, 7], og["dists"][vis])
-    np.testing.assert_array_equal(st["rec_b"][vis, 0:3], og["rgb"][vis])
-    cl = og["clamped"][vis, 0] | (og["clamped"][vis, 1] << 1) | (og["clamped"][vis, 2] << 2) | (og["clamped_p"][vis] << 3)
-    np.testing.assert_array_equal(st["clamped"][vis], cl)
+    # appearance: of every visible Gaussian (whole-frame binning), of those that stand in the sorted part of a list
+    # (tile-pull binning: the Gaussians marked in `need`)
+    app = vis & (st["need"] != 0) if pull else vis
+    if pull:
+        assert not (st["need"][~vis]).any()
+    np.testing.assert_array_equal(st["rec_b"][app, 0:3], og["rgb"][app])
+    cl = og["clamped"][app, 0] | (og["clamped"][app, 1] << 1) | (og["clamped"][app, 2] << 2) | (og["clamped_p"][app] << 3)
+    np.testing.assert_array_equal(st["clamped"][app], cl)
     # transcendental stage (sinf/cosf differ by ulps between glibc and the device library)
     # device keeps the phasor on its (R, I, Am) basis; planes 3..6 are +-R + dc*Am, +-I + dc*Am
-    Hh.assert_close("phasor RIA", og["phasor7"][vis, 0:3], st["rec_b"][vis, 3:6], rtol_max=2e-6, atol=1e-9)
+    Hh.assert_close("phasor RIA", og["phasor7"][app, 0:3], st["rec_b"][app, 3:6], rtol_max=2e-6, atol=1e-9)
     dc = scene["dc_offset"]
-    R_, I_, A_ = st["rec_b"][vis, 3], st["rec_b"][vis, 4], st["rec_b"][vis, 5]
+    R_, I_, A_ = st["rec_b"][app, 3], st["rec_b"][app, 4], st["rec_b"][app, 5]
     quad = np.stack([R_ + dc * A_, -R_ + dc * A_, I_ + dc * A_, -I_ + dc * A_], 1)
-    Hh.assert_close("phasor quads", og["phasor7"][vis, 3:7], quad, rtol_max=3e-6, atol=1e-9)
-    Hh.assert_close("phase_amp", og["phase_amp"][vis], st["rec_b"][vis, 6:8], rtol_max=1e-6, atol=1e-9)
-    # sorted list / ranges: bit-identical; the reference's 64-bit keys follow from them
+    Hh.assert_close("phasor quads", og["phasor7"][app, 3:7], quad, rtol_max=3e-6, atol=1e-9)
+    Hh.assert_close("phase_amp", og["phase_amp"][app], st["rec_b"][app, 6:8], rtol_max=1e-6, atol=1e-9)
+    pl = st["point_list"]
+    if pull:
+        # Tile-pull binning: the sorted HEAD of every list (whole depth bins, about 940 ids; the whole list when it is
+        # short) = the first ids of the reference's sorted list; a tile with a flagged quadrant has its list completed:
+        # head + the ids of the tail that can reach a flagged quadrant, in the reference's order.
+        listed = np.zeros(st["need"].shape, bool)
+        for t in range(lens.size):
+            a, b = int(f.ranges[t, 0]), int(f.ranges[t, 1])
+            ref = f.point_list[a:b]
+            k = int(st["front_len"][t])
+            r0, r1 = int(st["ranges"][t, 0]), int(st["ranges"][t, 1])
+            assert k <= b - a and k <= 2048
+            assert (int(st["tile_cut"][t]) == 0xffffffff) == (k == b - a), "tile %d" % t
+            if b - a <= 1024:
+                assert k == b - a
+            elif k < b - a:
+                # whole bins up to the one where the count reaches 940; a bin that overshoots 1024 is left out unless
+                # the head would be shorter than 512
+                assert k <= 1024 or k <= 2048
+            got = pl[r0:r1]
+            listed[got] = True
+            np.testing.assert_array_equal(got[:k], ref[:k], err_msg="head of tile %d" % t)
+            if st["unit_flag"][t].any() and k < b - a:
+                assert r0 >= lens.size * 2048, "a completed list lives in the pool"
+                assert is_subsequence(got[k:], ref[k:]), "culled tail of tile %d" % t
+            else:
+                assert r1 - r0 == k and (k == 0 or r0 == t * 2048)
+        np.testing.assert_array_equal(st["need"] != 0, listed)
+        if int(st["front_len"].sum()):
+            heads = np.concatenate([pl[int(st["ranges"][t, 0]):int(st["ranges"][t, 0]) + int(st["front_len"][t])] for t in range(lens.size)])
+            tile_of = np.repeat(np.arange(lens.size, dtype=np.uint64), st["front_len"].astype(np.int64))
+            keys = (tile_of << np.uint64(32)) | st["depth"][heads].view(np.uint32).astype(np.uint64)
+            ref_keys = np.concatenate([f.keys_sorted[int(f.ranges[t, 0]):int(f.ranges[t, 0]) + int(st["front_len"][t])] for t in range(lens.size)])
+            np.testing.assert_array_equal(keys, ref_keys)
+        return
+    # whole-frame binning: sorted list / ranges bit-identical; the reference's 64-bit keys follow from them
     np.testing.assert_array_equal(st["ranges"], f.ranges)
-    pl = st["point_list"].copy()
+    pl = pl[:st["R"]].copy()
     if st["lazy"]:
         # lazy sort: the head of every list is sorted, the tail is sorted only where a quadrant
         # needed it; everywhere the list holds exactly the tile's instances
@@ -315,7 +376,7 @@ def test_edge_cases(oracle, gpu):
     for flow in ("two-stage", "one-call"):
         api._instance_hint.pop(key, None)
         if flow == "one-call":
-            api._instance_hint[key] = (1000, 0, 0.0, 0)
+            api._instance_hint[key] = (1000, 0)
         with pytest.raises(RuntimeError, match="prefiltered"):
             Hh.run_gpu(far, gpu, backward=False, prefiltered=True)
     Hh.run_gpu(scene, gpu, backward=False, prefiltered=True)      # nothing culled: fine
@@ -387,23 +448,13 @@ def test_one_call_forward_matches_two_stage(oracle, gpu):
     R = api.last_call_stats["num_rendered"]
     assert R > 0 and api.last_call_stats["binning_instances"] == (R + 63) // 64 * 64 and not api.last_call_stats["restarted"]
     key = next(iter(api._instance_hint))
-    # (instance guess, depth cut of the lazy binning, restart expected): the Gaussians lie at view depths 1 .. 5.5
-    for hint, cut, restarted in ((None, 0.0, False), (R, 0.0, False), (1, 0.0, True), (0, 0.0, True),
-                                 (R, 2.5, False), (R, 0.5, False), (R, 50.0, False), (1, 2.5, True)):
+    # (instance guess, restart expected)
+    for hint, restarted in ((None, False), (R, False), (1, True), (0, True), (3 * R, False)):
         if hint is not None:
-            api._instance_hint[key] = (hint, api._instance_hint[key][1], cut, 0)
-            api._slab_state.pop(key, None)      # (no pause after the frames whose cut left quadrants unsaturated)
+            api._instance_hint[key] = (hint, api._instance_hint[key][1])
         out, grads, _ = Hh.run_gpu(scene, gpu)
         st = api.last_call_stats
         assert st["num_rendered"] == R and st["restarted"] == restarted
-        if hint is not None:
-            assert st["depth_cut"] == cut
-            if cut == 2.5 and not restarted:
-                assert 0 < st["near_instances"] < R
-            elif cut == 0.5:
-                assert st["near_instances"] == 0
-            elif cut in (0.0, 50.0):
-                assert st["near_instances"] == R
         assert st["binning_instances"] >= R
         for k in ref_out:
             np.testing.assert_array_equal(out[k], ref_out[k], err_msg=k)
@@ -444,15 +495,16 @@ def test_one_call_forward_with_wrong_list_guess(oracle, gpu):
     """One-call flow on a frame whose longest tile list is over the short-sort limit while the
     caller's guess (previous frame) said it would not be: the library sorts the long lists and
     renders again; outputs, counters and gradients equal the two-stage flow."""
-    from gftorf_amd import api
+    from gftorf_amd import _lib, api
     scene = Hh.small_scene(**SCENES["long_lists_lds128k"])
+    _lib.load().gft_set_binning_mode(0)           # whole-frame binning (the long-list sort belongs to it); reset below
     api._instance_hint.clear()
     ref_out, ref_grads, _ = Hh.run_gpu(scene, gpu)               # two-stage flow
     R, longest = api.last_call_stats["num_rendered"], api.last_call_stats["max_tile_list"]
     assert longest > 4096
     key = next(iter(api._instance_hint))
     for list_guess in (100, longest):                             # wrong guess, right guess
-        api._instance_hint[key] = (R, list_guess, 0.0, 0)
+        api._instance_hint[key] = (R, list_guess)
         out, grads, _ = Hh.run_gpu(scene, gpu)
         assert api.last_call_stats["num_rendered"] == R and not api.last_call_stats["restarted"]
         for k in ref_out:
@@ -460,124 +512,90 @@ def test_one_call_forward_with_wrong_list_guess(oracle, gpu):
         for k in ref_grads:
             if ref_grads[k] is not None:
                 Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
+    _lib.load().gft_set_binning_mode(-1)
     f, b = Hh.run_oracle(oracle, scene)
     check_outputs(f, ref_out)
 
 
 BIN_CASES = {
-    # (scene, depth cuts): frames where no / every / some quadrant outlives the near slab
-    "base": (dict(), (2.0, 3.5)),
-    "deep_lists": (SCENES["deep_lists"], (1.5, 2.5, 4.0)),
-    "opaque_early_exit": (SCENES["opaque_early_exit"], (1.3, 2.0)),             # most quadrants saturate inside the near slab
-    "long_near_and_far": (SCENES["long_lists_lds128k"], (2.0, 3.5)),            # both slabs hold lists of thousands of keys
-    "thin_fog": (dict(P=40000, W=64, H=64, scale_lo=0.01, scale_hi=0.05, opacity=0.02), (1.5, 3.0)),   # nothing saturates
-    "flat_depth": (SCENES["long_lists_flat"], (3.0, 2.9999)),                   # every key on one side of the cut
+    # frames where no / every / some quadrant walks past the sorted head of its list
+    "base": dict(),
+    "deep_lists": SCENES["deep_lists"],
+    "opaque_early_exit": SCENES["opaque_early_exit"],              # most quadrants saturate inside the head
+    "long_lists": SCENES["long_lists_lds128k"],                    # lists of thousands of keys, heads of ~940
+    "thin_fog": dict(P=40000, W=64, H=64, scale_lo=0.01, scale_hi=0.05, opacity=0.02),   # nothing saturates: every list is completed
+    "flat_depth": SCENES["long_lists_flat"],                       # every key in one depth bin: empty heads, the lists are built on demand
+    "global_tail": SCENES["long_lists_global"],                    # a culled tail larger than the LDS sorter: bin ranges
+    "silhouette": dict(P=30000, W=96, H=64, scale_lo=0.005, scale_hi=0.05, spread=0.55),   # cloud edge inside the image: quadrants that never saturate beside dense ones
 }
 
 
+@contextlib.contextmanager
+def binning_mode(mode):
+    from gftorf_amd import _lib
+    lib = _lib.load()
+    lib.gft_set_binning_mode(int(mode))
+    try:
+        yield
+    finally:
+        lib.gft_set_binning_mode(-1)
+
+
 @pytest.mark.parametrize("name", list(BIN_CASES))
-def test_lazy_binning_matches_full_binning(name, oracle, gpu):
-    """Depth-cut binning (near slab up front, far slab on demand for the tiles that ask): every output bit-identical
-    to the run that bins every instance, gradients equal up to the order of the atomic sums, for cuts in front of,
-    inside and behind the Gaussians, and the whole thing against the oracle."""
+def test_tile_pull_matches_whole_frame_binning(name, oracle, gpu):
+    """Tile-pull binning (heads pulled per tile, appearance on demand, lists completed and culled for flagged quadrants)
+    against whole-frame binning (every instance counted, keyed and sorted): every output bit-identical, in the first
+    frame of a shape (two-stage flow) and in the following ones (one call, buffer sized from the previous frame);
+    gradients equal up to the order of the atomic sums; and the whole thing against the oracle."""
     from gftorf_amd import _lib, api
-    kw, cuts = BIN_CASES[name]
-    scene = Hh.small_scene(seed=23, **kw)
+    if not _lib.load().gft_lazy_sort():
+        pytest.skip("GFT_LAZY_SORT=0: whole-frame binning only")
+    scene = Hh.small_scene(seed=23, **BIN_CASES[name])
+    with binning_mode(0):
+        api._instance_hint.clear()
+        ref_out, ref_grads, _ = Hh.run_gpu(scene, gpu)
+        R = api.last_call_stats["num_rendered"]
     api._instance_hint.clear()
-    ref_out, ref_grads, _ = Hh.run_gpu(scene, gpu)               # two-stage flow: every instance binned
-    R = api.last_call_stats["num_rendered"]
-    key = next(iter(api._instance_hint))
-    longest = api._instance_hint[key][1]
-    seen_partial = False
-    for cut in cuts:
-        api._instance_hint[key] = (R, longest, cut, 0)
-        api._slab_state.pop(key, None)                           # (no pause after a cut that left quadrants unsaturated)
+    for frame in range(3):
         out, grads, _ = Hh.run_gpu(scene, gpu)
         st = api.last_call_stats
-        assert st["num_rendered"] == R and not st["restarted"] and st["depth_cut"] == cut
-        assert 0 <= st["near_instances"] <= R
-        seen_partial |= 0 < st["near_instances"] < R
-        if not _lib.load().gft_lazy_sort():
-            assert st["near_instances"] == R                      # GFT_LAZY_SORT=0: no flags to resume from, no cut
+        assert st["num_rendered"] == R and not st["restarted"]
         for k in ref_out:
-            np.testing.assert_array_equal(out[k], ref_out[k], err_msg="%s cut %g" % (k, cut))
+            np.testing.assert_array_equal(out[k], ref_out[k], err_msg="%s frame %d" % (k, frame))
         for k in ref_grads:
             if ref_grads[k] is not None:
                 Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
-    if _lib.load().gft_lazy_sort() and name != "flat_depth":
-        assert seen_partial, "no cut of this case split the instances"
     f, b = Hh.run_oracle(oracle, scene)
     check_outputs(f, ref_out)
+    check_grads(b, grads, scene)
 
 
-def test_lazy_binning_cut_suggestion(gpu):
-    """The forward reports a depth cut for the next frame of the same kind: none for a frame with few instances per
-    tile, one that leaves about 900 instances per tile in the near slab for a dense frame; the frames rendered with
-    it equal the first one bit for bit."""
-    from gftorf_amd import _lib, api
+def test_tile_pull_structure(gpu, oracle):
+    """What the tile-pull forward leaves behind on frames that exercise its branches: short lists sorted whole and never
+    flagged; long lists with a head of about 940 ids; quadrants that walk past their head flagged and their tile's list
+    completed in the pool; Gaussians outside every sorted part without an appearance."""
+    from gftorf_amd import _lib
     if not _lib.load().gft_lazy_sort():
-        pytest.skip("GFT_LAZY_SORT=0")
-    sparse = Hh.small_scene(P=3000, seed=11)
-    api._instance_hint.clear()
-    for _ in range(3):
-        Hh.run_gpu(sparse, gpu, backward=False)
-    assert next(iter(api._instance_hint.values()))[2] == 0.0      # R is far below 1.5 x 896 per tile: no cut
-    dense = Hh.small_scene(seed=29, P=60000, W=64, H=64, scale_lo=0.01, scale_hi=0.06, opacity=0.6)
-    api._instance_hint.clear()
-    first, _, _ = Hh.run_gpu(dense, gpu, backward=False)          # two-stage, no cut, none suggested yet
-    R = api.last_call_stats["num_rendered"]
-    T = 16
-    assert R > 3 * 896 * T
-    Hh.run_gpu(dense, gpu, backward=False)                        # one-call without a cut: measures the depth histogram
-    cut = next(iter(api._instance_hint.values()))[2]
-    assert 1.0 < cut < 5.5
-    for _ in range(2):
-        api._slab_state.pop(next(iter(api._instance_hint)), None)     # (the cut itself is tested here, not the policy)
-        out, _, _ = Hh.run_gpu(dense, gpu, backward=False)
-        st = api.last_call_stats
-        assert st["depth_cut"] == cut and st["num_rendered"] == R
-        # the near slab holds about 896 instances per tile (one histogram bin of slack)
-        assert 0.8 * 896 * T <= st["near_instances"] <= 1.6 * 896 * T, st
-        for k in first:
-            np.testing.assert_array_equal(out[k], first[k], err_msg=k)
-    key = next(iter(api._instance_hint))
-    api._slab_state.pop(key, None)
-    # a cut that is too shallow: every quadrant outlives the near slab; the device reports them late (never waited for),
-    # the frame after reads the report -- far more than 1 % of the quadrants: whole frames are binned for a while (the
-    # second pass costs more than the cut saves), then the cut is tried again
-    h = api._instance_hint[key]
-    api._instance_hint[key] = (h[0], h[1], 1.02, 0)
-    out, _, _ = Hh.run_gpu(dense, gpu, backward=False)
-    assert api.last_call_stats["depth_cut"] == pytest.approx(1.02)
-    for k in first:
-        np.testing.assert_array_equal(out[k], first[k], err_msg=k)
-    torch.cuda.synchronize()
-    out, _, _ = Hh.run_gpu(dense, gpu, backward=False)            # reads the report
-    assert api._slab_state[key]["backoff"] == 4 and api.last_call_stats["depth_cut"] == 0.0
-    for k in first:
-        np.testing.assert_array_equal(out[k], first[k], err_msg=k)
-    for _ in range(3):
-        Hh.run_gpu(dense, gpu, backward=False)
-        assert api.last_call_stats["depth_cut"] == 0.0
-    out, _, _ = Hh.run_gpu(dense, gpu, backward=False)            # the pause is over: the suggested cut again
-    assert api.last_call_stats["depth_cut"] == cut
-    for k in first:
-        np.testing.assert_array_equal(out[k], first[k], err_msg=k)
-    # a few flagged quadrants (at most 1 %) only widen the next near slab
-    api._slab_state[key].update(per_tile=896, late=None, off=0)
-    import gftorf_amd.api as A
-    lib = A._lib.load()
-    real = lib.gft_forward_late
-    try:
-        def fake(slot, seq, ref):
-            ref._obj.value = 1
-            return 0
-        api._slab_state[key]["late"] = (0, 0)
-        A._lib.load().gft_forward_late = fake
-        Hh.run_gpu(dense, gpu, backward=False)
-    finally:
-        A._lib.load().gft_forward_late = real
-    assert api._slab_state[key]["per_tile"] > 896 and api._slab_state[key]["off"] == 0
+        pytest.skip("GFT_LAZY_SORT=0: whole-frame binning only")
+    fog = Hh.small_scene(seed=21, P=40000, W=64, H=64, scale_lo=0.01, scale_hi=0.05, opacity=0.02)
+    st = raw_forward(fog, gpu, mode=1)
+    f, _ = Hh.run_oracle(oracle, fog, backward=False)
+    lens = f.ranges[:, 1] - f.ranges[:, 0]
+    long_tiles = lens > 1024
+    assert long_tiles.any() and st["pull"]
+    assert ((st["front_len"][long_tiles] >= 512) & (st["front_len"][long_tiles] <= 2048)).all()
+    flagged = st["unit_flag"].any(1)
+    assert flagged[long_tiles].all() and int(st["ctrl"][4]) == int(st["unit_flag"].sum())      # nothing saturates in fog
+    assert (st["ranges"][long_tiles, 0] >= lens.size * 2048).all()                                # completed lists live in the pool
+    assert int(st["ctrl"][6]) == int((st["ranges"][flagged, 1] - st["ranges"][flagged, 0]).sum())  # pool slots taken
+    opaque = Hh.small_scene(seed=21, P=30000, W=64, H=48, scale_lo=0.02, scale_hi=0.1, opacity=0.9)
+    st = raw_forward(opaque, gpu, mode=1)
+    f, _ = Hh.run_oracle(oracle, opaque, backward=False)
+    lens = f.ranges[:, 1] - f.ranges[:, 0]
+    assert (lens > 1024).any() and not st["unit_flag"].any() and int(st["ctrl"][6]) == 0          # all saturate early: no list is completed
+    vis = f.geom["radii"] > 0
+    assert 0 < (st["need"] != 0).sum() < 0.6 * vis.sum()                                          # most Gaussians never get an appearance
+    assert (st["ranges"][:, 1] - st["ranges"][:, 0] == st["front_len"]).all()
 
 
 LAZY_CASES = {
@@ -596,7 +614,7 @@ def test_lazy_sort_resume_paths(name, oracle, gpu):
     'never resumes', 'always resumes' and the mix."""
     scene = Hh.small_scene(seed=21, **LAZY_CASES[name])
     f, b = Hh.run_oracle(oracle, scene)
-    st = raw_forward(scene, gpu)
+    st = raw_forward(scene, gpu, mode=0)                      # whole-frame binning: k_tile_front / k_tile_tail
     lens = f.ranges[:, 1] - f.ranges[:, 0]
     if st["lazy"]:
         long_tiles = lens > 1024
@@ -614,9 +632,11 @@ def test_lazy_sort_resume_paths(name, oracle, gpu):
             np.testing.assert_array_equal(st["point_list"][a:a + k], f.point_list[a:a + k])
             if flagged[t]:
                 np.testing.assert_array_equal(st["point_list"][a:e], f.point_list[a:e])
-    out, grads, _ = Hh.run_gpu(scene, gpu)
-    check_outputs(f, out)
-    check_grads(b, grads, scene)
+    for mode in (0, 1):
+        with binning_mode(mode):
+            out, grads, _ = Hh.run_gpu(scene, gpu)
+        check_outputs(f, out)
+        check_grads(b, grads, scene)
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
