@@ -207,6 +207,16 @@ __device__ __forceinline__ void gft_get_rect(float px, float py, int radius, int
     y1 = min(gy, max(0, (int)((((py + r) + 16.0f) - 1.0f) / 16.0f)));
 }
 
+// Depth bin of the tile-pull binning: GFT_DEPTH_BINS equal steps of the depth's float bits from the near plane on -- a
+// monotone integer function of the depth bits (positive floats order like their bits), no transcendental: keys of a
+// lower bin are smaller than keys of a higher bin.
+__device__ __forceinline__ uint32_t gft_depth_bin(uint32_t dbits, uint32_t near_bits, int shift)
+{
+    const uint32_t d = dbits > near_bits ? dbits - near_bits : 0u;
+    const uint32_t b = d >> shift;
+    return b < GFT_DEPTH_BINS ? b : GFT_DEPTH_BINS - 1u;
+}
+
 // Can a splat reach the 8x8 pixel quadrant whose first pixel centre is (qx0, qy0)?  a0 = {x, y, conic a, b},
 // a1 = {conic c, opacity, ..}.  alpha = min(0.99, o*exp(power)) >= 1/255  <=>  power >= -tau, tau = ln(255 o), i.e. the
 // pixels that can blend this splat lie in the ellipse q(u) = a ux^2 + 2 b ux uy + c uy^2 <= 2 tau around the centre.

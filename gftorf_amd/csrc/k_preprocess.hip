@@ -308,10 +308,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
 // Appearance on demand (tile-pull binning, k_pull.hip): the Gaussians k_tile_pull marked -- those in the sorted head of
 // some tile list -- get their SH colour, SH (phase, amplitude), phasor basis, direction gradients and clamp flags.  The
 // 320 bytes of SH coefficients of every other Gaussian are never read.  The marked Gaussians are scattered (one in
-// seven on the metric frame): a workgroup first compacts the ids of its 2048 Gaussians into LDS, so that every lane of
-// its waves then has a Gaussian to evaluate (a lane per Gaussian over all P ran with a sixth of its lanes: 36 us vs 21).
+// seven on the metric frame): a workgroup first compacts the ids of its 1024 Gaussians into LDS, so that the lanes of
+// its waves have a Gaussian each to evaluate (a lane per Gaussian over all P runs with a sixth of its lanes: 36 us).
 #define APP_THREADS 256
-#define APP_CHUNK 2048
+#define APP_CHUNK 1024        // Gaussians per workgroup: with one in seven wanted, a workgroup's compacted list fills one round of its lanes
 __global__ __launch_bounds__(APP_THREADS) void k_appearance(PreFwdArgs a, uint32_t cap)
 {
     __shared__ uint32_t s_ids[APP_CHUNK];
@@ -321,14 +321,16 @@ __global__ __launch_bounds__(APP_THREADS) void k_appearance(PreFwdArgs a, uint32
     if (tid == 0) s_n = 0;
     __syncthreads();
     const int base = blockIdx.x * APP_CHUNK;
-    // eight flags per thread as one 8-byte load (P is padded by the layout's alignment: reads past P stay inside geom)
+    // four flags per thread as one 4-byte load (P is padded by the layout's alignment: reads past P stay inside geom)
     {
-        const int i0 = base + tid * 8;
-        unsigned long long w = 0ull;
-        if (i0 < a.c.P) w = *reinterpret_cast<const unsigned long long*>(a.g.need + i0);
+        constexpr int PER = APP_CHUNK / APP_THREADS;
+        static_assert(PER == 4, "one 4-byte load of flags per thread");
+        const int i0 = base + tid * PER;
+        uint32_t w = 0u;
+        if (i0 < a.c.P) w = *reinterpret_cast<const uint32_t*>(a.g.need + i0);
         uint32_t mine = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) mine += (i0 + k < a.c.P && ((w >> (8 * k)) & 0xffull)) ? 1u : 0u;
+        for (int k = 0; k < PER; k++) mine += (i0 + k < a.c.P && ((w >> (8 * k)) & 0xffu)) ? 1u : 0u;
         // slots of this thread's ids: wave prefix + one LDS atomic per wave
         uint32_t x = mine;
 #pragma unroll
@@ -341,8 +343,8 @@ __global__ __launch_bounds__(APP_THREADS) void k_appearance(PreFwdArgs a, uint32
         wb = (uint32_t)__shfl((int)wb, 63, 64);
         uint32_t pos = wb + x - mine;
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (i0 + k < a.c.P && ((w >> (8 * k)) & 0xffull)) s_ids[pos++] = (uint32_t)(i0 + k);
+        for (int k = 0; k < PER; k++)
+            if (i0 + k < a.c.P && ((w >> (8 * k)) & 0xffu)) s_ids[pos++] = (uint32_t)(i0 + k);
     }
     __syncthreads();
     const uint32_t n = s_n;

@@ -14,8 +14,9 @@
 //   k_tile_pull      : one workgroup per tile scans its supertile's entries (L2), histograms its hits over the
 //                      depth bins, takes the nearest ~940 (whole bins) as the HEAD of its list: gathers their
 //                      depths, sorts the (depth bits, id) keys in LDS, writes the ids into the tile's head slot
-//                      and marks those Gaussians as needed (appearance on demand, k_preprocess.hip).  The rest
-//                      of the list is never formed unless somebody walks that far.
+//                      and marks those Gaussians as needed (appearance on demand, k_preprocess.hip; deriving the
+//                      marks in that kernel from the tiles' cuts instead cost it more than the byte stores cost
+//                      here: -6 / +11 us).  The rest of the list is never formed unless somebody walks that far.
 //   k_tail_build     : for the tiles with a FLAGGED quadrant (walked its whole head with unsaturated pixels --
 //                      the silhouette quadrants of a scene, whose pixels never saturate): pulls the rest of the
 //                      list, CULLS it against the flagged quadrants (most entries of a tile do not reach a given
@@ -42,13 +43,6 @@ namespace {
 #define HEAD_TARGET 940u            // wanted length of the sorted head of a longer list
 #define TAIL_LDS_KEYS 4096u         // culled tails are sorted in LDS in runs of at most this many keys (whole depth bins)
 #define TAIL_THREADS 512              // (1024 threads leave 128 registers per lane: the appearance evaluation then spills)
-
-__device__ __forceinline__ uint32_t depth_bin(uint32_t dbits, uint32_t near_bits, int shift)
-{
-    const uint32_t d = dbits > near_bits ? dbits - near_bits : 0u;
-    const uint32_t b = d >> shift;
-    return b < GFT_DEPTH_BINS ? b : GFT_DEPTH_BINS - 1u;
-}
 
 // entry = id | rel << 32 | bin << 52;  rel = x0 | y0 << 5 | x1 << 10 | y1 << 15 (tiles from the supertile's corner)
 __device__ __forceinline__ bool entry_hits(uint64_t e, uint32_t lx, uint32_t ly)
@@ -98,7 +92,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         r4[u] = in ? a.rect[idx] : make_ushort4(0, 0, 0, 0);
         const uint32_t tiles = (uint32_t)(r4[u].z - r4[u].x) * (uint32_t)(r4[u].w - r4[u].y);
         // (the depth is not written for culled Gaussians and not used for them either)
-        bin[u] = (in && tiles) ? depth_bin(__float_as_uint(a.depth[idx]), a.sh.near_bits, a.sh.bin_shift) : 0u;
+        bin[u] = (in && tiles) ? gft_depth_bin(__float_as_uint(a.depth[idx]), a.sh.near_bits, a.sh.bin_shift) : 0u;
         mine += tiles;
     }
     if (PASS == 0) {
@@ -211,6 +205,7 @@ struct PullArgs {
     const uint32_t* __restrict__ ctrl;
     uint32_t cap;
     float4* __restrict__ clear; size_t clear_vec4;
+    int dbg;
 };
 
 // block -> tile: blocks are dealt round-robin to the 8 XCDs; every XCD gets one contiguous run of the tiles in
@@ -242,16 +237,20 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
     __shared__ uint32_t s_n, s_cut, s_kf;
     __shared__ uint32_t s_wt[GFT_BLOCK / 64];
     if (a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
-    // fire-and-forget zero fill of the backward's accumulator: the stores drain while this workgroup works in LDS
-    if (a.clear) {
+    // Fire-and-forget zero fill of the backward's accumulator (64 B per Gaussian).  Issued where only LDS work and stores
+    // follow (in front of the sort): loads and stores count down one in-order counter, so a load behind these stores
+    // waits until HBM has taken all of them -- at the top of the kernel that stalled the first list read of every
+    // workgroup behind 64 MB of writes.
+    auto clear_slice = [&]() {
+        if (!a.clear) return;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         for (size_t i = (size_t)blockIdx.x * GFT_BLOCK + threadIdx.x; i < a.clear_vec4; i += (size_t)gridDim.x * GFT_BLOCK)
             a.clear[i] = z;
-    }
+    };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile, q;
     uint32_t lx, ly;
-    if (!pull_tile_of_block(a.sh, (int)blockIdx.x, tile, q, lx, ly)) return;
+    if (!pull_tile_of_block(a.sh, (int)blockIdx.x, tile, q, lx, ly)) { clear_slice(); return; }
     const int K = a.sh.K;
     for (int i = tid; i < GFT_DEPTH_BINS; i += GFT_BLOCK) s_hist[i] = 0;
     if (tid == 0) s_n = 0;
@@ -315,6 +314,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
         __syncthreads();                                 // (everybody has read the count before the next slab adds to it)
         if (n >= HEAD_TARGET) { kstop = k; break; }
     }
+    if (a.dbg == 1) { if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     bool more_slabs = false;
     for (int k = kstop + 1; k < K; k++) more_slabs |= a.st_cnt[q * K + k] != 0u;
     // the head: whole bins up to the one where the running count reaches HEAD_TARGET.  That bin is taken if the head then
@@ -352,6 +352,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
         kf = s_kf;
     }
     __syncthreads();
+    if (a.dbg == 2) { if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     if (tid == 0) s_n = 0;
     __syncthreads();
     // pass B: the head's keys
@@ -371,6 +372,8 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
         a.tile_cut[tile] = has_tail ? first_tail : GFT_NO_TAIL;
     }
     __syncthreads();
+    clear_slice();
+    if (a.dbg == 3) { if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     if (kf == 0u) return;
     uint32_t* ids = a.heads + start;
     if (kf <= 1024u) {
@@ -708,6 +711,9 @@ hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomVi
     a.tile_cnt = im.tile_cnt; a.tile_cut = im.tile_cut; a.need = g.need;
     a.ctrl = im.ctrl; a.cap = cap;
     a.clear = reinterpret_cast<float4*>(clear); a.clear_vec4 = clear_bytes / 16;
+    static const int dbg = [] { const char* e = getenv("GFT_PULL_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
+    if (dbg == 4) { a.clear = nullptr; a.dbg = 0; }
     const int Np = a.sh.NS << (2 * a.sh.sshift);
     hipLaunchKernelGGL(k_tile_pull, dim3(8 * ((Np + 7) / 8)), dim3(GFT_BLOCK), 0, s, a);
     return hipGetLastError();
