@@ -612,7 +612,15 @@ def train_iteration_extra(dev, scene, steps=10, warmup=3):
         torch.cuda.synchronize(dev)
         return a.elapsed_time(b) / k
 
+    from gftorf_amd import deform as deform_mod
     hip_ms = timed(build(True), steps, warmup)
+    net_rows = dict(deform_mod.last_backward_stats)
+    torch.cuda.empty_cache()
+    deform_mod.sparse_backward = False
+    try:
+        dense_ms = timed(build(True), steps, warmup)      # the network's backward over all queried points (round 2's)
+    finally:
+        deform_mod.sparse_backward = True
     torch.cuda.empty_cache()
     pair_ms = timed(build(True, pair=True), steps, warmup)
     torch.cuda.empty_cache()
@@ -620,6 +628,11 @@ def train_iteration_extra(dev, scene, steps=10, warmup=3):
     return {"what": "one training iteration of the reference's loop shape, %d Gaussians (30 %% dynamic), %dx%d: network query, "
                     "input assembly, colour + ToF rasterizer call (fwd/bwd), statistics, Adam" % (P, cfg["W"], cfg["H"]),
             "hip_ms": hip_ms, "hip_it_per_s": 1e3 / hip_ms,
+            # the network's backward runs over the points with a non-zero upstream gradient row only (the Gaussians some
+            # pixel blended); `network_backward_over_all_points_ms`: the same iteration with that switched off
+            "network_backward_points": net_rows["points"], "network_backward_points_processed": net_rows["points_processed"],
+            "network_backward_fraction": net_rows["points_processed"] / max(net_rows["points"], 1),
+            "network_backward_over_all_points_ms": dense_ms,
             # the same iteration with the two rasterizer calls as one GaussianRasterizerPair (opt-in API)
             "hip_pair_ms": pair_ms, "hip_pair_it_per_s": 1e3 / pair_ms,
             "eager_glue_ms": eager_ms, "speedup": eager_ms / hip_ms}

@@ -134,7 +134,7 @@ EXPORTS = [
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
     "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi", "gft_adam_step_rows",
     "gft_deform_inputs", "gft_deform_packed_bytes", "gft_deform_saved_bytes", "gft_deform_scratch_bytes", "gft_deform_pack",
-    "gft_deform_forward", "gft_deform_backward",
+    "gft_deform_forward", "gft_deform_backward", "gft_deform_compact",
     "gft_densify_stats", "gft_rows_rank_scratch_bytes", "gft_rows_rank", "gft_rows_gather",
 ]
 
@@ -201,6 +201,8 @@ def load():
     lib.gft_deform_backward.restype = C.c_int
     lib.gft_deform_backward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(DeformParams)]
+    lib.gft_deform_compact.restype = C.c_int
+    lib.gft_deform_compact.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 9
     lib.gft_densify_stats.restype = C.c_int
     lib.gft_densify_stats.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8
     lib.gft_rows_rank_scratch_bytes.restype = C.c_size_t

@@ -1412,6 +1412,44 @@ hipError_t set_attrs()
     return hipSuccess;
 }
 
+// ---- backward over the rows with a non-zero upstream gradient only (gft_deform_compact) ---------------------------
+// idx[rank[row]] = row for the selected rows
+__global__ __launch_bounds__(256) void k_deform_compact_index(int64_t n, const uint8_t* __restrict__ mask, const int32_t* __restrict__ rank,
+                                                              int32_t* __restrict__ idx)
+{
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row < n && mask[row]) idx[rank[row]] = (int32_t)row;
+}
+
+// dst[plane][r][0..width) = src[plane][idx[r]][0..width) for r < k, zeros for the padded rows k <= r < k_pad (the
+// weight-gradient GEMMs multiply them by zero gradients: they must hold finite values).  One workgroup per (row, plane).
+__global__ __launch_bounds__(64) void k_deform_compact_rows(int64_t k, int width /* floats, a multiple of 4 */, int64_t src_plane, int64_t dst_plane,
+                                                            const int32_t* __restrict__ idx, const float* __restrict__ src, float* __restrict__ dst)
+{
+    const int64_t r = blockIdx.x;
+    const int plane = blockIdx.y;
+    float4* d = reinterpret_cast<float4*>(dst + plane * dst_plane + r * width);
+    if (r < k) {
+        const float4* s4 = reinterpret_cast<const float4*>(src + plane * src_plane + (int64_t)idx[r] * width);
+        for (int i = threadIdx.x; i < width / 4; i += 64) d[i] = s4[i];
+    } else {
+        for (int i = threadIdx.x; i < width / 4; i += 64) d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// upstream gradient rows (3 and 48 floats: 4-byte pieces)
+__global__ __launch_bounds__(256) void k_deform_compact_grads(int64_t k, const int32_t* __restrict__ idx, const float* __restrict__ gx,
+                                                              const float* __restrict__ gs, float* __restrict__ gx_c, float* __restrict__ gs_c)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = e / 51;
+    if (r >= k) return;
+    const int c = (int)(e - r * 51);
+    const int64_t row = idx[r];
+    if (c < 3) { if (gx) gx_c[r * 3 + c] = gx[row * 3 + c]; }
+    else if (gs) gs_c[r * 48 + (c - 3)] = gs[row * 48 + (c - 3)];
+}
+
 }  // namespace
 
 
@@ -1613,5 +1651,32 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
         hipLaunchKernelGGL(k_deform_reduce, dim3((DF_W * DF_W + 255) / 256, k), dim3(256), 0, s, a);
         GFT_CHECK_HIP(hipGetLastError());
     }
+    return 0;
+}
+
+extern "C" int gft_deform_compact(void* hip_stream, int64_t n, int64_t k, const uint8_t* mask, const int32_t* rank, const void* saved,
+                                  const float* g_d_xyz, const float* g_d_sh, int32_t* idx, void* saved_c, float* g_d_xyz_c,
+                                  float* g_d_sh_c)
+{
+    if (n < 0 || k < 0 || k > n) return gft_fail("gft_deform_compact: bad row counts");
+    if (k == 0) return 0;
+    if (!mask || !rank || !saved || !idx || !saved_c) return gft_fail("gft_deform_compact: NULL argument");
+    if ((g_d_xyz && !g_d_xyz_c) || (g_d_sh && !g_d_sh_c)) return gft_fail("gft_deform_compact: a gradient has no destination");
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int64_t n_pad = pad_points(n), k_pad = pad_points(k);
+    hipLaunchKernelGGL(k_deform_compact_index, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, mask, rank, idx);
+    GFT_CHECK_HIP(hipGetLastError());
+    const float* src = (const float*)saved;
+    float* dst = (float*)saved_c;
+    // encoding [n_pad, E] | activations [8, n_pad, 256] | ReLU sign words [8, n_pad, 8] (gft_deform_saved_bytes)
+    hipLaunchKernelGGL(k_deform_compact_rows, dim3((unsigned)k_pad, 1), dim3(64), 0, s, k, DF_EMB, n_pad * DF_EMB, k_pad * DF_EMB, idx, src, dst);
+    src += n_pad * DF_EMB; dst += k_pad * DF_EMB;
+    hipLaunchKernelGGL(k_deform_compact_rows, dim3((unsigned)k_pad, DF_D), dim3(64), 0, s, k, DF_W, n_pad * DF_W, k_pad * DF_W, idx, src, dst);
+    src += n_pad * DF_D * DF_W; dst += k_pad * DF_D * DF_W;
+    hipLaunchKernelGGL(k_deform_compact_rows, dim3((unsigned)k_pad, DF_D), dim3(64), 0, s, k, DF_SIGN_WORDS, n_pad * DF_SIGN_WORDS,
+                       k_pad * DF_SIGN_WORDS, idx, src, dst);
+    if (g_d_xyz || g_d_sh)
+        hipLaunchKernelGGL(k_deform_compact_grads, dim3((unsigned)((k * 51 + 255) / 256)), dim3(256), 0, s, k, idx, g_d_xyz, g_d_sh, g_d_xyz_c, g_d_sh_c);
+    GFT_CHECK_HIP(hipGetLastError());
     return 0;
 }

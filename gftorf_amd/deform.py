@@ -24,6 +24,18 @@ from torch import nn
 from . import _lib
 
 _D, _W, _SH_DEGREE = 8, 256, 3
+_PAD = 192                       # DF_PAD: point counts are padded to multiples of 192 inside the saved / scratch buffers
+
+# The backward runs over the points whose upstream gradient row (d_xyz, d_sh) is non-zero only: in a training iteration
+# those are the Gaussians some pixel blended (6-14 % of the queried points on the metric scene); a row whose upstream
+# gradient is zero has dz = 0 in every layer and adds exactly nothing to any weight gradient.  The saved activations of
+# the rows that count are compacted (one rank computation, one blocking read of the count -- as the reference's
+# `t[mask]` has), then the same kernels run on the compact set: gradients equal the dense backward's up to summation
+# order.  Off: `gftorf_amd.deform.sparse_backward = False`.
+sparse_backward = True
+_SPARSE_MIN_POINTS = 8192        # below this the dense backward is launch-bound anyway
+_SPARSE_MAX_FRACTION = 0.6       # above this the compaction costs more than it saves
+last_backward_stats = {"points": 0, "points_processed": 0}
 
 
 def _param_list(mod):
@@ -101,6 +113,10 @@ class _DeformFn(torch.autograd.Function):
         grads = [torch.empty(s, **f32) for s in ctx.shapes]
         gx = g_dxyz.float().contiguous() if g_dxyz is not None else None
         gs = g_dsh.float().contiguous() if g_dsh is not None else None
+        last_backward_stats.update(points=n, points_processed=n)
+        if sparse_backward and n >= _SPARSE_MIN_POINTS and (gx is not None or gs is not None):
+            n, saved, gx, gs = _compact_rows(lib, n, saved, gx, gs)
+            last_backward_stats["points_processed"] = n
         scratch = torch.empty((lib.gft_deform_scratch_bytes(n) // 4,), **f32)
         stream = _lib.raw_stream(dev)
         with _lib.on_device(dev):
@@ -110,6 +126,35 @@ class _DeformFn(torch.autograd.Function):
                                                scratch.data_ptr() if n else None,
                                                C.byref(_fill(_lib.DeformParams(), grads))))
         return (None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[4:]))
+
+
+def _compact_rows(lib, n, saved, gx, gs):
+    """Rows of (saved activations, upstream gradients) whose upstream gradient is non-zero, compacted; everything
+    unchanged when most rows count.  `saved` = [n_pad, E] encoding | [8, n_pad, 256] activations | [8, n_pad, 8] ReLU sign
+    words (gft_deform_saved_bytes), n_pad = n rounded up to 192."""
+    from .densify import RowSelection
+    row_max = None
+    for g in (gx, gs):
+        if g is not None:
+            m = g.reshape(n, -1).abs().amax(dim=1)
+            row_max = m if row_max is None else torch.maximum(row_max, m)
+    sel = RowSelection(row_max > 0)
+    k = sel.count
+    if k > _SPARSE_MAX_FRACTION * n:
+        return n, saved, gx, gs
+    if k == 0:
+        return 0, saved, None, None
+    dev = saved.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = torch.empty((lib.gft_deform_saved_bytes(k) // 4,), **f32)
+    idx = torch.empty((k,), device=dev, dtype=torch.int32)
+    gx_c = torch.empty((k, 3), **f32) if gx is not None else None
+    gs_c = torch.empty((k, 16, 3), **f32) if gs is not None else None
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    with _lib.on_device(dev):
+        _lib.check(lib.gft_deform_compact(_lib.raw_stream(dev), n, k, sel.mask.data_ptr(), sel.rank.data_ptr(), saved.data_ptr(),
+                                          ptr(gx), ptr(gs), idx.data_ptr(), out.data_ptr(), ptr(gx_c), ptr(gs_c)))
+    return k, out, gx_c, gs_c
 
 
 class DeformNetwork(nn.Module):

@@ -94,6 +94,17 @@ int gft_deform_forward(void* hip_stream, int xyz_multires, int t_multires, int64
 int gft_deform_backward(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const void* packed, const void* saved,
                         const float* g_d_xyz, const float* g_d_sh, void* scratch, const gft_deform_grads* grads);
 
+/* The backward over the rows that count: a point whose upstream gradient row (g_d_xyz, g_d_sh) is all zero has dz = 0
+ * in every layer and adds nothing to any parameter gradient -- in a training iteration that is every queried point no
+ * pixel blended (86-94 % on the metric scene).  Compacts the saved activations and the upstream gradients of the k
+ * selected rows (mask[n] != 0, rank[row] = output row of a selected row: gft_rows_rank of gftorf_densify.h) into
+ * `saved_c` (gft_deform_saved_bytes(k); padded rows zeroed) and g_d_xyz_c[k,3] / g_d_sh_c[k,16,3];
+ * gft_deform_backward(n = k, saved_c, ...) then gives the gradients of the dense call up to summation order.
+ * idx: scratch of k int32. */
+int gft_deform_compact(void* hip_stream, int64_t n, int64_t k, const uint8_t* mask, const int32_t* rank, const void* saved,
+                       const float* g_d_xyz, const float* g_d_sh, int32_t* idx, void* saved_c, float* g_d_xyz_c,
+                       float* g_d_sh_c);
+
 #ifdef __cplusplus
 }
 #endif

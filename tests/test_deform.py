@@ -339,3 +339,45 @@ def test_fp32_mfma_walks_still_match():
                        env=dict(os.environ, GFT_DEFORM_BF16X3="0"), cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frac,n", [(0.1, 40_000), (0.0, 20_000), (0.5, 12_345), (0.9, 20_000)])
+def test_backward_over_rows_with_a_gradient_only(frac, n):
+    """In a training iteration only the Gaussians some pixel blended hand a non-zero (d_xyz, d_sh) gradient row to the
+    network (6-14 % of the queried points); a row whose upstream gradient is zero has dz = 0 in every layer.  The
+    backward compacts the rows that count and runs on those: weight gradients equal the dense backward's up to
+    summation order (2e-5 of the max-norm), for no / few / half / most rows active (the last one keeps the dense path)."""
+    from gftorf_amd import deform as D
+    dev = torch.device("cuda:0")
+    net, _ = _net(21, dev)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x, t = torch.rand((n, 3), generator=g).to(dev), torch.rand((n, 1), generator=g).to(dev)
+    keep = (torch.rand(n, generator=g) < frac).to(dev)
+    g_dxyz = torch.randn((n, 3), generator=g).to(dev) * keep[:, None]
+    g_dsh = torch.randn((n, 16, 3), generator=g).to(dev) * keep[:, None, None]
+    # rows with a gradient in only one of the two outputs count as well
+    if frac > 0:
+        only_xyz = torch.nonzero(keep)[:5, 0]
+        g_dsh[only_xyz] = 0
+
+    def grads(sparse):
+        D.sparse_backward = sparse
+        try:
+            net.zero_grad(set_to_none=True)
+            d_xyz, _, d_sh, _ = net(x, t)
+            torch.autograd.backward([d_xyz, d_sh], [g_dxyz, g_dsh])
+            return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, dict(D.last_backward_stats)
+        finally:
+            D.sparse_backward = True
+    dense, st_d = grads(False)
+    sparse, st_s = grads(True)
+    assert st_d == {"points": n, "points_processed": n}
+    k = int(keep.sum())
+    assert st_s["points"] == n and st_s["points_processed"] == (k if k <= 0.6 * n else n)
+    assert len(sparse) == len(dense) == 24
+    for name in dense:
+        if k == 0:
+            assert not sparse[name].any() and not dense[name].any(), name
+        else:
+            assert _rel(sparse[name].cpu().numpy(), dense[name].cpu().numpy()) < 2e-5, name
