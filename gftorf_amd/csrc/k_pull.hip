@@ -39,7 +39,9 @@
 namespace {
 
 #define TPULL_KEYS GFT_HEAD_SLOT    // 16 KB of LDS for the head's keys
-#define HEAD_DIRECT 1024u           // lists (scanned hits) up to this length are sorted whole
+#define HEAD_DIRECT 2048u           // lists (scanned hits) up to this length are sorted whole: a sparse frame (the reference's
+                                    // 100 k Gaussians at 320x240: ~1450 instances per tile, low opacities) saturates nowhere, every
+                                    // quadrant of a tile with a tail would flag and every list be completed in a second pass
 #define HEAD_TARGET 940u            // wanted length of the sorted head of a longer list
 #define TAIL_LDS_KEYS 4096u         // culled tails are sorted in LDS in runs of at most this many keys (whole depth bins)
 #define TAIL_THREADS 512              // (1024 threads leave 128 registers per lane: the appearance evaluation then spills)
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
                 const uint32_t before = run;
                 run += h[k];
                 if (before < HEAD_TARGET && run >= HEAD_TARGET) {
-                    const bool take = run <= HEAD_DIRECT || (before < 512u && run <= TPULL_KEYS);
+                    const bool take = run <= 1024u || (before < 512u && run <= TPULL_KEYS);
                     s_cut = (uint32_t)(16 * tid + k) + (take ? 1u : 0u);
                     s_kf = take ? run : before;
                 }

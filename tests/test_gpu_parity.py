@@ -189,7 +189,7 @@ def test_preprocess_and_binning_bit_exact(name, mode, oracle, gpu):
             r0, r1 = int(st["ranges"][t, 0]), int(st["ranges"][t, 1])
             assert k <= b - a and k <= 2048
             assert (int(st["tile_cut"][t]) == 0xffffffff) == (k == b - a), "tile %d" % t
-            if b - a <= 1024:
+            if b - a <= 2048:
                 assert k == b - a
             elif k < b - a:
                 # whole bins up to the one where the count reaches 940; a bin that overshoots 1024 is left out unless
@@ -581,7 +581,7 @@ def test_tile_pull_structure(gpu, oracle):
     st = raw_forward(fog, gpu, mode=1)
     f, _ = Hh.run_oracle(oracle, fog, backward=False)
     lens = f.ranges[:, 1] - f.ranges[:, 0]
-    long_tiles = lens > 1024
+    long_tiles = lens > 2048
     assert long_tiles.any() and st["pull"]
     assert ((st["front_len"][long_tiles] >= 512) & (st["front_len"][long_tiles] <= 2048)).all()
     flagged = st["unit_flag"].any(1)
@@ -592,7 +592,7 @@ def test_tile_pull_structure(gpu, oracle):
     st = raw_forward(opaque, gpu, mode=1)
     f, _ = Hh.run_oracle(oracle, opaque, backward=False)
     lens = f.ranges[:, 1] - f.ranges[:, 0]
-    assert (lens > 1024).any() and not st["unit_flag"].any() and int(st["ctrl"][6]) == 0          # all saturate early: no list is completed
+    assert (lens > 2048).any() and not st["unit_flag"].any() and int(st["ctrl"][6]) == 0          # all saturate early: no list is completed
     vis = f.geom["radii"] > 0
     assert 0 < (st["need"] != 0).sum() < 0.6 * vis.sum()                                          # most Gaussians never get an appearance
     assert (st["ranges"][:, 1] - st["ranges"][:, 0] == st["front_len"]).all()
