@@ -262,9 +262,24 @@ def load_counters(stage, workload):
             return None
         s = dict(w["stages"][stage])
         s["source"] = w["source"]
+        s["kernel_source_sha"] = w.get("kernel_source_sha")
         return s
     except Exception:
         return None
+
+
+def kernel_source_sha():
+    """sha1 over gftorf_amd/csrc/*.{hip,h}: the committed counter passes (profiles/counters.json) carry the hash of the
+    sources they were taken from, so a line can say whether its `traffic` belongs to the kernels that ran."""
+    import hashlib
+    h = hashlib.sha1()
+    root = os.path.join(ROOT, "gftorf_amd", "csrc")
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            with open(os.path.join(root, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 FP32_VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector)
@@ -1064,6 +1079,9 @@ def main():
                     "units_processed": units,
                     "counter_frac": (gbs(traffic, dom_ms) / HBM_PEAK_GBS) if (traffic and dom_ms > 0) else None,
                     "counter_source": cnt["source"] if cnt else None,
+                    # the counter passes were taken from these kernel sources / the sources that ran now
+                    "counter_source_sha": cnt.get("kernel_source_sha") if cnt else None, "kernel_source_sha": kernel_source_sha(),
+                    "counters_belong_to_this_source": bool(cnt) and cnt.get("kernel_source_sha") == kernel_source_sha(),
                     "reference_formula": {"algorithmic_bytes_per_launch": ref_kernel[dom], "achieved": gbs(ref_kernel[dom], dom_ms),
                                           "frac": gbs(ref_kernel[dom], dom_ms) / HBM_PEAK_GBS,
                                           "note": "SURVEY 8(d) x all instances (what the reference algorithm moves); early "

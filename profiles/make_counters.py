@@ -15,19 +15,31 @@ from collections import defaultdict
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CLOCK_GHZ, SIMDS = 2.4, 1024
-STAGE_OF = {"k_preprocess_fwd": "preprocess_fwd", "k_tile_count": "tile_count", "k_tile_scatter": "tile_scatter",
+STAGE_OF = {"k_preprocess_fwd": "preprocess_fwd", "k_appearance": "preprocess_fwd",
+            "k_tile_count": "tile_count", "k_tile_scatter": "tile_scatter",
             "k_tile_sort_small": "tile_sort", "k_tile_sort_big": "tile_sort", "k_tile_front": "tile_sort", "k_tile_tail": "tile_sort",
             "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd", "k_tile_order": "render_bwd",
             "k_preprocess_bwd": "preprocess_bwd", "k_preprocess_bwd_common": "preprocess_bwd", "k_offset_reduce": "preprocess_bwd",
-            # tile-pull binning of the near slab (frames with a depth cut).  k_super_bin runs twice per forward (count
-            # pass = stage tile_count, scatter pass = stage tile_scatter): one kernel name, so both launches are booked
-            # under tile_count and tile_scatter holds only k_tile_scatter's (idle) far-slab launch
-            "k_super_bin": "tile_count", "k_tile_pull": "tile_sort", "k_appearance_far": "preprocess_fwd"}
+            # tile-pull binning (k_pull.hip): count pass, scatter pass, per-tile pull + sort, lists completed on demand
+            "k_super_bin<0>": "tile_count", "k_super_bin<1>": "tile_scatter", "k_tile_pull": "tile_sort", "k_tail_build": "tile_sort"}
 ALL_STAGES = ("preprocess_fwd", "tile_count", "tile_scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
 
 
 def short(n):
-    return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    return n if n.startswith("k_super_bin<") else n.split("<")[0]      # (the two passes of k_super_bin are two stages)
+
+
+def source_sha():
+    """sha1 over the kernel sources the counters were taken from (bench.py compares it with the sources it runs)"""
+    import hashlib
+    h = hashlib.sha1()
+    root = os.path.join(os.path.dirname(HERE), "gftorf_amd", "csrc")
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def read(root, sub):
@@ -109,7 +121,7 @@ def main():
             s[f] = sq.get(main_k, {}).get(f)
     cpath = os.path.join(HERE, "counters.json")
     doc = json.load(open(cpath)) if os.path.exists(cpath) else {}
-    doc[workload] = {"source": ["profiles/" + t_name, "profiles/" + s_name], "stages": stages}
+    doc[workload] = {"source": ["profiles/" + t_name, "profiles/" + s_name], "kernel_source_sha": source_sha(), "stages": stages}
     json.dump(doc, open(cpath, "w"), indent=1)
     for st, s in stages.items():
         print("%-15s hbm %8.1f MB  valu insts %11.0f  %7.1f us  waves/SIMD %s  VALU slots %s" % (
