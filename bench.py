@@ -106,12 +106,18 @@ def algorithmic_bytes(P, P_vis, R, N, T, forward_only=False, units=None):
       R_bin   ids that are sorted into tile lists (the list heads, + the lists completed for flagged quadrants)
       R_walk  list entries the render stages walk (per tile up to its deepest contributor: early termination)
       P_blend Gaussians some pixel blended: K8 + K9 (928 B) run for those, every other Gaussian only gets its 376 B
-              of zero gradient rows (+ 8 B of radii), like a culled one"""
+              of zero gradient rows (+ 8 B of radii), like a culled one
+      P_zero  Gaussians whose 376 B of zero gradient rows are written in this step (default: all but the blended ones;
+              0 when the operator reuses gradient tensors it kept zero but for the rows of the previous backward)
+      P_rezero rows of kept gradient tensors that are zeroed again (the previous backward's blended Gaussians: 376 B each,
+              + 1 B of row marks per Gaussian), booked under `memset`"""
     P_cull = P - P_vis
-    u = dict(P_app=P_vis, R_bin=R, R_walk=R, P_blend=P_vis)
+    u = dict(P_app=P_vis, R_bin=R, R_walk=R, P_blend=P_vis, P_zero=None, P_rezero=0)
     if units:
         u.update({k: v for k, v in units.items() if v is not None})
     P_app, R_bin, R_walk, P_blend = u["P_app"], u["R_bin"], u["R_walk"], u["P_blend"]
+    P_zero = u["P_zero"] if u["P_zero"] is not None else P - P_blend
+    P_rezero = u["P_rezero"]
     per_kernel = {
         "preprocess_fwd": 484 * P_app + 112 * (P_vis - P_app) + 48 * P_cull,
         "tile_count": 8 * P_vis + 8 * R_bin,        # reference scan (K2) + tile ranges (K5)
@@ -119,8 +125,8 @@ def algorithmic_bytes(P, P_vis, R, N, T, forward_only=False, units=None):
         "tile_sort": 24 * R_bin,                    # reference key sort (K4), one read + one write of a pair
         "render_fwd": 76 * R_walk + 128 * N,
         "render_bwd": 148 * R_walk + 96 * N,
-        "preprocess_bwd": 928 * P_blend + 384 * (P - P_blend),
-        "memset": 76 * P_vis,
+        "preprocess_bwd": 928 * P_blend + 376 * P_zero + 8 * (P - P_blend),
+        "memset": 76 * P_vis + (376 * P_rezero + P if P_rezero else 0),
     }
     if forward_only:       # 512 P_vis + 48 P_cull + 120 R + 128 N
         for k in ("render_bwd", "preprocess_bwd", "memset"):
@@ -1056,6 +1062,9 @@ def main():
             units = {"P_app": walked["gaussians_with_appearance"],
                      "R_bin": (walked["head_ids"] + walked["completed_list_ids"]) if walked["tile_pull"] else R,
                      "R_walk": walked["per_tile_deepest"], "P_blend": P_vis if fo else P_blend}
+            if not fo and api.last_call_stats.get("grads_reused"):
+                # the gradient tensors were kept from the previous backward: its rows zeroed again, only this one's written
+                units.update(P_zero=0, P_rezero=P_blend)
         per_kernel, whole = algorithmic_bytes(P, P_vis, R, N, T, forward_only=fo, units=units)
         calls = max(prof["forward_calls"], 1)
         stage_ms = {k[:-3]: prof[k] / calls for k in prof if k.endswith("_ms")}
@@ -1133,6 +1142,9 @@ def main():
                               "counter_frac": (gbs(path_traffic, ms_per_step) / HBM_PEAK_GBS) if path_traffic else None,
                               "gpu_ms_sum_of_stages": sum(stage_ms.values())},
             "binning_restarts": {"restarted_forwards": restarts[0], "forwards": restarts[1]},
+            # gradient tensors kept from one backward to the next (their written rows re-zeroed) instead of 376 B of zeros
+            # per Gaussian written in every backward; only when no tensor aliases them any more and nobody wrote to them
+            "gradient_tensors_reused": bool(api.last_call_stats.get("grads_reused")),
             "tile_pull_binning": {k: walked[k] for k in ("tile_pull", "supertile_entries", "head_ids", "flagged_quadrants",
                                                          "completed_list_ids", "gaussians_with_appearance")} if walked else None,
             "stage_ms": stage_ms,

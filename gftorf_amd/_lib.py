@@ -47,7 +47,7 @@ BACKWARD_FIELDS = [
     "dL_dout_color", "dL_dout_phasor", "dL_dout_depth", "dL_dout_acc", "dL_dout_depth_distortion",
     "geom", "img", "binning", "acc",
     "dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dcov3D", "dL_dsh", "dL_dsh_p",
-    "dL_dscales", "dL_drotations", "dL_dphase_offset", "dL_ddc_offset", "det_partials",
+    "dL_dscales", "dL_drotations", "dL_dphase_offset", "dL_ddc_offset", "det_partials", "dirty_rows",
 ]
 
 LAYOUT_FIELDS = [
@@ -129,7 +129,7 @@ class AdamTensor(C.Structure):
 
 EXPORTS = [
     "gft_abi_version", "gft_lazy_sort", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes", "gft_acc_bytes",
-    "gft_det_partials_bytes", "gft_get_layout", "gft_binning_capacity", "gft_set_binning_mode", "gft_binning_mode", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_backward",
+    "gft_det_partials_bytes", "gft_get_layout", "gft_binning_capacity", "gft_set_binning_mode", "gft_binning_mode", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_backward", "gft_grads_rezero",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
     "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi", "gft_adam_step_rows",
@@ -231,6 +231,8 @@ def load():
     lib.gft_forward_render.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64, C.c_int64]
     lib.gft_backward.restype = C.c_int
     lib.gft_backward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(BackwardIO), C.c_int64]
+    lib.gft_grads_rezero.restype = C.c_int
+    lib.gft_grads_rezero.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(BackwardIO)]
     lib.gft_mark_visible.restype = C.c_int
     lib.gft_mark_visible.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_float, C.c_float, C.c_void_p]

@@ -69,6 +69,25 @@ _ZERO_FILL = _os.environ.get("GFT_GRADS_ZERO_FILL", "0") != "0"
 # (bit-reproducible gradients; several times slower: for tests)
 _DETERMINISTIC = _os.environ.get("GFT_BWD_DETERMINISTIC", "0") != "0"
 _HINT_HEADROOM = 1.25
+# Gradient tensors kept from one backward to the next.  The operator returns dense gradient tensors (376 B per Gaussian
+# with SH colour + SH phasor of 16 coefficients) of which a dense frame fills a few per cent of the rows (the Gaussians
+# some pixel blended); writing the zeros of all the other rows is most of the backward's preprocess kernel (65 of 100 us at
+# 1 M Gaussians).  A set of gradient tensors that nobody references any more -- the optimizer has consumed them and
+# `zero_grad(set_to_none=True)` or the next backward has dropped them -- is therefore kept: the rows its last backward
+# wrote are re-zeroed (gft_grads_rezero: they are marked in `dirty`), and the next backward writes only the rows of its own
+# blended Gaussians (cfg.grads_zeroed = 2).  Reuse is decided per call and only when it is provably safe:
+#   * no tensor aliases the buffer any more (storage use count back at its baseline; torch._C._storage_Use_Count, the
+#     private counter CUDA-graph trees use -- without it nothing is reused), and
+#   * nobody wrote to it through a tensor (version counter unchanged: an in-place op on `p.grad`, e.g. gradient
+#     accumulation over two backwards or clipping, bumps it; the library's kernels write through raw pointers).
+# Otherwise a fresh buffer is taken and written in full, exactly as before.  GFT_GRADS_REUSE=0 switches it off.
+_GRADS_REUSE = _os.environ.get("GFT_GRADS_REUSE", "1") != "0" and hasattr(torch._C, "_storage_Use_Count")
+_grad_pool = {}           # (device, P, layout) -> list of {buf, dirty, version, base}
+_GRAD_POOL_DEPTH = 3      # rasterizer calls of one iteration whose gradient tensors are alive at the same time
+
+
+def _storage_refs(t):
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
 _LIST_HEADROOM = 1.2      # longest tile list of the previous frame -> guess for this one
 
 
@@ -351,6 +370,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
                   sh_p=(P, M_p, 2) if has_sh_p else None, scales=(P, 3) if has_scales else None,
                   rotations=(P, 4) if has_scales else None)
     zero_buf = None
+    entry, reused_grads = None, False
     if share_grads is not None:
         # second view of a pair (gftorf_amd.pair): its backward adds to the first view's gradient tensors
         # (cfg.grads_accumulate); only the two scalar offset gradients are its own
@@ -361,7 +381,26 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         # (100 k Gaussians, 0.1 ms of kernels per call) is host time the device waits for.  With the zero-fill switch
         # the forward clears it beside its binning kernels and the backward writes only the rows of blended Gaussians.
         sizes = {k: (int(torch.Size(v).numel()) + 3) // 4 * 4 for k, v in shapes.items() if v is not None}
-        buf = torch.empty((sum(sizes.values()) + 4,), **f32)
+        total = sum(sizes.values()) + 4
+        entry = None
+        if _GRADS_REUSE and P and pixels is not None and want_bw_records and not zero_fill:
+            key = (dev.index, P, tuple(sorted(sizes.items())))
+            pool = _grad_pool.setdefault(key, [])
+            for e in pool:
+                if _storage_refs(e["buf"]) == e["base"] and e["buf"]._version == e["version"]:
+                    entry, reused_grads = e, True
+                    break
+            if entry is None:
+                buf = torch.empty((total,), **f32)
+                entry = dict(buf=buf, dirty=torch.zeros(((P + 3) // 4 * 4,), device=dev, dtype=torch.uint8), version=buf._version)
+                entry["base"] = _storage_refs(buf)
+                pool.append(entry)
+                del pool[:-_GRAD_POOL_DEPTH]
+                if len(_grad_pool) > 8:
+                    _grad_pool.pop(next(iter(_grad_pool)))
+            buf = entry["buf"]
+        else:
+            buf = torch.empty((total,), **f32)
         if zero_fill:
             zero_buf = buf
         g, o = {}, 0
@@ -379,8 +418,11 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         acc = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32)
     cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw_records)
     cfg.acc_zeroed = int(acc_zeroed)
-    cfg.grads_zeroed = int(zero_buf is not None)
+    cfg.grads_zeroed = 2 if reused_grads else int(zero_buf is not None)
     cfg.grads_accumulate = int(share_grads is not None)
+    if share_grads is not None and share_grads.get("dirty") is not None:
+        # second view of a pair: its rows are added to the first view's tensors and marked in the same array
+        entry = dict(dirty=share_grads["dirty"])
     io = _lib.BackwardIO()
     io.bg, io.means3D, io.radii = _ptr(bg_c), _ptr(means3D) if P else None, _ptr(radii) if P else None
     io.scales = _ptr(scales) if has_scales else None
@@ -402,7 +444,16 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
     if getattr(s, "optimize_phase_offset", True) or getattr(s, "optimize_dc_offset", True):
         io.dL_dphase_offset = g["offsets"].data_ptr()
         io.dL_ddc_offset = g["offsets"].data_ptr() + 4
+    if entry is not None:
+        io.dirty_rows = entry["dirty"].data_ptr()
+        if reused_grads:
+            # the rows the previous backward into these tensors wrote become zero again (queued on the current stream,
+            # behind whatever consumed them)
+            with _lib.on_device(dev):
+                _lib.check(lib.gft_grads_rezero(_lib.raw_stream(dev), C.byref(cfg), C.byref(io)))
+    last_call_stats["grads_reused"] = bool(reused_grads)
     return dict(grads=g, cfg=cfg, io=io, acc=acc, pixels=pixels, zero_buf=zero_buf, dev=dev, P=P, H=H, W=W,
+                dirty=entry["dirty"] if entry is not None else None,
                 debug_args=(s.bg, means3D, radii, scales, rotations, s.scale_modifier, cov3D, s.viewmatrix, s.projmatrix,
                             s.tanfovx, s.tanfovy, sh, sh_p, s.sh_degree, s.campos, s.debug, s.near_n, s.far_n, s.depth_range,
                             s.use_view_dependent_phase, ph_off, dc_off) if s.debug else None)

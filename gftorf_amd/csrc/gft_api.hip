@@ -664,7 +664,9 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     ImgView im = gft_img_view(const_cast<void*>(io->img), L);
     BinView b = gft_bin_view(const_cast<void*>(io->binning), L);
 
-    if (cfg->grads_zeroed) {
+    if (cfg->grads_zeroed == 2 && (!io->dirty_rows || !io->pixels))
+        return gft_fail("gft_backward: grads_zeroed = 2 needs dirty_rows and the forward's pixels");
+    if (cfg->grads_zeroed == 1) {
         SideFill* f = side_of_current_device();
         if (!f || !f->pending) return gft_fail("gft_backward: grads_zeroed without a forward that filled them");
         GFT_CHECK_HIP(hipStreamWaitEvent(s, f->filled, 0));
@@ -687,6 +689,20 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
         GFT_STAGE(s, cfg, "preprocess_bwd", gft_launch_preprocess_bwd(s, *cfg, *io, g));
     }
     if (g_prof.on) { std::lock_guard<std::mutex> lk(g_prof.mu); g_prof.bwd++; }
+    return 0;
+}
+
+extern "C" int gft_grads_rezero(void* hip_stream, const gft_config* cfg, const gft_backward_io* io)
+{
+    if (check_config(cfg)) return 1;
+    if (!io) return gft_fail("gft_grads_rezero: io is NULL");
+    if (cfg->P == 0) return 0;
+    if (!io->dirty_rows || !io->dL_dmeans3D || !io->dL_dmeans2D || !io->dL_dopacity)
+        return gft_fail("gft_grads_rezero: required pointer is NULL");
+    hipStream_t s = (hipStream_t)hip_stream;
+    StageTimer t(s, ST_MEMSET);
+    const hipError_t e = gft_launch_grads_rezero(s, *cfg, *io);
+    if (e != hipSuccess) return gft_fail("grads_rezero: %s", hipGetErrorString(e));
     return 0;
 }
 

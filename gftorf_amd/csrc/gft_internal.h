@@ -163,6 +163,7 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
                                  const GeomView& g, const ImgView& im, const BinView& b, bool lazy);
 hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
                                      const GeomView& g);
+hipError_t gft_launch_grads_rezero(hipStream_t s, const gft_config& c, const gft_backward_io& io);
 hipError_t gft_launch_mark_visible(hipStream_t s, int32_t P, const float* means3D,
                                    const float* view, float near_n, float far_n, uint8_t* present);
 

@@ -387,12 +387,15 @@ __device__ __forceinline__ bool gaussian_blended(const PreBwdArgs& a, int idx)
 // COMMON = the call a training loop makes (SH colour and SH phasor of 16 coefficients, scales + rotations, the forward's
 // direction-gradient record, whole gradient tensors written): the switches below are constants there and the other paths
 // are not compiled in; every other combination runs the general kernel.
-template <bool COMMON>
-__device__ __forceinline__ void preprocess_bwd_body(PreBwdArgs a)
+// ROWS = the kernel over the compacted rows of blended Gaussians (k_preprocess_bwd_rows: the gradient tensors are zero
+// but for the rows this call writes): `row_idx` = this lane's Gaussian (-1: none), only its rows are written, straight
+// from the lane, and its offset-gradient terms are handed back instead of being reduced here.
+template <bool COMMON, bool ROWS = false>
+__device__ __forceinline__ void preprocess_bwd_body(PreBwdArgs a, int row_idx = -1, float* row_phase = nullptr, float* row_dc = nullptr)
 {
     if (COMMON) {
-        a.stage_sh = 1; a.stage_shp = 1;
-        a.c.want_backward = 1; a.c.grads_accumulate = 0; a.c.grads_zeroed = 0;
+        a.stage_sh = ROWS ? 0 : 1; a.stage_shp = ROWS ? 0 : 1;
+        a.c.want_backward = 1; a.c.grads_accumulate = 0; a.c.grads_zeroed = ROWS ? 1 : 0;
         a.c.M = 16; a.c.M_p = 16;
         a.io.cov3D_precomp = nullptr; a.io.dL_dcolors = nullptr; a.io.dL_dcov3D = nullptr;
         __builtin_assume(a.io.shs != nullptr);
@@ -400,7 +403,7 @@ __device__ __forceinline__ void preprocess_bwd_body(PreBwdArgs a)
         __builtin_assume(a.io.scales != nullptr);
     }
     extern __shared__ float4 lds_rows[];
-    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    const int idx = ROWS ? row_idx : (int)(blockIdx.x * PRE_BLOCK + threadIdx.x);
     const int P = a.c.P;
     const int M = a.c.M, M_p = a.c.M_p;
     float sum_phase = 0.f, sum_dc = 0.f;
@@ -419,9 +422,11 @@ __device__ __forceinline__ void preprocess_bwd_body(PreBwdArgs a)
     }
 
     bool blended = false;      // this lane's Gaussian got a non-zero gradient row (cfg.grads_accumulate: the rows that are added)
-    if (idx < P) {
-        const bool visible = gaussian_blended(a, idx);
+    if (ROWS ? idx >= 0 : idx < P) {
+        const bool visible = ROWS ? true : gaussian_blended(a, idx);
         blended = visible;
+        // (the caller keeps the gradient tensors and re-zeroes exactly the rows that were written: gft_grads_rezero)
+        if (visible && a.io.dirty_rows) a.io.dirty_rows[idx] = 1;
         float dmean[3] = {0.f, 0.f, 0.f};
         float dmean2d[2] = {0.f, 0.f};
         float dopac = 0.f;
@@ -762,6 +767,11 @@ __device__ __forceinline__ void preprocess_bwd_body(PreBwdArgs a)
     // phase/dc offset gradients (the reference issues two same-address atomics per Gaussian,
     // backward.cu:556-567): wave sums -> the tail of the acc scratch, two floats per wave -> fixed-order
     // reduction in k_offset_reduce (deterministic).
+    if (ROWS) {
+        *row_phase += sum_phase;
+        *row_dc += sum_dc;
+        return;
+    }
     const float sp = gft_wave_sum_to_lane63(sum_phase);
     const float sd = gft_wave_sum_to_lane63(sum_dc);
     if (lane == 63 && a.io.shs_p != nullptr) {
@@ -773,6 +783,100 @@ __device__ __forceinline__ void preprocess_bwd_body(PreBwdArgs a)
 
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(PreBwdArgs a) { preprocess_bwd_body<false>(a); }
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd_common(PreBwdArgs a) { preprocess_bwd_body<true>(a); }
+
+// The backward over the rows of blended Gaussians only (cfg.grads_zeroed = 2: the caller's gradient tensors are zero but
+// for what this call writes).  A dense frame blends a fraction of its Gaussians (metric frame: 66 k of 1 M) and they are
+// scattered: a lane per Gaussian runs the chains with 4 of 64 lanes.  A workgroup compacts the blended ids of its 1024
+// Gaussians in LDS (in a fixed order: the partial sums of the two offset gradients then group the same way in every run),
+// then every lane has a Gaussian; its rows go straight from the lane to the tensors and are marked dirty.
+#define ROWS_THREADS 256
+#define ROWS_CHUNK 1024
+template <bool COMMON>
+__global__ __launch_bounds__(ROWS_THREADS) void k_preprocess_bwd_rows(PreBwdArgs a)
+{
+    __shared__ uint32_t s_ids[ROWS_CHUNK];
+    __shared__ uint32_t s_wt[ROWS_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.c.P;
+    const int i0 = blockIdx.x * ROWS_CHUNK + tid * 4;
+    bool on[4];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        on[k] = i0 + k < P && a.io.radii[i0 + k] > 0 && a.io.pixels[i0 + k] != 0.f;
+        mine += on[k] ? 1u : 0u;
+    }
+    uint32_t x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wt[wave] = x;
+    __syncthreads();
+    uint32_t pos = x - mine, n = 0;
+    for (int w = 0; w < ROWS_THREADS / 64; w++) {
+        if (w < wave) pos += s_wt[w];
+        n += s_wt[w];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (on[k]) s_ids[pos++] = (uint32_t)(i0 + k);
+    __syncthreads();
+    float sum_phase = 0.f, sum_dc = 0.f;
+    for (uint32_t r0 = 0; r0 < n; r0 += ROWS_THREADS) {
+        const uint32_t r = r0 + (uint32_t)tid;
+        preprocess_bwd_body<COMMON, true>(a, r < n ? (int)s_ids[r] : -1, &sum_phase, &sum_dc);
+    }
+    const float sp = gft_wave_sum_to_lane63(sum_phase);
+    const float sd = gft_wave_sum_to_lane63(sum_dc);
+    if (lane == 63 && a.io.shs_p != nullptr) {
+        float* part = a.io.acc + (size_t)P * GFT_ACC_STRIDE + 2 * ((size_t)blockIdx.x * (ROWS_THREADS / 64) + wave);     // one per wave
+        part[0] = sp;
+        part[1] = sd;
+    }
+}
+
+// Zeroes the gradient rows the previous backward into these tensors wrote (dirty[id] != 0) and clears the marks: the
+// tensors are then all zero again.  66 k rows of 376 B instead of 1 M.
+struct RezeroArgs {
+    int P, M, M_p;
+    uint8_t* dirty;
+    float *m3, *m2, *op, *col, *cov, *sh, *shp, *sc, *rot;
+};
+__global__ __launch_bounds__(256) void k_grads_rezero(RezeroArgs a)
+{
+    __shared__ uint32_t s_ids[1024];
+    __shared__ uint32_t s_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int i0 = blockIdx.x * 1024 + tid * 4;
+    uint32_t w = 0u;
+    if (i0 < a.P) w = *reinterpret_cast<const uint32_t*>(a.dirty + i0);        // (P is padded by the caller's allocation to a multiple of 4)
+    if (w) {
+        *reinterpret_cast<uint32_t*>(a.dirty + i0) = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (((w >> (8 * k)) & 0xffu) && i0 + k < a.P) s_ids[atomicAdd(&s_n, 1u)] = (uint32_t)(i0 + k);
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    for (uint32_t r = (uint32_t)wave; r < n; r += 4) {
+        const size_t id = s_ids[r];
+        if (lane < 3) {
+            a.m3[3 * id + lane] = 0.f;
+            a.m2[3 * id + lane] = 0.f;
+            if (a.col) a.col[3 * id + lane] = 0.f;
+            if (a.sc) a.sc[3 * id + lane] = 0.f;
+        }
+        if (lane < 4 && a.rot) a.rot[4 * id + lane] = 0.f;
+        if (lane < 6 && a.cov) a.cov[6 * id + lane] = 0.f;
+        if (lane == 0) a.op[id] = 0.f;
+        if (a.sh) for (int k = lane; k < 3 * a.M; k += 64) a.sh[id * (size_t)(3 * a.M) + k] = 0.f;
+        if (a.shp) for (int k = lane; k < 2 * a.M_p; k += 64) a.shp[id * (size_t)(2 * a.M_p) + k] = 0.f;
+    }
+}
 
 __global__ __launch_bounds__(1024) void k_offset_reduce(int nblocks, const float2* __restrict__ part,
                                                         float* __restrict__ out_phase, float* __restrict__ out_dc)
@@ -874,13 +978,21 @@ hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const g
     a.stage_shp = (io.shs_p != nullptr && c.M_p == 16 && !c.grads_zeroed) ? 1 : 0;
     const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_PAD : 0) + (a.stage_shp ? SHP_ROW_PAD : 0));
     const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;          // = waves = partial sums of the offset gradients
-    const bool common = c.want_backward && !c.grads_accumulate && !c.grads_zeroed && io.shs && c.M == 16 && io.shs_p && c.M_p == 16 &&
-                        !io.cov3D_precomp && io.scales && io.rotations && !io.dL_dcolors && !io.dL_dcov3D;
-    if (common) hipLaunchKernelGGL(k_preprocess_bwd_common, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
+    const bool common_shape = c.want_backward && io.shs && c.M == 16 && io.shs_p && c.M_p == 16 &&
+                              !io.cov3D_precomp && io.scales && io.rotations && !io.dL_dcolors && !io.dL_dcov3D;
+    const bool common = common_shape && !c.grads_accumulate && !c.grads_zeroed;
+    int partials = blocks;
+    if (c.grads_zeroed == 2 && io.pixels && c.want_backward) {
+        // rows of blended Gaussians only, compacted onto full waves
+        const int wgs = (c.P + ROWS_CHUNK - 1) / ROWS_CHUNK;
+        partials = wgs * (ROWS_THREADS / 64);
+        if (common_shape && !c.grads_accumulate) hipLaunchKernelGGL(k_preprocess_bwd_rows<true>, dim3(wgs), dim3(ROWS_THREADS), 0, s, a);
+        else hipLaunchKernelGGL(k_preprocess_bwd_rows<false>, dim3(wgs), dim3(ROWS_THREADS), 0, s, a);
+    } else if (common) hipLaunchKernelGGL(k_preprocess_bwd_common, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
     else hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
     // (the two scalar gradients are only reduced when the caller wants them: optimize_phase_offset / optimize_dc_offset)
     if (io.shs_p != nullptr && io.dL_dphase_offset != nullptr && io.dL_ddc_offset != nullptr)
-        hipLaunchKernelGGL(k_offset_reduce, dim3(1), dim3(1024), 0, s, blocks,
+        hipLaunchKernelGGL(k_offset_reduce, dim3(1), dim3(1024), 0, s, partials,
                            reinterpret_cast<const float2*>(io.acc + (size_t)c.P * GFT_ACC_STRIDE), io.dL_dphase_offset, io.dL_ddc_offset);
     return hipGetLastError();
 }
@@ -890,5 +1002,16 @@ hipError_t gft_launch_mark_visible(hipStream_t s, int32_t P, const float* means3
 {
     const int blocks = (P + GFT_BLOCK - 1) / GFT_BLOCK;
     hipLaunchKernelGGL(k_mark_visible, dim3(blocks), dim3(GFT_BLOCK), 0, s, P, means3D, view, near_n, far_n, present);
+    return hipGetLastError();
+}
+
+hipError_t gft_launch_grads_rezero(hipStream_t s, const gft_config& c, const gft_backward_io& io)
+{
+    RezeroArgs a;
+    a.P = c.P; a.M = c.M; a.M_p = c.M_p;
+    a.dirty = io.dirty_rows;
+    a.m3 = io.dL_dmeans3D; a.m2 = io.dL_dmeans2D; a.op = io.dL_dopacity; a.col = io.dL_dcolors; a.cov = io.dL_dcov3D;
+    a.sh = io.dL_dsh; a.shp = io.dL_dsh_p; a.sc = io.dL_dscales; a.rot = io.dL_drotations;
+    hipLaunchKernelGGL(k_grads_rezero, dim3((c.P + 1023) / 1024), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -68,8 +68,10 @@ typedef struct gft_config {
     int32_t want_backward;
     /* backward only: `acc` was cleared by the forward (gft_forward_io.acc), skip the clear */
     int32_t acc_zeroed;
-    int32_t grads_zeroed;   /* gft_backward: the gradient outputs were zeroed by the forward (gft_forward_io.grads_zero):
-                               only the rows of Gaussians that some pixel blended are written */
+    int32_t grads_zeroed;   /* gft_backward: 1 = the gradient outputs were zeroed by the forward (gft_forward_io.grads_zero),
+                               2 = they are zero because the caller kept them and re-zeroed the rows the previous
+                               backward wrote (gft_grads_rezero, gft_backward_io.dirty_rows): only the rows of Gaussians
+                               that some pixel blended are written */
     int32_t grads_accumulate; /* gft_backward: the per-Gaussian gradient outputs already hold the gradients of another view
                                of the same Gaussians (the colour / ToF camera pair of one training iteration,
                                gaussian_renderer/__init__.py:107-128): the rows of the Gaussians this view blended are
@@ -176,6 +178,12 @@ typedef struct gft_backward_io {
      * and one workgroup adds the rows tile by tile, entries in list order, quadrants 0..3: two runs give bit-identical
      * gradients (the reference's atomicAdd sums, backward.cu:795-886, have no defined order).  NULL = float atomics. */
     float* det_partials;
+    /* optional: uint8[P (rounded up to a multiple of 4)] marks of the rows a backward writes (non-zero gradient rows: the
+     * Gaussians some pixel blended).  A caller that keeps its gradient tensors from one backward to the next passes the
+     * same array every time: gft_grads_rezero() zeroes exactly the marked rows (and clears the marks), after which the
+     * tensors are all zero again and the next backward may run with cfg.grads_zeroed = 2: it then writes the rows of the
+     * blended Gaussians only, instead of streaming ~376 B of zeros for every other Gaussian. */
+    uint8_t* dirty_rows;
 } gft_backward_io;
 
 /* Byte offsets of the sub-arrays inside the scratch buffers (the forward <->
@@ -301,6 +309,10 @@ int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* i
  * With io->det_partials the sums are formed in a fixed order instead (bit-reproducible, slower: a test mode). */
 int gft_backward(void* hip_stream, const gft_config* cfg,
                  const gft_backward_io* io, int64_t binning_instances);
+
+/* Zeroes the rows of the gradient tensors in `io` (dL_d* pointers; P, M, M_p from cfg) that io->dirty_rows marks and
+ * clears the marks: what a caller that reuses its gradient tensors runs before the next backward (see dirty_rows). */
+int gft_grads_rezero(void* hip_stream, const gft_config* cfg, const gft_backward_io* io);
 
 int gft_mark_visible(void* hip_stream, int32_t P, const float* means3D,
                      const float* viewmatrix, const float* projmatrix,

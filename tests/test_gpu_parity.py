@@ -773,3 +773,45 @@ def test_depth_distortion_in_a_narrow_depth_range(z_lo, z_hi, oracle, gpu):
     # and the backward uses the same shifted sums: gradients against the oracle as everywhere else
     _, b = Hh.run_oracle(oracle, sc)
     check_grads(b, grads, sc)
+
+
+def test_gradient_tensors_are_reused_only_when_nobody_holds_or_modified_them(oracle, gpu):
+    """The operator keeps a set of gradient tensors whose rows it re-zeroes instead of writing 376 B of zeros per Gaussian
+    in every backward (api.py: _grad_pool).  Reuse must never be observable: gradients of alternating scenes of one shape
+    equal the oracle's every time; a caller that still holds a gradient, or wrote to one in place, gets fresh tensors and
+    its old ones stay as they were."""
+    from gftorf_amd import api
+    if not api._GRADS_REUSE:
+        pytest.skip("gradient-tensor reuse is off")
+    a = Hh.small_scene(P=3000, seed=31)
+    b = Hh.small_scene(P=3000, seed=32, opacity=0.7)
+    fa, ba = Hh.run_oracle(oracle, a)
+    fb, bb = Hh.run_oracle(oracle, b)
+    api._grad_pool.clear()
+    reused = []
+    for it in range(6):
+        sc, f, bw = (a, fa, ba) if it % 2 == 0 else (b, fb, bb)
+        out, grads, t = Hh.run_gpu(sc, gpu)
+        reused.append(api.last_call_stats["grads_reused"])
+        check_outputs(f, out)
+        check_grads(bw, grads, sc)
+        del t, grads, out
+    assert reused[0] is False and all(reused[1:]), reused
+    # a caller that keeps a gradient tensor: the next call must not touch it
+    out, grads, t = Hh.run_gpu(a, gpu)
+    held = t["leaf"]["means3D"].grad
+    snapshot = held.clone()
+    out2, grads2, t2 = Hh.run_gpu(b, gpu)
+    assert api.last_call_stats["grads_reused"] is False
+    assert torch.equal(held, snapshot)
+    check_grads(bb, grads2, b)
+    del t, t2, held, grads, grads2, out, out2
+    # ... and one that modified a gradient in place (clipping, accumulation over two backwards): not trusted again
+    out, grads, t = Hh.run_gpu(a, gpu)
+    t["leaf"]["shs"].grad.mul_(0.5)
+    del t, grads, out
+    out, grads, t = Hh.run_gpu(b, gpu)
+    check_grads(bb, grads, b)
+    torch.cuda.synchronize()
+    n_bad = sum(1 for e in api._grad_pool[next(iter(api._grad_pool))] if e["buf"]._version != e["version"])
+    assert n_bad >= 1
