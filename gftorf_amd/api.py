@@ -73,9 +73,9 @@ _HINT_HEADROOM = 1.25
 # with SH colour + SH phasor of 16 coefficients) of which a dense frame fills a few per cent of the rows (the Gaussians
 # some pixel blended); writing the zeros of all the other rows is most of the backward's preprocess kernel (65 of 100 us at
 # 1 M Gaussians).  A set of gradient tensors that nobody references any more -- the optimizer has consumed them and
-# `zero_grad(set_to_none=True)` or the next backward has dropped them -- is therefore kept: the rows its last backward
-# wrote are re-zeroed (gft_grads_rezero: they are marked in `dirty`), and the next backward writes only the rows of its own
-# blended Gaussians (cfg.grads_zeroed = 2).  Reuse is decided per call and only when it is provably safe:
+# `zero_grad(set_to_none=True)` or the next backward has dropped them -- is therefore kept: the next backward zeroes the rows
+# the last one wrote (they are marked in `dirty`) and writes only the rows of its own blended Gaussians
+# (cfg.grads_zeroed = 3).  Reuse is decided per call and only when it is provably safe:
 #   * no tensor aliases the buffer any more (storage use count back at its baseline; torch._C._storage_Use_Count, the
 #     private counter CUDA-graph trees use -- without it nothing is reused), and
 #   * nobody wrote to it through a tensor (version counter unchanged: an in-place op on `p.grad`, e.g. gradient
@@ -386,6 +386,9 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         if _GRADS_REUSE and P and pixels is not None and want_bw_records and not zero_fill:
             key = (dev.index, P, tuple(sorted(sizes.items())))
             pool = _grad_pool.setdefault(key, [])
+            # (a buffer somebody wrote to through a tensor -- autograd's in-place sum of two calls' gradients, clipping --
+            # is never trusted again: forgotten as soon as nobody references it)
+            pool[:] = [e for e in pool if e["buf"]._version == e["version"] or _storage_refs(e["buf"]) != e["base"]]
             for e in pool:
                 if _storage_refs(e["buf"]) == e["base"] and e["buf"]._version == e["version"]:
                     entry, reused_grads = e, True
@@ -418,7 +421,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         acc = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32)
     cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw_records)
     cfg.acc_zeroed = int(acc_zeroed)
-    cfg.grads_zeroed = 2 if reused_grads else int(zero_buf is not None)
+    cfg.grads_zeroed = 3 if reused_grads else int(zero_buf is not None)
     cfg.grads_accumulate = int(share_grads is not None)
     if share_grads is not None and share_grads.get("dirty") is not None:
         # second view of a pair: its rows are added to the first view's tensors and marked in the same array
@@ -445,12 +448,8 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         io.dL_dphase_offset = g["offsets"].data_ptr()
         io.dL_ddc_offset = g["offsets"].data_ptr() + 4
     if entry is not None:
+        # (cfg.grads_zeroed = 3: the backward zeroes the rows the previous one wrote and this one does not, then writes its own)
         io.dirty_rows = entry["dirty"].data_ptr()
-        if reused_grads:
-            # the rows the previous backward into these tensors wrote become zero again (queued on the current stream,
-            # behind whatever consumed them)
-            with _lib.on_device(dev):
-                _lib.check(lib.gft_grads_rezero(_lib.raw_stream(dev), C.byref(cfg), C.byref(io)))
     last_call_stats["grads_reused"] = bool(reused_grads)
     return dict(grads=g, cfg=cfg, io=io, acc=acc, pixels=pixels, zero_buf=zero_buf, dev=dev, P=P, H=H, W=W,
                 dirty=entry["dirty"] if entry is not None else None,

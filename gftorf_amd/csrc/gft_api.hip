@@ -664,8 +664,8 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     ImgView im = gft_img_view(const_cast<void*>(io->img), L);
     BinView b = gft_bin_view(const_cast<void*>(io->binning), L);
 
-    if (cfg->grads_zeroed == 2 && (!io->dirty_rows || !io->pixels))
-        return gft_fail("gft_backward: grads_zeroed = 2 needs dirty_rows and the forward's pixels");
+    if ((cfg->grads_zeroed == 2 || cfg->grads_zeroed == 3) && (!io->dirty_rows || !io->pixels || !cfg->want_backward))
+        return gft_fail("gft_backward: grads_zeroed = 2 / 3 needs dirty_rows, the forward's pixels and its direction-gradient records");
     if (cfg->grads_zeroed == 1) {
         SideFill* f = side_of_current_device();
         if (!f || !f->pending) return gft_fail("gft_backward: grads_zeroed without a forward that filled them");

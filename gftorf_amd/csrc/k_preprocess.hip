@@ -425,8 +425,13 @@ __device__ __forceinline__ void preprocess_bwd_body(PreBwdArgs a, int row_idx = 
     if (ROWS ? idx >= 0 : idx < P) {
         const bool visible = ROWS ? true : gaussian_blended(a, idx);
         blended = visible;
-        // (the caller keeps the gradient tensors and re-zeroes exactly the rows that were written: gft_grads_rezero)
-        if (visible && a.io.dirty_rows) a.io.dirty_rows[idx] = 1;
+        // Row marks for a caller that keeps its gradient tensors (gft_backward_io.dirty_rows): a full write leaves exactly
+        // the blended rows non-zero; an accumulating call (second view of a pair) adds its rows to the marks; the rows
+        // kernel writes the marks of its 1024 Gaussians in one go.
+        if (!ROWS && a.io.dirty_rows) {
+            if (!a.c.grads_accumulate) a.io.dirty_rows[idx] = visible ? 1 : 0;
+            else if (visible) a.io.dirty_rows[idx] = 1;
+        }
         float dmean[3] = {0.f, 0.f, 0.f};
         float dmean2d[2] = {0.f, 0.f};
         float dopac = 0.f;
@@ -791,14 +796,33 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd_common(PreBwdArgs 
 // then every lane has a Gaussian; its rows go straight from the lane to the tensors and are marked dirty.
 #define ROWS_THREADS 256
 #define ROWS_CHUNK 1024
+// zero rows of Gaussian `id` in every gradient tensor (one wave)
+__device__ __forceinline__ void zero_gradient_rows(const gft_backward_io& io, int M, int M_p, size_t id, int lane)
+{
+    if (lane < 3) {
+        io.dL_dmeans3D[3 * id + lane] = 0.f;
+        io.dL_dmeans2D[3 * id + lane] = 0.f;
+        if (io.dL_dcolors) io.dL_dcolors[3 * id + lane] = 0.f;
+        if (io.dL_dscales) io.dL_dscales[3 * id + lane] = 0.f;
+    }
+    if (lane < 4 && io.dL_drotations) io.dL_drotations[4 * id + lane] = 0.f;
+    if (lane < 6 && io.dL_dcov3D) io.dL_dcov3D[6 * id + lane] = 0.f;
+    if (lane == 0) io.dL_dopacity[id] = 0.f;
+    if (io.dL_dsh) for (int k = lane; k < 3 * M; k += 64) io.dL_dsh[id * (size_t)(3 * M) + k] = 0.f;
+    if (io.dL_dsh_p) for (int k = lane; k < 2 * M_p; k += 64) io.dL_dsh_p[id * (size_t)(2 * M_p) + k] = 0.f;
+}
+
 template <bool COMMON>
 __global__ __launch_bounds__(ROWS_THREADS) void k_preprocess_bwd_rows(PreBwdArgs a)
 {
     __shared__ uint32_t s_ids[ROWS_CHUNK];
+    __shared__ uint32_t s_stale[ROWS_CHUNK];
     __shared__ uint32_t s_wt[ROWS_THREADS / 64];
+    __shared__ uint32_t s_nstale;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.c.P;
     const int i0 = blockIdx.x * ROWS_CHUNK + tid * 4;
+    if (tid == 0) s_nstale = 0;
     bool on[4];
     uint32_t mine = 0;
 #pragma unroll
@@ -806,6 +830,11 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_preprocess_bwd_rows(PreBwdArgs
         on[k] = i0 + k < P && a.io.radii[i0 + k] > 0 && a.io.pixels[i0 + k] != 0.f;
         mine += on[k] ? 1u : 0u;
     }
+    // cfg.grads_zeroed = 3: the tensors still hold the rows the previous backward wrote (marked in dirty_rows): those of
+    // this workgroup's Gaussians that this backward does not rewrite are zeroed here, the marks become this backward's
+    const bool rezero = a.c.grads_zeroed == 3;
+    uint32_t old = 0u;
+    if (rezero && i0 < P) old = *reinterpret_cast<const uint32_t*>(a.io.dirty_rows + i0);
     uint32_t x = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -819,10 +848,15 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_preprocess_bwd_rows(PreBwdArgs
         if (w < wave) pos += s_wt[w];
         n += s_wt[w];
     }
+    uint32_t now = 0u;
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (on[k]) s_ids[pos++] = (uint32_t)(i0 + k);
+    for (int k = 0; k < 4; k++) {
+        if (on[k]) { s_ids[pos++] = (uint32_t)(i0 + k); now |= 1u << (8 * k); }
+        else if ((old >> (8 * k)) & 0xffu) s_stale[atomicAdd(&s_nstale, 1u)] = (uint32_t)(i0 + k);
+    }
+    if (i0 < P && (now != old || !rezero)) *reinterpret_cast<uint32_t*>(a.io.dirty_rows + i0) = now;
     __syncthreads();
+    for (uint32_t r = (uint32_t)wave; r < s_nstale; r += ROWS_THREADS / 64) zero_gradient_rows(a.io, a.c.M, a.c.M_p, s_stale[r], lane);
     float sum_phase = 0.f, sum_dc = 0.f;
     for (uint32_t r0 = 0; r0 < n; r0 += ROWS_THREADS) {
         const uint32_t r = r0 + (uint32_t)tid;
@@ -842,7 +876,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_preprocess_bwd_rows(PreBwdArgs
 struct RezeroArgs {
     int P, M, M_p;
     uint8_t* dirty;
-    float *m3, *m2, *op, *col, *cov, *sh, *shp, *sc, *rot;
+    gft_backward_io io;
 };
 __global__ __launch_bounds__(256) void k_grads_rezero(RezeroArgs a)
 {
@@ -862,20 +896,7 @@ __global__ __launch_bounds__(256) void k_grads_rezero(RezeroArgs a)
     }
     __syncthreads();
     const uint32_t n = s_n;
-    for (uint32_t r = (uint32_t)wave; r < n; r += 4) {
-        const size_t id = s_ids[r];
-        if (lane < 3) {
-            a.m3[3 * id + lane] = 0.f;
-            a.m2[3 * id + lane] = 0.f;
-            if (a.col) a.col[3 * id + lane] = 0.f;
-            if (a.sc) a.sc[3 * id + lane] = 0.f;
-        }
-        if (lane < 4 && a.rot) a.rot[4 * id + lane] = 0.f;
-        if (lane < 6 && a.cov) a.cov[6 * id + lane] = 0.f;
-        if (lane == 0) a.op[id] = 0.f;
-        if (a.sh) for (int k = lane; k < 3 * a.M; k += 64) a.sh[id * (size_t)(3 * a.M) + k] = 0.f;
-        if (a.shp) for (int k = lane; k < 2 * a.M_p; k += 64) a.shp[id * (size_t)(2 * a.M_p) + k] = 0.f;
-    }
+    for (uint32_t r = (uint32_t)wave; r < n; r += 4) zero_gradient_rows(a.io, a.M, a.M_p, s_ids[r], lane);
 }
 
 __global__ __launch_bounds__(1024) void k_offset_reduce(int nblocks, const float2* __restrict__ part,
@@ -982,7 +1003,7 @@ hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const g
                               !io.cov3D_precomp && io.scales && io.rotations && !io.dL_dcolors && !io.dL_dcov3D;
     const bool common = common_shape && !c.grads_accumulate && !c.grads_zeroed;
     int partials = blocks;
-    if (c.grads_zeroed == 2 && io.pixels && c.want_backward) {
+    if ((c.grads_zeroed == 2 || c.grads_zeroed == 3) && io.pixels && io.dirty_rows && c.want_backward) {
         // rows of blended Gaussians only, compacted onto full waves
         const int wgs = (c.P + ROWS_CHUNK - 1) / ROWS_CHUNK;
         partials = wgs * (ROWS_THREADS / 64);
@@ -1010,8 +1031,7 @@ hipError_t gft_launch_grads_rezero(hipStream_t s, const gft_config& c, const gft
     RezeroArgs a;
     a.P = c.P; a.M = c.M; a.M_p = c.M_p;
     a.dirty = io.dirty_rows;
-    a.m3 = io.dL_dmeans3D; a.m2 = io.dL_dmeans2D; a.op = io.dL_dopacity; a.col = io.dL_dcolors; a.cov = io.dL_dcov3D;
-    a.sh = io.dL_dsh; a.shp = io.dL_dsh_p; a.sc = io.dL_dscales; a.rot = io.dL_drotations;
+    a.io = io;
     hipLaunchKernelGGL(k_grads_rezero, dim3((c.P + 1023) / 1024), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -71,7 +71,9 @@ typedef struct gft_config {
     int32_t grads_zeroed;   /* gft_backward: 1 = the gradient outputs were zeroed by the forward (gft_forward_io.grads_zero),
                                2 = they are zero because the caller kept them and re-zeroed the rows the previous
                                backward wrote (gft_grads_rezero, gft_backward_io.dirty_rows): only the rows of Gaussians
-                               that some pixel blended are written */
+                               that some pixel blended are written; 3 = the caller kept them as the previous backward left
+                               them (zero but for the rows marked in dirty_rows): this backward zeroes the marked rows it does
+                               not rewrite, writes its own and leaves their marks */
     int32_t grads_accumulate; /* gft_backward: the per-Gaussian gradient outputs already hold the gradients of another view
                                of the same Gaussians (the colour / ToF camera pair of one training iteration,
                                gaussian_renderer/__init__.py:107-128): the rows of the Gaussians this view blended are
