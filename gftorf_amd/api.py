@@ -88,6 +88,57 @@ _GRAD_POOL_DEPTH = 3      # rasterizer calls of one iteration whose gradient ten
 
 def _storage_refs(t):
     return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+# The backward's accumulator (64 B per Gaussian) kept from one backward to the next.  The render backward adds to the rows
+# of the Gaussians some pixel blended and the preprocess backward reads each of those rows once; with cfg.acc_zeroed = 2
+# it zeroes them behind the read, so the buffer is all zero again after every backward and the next forward has nothing
+# to clear (64 MB of HBM writes per frame at 1 M Gaussians, issued beside the binning kernels: 14-27 us of a 0.42 ms
+# step).  A buffer is internal -- no tensor of it is ever handed out --, is reused only on the stream its last kernels ran
+# on (or where the caller orders the streams itself, gftorf_amd.pair), and only if its last user left it zero: a forward
+# whose backward never ran (its clear or its predecessor's zeroing stands), or a backward that returned without error.
+# GFT_ACC_REUSE=0 switches it off (every forward then clears a fresh buffer, as before).
+_ACC_REUSE = _os.environ.get("GFT_ACC_REUSE", "1") != "0"
+_acc_pool = {}            # (device, P) -> list of (buffer whose rows are zero, stream of its last kernels)
+_ACC_POOL_DEPTH = 3
+
+
+class _AccLease:
+    """One accumulator buffer on its way through a forward and (maybe) a backward."""
+    __slots__ = ("buf", "key", "stream", "zero", "was_zero")
+
+    def __init__(self, buf, key, stream, was_zero):
+        self.buf, self.key, self.stream = buf, key, stream
+        self.was_zero = was_zero      # taken from the pool: the forward clears nothing
+        self.zero = False             # the buffer is (in stream order) all zero and nobody is going to write to it
+
+    def give_back(self):
+        buf, self.buf = self.buf, None
+        if buf is None or not self.zero or not _ACC_REUSE:
+            return
+        pool = _acc_pool.setdefault(self.key, [])
+        pool.append((buf, self.stream))
+        del pool[:-_ACC_POOL_DEPTH]
+        if len(_acc_pool) > 8:
+            _acc_pool.pop(next(iter(_acc_pool)))
+
+    def __del__(self):
+        # a forward whose backward never ran: the accumulator was not touched after the forward's clear
+        try:
+            self.give_back()
+        except Exception:
+            pass
+
+
+def _take_acc(lib, dev, P, stream, any_stream=False):
+    key = (dev.index, P)
+    pool = _acc_pool.get(key) if _ACC_REUSE else None
+    if pool:
+        for i, (buf, st) in enumerate(pool):
+            if st == stream or any_stream:
+                del pool[i]
+                return _AccLease(buf, key, stream, True)
+    return _AccLease(torch.empty((lib.gft_acc_bytes(P) // 4,), device=dev, dtype=torch.float32), key, stream, False)
 _LIST_HEADROOM = 1.2      # longest tile list of the previous frame -> guess for this one
 
 
@@ -200,7 +251,7 @@ class _Settings(NamedTuple):
 
 def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
                    cov3Ds_precomp, ph_off, dc_off, want_bw, with_acc, stream=None, hint_slot=0, share_grads=None,
-                   pre_launch=None):
+                   pre_launch=None, acc_any_stream=False):
     """One forward of the native rasterizer (``RasterizeGaussiansCUDA``, rasterize_points.cu:42-165): allocates the
     outputs and the three scratch buffers, runs the C ABI on torch's current stream.  ``s`` holds the settings fields
     (``GaussianRasterizationSettings`` or ``_Settings``), ``ph_off`` / ``dc_off`` are floats.  Returns a dict.
@@ -264,9 +315,13 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
     io.out_depth_distortion, io.out_amp_distortion = depth_distortion.data_ptr(), amp_distortion.data_ptr()
     io.out_distribution = distribution.data_ptr()
     io.pixels, io.radii = _ptr(pixels) if P else None, _ptr(radii) if P else None
-    # the backward's accumulator: cleared by the forward under its render kernel
-    acc_buf = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32) if (want_bw and with_acc and P) else None
-    io.acc = _ptr(acc_buf)
+    # the backward's accumulator: cleared by the forward beside its binning kernels -- unless it comes from the pool of
+    # buffers that the last backward left zero (_AccLease)
+    lease = None
+    if want_bw and with_acc and P:
+        lease = _take_acc(lib, dev, P, stream if stream is not None else _lib.raw_stream(dev), acc_any_stream)
+    acc_buf = lease.buf if lease is not None else None
+    io.acc = None if (lease is not None and lease.was_zero) else _ptr(acc_buf)
 
     # the backward's gradient tensors and argument block, while the device is still busy with earlier work
     prep = None
@@ -274,7 +329,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         prep = prepare_backward(s, means3D_c, opac_c, sh_c, sh_p_c, scales_c, rot_c, cov_c, radii, geom, img,
                                 (bg_c, bsc, bsy, bsx), (view_c, proj_c, campos_c), ph_off, dc_off, acc_buf,
                                 colors_c is not None, cov_c is not None, want_bw, pixels,
-                                zero_fill=_ZERO_FILL and share_grads is None, share_grads=share_grads)
+                                zero_fill=_ZERO_FILL and share_grads is None, share_grads=share_grads, acc_lease=lease)
         if prep["zero_buf"] is not None:
             io.grads_zero = prep["zero_buf"].data_ptr()
             io.grads_zero_bytes = prep["zero_buf"].numel() * 4
@@ -336,6 +391,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
             raise ex
         assert binning_capacity(binning, W, H) == cap
+    if lease is not None:
+        lease.zero = True          # (cleared by this forward, or zero since its last backward)
 
     last_call_stats.update(num_rendered=R, binning_instances=cap, restarted=restarted,
                            max_tile_list=int(max_list.value) if P else 0)
@@ -351,7 +408,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
 
 
 def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, img, bg, consts, ph_off, dc_off,
-                     acc, want_colors, want_cov, want_bw_records=True, pixels=None, zero_fill=False, share_grads=None):
+                     acc, want_colors, want_cov, want_bw_records=True, pixels=None, zero_fill=False, share_grads=None,
+                     acc_lease=None):
     """Everything of a backward that does not depend on the upstream gradients: the gradient tensors, the argument
     block, the config.  The forward calls it BEFORE it queues its kernels, so that this host work overlaps the device's
     previous work instead of sitting between the forward's last kernel and the backward's first one."""
@@ -420,7 +478,8 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
     if acc is None:            # second backward through the same forward (retain_graph), or the pybind-level route
         acc = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32)
     cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw_records)
-    cfg.acc_zeroed = int(acc_zeroed)
+    # (2: the backward leaves the accumulator zero again -- the buffer goes back to the pool, _AccLease)
+    cfg.acc_zeroed = 2 if (acc_zeroed and acc_lease is not None and _ACC_REUSE) else int(acc_zeroed)
     cfg.grads_zeroed = 3 if reused_grads else int(zero_buf is not None)
     cfg.grads_accumulate = int(share_grads is not None)
     if share_grads is not None and share_grads.get("dirty") is not None:
@@ -451,7 +510,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         # (cfg.grads_zeroed = 3: the backward zeroes the rows the previous one wrote and this one does not, then writes its own)
         io.dirty_rows = entry["dirty"].data_ptr()
     last_call_stats["grads_reused"] = bool(reused_grads)
-    return dict(grads=g, cfg=cfg, io=io, acc=acc, pixels=pixels, zero_buf=zero_buf, dev=dev, P=P, H=H, W=W,
+    return dict(grads=g, cfg=cfg, io=io, acc=acc, acc_lease=acc_lease, pixels=pixels, zero_buf=zero_buf, dev=dev, P=P, H=H, W=W,
                 dirty=entry["dirty"] if entry is not None else None,
                 debug_args=(s.bg, means3D, radii, scales, rotations, s.scale_modifier, cov3D, s.viewmatrix, s.projmatrix,
                             s.tanfovx, s.tanfovy, sh, sh_p, s.sh_degree, s.campos, s.debug, s.near_n, s.far_n, s.depth_range,
@@ -486,9 +545,16 @@ def run_backward(prep, grads_out, geom, binning, img, debug=False):
         io.det_partials = det.data_ptr()
     if debug:
         cpu_args = cpu_deep_copy_tuple(prep["debug_args"] + tuple(grads_out) + (geom, binning, img))
+    lease = prep.get("acc_lease")
+    if lease is not None:
+        lease.zero = False             # the render backward writes to it; zero again only if the call below returns
     try:
         with _lib.on_device(dev):
-            _lib.check(lib.gft_backward(_lib.raw_stream(dev), C.byref(prep["cfg"]), C.byref(io), cap))
+            stream = _lib.raw_stream(dev)
+            _lib.check(lib.gft_backward(stream, C.byref(prep["cfg"]), C.byref(io), cap))
+        if lease is not None and prep["cfg"].acc_zeroed == 2:
+            lease.zero, lease.stream = True, stream
+            lease.give_back()
     except Exception as ex:
         if debug:
             torch.save(cpu_args, "snapshot_bw.dump")

@@ -671,6 +671,7 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
         if (!f || !f->pending) return gft_fail("gft_backward: grads_zeroed without a forward that filled them");
         GFT_CHECK_HIP(hipStreamWaitEvent(s, f->filled, 0));
     }
+    if (cfg->acc_zeroed < 0 || cfg->acc_zeroed > 2) return gft_fail("gft_backward: cfg.acc_zeroed must be 0, 1 or 2");
     if (!cfg->acc_zeroed) {
         StageTimer t(s, ST_MEMSET);
         GFT_CHECK_HIP(hipMemsetAsync(io->acc, 0, (size_t)cfg->P * GFT_ACC_STRIDE * sizeof(float), s));

@@ -448,6 +448,14 @@ __device__ __forceinline__ void preprocess_bwd_body(PreBwdArgs a, int row_idx = 
             // row = {dcolor[3], ddist | sum E dx, sum E dy, dconic.xy' | XR, XI, X2, XQ | dconic.w', dopacity, dndc, -}
             // (the order the render backward's pairwise wave reduction produces, k_render.hip)
             const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+            // cfg.acc_zeroed = 2: the caller keeps the accumulator; the rows of blended Gaussians are its only non-zero
+            // ones and each is read exactly once, here: zeroed behind the read, the buffer is all zero again when this
+            // kernel ends and the next forward has nothing to clear
+            if (a.c.acc_zeroed == 2) {
+                float4* zp = reinterpret_cast<float4*>(a.io.acc + (size_t)idx * GFT_ACC_STRIDE);
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                zp[0] = z; zp[1] = z; zp[2] = z; zp[3] = z;
+            }
             // (the forward's records for the chains further down, asked for together with the accumulator row: the wave's
             // time is its dependent memory round trips, two waves per SIMD do not hide a third one)
             const uint32_t clamp_bits = a.g.clamped[idx];

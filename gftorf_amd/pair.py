@@ -61,7 +61,8 @@ class _RasterizePair(torch.autograd.Function):
         rb = native_forward(settings_b, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
                             cov3Ds_precomp, offs[1][0], offs[1][1], want_bw, True,
                             stream=side.cuda_stream if overlap else None, hint_slot=2, share_grads=ra["prep"],
-                            pre_launch=fork if overlap else None)
+                            pre_launch=fork if overlap else None,
+                            acc_any_stream=overlap)      # (a kept accumulator's last kernels ran on the main stream: fork() orders them)
         if overlap:
             join = torch.cuda.Event()
             join.record(side)

@@ -66,7 +66,10 @@ typedef struct gft_config {
      * direction) so the backward does not have to re-read the 320 B of SH coefficients;
      * backward: that record is present in `geom` (same value as in the forward call) */
     int32_t want_backward;
-    /* backward only: `acc` was cleared by the forward (gft_forward_io.acc), skip the clear */
+    /* backward only: 0 = the library clears `acc` first; 1 = `acc` is zero (the forward cleared it, gft_forward_io.acc):
+     * skip the clear; 2 = `acc` is zero AND is to be left zero: the backward's preprocess kernel zeroes every accumulator
+     * row it has read (the rows of the blended Gaussians are the only non-zero ones), so a caller that keeps the buffer
+     * hands the next forward no `acc` to clear (64 B per Gaussian of HBM writes per frame saved) */
     int32_t acc_zeroed;
     int32_t grads_zeroed;   /* gft_backward: 1 = the gradient outputs were zeroed by the forward (gft_forward_io.grads_zero),
                                2 = they are zero because the caller kept them and re-zeroed the rows the previous
@@ -120,7 +123,9 @@ typedef struct gft_forward_io {
     int32_t* radii;                /* [P] */
     /* optional: the backward's accumulator (gft_acc_bytes(P)).  With want_backward the forward
      * clears it as a side job of the LDS-bound tile sort (64 B/Gaussian of HBM writes that
-     * would otherwise be a separate pass of the backward); pass cfg.acc_zeroed to gft_backward. */
+     * would otherwise be a separate pass of the backward); pass cfg.acc_zeroed to gft_backward.
+     * NULL: nothing is cleared (the caller's buffer is zero already, e.g. left so by a backward with
+     * cfg.acc_zeroed = 2). */
     float* acc;
     /* optional: the buffer that holds the backward's per-Gaussian gradient tensors (any layout, `grads_zero_bytes`
      * bytes).  The forward zero-fills it on a library-owned side stream while its render kernel (bound by VALU issue,

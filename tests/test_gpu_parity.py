@@ -817,3 +817,72 @@ def test_gradient_tensors_are_reused_only_when_nobody_holds_or_modified_them(ora
     check_grads(bb, grads, b)
     pool = api._grad_pool[next(iter(api._grad_pool))]
     assert edited[0] not in [e["buf"].data_ptr() for e in pool]     # ... and that buffer is forgotten, not reused
+
+
+def test_accumulator_is_kept_and_left_zero(oracle, gpu):
+    """The backward's accumulator (64 B per Gaussian) is kept between calls (api.py: _AccLease): the preprocess backward
+    zeroes the rows it has read (cfg.acc_zeroed = 2) and the next forward clears nothing.  Not observable: gradients of
+    alternating scenes equal the oracle's every time, the buffer in the pool is all zero after every backward, a forward
+    whose backward never runs hands its buffer back untouched, and a second backward through one forward
+    (retain_graph) takes a buffer of its own."""
+    from gftorf_amd import api
+    if not api._ACC_REUSE:
+        pytest.skip("accumulator reuse is off")
+    a = Hh.small_scene(P=3000, seed=41)
+    b = Hh.small_scene(P=3000, seed=42, opacity=0.7)
+    fa, ba = Hh.run_oracle(oracle, a)
+    fb, bb = Hh.run_oracle(oracle, b)
+    api._acc_pool.clear()
+    key = (torch.device(gpu).index, 3000)
+
+    def pool_is_zero():
+        torch.cuda.synchronize()
+        bufs = api._acc_pool.get(key, [])
+        assert len(bufs) >= 1
+        return all(float(buf.abs().max()) == 0.0 or float(buf[:3000 * 16].abs().max()) == 0.0 for buf, _ in bufs)
+
+    ptrs = []
+    for it in range(5):
+        sc, f, bw = (a, fa, ba) if it % 2 == 0 else (b, fb, bb)
+        out, grads, t = Hh.run_gpu(sc, gpu)
+        check_outputs(f, out)
+        check_grads(bw, grads, sc)
+        del t, grads, out
+        assert pool_is_zero()
+        ptrs.append(api._acc_pool[key][-1][0].data_ptr())
+    assert len(set(ptrs)) == 1, ptrs                      # one buffer went round
+    # a forward under grad whose backward never runs: its buffer comes back as it was
+    g = dict(a["gaussians"])
+    leaf = torch.tensor(g["means3D"], dtype=torch.float32, device=gpu, requires_grad=True)
+    from gftorf_amd import GaussianRasterizer
+    rast = GaussianRasterizer(raster_settings=Hh.gpu_settings(a, gpu))
+    kw = {k: (torch.tensor(v, dtype=torch.float32, device=gpu) if v is not None else None) for k, v in g.items() if k != "means3D"}
+    outs = rast(means3D=leaf, means2D=torch.zeros((3000, 3), device=gpu), opacities=kw["opacities"], shs=kw.get("shs"),
+                shs_p=kw.get("shs_p"), colors_precomp=kw.get("colors_precomp"), phasors_precomp=kw.get("phasors_precomp"),
+                scales=kw.get("scales"), rotations=kw.get("rotations"), cov3D_precomp=kw.get("cov3D_precomp"),
+                phase_offset=a["phase_offset"], dc_offset=a["dc_offset"])
+    assert len(api._acc_pool.get(key, [])) == 0           # (the forward holds the buffer)
+    del outs
+    import gc
+    gc.collect()
+    assert pool_is_zero() and api._acc_pool[key][-1][0].data_ptr() == ptrs[0]
+    out, grads, t = Hh.run_gpu(b, gpu)
+    check_grads(bb, grads, b)
+    del out, grads, t
+    # two backwards through one forward: the second takes its own accumulator, both give the oracle's gradients
+    leaf = {k: torch.tensor(v, dtype=torch.float32, device=gpu, requires_grad=True) for k, v in a["gaussians"].items() if v is not None}
+    m2 = torch.zeros((3000, 3), device=gpu, requires_grad=True)
+    outs = rast(means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf.get("shs"), shs_p=leaf.get("shs_p"),
+                colors_precomp=leaf.get("colors_precomp"), phasors_precomp=leaf.get("phasors_precomp"),
+                scales=leaf.get("scales"), rotations=leaf.get("rotations"), cov3D_precomp=leaf.get("cov3D_precomp"),
+                phase_offset=a["phase_offset"], dc_offset=a["dc_offset"])
+    o = dict(zip(Hh.OUT_NAMES, outs))
+    loss = sum((o[k] * torch.tensor(a["grads"][k], device=gpu)).sum() for k in Hh.GRAD_KEYS)
+    for rep in range(2):
+        for v in list(leaf.values()) + [m2]:
+            v.grad = None
+        loss.backward(retain_graph=(rep == 0))
+        grads = {k: (v.grad.detach().cpu().numpy() if v.grad is not None else None) for k, v in leaf.items()}
+        grads["means2D"] = m2.grad.detach().cpu().numpy()
+        check_grads(ba, grads, a)
+        assert pool_is_zero()
