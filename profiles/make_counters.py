@@ -20,6 +20,8 @@ STAGE_OF = {"k_preprocess_fwd": "preprocess_fwd", "k_appearance": "preprocess_fw
             "k_tile_sort_small": "tile_sort", "k_tile_sort_big": "tile_sort", "k_tile_front": "tile_sort", "k_tile_tail": "tile_sort",
             "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd", "k_tile_order": "render_bwd",
             "k_preprocess_bwd": "preprocess_bwd", "k_preprocess_bwd_common": "preprocess_bwd", "k_offset_reduce": "preprocess_bwd",
+            # gradient tensors kept between backwards: rows of blended Gaussians only (the training call's kernel)
+            "k_preprocess_bwd_rows": "preprocess_bwd", "k_grads_rezero": "preprocess_bwd",
             # tile-pull binning (k_pull.hip): count pass, scatter pass, per-tile pull + sort, lists completed on demand
             "k_super_bin<0>": "tile_count", "k_super_bin<1>": "tile_scatter", "k_tile_pull": "tile_sort", "k_tail_build": "tile_sort"}
 ALL_STAGES = ("preprocess_fwd", "tile_count", "tile_scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
