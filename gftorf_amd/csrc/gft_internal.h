@@ -252,36 +252,74 @@ __device__ __forceinline__ bool gft_splat_reaches_quadrant(const float4& a0, con
 __device__ inline void gft_tile_order_block(int T, const uint32_t* __restrict__ quad_max, uint32_t* __restrict__ order,
                                             const uint32_t* __restrict__ flag = nullptr)
 {
+    // One pass over global memory: a thread keeps the weights of its tiles (t = tid + k blockDim) in registers; the
+    // histogram over the 64 weight buckets is kept per wave (the heavy tiles of a dense frame crowd a few buckets: one
+    // shared counter per bucket serialised the block's LDS atomics), the bucket starts are one wave's prefix sum.
+    // (The order inside a bucket is whatever the atomics give: any order of equally heavy tiles serves.)
+    constexpr int PER = 16;                         // tiles per thread kept in registers; more (T > 16 blockDim) are re-read
     __shared__ uint32_t s_max;
-    __shared__ uint32_t cnt[64], base[64];
-    const int tid = threadIdx.x;
+    __shared__ uint32_t cnt[16][64];                // [wave][bucket]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_max = 0;
-    if (tid < 64) cnt[tid] = 0;
-    __syncthreads();
+    for (int i = tid; i < 16 * 64; i += (int)blockDim.x) (&cnt[0][0])[i] = 0;
     // weight of a tile: its deepest quadrant walk; a flagged quadrant's walk is not over: the tile counts as the heaviest
     auto weight = [&](int t) -> uint32_t {
         const uint4 q = reinterpret_cast<const uint4*>(quad_max)[t];
-        return max(max(q.x, q.y), max(q.z, q.w));
+        uint32_t w = max(max(q.x, q.y), max(q.z, q.w));
+        if (flag) {
+            const uint4 f = reinterpret_cast<const uint4*>(flag)[t];
+            if ((f.x | f.y | f.z | f.w) != 0u) w = 0xffffffffu;
+        }
+        return w;
     };
-    auto flagged = [&](int t) -> bool {
-        if (!flag) return false;
-        const uint4 f = reinterpret_cast<const uint4*>(flag)[t];
-        return (f.x | f.y | f.z | f.w) != 0u;
-    };
+    uint32_t w[PER];
     uint32_t m = 0;
-    for (int t = tid; t < T; t += (int)blockDim.x) m = max(m, weight(t));
-    atomicMax(&s_max, m);
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int t = tid + k * (int)blockDim.x;
+        w[k] = t < T ? weight(t) : 0u;
+        if (w[k] != 0xffffffffu) m = max(m, w[k]);
+    }
+    for (int t = tid + PER * (int)blockDim.x; t < T; t += (int)blockDim.x) {
+        const uint32_t x = weight(t);
+        if (x != 0xffffffffu) m = max(m, x);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
     __syncthreads();
-    const uint32_t wmax = s_max + 1;
-    for (int t = tid; t < T; t += (int)blockDim.x) atomicAdd(&cnt[flagged(t) ? 0u : 63 - (weight(t) * 64u) / wmax], 1u);
+    if (lane == 0 && m) atomicMax(&s_max, m);
     __syncthreads();
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (int b = 0; b < 64; b++) { base[b] = acc; acc += cnt[b]; cnt[b] = 0; }
+    // (any monotone map onto 64 buckets serves: a float multiply instead of an integer division per tile)
+    const float scale = 64.0f / (float)(s_max + 1u);
+    auto bucket = [&](uint32_t x) -> uint32_t { return x == 0xffffffffu ? 0u : 63u - min(63u, (uint32_t)((float)x * scale)); };
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+        if (tid + k * (int)blockDim.x < T) atomicAdd(&cnt[wave & 15][bucket(w[k])], 1u);
+    for (int t = tid + PER * (int)blockDim.x; t < T; t += (int)blockDim.x) atomicAdd(&cnt[wave & 15][bucket(weight(t))], 1u);
+    __syncthreads();
+    if (wave == 0) {
+        // bucket b of wave v starts at sum(buckets < b, all waves) + sum(bucket b, waves < v): cnt becomes those starts
+        uint32_t tot = 0;
+        for (int v = 0; v < 16; v++) tot += cnt[v][lane];
+        uint32_t x = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        uint32_t run = x - tot;
+        for (int v = 0; v < 16; v++) {
+            const uint32_t c = cnt[v][lane];
+            cnt[v][lane] = run;
+            run += c;
+        }
     }
     __syncthreads();
-    for (int t = tid; t < T; t += (int)blockDim.x) {
-        const uint32_t b = flagged(t) ? 0u : 63 - (weight(t) * 64u) / wmax;
-        order[base[b] + atomicAdd(&cnt[b], 1u)] = (uint32_t)t;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int t = tid + k * (int)blockDim.x;
+        if (t < T) order[atomicAdd(&cnt[wave & 15][bucket(w[k])], 1u)] = (uint32_t)t;
     }
+    for (int t = tid + PER * (int)blockDim.x; t < T; t += (int)blockDim.x)
+        order[atomicAdd(&cnt[wave & 15][bucket(weight(t))], 1u)] = (uint32_t)t;
 }
