@@ -419,6 +419,7 @@ struct TailArgs {
     uint32_t cap;
     const uint32_t* __restrict__ quad_max;
     uint32_t* __restrict__ order;
+    int dbg;
 };
 
 __device__ __forceinline__ void tail_appearance(const TailArgs& a, uint32_t id)
@@ -506,6 +507,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
                     }
                     bool s4[4];
                     float4 ra[4], rb[4];
+                    uint32_t dz[4];                              // depth bits of the hits: asked for with their geometry records
+                                                                 // (inside the loop below each would be a round trip of its own)
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const uint32_t b = entry_bin(e4[u]);
@@ -513,6 +516,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
                         const uint32_t id = s4[u] ? (uint32_t)e4[u] : 0u;
                         ra[u] = s4[u] ? a.pre.g.rec_a[2 * id] : make_float4(0.f, 0.f, 0.f, 0.f);
                         rb[u] = s4[u] ? a.pre.g.rec_a[2 * id + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        dz[u] = (s4[u] && mode != 2) ? __float_as_uint(a.pre.g.depth[id]) : 0u;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
                         const uint32_t pos = hb + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
                         if (mode == 0) atomicAdd(&s_hist[b], 1u);
                         if (mode == 2) dst[pos] = id;
-                        else if (pos < TAIL_LDS_KEYS) sk[sort_slot(pos)] = ((uint64_t)__float_as_uint(a.pre.g.depth[id]) << 32) | id;
+                        else if (pos < TAIL_LDS_KEYS) sk[sort_slot(pos)] = ((uint64_t)dz[u] << 32) | id;
                     }
                 }
             }
@@ -539,7 +543,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
         // sorts the n keys in LDS (n <= TAIL_LDS_KEYS), gives their Gaussians an appearance, writes the ids
         auto finish_lds = [&](uint32_t n, uint32_t* dst) {
             __syncthreads();
-            for (uint32_t i = tid; i < n; i += TAIL_THREADS) tail_appearance(a, (uint32_t)sk[sort_slot(i)]);
+            if (a.dbg != 3) for (uint32_t i = tid; i < n; i += TAIL_THREADS) tail_appearance(a, (uint32_t)sk[sort_slot(i)]);
+            if (a.dbg == 4) return;
             if (n <= 1024u) {
                 // a short tail (the usual case: a few hundred survivors): runs of 256 keys are sorted by one wave each in
                 // registers (no workgroup barrier), the runs are merged by rank -- a key's place = its place in its own run +
@@ -581,9 +586,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
             for (uint32_t i = tid; i < n; i += TAIL_THREADS) dst[i] = (uint32_t)sk[sort_slot(i)];
             __syncthreads();
         };
+        if (a.dbg == 1) return;
         scan(0, first_tail, GFT_DEPTH_BINS - 1u, nullptr);
         __syncthreads();
         const uint32_t m = s_m;
+        if (a.dbg == 2) return;
         // the completed list (head copy + culled tail) takes kf + m pool slots; over all tiles that is at most R <= cap
         if (tid == 0) s_pool = atomicAdd(&a.ctrl[GFT_CTRL_POOLCUR], kf + m);
         __syncthreads();
@@ -733,6 +740,8 @@ hipError_t gft_launch_tail_build(hipStream_t s, const gft_config& c, const gft_f
     a.front_len = im.front_len; a.unit_flag = im.unit_flag; a.tile_cut = im.tile_cut;
     a.ctrl = im.ctrl; a.cap = cap;
     a.quad_max = im.tile_max; a.order = want_order ? im.tile_order : nullptr;
+    static const int tdbg = [] { const char* e = getenv("GFT_TAIL_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = tdbg;
     const size_t lds = (size_t)SORT_SLOTS(TAIL_LDS_KEYS) * 8;
     {
         static std::atomic<uint64_t> done{0};
