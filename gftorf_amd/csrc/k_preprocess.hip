@@ -257,9 +257,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const int P = a.c.P;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // the binning kernels' counters (ctrl words, tile counters, depth histogram, supertile table): zeroed here instead
-    // of by a separate fill launch; nothing in this kernel reads or writes them
-    for (uint32_t w = (uint32_t)idx; w < a.clear_words; w += gridDim.x * PRE_BLOCK) a.ctrl[w] = 0u;
     float4* sh_l = lds_rows + wave * ((a.stage_sh ? 64 * SH_ROW_PAD : 0) + (a.stage_shp ? 64 * SHP_ROW_PAD : 0));
     float4* shp_l = sh_l + (a.stage_sh ? 64 * SH_ROW_PAD : 0);
     if (a.stage_sh | a.stage_shp) {
@@ -303,6 +300,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
         a.g.rect[idx] = rect;
         a.g.need[idx] = 0;
     }
+    // the binning kernels' counters (ctrl words, tile counters, tile cuts, supertile table): zeroed here instead of by a
+    // separate fill launch; nothing in this kernel reads or writes them.  (Behind the kernel's loads: in front, the first
+    // workgroups' loads waited for these stores.)
+    for (uint32_t w = (uint32_t)idx; w < a.clear_words; w += gridDim.x * PRE_BLOCK) a.ctrl[w] = 0u;
 }
 
 // Appearance on demand (tile-pull binning, k_pull.hip): the Gaussians k_tile_pull marked -- those in the sorted head of
@@ -864,12 +865,14 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_preprocess_bwd_rows(PreBwdArgs
     }
     if (i0 < P && (now != old || !rezero)) *reinterpret_cast<uint32_t*>(a.io.dirty_rows + i0) = now;
     __syncthreads();
-    for (uint32_t r = (uint32_t)wave; r < s_nstale; r += ROWS_THREADS / 64) zero_gradient_rows(a.io, a.c.M, a.c.M_p, s_stale[r], lane);
     float sum_phase = 0.f, sum_dc = 0.f;
     for (uint32_t r0 = 0; r0 < n; r0 += ROWS_THREADS) {
         const uint32_t r = r0 + (uint32_t)tid;
         preprocess_bwd_body<COMMON, true>(a, r < n ? (int)s_ids[r] : -1, &sum_phase, &sum_dc);
     }
+    // (the stale rows are zeroed BEHIND the rows' work: loads and stores count down one in-order counter, so in front of
+    // it every load of the chains above waited until HBM had taken these stores)
+    for (uint32_t r = (uint32_t)wave; r < s_nstale; r += ROWS_THREADS / 64) zero_gradient_rows(a.io, a.c.M, a.c.M_p, s_stale[r], lane);
     const float sp = gft_wave_sum_to_lane63(sum_phase);
     const float sd = gft_wave_sum_to_lane63(sum_dc);
     if (lane == 63 && a.io.shs_p != nullptr) {

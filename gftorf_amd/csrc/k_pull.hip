@@ -256,7 +256,6 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
     const int K = a.sh.K;
     for (int i = tid; i < GFT_DEPTH_BINS; i += GFT_BLOCK) s_hist[i] = 0;
     if (tid == 0) s_n = 0;
-    if (tid < 4) a.unit_flag[4 * tile + tid] = 0;
     __syncthreads();
 
     // pass over one entry list of the supertile.  MODE 0: count the tile's hits and histogram them over the depth bins;
@@ -316,7 +315,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
         __syncthreads();                                 // (everybody has read the count before the next slab adds to it)
         if (n >= HEAD_TARGET) { kstop = k; break; }
     }
-    if (a.dbg == 1) { if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
+    if (a.dbg == 1) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     bool more_slabs = false;
     for (int k = kstop + 1; k < K; k++) more_slabs |= a.st_cnt[q * K + k] != 0u;
     // the head: whole bins up to the one where the running count reaches HEAD_TARGET.  That bin is taken if the head then
@@ -354,7 +353,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
         kf = s_kf;
     }
     __syncthreads();
-    if (a.dbg == 2) { if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
+    if (a.dbg == 2) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     if (tid == 0) s_n = 0;
     __syncthreads();
     // pass B: the head's keys
@@ -373,6 +372,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
         a.tile_cnt[tile] = n;
         a.tile_cut[tile] = has_tail ? first_tail : GFT_NO_TAIL;
     }
+    if (tid < 4) a.unit_flag[4 * tile + tid] = 0;        // (behind the scans: a store in front of them holds up the wave's loads)
     __syncthreads();
     clear_slice();
     if (a.dbg == 3) { if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
