@@ -53,7 +53,7 @@ struct ImgView {
     uint32_t* tile_cursor;// [T]
     uint32_t* tile_order; // [T] tiles by backward weight, heaviest first
     uint32_t* front_len;  // [T] length of the sorted head of the tile's id list
-    uint32_t* unit_flag;  // [4T] quadrant reached the end of the head unsaturated
+    uint32_t* unit_flag;  // [4T] non-zero: the quadrant reached the end of the head unsaturated (gft_flag_word: with the box of those pixels)
     float4* resume_state; // [N][4] blend state of the pixels of flagged quadrants
 };
 
@@ -225,21 +225,49 @@ __device__ __forceinline__ uint32_t gft_depth_bin(uint32_t dbits, uint32_t near_
 // rectangle sits on an edge facing the centre: two 1-D clamped minimisations.  (A bounding-box test passes 195 of 429
 // walked splats per quadrant on the metric frame, this one 154; 144 really touch a pixel.)  Conservative: a splat that
 // fails can blend into no pixel of the quadrant (forward.cu:536-548).
-__device__ __forceinline__ bool gft_splat_reaches_quadrant(const float4& a0, const float4& a1, float qx0, float qy0)
+// (general form: the rectangle of pixel centres [bx0, bx0 + bw] x [by0, by0 + bh])
+__device__ __forceinline__ bool gft_splat_reaches_box(const float4& a0, const float4& a1, float bx0, float by0, float bw, float bh)
 {
     const float ca = a0.z, cb = a0.w, cc = a1.x, op = a1.y;
     const float det = ca * cc - cb * cb;
     const float tau = __logf(255.0f * op);
     if (!(tau > 0.0f)) return false;            // opacity <= 1/255: can never pass the alpha test
     if (!(det > 0.0f && ca > 0.0f && cc > 0.0f)) return true;   // degenerate conic: let the pixel test decide
-    const float ux0 = qx0 - a0.x, ux1 = ux0 + 7.0f;
-    const float uy0 = qy0 - a0.y, uy1 = uy0 + 7.0f;
+    const float ux0 = bx0 - a0.x, ux1 = ux0 + bw;
+    const float uy0 = by0 - a0.y, uy1 = uy0 + bh;
     const float X = fminf(fmaxf(0.0f, ux0), ux1), Y = fminf(fmaxf(0.0f, uy0), uy1);   // rectangle point nearest the centre, per axis
     const float ys = fminf(fmaxf(-cb * X * __frcp_rn(cc), uy0), uy1);
     const float xs = fminf(fmaxf(-cb * Y * __frcp_rn(ca), ux0), ux1);
     const float q1 = ca * X * X + 2.0f * cb * X * ys + cc * ys * ys;
     const float q2 = ca * xs * xs + 2.0f * cb * xs * Y + cc * Y * Y;
     return fminf(q1, q2) <= 2.0f * tau * 1.0005f + 0.01f;       // margins keep the test conservative
+}
+__device__ __forceinline__ bool gft_splat_reaches_quadrant(const float4& a0, const float4& a1, float qx0, float qy0)
+{
+    return gft_splat_reaches_box(a0, a1, qx0, qy0, 7.0f, 7.0f);
+}
+
+// Flag word of a quadrant that walked its whole head with unsaturated pixels (ImgView::unit_flag): non-zero, and it
+// carries the bounding box of those pixels inside the quadrant (x0 | y0 << 3 | x1 << 6 | y1 << 9, pixels 0..7): the rest
+// of the tile's list is culled against that box -- saturated pixels blend nothing more, and a silhouette quadrant's
+// unsaturated pixels are a band along one edge, not the quadrant.
+#define GFT_FLAG_SET 0x80000000u
+__device__ __forceinline__ uint32_t gft_flag_word(unsigned long long unsaturated)      // (non-zero mask, lane = 8 y + x)
+{
+    uint32_t c = (uint32_t)(unsaturated | (unsaturated >> 32));
+    c |= c >> 16;
+    c |= c >> 8;
+    c &= 0xffu;
+    const uint32_t x0 = (uint32_t)__builtin_ctz(c), x1 = 31u - (uint32_t)__builtin_clz(c);
+    const uint32_t y0 = (uint32_t)__builtin_ctzll(unsaturated) >> 3, y1 = (63u - (uint32_t)__builtin_clzll(unsaturated)) >> 3;
+    return GFT_FLAG_SET | x0 | (y0 << 3) | (x1 << 6) | (y1 << 9);
+}
+// can the splat reach an unsaturated pixel of the flagged quadrant whose first pixel centre is (qx0, qy0)?
+__device__ __forceinline__ bool gft_splat_reaches_flagged(uint32_t flag, const float4& a0, const float4& a1, float qx0, float qy0)
+{
+    if (!flag) return false;
+    const uint32_t x0 = flag & 7u, y0 = (flag >> 3) & 7u, x1 = (flag >> 6) & 7u, y1 = (flag >> 9) & 7u;
+    return gft_splat_reaches_box(a0, a1, qx0 + (float)x0, qy0 + (float)y0, (float)(x1 - x0), (float)(y1 - y0));
 }
 
 // Heavy-first launch order for the backward: the work of a quadrant is proportional to its

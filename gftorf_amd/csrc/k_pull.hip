@@ -19,8 +19,9 @@
 //                      here: -6 / +11 us).  The rest of the list is never formed unless somebody walks that far.
 //   k_tail_build     : for the tiles with a FLAGGED quadrant (walked its whole head with unsaturated pixels --
 //                      the silhouette quadrants of a scene, whose pixels never saturate): pulls the rest of the
-//                      list, CULLS it against the flagged quadrants (most entries of a tile do not reach a given
-//                      8x8 quadrant), gives the survivors their appearance, sorts them and writes head + culled
+//                      list, CULLS it against the unsaturated pixels of the flagged quadrants (their bounding box
+//                      rides in the flag word; most entries of a tile do not reach a given 8x8 quadrant, fewer
+//                      still the band of pixels along a silhouette), gives the survivors their appearance, sorts them and writes head + culled
 //                      tail as one list into the pool; the render kernel's resume pass and the backward walk
 //                      that list.  Non-reaching entries contribute nothing to any pixel of those quadrants, so
 //                      the blend is the same arithmetic sequence as over the reference's full list: images,
@@ -523,8 +524,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
                         const uint32_t id = (uint32_t)e4[u], b = entry_bin(e4[u]);
                         bool sv = s4[u];
                         if (sv)
-                            sv = (f.x && gft_splat_reaches_quadrant(ra[u], rb[u], qx, qy)) || (f.y && gft_splat_reaches_quadrant(ra[u], rb[u], qx + 8.f, qy)) ||
-                                 (f.z && gft_splat_reaches_quadrant(ra[u], rb[u], qx, qy + 8.f)) || (f.w && gft_splat_reaches_quadrant(ra[u], rb[u], qx + 8.f, qy + 8.f)) ||
+                            sv = gft_splat_reaches_flagged(f.x, ra[u], rb[u], qx, qy) || gft_splat_reaches_flagged(f.y, ra[u], rb[u], qx + 8.f, qy) ||
+                                 gft_splat_reaches_flagged(f.z, ra[u], rb[u], qx, qy + 8.f) || gft_splat_reaches_flagged(f.w, ra[u], rb[u], qx + 8.f, qy + 8.f) ||
                                  id == keep_id;
                         const unsigned long long sm = __builtin_amdgcn_ballot_w64(sv);
                         if (sm == 0ull) continue;                // wave-uniform

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
             a.resume_state[4 * pix_i + 3] = make_float4(WD1, WD2, __uint_as_float(last_contributor), is_done ? 1.f : 0.f);
         }
         if (lane == 0) {
-            a.unit_flag[v] = 1u;
+            a.unit_flag[v] = gft_flag_word(~done_m);     // (pixels outside the image count as done)
             atomicAdd(a.nflag, 1u);
         }
     }

@@ -224,7 +224,8 @@ typedef struct gft_layout {
     size_t img_tile_cursor;   /* uint32[T]    scatter cursors */
     size_t img_tile_order;    /* uint32[T]    tiles by backward weight, heaviest first */
     size_t img_front_len;     /* uint32[T]    length of the sorted head of the tile's id list */
-    size_t img_unit_flag;     /* uint32[4T]   quadrant ran out of sorted ids before saturating */
+    size_t img_unit_flag;     /* uint32[4T]   non-zero: the quadrant ran out of sorted ids before saturating (bit 31 + the bounding box
+                                 of its unsaturated pixels, 4 x 3 bits) */
     size_t img_resume_state;  /* float[N][16] blend state of such quadrants' pixels */
     size_t img_pix_sums;      /* float[N][8]  final blend sums {C0,C1,C2,R | I,Am,dist,A}: the split backward starts mid-list from them */
     size_t img_snaps;         /* float[4T][S-1][12][64] blend state of every 8x8 quadrant in front of list entries 256, 512, ...
