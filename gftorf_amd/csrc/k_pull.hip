@@ -45,6 +45,7 @@ namespace {
                                     // quadrant of a tile with a tail would flag and every list be completed in a second pass
 #define HEAD_TARGET 940u            // wanted length of the sorted head of a longer list
 #define TAIL_LDS_KEYS 4096u         // culled tails are sorted in LDS in runs of at most this many keys (whole depth bins)
+#define TAIL_ITEMS 4                  // entries per thread and scan trip (8: no faster, 196 registers)
 #define TAIL_THREADS 512              // (1024 threads leave 128 registers per lane: the appearance evaluation then spills)
 
 // entry = id | rel << 32 | bin << 52;  rel = x0 | y0 << 5 | x1 << 10 | y1 << 15 (tiles from the supertile's corner)
@@ -497,21 +498,21 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
                 if ((((uint32_t)k + 1u) << a.sh.kshift) <= lo || ((uint32_t)k << a.sh.kshift) > hi) continue;   // slab outside [lo, hi]
                 const uint32_t ln = a.st_cnt[q * K + k];
                 const uint64_t* __restrict__ list = a.sl_ent + a.st_start[q * K + k];
-                // four entries per thread and trip: their loads, then the geometry records of the hits, are in flight together
+                // TAIL_ITEMS entries per thread and trip: their loads, then the geometry records of the hits, are in flight together
                 // (a trip is two dependent memory round trips)
-                for (uint32_t i0 = 0; i0 < ln; i0 += 4 * TAIL_THREADS) {
-                    uint64_t e4[4];
+                for (uint32_t i0 = 0; i0 < ln; i0 += TAIL_ITEMS * TAIL_THREADS) {
+                    uint64_t e4[TAIL_ITEMS];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < TAIL_ITEMS; u++) {
                         const uint32_t i = i0 + u * TAIL_THREADS + tid;
                         e4[u] = i < ln ? list[i] : 0ull;
                     }
-                    bool s4[4];
-                    float4 ra[4], rb[4];
-                    uint32_t dz[4];                              // depth bits of the hits: asked for with their geometry records
+                    bool s4[TAIL_ITEMS];
+                    float4 ra[TAIL_ITEMS], rb[TAIL_ITEMS];
+                    uint32_t dz[TAIL_ITEMS];                             // depth bits of the hits: asked for with their geometry records
                                                                  // (inside the loop below each would be a round trip of its own)
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < TAIL_ITEMS; u++) {
                         const uint32_t b = entry_bin(e4[u]);
                         s4[u] = entry_hits(e4[u], lx, ly) && b >= lo && b <= hi;
                         const uint32_t id = s4[u] ? (uint32_t)e4[u] : 0u;
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
                         dz[u] = (s4[u] && mode != 2) ? __float_as_uint(a.pre.g.depth[id]) : 0u;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < TAIL_ITEMS; u++) {
                         const uint32_t id = (uint32_t)e4[u], b = entry_bin(e4[u]);
                         bool sv = s4[u];
                         if (sv)
