@@ -101,9 +101,12 @@ struct BinView {
 #endif
 inline int gft_bwd_segments(size_t T)
 {
-    // (2 ... 8 segments measure alike on the metric frame -- the kernel is bound by VALU issue, not by its chains --;
-    // 4 keeps the forward's snapshot traffic low.  GFT_BWD_NSEG overrides for tuning.)
-    static const int cap = [] { const char* e = getenv("GFT_BWD_NSEG"); const int v = e ? atoi(e) : 0; return v > 0 ? (v > 8 ? 8 : v) : 4; }();
+    // (2 ... 8 segments measure alike on the repeated metric frame, whose walks end inside the ~940-entry heads -- the
+    // kernel is bound by VALU issue there, not by its chains.  Other views of the same scene have quadrants that walk
+    // whole 2048-entry lists: with 4 segments their last one is 1280 entries long and sets the kernel's time
+    // (views at the ends of the bench's arc: 180-190 us against 155-170 with 8 segments; over the 30 views 166 -> 155).
+    // GFT_BWD_NSEG overrides for tuning.)
+    static const int cap = [] { const char* e = getenv("GFT_BWD_NSEG"); const int v = e ? atoi(e) : 0; return v > 0 ? (v > 8 ? 8 : v) : 8; }();
     const size_t v = 4 * (T ? T : 1);
     const size_t n = 65536 / v;
     return n < 1 ? 1 : (n > (size_t)cap ? cap : (int)n);

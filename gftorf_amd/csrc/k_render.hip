@@ -66,18 +66,32 @@ __device__ __forceinline__ uint64_t to_sgpr(unsigned long long m)
     return ((uint64_t)hi << 32) | lo;
 }
 
-// Stage splat `id` into LDS slot `slot`; returns whether it can reach the quadrant whose
-// first pixel is (qx0, qy0).
+// Bounding box {x0, y0, x1 - x0, y1 - y0} (pixel centres) of the pixels of mask m (lane = 8 y + x, m != 0, wave-uniform:
+// scalar work) inside the quadrant whose first pixel is (qx0, qy0): the pixels that can still take a splat.  A batch of
+// the list is culled against it -- late in a quadrant's walk a few open pixels keep the wave going, and most entries
+// that reach the quadrant do not reach them.
+__device__ __forceinline__ float4 box_of_mask(unsigned long long m, int qx0, int qy0)
+{
+    uint32_t c = (uint32_t)(m | (m >> 32));
+    c |= c >> 16;
+    c |= c >> 8;
+    c &= 0xffu;
+    const int x0 = __builtin_ctz(c), x1 = 31 - __builtin_clz(c);
+    const int y0 = (int)(__builtin_ctzll(m) >> 3), y1 = (int)((63 - __builtin_clzll(m)) >> 3);
+    return make_float4((float)(qx0 + x0), (float)(qy0 + y0), (float)(x1 - x0), (float)(y1 - y0));
+}
+
+// Stage splat `id` into LDS slot `slot`; returns whether it can reach a pixel centre of the rectangle `box`.
 __device__ __forceinline__ bool stage_splat(uint32_t id, int slot, const float4* __restrict__ rec_a,
                                             const float4* __restrict__ rec_b, float4* sA, float4* sB,
-                                            float qx0, float qy0)
+                                            const float4& box)
 {
     const float4 a0 = rec_a[2 * id], a1 = rec_a[2 * id + 1];
     sA[2 * slot] = a0;
     sA[2 * slot + 1] = a1;
     sB[2 * slot] = rec_b[2 * id];
     sB[2 * slot + 1] = rec_b[2 * id + 1];
-    return gft_splat_reaches_quadrant(a0, a1, qx0, qy0);
+    return gft_splat_reaches_box(a0, a1, box.x, box.y, box.z, box.w);
 }
 
 struct RenderFwdArgs {
@@ -188,12 +202,14 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
         bool reach = false;
         uint32_t my_id = 0;
         uint32_t cnt = 0;                        // lane j: pixels of this quadrant that blend splat j of the batch
+        // the pixels that are still open (not all are done: checked above); while most are, the box is the quadrant
+        const float4 box = __popcll(~done_m) <= 24 ? box_of_mask(~done_m, qx0, qy0) : make_float4((float)qx0, (float)qy0, 7.f, 7.f);
         __syncthreads();                         // previous batch has read LDS
         if (lane < n) {
             const int pos = base + lane;
             const uint32_t id = a.point_list[range.x + (uint32_t)pos];
             my_id = id;
-            reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, (float)qx0, (float)qy0);
+            reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, box);
         }
         uint64_t m = to_sgpr(wave_ballot(reach));
         __syncthreads();
@@ -559,11 +575,12 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     for (int hi = hi_first; hi > lo_last; hi -= RB) {        // list indices [hi-n, hi), descending
         const int n = min(RB, hi - lo_last);
         bool reach = false;
+        const float4 box = make_float4((float)qx0, (float)qy0, 7.f, 7.f);
         __syncthreads();                           // previous batch's flush has read LDS
         if (lane < n) {
             const uint32_t id = a.point_list[phys((uint32_t)(hi - 1 - lane))];
             sId[lane] = id;
-            reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, (float)qx0, (float)qy0);
+            reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, box);
         }
         uint64_t m = to_sgpr(wave_ballot(reach));
         __syncthreads();
