@@ -187,6 +187,9 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     // where the in-order counter of outstanding memory operations makes them wait for the previous batch's pixel-count
     // atomics and snapshot stores as well)
     asm volatile("" : : "v"(zref), "v"(T), "v"(C0), "v"(WD1));
+    // (the ids of a batch are asked for one batch ahead: a quadrant on the scene's silhouette walks thousands of entries
+    // of which few reach it -- its batches are two dependent memory round trips and little else, this removes one)
+    uint32_t id_next = (begin + lane < total) ? a.point_list[range.x + (uint32_t)(begin + lane)] : 0u;
     for (int base = begin; base < total; base += RB) {
         // all 64 pixels finished -> the rest of the list is never used
         if (done_m == ~0ull) break;
@@ -205,11 +208,13 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
         // the pixels that are still open (not all are done: checked above); while most are, the box is the quadrant
         const float4 box = __popcll(~done_m) <= 24 ? box_of_mask(~done_m, qx0, qy0) : make_float4((float)qx0, (float)qy0, 7.f, 7.f);
         __syncthreads();                         // previous batch has read LDS
-        if (lane < n) {
-            const int pos = base + lane;
-            const uint32_t id = a.point_list[range.x + (uint32_t)pos];
-            my_id = id;
-            reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, box);
+        {
+            const uint32_t id = id_next;
+            if (base + RB + lane < total) id_next = a.point_list[range.x + (uint32_t)(base + RB + lane)];
+            if (lane < n) {
+                my_id = id;
+                reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, box);
+            }
         }
         uint64_t m = to_sgpr(wave_ballot(reach));
         __syncthreads();
