@@ -34,7 +34,7 @@ inline PreFwdArgs gft_pre_fwd_args(const gft_config& c, const gft_forward_io& io
     {
         // ctrl | tile_cnt[T] | tile_cut[T] | super_tab are contiguous (gft_compute_layout)
         const size_t T = (size_t)((c.W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((c.H + GFT_TILE_Y - 1) / GFT_TILE_Y);
-        a.clear_words = (uint32_t)(GFT_CTRL_WORDS + 2 * T + 3 * GFT_SUPER_CELLS);
+        a.clear_words = (uint32_t)(GFT_CTRL_WORDS + 2 * T + GFT_SUPER_CELLS);      // (of super_tab only the counters' plane)
     }
     // reference rasterizer_impl.cu:249-250, forward.cu:752
     a.focal_y = c.H / (2.0f * c.tanfovy);

@@ -49,7 +49,7 @@ struct ImgView {
     uint32_t* ctrl;       // [GFT_CTRL_WORDS], directly followed by tile_cnt, tile_cut, super_tab (cleared together by k_preprocess_fwd)
     uint32_t* tile_cnt;   // [T]  instances per tile
     uint32_t* tile_cut;   // [T]  tile-pull binning: last depth bin inside the sorted head; GFT_NO_TAIL when the head is the whole list
-    uint32_t* super_tab;  // [3][GFT_SUPER_CELLS] tile-pull binning: per (supertile, depth slab) entry count, list start, scatter cursor
+    uint32_t* super_tab;  // [4][GFT_SUPER_CELLS] tile-pull binning: per (copy, supertile, depth slab) entry counters and scatter cursors; per (supertile, slab) entry count and list start
     uint32_t* tile_cursor;// [T]
     uint32_t* tile_order; // [T] tiles by backward weight, heaviest first
     uint32_t* front_len;  // [T] length of the sorted head of the tile's id list
@@ -303,12 +303,27 @@ __device__ inline void gft_tile_order_block(int T, const uint32_t* __restrict__ 
         }
         return w;
     };
+    // (the PER loads of a thread unconditionally and together -- tile index clamped --, then the selects: under `t < T`
+    // every load was a memory round trip of its own)
     uint32_t w[PER];
     uint32_t m = 0;
+    {
+        uint4 q[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) q[k] = reinterpret_cast<const uint4*>(quad_max)[min(tid + k * (int)blockDim.x, T - 1)];
+#pragma unroll
+        for (int k = 0; k < PER; k++) w[k] = max(max(q[k].x, q[k].y), max(q[k].z, q[k].w));
+        if (flag) {
+#pragma unroll
+            for (int k = 0; k < PER; k++) q[k] = reinterpret_cast<const uint4*>(flag)[min(tid + k * (int)blockDim.x, T - 1)];
+#pragma unroll
+            for (int k = 0; k < PER; k++)
+                if ((q[k].x | q[k].y | q[k].z | q[k].w) != 0u) w[k] = 0xffffffffu;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const int t = tid + k * (int)blockDim.x;
-        w[k] = t < T ? weight(t) : 0u;
+        if (tid + k * (int)blockDim.x >= T) w[k] = 0u;
         if (w[k] != 0xffffffffu) m = max(m, w[k]);
     }
     for (int t = tid + PER * (int)blockDim.x; t < T; t += (int)blockDim.x) {

@@ -61,9 +61,14 @@ struct SuperArgs {
     SuperShape sh;
     const ushort4* __restrict__ rect;
     const float* __restrict__ depth;
+    // Every (supertile, slab) counter exists in `copies` copies (power of two, <= 8): workgroup b adds to copy b & (copies - 1),
+    // so a counter takes an eighth of the same-address atomics -- 1000 workgroups x 300 cells queued up on 300 addresses,
+    // and the scatter pass's reservations are RETURNING atomics, each waiting for the ones in front of it.
+    uint32_t* cnt_copy;             // [copies][NS * K] entries per (copy, supertile, slab)         (zero at kernel start)
+    uint32_t* cur_copy;             // [copies][NS * K] next free entry of the copy's part of the list (absolute)
     uint32_t* st_cnt;               // [NS * K] entries per (supertile, slab)
     uint32_t* st_start;             // [NS * K] first entry of every list
-    uint32_t* st_cursor;            // [NS * K]
+    int copies;
     uint64_t* sl_ent;               // entries grouped by (supertile, slab)
     uint32_t* ctrl;
     uint32_t* mail; uint32_t seq;
@@ -89,14 +94,22 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
     ushort4 r4[BIN_ITEMS];
     uint32_t bin[BIN_ITEMS];
     uint32_t mine = 0;
+    // All loads of the thread's items first, unconditionally (index clamped to the last Gaussian), then the selects: a load
+    // under a lane condition ends in a wait for everything outstanding where its branch joins, so `in ? load : 0` per
+    // item made this prologue eight memory round trips in a row instead of one.
+    uint32_t dbits[BIN_ITEMS];
 #pragma unroll
     for (int u = 0; u < BIN_ITEMS; u++) {
-        const int idx = base + u * BIN_THREADS + tid;
-        const bool in = idx < a.P;
-        r4[u] = in ? a.rect[idx] : make_ushort4(0, 0, 0, 0);
+        const int idx = min(base + u * BIN_THREADS + tid, a.P - 1);
+        r4[u] = a.rect[idx];
+        dbits[u] = __float_as_uint(a.depth[idx]);      // (not written for culled Gaussians and not used for them either)
+    }
+#pragma unroll
+    for (int u = 0; u < BIN_ITEMS; u++) {
+        const bool in = base + u * BIN_THREADS + tid < a.P;
+        if (!in) r4[u] = make_ushort4(0, 0, 0, 0);
         const uint32_t tiles = (uint32_t)(r4[u].z - r4[u].x) * (uint32_t)(r4[u].w - r4[u].y);
-        // (the depth is not written for culled Gaussians and not used for them either)
-        bin[u] = (in && tiles) ? gft_depth_bin(__float_as_uint(a.depth[idx]), a.sh.near_bits, a.sh.bin_shift) : 0u;
+        bin[u] = tiles ? gft_depth_bin(dbits[u], a.sh.near_bits, a.sh.bin_shift) : 0u;
         mine += tiles;
     }
     if (PASS == 0) {
@@ -118,7 +131,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         for (int i = tid; i < cells; i += BIN_THREADS) {
             const int cidx = i + rot >= cells ? i + rot - cells : i + rot;
             const uint32_t c = s_cnt[cidx];
-            if (c) atomicAdd(&a.st_cnt[cidx], c);
+            if (c) atomicAdd(&a.cnt_copy[(size_t)(blockIdx.x & (a.copies - 1)) * cells + cidx], c);
         }
         if (tid == 0 && s_sum) atomicAdd(&a.ctrl[GFT_CTRL_RSUM], s_sum);
         // The workgroup that draws the last ticket scans.  Every counter update above is a device-scope atomic, complete
@@ -128,13 +141,34 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         if (tid == 0) s_last = atomicAdd(&a.ctrl[GFT_CTRL_DONE], 1u) == gridDim.x - 1 ? 1u : 0u;
         __syncthreads();
         if (!s_last) return;
-        // last workgroup: exclusive scan of the entry counts -> list starts; frame totals -> ctrl + host mailbox
+        // last workgroup: exclusive scan of the entry counts -> list starts (and, inside a list, the start of every copy's
+        // part); frame totals -> ctrl + host mailbox.  A thread takes PER consecutive cells; all its counter loads
+        // (copies x PER) are issued together: one memory round trip per 16 cells and thread.
         if (tid == 0) s_carry = 0;
         __syncthreads();
-        for (int b0 = 0; b0 < cells; b0 += BIN_THREADS) {
-            const int i = b0 + tid;
-            const uint32_t v = i < cells ? __hip_atomic_load(&a.st_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            uint32_t x = v;
+        const int C = a.copies;
+        constexpr int PER = 4;                               // consecutive cells per thread and trip
+        for (int c0 = 0; c0 < cells; c0 += PER * BIN_THREADS) {
+            const int first = c0 + tid * PER;
+            uint32_t v[8][PER];                              // [copy][cell]: all loads of the trip in flight together
+#pragma unroll
+            for (int cp = 0; cp < 8; cp++)
+#pragma unroll
+                for (int k = 0; k < PER; k++)
+                    v[cp][k] = __hip_atomic_load(&a.cnt_copy[(size_t)min(cp, C - 1) * cells + min(first + k, cells - 1)],
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t tot[PER], mine_sum = 0;
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                tot[k] = 0;
+#pragma unroll
+                for (int cp = 0; cp < 8; cp++) {
+                    if (cp >= C || first + k >= cells) v[cp][k] = 0u;
+                    tot[k] += v[cp][k];
+                }
+                mine_sum += tot[k];
+            }
+            uint32_t x = mine_sum;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t y = __shfl_up(x, d, 64);
@@ -145,9 +179,21 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
             uint32_t woff = 0;
             for (int w = 0; w < wave; w++) woff += s_wt[w];
             const uint32_t carry = s_carry;
-            if (i < cells) {
-                a.st_start[i] = carry + woff + x - v;
-                a.st_cursor[i] = 0;
+            uint32_t run = carry + woff + x - mine_sum;       // first entry of this thread's first cell
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int cell = first + k;
+                if (cell < cells) {
+                    a.st_cnt[cell] = tot[k];
+                    a.st_start[cell] = run;
+                    uint32_t inner = run;
+#pragma unroll
+                    for (int cp = 0; cp < 8; cp++) {
+                        if (cp < C) a.cur_copy[(size_t)cp * cells + cell] = inner;
+                        inner += v[cp][k];
+                    }
+                }
+                run += tot[k];
             }
             __syncthreads();
             if (tid == BIN_THREADS - 1) s_carry = carry + woff + x;
@@ -170,7 +216,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
     // scatter: one chunk per (workgroup, supertile, slab)
     for (int i = tid; i < cells; i += BIN_THREADS) {
         const uint32_t c = s_cnt[i];
-        s_first[i] = c ? a.st_start[i] + atomicAdd(&a.st_cursor[i], c) : 0u;
+        s_first[i] = c ? atomicAdd(&a.cur_copy[(size_t)(blockIdx.x & (a.copies - 1)) * cells + i], c) : 0u;
         s_cnt[i] = 0;
     }
     __syncthreads();
@@ -264,12 +310,14 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
     // MODE 1: keys (gathered depth bits, id) of the hits in front of bin `first_tail` -> LDS, Gaussians marked as needed
     auto scan = [&](const uint64_t* __restrict__ list, uint32_t ln, int mode, uint32_t first_tail) {
         for (uint32_t i0 = 0; i0 < ln; i0 += 4 * GFT_BLOCK) {
+            // (loads first and unconditionally -- index clamped --, selects afterwards: a load under a lane condition is
+            // waited for where its branch joins, which made the four loads two or four round trips in a row)
             uint64_t e4[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t i = i0 + u * GFT_BLOCK + tid;
-                e4[u] = i < ln ? list[i] : 0ull;                     // (an all-zero rectangle covers no tile)
-            }
+            for (int u = 0; u < 4; u++) e4[u] = list[min(i0 + u * GFT_BLOCK + tid, ln - 1u)];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i0 + u * GFT_BLOCK + tid >= ln) e4[u] = 0ull;    // (an all-zero rectangle covers no tile)
             bool hit[4];
             unsigned long long hm[4];
             uint32_t off[4], cnt = 0;
@@ -291,17 +339,18 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
                 continue;
             }
             hb = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb);
-            // the depth gathers of the hits are issued together
+            // the depth gathers of the hits are issued together (a lane without a hit reads Gaussian 0's)
             uint32_t d4[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) d4[u] = hit[u] ? __float_as_uint(a.depth[(uint32_t)e4[u]]) : 0u;
+            for (int u = 0; u < 4; u++) d4[u] = __float_as_uint(a.depth[hit[u] ? (uint32_t)e4[u] : 0u]);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (!hit[u]) continue;
                 const uint32_t id = (uint32_t)e4[u];
                 const uint32_t pos = hb + off[u] + (uint32_t)__popcll(hm[u] & ((1ull << lane) - 1ull));
                 if (pos < TPULL_KEYS) sk[pos] = ((uint64_t)d4[u] << 32) | id;
-                a.need[id] = 1;                                      // its appearance is wanted (k_appearance)
+                // (the head's Gaussians are marked as needed behind the scan, from the keys: a store in this loop was
+                // waited for by the next entry's LDS write -- one HBM write acknowledgement per entry and trip)
             }
         }
     };
@@ -376,6 +425,8 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
     }
     if (tid < 4) a.unit_flag[4 * tile + tid] = 0;        // (behind the scans: a store in front of them holds up the wave's loads)
     __syncthreads();
+    // the Gaussians of the head get an appearance (k_appearance): marked here, where only LDS work and stores follow
+    for (uint32_t i = tid; i < kf; i += GFT_BLOCK) a.need[(uint32_t)sk[i]] = 1;
     clear_slice();
     if (a.dbg == 3) { if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     if (kf == 0u) return;
@@ -501,12 +552,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
                 // TAIL_ITEMS entries per thread and trip: their loads, then the geometry records of the hits, are in flight together
                 // (a trip is two dependent memory round trips)
                 for (uint32_t i0 = 0; i0 < ln; i0 += TAIL_ITEMS * TAIL_THREADS) {
+                    // (every load unconditional, index clamped / Gaussian 0 for a lane without a hit, selects afterwards: a
+                    // load under a lane condition is waited for where its branch joins -- the gathers below were twelve
+                    // memory round trips in a row per trip)
                     uint64_t e4[TAIL_ITEMS];
 #pragma unroll
-                    for (int u = 0; u < TAIL_ITEMS; u++) {
-                        const uint32_t i = i0 + u * TAIL_THREADS + tid;
-                        e4[u] = i < ln ? list[i] : 0ull;
-                    }
+                    for (int u = 0; u < TAIL_ITEMS; u++) e4[u] = list[min(i0 + u * TAIL_THREADS + tid, ln - 1u)];
+#pragma unroll
+                    for (int u = 0; u < TAIL_ITEMS; u++)
+                        if (i0 + u * TAIL_THREADS + tid >= ln) e4[u] = 0ull;
                     bool s4[TAIL_ITEMS];
                     float4 ra[TAIL_ITEMS], rb[TAIL_ITEMS];
                     uint32_t dz[TAIL_ITEMS];                             // depth bits of the hits: asked for with their geometry records
@@ -516,9 +570,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
                         const uint32_t b = entry_bin(e4[u]);
                         s4[u] = entry_hits(e4[u], lx, ly) && b >= lo && b <= hi;
                         const uint32_t id = s4[u] ? (uint32_t)e4[u] : 0u;
-                        ra[u] = s4[u] ? a.pre.g.rec_a[2 * id] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        rb[u] = s4[u] ? a.pre.g.rec_a[2 * id + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        dz[u] = (s4[u] && mode != 2) ? __float_as_uint(a.pre.g.depth[id]) : 0u;
+                        ra[u] = a.pre.g.rec_a[2 * id];
+                        rb[u] = a.pre.g.rec_a[2 * id + 1];
+                        dz[u] = __float_as_uint(a.pre.g.depth[id]);
                     }
 #pragma unroll
                     for (int u = 0; u < TAIL_ITEMS; u++) {
@@ -692,7 +746,11 @@ hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomVi
     a.P = c.P;
     a.sh = gft_super_shape(c);
     a.rect = g.rect; a.depth = g.depth;
-    a.st_cnt = im.super_tab; a.st_start = im.super_tab + GFT_SUPER_CELLS; a.st_cursor = im.super_tab + 2 * GFT_SUPER_CELLS;
+    a.cnt_copy = im.super_tab; a.cur_copy = im.super_tab + GFT_SUPER_CELLS;
+    a.st_cnt = im.super_tab + 2 * GFT_SUPER_CELLS; a.st_start = im.super_tab + 3 * GFT_SUPER_CELLS;
+    static const int env_copies = [] { const char* e = getenv("GFT_SUPER_COPIES"); return e ? atoi(e) : 0; }();
+    a.copies = (env_copies == 1 || env_copies == 2 || env_copies == 4) ? env_copies : 8;
+    while (a.copies > 1 && (size_t)a.copies * a.sh.NS * a.sh.K > (size_t)GFT_SUPER_CELLS) a.copies >>= 1;
     // the entry lists live in the key array (`cap` 8-byte slots: there are at most as many (Gaussian, supertile) pairs as
     // (Gaussian, tile) instances)
     a.sl_ent = pass == 1 ? b.keys : nullptr;
@@ -716,7 +774,7 @@ hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomVi
     PullArgs a;
     a.sh = gft_super_shape(c);
     a.depth = g.depth;
-    a.st_cnt = im.super_tab; a.st_start = im.super_tab + GFT_SUPER_CELLS;
+    a.st_cnt = im.super_tab + 2 * GFT_SUPER_CELLS; a.st_start = im.super_tab + 3 * GFT_SUPER_CELLS;
     a.sl_ent = b.keys;
     a.ranges = im.ranges; a.heads = b.point_list; a.front_len = im.front_len; a.unit_flag = im.unit_flag;
     a.tile_cnt = im.tile_cnt; a.tile_cut = im.tile_cut; a.need = g.need;
@@ -736,7 +794,7 @@ hipError_t gft_launch_tail_build(hipStream_t s, const gft_config& c, const gft_f
     TailArgs a;
     a.pre = gft_pre_fwd_args(c, io, g, im, nullptr, true);
     a.sh = gft_super_shape(c);
-    a.st_cnt = im.super_tab; a.st_start = im.super_tab + GFT_SUPER_CELLS;
+    a.st_cnt = im.super_tab + 2 * GFT_SUPER_CELLS; a.st_start = im.super_tab + 3 * GFT_SUPER_CELLS;
     a.sl_ent = b.keys;
     a.ranges = im.ranges; a.point_list = b.point_list; a.pool_base = (uint32_t)a.sh.T * GFT_HEAD_SLOT;
     a.front_len = im.front_len; a.unit_flag = im.unit_flag; a.tile_cut = im.tile_cut;

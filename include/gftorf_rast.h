@@ -219,8 +219,9 @@ typedef struct gft_layout {
     size_t img_tile_cnt;      /* uint32[T]    instances per tile (tile-pull binning with depth slabs: of the slabs a tile scanned) */
     size_t img_tile_cut;      /* uint32[T]    tile-pull binning: first depth bin behind the sorted head of the tile's list;
                                  0xffffffff: the head is the whole list */
-    size_t img_super_tab;     /* uint32[3][16384] tile-pull binning: per (supertile of S x S tiles, depth slab) entry count, list
-                                 start, scatter cursor */
+    size_t img_super_tab;     /* uint32[4][16384] tile-pull binning: per (counter copy, supertile of S x S tiles, depth slab) entry
+                                 counters and scatter cursors (up to 8 copies spread the same-address atomics), per (supertile,
+                                 slab) entry count and list start */
     size_t img_tile_cursor;   /* uint32[T]    scatter cursors */
     size_t img_tile_order;    /* uint32[T]    tiles by backward weight, heaviest first */
     size_t img_front_len;     /* uint32[T]    length of the sorted head of the tile's id list */
