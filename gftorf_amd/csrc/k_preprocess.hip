@@ -834,16 +834,29 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_preprocess_bwd_rows(PreBwdArgs
     if (tid == 0) s_nstale = 0;
     bool on[4];
     uint32_t mine = 0;
+    // (the previous backward's marks of these four Gaussians, asked for with the loads below; used when cfg.grads_zeroed = 3)
+    uint32_t old = *reinterpret_cast<const uint32_t*>(a.io.dirty_rows + min(i0, (P - 1) & ~3));
+    {
+        // (the eight loads unconditionally and together -- index clamped --, then the tests: `a && load && load` per item
+        // was eight memory round trips in a row at the head of every workgroup)
+        int rad[4];
+        float pix[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        on[k] = i0 + k < P && a.io.radii[i0 + k] > 0 && a.io.pixels[i0 + k] != 0.f;
-        mine += on[k] ? 1u : 0u;
+        for (int k = 0; k < 4; k++) {
+            const int i = min(i0 + k, P - 1);
+            rad[k] = a.io.radii[i];
+            pix[k] = a.io.pixels[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            on[k] = i0 + k < P && rad[k] > 0 && pix[k] != 0.f;
+            mine += on[k] ? 1u : 0u;
+        }
     }
     // cfg.grads_zeroed = 3: the tensors still hold the rows the previous backward wrote (marked in dirty_rows): those of
     // this workgroup's Gaussians that this backward does not rewrite are zeroed here, the marks become this backward's
     const bool rezero = a.c.grads_zeroed == 3;
-    uint32_t old = 0u;
-    if (rezero && i0 < P) old = *reinterpret_cast<const uint32_t*>(a.io.dirty_rows + i0);
+    if (!(rezero && i0 < P)) old = 0u;
     uint32_t x = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
