@@ -70,7 +70,7 @@ void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* 
     L->img_pix_state = o;   o = align_up(o + n * 16);
     L->img_ranges = o;      o = align_up(o + T * 8);
     L->img_tile_max = o;    o = align_up(o + T * 4 * 4);   // one entry per 8x8 quadrant
-    L->img_ctrl = o;        o += GFT_CTRL_WORDS * 4;          // ctrl words, tile counters, tile cuts and the supertile tables are
+    L->img_ctrl = o;        o += (GFT_CTRL_WORDS + GFT_TICKET_WORDS) * 4;   // ctrl words (+ ticket counters), tile counters, tile cuts and the supertile tables are
     L->img_tile_cnt = o;    o += T * 4;                       // contiguous: k_preprocess_fwd clears them in one sweep
     L->img_tile_cut = o;    o += T * 4;
     L->img_super_tab = o;   o = align_up(o + 4 * (size_t)GFT_SUPER_CELLS * 4);

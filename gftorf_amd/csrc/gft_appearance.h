@@ -32,9 +32,9 @@ inline PreFwdArgs gft_pre_fwd_args(const gft_config& c, const gft_forward_io& io
     a.mail = mail;
     a.defer_appearance = defer_appearance ? 1 : 0;
     {
-        // ctrl | tile_cnt[T] | tile_cut[T] | super_tab are contiguous (gft_compute_layout)
+        // ctrl | tickets | tile_cnt[T] | tile_cut[T] | super_tab are contiguous (gft_compute_layout)
         const size_t T = (size_t)((c.W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((c.H + GFT_TILE_Y - 1) / GFT_TILE_Y);
-        a.clear_words = (uint32_t)(GFT_CTRL_WORDS + 2 * T + GFT_SUPER_CELLS);      // (of super_tab only the counters' plane)
+        a.clear_words = (uint32_t)(GFT_CTRL_WORDS + GFT_TICKET_WORDS + 2 * T + GFT_SUPER_CELLS);      // (of super_tab only the counters' plane)
     }
     // reference rasterizer_impl.cu:249-250, forward.cu:752
     a.focal_y = c.H / (2.0f * c.tanfovy);

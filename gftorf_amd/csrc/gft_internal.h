@@ -76,6 +76,11 @@ struct BinView {
 #define GFT_CTRL_RSUM 9      // tile-pull binning: R as summed by the supertile count pass
 #define GFT_CTRL_ORDER_OK 11 // the forward computed the backward's heavy-first tile order
 #define GFT_CTRL_WORDS 16
+// Behind the ctrl words: first-level ticket counters of the count pass.  Its ~1000 workgroups are resident together and all
+// draw a ticket at about the same time; returning atomics on ONE address are served one after the other (~10 ns each):
+// the workgroup that draws the last ticket -- the one that scans -- waited ~10 us for its answer.  Workgroup b draws from
+// counter b % GFT_TICKET_WORDS, the last of every group from the second-level counter ctrl[GFT_CTRL_DONE].
+#define GFT_TICKET_WORDS 32
 #define GFT_SUPER_MAX 1024   // supertiles (groups of S x S tiles) of the tile-pull binning
 #define GFT_SLAB_MAX 16      // depth slabs per supertile list
 #define GFT_SUPER_CELLS (GFT_SUPER_MAX * GFT_SLAB_MAX)

@@ -138,7 +138,15 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         // once vmcnt drains, and the scan reads the counters with device-scope loads: no cache write-back is needed.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) s_last = atomicAdd(&a.ctrl[GFT_CTRL_DONE], 1u) == gridDim.x - 1 ? 1u : 0u;
+        if (tid == 0) {
+            // two-level ticket (GFT_TICKET_WORDS): the last workgroup of a group draws from the second level
+            const uint32_t G = min((uint32_t)GFT_TICKET_WORDS, gridDim.x), grp = blockIdx.x % G;
+            const uint32_t members = (gridDim.x - grp + G - 1u) / G;
+            uint32_t last = 0u;
+            if (atomicAdd(&a.ctrl[GFT_CTRL_WORDS + grp], 1u) == members - 1u)
+                last = atomicAdd(&a.ctrl[GFT_CTRL_DONE], 1u) == G - 1u ? 1u : 0u;
+            s_last = last;
+        }
         __syncthreads();
         if (!s_last) return;
         // last workgroup: exclusive scan of the entry counts -> list starts (and, inside a list, the start of every copy's

@@ -215,7 +215,7 @@ typedef struct gft_layout {
     size_t img_pix_state;     /* float[N][4]  {final_T, n_contrib(bits), w_z, w_z2} */
     size_t img_ranges;        /* uint32[T][2] [first,last) of the tile's list */
     size_t img_tile_max;      /* uint32[T][4] max n_contrib over each 8x8 quadrant of the tile */
-    size_t img_ctrl;          /* uint32[16]   {R, flags, max tile list length, ...}; tile_cnt, tile_cut, super_tab follow directly */
+    size_t img_ctrl;          /* uint32[16]   {R, flags, max tile list length, ...}; 32 ticket counters, then tile_cnt, tile_cut, super_tab follow directly */
     size_t img_tile_cnt;      /* uint32[T]    instances per tile (tile-pull binning with depth slabs: of the slabs a tile scanned) */
     size_t img_tile_cut;      /* uint32[T]    tile-pull binning: first depth bin behind the sorted head of the tile's list;
                                  0xffffffff: the head is the whole list */

@@ -91,7 +91,7 @@ def test_size_queries_and_layout_need_no_gpu(lib):
     # every region is 256-B aligned, except those that directly follow the 64-B ctrl block
     # (the ctrl words, the tile counters, the tile cuts and the supertile tables are contiguous: one clear)
     assert all(o % 256 == 0 for n, o in zip(_lib.LAYOUT_FIELDS, offs) if n not in ("img_tile_cnt", "img_tile_cut", "img_super_tab"))
-    assert L.img_tile_cnt == L.img_ctrl + 64 and L.img_tile_cut == L.img_tile_cnt + 4 * 1200
+    assert L.img_tile_cnt == L.img_ctrl + 64 + 128 and L.img_tile_cut == L.img_tile_cnt + 4 * 1200      # ctrl words + ticket counters
     assert L.img_super_tab == L.img_tile_cut + 4 * 1200
     assert L.geom_rec_b >= 32 * 1000 and L.bin_point_list >= 8 * 5000 and L.bin_total >= 12 * 5000 + 1200 * 2048 * 4
     assert lib.gft_binning_bytes(0, 640, 480) >= 0
