@@ -43,6 +43,8 @@ namespace {
 #define HEAD_DIRECT 2048u           // lists (scanned hits) up to this length are sorted whole: a sparse frame (the reference's
                                     // 100 k Gaussians at 320x240: ~1450 instances per tile, low opacities) saturates nowhere, every
                                     // quadrant of a tile with a tail would flag and every list be completed in a second pass
+#define PULL_GROUP_MAX 31u          // largest depth bin of a head whose keys are still ordered by looking through their bin (5-bit count)
+#define PULL_WINDOW 2048u           // depth bins, from the tile's first occupied one, that have a cursor
 #define HEAD_TARGET 940u            // wanted length of the sorted head of a longer list
 #define TAIL_LDS_KEYS 4096u         // culled tails are sorted in LDS in runs of at most this many keys (whole depth bins)
 #define TAIL_ITEMS 4                  // entries per thread and scan trip (8: no faster, 196 registers)
@@ -292,8 +294,12 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
     __shared__ uint64_t sk[SORT_SLOTS(TPULL_KEYS)];
     static_assert(sizeof(uint64_t) * SORT_SLOTS(TPULL_KEYS) >= sizeof(uint32_t) * GFT_DEPTH_BINS, "histogram fits the key buffer");
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(sk);
-    __shared__ uint32_t s_n, s_cut, s_kf;
+    __shared__ uint32_t s_n, s_cut, s_kf, s_gmax, s_gmax2, s_bmin, s_bmax;
     __shared__ uint32_t s_wt[GFT_BLOCK / 64];
+    // 16-bit cursors, one per depth bin of a window of PULL_WINDOW bins from the tile's first occupied one (two per word):
+    // place of the bin's next key in the head (11 bits) | keys in the bin (5 bits).  Pass B places the keys grouped by
+    // bin: the order of the bins IS the order of the sort, what is left is the order inside a bin.
+    __shared__ uint32_t s_cur[PULL_WINDOW / 2];
     if (a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
     // Fire-and-forget zero fill of the backward's accumulator (64 B per Gaussian).  Issued where only LDS work and stores
     // follow (in front of the sort): loads and stores count down one in-order counter, so a load behind these stores
@@ -314,8 +320,11 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
     if (tid == 0) s_n = 0;
     __syncthreads();
 
+    uint32_t win_base = 0;                               // first depth bin with a cursor (set behind pass A)
+    uint32_t cshift = 0;                                 // a cursor serves 1 << cshift depth bins (a whole list may span more bins than there are cursors)
     // pass over one entry list of the supertile.  MODE 0: count the tile's hits and histogram them over the depth bins;
-    // MODE 1: keys (gathered depth bits, id) of the hits in front of bin `first_tail` -> LDS, Gaussians marked as needed
+    // MODE 1: keys (gathered depth bits, id) of the hits in front of bin `first_tail` -> LDS in the order they come;
+    // MODE 2: the same keys, each to the next free place of its depth bin (s_cur)
     auto scan = [&](const uint64_t* __restrict__ list, uint32_t ln, int mode, uint32_t first_tail) {
         for (uint32_t i0 = 0; i0 < ln; i0 += 4 * GFT_BLOCK) {
             // (loads first and unconditionally -- index clamped --, selects afterwards: a load under a lane condition is
@@ -337,6 +346,21 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
                 cnt += (uint32_t)__popcll(hm[u]);
             }
             if (cnt == 0u) continue;                                 // wave-uniform
+            if (mode == 2) {
+                // grouped placement: a key goes to the next free place of its depth bin
+                uint32_t d4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) d4[u] = __float_as_uint(a.depth[hit[u] ? (uint32_t)e4[u] : 0u]);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (!hit[u]) continue;
+                    const uint32_t b = (entry_bin(e4[u]) - win_base) >> cshift;
+                    const uint32_t w = atomicAdd(&s_cur[b >> 1], (b & 1u) ? 0x10000u : 1u);
+                    const uint32_t pos = ((b & 1u) ? (w >> 16) : w) & 0x7ffu;
+                    if (pos < TPULL_KEYS) sk[pos] = ((uint64_t)d4[u] << 32) | (uint32_t)e4[u];
+                }
+                continue;
+            }
             // one LDS atomic per wave reserves the slots of all four entries
             uint32_t hb = 0;
             if (lane == 0) hb = atomicAdd(&s_n, cnt);
@@ -381,8 +405,8 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
     // still sorts as one 1024-key unit; a bin that overshoots is left out unless the head would otherwise be shorter than
     // 512 and the bin fits the 2048-key sorter.  first_tail = first bin outside the head.
     uint32_t first_tail = (uint32_t)(kstop + 1) << a.sh.kshift, kf = n;
-    if (n > HEAD_DIRECT) {
-        uint32_t h[16], sum = 0;
+    uint32_t h[16], sum = 0, run0;
+    {
 #pragma unroll
         for (int k = 0; k < 16; k++) { h[k] = s_hist[16 * tid + k]; sum += h[k]; }
         uint32_t x = sum;
@@ -392,24 +416,84 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
             if (lane >= d) x += y;
         }
         if (lane == 63) s_wt[wave] = x;
+        if (tid == 0) { s_gmax = 0; s_gmax2 = 0; s_bmin = GFT_DEPTH_BINS; s_bmax = 0; }
         __syncthreads();
         for (int w = 0; w < wave; w++) x += s_wt[w];
-        uint32_t run = x - sum;
-        if (run < HEAD_TARGET && x >= HEAD_TARGET) {                 // exactly one thread: the crossing lies in its 16 bins
+        run0 = x - sum;                                              // hits in the bins in front of this thread's sixteen
+        if (n > HEAD_DIRECT) {
+            uint32_t run = run0;
+            if (run < HEAD_TARGET && x >= HEAD_TARGET) {             // exactly one thread: the crossing lies in its 16 bins
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t before = run;
-                run += h[k];
-                if (before < HEAD_TARGET && run >= HEAD_TARGET) {
-                    const bool take = run <= 1024u || (before < 512u && run <= TPULL_KEYS);
-                    s_cut = (uint32_t)(16 * tid + k) + (take ? 1u : 0u);
-                    s_kf = take ? run : before;
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t before = run;
+                    run += h[k];
+                    if (before < HEAD_TARGET && run >= HEAD_TARGET) {
+                        const bool take = run <= 1024u || (before < 512u && run <= TPULL_KEYS);
+                        s_cut = (uint32_t)(16 * tid + k) + (take ? 1u : 0u);
+                        s_kf = take ? run : before;
+                    }
                 }
             }
+            __syncthreads();
+            first_tail = s_cut;
+            kf = s_kf;
         }
-        __syncthreads();
-        first_tail = s_cut;
-        kf = s_kf;
+    }
+    // Placement of the head's keys: the bins' start places (running count of the histogram) become cursors; the largest
+    // bin inside the head and the span of its bins decide whether the order inside the bins is found by looking through a
+    // key's bin (the usual case: a head of ~940 keys spreads over hundreds of bins) or the keys are sorted as a whole.
+    {
+        uint32_t gm = 0, gm2 = 0, first = GFT_DEPTH_BINS, last1 = 0;     // gm2: largest pair of bins; last1 = last occupied bin + 1
+#pragma unroll
+        for (int k = 15; k >= 0; k--) {
+            const uint32_t b = (uint32_t)(16 * tid + k);
+            if (b < first_tail) gm = max(gm, h[k]);
+            if (!(k & 1) && b < first_tail) gm2 = max(gm2, h[k] + h[k + 1]);
+            if (h[k]) { first = b; last1 = max(last1, b + 1u); }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            gm = max(gm, (uint32_t)__shfl_xor((int)gm, d, 64));
+            gm2 = max(gm2, (uint32_t)__shfl_xor((int)gm2, d, 64));
+            first = min(first, (uint32_t)__shfl_xor((int)first, d, 64));
+            last1 = max(last1, (uint32_t)__shfl_xor((int)last1, d, 64));
+        }
+        if (lane == 0) {
+            if (gm) atomicMax(&s_gmax, gm);
+            if (gm2) atomicMax(&s_gmax2, gm2);
+            atomicMin(&s_bmin, first);
+            atomicMax(&s_bmax, last1);
+        }
+    }
+    __syncthreads();
+    win_base = s_bmin & ~15u;                                        // (a thread's sixteen bins lie inside or outside the window together)
+    // (the head's bins end at first_tail or, a whole list, at its last occupied bin; the bins are at most twice the cursors)
+    cshift = min(first_tail, s_bmax) > win_base + PULL_WINDOW ? 1u : 0u;
+    const bool grouped = (cshift ? s_gmax2 : s_gmax) <= PULL_GROUP_MAX && kf < 2048u;     // (places of 11 bits)
+    if (grouped && (uint32_t)(16 * tid) >= win_base && (uint32_t)(16 * tid) < win_base + (PULL_WINDOW << cshift)) {
+        uint32_t r = run0;
+        if (cshift == 0u) {
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                const uint32_t b = (uint32_t)(16 * tid + k) - win_base;
+                const uint32_t lo = (r & 0x7ffu) | (min(h[k], 31u) << 11);
+                r += h[k];
+                const uint32_t hi = (r & 0x7ffu) | (min(h[k + 1], 31u) << 11);
+                r += h[k + 1];
+                s_cur[b >> 1] = lo | (hi << 16);                     // (places beyond the head are never used)
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) {
+                const uint32_t c = ((uint32_t)(16 * tid + k) - win_base) >> 1;       // cursor of the bins k, k + 1; the next one of k + 2, k + 3
+                const uint32_t n0 = h[k] + h[k + 1], n1 = h[k + 2] + h[k + 3];
+                const uint32_t lo = (r & 0x7ffu) | (min(n0, 31u) << 11);
+                r += n0;
+                const uint32_t hi = (r & 0x7ffu) | (min(n1, 31u) << 11);
+                r += n1;
+                s_cur[c >> 1] = lo | (hi << 16);
+            }
+        }
     }
     __syncthreads();
     if (a.dbg == 2) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
@@ -420,7 +504,7 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
         for (int k = 0; k <= kstop; k++) {
             if (((uint32_t)k << a.sh.kshift) >= first_tail) break;
             const uint32_t ln = a.st_cnt[q * K + k];
-            if (ln) scan(a.sl_ent + a.st_start[q * K + k], ln, 1, first_tail);
+            if (ln) scan(a.sl_ent + a.st_start[q * K + k], ln, grouped ? 2 : 1, first_tail);
         }
     }
     const bool has_tail = kf < n || more_slabs;
@@ -439,6 +523,22 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
     if (a.dbg == 3) { if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     if (kf == 0u) return;
     uint32_t* ids = a.heads + start;
+    if (grouped) {
+        // the keys stand grouped by depth bin, the bins in ascending order: a key's place = start of its bin's group + the
+        // number of smaller keys in the group (keys are distinct: the id is their low half).  The bin's cursor now holds
+        // the end of its group and its size.
+        for (uint32_t p = tid; p < kf; p += GFT_BLOCK) {
+            const uint64_t key = sk[p];
+            const uint32_t b = (gft_depth_bin((uint32_t)(key >> 32), a.sh.near_bits, a.sh.bin_shift) - win_base) >> cshift;
+            const uint32_t w = s_cur[b >> 1];
+            const uint32_t half = (b & 1u) ? (w >> 16) : (w & 0xffffu);
+            const uint32_t end = half & 0x7ffu, g = half >> 11, lo = end - g;
+            uint32_t below = 0;
+            for (uint32_t qd = 0; qd < g; qd++) below += sk[lo + qd] < key ? 1u : 0u;
+            ids[lo + below] = (uint32_t)key;
+        }
+        return;
+    }
     if (kf <= 1024u) {
         const uint32_t npad = next_pow2(kf < 2u ? 2u : kf);
         for (uint32_t i = tid + kf; i < npad; i += GFT_BLOCK) sk[i] = ~0ull;
