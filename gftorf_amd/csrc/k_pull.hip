@@ -326,12 +326,18 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
     // MODE 1: keys (gathered depth bits, id) of the hits in front of bin `first_tail` -> LDS in the order they come;
     // MODE 2: the same keys, each to the next free place of its depth bin (s_cur)
     auto scan = [&](const uint64_t* __restrict__ list, uint32_t ln, int mode, uint32_t first_tail) {
+        // (loads unconditionally -- index clamped --, selects afterwards: a load under a lane condition is waited for where
+        // its branch joins, which made the four loads two or four round trips in a row; and one trip ahead: a trip is a
+        // memory round trip and a little work)
+        uint64_t nx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) nx[u] = list[min((uint32_t)(u * GFT_BLOCK + tid), ln - 1u)];
         for (uint32_t i0 = 0; i0 < ln; i0 += 4 * GFT_BLOCK) {
-            // (loads first and unconditionally -- index clamped --, selects afterwards: a load under a lane condition is
-            // waited for where its branch joins, which made the four loads two or four round trips in a row)
             uint64_t e4[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) e4[u] = list[min(i0 + u * GFT_BLOCK + tid, ln - 1u)];
+            for (int u = 0; u < 4; u++) e4[u] = nx[u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) nx[u] = list[min(i0 + (uint32_t)((4 + u) * GFT_BLOCK + tid), ln - 1u)];
 #pragma unroll
             for (int u = 0; u < 4; u++)
                 if (i0 + u * GFT_BLOCK + tid >= ln) e4[u] = 0ull;    // (an all-zero rectangle covers no tile)
