@@ -128,6 +128,12 @@ SCENES = {
     "long_lists_flat": dict(P=9000, W=32, H=32, scale_lo=0.05, scale_hi=0.3, w2c=None, z_lo=3.0, z_hi=3.0),   # all depths equal: splitters and order decided by the id half of the keys
     "long_lists_global": dict(P=24000, W=32, H=16, scale_lo=0.05, scale_hi=0.3),    # tile list > 16384: global-memory sort
     "scatter_direct": dict(P=9000, W=64, H=64, scale_lo=0.25, scale_hi=0.6),         # 30 k instances per 4096-Gaussian workgroup: more than the LDS stage takes, keys are written directly
+    # tile-pull binning places a head's keys by depth bin (k_tile_pull): whole lists over a depth range of eight octaves span
+    # more bins than there are cursors (one cursor per two bins) ...
+    "wide_depth_range": dict(P=2500, W=64, H=48, scale_lo=0.02, scale_hi=0.2, z_lo=0.25, z_hi=70.0),
+    # ... and a few hundred Gaussians per tile inside 2 % of one depth crowd single bins (beyond the 5-bit group count: the
+    # keys are sorted as a whole)
+    "crowded_depth_bins": dict(P=4000, W=48, H=32, scale_lo=0.03, scale_hi=0.2, z_lo=3.0, z_hi=3.05),
 }
 
 
@@ -527,6 +533,8 @@ BIN_CASES = {
     "flat_depth": SCENES["long_lists_flat"],                       # every key in one depth bin: empty heads, the lists are built on demand
     "global_tail": SCENES["long_lists_global"],                    # a culled tail larger than the LDS sorter: bin ranges
     "silhouette": dict(P=30000, W=96, H=64, scale_lo=0.005, scale_hi=0.05, spread=0.55),   # cloud edge inside the image: quadrants that never saturate beside dense ones
+    "wide_depth_range": SCENES["wide_depth_range"],                # whole lists over more depth bins than the pull kernel has cursors
+    "crowded_depth_bins": SCENES["crowded_depth_bins"],            # depth bins with more keys than a cursor counts: sorted as a whole
 }
 
 
