@@ -13,7 +13,10 @@
 //                      per (workgroup, supertile, depth slab)                      [8 B per entry, ~0.5 per instance]
 //   k_tile_pull      : one workgroup per tile scans its supertile's entries (L2), histograms its hits over the
 //                      depth bins, takes the nearest ~940 (whole bins) as the HEAD of its list: gathers their
-//                      depths, sorts the (depth bits, id) keys in LDS, writes the ids into the tile's head slot
+//                      depths, places the (depth bits, id) keys in LDS GROUPED BY DEPTH BIN (the histogram's running
+//                      count gives every bin its place: the bins' order is the sort's order) and finds a key's
+//                      place inside its bin by looking through the bin's few keys -- a sorting network only when
+//                      a bin is crowded --, writes the ids into the tile's head slot
 //                      and marks those Gaussians as needed (appearance on demand, k_preprocess.hip; deriving the
 //                      marks in that kernel from the tiles' cuts instead cost it more than the byte stores cost
 //                      here: -6 / +11 us).  The rest of the list is never formed unless somebody walks that far.
@@ -21,8 +24,8 @@
 //                      the silhouette quadrants of a scene, whose pixels never saturate): pulls the rest of the
 //                      list, CULLS it against the unsaturated pixels of the flagged quadrants (their bounding box
 //                      rides in the flag word; most entries of a tile do not reach a given 8x8 quadrant, fewer
-//                      still the band of pixels along a silhouette), gives the survivors their appearance, sorts them and writes head + culled
-//                      tail as one list into the pool; the render kernel's resume pass and the backward walk
+//                      still the band of pixels along a silhouette), gives the survivors their appearance, sorts
+//                      them and writes head + culled tail as one list into the pool; the render kernel's resume pass and the backward walk
 //                      that list.  Non-reaching entries contribute nothing to any pixel of those quadrants, so
 //                      the blend is the same arithmetic sequence as over the reference's full list: images,
 //                      pixel counts and gradients are bit-identical to whole-frame binning (k_binning.hip).
