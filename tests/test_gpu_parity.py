@@ -152,7 +152,8 @@ def test_preprocess_and_binning_bit_exact(name, mode, oracle, gpu):
     np.testing.assert_array_equal(st["tiles"], og["tiles_touched"])
     assert st["R"] == f.num_rendered == int(st["ctrl"][0])
     lens = f.ranges[:, 1] - f.ranges[:, 0]
-    np.testing.assert_array_equal(st["tile_cnt"], lens)          # (small frames: one depth slab, every tile scans its whole list)
+    if os.environ.get("GFT_SLABS", "1") in ("", "0", "1"):
+        np.testing.assert_array_equal(st["tile_cnt"], lens)      # (small frames: one depth slab, every tile scans its whole list)
     if not pull:
         assert int(st["ctrl"][2]) == int(lens.max())
     W, H = scene["cfg"]["W"], scene["cfg"]["H"]
@@ -195,8 +196,9 @@ def test_preprocess_and_binning_bit_exact(name, mode, oracle, gpu):
             r0, r1 = int(st["ranges"][t, 0]), int(st["ranges"][t, 1])
             assert k <= b - a and k <= 2048
             assert (int(st["tile_cut"][t]) == 0xffffffff) == (k == b - a), "tile %d" % t
-            if b - a <= 2048:
-                assert k == b - a
+            one_slab = os.environ.get("GFT_SLABS", "1") in ("", "0", "1")      # (small frames: one depth slab unless forced)
+            if b - a <= 2048 and one_slab:
+                assert k == b - a       # the tile has seen its whole list (with several slabs it stops at the one that covers the head)
             elif k < b - a:
                 # whole bins up to the one where the count reaches 940; a bin that overshoots 1024 is left out unless
                 # the head would be shorter than 512
