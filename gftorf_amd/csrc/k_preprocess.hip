@@ -804,7 +804,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd_common(PreBwdArgs 
 // Gaussians in LDS (in a fixed order: the partial sums of the two offset gradients then group the same way in every run),
 // then every lane has a Gaussian; its rows go straight from the lane to the tensors and are marked dirty.
 #define ROWS_THREADS 256
-#define ROWS_CHUNK 1024
+#define ROWS_SUBS_MAX 4
+#define ROWS_CHUNK_OF(subs) ((subs) * 4 * ROWS_THREADS)      // Gaussians per workgroup: 2048 or, on big scenes, 4096
 // zero rows of Gaussian `id` in every gradient tensor (one wave)
 __device__ __forceinline__ void zero_gradient_rows(const gft_backward_io& io, int M, int M_p, size_t id, int lane)
 {
@@ -821,62 +822,74 @@ __device__ __forceinline__ void zero_gradient_rows(const gft_backward_io& io, in
     if (io.dL_dsh_p) for (int k = lane; k < 2 * M_p; k += 64) io.dL_dsh_p[id * (size_t)(2 * M_p) + k] = 0.f;
 }
 
-template <bool COMMON>
+template <bool COMMON, int ROWS_SUBS>
 __global__ __launch_bounds__(ROWS_THREADS) void k_preprocess_bwd_rows(PreBwdArgs a)
 {
+    // A workgroup takes ROWS_SUBS x 1024 Gaussians in steps of 4 per thread: with 1024 per workgroup a dense frame left it
+    // ~66 blended rows -- one wave of four had work, and the ~1000 workgroups needed two rounds at two waves per SIMD
+    // (measured, 1 M / 5 M Gaussians: 1024 per workgroup 28 / 79 us, 2048: 26 / 51, 4096: 32.5 / 41).
+    constexpr int ROWS_CHUNK = ROWS_CHUNK_OF(ROWS_SUBS);
     __shared__ uint32_t s_ids[ROWS_CHUNK];
     __shared__ uint32_t s_stale[ROWS_CHUNK];
     __shared__ uint32_t s_wt[ROWS_THREADS / 64];
     __shared__ uint32_t s_nstale;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.c.P;
-    const int i0 = blockIdx.x * ROWS_CHUNK + tid * 4;
     if (tid == 0) s_nstale = 0;
-    bool on[4];
-    uint32_t mine = 0;
-    // (the previous backward's marks of these four Gaussians, asked for with the loads below; used when cfg.grads_zeroed = 3)
-    uint32_t old = *reinterpret_cast<const uint32_t*>(a.io.dirty_rows + min(i0, (P - 1) & ~3));
-    {
-        // (the eight loads unconditionally and together -- index clamped --, then the tests: `a && load && load` per item
-        // was eight memory round trips in a row at the head of every workgroup)
-        int rad[4];
-        float pix[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = min(i0 + k, P - 1);
-            rad[k] = a.io.radii[i];
-            pix[k] = a.io.pixels[i];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            on[k] = i0 + k < P && rad[k] > 0 && pix[k] != 0.f;
-            mine += on[k] ? 1u : 0u;
-        }
-    }
     // cfg.grads_zeroed = 3: the tensors still hold the rows the previous backward wrote (marked in dirty_rows): those of
     // this workgroup's Gaussians that this backward does not rewrite are zeroed here, the marks become this backward's
     const bool rezero = a.c.grads_zeroed == 3;
-    if (!(rezero && i0 < P)) old = 0u;
-    uint32_t x = mine;
+    // (all loads of the thread's Gaussians unconditionally and together -- index clamped --, then the tests: `a && load &&
+    // load` per item was a memory round trip each, in a row, at the head of every workgroup)
+    int rad[ROWS_SUBS][4];
+    float pix[ROWS_SUBS][4];
+    uint32_t old[ROWS_SUBS];           // the previous backward's marks of the four Gaussians (used when cfg.grads_zeroed = 3)
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    if (lane == 63) s_wt[wave] = x;
-    __syncthreads();
-    uint32_t pos = x - mine, n = 0;
-    for (int w = 0; w < ROWS_THREADS / 64; w++) {
-        if (w < wave) pos += s_wt[w];
-        n += s_wt[w];
-    }
-    uint32_t now = 0u;
+    for (int g = 0; g < ROWS_SUBS; g++) {
+        const int i0 = blockIdx.x * ROWS_CHUNK + g * (4 * ROWS_THREADS) + tid * 4;
+        old[g] = *reinterpret_cast<const uint32_t*>(a.io.dirty_rows + min(i0, (P - 1) & ~3));
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (on[k]) { s_ids[pos++] = (uint32_t)(i0 + k); now |= 1u << (8 * k); }
-        else if ((old >> (8 * k)) & 0xffu) s_stale[atomicAdd(&s_nstale, 1u)] = (uint32_t)(i0 + k);
+        for (int k = 0; k < 4; k++) {
+            const int i = min(i0 + k, P - 1);
+            rad[g][k] = a.io.radii[i];
+            pix[g][k] = a.io.pixels[i];
+        }
     }
-    if (i0 < P && (now != old || !rezero)) *reinterpret_cast<uint32_t*>(a.io.dirty_rows + i0) = now;
+    uint32_t n = 0;                    // blended Gaussians of the workgroup so far: ids in s_ids, in a fixed order
+#pragma unroll
+    for (int g = 0; g < ROWS_SUBS; g++) {
+        const int i0 = blockIdx.x * ROWS_CHUNK + g * (4 * ROWS_THREADS) + tid * 4;
+        bool on[4];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            on[k] = i0 + k < P && rad[g][k] > 0 && pix[g][k] != 0.f;
+            mine += on[k] ? 1u : 0u;
+        }
+        const uint32_t was = (rezero && i0 < P) ? old[g] : 0u;
+        uint32_t x = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        __syncthreads();               // (the previous step has read s_wt)
+        if (lane == 63) s_wt[wave] = x;
+        __syncthreads();
+        uint32_t pos = n + x - mine, total = 0;
+        for (int w = 0; w < ROWS_THREADS / 64; w++) {
+            if (w < wave) pos += s_wt[w];
+            total += s_wt[w];
+        }
+        n += total;
+        uint32_t now = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (on[k]) { s_ids[pos++] = (uint32_t)(i0 + k); now |= 1u << (8 * k); }
+            else if ((was >> (8 * k)) & 0xffu) s_stale[atomicAdd(&s_nstale, 1u)] = (uint32_t)(i0 + k);
+        }
+        if (i0 < P && (now != was || !rezero)) *reinterpret_cast<uint32_t*>(a.io.dirty_rows + i0) = now;
+    }
     __syncthreads();
     float sum_phase = 0.f, sum_dc = 0.f;
     for (uint32_t r0 = 0; r0 < n; r0 += ROWS_THREADS) {
@@ -1029,10 +1042,14 @@ hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const g
     int partials = blocks;
     if ((c.grads_zeroed == 2 || c.grads_zeroed == 3) && io.pixels && io.dirty_rows && c.want_backward) {
         // rows of blended Gaussians only, compacted onto full waves
-        const int wgs = (c.P + ROWS_CHUNK - 1) / ROWS_CHUNK;
+        const int subs = c.P >= 3000000 ? 4 : 2;
+        const int wgs = (c.P + ROWS_CHUNK_OF(subs) - 1) / ROWS_CHUNK_OF(subs);
         partials = wgs * (ROWS_THREADS / 64);
-        if (common_shape && !c.grads_accumulate) hipLaunchKernelGGL(k_preprocess_bwd_rows<true>, dim3(wgs), dim3(ROWS_THREADS), 0, s, a);
-        else hipLaunchKernelGGL(k_preprocess_bwd_rows<false>, dim3(wgs), dim3(ROWS_THREADS), 0, s, a);
+        const bool fast = common_shape && !c.grads_accumulate;
+        if (fast && subs == 4) hipLaunchKernelGGL((k_preprocess_bwd_rows<true, 4>), dim3(wgs), dim3(ROWS_THREADS), 0, s, a);
+        else if (fast) hipLaunchKernelGGL((k_preprocess_bwd_rows<true, 2>), dim3(wgs), dim3(ROWS_THREADS), 0, s, a);
+        else if (subs == 4) hipLaunchKernelGGL((k_preprocess_bwd_rows<false, 4>), dim3(wgs), dim3(ROWS_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((k_preprocess_bwd_rows<false, 2>), dim3(wgs), dim3(ROWS_THREADS), 0, s, a);
     } else if (common) hipLaunchKernelGGL(k_preprocess_bwd_common, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
     else hipLaunchKernelGGL(k_preprocess_bwd, dim3(blocks), dim3(PRE_BLOCK), lds, s, a);
     // (the two scalar gradients are only reduced when the caller wants them: optimize_phase_offset / optimize_dc_offset)
