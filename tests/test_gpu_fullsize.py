@@ -298,3 +298,48 @@ def test_c3_shaped_view_sequence_vs_oracle(oracle, gpu):
                 Hh.assert_close("%s (iteration %d, %s call)" % (name, it, "ToF" if tof else "colour"), ref, got.cpu().numpy(),
                                 rtol_max=5e-4, atol=1e-6, frac_bad=1e-5)
     assert restarts <= 2          # the buffer guess (decaying maximum of the recent frames + 25 %) rarely misses
+
+
+def test_metric_views_repeat_bit_identically(gpu):
+    """Soak over changing views at the metric size: 8 views of an arc in shuffled order, three rounds, forward + backward
+    each.  Everything that is kept between calls (gradient tensors and their row marks, the accumulator the backward leaves
+    zero, the buffer-size guess) and everything decided per frame (heads, flagged tiles, completed lists) must leave no
+    trace: a view's outputs are bit-identical every time it comes round, its gradient sums equal up to the order of the
+    float atomics."""
+    import random
+    from gftorf_amd import GaussianRasterizationSettings, GaussianRasterizer
+    sc = _scene("metric")
+    cfg, g = sc["cfg"], sc["gaussians"]
+    P, W, H = cfg["P"], cfg["W"], cfg["H"]
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=gpu)
+    bg = t(sc["bg"])
+    rasts = []
+    for v in range(8):
+        a = (v / 7 - 0.5) * 0.30
+        cam = synth.make_camera(W, H, w2c=synth.look_at_w2c(yaw=a, pitch=0.04 * np.sin(3 * a), t=(-3.2 * np.sin(a), 0.0, 3.2 * (1 - np.cos(a)))))
+        rasts.append(GaussianRasterizer(GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, scale_modifier=1.0,
+            viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=cfg["D"], campos=t(cam["campos"]),
+            prefiltered=False, debug=False, near_n=cam["znear"], far_n=cam["zfar"], depth_range=sc["depth_range"],
+            use_view_dependent_phase=sc["use_view_dependent_phase"])))
+    leaf = {k: t(v).requires_grad_(True) for k, v in g.items() if v is not None}
+    m2 = torch.zeros((P, 3), device=gpu, requires_grad=True)
+    ups = [t(sc["grads"][k]) for k in ("color", "phasor", "depth", "acc", "depth_distortion")]
+    ref, rng = {}, random.Random(5)
+    for rd in range(3):
+        for v in rng.sample(range(8), 8):
+            for x in leaf.values():
+                x.grad = None
+            m2.grad = None
+            o = rasts[v](means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf["shs"], shs_p=leaf["shs_p"],
+                         scales=leaf["scales"], rotations=leaf["rotations"], phase_offset=sc["phase_offset"], dc_offset=sc["dc_offset"])
+            torch.autograd.backward([o[0], o[1], o[2], o[4], o[6]], ups)
+            img = torch.cat([o[i].reshape(-1) for i in (0, 1, 2, 4, 6, 8, 9)])
+            gs = torch.stack([leaf[k].grad.double().abs().sum() for k in ("means3D", "opacities", "shs", "shs_p", "scales", "rotations")]
+                             + [m2.grad.double().abs().sum()])
+            if v not in ref:
+                ref[v] = (img.clone(), gs.clone())
+                continue
+            assert torch.equal(img, ref[v][0]), "view %d, round %d: forward outputs differ" % (v, rd)
+            rel = float(((gs - ref[v][1]).abs() / (ref[v][1].abs() + 1e-30)).max())
+            assert rel < 1e-5, (v, rd, rel)
