@@ -312,9 +312,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(PreFwdArgs a)
 // seven on the metric frame): a workgroup first compacts the ids of its 1024 Gaussians into LDS, so that the lanes of
 // its waves have a Gaussian each to evaluate (a lane per Gaussian over all P runs with a sixth of its lanes: 36 us).
 #define APP_THREADS 256
-#define APP_CHUNK 1024        // Gaussians per workgroup: with one in seven wanted, a workgroup's compacted list fills one round of its lanes
+#define APP_CHUNK_OF(words) ((words) * 4 * APP_THREADS)        // Gaussians per workgroup: 1024 -- with one in seven wanted, a workgroup's
+                                                               // compacted list fills one round of its lanes --, 4096 on big scenes (5 M
+                                                               // Gaussians @ 1080p: one in thirty wanted)
+template <int WORDS>      // 4-byte words of flags per thread
 __global__ __launch_bounds__(APP_THREADS) void k_appearance(PreFwdArgs a, uint32_t cap)
 {
+    constexpr int APP_CHUNK = APP_CHUNK_OF(WORDS);
     __shared__ uint32_t s_ids[APP_CHUNK];
     __shared__ uint32_t s_n;
     if (a.ctrl[GFT_CTRL_TOTAL] > cap) return;
@@ -322,16 +326,21 @@ __global__ __launch_bounds__(APP_THREADS) void k_appearance(PreFwdArgs a, uint32
     if (tid == 0) s_n = 0;
     __syncthreads();
     const int base = blockIdx.x * APP_CHUNK;
-    // four flags per thread as one 4-byte load (P is padded by the layout's alignment: reads past P stay inside geom)
+    // 4 * WORDS flags per thread as one load (P is padded by the layout's alignment: reads past P stay inside geom)
     {
-        constexpr int PER = APP_CHUNK / APP_THREADS;
-        static_assert(PER == 4, "one 4-byte load of flags per thread");
+        constexpr int PER = 4 * WORDS;
         const int i0 = base + tid * PER;
-        uint32_t w = 0u;
-        if (i0 < a.c.P) w = *reinterpret_cast<const uint32_t*>(a.g.need + i0);
+        uint32_t w[WORDS];
+        if (WORDS == 4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(a.g.need + min(i0, (a.c.P - 1) & ~15));
+            w[0] = q.x; w[WORDS > 1 ? 1 : 0] = q.y; w[WORDS > 2 ? 2 : 0] = q.z; w[WORDS > 3 ? 3 : 0] = q.w;
+        } else {
+            w[0] = *reinterpret_cast<const uint32_t*>(a.g.need + min(i0, (a.c.P - 1) & ~3));
+        }
+        auto wanted = [&](int k) { return i0 + k < a.c.P && ((w[k >> 2] >> (8 * (k & 3))) & 0xffu); };
         uint32_t mine = 0;
 #pragma unroll
-        for (int k = 0; k < PER; k++) mine += (i0 + k < a.c.P && ((w >> (8 * k)) & 0xffu)) ? 1u : 0u;
+        for (int k = 0; k < PER; k++) mine += wanted(k) ? 1u : 0u;
         // slots of this thread's ids: wave prefix + one LDS atomic per wave
         uint32_t x = mine;
 #pragma unroll
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(APP_THREADS) void k_appearance(PreFwdArgs a, uint32
         uint32_t pos = wb + x - mine;
 #pragma unroll
         for (int k = 0; k < PER; k++)
-            if (i0 + k < a.c.P && ((w >> (8 * k)) & 0xffu)) s_ids[pos++] = (uint32_t)(i0 + k);
+            if (wanted(k)) s_ids[pos++] = (uint32_t)(i0 + k);
     }
     __syncthreads();
     const uint32_t n = s_n;
@@ -989,8 +998,11 @@ hipError_t gft_launch_appearance(hipStream_t s, const gft_config& c, const gft_f
                                  const ImgView& im, uint32_t cap)
 {
     PreFwdArgs a = gft_pre_fwd_args(c, io, g, im, nullptr, true);
-    const int blocks = (c.P + APP_CHUNK - 1) / APP_CHUNK;
-    hipLaunchKernelGGL(k_appearance, dim3(blocks), dim3(APP_THREADS), 0, s, a, cap);
+    if (c.P >= 3000000) {
+        hipLaunchKernelGGL(k_appearance<4>, dim3((c.P + APP_CHUNK_OF(4) - 1) / APP_CHUNK_OF(4)), dim3(APP_THREADS), 0, s, a, cap);
+    } else {
+        hipLaunchKernelGGL(k_appearance<1>, dim3((c.P + APP_CHUNK_OF(1) - 1) / APP_CHUNK_OF(1)), dim3(APP_THREADS), 0, s, a, cap);
+    }
     return hipGetLastError();
 }
 
