@@ -954,8 +954,8 @@ def main_cpu_rehearsal(args, env, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50; 7000 iterations for --workload C3)")
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 100, SURVEY 8(d); 7000 iterations for --workload C3)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="metric", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -967,7 +967,7 @@ def main():
                                                          "GaussianRasterizerPair (opt-in API; default: two calls, as the reference)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 7000 if args.workload == "C3" else 50
+        args.steps = 7000 if args.workload == "C3" else 100
 
     env = dist_env()
     world = max(env["world"], 1)
