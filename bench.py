@@ -546,7 +546,7 @@ def densify_extra(dev, P=1_000_000):
             "prune_frac_of_hbm_peak": prune_bytes / (prune_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
-def train_iteration_extra(dev, scene, steps=10, warmup=3):
+def train_iteration_extra(dev, scene, steps=10, warmup=3, only_fused=False):
     """One iteration of the reference's loop shape (train.py:164-177, 441-449, 470-474) at the metric size: one
     deformation-network query for the dynamic 30 %, one input assembly, the colour-camera and the ToF-camera rasterizer
     call (forward + backward of both), densification statistics, Adam on the Gaussians and on the network.  `hip`: every piece
@@ -636,6 +636,8 @@ def train_iteration_extra(dev, scene, steps=10, warmup=3):
     from gftorf_amd import deform as deform_mod
     hip_ms = timed(build(True), steps, warmup)
     net_rows = dict(deform_mod.last_backward_stats)
+    if only_fused:          # (profiles/train_workload.py: the iteration of this package alone, for rocprofv3)
+        return {"hip_ms": hip_ms, "network_backward_fraction": net_rows["points_processed"] / max(net_rows["points"], 1)}
     torch.cuda.empty_cache()
     deform_mod.sparse_backward = False
     try:
