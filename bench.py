@@ -915,15 +915,23 @@ def spawn_ranks(n):
     failed."""
     import socket
     import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     envc = dict(os.environ)
     envc.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     envc.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=envc).returncode
+    rc = 1
+    for attempt in range(2):
+        # (the port is free when asked and may be taken before the launcher binds it: one retry with another port)
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, env=envc, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(r.stderr)
+        rc = r.returncode
+        if rc == 0 or "Address already in use" not in r.stderr and "EADDRINUSE" not in r.stderr:
+            break
+    return rc
 
 
 def main_cpu_rehearsal(args, env, world):

@@ -429,7 +429,9 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
                   rotations=(P, 4) if has_scales else None)
     zero_buf = None
     entry, reused_grads = None, False
+    pool_entry = None              # the kept set of gradient tensors this backward writes (or, second view of a pair, adds to)
     if share_grads is not None:
+        pool_entry = share_grads.get("pool_entry")
         # second view of a pair (gftorf_amd.pair): its backward adds to the first view's gradient tensors
         # (cfg.grads_accumulate); only the two scalar offset gradients are its own
         g = {k: v for k, v in share_grads["grads"].items() if k != "offsets"}
@@ -447,19 +449,29 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
             # (a buffer somebody wrote to through a tensor -- autograd's in-place sum of two calls' gradients, clipping --
             # is never trusted again: forgotten as soon as nobody references it)
             pool[:] = [e for e in pool if e["buf"]._version == e["version"] or _storage_refs(e["buf"]) != e["base"]]
-            for e in pool:
-                if _storage_refs(e["buf"]) == e["base"] and e["buf"]._version == e["version"]:
+            free = [e for e in pool if _storage_refs(e["buf"]) == e["base"] and e["buf"]._version == e["version"]]
+            # `valid`: the last backward into this buffer returned without error, so every row is defined -- zero or marked
+            # in `dirty`.  A buffer that was handed to a forward whose backward never ran (a render under grad used only
+            # for logging, a loss skipped by a NaN guard) or failed holds rows nobody wrote: it may be taken again, but as
+            # a fresh one that the backward writes in full.
+            for e in free:
+                if e["valid"]:
                     entry, reused_grads = e, True
                     break
+            if entry is None and free:
+                entry = free[0]
             if entry is None:
                 buf = torch.empty((total,), **f32)
-                entry = dict(buf=buf, dirty=torch.zeros(((P + 3) // 4 * 4,), device=dev, dtype=torch.uint8), version=buf._version)
+                entry = dict(buf=buf, dirty=torch.zeros(((P + 3) // 4 * 4,), device=dev, dtype=torch.uint8), version=buf._version,
+                             valid=False)
                 entry["base"] = _storage_refs(buf)
                 pool.append(entry)
                 del pool[:-_GRAD_POOL_DEPTH]
                 if len(_grad_pool) > 8:
                     _grad_pool.pop(next(iter(_grad_pool)))
+            entry["valid"] = False        # until the backward of this forward has returned (run_backward)
             buf = entry["buf"]
+            pool_entry = entry
         else:
             buf = torch.empty((total,), **f32)
         if zero_fill:
@@ -511,7 +523,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         io.dirty_rows = entry["dirty"].data_ptr()
     last_call_stats["grads_reused"] = bool(reused_grads)
     return dict(grads=g, cfg=cfg, io=io, acc=acc, acc_lease=acc_lease, pixels=pixels, zero_buf=zero_buf, dev=dev, P=P, H=H, W=W,
-                dirty=entry["dirty"] if entry is not None else None,
+                dirty=entry["dirty"] if entry is not None else None, pool_entry=pool_entry,
                 debug_args=(s.bg, means3D, radii, scales, rotations, s.scale_modifier, cov3D, s.viewmatrix, s.projmatrix,
                             s.tanfovx, s.tanfovy, sh, sh_p, s.sh_degree, s.campos, s.debug, s.near_n, s.far_n, s.depth_range,
                             s.use_view_dependent_phase, ph_off, dc_off) if s.debug else None)
@@ -548,14 +560,19 @@ def run_backward(prep, grads_out, geom, binning, img, debug=False):
     lease = prep.get("acc_lease")
     if lease is not None:
         lease.zero = False             # the render backward writes to it; zero again only if the call below returns
+    pool_entry = prep.get("pool_entry")
     try:
         with _lib.on_device(dev):
             stream = _lib.raw_stream(dev)
             _lib.check(lib.gft_backward(stream, C.byref(prep["cfg"]), C.byref(io), cap))
+        if pool_entry is not None and not prep["cfg"].grads_accumulate:
+            pool_entry["valid"] = True     # every row of the kept gradient tensors is defined now (api._grad_pool)
         if lease is not None and prep["cfg"].acc_zeroed == 2:
             lease.zero, lease.stream = True, stream
             lease.give_back()
     except Exception as ex:
+        if pool_entry is not None:
+            pool_entry["valid"] = False
         if debug:
             torch.save(cpu_args, "snapshot_bw.dump")
             print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")

@@ -138,7 +138,9 @@ def _compact_rows(lib, n, saved, gx, gs):
         if g is not None:
             m = g.reshape(n, -1).abs().amax(dim=1)
             row_max = m if row_max is None else torch.maximum(row_max, m)
-    sel = RowSelection(row_max > 0)
+    # (a NaN upstream row compares False to everything: `~(== 0)` keeps it in the set, so a diverged step shows in the
+    # weight gradients as it does with the dense backward and in the reference)
+    sel = RowSelection(~(row_max == 0))
     k = sel.count
     if k > _SPARSE_MAX_FRACTION * n:
         return n, saved, gx, gs

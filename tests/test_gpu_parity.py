@@ -829,6 +829,32 @@ def test_gradient_tensors_are_reused_only_when_nobody_holds_or_modified_them(ora
     check_grads(bb, grads, b)
     pool = api._grad_pool[next(iter(api._grad_pool))]
     assert edited[0] not in [e["buf"].data_ptr() for e in pool]     # ... and that buffer is forgotten, not reused
+    del out, grads, t
+    # a forward under grad whose backward never runs (a render for logging, a loss skipped by a NaN guard) takes a set of
+    # tensors that nobody ever writes: the next call may take the same buffer, but must write it in full
+    api._grad_pool.clear()
+    ga = dict(a["gaussians"])
+    leaf = torch.tensor(ga["means3D"], dtype=torch.float32, device=gpu, requires_grad=True)
+    from gftorf_amd import GaussianRasterizer
+    rast = GaussianRasterizer(raster_settings=Hh.gpu_settings(a, gpu))
+    kw = {k: (torch.tensor(v, dtype=torch.float32, device=gpu) if v is not None else None) for k, v in ga.items() if k != "means3D"}
+    outs = rast(means3D=leaf, means2D=torch.zeros((3000, 3), device=gpu), opacities=kw["opacities"], shs=kw.get("shs"),
+                shs_p=kw.get("shs_p"), colors_precomp=kw.get("colors_precomp"), phasors_precomp=kw.get("phasors_precomp"),
+                scales=kw.get("scales"), rotations=kw.get("rotations"), cov3D_precomp=kw.get("cov3D_precomp"),
+                phase_offset=a["phase_offset"], dc_offset=a["dc_offset"])
+    pool = api._grad_pool[next(iter(api._grad_pool))]
+    assert len(pool) == 1 and pool[0]["valid"] is False
+    pool[0]["buf"].fill_(float("nan"))          # what uninitialised memory may hold (through the pool's own alias: the
+    pool[0]["version"] = pool[0]["buf"]._version   # version counter is the test's doing, not a caller's edit)
+    del outs, leaf
+    import gc
+    gc.collect()
+    for sc, bw in ((b, bb), (a, ba)):
+        out, grads, t = Hh.run_gpu(sc, gpu)
+        check_grads(bw, grads, sc)
+        del out, grads, t
+    assert api.last_call_stats["grads_reused"] is True
+    assert len(api._grad_pool[next(iter(api._grad_pool))]) == 1        # the same buffer all along
 
 
 def test_accumulator_is_kept_and_left_zero(oracle, gpu):
