@@ -222,6 +222,16 @@ def cpu_baseline(scene, budget_s=20.0, max_iters=5, forward_only=False, one_core
     import helpers as Hh
     oracle.build()
     oracle.lib()
+    # output / scratch arrays kept between iterations and zero-filled on all cores (as a CPU rasterizer would keep its
+    # buffers; fresh numpy arrays cost single-threaded page-fault and unmap work per iteration)
+    oracle.reuse_buffers(True)
+    try:
+        return _cpu_baseline(oracle, Hh, scene, budget_s, max_iters, forward_only, one_core, one_core_budget_s)
+    finally:
+        oracle.reuse_buffers(False)
+
+
+def _cpu_baseline(oracle, Hh, scene, budget_s, max_iters, forward_only, one_core, one_core_budget_s):
     t_all = []
     t_start = time.perf_counter()
     Hh.run_oracle(oracle, scene, backward=not forward_only)  # warm-up (page faults, thread pool)

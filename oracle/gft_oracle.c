@@ -432,15 +432,39 @@ int gfto_preprocess_fwd(const gfto_config* cfg,
     return trap ? -1 : 0;
 }
 
-/* ---- K2: rasterizer_impl.cu:307 ------------------------------------------ */
+/* ---- K2: rasterizer_impl.cu:307 (cub::DeviceScan::InclusiveSum) -----------
+ * Integer sums: any grouping gives the same bits.  Blocked two-pass scan so
+ * that the CPU baseline uses its cores. */
 uint32_t gfto_scan(int P, const uint32_t* tiles_touched, uint32_t* offsets)
 {
-    uint32_t s = 0;
-    for (int i = 0; i < P; i++) {
-        s += tiles_touched[i];
-        offsets[i] = s;
+    if (P <= 0)
+        return 0;
+    int nb = gfto_num_threads();
+    if (nb > 256) nb = 256;
+    if (P < 65536) nb = 1;
+    uint32_t sums[257];
+    const int chunk = (P + nb - 1) / nb;
+#pragma omp parallel for schedule(static, 1) num_threads(nb)
+    for (int b = 0; b < nb; b++) {
+        const int i0 = b * chunk, i1 = imin_(P, i0 + chunk);
+        uint32_t s = 0;
+        for (int i = i0; i < i1; i++)
+            s += tiles_touched[i];
+        sums[b + 1] = s;
     }
-    return s;
+    sums[0] = 0;
+    for (int b = 0; b < nb; b++)
+        sums[b + 1] += sums[b];
+#pragma omp parallel for schedule(static, 1) num_threads(nb)
+    for (int b = 0; b < nb; b++) {
+        const int i0 = b * chunk, i1 = imin_(P, i0 + chunk);
+        uint32_t s = sums[b];
+        for (int i = i0; i < i1; i++) {
+            s += tiles_touched[i];
+            offsets[i] = s;
+        }
+    }
+    return sums[nb];
 }
 
 /* ---- K3: rasterizer_impl.cu:72-113 --------------------------------------- */
@@ -473,9 +497,12 @@ void gfto_duplicate_with_keys(int P, int W, int H, const float* means2D,
     }
 }
 
-/* ---- K4: cub::DeviceRadixSort::SortPairs semantics (stable LSD) ---------- */
-void gfto_sort_pairs(uint32_t R, const uint64_t* keys_in, const uint32_t* vals_in,
-                     uint64_t* keys_out, uint32_t* vals_out, int end_bit)
+/* ---- K4: cub::DeviceRadixSort::SortPairs semantics (stable LSD) ----------
+ * The plain restatement: one thread, 8-bit digits over the low `end_bit` bits.
+ * Kept as the definition the parallel version below is tested against
+ * (tests/test_oracle_properties.py). */
+void gfto_sort_pairs_serial(uint32_t R, const uint64_t* keys_in, const uint32_t* vals_in,
+                            uint64_t* keys_out, uint32_t* vals_out, int end_bit)
 {
     uint64_t* ka = (uint64_t*)malloc((size_t)R * 8 + 8);
     uint64_t* kb = (uint64_t*)malloc((size_t)R * 8 + 8);
@@ -505,11 +532,127 @@ void gfto_sort_pairs(uint32_t R, const uint64_t* keys_in, const uint32_t* vals_i
     free(ka); free(kb); free(va); free(vb);
 }
 
-/* ---- K5: rasterizer_impl.cu:118-140 + memset :341 ------------------------ */
+/* One bucket of the parallel sort: stable LSD radix over the low 32 key bits
+ * (the depth bits), ping-pong between (k0,v0) = the bucket's place in the
+ * output and thread-local scratch; four passes end in (k0,v0). */
+static void sort_bucket_low32(uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, size_t n)
+{
+    if (n < 2)
+        return;
+    if (n <= 32) { /* stable insertion sort */
+        for (size_t i = 1; i < n; i++) {
+            const uint64_t k = k0[i];
+            const uint32_t v = v0[i], lo = (uint32_t)k;
+            size_t j = i;
+            while (j > 0 && (uint32_t)k0[j - 1] > lo) {
+                k0[j] = k0[j - 1];
+                v0[j] = v0[j - 1];
+                j--;
+            }
+            k0[j] = k;
+            v0[j] = v;
+        }
+        return;
+    }
+    uint64_t* ka = k0; uint32_t* va = v0;
+    uint64_t* kb = k1; uint32_t* vb = v1;
+    for (int shift = 0; shift < 32; shift += 8) {
+        size_t count[257];
+        memset(count, 0, sizeof(count));
+        for (size_t i = 0; i < n; i++)
+            count[((ka[i] >> shift) & 255u) + 1]++;
+        for (int b = 0; b < 256; b++)
+            count[b + 1] += count[b];
+        for (size_t i = 0; i < n; i++) {
+            size_t d = count[(ka[i] >> shift) & 255u]++;
+            kb[d] = ka[i];
+            vb[d] = va[i];
+        }
+        uint64_t* tk = ka; ka = kb; kb = tk;
+        uint32_t* tv = va; va = vb; vb = tv;
+    }
+}
+
+/* The same result on all cores.  A stable sort on the low `end_bit` bits of
+ * keys `tile << 32 | depth bits` (rasterizer_impl.cu:331-339: end_bit = 32 +
+ * getHigherMsb(tiles)) is: group by the `end_bit - 32` tile bits keeping the
+ * input order (per-thread histograms over contiguous input chunks, chunks
+ * placed in order), then a stable sort of every group on the low 32 bits.
+ * The order is unique, so the output equals gfto_sort_pairs_serial's bit for
+ * bit. */
+void gfto_sort_pairs(uint32_t R, const uint64_t* keys_in, const uint32_t* vals_in,
+                     uint64_t* keys_out, uint32_t* vals_out, int end_bit)
+{
+    const int hb = end_bit - 32;
+    if (R < 32768u || hb < 1 || hb > 20) {
+        gfto_sort_pairs_serial(R, keys_in, vals_in, keys_out, vals_out, end_bit);
+        return;
+    }
+    const size_t NB = (size_t)1 << hb;
+    const uint32_t hmask = (uint32_t)(NB - 1);
+    int nt = gfto_num_threads();
+    if (nt > 256) nt = 256;
+    const size_t chunk = ((size_t)R + nt - 1) / nt;
+    uint32_t* hist = (uint32_t*)calloc((size_t)nt * NB, 4);
+    uint32_t* base = (uint32_t*)malloc((NB + 1) * 4);
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+    for (int t = 0; t < nt; t++) {
+        uint32_t* h = hist + (size_t)t * NB;
+        size_t i0 = (size_t)t * chunk, i1 = i0 + chunk < R ? i0 + chunk : R;
+        for (size_t i = i0; i < i1; i++)
+            h[(uint32_t)(keys_in[i] >> 32) & hmask]++;
+    }
+    /* start of (thread, bucket) = start of the bucket + what earlier threads hold of it */
+    size_t maxlen = 0;
+    {
+        uint32_t s = 0;
+        for (size_t b = 0; b < NB; b++) {
+            base[b] = s;
+            uint32_t run = s;
+            for (int t = 0; t < nt; t++) {
+                uint32_t c = hist[(size_t)t * NB + b];
+                hist[(size_t)t * NB + b] = run;
+                run += c;
+            }
+            if (run - s > maxlen) maxlen = run - s;
+            s = run;
+        }
+        base[NB] = s;
+    }
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+    for (int t = 0; t < nt; t++) {
+        uint32_t* h = hist + (size_t)t * NB;
+        size_t i0 = (size_t)t * chunk, i1 = i0 + chunk < R ? i0 + chunk : R;
+        for (size_t i = i0; i < i1; i++) {
+            const uint64_t k = keys_in[i];
+            const uint32_t d = h[(uint32_t)(k >> 32) & hmask]++;
+            keys_out[d] = k;
+            vals_out[d] = vals_in[i];
+        }
+    }
+#pragma omp parallel num_threads(nt)
+    {
+        uint64_t* k1 = (uint64_t*)malloc(maxlen * 8 + 8);
+        uint32_t* v1 = (uint32_t*)malloc(maxlen * 4 + 4);
+#pragma omp for schedule(dynamic, 4)
+        for (size_t b = 0; b < NB; b++)
+            sort_bucket_low32(keys_out + base[b], vals_out + base[b], k1, v1, (size_t)(base[b + 1] - base[b]));
+        free(k1);
+        free(v1);
+    }
+    free(hist);
+    free(base);
+}
+
+/* ---- K5: rasterizer_impl.cu:118-140 + memset :341 ------------------------
+ * One "thread" per sorted instance, as in the reference: every boundary is
+ * written by exactly one index. */
 void gfto_tile_ranges(uint32_t R, const uint64_t* keys, int T, uint32_t* ranges)
 {
     memset(ranges, 0, (size_t)T * 8);
-    for (uint32_t idx = 0; idx < R; idx++) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)R; i++) {
+        const uint32_t idx = (uint32_t)i;
         uint32_t currtile = (uint32_t)(keys[idx] >> 32);
         if (idx == 0)
             ranges[2 * currtile + 0] = 0;
@@ -522,6 +665,18 @@ void gfto_tile_ranges(uint32_t R, const uint64_t* keys, int T, uint32_t* ranges)
         }
         if (idx == R - 1)
             ranges[2 * currtile + 1] = R;
+    }
+}
+
+/* parallel zero fill for the driver's kept output arrays (oracle.py: reuse_buffers) */
+void gfto_zero(void* p, size_t bytes)
+{
+    const size_t step = (size_t)1 << 20;
+    const int64_t n = (int64_t)((bytes + step - 1) / step);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        size_t o = (size_t)i * step;
+        memset((char*)p + o, 0, bytes - o < step ? bytes - o : step);
     }
 }
 
@@ -641,7 +796,18 @@ void gfto_render_bwd(int W, int H, const uint32_t* ranges,
     const int gx = (W + GFTO_BLOCK_X - 1) / GFTO_BLOCK_X;
     const int gy = (H + GFTO_BLOCK_Y - 1) / GFTO_BLOCK_Y;
     const size_t HW = (size_t)H * W;
-    double* dacc = (double*)calloc((size_t)P * GFTO_NUM_ACC, sizeof(double));
+    /* double accumulators, kept between calls and all zero outside this function (the fold below
+     * re-zeroes what it reads): one caller at a time, as everywhere in the oracle */
+    static double* dacc_keep = NULL;
+    static size_t dacc_n = 0;
+    const size_t nacc = (size_t)P * GFTO_NUM_ACC;
+    if (nacc > dacc_n) {
+        free(dacc_keep);
+        dacc_keep = (double*)malloc(nacc * sizeof(double));
+        dacc_n = nacc;
+        gfto_zero(dacc_keep, nacc * sizeof(double));
+    }
+    double* dacc = dacc_keep;
 
     /* backward.cu:708-709 */
     const float ddelx_dx = (float)(0.5 * W);
@@ -810,9 +976,35 @@ void gfto_render_bwd(int W, int H, const uint32_t* ranges,
         }
         free(part);
     }
-    for (size_t i = 0; i < (size_t)P * GFTO_NUM_ACC; i++)
-        acc[i] += (float)dacc[i];
-    free(dacc);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)nacc; i++) {
+        if (dacc[i] != 0.0) {
+            acc[i] += (float)dacc[i];
+            dacc[i] = 0.0;
+        }
+    }
+}
+
+/* The 18 sums per Gaussian as the arrays the reference's backward keeps apart (rasterize_points.cu:222-236):
+ * plain copies, on all cores. */
+void gfto_unpack_acc(int P, const float* acc, float* dL_dmeans2D /*[P,3]*/, float* dL_dconic /*[P,4]*/,
+                     float* dL_dopacity, float* dL_dcolors /*[P,3]*/, float* dL_dphasors /*[P,7]*/,
+                     float* dL_ddist, float* dL_dndc)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        const float* a = acc + (size_t)i * GFTO_NUM_ACC;
+        dL_dmeans2D[3 * (size_t)i + 0] = a[0];
+        dL_dmeans2D[3 * (size_t)i + 1] = a[1];
+        dL_dconic[4 * (size_t)i + 0] = a[2];
+        dL_dconic[4 * (size_t)i + 1] = a[3];
+        dL_dconic[4 * (size_t)i + 3] = a[4];
+        dL_dopacity[i] = a[5];
+        for (int k = 0; k < 3; k++) dL_dcolors[3 * (size_t)i + k] = a[6 + k];
+        for (int k = 0; k < 7; k++) dL_dphasors[7 * (size_t)i + k] = a[9 + k];
+        dL_ddist[i] = a[16];
+        dL_dndc[i] = a[17];
+    }
 }
 
 /* ---- SH backward shared by colour/phasor: backward.cu:20-139,143-260 ------

@@ -58,6 +58,32 @@ def lib():
     return _lib
 
 
+# Kept arrays for timing loops (bench.py's cpu_baseline): with reuse_buffers(True) the big outputs and scratch arrays
+# are allocated once per (name, shape) and zero-filled on all cores for every call -- like the reference, which memsets
+# its outputs on the device -- instead of being page-faulted in and unmapped again by every iteration (single-threaded
+# kernel work that dominated the 128-core timing).  Results of an earlier call are overwritten by the next one: tests
+# leave it off.
+_keep = None
+
+
+def reuse_buffers(on=True):
+    global _keep
+    _keep = {} if on else None
+
+
+def _zeros(tag, shape, dtype):
+    if _keep is None:
+        return np.zeros(shape, dtype)
+    shape = (shape,) if isinstance(shape, int) else tuple(shape)
+    key = (tag, shape, np.dtype(dtype).str)
+    a = _keep.get(key)
+    if a is None:
+        a = _keep[key] = np.empty(shape, dtype)
+    if a.nbytes:
+        lib().gfto_zero(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes))
+    return a
+
+
 def _p(a):
     """numpy array (or None) -> void* ; None == tensor absent (NULL)."""
     if a is None:
@@ -109,14 +135,15 @@ def preprocess_fwd(cfg, means3D, scales, rotations, opacities, shs, shs_p,
                    cov3D_precomp, colors_precomp, phasors_precomp, viewmatrix,
                    projmatrix, campos):
     P = cfg.P
+    z = lambda n, shape, dt: _zeros("g." + n, shape, dt)
     g = dict(
-        radii=np.zeros(P, np.int32), means2D=np.zeros((P, 2), np.float32),
-        depths=np.zeros(P, np.float32), dists_ndc=np.zeros(P, np.float32),
-        cov3D=np.zeros((P, 6), np.float32), conic_opacity=np.zeros((P, 4), np.float32),
-        rgb=np.zeros((P, 3), np.float32), phasor7=np.zeros((P, 7), np.float32),
-        dists=np.zeros(P, np.float32), phase_amp=np.zeros((P, 2), np.float32),
-        clamped=np.zeros((P, 3), np.uint8), clamped_p=np.zeros(P, np.uint8),
-        tiles_touched=np.zeros(P, np.uint32),
+        radii=z("radii", P, np.int32), means2D=z("means2D", (P, 2), np.float32),
+        depths=z("depths", P, np.float32), dists_ndc=z("dists_ndc", P, np.float32),
+        cov3D=z("cov3D", (P, 6), np.float32), conic_opacity=z("conic_opacity", (P, 4), np.float32),
+        rgb=z("rgb", (P, 3), np.float32), phasor7=z("phasor7", (P, 7), np.float32),
+        dists=z("dists", P, np.float32), phase_amp=z("phase_amp", (P, 2), np.float32),
+        clamped=z("clamped", (P, 3), np.uint8), clamped_p=z("clamped_p", P, np.uint8),
+        tiles_touched=z("tiles_touched", P, np.uint32),
     )
     rc = lib().gfto_preprocess_fwd(
         C.byref(cfg), _p(means3D), _p(scales), _p(rotations), _p(opacities),
@@ -138,12 +165,19 @@ def bin_and_sort(W, H, means2D, radii, depths, tiles_touched=None):
     T = gx * gy
     if tiles_touched is None:
         tiles_touched = tiles_from_rect(W, H, means2D, radii)
-    offsets = np.zeros(P, np.uint32)
+    offsets = _zeros("offsets", P, np.uint32)
     R = int(lib().gfto_scan(C.c_int(P), _p(np.ascontiguousarray(tiles_touched, np.uint32)), _p(offsets))) if P else 0
-    keys = np.zeros(max(R, 1), np.uint64)
-    vals = np.zeros(max(R, 1), np.uint32)
-    keys_s = np.zeros(max(R, 1), np.uint64)
-    vals_s = np.zeros(max(R, 1), np.uint32)
+    if _keep is None:
+        keys = np.zeros(max(R, 1), np.uint64)
+        vals = np.zeros(max(R, 1), np.uint32)
+        keys_s = np.zeros(max(R, 1), np.uint64)
+        vals_s = np.zeros(max(R, 1), np.uint32)
+    else:       # (every slot in [0, R) is written by the duplication / the sort: kept arrays need no fill)
+        cap = _keep.get("cap", 0)
+        if max(R, 1) > cap:
+            cap = _keep["cap"] = int(max(R, 1) * 1.25)
+            _keep["kv"] = [np.empty(cap, np.uint64), np.empty(cap, np.uint32), np.empty(cap, np.uint64), np.empty(cap, np.uint32)]
+        keys, vals, keys_s, vals_s = _keep["kv"]
     ranges = np.zeros((T, 2), np.uint32)
     if P:
         lib().gfto_duplicate_with_keys(C.c_int(P), C.c_int(W), C.c_int(H), _p(means2D),
@@ -174,14 +208,15 @@ def tiles_from_rect(W, H, means2D, radii):
 
 def render_fwd(W, H, ranges, point_list, g, bg, P):
     N = W * H
+    z = lambda n, shape, dt: _zeros("img." + n, shape, dt)
     o = dict(
-        final_T=np.zeros(N, np.float32), n_contrib=np.zeros(N, np.uint32),
-        w_z_total=np.zeros(N, np.float32), w_z2_total=np.zeros(N, np.float32),
-        color=np.zeros((3, H, W), np.float32), phasor=np.zeros((7, H, W), np.float32),
-        depth=np.zeros((1, H, W), np.float32), acc=np.zeros((1, H, W), np.float32),
-        depth_distortion=np.zeros((1, H, W), np.float32),
-        distribution=np.zeros((3, H, W), np.float32),
-        pixels=np.zeros((P, 1), np.float32),
+        final_T=z("final_T", N, np.float32), n_contrib=z("n_contrib", N, np.uint32),
+        w_z_total=z("w_z_total", N, np.float32), w_z2_total=z("w_z2_total", N, np.float32),
+        color=z("color", (3, H, W), np.float32), phasor=z("phasor", (7, H, W), np.float32),
+        depth=z("depth", (1, H, W), np.float32), acc=z("acc", (1, H, W), np.float32),
+        depth_distortion=z("depth_distortion", (1, H, W), np.float32),
+        distribution=z("distribution", (3, H, W), np.float32),
+        pixels=z("pixels", (P, 1), np.float32),
     )
     pl = np.ascontiguousarray(point_list, np.uint32)
     if pl.size == 0:
@@ -197,7 +232,7 @@ def render_fwd(W, H, ranges, point_list, g, bg, P):
 
 def render_bwd(W, H, ranges, point_list, P, bg, g, img, dL_dcolor, dL_dphasor,
                dL_ddepth, dL_dacc, dL_ddd):
-    acc = np.zeros((P, 18), np.float32)
+    acc = _zeros("bwd.acc", (P, 18), np.float32)
     pl = np.ascontiguousarray(point_list, np.uint32)
     if pl.size == 0:
         pl = np.zeros(1, np.uint32)
@@ -280,12 +315,13 @@ def backward(fwd, dL_dcolor, dL_dphasor, dL_ddepth, dL_dacc, dL_ddepth_distortio
     cfg, inp = fwd.cfg, fwd.inputs
     P, W, H = fwd.P, fwd.W, fwd.H
     M, M_p = cfg.M, cfg.M_p
+    z = lambda n, shape: _zeros("bwd." + n, shape, np.float32)
     out = dict(
-        dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dmeans2D=np.zeros((P, 3), np.float32),
-        dL_dcolors=np.zeros((P, 3), np.float32), dL_dphasors=np.zeros((P, 7), np.float32),
-        dL_dopacity=np.zeros((P, 1), np.float32), dL_dcov3D=np.zeros((P, 6), np.float32),
-        dL_dsh=np.zeros((P, M, 3), np.float32), dL_dsh_p=np.zeros((P, M_p, 2), np.float32),
-        dL_dscales=np.zeros((P, 3), np.float32), dL_drotations=np.zeros((P, 4), np.float32),
+        dL_dmeans3D=z("means3D", (P, 3)), dL_dmeans2D=z("means2D", (P, 3)),
+        dL_dcolors=z("colors", (P, 3)), dL_dphasors=z("phasors", (P, 7)),
+        dL_dopacity=z("opacity", (P, 1)), dL_dcov3D=z("cov3D", (P, 6)),
+        dL_dsh=z("sh", (P, M, 3)), dL_dsh_p=z("sh_p", (P, M_p, 2)),
+        dL_dscales=z("scales", (P, 3)), dL_drotations=z("rotations", (P, 4)),
         dL_dphase_offset=np.zeros(1, np.float32), dL_ddc_offset=np.zeros(1, np.float32),
     )
     if P == 0:
@@ -296,17 +332,14 @@ def backward(fwd, dL_dcolor, dL_dphasor, dL_ddepth, dL_dacc, dL_ddepth_distortio
                      f(dL_dcolor, 3), f(dL_dphasor, 7), f(dL_ddepth, 1), f(dL_dacc, 1),
                      f(dL_ddepth_distortion, 1))
     out["acc"] = acc
-    out["dL_dmeans2D"][:, 0:2] = acc[:, 0:2]
-    dL_dconic = np.zeros((P, 4), np.float32)
-    dL_dconic[:, 0] = acc[:, 2]
-    dL_dconic[:, 1] = acc[:, 3]
-    dL_dconic[:, 3] = acc[:, 4]
+    # the 18 per-Gaussian sums of the render backward -> the arrays the reference keeps separately
+    # (rasterize_points.cu:222-236; dL_dconic is float4 with .z unused, backward.cu:883-885)
+    dL_dconic = z("conic", (P, 4))
+    dL_ddist = z("ddist", P)
+    dL_dndc = z("dndc", P)
+    lib().gfto_unpack_acc(C.c_int(P), _p(acc), _p(out["dL_dmeans2D"]), _p(dL_dconic), _p(out["dL_dopacity"]),
+                          _p(out["dL_dcolors"]), _p(out["dL_dphasors"]), _p(dL_ddist), _p(dL_dndc))
     out["dL_dconic"] = dL_dconic
-    out["dL_dopacity"][:, 0] = acc[:, 5]
-    out["dL_dcolors"][:] = acc[:, 6:9]
-    out["dL_dphasors"][:] = acc[:, 9:16]
-    dL_ddist = np.ascontiguousarray(acc[:, 16])
-    dL_dndc = np.ascontiguousarray(acc[:, 17])
     cov3D = inp["cov3D_precomp"] if inp["cov3D_precomp"] is not None else g["cov3D"]
     lib().gfto_preprocess_bwd(
         C.byref(cfg), _p(inp["means3D"]), _p(g["radii"]), _p(inp["shs"]), _p(inp["shs_p"]),

@@ -110,3 +110,69 @@ def test_gradients_vanish_for_unused_outputs(oracle):
     only_color = dict(z, color=sc["grads"]["color"])
     f, b = Hh.run_oracle(oracle, dict(sc, grads=only_color))
     assert b["dL_dsh"].any() and not b["dL_dsh_p"].any() and b["dL_dphase_offset"][0] == 0
+
+
+def test_parallel_binning_stages_equal_the_serial_restatement(oracle):
+    """The oracle's scan / sort / tile ranges run on all cores so that the CPU baseline is a fair one; the
+    one-thread LSD radix restatement of cub::DeviceRadixSort::SortPairs (rasterizer_impl.cu:331-339) stays in the
+    library as the definition: same bits on random keys with many ties, on a binned scene and for every thread count."""
+    import ctypes as C
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    threads = oracle.num_threads()
+    try:
+        for nthr in (1, 3, threads):
+            oracle.set_num_threads(nthr)
+            for R, T in ((40_000, 300), (200_000, 1200), (100_000, 8160), (70_000, 2)):
+                bit = oracle.get_higher_msb(T)
+                tiles = rng.integers(0, T, R).astype(np.uint64)
+                depth = rng.integers(0, 50, R).astype(np.uint64) * np.uint64(0x01010101)     # many equal keys
+                depth[::3] = rng.integers(0, 2 ** 32, depth[::3].size).astype(np.uint64)
+                keys = (tiles << np.uint64(32)) | depth
+                vals = rng.permutation(R).astype(np.uint32)
+                out = []
+                for fn in (L.gfto_sort_pairs_serial, L.gfto_sort_pairs):
+                    ks, vs = np.zeros(R, np.uint64), np.zeros(R, np.uint32)
+                    fn(C.c_uint32(R), C.c_void_p(keys.ctypes.data), C.c_void_p(vals.ctypes.data),
+                       C.c_void_p(ks.ctypes.data), C.c_void_p(vs.ctypes.data), C.c_int(32 + bit))
+                    out.append((ks, vs))
+                np.testing.assert_array_equal(out[0][0], out[1][0])
+                np.testing.assert_array_equal(out[0][1], out[1][1])
+                ranges = np.zeros((T, 2), np.uint32)
+                L.gfto_tile_ranges(C.c_uint32(R), C.c_void_p(out[1][0].ctypes.data), C.c_int(T), C.c_void_p(ranges.ctypes.data))
+                st = (out[1][0] >> np.uint64(32)).astype(np.int64)
+                cnt = np.bincount(st, minlength=T)
+                first = np.searchsorted(st, np.arange(T))
+                np.testing.assert_array_equal(ranges[:, 0], np.where(cnt > 0, first, 0))
+                np.testing.assert_array_equal(ranges[:, 1], np.where(cnt > 0, first + cnt, 0))
+            tt = rng.integers(0, 40, 300_001).astype(np.uint32)
+            off = np.zeros_like(tt)
+            L.gfto_scan.restype = C.c_uint32
+            tot = L.gfto_scan(C.c_int(tt.size), C.c_void_p(tt.ctypes.data), C.c_void_p(off.ctypes.data))
+            np.testing.assert_array_equal(off, np.cumsum(tt, dtype=np.uint64).astype(np.uint32))
+            assert tot == int(off[-1])
+    finally:
+        oracle.set_num_threads(threads)
+
+
+def test_kept_buffers_give_the_same_results(oracle):
+    """bench.py times the oracle with its output arrays kept between iterations (oracle.reuse_buffers): same
+    numbers as with fresh arrays, also when the second scene leaves rows untouched that the first one wrote."""
+    a = Hh.small_scene(P=700, W=90, H=70, seed=8)
+    b = Hh.small_scene(P=700, W=90, H=70, seed=9, z_lo=2.0)
+    ref = []
+    for sc in (a, b):
+        f, g = Hh.run_oracle(oracle, sc)
+        ref.append(({k: np.array(f[k]) for k in ("color", "phasor", "depth", "acc", "pixels", "radii", "point_list")},
+                    {k: np.array(v) for k, v in g.items()}))
+    oracle.reuse_buffers(True)
+    try:
+        for it in range(4):
+            f, g = Hh.run_oracle(oracle, (a, b)[it % 2])
+            rf, rg = ref[it % 2]
+            for k, v in rf.items():
+                np.testing.assert_array_equal(v, f[k], err_msg=k)
+            for k, v in rg.items():
+                np.testing.assert_allclose(v, g[k], rtol=1e-6, atol=1e-9, err_msg=k)   # (double sums in thread order)
+    finally:
+        oracle.reuse_buffers(False)
