@@ -44,6 +44,12 @@ WORKLOADS = {
     # with the CPU oracle timed beside it
     "C1": dict(P=10_000, W=256, H=256, D=0, sh_coeffs=1, tof=False, forward_only=True,
                label="10k Gaussians, 256x256, SH deg 0, RGB-only forward"),
+    # BASELINE.json config 4: 8 frames x 1 M Gaussians, one frame per GPU.  A step is the per-rank iteration of the
+    # reference's dynamic branch (train.py:164-178): deformation-network query at the frame's time, input assembly,
+    # rasterizer forward + backward, network backward, ONE all-reduce of the network's gradient bucket (c4_step_fn)
+    "C4": dict(P=1_000_000, W=640, H=480, D=3, sh_coeffs=16, tof=True, composed=True,
+               label="C4: 8 frames x 1M Gaussians (30% dynamic), 640x480, one frame per GPU: deform query(t_g) + input assembly + "
+                     "raster forward+backward + network backward + deform-gradient all-reduce per step"),
     # BASELINE.json config 3: handled by bench_loop.py (the whole optimisation loop, not one rasterizer call)
     "C3": dict(loop=True),
 }
@@ -164,8 +170,8 @@ def build_scene(workload, rank, world):
     from gftorf_amd import synth
     cfg = dict(WORKLOADS[workload])
     frame = frame_of_rank(rank, 0, world)
-    # one frame per rank: same Gaussian population, its own view (small arc) -- the
-    # per-frame deform offsets of the reference's dynamic scenes are out of scope here
+    # one frame per rank: same Gaussian population, its own view (small arc); the per-frame deform offsets of the
+    # reference's dynamic scenes are part of the composed workload (C4: c4_step_fn), not of the raster-only ones
     w2c = synth.look_at_w2c(yaw=0.02 * frame, pitch=-0.01 * frame, t=(0.01 * frame, 0.0, 0.0))
     scene = synth.make_scene(cfg, seed=1234, w2c=w2c)
     scene["label"] = cfg["label"]
@@ -212,6 +218,51 @@ def gpu_step_fn(scene, dev):
         state["radii"] = outs[10]
         state["pixels"] = outs[8]
 
+    return step, state, leaf
+
+
+def c4_step_fn(scene, dev, dist, rank, world):
+    """BASELINE.json config 4 as one composed step per rank (gftorf_amd.frames.FrameStep): rank r renders frame
+    step*world + r of 8 -- its own camera, its own time t_g for the deformation network --, and the step ends with the
+    path's one collective, the all-reduce of the network's gradient bucket.  Same Gaussians and network replica on
+    every rank; no optimizer in the step (the metric is the rasterizer's forward + backward)."""
+    import numpy as np
+    import torch
+    from gftorf_amd import GaussianRasterizationSettings, GaussianRasterizer, reference_network
+    from gftorf_amd.frames import FrameStep
+    cam, cfg, g = scene["cam"], scene["cfg"], scene["gaussians"]
+    P = cfg["P"]
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
+    settings = GaussianRasterizationSettings(
+        image_height=cfg["H"], image_width=cfg["W"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t(scene["bg"]),
+        scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=cfg["D"],
+        campos=t(cam["campos"]), prefiltered=False, debug=False, near_n=cam["znear"], far_n=cam["zfar"],
+        depth_range=scene["depth_range"], use_view_dependent_phase=scene["use_view_dependent_phase"])
+    rast = GaussianRasterizer(settings)
+    rng = np.random.default_rng(21)                         # same dynamic set and same replica on every rank
+    mask = torch.tensor(rng.random(P) < 0.3, device=dev)
+    torch.manual_seed(7)
+    net = reference_network()
+    for name, p in net.named_parameters():
+        torch.nn.init.normal_(p, 0.0, 0.06 if (name.startswith("linear") and name.endswith("weight")) else 1e-3)
+    net = net.to(dev)
+    leaf = dict(xyz=t(g["means3D"]), opacity=t(g["opacities"]).reshape(P, 1), scaling=t(g["scales"]),
+                rotation_raw=t(g["rotations"]), fc=t(g["shs"]), fp=t(g["shs_p"]))
+    for v in leaf.values():
+        v.requires_grad_(True)
+    gr = scene["grads"]
+    upstream = [t(gr[k]) for k in ("color", "phasor", "depth", "acc", "depth_distortion")]
+
+    def render(frame_id, **kw):
+        return rast(phase_offset=scene["phase_offset"], dc_offset=scene["dc_offset"], **kw)
+    fs = FrameStep(net, leaf, mask, render, upstream, dist=dist, num_frames=8)
+    state = {"it": 0, "frame_step": fs}
+
+    def step():
+        fs.zero_grad()
+        outs = fs(frame_of_rank(rank, state["it"], world))
+        state["it"] += 1
+        state["radii"], state["pixels"] = outs[10], outs[8]
     return step, state, leaf
 
 
@@ -1029,7 +1080,26 @@ def main():
     if args.workload == "C3":
         return main_loop(args, env, world, dev, dist)
     scene = build_scene(args.workload, env["rank"], world)
-    step, state, _ = gpu_step_fn(scene, dev)
+    composed = bool(scene["cfg"].get("composed"))
+    if composed:
+        if dist is None:
+            # one rank: the step still ends with its collective -- a single-rank RCCL group (the all-reduce is then a
+            # device-side copy, but librccl is loaded, a communicator exists and its kernel is launched)
+            try:
+                import socket
+                import torch.distributed as dist_mod
+                with socket.socket() as so:
+                    so.bind(("127.0.0.1", 0))
+                    port = so.getsockname()[1]
+                dist_mod.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                            device_id=dev)
+                dist = dist_mod
+            except Exception as e:
+                print("bench.py: single-rank RCCL group unavailable (%s: %s): the step runs without its exchange"
+                      % (type(e).__name__, e), file=sys.stderr)
+        step, state, _ = c4_step_fn(scene, dev, dist, env["rank"], world)
+    else:
+        step, state, _ = gpu_step_fn(scene, dev)
     sync = torch.cuda.synchronize
 
     # Device spin-up before the W warm-up steps: the power management raises the clocks over the first
@@ -1064,7 +1134,13 @@ def main():
     restarts = (api.last_call_stats.get("restarts", 0), api.last_call_stats.get("forwards", 0))
 
     exchange = None
-    if dist is not None and not args.no_extras:
+    if composed:
+        fs = state["frame_step"]
+        exchange = {"in_the_timed_step": True, "collectives_per_step": fs.exchanges / max(state["it"], 1),
+                    "bucket_bytes": fs.exchanged_bytes, "backend": dist.get_backend() if dist is not None else None,
+                    "ranks": dist.get_world_size() if dist is not None else 0,
+                    "dynamic_gaussians": int(fs.x_norm.size(0)), "frames": fs.num_frames}
+    elif dist is not None and not args.no_extras:
         # the deform-network exchange leg runs on every rank (it holds the path's only collective)
         try:
             exchange = deform_exchange(dev, dist, env["rank"], world)
@@ -1138,8 +1214,10 @@ def main():
             "config": {"workload": scene["label"], "P": P, "W": W, "H": H, "sh_degree": cfg["D"],
                        "P_visible": P_vis, "num_rendered": R,
                        "longest_tile_list": int(api.last_call_stats["max_tile_list"]), "frames_per_step": world,
-                       "parallelism": "frame-sharded x%d (no collective in the raster path; the deform-gradient all-reduce is "
-                                      "measured in deform_exchange)" % world},
+                       "parallelism": ("frame-sharded x%d (no collective in the raster path; one all-reduce of the deform-network "
+                                       "gradient bucket per step, inside the timed step: deform_exchange)" % world) if composed else
+                                      ("frame-sharded x%d (no collective in the raster path; the deform-gradient all-reduce is "
+                                       "measured in deform_exchange)" % world)},
             "mpix_per_s": value * N / 1e6,
             "roofline": roofline,
             # whole step: per-unit bytes of SURVEY 8(d) x units processed (P_app, R_bin, R_walk, P_blend, see

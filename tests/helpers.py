@@ -142,3 +142,37 @@ def assert_close(name, ref, got, rtol_max=2e-4, atol=1e-6, frac_bad=0.0, rtol_el
     else:
         assert err.max() <= rtol_max * den + atol, "%s: max err %.3g > %.3g*%.3g+%.3g" % (
             name, err.max(), rtol_max, den, atol)
+
+
+class _OracleRasterize(torch.autograd.Function):
+    """The CPU oracle behind the operator's autograd surface (CPU tensors): forward = oracle.forward, backward =
+    oracle.backward.  Stand-in for the HIP rasterizer where a composed step is rehearsed without a GPU."""
+
+    @staticmethod
+    def forward(ctx, oracle, kw, means3D, means2D, opacities, shs, shs_p, scales, rotations):
+        n = lambda t: t.detach().cpu().numpy()
+        f = oracle.forward(n(means3D), n(opacities), shs=n(shs), shs_p=n(shs_p), scales=n(scales), rotations=n(rotations), **kw)
+        ctx.oracle, ctx.f, ctx.op_shape = oracle, f, opacities.shape
+        t = lambda a: torch.tensor(np.asarray(a))
+        outs = (t(f.color), t(f.phasor), t(f.depth), t(f.normal), t(f.acc), t(f.entropy), t(f.depth_distortion),
+                t(f.amp_distortion), t(f.pixels), t(f.distribution), t(f.radii))
+        ctx.mark_non_differentiable(outs[10])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_color, g_phasor, g_depth, _gn, g_acc, _ge, g_dd, *_rest):
+        f = ctx.f
+        z = lambda g, c: np.zeros((c, f.H, f.W), np.float32) if g is None else g.detach().numpy()
+        b = ctx.oracle.backward(f, z(g_color, 3), z(g_phasor, 7), z(g_depth, 1), z(g_acc, 1), z(g_dd, 1))
+        t = lambda a: torch.tensor(np.asarray(a, np.float32))
+        return (None, None, t(b["dL_dmeans3D"]), t(b["dL_dmeans2D"]), t(b["dL_dopacity"]).reshape(ctx.op_shape), t(b["dL_dsh"]),
+                t(b["dL_dsh_p"]), t(b["dL_dscales"]), t(b["dL_drotations"]))
+
+
+def oracle_rasterizer(oracle, scene, **over):
+    """render(frame_id, means3D=, means2D=, opacities=, shs=, shs_p=, scales=, rotations=) -> 11-tuple, on the CPU oracle."""
+    kw = oracle_kwargs(scene, **over)
+
+    def render(frame_id, means3D, means2D, opacities, shs, shs_p, scales, rotations):
+        return _OracleRasterize.apply(oracle, kw, means3D, means2D, opacities, shs, shs_p, scales, rotations)
+    return render

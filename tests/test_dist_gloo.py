@@ -140,3 +140,103 @@ def test_bare_bench_gpus2_spawns_two_ranks():
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stdout + r2.stderr)
+
+
+def _frame_step_parts(P=500, W=64, H=48):
+    """A small scene and the host-side stand-ins of the composed C4 step: the CPU oracle behind the operator's autograd
+    surface, the eager input assembly, the reference network's eager statements on this package's module (same
+    parameters, names and order)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as Hh
+    from oracle import assemble_ref, deform_ref, oracle
+    from gftorf_amd.deform import DeformNetwork, REFERENCE_ARCH
+    oracle.build()
+
+    class EagerNet(DeformNetwork):
+        def forward(self, x, t):
+            return deform_ref.deform_eager(dict(self.named_parameters()), x, t)
+
+    scene = Hh.small_scene(P=P, W=W, H=H, seed=17)
+    g = scene["gaussians"]
+    torch.manual_seed(3)                                   # replicas start identical
+    net = EagerNet(**REFERENCE_ARCH)
+    for name, p in net.named_parameters():
+        torch.nn.init.normal_(p, 0.0, 0.05 if (name.startswith("linear") and name.endswith("weight")) else 2e-3)
+    t = lambda a: torch.tensor(np.asarray(a, np.float32))
+    leaf = dict(xyz=t(g["means3D"]), opacity=t(g["opacities"]).reshape(P, 1), scaling=t(g["scales"]),
+                rotation_raw=t(g["rotations"]), fc=t(g["shs"]), fp=t(g["shs_p"]))
+    for v in leaf.values():
+        v.requires_grad_(True)
+    mask = torch.tensor(np.random.default_rng(4).random(P) < 0.4)
+    upstream = [t(scene["grads"][k]) for k in Hh.GRAD_KEYS]
+    return scene, net, leaf, mask, upstream, Hh.oracle_rasterizer(oracle, scene), assemble_ref.assemble_eager
+
+
+def _worker_frame_step(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    import bench
+    from gftorf_amd.frames import FrameStep
+    from gftorf_amd.deform import flat_grad_bucket
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene, net, leaf, mask, upstream, render, assemble = _frame_step_parts()
+    calls = []
+
+    def exchange(module, d, average=True):
+        from gftorf_amd.deform import allreduce_gradients
+        calls.append(1)
+        return allreduce_gradients(module, d, average=average)
+    fs = FrameStep(net, leaf, mask, render, upstream, dist=dist, num_frames=8, assemble=assemble, exchange=exchange)
+    local = FrameStep(net, leaf, mask, render, upstream, dist=None, num_frames=8, assemble=assemble)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, eps=1e-15)
+    mine, reduced, frames = None, None, []
+    for it in range(3):
+        frame = bench.frame_of_rank(rank, it, world)
+        frames.append(frame)
+        if it == 0:
+            local.zero_grad()
+            local(frame)                                   # this rank's own gradients, no exchange
+            mine = flat_grad_bucket(net)[0].clone()
+        fs.zero_grad()
+        fs(frame)
+        if it == 0:
+            reduced = flat_grad_bucket(net)[0].clone()
+        opt.step()                                         # identical gradients -> identical replicas
+    weights = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    # (numpy: pickled by value -- a tensor travels as a file descriptor that dies with this process)
+    q.put((rank, frames, len(calls), fs.exchanges, fs.exchanged_bytes, mine.numpy(), reduced.numpy(), weights.numpy(),
+           float(leaf["xyz"].grad.abs().sum()), fs.frame_time(frames[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_composed_frame_step():
+    """BASELINE.json config 4's step (gftorf_amd.frames.FrameStep: deform query at the rank's frame time -> input assembly
+    -> rasterizer forward + backward -> network backward -> gradient all-reduce), rehearsed by two gloo ranks with
+    host-side stand-ins for the kernels (CPU oracle, eager assembly, eager network): exactly one exchange per iteration,
+    the exchanged gradients are the mean of the ranks' own, and the replicas stay bit-identical through optimizer steps."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_frame_step, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, f0, c0, e0, b0, mine0, red0, w0, gx0, t0), (_, f1, c1, e1, b1, mine1, red1, w1, gx1, t1) = res
+    assert f0 == [0, 2, 4] and f1 == [1, 3, 5]                    # frames sharded over the ranks
+    assert t0 == 0.0 and abs(t1 - 1 / 7) < 1e-12                  # each rank queries the network at its own frame's time
+    assert c0 == c1 == e0 == e1 == 3                              # one collective per iteration, no more
+    assert b0 == b1 == (522055 - 5140) * 4
+    import numpy as np
+    assert not np.array_equal(mine0, mine1)                       # different frames -> different local gradients
+    np.testing.assert_allclose(red0, (mine0 + mine1) / 2, rtol=1e-6, atol=1e-12)
+    assert np.array_equal(red0, red1)
+    assert np.array_equal(w0, w1)                                 # replicas end bit-identical
+    assert gx0 > 0 and gx1 > 0 and gx0 != gx1                     # the Gaussians' own gradients stay local (per frame)

@@ -100,6 +100,37 @@ def test_c1_10k_256_deg0_rgb_forward_vs_oracle(oracle, gpu):
         assert not out[k].any()
 
 
+def test_c5_5m_1080p_vs_oracle(oracle, gpu):
+    """BASELINE.json config 5 at its full size against the oracle: 5 M Gaussians @ 1920x1080, SH degree 3, RGB + ToF,
+    forward + backward (74.7 M instances on 8160 tiles; the oracle's binning runs on all host cores).  Two frames: the
+    two-stage flow of a shape's first frame, then the one-call flow with the buffer sized from it.  `radii` bit-exact,
+    images L1 < 1e-5, pixel counts, every gradient in the band of the 1 M test."""
+    from gftorf_amd import api
+    sc = _scene("C5")
+    f, b = Hh.run_oracle(oracle, sc)
+    assert f.num_rendered > 70_000_000
+    api._instance_hint.clear()
+    for frame in range(2):
+        out, grads, _ = Hh.run_gpu(sc, gpu, optimize_offsets=True)
+        st = api.last_call_stats
+        assert st["num_rendered"] == f.num_rendered and not st["restarted"]
+        np.testing.assert_array_equal(out["radii"], f.radii)
+        for k in ["color", "phasor", "depth", "acc", "depth_distortion"]:
+            l1 = float(np.abs(out[k].astype(np.float64) - f[k]).mean())
+            assert l1 < 1e-5 * max(1.0, float(np.abs(f[k]).max())), (k, l1, frame)
+        Hh.assert_close("distribution", f["distribution"], out["distribution"], rtol_max=2e-4, atol=1e-6, frac_bad=1e-3)
+        mism = float((out["pixels"] != f.pixels).mean())
+        assert mism < 2e-3, mism
+        for name, ref, got in [("means3D", b["dL_dmeans3D"], grads["means3D"]), ("means2D", b["dL_dmeans2D"], grads["means2D"]),
+                               ("opacity", b["dL_dopacity"], grads["opacities"]), ("sh", b["dL_dsh"], grads["shs"]),
+                               ("sh_p", b["dL_dsh_p"], grads["shs_p"]), ("scales", b["dL_dscales"], grads["scales"]),
+                               ("rot", b["dL_drotations"], grads["rotations"])]:
+            Hh.assert_close(name, ref, got, rtol_max=5e-4, atol=1e-6, frac_bad=1e-5)
+        Hh.assert_close("phase_offset", b["dL_dphase_offset"], grads["phase_offset"], rtol_max=1e-3, atol=1e-3)
+        Hh.assert_close("dc_offset", b["dL_ddc_offset"], grads["dc_offset"], rtol_max=1e-3, atol=1e-3)
+        del out, grads
+
+
 def test_c5_5m_1080p_with_deform_offsets_tile_pull_vs_whole_frame(gpu):
     """BASELINE.json config 5 as it is named: 5 M Gaussians @ 1920x1080, ToF + dynamic deform -- d_xyz / d_sh of the
     deformation network (the architecture the reference constructs) for the 30 % dynamic Gaussians, composed in by the
