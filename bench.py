@@ -284,6 +284,8 @@ def cpu_baseline(scene, budget_s=20.0, max_iters=5, forward_only=False, one_core
 
 def _cpu_baseline(oracle, Hh, scene, budget_s, max_iters, forward_only, one_core, one_core_budget_s):
     t_all = []
+    default_threads = oracle.num_threads()
+    oracle.set_num_threads(oracle.cpu_budget())        # the CPUs this process may really use (cgroup quota), not the host's count
     t_start = time.perf_counter()
     Hh.run_oracle(oracle, scene, backward=not forward_only)  # warm-up (page faults, thread pool)
     warm = time.perf_counter() - t_start
@@ -297,8 +299,9 @@ def _cpu_baseline(oracle, Hh, scene, budget_s, max_iters, forward_only, one_core
     med = t_all[len(t_all) // 2]
     cores = oracle.num_threads()
     out = dict(value=1.0 / med, unit="it/s", cores=cores, kind="port",
-               sample="%d full %s iterations of the same frame (median %.3f s)" % (
-                   len(t_all), "forward" if forward_only else "forward+backward", med))
+               sample="%d full %s iterations of the same frame (median %.3f s) on %d OpenMP threads = the CPUs this "
+                      "process may use (%d logical CPUs on the host)" % (
+                   len(t_all), "forward" if forward_only else "forward+backward", med, cores, os.cpu_count() or 0))
     if one_core and cores > 1:
         # "with all cores ... and with 1 core".  One thread takes ~15 s per 1 M frame: a single full iteration
         # (a second one while the budget lasts), no warm-up run -- the pages are warm from the runs above
@@ -313,6 +316,7 @@ def _cpu_baseline(oracle, Hh, scene, budget_s, max_iters, forward_only, one_core
             oracle.set_num_threads(cores)
         out["one_core"] = dict(value=1.0 / min(t1), unit="it/s", cores=1, kind="port",
                                sample="%d full iteration(s) of the same frame on one thread (best %.2f s)" % (len(t1), min(t1)))
+    oracle.set_num_threads(default_threads)
     return out
 
 
