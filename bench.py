@@ -36,6 +36,10 @@ WORKLOADS = {
                label="500k Gaussians, 640x480, SH deg 3, RGB+ToF phasor, forward+backward"),
     "C5": dict(P=5_000_000, W=1920, H=1080, D=3, sh_coeffs=16, tof=True,
                label="5M Gaussians, 1920x1080, SH deg 3, RGB+ToF phasor, forward+backward"),
+    # the metric frame in the regime the reference trains in: opacities 0.05-0.1 (arguments/__init__.py:99 starts every
+    # Gaussian at 0.1), so no pixel saturates, every tile list is walked whole and most visible Gaussians are blended
+    "fog": dict(P=1_000_000, W=640, H=480, D=3, sh_coeffs=16, tof=True, opacity_range=(0.05, 0.1),
+                label="fog: 1M Gaussians with opacity 0.05-0.1 (nothing saturates), 640x480, SH deg 3, RGB+ToF phasor, forward+backward"),
     "clustered": dict(P=1_000_000, W=640, H=480, D=3, sh_coeffs=16, tof=True, cluster=0.4,
                       label="1M Gaussians concentrated at the image centre, 640x480 (load-balance check)"),
     "tiny": dict(P=20_000, W=256, H=256, D=3, sh_coeffs=16, tof=True,
@@ -882,6 +886,54 @@ def views_extra(dev, scene, steps=90, warmup=30, views=30):
             "roofline": views_roofline(stage_ms, P, W * H, ((W + 15) // 16) * ((H + 15) // 16), R_sum / n_units, walk_sum / n_units)}
 
 
+def fog_extra(dev, steps=50, warmup=15):
+    """The headline step on the `fog` workload (the metric frame with opacities 0.05-0.1: the regime the reference's own
+    scenes start in, arguments/__init__.py:99): no pixel saturates, every list is walked whole, most visible Gaussians are
+    blended -- what the lazy stages (list heads, appearance on demand, kept gradient tensors) cost or gain there."""
+    import torch
+    from gftorf_amd import _lib, api
+    scene = build_scene("fog", 0, 1)
+    step, state, leaf = gpu_step_fn(scene, dev)
+    sync = lambda: torch.cuda.synchronize(dev)
+    elapsed = timed_steps(step, steps, warmup, sync)
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    for _ in range(steps):
+        step()
+    sync()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    cfg = scene["cfg"]
+    P, W, H = cfg["P"], cfg["W"], cfg["H"]
+    N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    P_vis = int((state["radii"] > 0).sum().item())
+    P_blend = int((state["pixels"] > 0).sum().item())
+    pairs = float(state["pixels"].double().sum().item())
+    R = int(api.last_call_stats["num_rendered"])
+    w = walked_instances(dev, state["radii"])
+    units = {"P_app": w["gaussians_with_appearance"] or P_vis, "R_bin": (w["head_ids"] + w["completed_list_ids"]) if w["tile_pull"] else R,
+             "R_walk": w["per_tile_deepest"], "P_blend": P_blend}
+    if api.last_call_stats.get("grads_reused"):
+        units.update(P_zero=0, P_rezero=P_blend)
+    per_kernel, whole = algorithmic_bytes(P, P_vis, R, N, T, units=units)
+    calls = max(prof["forward_calls"], 1)
+    stage_ms = {k[:-3]: prof[k] / calls for k in prof if k.endswith("_ms")}
+    dom = max(stage_ms, key=lambda k: stage_ms[k])
+    ms = elapsed / steps * 1e3
+    gbs = lambda b, m: b / (m * 1e-3) / 1e9 if m > 0 else 0.0
+    cnt = load_counters(dom, "fog")
+    return {"what": scene["label"], "it_per_s": steps / elapsed, "ms_per_step": ms, "steps": steps,
+            "P_visible": P_vis, "gaussians_blended": P_blend, "blended_share_of_visible": P_blend / max(P_vis, 1),
+            "num_rendered": R, "pair_evaluations": pairs, "flagged_quadrants": w["flagged_quadrants"],
+            "stage_ms": stage_ms, "gpu_ms_sum_of_stages": sum(stage_ms.values()), "units_processed": units,
+            "gradient_tensors_reused": bool(api.last_call_stats.get("grads_reused")),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": gbs(per_kernel[dom], stage_ms[dom]), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs(per_kernel[dom], stage_ms[dom]) / HBM_PEAK_GBS,
+                         "traffic": cnt["hbm_bytes"] if cnt else None,
+                         "algorithmic_bytes_per_launch": per_kernel[dom], "avg_launch_ms": stage_ms[dom]},
+            "path_roofline": {"algorithmic_bytes_per_step": whole, "frac": gbs(whole, ms) / HBM_PEAK_GBS}}
+
+
 def views_roofline(stage_ms, P, N, T, R, R_walk):
     """`roofline` object of the varying-view step: dominant stage by HIP events, SURVEY 8(d) bytes x units processed
     (mean instance count / walked entries over the sampled frames; every visible Gaussian charged as P)."""
@@ -1259,7 +1311,7 @@ def main():
             del state, step
             torch.cuda.empty_cache()
             table = [("train_iteration", lambda: train_iteration_extra(dev, scene)), ("render_pair", lambda: pair_extra(dev, scene)),
-                     ("varying_views", lambda: views_extra(dev, scene)), ("assemble_inputs", lambda: assemble_extra(dev)),
+                     ("varying_views", lambda: views_extra(dev, scene)), ("fog", lambda: fog_extra(dev)), ("assemble_inputs", lambda: assemble_extra(dev)),
                      ("knn", lambda: knn_extra(dev)), ("adam", lambda: adam_extra(dev)), ("deform_network", lambda: deform_extra(dev)),
                      ("densify", lambda: densify_extra(dev))]
             want = None if args.extras == "all" else set(args.extras.split(","))

@@ -61,7 +61,7 @@ def make_camera(W, H, fovx_deg=60.0, znear=0.45, zfar=6.05, w2c=None):
 
 
 def make_gaussians(P, cam, seed, sh_coeffs=16, scale_lo=0.002, scale_hi=0.02,
-                   z_lo=1.0, z_hi=5.5, spread=1.05, cluster=0.0):
+                   z_lo=1.0, z_hi=5.5, spread=1.05, cluster=0.0, opacity_range=None):
     """Gaussians placed in the camera frustum (camera space), mapped to world by
     the inverse of cam['w2c'].  Returns a dict of float32 arrays."""
     rng = np.random.default_rng(seed)
@@ -80,6 +80,12 @@ def make_gaussians(P, cam, seed, sh_coeffs=16, scale_lo=0.002, scale_hi=0.02,
     q = rng.normal(size=(P, 4))
     rotations = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
     opacities = (1.0 / (1.0 + np.exp(-rng.normal(0, 1.5, (P, 1))))).astype(np.float32)
+    if opacity_range is not None:
+        # thin scenes: the reference initialises every opacity to 0.1 (arguments/__init__.py:99,
+        # scene/gaussian_model.py:202) -- nothing saturates, every list is walked whole.  Drawn from a
+        # generator of its own so that every other attribute equals the default scene's.
+        lo, hi = opacity_range
+        opacities = np.random.default_rng(seed + 31337).uniform(lo, hi, (P, 1)).astype(np.float32)
     M = sh_coeffs
     shs = np.zeros((P, M, 3), np.float32)
     shs[:, 0, :] = rng.uniform(-1, 1, (P, 3)) / SH_C0 * 0.5
@@ -112,6 +118,8 @@ CONFIGS = {
     "C2": dict(P=500_000, W=640, H=480, D=3, sh_coeffs=16, tof=True),
     "metric": dict(P=1_000_000, W=640, H=480, D=3, sh_coeffs=16, tof=True),
     "C5": dict(P=5_000_000, W=1920, H=1080, D=3, sh_coeffs=16, tof=True),
+    # the metric frame with the opacities the reference's scenes start from: nothing saturates
+    "fog": dict(P=1_000_000, W=640, H=480, D=3, sh_coeffs=16, tof=True, opacity_range=(0.05, 0.1)),
 }
 
 
@@ -120,7 +128,8 @@ def make_scene(name_or_cfg, seed=1234, w2c=None, P=None):
     if P is not None:
         cfg["P"] = P
     cam = make_camera(cfg["W"], cfg["H"], w2c=w2c)
-    g = make_gaussians(cfg["P"], cam, seed, sh_coeffs=cfg["sh_coeffs"], cluster=cfg.get("cluster", 0.0))
+    g = make_gaussians(cfg["P"], cam, seed, sh_coeffs=cfg["sh_coeffs"], cluster=cfg.get("cluster", 0.0),
+                       opacity_range=cfg.get("opacity_range"))
     if not cfg.get("tof", True):
         g["shs_p"] = None
     return dict(cfg=cfg, cam=cam, gaussians=g, bg=make_background(cfg["W"], cfg["H"], seed),

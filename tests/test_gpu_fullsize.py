@@ -100,6 +100,37 @@ def test_c1_10k_256_deg0_rgb_forward_vs_oracle(oracle, gpu):
         assert not out[k].any()
 
 
+def test_fog_1m_vs_oracle(oracle, gpu):
+    """The metric frame in the regime the reference's scenes start in (opacity 0.05-0.1, arguments/__init__.py:99): no pixel
+    saturates, every tile list (~3000 entries) is walked whole by forward and backward, most visible Gaussians are blended
+    -- lists behind the sorted heads are completed for every tile.  Forward + backward against the oracle at full size."""
+    from gftorf_amd import api
+    sc = _scene("fog")
+    assert float(sc["gaussians"]["opacities"].max()) <= 0.1
+    f, b = Hh.run_oracle(oracle, sc)
+    vis = f.radii > 0
+    assert float((f.pixels[vis] > 0).mean()) > 0.8                 # most visible Gaussians are blended by some pixel
+    assert float(f.img["final_T"].min()) > 1e-4                     # ... and nothing saturates
+    api._instance_hint.clear()
+    for frame in range(2):
+        out, grads, _ = Hh.run_gpu(sc, gpu, optimize_offsets=True)
+        assert api.last_call_stats["num_rendered"] == f.num_rendered
+        np.testing.assert_array_equal(out["radii"], f.radii)
+        for k in ["color", "phasor", "depth", "acc", "depth_distortion"]:
+            l1 = float(np.abs(out[k].astype(np.float64) - f[k]).mean())
+            assert l1 < 1e-5 * max(1.0, float(np.abs(f[k]).max())), (k, l1, frame)
+        Hh.assert_close("distribution", f["distribution"], out["distribution"], rtol_max=2e-4, atol=1e-6, frac_bad=1e-3)
+        mism = float((out["pixels"] != f.pixels).mean())
+        assert mism < 2e-3, mism
+        for name, ref, got in [("means3D", b["dL_dmeans3D"], grads["means3D"]), ("means2D", b["dL_dmeans2D"], grads["means2D"]),
+                               ("opacity", b["dL_dopacity"], grads["opacities"]), ("sh", b["dL_dsh"], grads["shs"]),
+                               ("sh_p", b["dL_dsh_p"], grads["shs_p"]), ("scales", b["dL_dscales"], grads["scales"]),
+                               ("rot", b["dL_drotations"], grads["rotations"])]:
+            Hh.assert_close(name, ref, got, rtol_max=5e-4, atol=1e-6, frac_bad=1e-5)
+        Hh.assert_close("phase_offset", b["dL_dphase_offset"], grads["phase_offset"], rtol_max=1e-3, atol=1e-3)
+        Hh.assert_close("dc_offset", b["dL_ddc_offset"], grads["dc_offset"], rtol_max=1e-3, atol=1e-3)
+
+
 def test_c5_5m_1080p_vs_oracle(oracle, gpu):
     """BASELINE.json config 5 at its full size against the oracle: 5 M Gaussians @ 1920x1080, SH degree 3, RGB + ToF,
     forward + backward (74.7 M instances on 8160 tiles; the oracle's binning runs on all host cores).  Two frames: the
