@@ -116,6 +116,16 @@ inline int gft_bwd_segments(size_t T)
     const size_t n = 65536 / v;
     return n < 1 ? 1 : (n > (size_t)cap ? cap : (int)n);
 }
+// Waves that may share the FORWARD walk of one quadrant (k_render_fwd_seg): as many as keep all quadrants of the frame
+// resident together -- 1024 SIMDs x 6 waves over 4 T quadrants; from 768 tiles on, one wave per quadrant fills the chip
+// and the serial kernel runs.  GFT_FWD_SEG_WAVES overrides for tuning.
+inline int gft_fwd_seg_waves(int T)
+{
+    static const int force = [] { const char* e = getenv("GFT_FWD_SEG_WAVES"); return e ? atoi(e) : 0; }();
+    if (force > 0) return force > 8 ? 8 : force;
+    const int n = 6144 / (4 * (T > 0 ? T : 1));
+    return n < 1 ? 1 : (n > 8 ? 8 : n);
+}
 #define GFT_SNAP_F4 3      // float4 per pixel and snapshot: {T, C0, C1, C2} {PR, PI, PA, Dd} {A, DD_D, DD_D2, -}
 
 void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* L);
@@ -166,7 +176,7 @@ hipError_t gft_launch_tail_build(hipStream_t s, const gft_config& c, const gft_f
 // lazy: 0 = lists sorted whole, 1 = first pass over the sorted heads, 2 = resume pass of the flagged quadrants
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b, bool check_cap, uint32_t cap,
-                                 int lazy, bool pull);
+                                 int lazy, bool pull, bool segmented = false);
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b, bool lazy);
 hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,

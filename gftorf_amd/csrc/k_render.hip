@@ -345,6 +345,325 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Segment-parallel forward: one workgroup of up to FSEG_WAVES waves per 8x8 quadrant, wave s walks list entries
+// [256 s, 256 (s + 1)) (the last one to the end of the head).  For a frame in which nothing saturates early -- the regime
+// the reference trains in: 100 k Gaussians, opacities from 0.1, every list walked whole -- one wave per quadrant is one
+// serial chain of ~1700 entries on 15 % of the chip's wave slots; the blend, however, is a composition of per-entry maps
+// that can be cut anywhere once the transmittance in front of the cut is known:
+//   phase 1  every wave multiplies up the transmittance factor of ITS segment from T = 1 (alpha test only: record,
+//            power, exp, one multiply per reaching entry -- no sums, no counters);
+//   exchange T in front of segment s = product of the factors of segments 0 .. s - 1 (LDS, one barrier); a pixel is
+//            done in front of s exactly when that product is below 1e-4 (the serial walk's test_T is the running
+//            product, and it is monotone);
+//   phase 2  every wave blends its segment with the reference's arithmetic and stop rule from the TRUE transmittance
+//            (forward.cu:536-631: power / alpha skips, test_T < 1e-4 ends the pixel without blending the entry, pixel
+//            counts, first hit, contributor numbers);
+//   combine  sums and deepest contributors add over the segments; T_final is that of the first segment that ended
+//            done; the first-hit triple that of the first segment with a hit; the prefix sums in front of every cut ARE
+//            the blend-state snapshots the backward's segments start from.
+// Differences to the serial walk: the transmittance in front of a cut is (T0 T1 ..) instead of ((((1 a)(1 b)) ..): fp32
+// association, ~1e-7 relative; a pixel whose running product stands within that of 1e-4 at a cut may end one entry
+// earlier or later -- the entry in question is never blended either way (any alpha >= 1/255 takes it below the
+// threshold).  Used for the frames whose previous frame of the same shape walked most of its lists (api.py decides
+// from the forward's late report); bit-identical results from call to call, like the serial kernel.
+#define FSEG_WAVES_MAX 8
+#define FSEG_MIN_LEN 128
+
+template <int FSEG_WAVES>      // waves per workgroup = segments per quadrant at most
+__global__ __launch_bounds__(64 * FSEG_WAVES) void k_render_fwd_seg(RenderFwdArgs a)
+{
+    __shared__ float4 sStage[FSEG_WAVES][RB * 4];        // per wave: rec_a | rec_b of a batch; afterwards the segment's result
+    __shared__ float sT[FSEG_WAVES][64];                 // transmittance factor of every segment, per pixel
+
+    if (a.ctrl && a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
+    const int V = a.T * 4;
+    const int v = unit_of_block(blockIdx.x, V);
+    if (v >= V) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4* sA = &sStage[wave][0];
+    float4* sB = &sStage[wave][RB * 2];
+    const int tile = v >> 2, quad = v & 3;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const int qx0 = tx * GFT_TILE_X + (quad & 1) * 8, qy0 = ty * GFT_TILE_Y + (quad >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < a.W && py < a.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = a.ranges[tile];
+    const int full = (int)(range.y - range.x);
+    const int head = a.front_len ? (int)a.front_len[tile] : full;
+    const bool more = a.tile_cut != nullptr && a.tile_cut[tile] != GFT_NO_TAIL;
+    const int total = head;
+    // Segments of equal length, whole 64-entry batches, at least FSEG_MIN_LEN entries (uniform over the workgroup)
+    const int L = max(FSEG_MIN_LEN, RB * ((total + RB * FSEG_WAVES - 1) / (RB * FSEG_WAVES)));
+    const int S = max(1, (total + L - 1) / L);
+    // (waves without a segment leave at once: a barrier waits for the surviving waves of its workgroup only)
+    if (wave >= S) return;
+    const bool active = true;
+    const int seg_begin = wave * L;
+    const int seg_end = min(total, seg_begin + L);
+    const float zref = full > 0 ? a.rec_a[2 * a.point_list[range.x] + 1].z : 0.0f;
+    const float4 qbox = make_float4((float)qx0, (float)qy0, 7.f, 7.f);
+    // (LDS accesses of one wave are served in the order they were issued: inside a wave's own staging buffer a
+    // scheduling barrier is all that stands between the lanes' writes and the broadcast reads)
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+
+    // ---- phase 1: the segment's transmittance factor ---------------------------------------------------------------
+    float P = 1.0f;                          // transmittance in front of this wave's segment
+    if (S > 1) {
+        float Tl = 1.0f;
+        if (active) {
+            uint32_t id_next = (seg_begin + lane < seg_end) ? a.point_list[range.x + (uint32_t)(seg_begin + lane)] : 0u;
+            for (int base = seg_begin; base < seg_end; base += RB) {
+                const int n = min(RB, seg_end - base);
+                bool reach = false;
+                wave_sync();
+                {
+                    const uint32_t id = id_next;
+                    if (base + RB + lane < seg_end) id_next = a.point_list[range.x + (uint32_t)(base + RB + lane)];
+                    if (lane < n) {
+                        const float4 a0 = a.rec_a[2 * id], a1 = a.rec_a[2 * id + 1];
+                        sA[2 * lane] = a0;
+                        sA[2 * lane + 1] = a1;
+                        reach = gft_splat_reaches_box(a0, a1, qbox.x, qbox.y, qbox.z, qbox.w);
+                    }
+                }
+                uint64_t m = to_sgpr(wave_ballot(reach));
+                wave_sync();
+                // (the next entry's record is read from LDS while the current one is evaluated, as in the blend loops)
+                if (m) {
+                    int j = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    float4 a0 = sA[2 * j], a1 = sA[2 * j + 1];
+                    for (;;) {
+                        const bool more_e = m != 0;
+                        float4 n0 = a0, n1 = a1;
+                        if (more_e) { j = (int)__builtin_ctzll(m); m &= m - 1; n0 = sA[2 * j]; n1 = sA[2 * j + 1]; }
+                        const float dx = a0.x - pxf, dy = a0.y - pyf;
+                        const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+                        const float alpha = fminf(0.99f, a1.y * gft_exp(power));
+                        const bool takes = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                        Tl = takes ? Tl * (1 - alpha) : Tl;
+                        if (!more_e) break;
+                        a0 = n0; a1 = n1;
+                    }
+                }
+            }
+        }
+        sT[wave][lane] = Tl;
+        __syncthreads();
+        for (int k = 0; k < wave; k++) P *= sT[k][lane];
+    }
+
+    // ---- phase 2: the exact blend of the segment from the true transmittance ---------------------------------------
+    const bool alive_start = inside && !(P < 0.0001f);
+    unsigned long long done_m = ~wave_ballot(alive_start);
+    float T = P;
+    uint32_t last_contributor = 0;
+    float C0 = 0, C1 = 0, C2 = 0;
+    float PR = 0, PI = 0, PA = 0;
+    float Dd = 0, A = 0, DD_D = 0, DD_D2 = 0;
+    float WD0 = 0, WD1 = 0, WD2 = 0;
+    uint32_t inner_cuts = 0;                 // bit k: the snapshot of list position 256 k was parked by this wave (uniform)
+    if (active) {
+        asm volatile("" : : "v"(zref), "v"(T));
+        uint32_t id_next = (seg_begin + lane < seg_end) ? a.point_list[range.x + (uint32_t)(seg_begin + lane)] : 0u;
+        for (int base = seg_begin; base < seg_end; base += RB) {
+            if (done_m == ~0ull) break;
+            // a cut of the backward (list position 256 k) INSIDE this segment: the sums blended by this wave so far and the
+            // true transmittance are parked in the cut's snapshot slot; the sums of the segments in front are added below
+            if (a.snaps && base > seg_begin && (base & (GFT_SEG_LEN - 1)) == 0 && base / GFT_SEG_LEN <= a.nsnap) {
+                float4* sp = a.snaps + ((size_t)v * a.nsnap + (base / GFT_SEG_LEN - 1)) * (GFT_SNAP_F4 * 64) + lane;
+                sp[0] = make_float4(T, C0, C1, C2);
+                sp[64] = make_float4(PR, PI, PA, Dd);
+                sp[128] = make_float4(A, DD_D, DD_D2, 0.f);
+                inner_cuts |= 1u << (base / GFT_SEG_LEN);
+            }
+            const int n = min(RB, seg_end - base);
+            bool reach = false;
+            uint32_t my_id = 0;
+            uint32_t cnt = 0;
+            const float4 box = __popcll(~done_m) <= 24 ? box_of_mask(~done_m, qx0, qy0) : qbox;
+            wave_sync();
+            {
+                const uint32_t id = id_next;
+                if (base + RB + lane < seg_end) id_next = a.point_list[range.x + (uint32_t)(base + RB + lane)];
+                if (lane < n) {
+                    my_id = id;
+                    reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, box);
+                }
+            }
+            uint64_t m = to_sgpr(wave_ballot(reach));
+            wave_sync();
+            auto blend = [&](const int j, const float4& a0, const float4& a1, const float4& b0, const float4& b1) {
+                const float dx = a0.x - pxf, dy = a0.y - pyf;
+                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+                const float alpha = fminf(0.99f, a1.y * gft_exp(power));
+                const unsigned long long vm = wave_ballot(!(power > 0.0f)) & wave_ballot(!(alpha < 1.0f / 255.0f)) & ~done_m;
+                if (vm == 0ull) return;
+                const float test_T = T * (1 - alpha);
+                const unsigned long long tm = vm & wave_ballot(test_T < 0.0001f);
+                const unsigned long long cm = vm & ~tm;
+                done_m |= tm;
+                if (cm != 0ull) {
+                    const float al = sel_mask(cm, alpha, 0.f);
+                    const float w = al * T;
+                    const float w_p = w * T;
+                    C0 += b0.x * w; C1 += b0.y * w; C2 += b0.z * w;
+                    PR += b0.w * w_p; PI += b1.x * w_p; PA += b1.y * w_p;
+                    const float dist = a1.w;
+                    Dd += dist * w;
+                    const unsigned long long fm = cm & wave_ballot(last_contributor == 0u);
+                    WD0 = sel_mask(fm, alpha, WD0);
+                    WD1 = sel_mask(fm, dist, WD1);
+                    WD2 = sel_mask(fm, b1.y, WD2);
+                    const float z = a1.z - zref;
+                    const float wz = w * z;
+                    DD_D += wz;
+                    DD_D2 = fmaf(wz, z, DD_D2);
+                    A += w;
+                    T = sel_mask(cm, test_T, T);
+                    last_contributor = sel_mask(cm, (uint32_t)(base + j + 1), last_contributor);
+                    {
+                        const uint32_t pc = (uint32_t)__popcll(cm);
+                        uint32_t m0_keep;
+                        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                                     : "+v"(cnt), "=&s"(m0_keep) : "s"(pc), "s"(j));
+                    }
+                }
+            };
+            if (m) {
+                int j0 = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                float4 p0 = sA[2 * j0], p1 = sA[2 * j0 + 1], q0 = sB[2 * j0], q1 = sB[2 * j0 + 1];
+                for (;;) {
+                    const bool more1 = m != 0;
+                    int j1 = j0;
+                    if (more1) { j1 = (int)__builtin_ctzll(m); m &= m - 1; }
+                    const float4 r0 = sA[2 * j1], r1 = sA[2 * j1 + 1], t0 = sB[2 * j1], t1 = sB[2 * j1 + 1];
+                    blend(j0, p0, p1, q0, q1);
+                    if (!more1 || done_m == ~0ull) break;
+                    const bool more0 = m != 0;
+                    j0 = j1;
+                    if (more0) { j0 = (int)__builtin_ctzll(m); m &= m - 1; }
+                    p0 = sA[2 * j0]; p1 = sA[2 * j0 + 1]; q0 = sB[2 * j0]; q1 = sB[2 * j0 + 1];
+                    blend(j1, r0, r1, t0, t1);
+                    if (!more0 || done_m == ~0ull) break;
+                }
+            }
+            if (cnt) atomicAdd(&a.pixels[my_id], (float)cnt);
+        }
+    }
+
+    // ---- combine ----------------------------------------------------------------------------------------------------
+    if (S > 1) {
+        wave_sync();
+        if (active) {
+            const uint32_t fl = (((done_m >> lane) & 1ull) ? 1u : 0u) | (alive_start ? 2u : 0u);
+            float4* res = &sStage[wave][0];
+            res[lane] = make_float4(T, C0, C1, C2);
+            res[64 + lane] = make_float4(PR, PI, PA, Dd);
+            res[128 + lane] = make_float4(A, DD_D, DD_D2, WD0);
+            res[192 + lane] = make_float4(WD1, WD2, __uint_as_float(last_contributor), __uint_as_float(fl));
+        }
+        __syncthreads();
+        // state in front of segment `upto` (wave 0: behind the last one = the quadrant's result)
+        const int upto = wave == 0 ? S : wave;
+        T = 1.0f; C0 = C1 = C2 = PR = PI = PA = Dd = A = DD_D = DD_D2 = 0.f; WD0 = WD1 = WD2 = 0.f;
+        last_contributor = 0;
+        bool ended = !inside, hit = false;
+        for (int k = 0; k < upto; k++) {
+            const float4 r0 = sStage[k][lane], r1 = sStage[k][64 + lane], r2 = sStage[k][128 + lane], r3 = sStage[k][192 + lane];
+            const uint32_t fl = __float_as_uint(r3.w), lc = __float_as_uint(r3.z);
+            // (a segment that started with the pixel done has blended nothing: zeros, T untouched)
+            C0 += r0.y; C1 += r0.z; C2 += r0.w; PR += r1.x; PI += r1.y; PA += r1.z; Dd += r1.w;
+            A += r2.x; DD_D += r2.y; DD_D2 += r2.z;
+            if (!ended && (fl & 2u)) T = r0.x;
+            if (!hit && lc != 0u) { WD0 = r2.w; WD1 = r3.x; WD2 = r3.y; hit = true; }
+            last_contributor = max(last_contributor, lc);
+            ended = ended || (fl & 1u);
+        }
+        if (wave != 0) {
+            if (a.snaps) {
+                // blend state in front of this wave's segment, if the backward cuts the quadrant's walk there
+                if ((seg_begin & (GFT_SEG_LEN - 1)) == 0 && seg_begin / GFT_SEG_LEN <= a.nsnap) {
+                    float4* sp = a.snaps + ((size_t)v * a.nsnap + (seg_begin / GFT_SEG_LEN - 1)) * (GFT_SNAP_F4 * 64) + lane;
+                    sp[0] = make_float4(T, C0, C1, C2);
+                    sp[64] = make_float4(PR, PI, PA, Dd);
+                    sp[128] = make_float4(A, DD_D, DD_D2, 0.f);
+                }
+                // ... and the cuts inside the segment: the parked sums (this lane's own stores, in front of the barrier
+                // above) + the sums of the segments in front; the transmittance parked there is already the true one
+                while (inner_cuts) {
+                    const int k = __builtin_ctz(inner_cuts);
+                    inner_cuts &= inner_cuts - 1;
+                    float4* sp = a.snaps + ((size_t)v * a.nsnap + (k - 1)) * (GFT_SNAP_F4 * 64) + lane;
+                    float4 s0 = sp[0], s1 = sp[64], s2 = sp[128];
+                    // (a pixel that was done in front of this segment: its transmittance stands where it ended, not at
+                    // the running product this wave started from)
+                    if (!alive_start) s0.x = T;
+                    s0.y += C0; s0.z += C1; s0.w += C2;
+                    s1.x += PR; s1.y += PI; s1.z += PA; s1.w += Dd;
+                    s2.x += A; s2.y += DD_D; s2.z += DD_D2;
+                    sp[0] = s0; sp[64] = s1; sp[128] = s2;
+                }
+            }
+            return;
+        }
+        done_m = wave_ballot(ended);
+    }
+
+    // wave 0 holds the quadrant's result: the rest is the serial kernel's epilogue
+    const size_t pix_i = inside ? (size_t)a.W * py + px : 0;
+    if ((head < full || more) && done_m != ~0ull) {
+        if (inside) {
+            const bool is_done = (done_m >> lane) & 1ull;
+            a.resume_state[4 * pix_i] = make_float4(T, C0, C1, C2);
+            a.resume_state[4 * pix_i + 1] = make_float4(PR, PI, PA, Dd);
+            a.resume_state[4 * pix_i + 2] = make_float4(A, DD_D, DD_D2, WD0);
+            a.resume_state[4 * pix_i + 3] = make_float4(WD1, WD2, __uint_as_float(last_contributor), is_done ? 1.f : 0.f);
+        }
+        if (lane == 0) {
+            a.unit_flag[v] = gft_flag_word(~done_m);
+            atomicAdd(a.nflag, 1u);
+        }
+    }
+    if (inside) {
+        const size_t HW = (size_t)a.H * a.W;
+        const size_t pix = pix_i;
+        a.pix_state[pix] = make_float4(T, __uint_as_float(last_contributor), DD_D, DD_D2);
+        a.pix_sums[2 * pix] = make_float4(C0, C1, C2, PR);
+        a.pix_sums[2 * pix + 1] = make_float4(PI, PA, Dd, A);
+        const float* bgp = a.bg + (int64_t)py * a.bsy + (int64_t)px * a.bsx;
+        const float g0 = bgp[0], g1 = bgp[a.bsc], g2 = bgp[2 * a.bsc], g3 = bgp[3 * a.bsc];
+        const float g4 = bgp[4 * a.bsc], g5 = bgp[5 * a.bsc], g6 = bgp[6 * a.bsc];
+        a.out_color[pix] = C0 + T * g0;
+        a.out_color[HW + pix] = C1 + T * g1;
+        a.out_color[2 * HW + pix] = C2 + T * g2;
+        const float dcA = a.dc_offset * PA;
+        a.out_phasor[pix] = PR + T * g0;
+        a.out_phasor[HW + pix] = PI + T * g1;
+        a.out_phasor[2 * HW + pix] = PA + T * g2;
+        a.out_phasor[3 * HW + pix] = (PR + dcA) + T * g3;
+        a.out_phasor[4 * HW + pix] = (dcA - PR) + T * g4;
+        a.out_phasor[5 * HW + pix] = (PI + dcA) + T * g5;
+        a.out_phasor[6 * HW + pix] = (dcA - PI) + T * g6;
+        a.out_depth[pix] = Dd;
+        a.out_acc[pix] = A;
+        a.out_dd[pix] = fmaf(A, DD_D2, -DD_D * DD_D);
+        a.out_distribution[pix] = WD0;
+        a.out_distribution[HW + pix] = WD1;
+        a.out_distribution[2 * HW + pix] = WD2;
+        a.out_normal[pix] = 0.f; a.out_normal[HW + pix] = 0.f; a.out_normal[2 * HW + pix] = 0.f;
+        a.out_entropy[pix] = 0.f;
+        a.out_ad[pix] = 0.f;
+    }
+    uint32_t mx = last_contributor;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (lane == 0) a.quad_max[v] = mx;
+}
+
+// ---------------------------------------------------------------------------
 struct RenderBwdArgs {
     int W, H, gx, T;
     const uint2* __restrict__ ranges;
@@ -734,7 +1053,8 @@ __global__ __launch_bounds__(1024) void k_acc_reduce_det(int T, const uint2* __r
 }  // namespace
 
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
-                                 const ImgView& im, const BinView& b, bool check_cap, uint32_t cap, int lazy, bool pull)
+                                 const ImgView& im, const BinView& b, bool check_cap, uint32_t cap, int lazy, bool pull,
+                                 bool segmented)
 {
     RenderFwdArgs a;
     a.nsnap = gft_bwd_segments((size_t)((c.W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((c.H + GFT_TILE_Y - 1) / GFT_TILE_Y)) - 1;
@@ -762,7 +1082,22 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     a.resume_state = im.resume_state;
     a.resume = lazy == 2;
     const int blocks = 8 * ((a.T * 4 + 7) / 8);
-    hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(64), 0, s, a);
+    // segmented: up to FSEG_WAVES waves per quadrant (first pass only; the resume pass of flagged quadrants stays one
+    // wave per quadrant).  GFT_FWD_SEG=0 / 1 in the environment forces one of the two kernels for every frame.
+    static const int force = [] { const char* e = getenv("GFT_FWD_SEG"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    const bool seg = (force < 0 ? segmented : force == 1) && !a.resume && gft_fwd_seg_waves(a.T) > 1;
+    if (seg) {
+        switch (gft_fwd_seg_waves(a.T)) {
+        case 2: hipLaunchKernelGGL(k_render_fwd_seg<2>, dim3(blocks), dim3(64 * 2), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(k_render_fwd_seg<3>, dim3(blocks), dim3(64 * 3), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(k_render_fwd_seg<4>, dim3(blocks), dim3(64 * 4), 0, s, a); break;
+        case 5: hipLaunchKernelGGL(k_render_fwd_seg<5>, dim3(blocks), dim3(64 * 5), 0, s, a); break;
+        case 6: hipLaunchKernelGGL(k_render_fwd_seg<6>, dim3(blocks), dim3(64 * 6), 0, s, a); break;
+        case 7: hipLaunchKernelGGL(k_render_fwd_seg<7>, dim3(blocks), dim3(64 * 7), 0, s, a); break;
+        default: hipLaunchKernelGGL(k_render_fwd_seg<8>, dim3(blocks), dim3(64 * 8), 0, s, a); break;
+        }
+    }
+    else hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
