@@ -129,7 +129,7 @@ class AdamTensor(C.Structure):
 
 EXPORTS = [
     "gft_abi_version", "gft_lazy_sort", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes", "gft_acc_bytes",
-    "gft_det_partials_bytes", "gft_get_layout", "gft_binning_capacity", "gft_set_binning_mode", "gft_binning_mode", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_backward", "gft_grads_rezero",
+    "gft_det_partials_bytes", "gft_get_layout", "gft_binning_capacity", "gft_set_binning_mode", "gft_binning_mode", "gft_set_render_mode", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_backward", "gft_grads_rezero",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
     "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi", "gft_adam_step_rows",
@@ -168,6 +168,8 @@ def load():
     lib.gft_binning_capacity.argtypes = [C.c_size_t, C.c_int32, C.c_int32]
     lib.gft_set_binning_mode.restype = C.c_int
     lib.gft_set_binning_mode.argtypes = [C.c_int]
+    lib.gft_set_render_mode.restype = C.c_int
+    lib.gft_set_render_mode.argtypes = [C.c_int]
     lib.gft_binning_mode.restype = C.c_int
     lib.gft_binning_mode.argtypes = [C.POINTER(Config)]
     lib.gft_get_layout.restype = C.c_int

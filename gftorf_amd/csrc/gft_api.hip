@@ -422,6 +422,25 @@ static bool pull_enabled(const gft_config* cfg)
 }
 extern "C" int gft_binning_mode(const gft_config* cfg) { return (cfg && pull_enabled(cfg)) ? 1 : 0; }
 
+// Forward blend kernel: -1 = default (segment-parallel on frames that leave the chip under-filled), 0 = one wave per
+// quadrant always, 1 = segments wherever more than one wave per quadrant fits; GFT_FWD_SEG in the environment.
+static std::atomic<int> g_render_mode{-2};
+extern "C" int gft_set_render_mode(int mode)
+{
+    g_render_mode.store(mode < 0 ? -2 : (mode ? 1 : 0));       // (< 0: back to the environment's choice)
+    return 0;
+}
+int gft_render_mode()
+{
+    int m = g_render_mode.load();
+    if (m == -2) {
+        const char* e = getenv("GFT_FWD_SEG");
+        m = e ? (atoi(e) != 0 ? 1 : 0) : -1;
+        g_render_mode.store(m);
+    }
+    return m;
+}
+
 // preprocess + instance counting; the totals arrive in the mailbox slot
 static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
                           const ImgView& im, uint32_t* mail_dev, uint32_t seq, bool pull)

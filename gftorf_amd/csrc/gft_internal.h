@@ -126,6 +126,7 @@ inline int gft_fwd_seg_waves(int T)
     const int n = 6144 / (4 * (T > 0 ? T : 1));
     return n < 1 ? 1 : (n > 8 ? 8 : n);
 }
+int gft_render_mode();      // -1: default (segments on under-filled frames), 0: one wave per quadrant, 1: segments (gft_set_render_mode / GFT_FWD_SEG)
 #define GFT_SNAP_F4 3      // float4 per pixel and snapshot: {T, C0, C1, C2} {PR, PI, PA, Dd} {A, DD_D, DD_D2, -}
 
 void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* L);
@@ -176,7 +177,7 @@ hipError_t gft_launch_tail_build(hipStream_t s, const gft_config& c, const gft_f
 // lazy: 0 = lists sorted whole, 1 = first pass over the sorted heads, 2 = resume pass of the flagged quadrants
 hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b, bool check_cap, uint32_t cap,
-                                 int lazy, bool pull, bool segmented = false);
+                                 int lazy, bool pull, bool segmented = true);
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
                                  const GeomView& g, const ImgView& im, const BinView& b, bool lazy);
 hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,

@@ -1084,7 +1084,7 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     const int blocks = 8 * ((a.T * 4 + 7) / 8);
     // segmented: up to FSEG_WAVES waves per quadrant (first pass only; the resume pass of flagged quadrants stays one
     // wave per quadrant).  GFT_FWD_SEG=0 / 1 in the environment forces one of the two kernels for every frame.
-    static const int force = [] { const char* e = getenv("GFT_FWD_SEG"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    const int force = gft_render_mode();
     const bool seg = (force < 0 ? segmented : force == 1) && !a.resume && gft_fwd_seg_waves(a.T) > 1;
     if (seg) {
         switch (gft_fwd_seg_waves(a.T)) {

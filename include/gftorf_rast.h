@@ -265,6 +265,13 @@ int64_t gft_binning_capacity(size_t bytes, int32_t W, int32_t H);
  * also GFT_LAZY_BIN=0 in the environment.  Results are identical.  Process-wide; meant for tests and tuning. */
 int gft_set_binning_mode(int mode);
 int gft_binning_mode(const gft_config* cfg);   /* the mode a forward with this config runs in */
+/* Forward blend kernel.  -1 (default): on frames with fewer than 768 tiles -- where one wave per 8x8 pixel quadrant
+ * leaves most of the chip idle -- every quadrant's list is cut into segments that several waves blend side by side
+ * (k_render_fwd_seg); larger frames run one wave per quadrant.  0: always one wave per quadrant;
+ * 1: segments wherever the tile count allows more than one wave.  Also GFT_FWD_SEG=0 / 1 in the environment.  The two
+ * kernels agree to fp32 rounding of the transmittance products (not bit for bit); each is deterministic.
+ * Process-wide; meant for tests and tuning. */
+int gft_set_render_mode(int mode);
 int gft_get_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* out /*host*/);
 
 /* The forward in two stages, shaped like the reference's resize callbacks

@@ -551,6 +551,46 @@ def binning_mode(mode):
         lib.gft_set_binning_mode(-1)
 
 
+@contextlib.contextmanager
+def render_mode(mode):
+    """0: one wave per quadrant, 1: segment-parallel forward wherever the tile count allows, -1: the library's default"""
+    from gftorf_amd import _lib
+    lib = _lib.load()
+    lib.gft_set_render_mode(int(mode))
+    try:
+        yield
+    finally:
+        lib.gft_set_render_mode(-1)
+
+
+@pytest.mark.parametrize("name", list(BIN_CASES))
+def test_segmented_forward_matches_one_wave_per_quadrant(name, oracle, gpu):
+    """The segment-parallel forward (k_render_fwd_seg: several waves per quadrant, transmittance factors exchanged, exact
+    blend from the true transmittance) against the serial walk of one wave per quadrant: discrete results equal (radii,
+    contributor counts up to pixels that stand within rounding of the 1e-4 stop), images to fp32 rounding of the
+    transmittance products, gradients -- which start from the snapshots the forward leaves at the backward's cuts -- to
+    the order of their sums.  Frames where no / every / some quadrant walks past its sorted head."""
+    from gftorf_amd import api
+    scene = Hh.small_scene(seed=23, **BIN_CASES[name])
+    res = {}
+    for mode in (0, 1):
+        with render_mode(mode):
+            api._instance_hint.clear()
+            for frame in range(2):                 # two-stage flow, then one call
+                res[mode] = Hh.run_gpu(scene, gpu)[:2]
+    (o0, g0), (o1, g1) = res[0], res[1]
+    np.testing.assert_array_equal(o0["radii"], o1["radii"])
+    assert float((o0["pixels"] != o1["pixels"]).mean()) < 1e-4
+    for k in ["color", "phasor", "depth", "acc", "depth_distortion", "distribution"]:
+        Hh.assert_close(k, o0[k], o1[k], rtol_max=2e-6, atol=1e-7, frac_bad=2e-4, rtol_elem=2e-6)
+    for k in g0:
+        if g0[k] is not None:
+            Hh.assert_close(k, g0[k], g1[k], rtol_max=2e-5, atol=1e-7, frac_bad=1e-4, rtol_elem=2e-5)
+    f, b = Hh.run_oracle(oracle, scene)
+    check_outputs(f, o1)
+    check_grads(b, g1, scene)
+
+
 @pytest.mark.parametrize("name", list(BIN_CASES))
 def test_tile_pull_matches_whole_frame_binning(name, oracle, gpu):
     """Tile-pull binning (heads pulled per tile, appearance on demand, lists completed and culled for flagged quadrants)
@@ -561,20 +601,23 @@ def test_tile_pull_matches_whole_frame_binning(name, oracle, gpu):
     if not _lib.load().gft_lazy_sort():
         pytest.skip("GFT_LAZY_SORT=0: whole-frame binning only")
     scene = Hh.small_scene(seed=23, **BIN_CASES[name])
-    with binning_mode(0):
+    # (one wave per quadrant in both: the segment-parallel forward cuts a list by its length, and the sorted heads of the
+    # two binning modes differ in length -- the sums would agree to rounding, not bit for bit)
+    with render_mode(0):
+        with binning_mode(0):
+            api._instance_hint.clear()
+            ref_out, ref_grads, _ = Hh.run_gpu(scene, gpu)
+            R = api.last_call_stats["num_rendered"]
         api._instance_hint.clear()
-        ref_out, ref_grads, _ = Hh.run_gpu(scene, gpu)
-        R = api.last_call_stats["num_rendered"]
-    api._instance_hint.clear()
-    for frame in range(3):
-        out, grads, _ = Hh.run_gpu(scene, gpu)
-        st = api.last_call_stats
-        assert st["num_rendered"] == R and not st["restarted"]
-        for k in ref_out:
-            np.testing.assert_array_equal(out[k], ref_out[k], err_msg="%s frame %d" % (k, frame))
-        for k in ref_grads:
-            if ref_grads[k] is not None:
-                Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
+        for frame in range(3):
+            out, grads, _ = Hh.run_gpu(scene, gpu)
+            st = api.last_call_stats
+            assert st["num_rendered"] == R and not st["restarted"]
+            for k in ref_out:
+                np.testing.assert_array_equal(out[k], ref_out[k], err_msg="%s frame %d" % (k, frame))
+            for k in ref_grads:
+                if ref_grads[k] is not None:
+                    Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
     f, b = Hh.run_oracle(oracle, scene)
     check_outputs(f, ref_out)
     check_grads(b, grads, scene)
