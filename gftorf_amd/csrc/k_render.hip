@@ -368,12 +368,14 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
 // from the forward's late report); bit-identical results from call to call, like the serial kernel.
 #define FSEG_WAVES_MAX 8
 #define FSEG_MIN_LEN 128
+#define FSEG_SPEC_MAX 512     // longest segment that is blended speculatively (its pixel counts wait in LDS)
 
 template <int FSEG_WAVES>      // waves per workgroup = segments per quadrant at most
 __global__ __launch_bounds__(64 * FSEG_WAVES) void k_render_fwd_seg(RenderFwdArgs a)
 {
     __shared__ float4 sStage[FSEG_WAVES][RB * 4];        // per wave: rec_a | rec_b of a batch; afterwards the segment's result
     __shared__ float sT[FSEG_WAVES][64];                 // transmittance factor of every segment, per pixel
+    __shared__ uint8_t sCnt[FSEG_WAVES][FSEG_SPEC_MAX];  // speculative pass: pixels that blended every entry of the segment
 
     if (a.ctrl && a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
     const int V = a.T * 4;
@@ -407,12 +409,107 @@ __global__ __launch_bounds__(64 * FSEG_WAVES) void k_render_fwd_seg(RenderFwdArg
     // scheduling barrier is all that stands between the lanes' writes and the broadcast reads)
     auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
 
-    // ---- phase 1: the segment's transmittance factor ---------------------------------------------------------------
+    // ---- pass A ----------------------------------------------------------------------------------------------------
+    // Segments of up to FSEG_SPEC_MAX entries are blended SPECULATIVELY from T = 1, without the stop rule: colour-like
+    // sums come out short by the factor T_in, phasor sums by T_in^2 (w = alpha T, w_p = alpha T^2), the pixel counts wait
+    // in LDS.  If, once T_in is known, no pixel of the quadrant stands below 1e-4 (+ a margin for the rounding of the
+    // products) at the end of the segment, no pixel has ended anywhere in it -- the running product is monotone -- and
+    // the scaled sums ARE the serial walk's: nothing is evaluated twice (a frame in which nothing saturates, the regime
+    // the reference trains in, runs this path only).  Otherwise the segment is blended again with the stop rule, from the
+    // true transmittance.  Longer segments (lists beyond 8 x 512 entries, whole-frame binning without the lazy sort) take
+    // the transmittance factor alone first (alpha test only) and always blend exactly.
+    const bool speculate = S > 1 && L <= FSEG_SPEC_MAX;           // uniform over the workgroup
     float P = 1.0f;                          // transmittance in front of this wave's segment
+    bool exact = true;                       // the segment (still) has to be blended with the stop rule
+    float T = 1.0f;
+    uint32_t last_contributor = 0;
+    float C0 = 0, C1 = 0, C2 = 0;
+    float PR = 0, PI = 0, PA = 0;
+    float Dd = 0, A = 0, DD_D = 0, DD_D2 = 0;
+    float WD0 = 0, WD1 = 0, WD2 = 0;
+    uint32_t inner_cuts = 0;                 // bit k: the snapshot of list position 256 k was parked by this wave (uniform)
+    bool cuts_local = false;                 // ... in the units of the speculative pass (scaled when the prefix is added)
+    const unsigned long long in_m = wave_ballot(inside);
     if (S > 1) {
         float Tl = 1.0f;
-        if (active) {
-            uint32_t id_next = (seg_begin + lane < seg_end) ? a.point_list[range.x + (uint32_t)(seg_begin + lane)] : 0u;
+        uint32_t id_next = (seg_begin + lane < seg_end) ? a.point_list[range.x + (uint32_t)(seg_begin + lane)] : 0u;
+        if (speculate) {
+            unsigned long long hit_m = 0ull;         // pixels that have blended something
+            asm volatile("" : : "v"(zref));
+            for (int base = seg_begin; base < seg_end; base += RB) {
+                if (a.snaps && base > seg_begin && (base & (GFT_SEG_LEN - 1)) == 0 && base / GFT_SEG_LEN <= a.nsnap) {
+                    float4* sp = a.snaps + ((size_t)v * a.nsnap + (base / GFT_SEG_LEN - 1)) * (GFT_SNAP_F4 * 64) + lane;
+                    sp[0] = make_float4(Tl, C0, C1, C2);
+                    sp[64] = make_float4(PR, PI, PA, Dd);
+                    sp[128] = make_float4(A, DD_D, DD_D2, 0.f);
+                    inner_cuts |= 1u << (base / GFT_SEG_LEN);
+                }
+                const int n = min(RB, seg_end - base);
+                bool reach = false;
+                uint32_t cnt = 0;
+                wave_sync();
+                {
+                    const uint32_t id = id_next;
+                    if (base + RB + lane < seg_end) id_next = a.point_list[range.x + (uint32_t)(base + RB + lane)];
+                    if (lane < n) reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, qbox);
+                }
+                uint64_t m = to_sgpr(wave_ballot(reach));
+                wave_sync();
+                auto blend = [&](const int j, const float4& a0, const float4& a1, const float4& b0, const float4& b1) {
+                    const float dx = a0.x - pxf, dy = a0.y - pyf;
+                    const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+                    const float alpha = fminf(0.99f, a1.y * gft_exp(power));
+                    const unsigned long long vm = wave_ballot(!(power > 0.0f)) & wave_ballot(!(alpha < 1.0f / 255.0f)) & in_m;
+                    if (vm == 0ull) return;
+                    const float al = sel_mask(vm, alpha, 0.f);
+                    const float w = al * Tl;
+                    const float w_p = w * Tl;
+                    C0 += b0.x * w; C1 += b0.y * w; C2 += b0.z * w;
+                    PR += b0.w * w_p; PI += b1.x * w_p; PA += b1.y * w_p;
+                    const float dist = a1.w;
+                    Dd += dist * w;
+                    const unsigned long long fm = vm & ~hit_m;
+                    hit_m |= vm;
+                    WD0 = sel_mask(fm, alpha, WD0);
+                    WD1 = sel_mask(fm, dist, WD1);
+                    WD2 = sel_mask(fm, b1.y, WD2);
+                    const float z = a1.z - zref;
+                    const float wz = w * z;
+                    DD_D += wz;
+                    DD_D2 = fmaf(wz, z, DD_D2);
+                    A += w;
+                    Tl = Tl * (1 - al);                  // (al = 0 leaves it exactly)
+                    last_contributor = sel_mask(vm, (uint32_t)(base + j + 1), last_contributor);
+                    {
+                        const uint32_t pc = (uint32_t)__popcll(vm);
+                        uint32_t m0_keep;
+                        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                                     : "+v"(cnt), "=&s"(m0_keep) : "s"(pc), "s"(j));
+                    }
+                };
+                if (m) {
+                    int j0 = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    float4 p0 = sA[2 * j0], p1 = sA[2 * j0 + 1], q0 = sB[2 * j0], q1 = sB[2 * j0 + 1];
+                    for (;;) {
+                        const bool more1 = m != 0;
+                        int j1 = j0;
+                        if (more1) { j1 = (int)__builtin_ctzll(m); m &= m - 1; }
+                        const float4 r0 = sA[2 * j1], r1 = sA[2 * j1 + 1], t0 = sB[2 * j1], t1 = sB[2 * j1 + 1];
+                        blend(j0, p0, p1, q0, q1);
+                        if (!more1) break;
+                        const bool more0 = m != 0;
+                        j0 = j1;
+                        if (more0) { j0 = (int)__builtin_ctzll(m); m &= m - 1; }
+                        p0 = sA[2 * j0]; p1 = sA[2 * j0 + 1]; q0 = sB[2 * j0]; q1 = sB[2 * j0 + 1];
+                        blend(j1, r0, r1, t0, t1);
+                        if (!more0) break;
+                    }
+                }
+                if (lane < n) sCnt[wave][base - seg_begin + lane] = (uint8_t)cnt;       // (at most 64 pixels per entry)
+            }
+        } else {
+            // the segment's transmittance factor alone
             for (int base = seg_begin; base < seg_end; base += RB) {
                 const int n = min(RB, seg_end - base);
                 bool reach = false;
@@ -452,19 +549,36 @@ __global__ __launch_bounds__(64 * FSEG_WAVES) void k_render_fwd_seg(RenderFwdArg
         sT[wave][lane] = Tl;
         __syncthreads();
         for (int k = 0; k < wave; k++) P *= sT[k][lane];
+        if (speculate) {
+            const float P_end = P * Tl;
+            // some pixel of the quadrant at (or within rounding of) the stop threshold by the end of this segment?
+            exact = wave_ballot(inside && P_end < 1.0001e-4f) != 0ull;
+            if (!exact) {
+                const float P2 = P * P;
+                T = P_end;
+                C0 *= P; C1 *= P; C2 *= P; Dd *= P; A *= P; DD_D *= P; DD_D2 *= P;
+                PR *= P2; PI *= P2; PA *= P2;
+                cuts_local = true;
+                // the pixel counts of the segment: one atomic per entry some pixel blended
+                for (int i = lane; i < seg_end - seg_begin; i += 64) {
+                    const uint32_t c = sCnt[wave][i];
+                    if (c) atomicAdd(&a.pixels[a.point_list[range.x + (uint32_t)(seg_begin + i)]], (float)c);
+                }
+            }
+        }
     }
 
     // ---- phase 2: the exact blend of the segment from the true transmittance ---------------------------------------
     const bool alive_start = inside && !(P < 0.0001f);
-    unsigned long long done_m = ~wave_ballot(alive_start);
-    float T = P;
-    uint32_t last_contributor = 0;
-    float C0 = 0, C1 = 0, C2 = 0;
-    float PR = 0, PI = 0, PA = 0;
-    float Dd = 0, A = 0, DD_D = 0, DD_D2 = 0;
-    float WD0 = 0, WD1 = 0, WD2 = 0;
-    uint32_t inner_cuts = 0;                 // bit k: the snapshot of list position 256 k was parked by this wave (uniform)
-    if (active) {
+    unsigned long long done_m = ~wave_ballot(exact ? alive_start : inside);
+    if (exact) {
+        T = P;
+        last_contributor = 0;
+        C0 = C1 = C2 = PR = PI = PA = Dd = A = DD_D = DD_D2 = 0.f;
+        WD0 = WD1 = WD2 = 0.f;
+        inner_cuts = 0;
+    }
+    if (exact) {
         asm volatile("" : : "v"(zref), "v"(T));
         uint32_t id_next = (seg_begin + lane < seg_end) ? a.point_list[range.x + (uint32_t)(seg_begin + lane)] : 0u;
         for (int base = seg_begin; base < seg_end; base += RB) {
@@ -558,7 +672,7 @@ __global__ __launch_bounds__(64 * FSEG_WAVES) void k_render_fwd_seg(RenderFwdArg
     if (S > 1) {
         wave_sync();
         if (active) {
-            const uint32_t fl = (((done_m >> lane) & 1ull) ? 1u : 0u) | (alive_start ? 2u : 0u);
+            const uint32_t fl = (((done_m >> lane) & 1ull) ? 1u : 0u) | ((exact ? alive_start : inside) ? 2u : 0u);
             float4* res = &sStage[wave][0];
             res[lane] = make_float4(T, C0, C1, C2);
             res[64 + lane] = make_float4(PR, PI, PA, Dd);
@@ -598,9 +712,16 @@ __global__ __launch_bounds__(64 * FSEG_WAVES) void k_render_fwd_seg(RenderFwdArg
                     inner_cuts &= inner_cuts - 1;
                     float4* sp = a.snaps + ((size_t)v * a.nsnap + (k - 1)) * (GFT_SNAP_F4 * 64) + lane;
                     float4 s0 = sp[0], s1 = sp[64], s2 = sp[128];
+                    if (cuts_local) {
+                        // parked by the speculative pass: in its units
+                        const float P2 = P * P;
+                        s0.x *= P; s0.y *= P; s0.z *= P; s0.w *= P;
+                        s1.x *= P2; s1.y *= P2; s1.z *= P2; s1.w *= P;
+                        s2.x *= P; s2.y *= P; s2.z *= P;
+                    }
                     // (a pixel that was done in front of this segment: its transmittance stands where it ended, not at
                     // the running product this wave started from)
-                    if (!alive_start) s0.x = T;
+                    else if (!alive_start) s0.x = T;
                     s0.y += C0; s0.z += C1; s0.w += C2;
                     s1.x += PR; s1.y += PI; s1.z += PA; s1.w += Dd;
                     s2.x += A; s2.y += DD_D; s2.z += DD_D2;

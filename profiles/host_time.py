@@ -1,0 +1,39 @@
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import bench
+from gftorf_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib, api
+_lib.load()
+dev = torch.device("cuda:0")
+scene = bench.build_scene("tiny", 0, 1)     # tiny GPU work: the loop time is the host's
+cfg, g = scene["cfg"], scene["gaussians"]
+P, W, H = cfg["P"], cfg["W"], cfg["H"]
+t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
+bg = t(scene["bg"]); cam = scene["cam"]
+r = GaussianRasterizer(GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, scale_modifier=1.0,
+    viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=cfg["D"], campos=t(cam["campos"]), prefiltered=False, debug=False,
+    near_n=cam["znear"], far_n=cam["zfar"], depth_range=scene["depth_range"], use_view_dependent_phase=scene["use_view_dependent_phase"]))
+leaf = {k: t(v).requires_grad_(True) for k, v in g.items() if v is not None}
+m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+gr = {k: t(v) for k, v in scene["grads"].items()}
+ups = [gr["color"], gr["phasor"], gr["depth"], gr["acc"], gr["depth_distortion"]]
+def step():
+    for x in leaf.values(): x.grad = None
+    m2.grad = None
+    o = r(means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf["shs"], shs_p=leaf["shs_p"], scales=leaf["scales"],
+          rotations=leaf["rotations"], phase_offset=scene["phase_offset"], dc_offset=scene["dc_offset"])
+    torch.autograd.backward([o[0], o[1], o[2], o[4], o[6]], ups)
+for _ in range(50): step()
+torch.cuda.synchronize()
+import cProfile, pstats
+t0 = time.perf_counter()
+for _ in range(500): step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("host loop %.1f us per step (queue drained %.1f ms later)" % ((t1 - t0) / 500 * 1e6, (t2 - t1) * 1e3))
+pr = cProfile.Profile(); pr.enable()
+for _ in range(300): step()
+pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(28)
