@@ -886,6 +886,35 @@ def views_extra(dev, scene, steps=90, warmup=30, views=30):
             "roofline": views_roofline(stage_ms, P, W * H, ((W + 15) // 16) * ((H + 15) // 16), R_sum / n_units, walk_sum / n_units)}
 
 
+def grads_kept_extra(dev, scene, steps=50, warmup=15):
+    """The headline step for a caller that KEEPS its gradients (accumulation over several backwards,
+    `zero_grad(set_to_none=False)`, an optimizer that holds `.grad`): the operator then cannot take back the gradient tensors
+    of the previous backward and writes a fresh dense set every time -- 376 B of zeros per Gaussian nobody blended
+    (GFT_GRADS_REUSE=0 gives the same path).  The other end of `gradient_tensors_reused` in the headline line."""
+    import torch
+    from gftorf_amd import _lib, api
+    step, state, leaf = gpu_step_fn(scene, dev)
+    sync = lambda: torch.cuda.synchronize(dev)
+    keep = api._GRADS_REUSE
+    api._GRADS_REUSE = False
+    try:
+        elapsed = timed_steps(step, steps, warmup, sync)
+        reused = bool(api.last_call_stats.get("grads_reused"))
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        for _ in range(steps):
+            step()
+        sync()
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
+    finally:
+        api._GRADS_REUSE = keep
+    calls = max(prof["forward_calls"], 1)
+    return {"what": "headline step with the gradient tensors written in full by every backward (the caller keeps them)",
+            "it_per_s": steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "gradient_tensors_reused": reused,
+            "preprocess_bwd_ms": prof["preprocess_bwd_ms"] / calls}
+
+
 def fog_extra(dev, steps=50, warmup=15):
     """The headline step on the `fog` workload (the metric frame with opacities 0.05-0.1: the regime the reference's own
     scenes start in, arguments/__init__.py:99): no pixel saturates, every list is walked whole, most visible Gaussians are
@@ -1311,7 +1340,7 @@ def main():
             del state, step
             torch.cuda.empty_cache()
             table = [("train_iteration", lambda: train_iteration_extra(dev, scene)), ("render_pair", lambda: pair_extra(dev, scene)),
-                     ("varying_views", lambda: views_extra(dev, scene)), ("fog", lambda: fog_extra(dev)), ("assemble_inputs", lambda: assemble_extra(dev)),
+                     ("varying_views", lambda: views_extra(dev, scene)), ("fog", lambda: fog_extra(dev)), ("grads_kept", lambda: grads_kept_extra(dev, scene)), ("assemble_inputs", lambda: assemble_extra(dev)),
                      ("knn", lambda: knn_extra(dev)), ("adam", lambda: adam_extra(dev)), ("deform_network", lambda: deform_extra(dev)),
                      ("densify", lambda: densify_extra(dev))]
             want = None if args.extras == "all" else set(args.extras.split(","))

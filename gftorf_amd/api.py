@@ -81,7 +81,13 @@ _HINT_HEADROOM = 1.25
 #   * nobody wrote to it through a tensor (version counter unchanged: an in-place op on `p.grad`, e.g. gradient
 #     accumulation over two backwards or clipping, bumps it; the library's kernels write through raw pointers).
 # Otherwise a fresh buffer is taken and written in full, exactly as before.  GFT_GRADS_REUSE=0 switches it off.
+# CONTRACT of the reuse: gradients handed out by the operator are written through tensors only (autograd,
+# optimizers, clipping, `p.grad.add_()`: all bump the version counter) -- a write through `.data`, `.detach()`-free raw
+# pointers or another extension is invisible here and would leave non-zero rows the next backward does not know about.
+# GFT_GRADS_REUSE_CHECK=1 verifies before every reuse that the unmarked rows are still zero (a debug mode: it reads the
+# whole buffer) and raises if not.
 _GRADS_REUSE = _os.environ.get("GFT_GRADS_REUSE", "1") != "0" and hasattr(torch._C, "_storage_Use_Count")
+_GRADS_CHECK = _os.environ.get("GFT_GRADS_REUSE_CHECK", "0") != "0"
 _grad_pool = {}           # (device, P, layout) -> list of {buf, dirty, version, base}
 _GRAD_POOL_DEPTH = 3      # rasterizer calls of one iteration whose gradient tensors are alive at the same time
 
@@ -484,6 +490,13 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
                 g[k] = buf[o:o + int(torch.Size(v).numel())].view(v)
                 o += sizes[k]
         g["offsets"] = buf[o:o + 2]
+        if reused_grads and _GRADS_CHECK:
+            clean = entry["dirty"][:P] == 0
+            for k, t in g.items():
+                if t is not None and k != "offsets" and bool(t.reshape(P, -1)[clean].ne(0).any()):
+                    raise RuntimeError("gftorf_amd: the kept gradient tensor '%s' holds non-zero rows the last backward did not "
+                                       "write -- somebody wrote to it past the version counter (`.data`, a raw pointer); "
+                                       "set GFT_GRADS_REUSE=0 for such a caller" % k)
     if "offsets" not in g:
         g["offsets"] = torch.empty((2,), **f32)
     acc_zeroed = acc is not None

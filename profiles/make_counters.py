@@ -18,7 +18,7 @@ CLOCK_GHZ, SIMDS = 2.4, 1024
 STAGE_OF = {"k_preprocess_fwd": "preprocess_fwd", "k_appearance": "preprocess_fwd",
             "k_tile_count": "tile_count", "k_tile_scatter": "tile_scatter",
             "k_tile_sort_small": "tile_sort", "k_tile_sort_big": "tile_sort", "k_tile_front": "tile_sort", "k_tile_tail": "tile_sort",
-            "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd", "k_tile_order": "render_bwd",
+            "k_render_fwd": "render_fwd", "k_render_fwd_seg": "render_fwd", "k_render_bwd": "render_bwd", "k_tile_order": "render_bwd",
             "k_preprocess_bwd": "preprocess_bwd", "k_preprocess_bwd_common": "preprocess_bwd", "k_offset_reduce": "preprocess_bwd",
             # gradient tensors kept between backwards: rows of blended Gaussians only (the training call's kernel)
             "k_preprocess_bwd_rows": "preprocess_bwd", "k_grads_rezero": "preprocess_bwd",

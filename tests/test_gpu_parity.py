@@ -898,6 +898,19 @@ def test_gradient_tensors_are_reused_only_when_nobody_holds_or_modified_them(ora
         del out, grads, t
     assert api.last_call_stats["grads_reused"] is True
     assert len(api._grad_pool[next(iter(api._grad_pool))]) == 1        # the same buffer all along
+    # the contract of the reuse: gradients are written through tensors only.  A write past the version counter (`.data`)
+    # is invisible to the operator; the debug mode GFT_GRADS_REUSE_CHECK=1 finds it before the next reuse.
+    api._GRADS_CHECK = True
+    try:
+        out, grads, t = Hh.run_gpu(b, gpu)                              # checked reuse of an untouched buffer: fine
+        check_grads(bb, grads, b)
+        t["leaf"]["means3D"].grad.data.add_(1.0)                        # old-style manual weight decay
+        del out, grads, t
+        with pytest.raises(RuntimeError, match="past the version counter"):
+            Hh.run_gpu(a, gpu)
+    finally:
+        api._GRADS_CHECK = False
+        api._grad_pool.clear()
 
 
 def test_accumulator_is_kept_and_left_zero(oracle, gpu):
