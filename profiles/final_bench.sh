@@ -5,9 +5,13 @@ python3 bench.py --workload C2 --no-cpu-baseline --extras varying_views > gpurun
 python3 bench.py --workload C5 --no-cpu-baseline --extras varying_views > gpurun_out/${T}_bench_C5.json 2>/dev/null && echo c5 ok &&
 python3 bench.py --workload C3 > gpurun_out/${T}_bench_C3.json 2>/dev/null && echo c3 ok &&
 python3 bench.py --workload C3 --pair > gpurun_out/${T}_bench_C3_pair.json 2>/dev/null && echo c3p ok
+python3 bench.py --workload C4 --no-cpu-baseline > gpurun_out/${T}_bench_C4.json 2>/dev/null && echo c4 ok
+python3 bench.py --workload fog --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_fog.json 2>/dev/null && echo fog ok
+python3 profiles/stage_bench.py c3 200 > gpurun_out/${T}_stage_c3.json 2>/dev/null
+GFT_FWD_SEG=0 python3 profiles/stage_bench.py c3 200 > gpurun_out/${T}_stage_c3_serial.json 2>/dev/null
 python3 - <<PY
 import json
-for w in ("full","C1","C2","C5","C3","C3_pair"):
+for w in ("full","C1","C2","C5","C3","C3_pair","C4","fog"):
     try:
         d=json.loads(open("gpurun_out/${T}_bench_%s.json"%w).read().strip().splitlines()[-1])
     except Exception as e:
