@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
 #define FSEG_SPEC_MAX 512     // longest segment that is blended speculatively (its pixel counts wait in LDS)
 
 template <int FSEG_WAVES>      // waves per workgroup = segments per quadrant at most
-__global__ __launch_bounds__(64 * FSEG_WAVES) void k_render_fwd_seg(RenderFwdArgs a)
+__global__ __launch_bounds__(64 * FSEG_WAVES) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_render_fwd_seg(RenderFwdArgs a)
 {
     __shared__ float4 sStage[FSEG_WAVES][RB * 4];        // per wave: rec_a | rec_b of a batch; afterwards the segment's result
     __shared__ float sT[FSEG_WAVES][64];                 // transmittance factor of every segment, per pixel
