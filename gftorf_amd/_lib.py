@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 DEFORM_MAX_INPUTS = 96          # GFT_DEFORM_MAX_INPUTS (include/gftorf_deform.h)
 ACC_STRIDE = 16
 
@@ -47,7 +47,7 @@ BACKWARD_FIELDS = [
     "dL_dout_color", "dL_dout_phasor", "dL_dout_depth", "dL_dout_acc", "dL_dout_depth_distortion",
     "geom", "img", "binning", "acc",
     "dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dcov3D", "dL_dsh", "dL_dsh_p",
-    "dL_dscales", "dL_drotations", "dL_dphase_offset", "dL_ddc_offset", "det_partials", "dirty_rows",
+    "dL_dscales", "dL_drotations", "dL_dphase_offset", "dL_ddc_offset", "det_partials", "dirty_rows", "rows_report",
 ]
 
 LAYOUT_FIELDS = [

@@ -89,6 +89,8 @@ _HINT_HEADROOM = 1.25
 _GRADS_REUSE = _os.environ.get("GFT_GRADS_REUSE", "1") != "0" and hasattr(torch._C, "_storage_Use_Count")
 _GRADS_CHECK = _os.environ.get("GFT_GRADS_REUSE_CHECK", "0") != "0"
 _grad_pool = {}           # (device, P, layout) -> list of {buf, dirty, version, base}
+_DENSE_SHARE = 0.3        # rows written by the last rows-only backward / P above which the tensors are written in full
+_DENSE_RUN = 15           # ... for this many backwards, before a rows-only one counts again
 _GRAD_POOL_DEPTH = 3      # rasterizer calls of one iteration whose gradient tensors are alive at the same time
 
 
@@ -468,8 +470,11 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
                 entry = free[0]
             if entry is None:
                 buf = torch.empty((total,), **f32)
-                entry = dict(buf=buf, dirty=torch.zeros(((P + 3) // 4 * 4,), device=dev, dtype=torch.uint8), version=buf._version,
-                             valid=False)
+                # (`dirty`: a mark per Gaussian + the 144 bytes behind them in which the rows backward counts; `report`: pinned
+                # host word into which it stores the number of rows it wrote -- gft_backward_io.rows_report)
+                report = torch.zeros((4,), dtype=torch.int32).pin_memory()
+                entry = dict(buf=buf, dirty=torch.zeros(((P + 3) // 4 * 4 + 144,), device=dev, dtype=torch.uint8), version=buf._version,
+                             valid=False, report=report, report_np=report.numpy(), dense_left=0)
                 entry["base"] = _storage_refs(buf)
                 pool.append(entry)
                 del pool[:-_GRAD_POOL_DEPTH]
@@ -505,7 +510,29 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
     cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw_records)
     # (2: the backward leaves the accumulator zero again -- the buffer goes back to the pool, _AccLease)
     cfg.acc_zeroed = 2 if (acc_zeroed and acc_lease is not None and _ACC_REUSE) else int(acc_zeroed)
-    cfg.grads_zeroed = 3 if reused_grads else int(zero_buf is not None)
+    # A kept set of gradient tensors is rewritten row by row only while few rows are written (a dense frame blends a few
+    # per cent of its Gaussians): the rows kernel stores its rows straight from the lanes, and from about a third of the
+    # Gaussians on the full write through LDS -- coalesced, zeros included -- is faster (C3-shaped frame, 96 % blended: 16 vs
+    # 54 us; fog: 140 vs 203 us).  The last rows backward has left its row count in pinned memory: above _DENSE_SHARE the
+    # next _DENSE_RUN backwards into these tensors write them in full (which marks every row), then one rows backward
+    # looks again.
+    rows_only = reused_grads
+    sample = False                 # this backward reports its row count (the report costs the rows kernel ~4 us: every 16th call)
+    if reused_grads and pool_entry is not None and "report_np" in pool_entry:
+        e = pool_entry
+        if e["dense_left"] > 0:
+            e["dense_left"] -= 1
+            rows_only = False
+            e["probe"] = e["dense_left"] == 0
+        elif int(e["report_np"][0]) > _DENSE_SHARE * P:
+            e["dense_left"] = _DENSE_RUN
+            e["report_np"][0] = 0
+            rows_only = False
+        else:
+            e["tick"] = e.get("tick", 0) + 1
+            sample = e.get("probe", False) or e["tick"] <= 2 or e["tick"] % 16 == 0
+            e["probe"] = False
+    cfg.grads_zeroed = 3 if rows_only else int(zero_buf is not None)
     cfg.grads_accumulate = int(share_grads is not None)
     if share_grads is not None and share_grads.get("dirty") is not None:
         # second view of a pair: its rows are added to the first view's tensors and marked in the same array
@@ -534,7 +561,10 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
     if entry is not None:
         # (cfg.grads_zeroed = 3: the backward zeroes the rows the previous one wrote and this one does not, then writes its own)
         io.dirty_rows = entry["dirty"].data_ptr()
+        if sample and entry.get("report") is not None:
+            io.rows_report = entry["report"].data_ptr()
     last_call_stats["grads_reused"] = bool(reused_grads)
+    last_call_stats["grads_rows_only"] = bool(rows_only)
     return dict(grads=g, cfg=cfg, io=io, acc=acc, acc_lease=acc_lease, pixels=pixels, zero_buf=zero_buf, dev=dev, P=P, H=H, W=W,
                 dirty=entry["dirty"] if entry is not None else None, pool_entry=pool_entry,
                 debug_args=(s.bg, means3D, radii, scales, rotations, s.scale_modifier, cov3D, s.viewmatrix, s.projmatrix,

@@ -14,6 +14,7 @@
 // same on the device as in the fp32 CPU oracle: "bit-exact tile/key indexing".
 #include "gft_internal.h"
 #include "gft_appearance.h"
+#include <mutex>
 
 #pragma clang fp contract(off)
 
@@ -376,6 +377,7 @@ struct PreBwdArgs {
     GeomView g;
     float focal_x, focal_y, dist2phase;
     int stage_sh, stage_shp;
+    uint32_t* rows_report;      // rows-only backward: device pointer of the caller's pinned word (NULL: no report)
 };
 
 // Is Gaussian idx one that some pixel blended (non-zero accumulators, hence possibly non-zero gradients)?
@@ -915,6 +917,30 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_preprocess_bwd_rows(PreBwdArgs
         part[0] = sp;
         part[1] = sd;
     }
+    if (a.rows_report && tid == 0) {
+        // rows this backward writes, for the caller (gft_backward_io.rows_report): summed behind dirty_rows, the workgroup
+        // that draws the last ticket stores the total to the host and leaves the two words zero for the next backward
+        uint32_t* cnt = reinterpret_cast<uint32_t*>(a.io.dirty_rows + (((size_t)P + 3) & ~(size_t)3));
+        if (n) atomicAdd(&cnt[0], n);
+        // (a device-scope atomic is complete once vmcnt drains, and the last workgroup reads the sum with a device-scope load: no
+        // cache write-back is needed -- a __threadfence here cost the kernel 17 us)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // two-level ticket (as in the supertile count pass: hundreds of returning atomics on one address are served one
+        // after the other): workgroup b draws from first-level counter b % 32, the last of every group from cnt[1]
+        const uint32_t G = min(32u, gridDim.x), grp = blockIdx.x % G;
+        const uint32_t members = (gridDim.x - grp + G - 1u) / G;
+        bool last = false;
+        if (atomicAdd(&cnt[2 + grp], 1u) == members - 1u) {
+            __hip_atomic_store(&cnt[2 + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = atomicAdd(&cnt[1], 1u) == G - 1u;
+        }
+        if (last) {
+            const uint32_t total = __hip_atomic_load(&cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.rows_report, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&cnt[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&cnt[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Zeroes the gradient rows the previous backward into these tensors wrote (dirty[id] != 0) and clears the marks: the
@@ -1046,6 +1072,20 @@ hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const g
     // tensors hold)
     a.stage_sh = (io.shs != nullptr && c.M == 16 && !c.grads_zeroed) ? 1 : 0;
     a.stage_shp = (io.shs_p != nullptr && c.M_p == 16 && !c.grads_zeroed) ? 1 : 0;
+    a.rows_report = nullptr;
+    if (io.rows_report) {
+        // (pinned host memory: the device pointer is asked for once per address; a pointer that is not mapped gets no report)
+        static std::mutex mu;
+        static const void* last_host = nullptr;
+        static uint32_t* last_dev = nullptr;
+        std::lock_guard<std::mutex> lk(mu);
+        if (last_host != (const void*)io.rows_report) {
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, (void*)io.rows_report, 0) == hipSuccess) { last_host = io.rows_report; last_dev = (uint32_t*)d; }
+            else { (void)hipGetLastError(); last_host = io.rows_report; last_dev = nullptr; }
+        }
+        a.rows_report = last_dev;
+    }
     const size_t lds = (size_t)(PRE_BLOCK / 64) * 64 * 16 * ((a.stage_sh ? SH_ROW_PAD : 0) + (a.stage_shp ? SHP_ROW_PAD : 0));
     const int blocks = (c.P + PRE_BLOCK - 1) / PRE_BLOCK;          // = waves = partial sums of the offset gradients
     const bool common_shape = c.want_backward && io.shs && c.M == 16 && io.shs_p && c.M_p == 16 &&

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GFT_ABI_VERSION 7
+#define GFT_ABI_VERSION 8
 
 /* compile-time constants of the reference (RAST/cuda_rasterizer/config.h:15-23) */
 #define GFT_NUM_CHANNELS 3
@@ -191,6 +191,13 @@ typedef struct gft_backward_io {
      * tensors are all zero again and the next backward may run with cfg.grads_zeroed = 2: it then writes the rows of the
      * blended Gaussians only, instead of streaming ~376 B of zeros for every other Gaussian. */
     uint8_t* dirty_rows;
+    /* optional, with grads_zeroed = 2 / 3: pinned host memory (one uint32) into which the backward stores the number of
+     * gradient rows it wrote -- the Gaussians some pixel blended -- when it ends (no wait, no copy: a caller reads it
+     * whenever it likes and finds the most recent backward's count).  dirty_rows must then be followed by 144 more bytes
+     * (device counter + tickets, zero before the first use).  The rows-only backward pays when few rows are written (a
+     * dense frame: 7 %); a frame that blends most of its Gaussians is better served by a full write (grads_zeroed = 0
+     * into the same tensors: marks every row): gftorf_amd/api.py switches on this count. */
+    uint32_t* rows_report;
 } gft_backward_io;
 
 /* Byte offsets of the sub-arrays inside the scratch buffers (the forward <->

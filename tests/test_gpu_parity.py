@@ -913,6 +913,39 @@ def test_gradient_tensors_are_reused_only_when_nobody_holds_or_modified_them(ora
         api._grad_pool.clear()
 
 
+def test_kept_gradient_tensors_switch_between_rows_and_full_writes(oracle, gpu):
+    """A kept set of gradient tensors is rewritten row by row while few Gaussians are blended and in full (coalesced, zeros
+    included, every row marked) when most are: the rows backward leaves its row count in pinned host memory
+    (gft_backward_io.rows_report) and api.py switches on it.  Not observable in the values: a frame that blends nearly
+    everything and one that blends little, repeated and alternated, give the oracle's gradients in every mode and across
+    every switch."""
+    from gftorf_amd import api
+    if not api._GRADS_REUSE:
+        pytest.skip("gradient-tensor reuse is off")
+    dense = Hh.small_scene(P=3000, seed=51, opacity=0.03)                       # thin: every visible Gaussian is blended
+    sparse = Hh.small_scene(P=3000, seed=52, opacity=0.97, scale_lo=0.05, scale_hi=0.25)   # opaque: a fraction is
+    ref = {id(sc): Hh.run_oracle(oracle, sc) for sc in (dense, sparse)}
+    share = lambda sc: float((ref[id(sc)][0].pixels > 0).mean())
+    assert share(dense) > 0.6 and share(sparse) < 0.3, (share(dense), share(sparse))
+    api._grad_pool.clear()
+    keep = api._DENSE_RUN
+    api._DENSE_RUN = 2
+    modes = []
+    try:
+        for sc in [dense] * 7 + [sparse] * 7 + [dense, sparse] * 4:
+            out, grads, t = Hh.run_gpu(sc, gpu)
+            torch.cuda.synchronize()
+            modes.append((api.last_call_stats["grads_reused"], api.last_call_stats["grads_rows_only"], sc is dense))
+            check_grads(ref[id(sc)][1], grads, sc)
+            del out, grads, t
+    finally:
+        api._DENSE_RUN = keep
+        api._grad_pool.clear()
+    assert all(m[0] for m in modes[1:])                                # one buffer went round
+    assert any(m[0] and not m[1] for m in modes[:7])                   # the dense frame came to be written in full ...
+    assert any(m[1] for m in modes[7:14])                              # ... and the sparse one by rows again
+
+
 def test_accumulator_is_kept_and_left_zero(oracle, gpu):
     """The backward's accumulator (64 B per Gaussian) is kept between calls (api.py: _AccLease): the preprocess backward
     zeroes the rows it has read (cfg.acc_zeroed = 2) and the next forward clears nothing.  Not observable: gradients of
