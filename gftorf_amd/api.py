@@ -150,6 +150,16 @@ def _take_acc(lib, dev, P, stream, any_stream=False):
 _LIST_HEADROOM = 1.2      # longest tile list of the previous frame -> guess for this one
 
 
+_EMPTY = torch.Tensor([])      # "tensor absent" (reference __init__.py:239-252)
+
+
+def _prod(shape):
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return n
+
+
 def cpu_deep_copy_tuple(input_tuple):
     return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
 
@@ -164,7 +174,8 @@ def _f32(t, dev, name):
         raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))
     if t.device != dev:
         raise RuntimeError("%s is on %s, expected %s" % (name, t.device, dev))
-    t = t.contiguous()
+    if not t.is_contiguous():
+        t = t.contiguous()
     if t.data_ptr() % 16:
         t = t.clone()
     return t
@@ -448,7 +459,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         # offset gradients at its end): ten torch.empty calls less per forward, which at the reference's scene size
         # (100 k Gaussians, 0.1 ms of kernels per call) is host time the device waits for.  With the zero-fill switch
         # the forward clears it beside its binning kernels and the backward writes only the rows of blended Gaussians.
-        sizes = {k: (int(torch.Size(v).numel()) + 3) // 4 * 4 for k, v in shapes.items() if v is not None}
+        sizes = {k: (_prod(v) + 3) // 4 * 4 for k, v in shapes.items() if v is not None}
         total = sum(sizes.values()) + 4
         entry = None
         if _GRADS_REUSE and P and pixels is not None and want_bw_records and not zero_fill:
@@ -492,7 +503,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
             if v is None:
                 g[k] = None
             else:
-                g[k] = buf[o:o + int(torch.Size(v).numel())].view(v)
+                g[k] = buf[o:o + _prod(v)].view(v)
                 o += sizes[k]
         g["offsets"] = buf[o:o + 2]
         if reused_grads and _GRADS_CHECK:
@@ -583,7 +594,7 @@ def run_backward(prep, grads_out, geom, binning, img, debug=False):
         # accepted and ignored, as in the reference kernels (backward.cu:609-630)
         if t is None:
             return None
-        if tuple(t.shape) != (c, H, W):
+        if t.dim() != 3 or t.size(0) != c or t.size(1) != H or t.size(2) != W:
             raise RuntimeError("grad of %s has shape %s, expected %s" % (name, tuple(t.shape), (c, H, W)))
         return _f32(t, dev, "grad_" + name)
 
@@ -734,20 +745,22 @@ class GaussianRasterizer(nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
 
+        # (the reference builds a fresh `torch.Tensor([])` for every absent input on every call; one shared empty tensor
+        # says the same -- it is never written to -- and saves the host ~2 us each)
         if shs is None:
-            shs = torch.Tensor([])
+            shs = _EMPTY
         if colors_precomp is None:
-            colors_precomp = torch.Tensor([])
+            colors_precomp = _EMPTY
         if shs_p is None:
-            shs_p = torch.Tensor([])
+            shs_p = _EMPTY
         if phasors_precomp is None:
-            phasors_precomp = torch.Tensor([])
+            phasors_precomp = _EMPTY
         if scales is None:
-            scales = torch.Tensor([])
+            scales = _EMPTY
         if rotations is None:
-            rotations = torch.Tensor([])
+            rotations = _EMPTY
         if cov3D_precomp is None:
-            cov3D_precomp = torch.Tensor([])
+            cov3D_precomp = _EMPTY
 
         return rasterize_gaussians(means3D, means2D, shs, shs_p, colors_precomp, phasors_precomp, opacities,
                                    scales, rotations, cov3D_precomp, phase_offset, dc_offset, raster_settings)
