@@ -430,10 +430,120 @@ __global__ __launch_bounds__(64 * FSEG_WAVES) __attribute__((amdgpu_waves_per_eu
     uint32_t inner_cuts = 0;                 // bit k: the snapshot of list position 256 k was parked by this wave (uniform)
     bool cuts_local = false;                 // ... in the units of the speculative pass (scaled when the prefix is added)
     const unsigned long long in_m = wave_ballot(inside);
+    bool alive_start = inside;
+    unsigned long long done_m = ~in_m;
+    // The first segment's transmittance in front IS known (1): its wave blends exactly straight away -- never twice, and it
+    // stops early where the quadrant saturates inside the segment (a frame that saturates early has most of its quadrants
+    // end there).  For the waves behind it a pixel that ended here counts as transmittance 0.
+    const bool lead_exact = S > 1 && wave == 0;
+    // ---- phase 2: the exact blend of the segment from the true transmittance ---------------------------------------
+    auto run_exact = [&] {
+    alive_start = inside && !(P < 0.0001f);
+    done_m = ~wave_ballot(exact ? alive_start : inside);
+    if (exact) {
+        T = P;
+        last_contributor = 0;
+        C0 = C1 = C2 = PR = PI = PA = Dd = A = DD_D = DD_D2 = 0.f;
+        WD0 = WD1 = WD2 = 0.f;
+        inner_cuts = 0;
+    }
+    if (exact) {
+        asm volatile("" : : "v"(zref), "v"(T));
+        uint32_t id_next = (seg_begin + lane < seg_end) ? a.point_list[range.x + (uint32_t)(seg_begin + lane)] : 0u;
+        for (int base = seg_begin; base < seg_end; base += RB) {
+            if (done_m == ~0ull) break;
+            // a cut of the backward (list position 256 k) INSIDE this segment: the sums blended by this wave so far and the
+            // true transmittance are parked in the cut's snapshot slot; the sums of the segments in front are added below
+            if (a.snaps && base > seg_begin && (base & (GFT_SEG_LEN - 1)) == 0 && base / GFT_SEG_LEN <= a.nsnap) {
+                float4* sp = a.snaps + ((size_t)v * a.nsnap + (base / GFT_SEG_LEN - 1)) * (GFT_SNAP_F4 * 64) + lane;
+                sp[0] = make_float4(T, C0, C1, C2);
+                sp[64] = make_float4(PR, PI, PA, Dd);
+                sp[128] = make_float4(A, DD_D, DD_D2, 0.f);
+                inner_cuts |= 1u << (base / GFT_SEG_LEN);
+            }
+            const int n = min(RB, seg_end - base);
+            bool reach = false;
+            uint32_t my_id = 0;
+            uint32_t cnt = 0;
+            const float4 box = __popcll(~done_m) <= 24 ? box_of_mask(~done_m, qx0, qy0) : qbox;
+            wave_sync();
+            {
+                const uint32_t id = id_next;
+                if (base + RB + lane < seg_end) id_next = a.point_list[range.x + (uint32_t)(base + RB + lane)];
+                if (lane < n) {
+                    my_id = id;
+                    reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, box);
+                }
+            }
+            uint64_t m = to_sgpr(wave_ballot(reach));
+            wave_sync();
+            auto blend = [&](const int j, const float4& a0, const float4& a1, const float4& b0, const float4& b1) {
+                const float dx = a0.x - pxf, dy = a0.y - pyf;
+                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
+                const float alpha = fminf(0.99f, a1.y * gft_exp(power));
+                const unsigned long long vm = wave_ballot(!(power > 0.0f)) & wave_ballot(!(alpha < 1.0f / 255.0f)) & ~done_m;
+                if (vm == 0ull) return;
+                const float test_T = T * (1 - alpha);
+                const unsigned long long tm = vm & wave_ballot(test_T < 0.0001f);
+                const unsigned long long cm = vm & ~tm;
+                done_m |= tm;
+                if (cm != 0ull) {
+                    const float al = sel_mask(cm, alpha, 0.f);
+                    const float w = al * T;
+                    const float w_p = w * T;
+                    C0 += b0.x * w; C1 += b0.y * w; C2 += b0.z * w;
+                    PR += b0.w * w_p; PI += b1.x * w_p; PA += b1.y * w_p;
+                    const float dist = a1.w;
+                    Dd += dist * w;
+                    const unsigned long long fm = cm & wave_ballot(last_contributor == 0u);
+                    WD0 = sel_mask(fm, alpha, WD0);
+                    WD1 = sel_mask(fm, dist, WD1);
+                    WD2 = sel_mask(fm, b1.y, WD2);
+                    const float z = a1.z - zref;
+                    const float wz = w * z;
+                    DD_D += wz;
+                    DD_D2 = fmaf(wz, z, DD_D2);
+                    A += w;
+                    T = sel_mask(cm, test_T, T);
+                    last_contributor = sel_mask(cm, (uint32_t)(base + j + 1), last_contributor);
+                    {
+                        const uint32_t pc = (uint32_t)__popcll(cm);
+                        uint32_t m0_keep;
+                        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                                     : "+v"(cnt), "=&s"(m0_keep) : "s"(pc), "s"(j));
+                    }
+                }
+            };
+            if (m) {
+                int j0 = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                float4 p0 = sA[2 * j0], p1 = sA[2 * j0 + 1], q0 = sB[2 * j0], q1 = sB[2 * j0 + 1];
+                for (;;) {
+                    const bool more1 = m != 0;
+                    int j1 = j0;
+                    if (more1) { j1 = (int)__builtin_ctzll(m); m &= m - 1; }
+                    const float4 r0 = sA[2 * j1], r1 = sA[2 * j1 + 1], t0 = sB[2 * j1], t1 = sB[2 * j1 + 1];
+                    blend(j0, p0, p1, q0, q1);
+                    if (!more1 || done_m == ~0ull) break;
+                    const bool more0 = m != 0;
+                    j0 = j1;
+                    if (more0) { j0 = (int)__builtin_ctzll(m); m &= m - 1; }
+                    p0 = sA[2 * j0]; p1 = sA[2 * j0 + 1]; q0 = sB[2 * j0]; q1 = sB[2 * j0 + 1];
+                    blend(j1, r0, r1, t0, t1);
+                    if (!more0 || done_m == ~0ull) break;
+                }
+            }
+            if (cnt) atomicAdd(&a.pixels[my_id], (float)cnt);
+        }
+    }
+    };
     if (S > 1) {
         float Tl = 1.0f;
-        uint32_t id_next = (seg_begin + lane < seg_end) ? a.point_list[range.x + (uint32_t)(seg_begin + lane)] : 0u;
-        if (speculate) {
+        uint32_t id_next = (seg_begin + lane < seg_end && !lead_exact) ? a.point_list[range.x + (uint32_t)(seg_begin + lane)] : 0u;
+        if (lead_exact) {
+            run_exact();                                         // (P = 1, exact = true)
+            Tl = ((done_m >> lane) & 1ull) ? 0.0f : T;           // a pixel that ended here: nothing behind it blends
+        } else if (speculate) {
             unsigned long long hit_m = 0ull;         // pixels that have blended something
             asm volatile("" : : "v"(zref));
             for (int base = seg_begin; base < seg_end; base += RB) {
@@ -549,7 +659,7 @@ __global__ __launch_bounds__(64 * FSEG_WAVES) __attribute__((amdgpu_waves_per_eu
         sT[wave][lane] = Tl;
         __syncthreads();
         for (int k = 0; k < wave; k++) P *= sT[k][lane];
-        if (speculate) {
+        if (speculate && !lead_exact) {
             const float P_end = P * Tl;
             // some pixel of the quadrant at (or within rounding of) the stop threshold by the end of this segment?
             exact = wave_ballot(inside && P_end < 1.0001e-4f) != 0ull;
@@ -568,105 +678,7 @@ __global__ __launch_bounds__(64 * FSEG_WAVES) __attribute__((amdgpu_waves_per_eu
         }
     }
 
-    // ---- phase 2: the exact blend of the segment from the true transmittance ---------------------------------------
-    const bool alive_start = inside && !(P < 0.0001f);
-    unsigned long long done_m = ~wave_ballot(exact ? alive_start : inside);
-    if (exact) {
-        T = P;
-        last_contributor = 0;
-        C0 = C1 = C2 = PR = PI = PA = Dd = A = DD_D = DD_D2 = 0.f;
-        WD0 = WD1 = WD2 = 0.f;
-        inner_cuts = 0;
-    }
-    if (exact) {
-        asm volatile("" : : "v"(zref), "v"(T));
-        uint32_t id_next = (seg_begin + lane < seg_end) ? a.point_list[range.x + (uint32_t)(seg_begin + lane)] : 0u;
-        for (int base = seg_begin; base < seg_end; base += RB) {
-            if (done_m == ~0ull) break;
-            // a cut of the backward (list position 256 k) INSIDE this segment: the sums blended by this wave so far and the
-            // true transmittance are parked in the cut's snapshot slot; the sums of the segments in front are added below
-            if (a.snaps && base > seg_begin && (base & (GFT_SEG_LEN - 1)) == 0 && base / GFT_SEG_LEN <= a.nsnap) {
-                float4* sp = a.snaps + ((size_t)v * a.nsnap + (base / GFT_SEG_LEN - 1)) * (GFT_SNAP_F4 * 64) + lane;
-                sp[0] = make_float4(T, C0, C1, C2);
-                sp[64] = make_float4(PR, PI, PA, Dd);
-                sp[128] = make_float4(A, DD_D, DD_D2, 0.f);
-                inner_cuts |= 1u << (base / GFT_SEG_LEN);
-            }
-            const int n = min(RB, seg_end - base);
-            bool reach = false;
-            uint32_t my_id = 0;
-            uint32_t cnt = 0;
-            const float4 box = __popcll(~done_m) <= 24 ? box_of_mask(~done_m, qx0, qy0) : qbox;
-            wave_sync();
-            {
-                const uint32_t id = id_next;
-                if (base + RB + lane < seg_end) id_next = a.point_list[range.x + (uint32_t)(base + RB + lane)];
-                if (lane < n) {
-                    my_id = id;
-                    reach = stage_splat(id, lane, a.rec_a, a.rec_b, sA, sB, box);
-                }
-            }
-            uint64_t m = to_sgpr(wave_ballot(reach));
-            wave_sync();
-            auto blend = [&](const int j, const float4& a0, const float4& a1, const float4& b0, const float4& b1) {
-                const float dx = a0.x - pxf, dy = a0.y - pyf;
-                const float power = -0.5f * (a0.z * dx * dx + a1.x * dy * dy) - a0.w * dx * dy;
-                const float alpha = fminf(0.99f, a1.y * gft_exp(power));
-                const unsigned long long vm = wave_ballot(!(power > 0.0f)) & wave_ballot(!(alpha < 1.0f / 255.0f)) & ~done_m;
-                if (vm == 0ull) return;
-                const float test_T = T * (1 - alpha);
-                const unsigned long long tm = vm & wave_ballot(test_T < 0.0001f);
-                const unsigned long long cm = vm & ~tm;
-                done_m |= tm;
-                if (cm != 0ull) {
-                    const float al = sel_mask(cm, alpha, 0.f);
-                    const float w = al * T;
-                    const float w_p = w * T;
-                    C0 += b0.x * w; C1 += b0.y * w; C2 += b0.z * w;
-                    PR += b0.w * w_p; PI += b1.x * w_p; PA += b1.y * w_p;
-                    const float dist = a1.w;
-                    Dd += dist * w;
-                    const unsigned long long fm = cm & wave_ballot(last_contributor == 0u);
-                    WD0 = sel_mask(fm, alpha, WD0);
-                    WD1 = sel_mask(fm, dist, WD1);
-                    WD2 = sel_mask(fm, b1.y, WD2);
-                    const float z = a1.z - zref;
-                    const float wz = w * z;
-                    DD_D += wz;
-                    DD_D2 = fmaf(wz, z, DD_D2);
-                    A += w;
-                    T = sel_mask(cm, test_T, T);
-                    last_contributor = sel_mask(cm, (uint32_t)(base + j + 1), last_contributor);
-                    {
-                        const uint32_t pc = (uint32_t)__popcll(cm);
-                        uint32_t m0_keep;
-                        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-                                     : "+v"(cnt), "=&s"(m0_keep) : "s"(pc), "s"(j));
-                    }
-                }
-            };
-            if (m) {
-                int j0 = (int)__builtin_ctzll(m);
-                m &= m - 1;
-                float4 p0 = sA[2 * j0], p1 = sA[2 * j0 + 1], q0 = sB[2 * j0], q1 = sB[2 * j0 + 1];
-                for (;;) {
-                    const bool more1 = m != 0;
-                    int j1 = j0;
-                    if (more1) { j1 = (int)__builtin_ctzll(m); m &= m - 1; }
-                    const float4 r0 = sA[2 * j1], r1 = sA[2 * j1 + 1], t0 = sB[2 * j1], t1 = sB[2 * j1 + 1];
-                    blend(j0, p0, p1, q0, q1);
-                    if (!more1 || done_m == ~0ull) break;
-                    const bool more0 = m != 0;
-                    j0 = j1;
-                    if (more0) { j0 = (int)__builtin_ctzll(m); m &= m - 1; }
-                    p0 = sA[2 * j0]; p1 = sA[2 * j0 + 1]; q0 = sB[2 * j0]; q1 = sB[2 * j0 + 1];
-                    blend(j1, r0, r1, t0, t1);
-                    if (!more0 || done_m == ~0ull) break;
-                }
-            }
-            if (cnt) atomicAdd(&a.pixels[my_id], (float)cnt);
-        }
-    }
+    if (!lead_exact) run_exact();
 
     // ---- combine ----------------------------------------------------------------------------------------------------
     if (S > 1) {
@@ -719,9 +731,9 @@ __global__ __launch_bounds__(64 * FSEG_WAVES) __attribute__((amdgpu_waves_per_eu
                         s1.x *= P2; s1.y *= P2; s1.z *= P2; s1.w *= P;
                         s2.x *= P; s2.y *= P; s2.z *= P;
                     }
-                    // (a pixel that was done in front of this segment: its transmittance stands where it ended, not at
-                    // the running product this wave started from)
-                    else if (!alive_start) s0.x = T;
+                    // (a pixel that was done in front of this segment -- or lies outside the image --: its transmittance
+                    // stands where it ended, not at the running product this wave started from, which may be 0)
+                    if (!alive_start) s0.x = T;
                     s0.y += C0; s0.z += C1; s0.w += C2;
                     s1.x += PR; s1.y += PI; s1.z += PA; s1.w += Dd;
                     s2.x += A; s2.y += DD_D; s2.z += DD_D2;

@@ -537,6 +537,9 @@ BIN_CASES = {
     "silhouette": dict(P=30000, W=96, H=64, scale_lo=0.005, scale_hi=0.05, spread=0.55),   # cloud edge inside the image: quadrants that never saturate beside dense ones
     "wide_depth_range": SCENES["wide_depth_range"],                # whole lists over more depth bins than the pull kernel has cursors
     "crowded_depth_bins": SCENES["crowded_depth_bins"],            # depth bins with more keys than a cursor counts: sorted as a whole
+    # thin lists of ~1500 entries over an image that ends inside its last quadrants: segments with the backward's cuts
+    # inside them, blended speculatively, with lanes outside the image (their snapshots must not carry a zero transmittance)
+    "ragged_thin_deep": dict(P=6000, W=50, H=37, scale_lo=0.03, scale_hi=0.2, opacity=0.04),
 }
 
 
