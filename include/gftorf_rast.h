@@ -274,7 +274,7 @@ int gft_set_binning_mode(int mode);
 int gft_binning_mode(const gft_config* cfg);   /* the mode a forward with this config runs in */
 /* Forward blend kernel.  -1 (default): on frames with fewer than 768 tiles -- where one wave per 8x8 pixel quadrant
  * leaves most of the chip idle -- every quadrant's list is cut into segments that several waves blend side by side
- * (k_render_fwd_seg, DESIGN.md section 4c); larger frames run one wave per quadrant.  0: always one wave per quadrant;
+ * (k_render_fwd_seg, DESIGN.md section 5.3); larger frames run one wave per quadrant.  0: always one wave per quadrant;
  * 1: segments wherever the tile count allows more than one wave.  Also GFT_FWD_SEG=0 / 1 in the environment.  The two
  * kernels agree to fp32 rounding of the transmittance products (not bit for bit); each is deterministic.
  * Process-wide; meant for tests and tuning. */
@@ -320,7 +320,7 @@ typedef struct gft_forward_report {
  * If report->num_rendered > hints->binning_instances the stage-2 kernels have done nothing (they
  * compare the device-side count themselves): allocate for report->num_rendered and call
  * gft_forward_render().  The size of the buffer is the only thing taken from earlier frames: what is binned,
- * sorted and given an appearance is decided from the frame itself (tile-pull binning, DESIGN.md section 4b).
+ * sorted and given an appearance is decided from the frame itself (tile-pull binning, DESIGN.md section 5.2).
  *
  * Results are identical to the two-stage flow in every case (same lists, same arithmetic order). */
 int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
@@ -328,7 +328,7 @@ int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* i
 
 /* The backward of the forward whose scratch buffers `io` carries.  Gradient sums are added with float atomics
  * (as in the reference), so two runs agree to rounding, not bit for bit.  GFT_BWD_SPLIT=0 in the environment
- * keeps one wave per pixel quadrant (default: deep quadrants are walked by two waves).
+ * keeps one wave per pixel quadrant (default: deep quadrants are walked by up to eight waves).
  * With io->det_partials the sums are formed in a fixed order instead (bit-reproducible, slower: a test mode). */
 int gft_backward(void* hip_stream, const gft_config* cfg,
                  const gft_backward_io* io, int64_t binning_instances);
