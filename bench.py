@@ -1219,8 +1219,30 @@ def main():
     restarts = (api.last_call_stats.get("restarts", 0), api.last_call_stats.get("forwards", 0))
 
     exchange = None
+    composed_step = None
     if composed:
         fs = state["frame_step"]
+        # phases of the composed step by events on the launch stream (a third pass of 20 steps)
+        marks = []
+        fs.mark = lambda name: marks.append((name, torch.cuda.Event(enable_timing=True))) or marks[-1][1].record()
+        for _ in range(20):
+            step()
+        sync()
+        fs.mark = None
+        phase = {}
+        for (n0, e0), (n1, e1) in zip(marks, marks[1:]):
+            if n1 != "start":
+                phase[n1] = phase.get(n1, 0.0) + e0.elapsed_time(e1) / 20
+        n_dyn = int(fs.x_norm.size(0))
+        n_in = fs.net.xyz_input_ch + fs.net.t_input_ch
+        macs_fwd = n_in * 256 + 6 * 256 * 256 + (n_in + 256) * 256 + 51 * 256
+        tf_fwd = 2.0 * macs_fwd * n_dyn / (phase["network_forward"] * 1e-3) / 1e12 if phase.get("network_forward") else 0.0
+        composed_step = {"phase_ms": phase, "gpu_ms_sum_of_phases": sum(phase.values()),
+                         # the largest kernel of the composed step is the deformation network's forward walk (all dynamic
+                         # points: positions decide visibility, it cannot be thinned); fp32 results from six bf16 MFMAs per product
+                         "dominant": {"kernel": "k_deform_fwd_bf", "bound": "mfma", "achieved": tf_fwd, "peak": BF16_MFMA_PEAK_TFLOPS / 6.0,
+                                      "unit": "TFLOP/s", "frac": tf_fwd / (BF16_MFMA_PEAK_TFLOPS / 6.0), "points": n_dyn,
+                                      "avg_launch_ms": phase.get("network_forward")}}
         exchange = {"in_the_timed_step": True, "collectives_per_step": fs.exchanges / max(state["it"], 1),
                     "bucket_bytes": fs.exchanged_bytes, "backend": dist.get_backend() if dist is not None else None,
                     "ranks": dist.get_world_size() if dist is not None else 0,
@@ -1334,6 +1356,8 @@ def main():
         }
         if exchange is not None:
             out["deform_exchange"] = exchange
+        if composed_step is not None:
+            out["composed_step"] = composed_step
         # (the measurements beside the headline belong to the metric workload; named explicitly they run on any workload's
         # scene, e.g. `--workload C5 --extras varying_views`)
         if world == 1 and not args.no_extras and (args.workload == "metric" or args.extras != "all"):

@@ -50,6 +50,7 @@ class FrameStep:
         self.exchanges = 0          # collectives issued so far: one per iteration
         self.exchanged_bytes = 0
         self.last = None
+        self.mark = None            # optional `mark(name)` called at the phase boundaries (bench.py records events there)
 
     def frame_time(self, frame_id):
         return float(frame_id % self.num_frames) / max(self.num_frames - 1, 1)
@@ -57,17 +58,24 @@ class FrameStep:
     def __call__(self, frame_id):
         g, dev = self.g, self.g["xyz"].device
         n = self.x_norm.size(0)
+        mark = self.mark or (lambda name: None)
+        mark("start")
         t = torch.full((1, 1), self.frame_time(frame_id), device=dev, dtype=torch.float32).expand(n, -1)
         d_xyz, d_rot, d_sh, d_sh_p = self.net(self.x_norm, t)
+        mark("network_forward")
         ssp = torch.zeros((g["xyz"].size(0), 3), device=dev, dtype=torch.float32, requires_grad=True)
         rot = torch.nn.functional.normalize(g["rotation_raw"])
         m3, m2, op, sc, ro, shs, shp = self.assemble(g["xyz"], ssp, g["opacity"], g["scaling"], rot, g["rotation_raw"],
                                                      g["fc"], g["fp"], self.mask, d_xyz, d_rot, d_sh, d_sh_p)
+        mark("assembly")
         outs = self.render(frame_id, means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro)
+        mark("raster_forward")
         torch.autograd.backward([outs[i] for i in DIFFERENTIABLE_OUTPUTS], self.upstream)
+        mark("backward")               # rasterizer -> assembly -> network
         if self.dist is not None:
             self.exchanged_bytes = self.exchange(self.net, self.dist, average=True)
             self.exchanges += 1
+        mark("exchange")
         self.last = (outs, ssp)
         return outs
 
