@@ -86,8 +86,17 @@ _HINT_HEADROOM = 1.25
 # pointers or another extension is invisible here and would leave non-zero rows the next backward does not know about.
 # GFT_GRADS_REUSE_CHECK=1 verifies before every reuse that the unmarked rows are still zero (a debug mode: it reads the
 # whole buffer) and raises if not.
-_GRADS_REUSE = _os.environ.get("GFT_GRADS_REUSE", "1") != "0" and hasattr(torch._C, "_storage_Use_Count")
+_GRADS_REUSE = _os.environ.get("GFT_GRADS_REUSE", "1") != "0"
 _GRADS_CHECK = _os.environ.get("GFT_GRADS_REUSE_CHECK", "0") != "0"
+# "Nobody aliases the buffer any more" is read from the storage's use count where torch has the (private) counter
+# CUDA-graph trees use.  Without it -- another torch version; GFT_GRADS_LIFETIME=dlpack forces it -- the public route:
+# the pool owns the memory and never hands it out; every forward gets an ALIAS of it through DLPack (torch.from_dlpack of a
+# capsule made here), whose deleter torch calls when the last tensor on that alias dies.  The version counter of an alias
+# dies with it, so on this route in-place writes are not seen afterwards; the one writer that is not the caller's doing --
+# autograd summing a second gradient INTO a tensor it took over as a leaf's `.grad` -- is kept out by holding a reference
+# to the handed-out tensors until the next forward of the shape: autograd then copies into `.grad` instead of taking them
+# (a copy per directly fed leaf: the price of the fallback), everything else is the contract above.
+_USE_COUNT_API = hasattr(torch._C, "_storage_Use_Count") and _os.environ.get("GFT_GRADS_LIFETIME", "") != "dlpack"
 _grad_pool = {}           # (device, P, layout) -> list of {buf, dirty, version, base}
 _DENSE_SHARE = 0.3        # rows written by the last rows-only backward / P above which the tensors are written in full
 _DENSE_RUN = 15           # ... for this many backwards, before a rows-only one counts again
@@ -96,6 +105,57 @@ _GRAD_POOL_DEPTH = 3      # rasterizer calls of one iteration whose gradient ten
 
 def _storage_refs(t):
     return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+class _DLDevice(C.Structure):
+    _fields_ = [("device_type", C.c_int32), ("device_id", C.c_int32)]
+
+
+class _DLDataType(C.Structure):
+    _fields_ = [("code", C.c_uint8), ("bits", C.c_uint8), ("lanes", C.c_uint16)]
+
+
+class _DLTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("device", _DLDevice), ("ndim", C.c_int32), ("dtype", _DLDataType),
+                ("shape", C.POINTER(C.c_int64)), ("strides", C.POINTER(C.c_int64)), ("byte_offset", C.c_uint64)]
+
+
+class _DLManagedTensor(C.Structure):
+    pass
+
+
+_DL_DELETER = C.CFUNCTYPE(None, C.POINTER(_DLManagedTensor))
+_DLManagedTensor._fields_ = [("dl_tensor", _DLTensor), ("manager_ctx", C.c_void_p), ("deleter", _DL_DELETER)]
+_dl_live = {}             # token -> (struct, shape array, callback, entry): alive until torch has called the deleter
+_dl_token = [0]
+
+
+def _dl_alias(entry):
+    """A float32 tensor on the memory of ``entry["mem"]`` with a storage of its own (DLPack, kDLROCM): when the last tensor
+    on that storage dies torch calls the capsule's deleter, which marks the entry free."""
+    mem = entry["mem"]
+    _dl_token[0] += 1
+    token = _dl_token[0]
+    m = _DLManagedTensor()
+    shape = (C.c_int64 * 1)(mem.numel())
+    m.dl_tensor.data = mem.data_ptr()
+    m.dl_tensor.device = _DLDevice(10 if mem.is_cuda else 1, mem.device.index or 0)      # kDLROCM / kDLCPU
+    m.dl_tensor.ndim = 1
+    m.dl_tensor.dtype = _DLDataType(2, 32, 1)                                               # kDLFloat, 32 bits
+    m.dl_tensor.shape = shape
+    m.dl_tensor.strides = None
+    m.dl_tensor.byte_offset = 0
+
+    def released(_ptr, token=token, entry=entry):
+        entry["free"] = True
+        _dl_live.pop(token, None)
+    cb = _DL_DELETER(released)
+    m.deleter = cb
+    _dl_live[token] = (m, shape, cb, entry)
+    entry["free"] = False
+    new = C.pythonapi.PyCapsule_New
+    new.restype, new.argtypes = C.py_object, [C.c_void_p, C.c_char_p, C.c_void_p]
+    return torch.from_dlpack(new(C.addressof(m), b"dltensor", None))
 
 
 # The backward's accumulator (64 B per Gaussian) kept from one backward to the next.  The render backward adds to the rows
@@ -465,10 +525,17 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         if _GRADS_REUSE and P and pixels is not None and want_bw_records and not zero_fill:
             key = (dev.index, P, tuple(sorted(sizes.items())))
             pool = _grad_pool.setdefault(key, [])
-            # (a buffer somebody wrote to through a tensor -- autograd's in-place sum of two calls' gradients, clipping --
-            # is never trusted again: forgotten as soon as nobody references it)
-            pool[:] = [e for e in pool if e["buf"]._version == e["version"] or _storage_refs(e["buf"]) != e["base"]]
-            free = [e for e in pool if _storage_refs(e["buf"]) == e["base"] and e["buf"]._version == e["version"]]
+            if _USE_COUNT_API:
+                # (a buffer somebody wrote to through a tensor -- autograd's in-place sum of two calls' gradients, clipping
+                # -- is never trusted again: forgotten as soon as nobody references it)
+                pool[:] = [e for e in pool if e["buf"]._version == e["version"] or _storage_refs(e["buf"]) != e["base"]]
+                free = [e for e in pool if _storage_refs(e["buf"]) == e["base"] and e["buf"]._version == e["version"]]
+            else:
+                # (DLPack route: the references that kept autograd from taking the tensors over are dropped now; an alias
+                # nobody else holds dies right here and its deleter marks the entry free)
+                for e in pool:
+                    e["held"] = None
+                free = [e for e in pool if e["free"]]
             # `valid`: the last backward into this buffer returned without error, so every row is defined -- zero or marked
             # in `dirty`.  A buffer that was handed to a forward whose backward never ran (a render under grad used only
             # for logging, a loss skipped by a NaN guard) or failed holds rows nobody wrote: it may be taken again, but as
@@ -486,13 +553,16 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
                 report = torch.zeros((4,), dtype=torch.int32).pin_memory()
                 entry = dict(buf=buf, dirty=torch.zeros(((P + 3) // 4 * 4 + 144,), device=dev, dtype=torch.uint8), version=buf._version,
                              valid=False, report=report, report_np=report.numpy(), dense_left=0)
-                entry["base"] = _storage_refs(buf)
+                if _USE_COUNT_API:
+                    entry["base"] = _storage_refs(buf)
+                else:
+                    entry.update(mem=buf, buf=None, free=True, held=None)
                 pool.append(entry)
                 del pool[:-_GRAD_POOL_DEPTH]
                 if len(_grad_pool) > 8:
                     _grad_pool.pop(next(iter(_grad_pool)))
             entry["valid"] = False        # until the backward of this forward has returned (run_backward)
-            buf = entry["buf"]
+            buf = entry["buf"] if _USE_COUNT_API else _dl_alias(entry)
             pool_entry = entry
         else:
             buf = torch.empty((total,), **f32)
@@ -506,6 +576,8 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
                 g[k] = buf[o:o + _prod(v)].view(v)
                 o += sizes[k]
         g["offsets"] = buf[o:o + 2]
+        if entry is not None and not _USE_COUNT_API:
+            entry["held"] = (buf, [t for t in g.values() if t is not None])
         if reused_grads and _GRADS_CHECK:
             clean = entry["dirty"][:P] == 0
             for k, t in g.items():

@@ -916,6 +916,62 @@ def test_gradient_tensors_are_reused_only_when_nobody_holds_or_modified_them(ora
         api._grad_pool.clear()
 
 
+def test_gradient_tensors_are_reused_without_the_private_use_count(oracle, gpu):
+    """`torch._C._storage_Use_Count` is a private counter.  Without it (another torch version; GFT_GRADS_LIFETIME=dlpack)
+    the pool hands out DLPack aliases of its memory, whose deleter tells when nobody references them any more (public
+    API), and keeps autograd from taking the tensors over as `.grad` by holding them until the next forward.  Reuse works
+    the same: alternating scenes against the oracle with reuse from the second call on; a gradient the caller keeps
+    stays intact (it is autograd's copy on this route); a forward whose backward never ran leaves a buffer that is
+    written in full next time."""
+    from gftorf_amd import api
+    if not api._GRADS_REUSE:
+        pytest.skip("gradient-tensor reuse is off")
+    a = Hh.small_scene(P=3000, seed=61)
+    b = Hh.small_scene(P=3000, seed=62, opacity=0.7)
+    fa, ba = Hh.run_oracle(oracle, a)
+    fb, bb = Hh.run_oracle(oracle, b)
+    keep = api._USE_COUNT_API
+    api._USE_COUNT_API = False
+    api._grad_pool.clear()
+    try:
+        reused, held = [], None
+        for it in range(6):
+            sc, bw = (a, ba) if it % 2 == 0 else (b, bb)
+            out, grads, t = Hh.run_gpu(sc, gpu)
+            reused.append(api.last_call_stats["grads_reused"])
+            check_grads(bw, grads, sc)
+            if it == 2:
+                held = t["leaf"]["means3D"].grad
+                snapshot = held.clone()
+            del t, grads, out
+        assert reused[0] is False and all(reused[1:]), reused
+        assert torch.equal(held, snapshot)
+        pool = api._grad_pool[next(iter(api._grad_pool))]
+        assert len(pool) == 1 and "mem" in pool[0]                         # one buffer went round, on the DLPack route
+        # a forward under grad whose backward never runs
+        api._grad_pool.clear()
+        from gftorf_amd import GaussianRasterizer
+        ga = dict(a["gaussians"])
+        leaf = torch.tensor(ga["means3D"], dtype=torch.float32, device=gpu, requires_grad=True)
+        kw = {k: (torch.tensor(v, dtype=torch.float32, device=gpu) if v is not None else None) for k, v in ga.items() if k != "means3D"}
+        outs = GaussianRasterizer(raster_settings=Hh.gpu_settings(a, gpu))(
+            means3D=leaf, means2D=torch.zeros((3000, 3), device=gpu), opacities=kw["opacities"], shs=kw.get("shs"), shs_p=kw.get("shs_p"),
+            scales=kw.get("scales"), rotations=kw.get("rotations"), phase_offset=a["phase_offset"], dc_offset=a["dc_offset"])
+        pool = api._grad_pool[next(iter(api._grad_pool))]
+        pool[0]["mem"].fill_(float("nan"))
+        del outs, leaf
+        import gc
+        gc.collect()
+        for sc, bw in ((b, bb), (a, ba)):
+            out, grads, t = Hh.run_gpu(sc, gpu)
+            check_grads(bw, grads, sc)
+            del out, grads, t
+        assert api.last_call_stats["grads_reused"] is True
+    finally:
+        api._USE_COUNT_API = keep
+        api._grad_pool.clear()
+
+
 def test_kept_gradient_tensors_switch_between_rows_and_full_writes(oracle, gpu):
     """A kept set of gradient tensors is rewritten row by row while few Gaussians are blended and in full (coalesced, zeros
     included, every row marked) when most are: the rows backward leaves its row count in pinned host memory
