@@ -485,17 +485,22 @@ def deform_extra(dev, n=300_000, steps=10, warmup=3):
     macs = macs_fwd + (7 * 256 * 256 + 51 * 256) + macs_fwd
     tf = 2.0 * macs * n / (ms * 1e-3) / 1e12
     tf_fwd = 2.0 * macs_fwd * n / (fwd_ms * 1e-3) / 1e12
-    return {"what": "deformation network fwd+bwd (SURVEY 8(f)#2), %d points, fp32 results from six bf16 MFMAs per product "
-                    "(GFT_DEFORM_BF16X3=0: fp32-operand MFMA)" % n,
+    # matrix-pipe multiplies per fp32 product: the forward walk takes 3 (two fp16 planes per operand; GFT_DEFORM_FP16X2=0: 6,
+    # three bf16 planes), the backward walk and the weight-gradient kernel 6
+    fwd_terms = 3.0 if os.environ.get("GFT_DEFORM_FP16X2", "1") != "0" else 6.0
+    peak_fwd = BF16_MFMA_PEAK_TFLOPS / fwd_terms
+    peak_all = macs / (macs_fwd / peak_fwd + (macs - macs_fwd) / (BF16_MFMA_PEAK_TFLOPS / 6.0))
+    return {"what": "deformation network fwd+bwd (SURVEY 8(f)#2), %d points, fp32 results from the fp16 / bf16 matrix pipe: three "
+                    "fp16 MFMAs per product in the forward walk, six bf16 MFMAs in the backward kernels "
+                    "(GFT_DEFORM_FP16X2=0: six in the forward too; GFT_DEFORM_BF16X3=0: fp32-operand MFMA)" % n,
             "fwd_bwd_ms": ms, "inference_fwd_ms": fwd_ms, "eager_torch_ms": eager_ms, "speedup_vs_eager": eager_ms / ms,
             "algorithmic_flops": 2.0 * macs * n, "achieved_TFLOPs": tf, "inference_TFLOPs": tf_fwd,
             "architecture": dict(D=net.D, W=net.W, xyz_multires=net.xyz_multires, t_multires=net.t_multires,
                                  encoded_inputs=n_in, parameters=sum(p.numel() for p in net.parameters())),
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": BF16_MFMA_PEAK_TFLOPS / 6.0, "unit": "TFLOP/s",
-                         "frac": tf / (BF16_MFMA_PEAK_TFLOPS / 6.0),
-                         "note": "fp32 products on the bf16 matrix pipe cost six v_mfma_f32_32x32x16_bf16 each: "
-                                 "peak = 2500 / 6 TFLOP/s of fp32 multiply-adds"},
-            "inference_frac": tf_fwd / (BF16_MFMA_PEAK_TFLOPS / 6.0),
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": peak_all, "unit": "TFLOP/s", "frac": tf / peak_all,
+                         "note": "fp32 products on the 16-bit matrix pipe (2500 TFLOP/s dense): %d multiplies each in the forward "
+                                 "walk, 6 in the backward kernels; peak = the flop-weighted mix" % int(fwd_terms)},
+            "inference_frac": tf_fwd / peak_fwd, "inference_peak_TFLOPs": peak_fwd,
             "ratio_to_fp32_operand_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS,
             "points_per_s": n / (ms * 1e-3),
             "cpu_baseline": {"value": ns / cpu_s, "unit": "points/s", "cores": os.cpu_count(), "kind": "port",
@@ -1237,11 +1242,14 @@ def main():
         n_in = fs.net.xyz_input_ch + fs.net.t_input_ch
         macs_fwd = n_in * 256 + 6 * 256 * 256 + (n_in + 256) * 256 + 51 * 256
         tf_fwd = 2.0 * macs_fwd * n_dyn / (phase["network_forward"] * 1e-3) / 1e12 if phase.get("network_forward") else 0.0
+        fwd_terms = 3.0 if os.environ.get("GFT_DEFORM_FP16X2", "1") != "0" else 6.0
         composed_step = {"phase_ms": phase, "gpu_ms_sum_of_phases": sum(phase.values()),
                          # the largest kernel of the composed step is the deformation network's forward walk (all dynamic
-                         # points: positions decide visibility, it cannot be thinned); fp32 results from six bf16 MFMAs per product
-                         "dominant": {"kernel": "k_deform_fwd_bf", "bound": "mfma", "achieved": tf_fwd, "peak": BF16_MFMA_PEAK_TFLOPS / 6.0,
-                                      "unit": "TFLOP/s", "frac": tf_fwd / (BF16_MFMA_PEAK_TFLOPS / 6.0), "points": n_dyn,
+                         # points: positions decide visibility, it cannot be thinned); fp32 results from three fp16 MFMAs per
+                         # product (six bf16 ones with GFT_DEFORM_FP16X2=0)
+                         "dominant": {"kernel": "k_deform_fwd_h" if fwd_terms == 3.0 else "k_deform_fwd_bf", "bound": "mfma", "achieved": tf_fwd,
+                                      "peak": BF16_MFMA_PEAK_TFLOPS / fwd_terms,
+                                      "unit": "TFLOP/s", "frac": tf_fwd / (BF16_MFMA_PEAK_TFLOPS / fwd_terms), "points": n_dyn,
                                       "avg_launch_ms": phase.get("network_forward")}}
         exchange = {"in_the_timed_step": True, "collectives_per_step": fs.exchanges / max(state["it"], 1),
                     "bucket_bytes": fs.exchanged_bytes, "backend": dist.get_backend() if dist is not None else None,

@@ -709,6 +709,293 @@ __global__ __launch_bounds__(64 * DF_FWD_WAVES) void k_deform_fwd_bf(FwdArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Forward walk on TWO fp16 planes (round 4).  The bf16 split needs three planes and six multiplies per product
+// because a bf16 carries 8 mantissa bits.  An fp16 carries 11: x = hi + lo 2^-11 with hi = fp16(x), lo = fp16((x - hi) 2^11)
+// holds 22 bits, and a product is hi*hi + (hi*lo + lo*hi) 2^-11 -- THREE v_mfma_f32_32x32x16_f16, the cross terms in an
+// accumulator of their own that is scaled once per layer (the dropped lo*lo is below 2^-22 of the product).  Measured
+// against float64 (numpy model of the arithmetic, K = 256): 4-6e-7 of the max-norm, where a plain fp32 GEMM has 4.6e-7 and
+// the six bf16 terms 2.2e-7; the parity tests and their tolerances did not change.  Half the multiplies, two thirds of
+// the operand bytes from L2 and LDS.  The price is fp16's range: an activation or weight beyond 65504 becomes inf (and
+// shows as inf / NaN in the outputs); lo is scaled so that small values keep their bits (an fp16 subnormal still
+// resolves 6e-8 absolutely, the scaled remainder below that).  GFT_DEFORM_FP16X2=0 keeps the bf16 walk.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+constexpr float DF_H_SCALE = 2048.0f, DF_H_INV = 1.0f / 2048.0f;
+constexpr int64_t DF_H_FLOATS = DF_F_TOTAL;                    // forward stream only: 2 planes x 2 bytes per weight
+constexpr size_t DF_FWD_H_LDS = 2 * DF_BF_ACT_PLANE + 2 * DF_BF_ENC_PLANE + (size_t)DF_BIAS_FLOATS * 4;   // 99584
+
+__device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b)
+{
+    const f32x2_t v = {a, b};
+    const f16x2_t r = __builtin_convertvector(v, f16x2_t);
+    uint32_t u;
+    __builtin_memcpy(&u, &r, 4);
+    return u;
+}
+__device__ __forceinline__ float f16_lo(uint32_t u) { f16x2_t h; __builtin_memcpy(&h, &u, 4); return (float)h.x; }
+__device__ __forceinline__ float f16_hi(uint32_t u) { f16x2_t h; __builtin_memcpy(&h, &u, 4); return (float)h.y; }
+
+// fp32 packed forward stream ([k/4][n][4] per segment) -> fp16 planes ([plane][k/8][n][8] per segment)
+__global__ __launch_bounds__(256) void k_deform_pack_h(const float* __restrict__ packed, _Float16* __restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= DF_F_TOTAL) return;
+    int sgi = 0;
+    for (int q = 1; q <= 9; q++)
+        if (e >= df_seg(q).off) sgi = q;
+    const DfSeg sg = df_seg(sgi);
+    const int64_t r = e - sg.off;
+    const int kq = (int)(r / (sg.ncol * 4)), n = (int)((r >> 2) % sg.ncol), k = 4 * kq + (int)(r & 3);
+    const float x = packed[e];
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)((x - (float)hi) * DF_H_SCALE);
+    const int64_t plane = (int64_t)sg.K * sg.ncol;
+    const int64_t o = 2 * sg.off + ((int64_t)(k >> 3) * sg.ncol + n) * 8 + (k & 7);
+    out[o] = hi;
+    out[o + plane] = lo;
+}
+
+__device__ __forceinline__ WSeg wseg_h(const _Float16* hf, int s, int lane_col, int hh)
+{
+    const DfSeg sg = df_seg(s);
+    WSeg w;
+    w.p = reinterpret_cast<const uint4*>(hf + 2 * sg.off) + hh * sg.ncol + lane_col;
+    w.plane = sg.K * sg.ncol / 8;
+    return w;
+}
+
+template <int NC, int NCOL>
+__device__ __forceinline__ void load_wh(uint4 (&w)[2][NC], const WSeg& sgp, int chunk)
+{
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++) w[pl][ct] = sgp.p[(size_t)pl * sgp.plane + (size_t)(2 * chunk) * NCOL + 32 * ct];
+}
+
+__device__ __forceinline__ f16x8 as_h(const uint4& v)
+{
+    f16x8 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+
+// acc += hi * hi, accx += hi * lo + lo * hi over `nchunks` 16-k chunks (see stream_gemm_bf for the operand roles).  With
+// three multiplies per tile and chunk instead of six, a prefetch distance of two chunks is half the cycles it was: the
+// weights of a chunk (from L2) are asked for THREE chunks ahead (w0 = current, w1, w2 in flight, the fourth set loaded
+// here), the activations (from LDS) one chunk ahead; the loads go between the multiplies.
+template <int NR, int NC, int NCOL>
+__device__ __forceinline__ void stream_gemm_h(f32x16 (&acc)[NR][NC], f32x16 (&accx)[NR][NC], const char* a_lane, int a_row_bytes,
+                                              size_t a_plane_bytes, int nchunks, const WSeg& cur, const WSeg* nxt, uint4 (&w0)[2][NC],
+                                              uint4 (&w1)[2][NC], uint4 (&w2)[2][NC])
+{
+    uint4 acur[2][NR];
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+        for (int rt = 0; rt < NR; rt++)
+            acur[pl][rt] = *reinterpret_cast<const uint4*>(a_lane + pl * a_plane_bytes + (size_t)rt * 32 * a_row_bytes);
+    for (int c = 0; c < nchunks; c++) {
+        const bool last = c + 1 >= nchunks;
+        uint4 w3[2][NC], anxt[2][NR];
+        // (unconditional loads from valid addresses: conditionally filled arrays end up in scratch)
+        if (c + 3 < nchunks) load_wh<NC, NCOL>(w3, cur, c + 3);
+        else load_wh<NC, NCOL>(w3, nxt ? *nxt : cur, c + 3 - nchunks);
+        const int cn = last ? c : c + 1;
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+            for (int rt = 0; rt < NR; rt++)
+                anxt[pl][rt] = *reinterpret_cast<const uint4*>(a_lane + pl * a_plane_bytes + (size_t)rt * 32 * a_row_bytes + cn * 32);
+#pragma unroll
+        for (int rt = 0; rt < NR; rt++)
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++) {
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(w0[0][ct]), as_h(acur[0][rt]), acc[rt][ct], 0, 0, 0);
+                accx[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(w0[0][ct]), as_h(acur[1][rt]), accx[rt][ct], 0, 0, 0);
+                accx[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(w0[1][ct]), as_h(acur[0][rt]), accx[rt][ct], 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < 2 * NC + 2 * NR; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+            if (i < 2 * NC) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   // VMEM read
+            else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                              // DS read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++) { w0[pl][ct] = w1[pl][ct]; w1[pl][ct] = w2[pl][ct]; w2[pl][ct] = w3[pl][ct]; }
+#pragma unroll
+            for (int rt = 0; rt < NR; rt++) acur[pl][rt] = anxt[pl][rt];
+        }
+    }
+}
+
+// four consecutive fp32 values of one point -> 4 fp16 in each of the two planes (hi, scaled lo)
+__device__ __forceinline__ void store_split4_h(char* plane0, size_t plane_bytes, size_t byte_off, const float4& v)
+{
+    uint2 ph, pl;
+    ph.x = cvt_pk_f16(v.x, v.y);
+    ph.y = cvt_pk_f16(v.z, v.w);
+    pl.x = cvt_pk_f16((v.x - f16_lo(ph.x)) * DF_H_SCALE, (v.y - f16_hi(ph.x)) * DF_H_SCALE);
+    pl.y = cvt_pk_f16((v.z - f16_lo(ph.y)) * DF_H_SCALE, (v.w - f16_hi(ph.y)) * DF_H_SCALE);
+    *reinterpret_cast<uint2*>(plane0 + byte_off) = ph;
+    *reinterpret_cast<uint2*>(plane0 + plane_bytes + byte_off) = pl;
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(64 * DF_FWD_WAVES) void k_deform_fwd_h(FwdArgs a)
+{
+    extern __shared__ float4 df_lds[];
+    char* hP = reinterpret_cast<char*>(df_lds);                  // activation planes [2][64][264] fp16
+    char* eP = hP + 2 * DF_BF_ACT_PLANE;                         // encoding planes   [2][64][104] fp16
+    float* bL = reinterpret_cast<float*>(eP + 2 * DF_BF_ENC_PLANE);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    constexpr int NC = DF_FWD_NC, NT = 64 * DF_FWD_WAVES;
+    const int n0 = wave * 32 * NC;
+    const _Float16* hf = reinterpret_cast<const _Float16*>(a.packed + DF_PACKED_FLOATS + DF_BF_FLOATS);
+    WSeg seg = wseg_h(hf, 0, n0 + li, hh);
+    uint4 wcur[2][NC], wnx1[2][NC], wnx2[2][NC];
+    load_wh<NC, DF_W>(wcur, seg, 0);
+    load_wh<NC, DF_W>(wnx1, seg, 1);
+    load_wh<NC, DF_W>(wnx2, seg, 2);
+    for (int q = tid; q < DF_BIAS_FLOATS; q += NT) bL[q] = a.packed[DF_BIAS_BASE + q];
+
+    // positional encoding (time_utils.py:24-53), split into the two planes; the fp32 values are saved for the
+    // weight-gradient GEMMs
+    {
+        const int pt = tid & 63, grp = tid >> 6;
+        const int64_t p = p0 + pt;
+        auto put = [&](int col, float v) {
+            const _Float16 h = (_Float16)v;
+            _Float16* e = reinterpret_cast<_Float16*>(eP) + pt * DF_BE + col;
+            e[0] = h;
+            e[DF_BF_ENC_PLANE / 2] = (_Float16)((v - (float)h) * DF_H_SCALE);
+            if (SAVE) a.emb[p * DF_EMB + col] = v;
+        };
+        if (grp > 3) {
+        } else if (grp < 3) {
+            const float v = p < a.n ? a.xyz[3 * p + grp] : 0.f;
+            put(grp, v);
+            for (int f = 0; f < a.xm; f++) {
+                float sn, cs;
+                sincosf(v * (float)(1 << f), &sn, &cs);
+                put(3 + 6 * f + grp, sn);
+                put(6 + 6 * f + grp, cs);
+            }
+        } else {
+            const float v = p < a.n ? a.t[p * a.t_stride] : 0.f;
+            const int t0 = 3 + 6 * a.xm;
+            put(t0, v);
+            for (int f = 0; f < a.tm; f++) {
+                float sn, cs;
+                sincosf(v * (float)(1 << f), &sn, &cs);
+                put(t0 + 1 + 2 * f, sn);
+                put(t0 + 2 + 2 * f, cs);
+            }
+            for (int c = t0 + 1 + 2 * a.tm; c < DF_INK; c++) put(c, 0.f);
+        }
+    }
+    __syncthreads();
+
+    const char* h_lane = hP + (size_t)li * DF_BH * 2 + 16 * hh;
+    const char* e_lane = eP + (size_t)li * DF_BE * 2 + 16 * hh;
+    f32x16 acc[2][NC], accx[2][NC];
+    for (int l = 0; l < DF_D; l++) {
+        zero_acc(acc);
+        zero_acc(accx);
+        if (l == 0) {
+            const WSeg nx = wseg_h(hf, 1, n0 + li, hh);
+            stream_gemm_h<2, NC, DF_W>(acc, accx, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur, wnx1, wnx2);
+            seg = nx;
+        } else {
+            if (l == 5) {
+                const WSeg nx = wseg_h(hf, 6, n0 + li, hh);
+                stream_gemm_h<2, NC, DF_W>(acc, accx, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur, wnx1, wnx2);
+                seg = nx;
+            }
+            const int s_next = l < 4 ? l + 1 : l == 4 ? 5 : l < 7 ? l + 2 : -1;
+            if (s_next >= 0) {
+                const WSeg nx = wseg_h(hf, s_next, n0 + li, hh);
+                stream_gemm_h<2, NC, DF_W>(acc, accx, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, &nx, wcur, wnx1, wnx2);
+                seg = nx;
+            } else {
+                stream_gemm_h<2, NC, DF_W>(acc, accx, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur, wnx1, wnx2);
+            }
+        }
+        float4 bv[NC][4];
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                bv[ct][g] = *reinterpret_cast<const float4*>(bL + l * DF_W + n0 + 32 * ct + acc_col4(g, hh));
+        __syncthreads();      // every wave is past its last read of this layer's input
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int row = 32 * rt + li, col = n0 + 32 * ct + acc_col4(g, hh);
+                    float4 v;
+                    v.x = fmaxf(fmaf(accx[rt][ct][4 * g], DF_H_INV, acc[rt][ct][4 * g]) + bv[ct][g].x, 0.f);
+                    v.y = fmaxf(fmaf(accx[rt][ct][4 * g + 1], DF_H_INV, acc[rt][ct][4 * g + 1]) + bv[ct][g].y, 0.f);
+                    v.z = fmaxf(fmaf(accx[rt][ct][4 * g + 2], DF_H_INV, acc[rt][ct][4 * g + 2]) + bv[ct][g].z, 0.f);
+                    v.w = fmaxf(fmaf(accx[rt][ct][4 * g + 3], DF_H_INV, acc[rt][ct][4 * g + 3]) + bv[ct][g].w, 0.f);
+                    store_split4_h(hP, DF_BF_ACT_PLANE, ((size_t)row * DF_BH + col) * 2, v);
+                    if (SAVE) {
+                        *reinterpret_cast<float4*>(a.acts + ((int64_t)l * a.n_pad + p0 + row) * DF_W + col) = v;
+                        bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
+                                << acc_col4(g, hh);
+                    }
+                }
+                if (SAVE) {
+                    bits |= (uint32_t)__shfl_xor((int)bits, 32);
+                    if (hh == 0) a.signs[((int64_t)l * a.n_pad + p0 + 32 * rt + li) * DF_SIGN_WORDS + NC * wave + ct] = bits;
+                }
+            }
+        __syncthreads();
+    }
+    // heads: 64 columns, one 32 x 32 tile per wave (of the first four)
+    if (wave < 4) {
+        const int ct = wave & 1, r0 = 32 * (wave >> 1);
+        const WSeg hs = wseg_h(hf, 9, 32 * ct + li, hh);
+        uint4 hw[2][1], hw1[2][1], hw2[2][1];
+        load_wh<1, DF_HEAD>(hw, hs, 0);
+        load_wh<1, DF_HEAD>(hw1, hs, 1);
+        load_wh<1, DF_HEAD>(hw2, hs, 2);
+        f32x16 hacc[1][1], haccx[1][1];
+        zero_acc(hacc);
+        zero_acc(haccx);
+        stream_gemm_h<1, 1, DF_HEAD>(hacc, haccx, hP + (size_t)(r0 + li) * DF_BH * 2 + 16 * hh, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16,
+                                     hs, nullptr, hw, hw1, hw2);
+        const int64_t p = p0 + r0 + li;
+        if (p < a.n) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = 32 * ct + acc_col4(g, hh);
+                const float4 bq = *reinterpret_cast<const float4*>(bL + DF_D * DF_W + col);
+                const float4 v = make_float4(fmaf(haccx[0][0][4 * g], DF_H_INV, hacc[0][0][4 * g]) + bq.x,
+                                             fmaf(haccx[0][0][4 * g + 1], DF_H_INV, hacc[0][0][4 * g + 1]) + bq.y,
+                                             fmaf(haccx[0][0][4 * g + 2], DF_H_INV, hacc[0][0][4 * g + 2]) + bq.z,
+                                             fmaf(haccx[0][0][4 * g + 3], DF_H_INV, hacc[0][0][4 * g + 3]) + bq.w);
+                if (col < 48) {
+                    *reinterpret_cast<float4*>(a.d_sh + p * 48 + col) = v;
+                } else if (col == 48) {
+                    a.d_xyz[p * 3] = v.x;
+                    a.d_xyz[p * 3 + 1] = v.y;
+                    a.d_xyz[p * 3 + 2] = v.z;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward walk: dz_l = dh_l * [act_l > 0], dh_{l-1} = dz_l W_l
 // ---------------------------------------------------------------------------------------------
 struct BwdArgs {
@@ -1393,19 +1680,27 @@ bool bf16_planes()
     static const bool on = [] { const char* e = getenv("GFT_DEFORM_BF16X3"); return e ? atoi(e) != 0 : true; }();
     return on;
 }
+// GFT_DEFORM_FP16X2=0: the forward walk on three bf16 planes (six multiplies per product) instead of two fp16 planes (three)
+bool fp16_forward()
+{
+    static const bool on = [] { const char* e = getenv("GFT_DEFORM_FP16X2"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
 
 // the walks' dynamic-LDS opt-in, per device (gft_lds_opt_in)
 hipError_t set_attrs()
 {
-    static std::atomic<uint64_t> done[6];
-    struct { const void* fn; size_t bytes; } k[6] = {
+    static std::atomic<uint64_t> done[8];
+    struct { const void* fn; size_t bytes; } k[8] = {
+        {reinterpret_cast<const void*>(&k_deform_fwd_h<true>), DF_FWD_H_LDS},
+        {reinterpret_cast<const void*>(&k_deform_fwd_h<false>), DF_FWD_H_LDS},
         {reinterpret_cast<const void*>(&k_deform_bwd_bf), DF_BWD_BF_LDS},
         {reinterpret_cast<const void*>(&k_deform_fwd_bf<true>), DF_FWD_BF_LDS},
         {reinterpret_cast<const void*>(&k_deform_fwd_bf<false>), DF_FWD_BF_LDS},
         {reinterpret_cast<const void*>(&k_deform_fwd<true>), DF_FWD_LDS},
         {reinterpret_cast<const void*>(&k_deform_fwd<false>), DF_FWD_LDS},
         {reinterpret_cast<const void*>(&k_deform_bwd), DF_BWD_LDS}};
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < 8; i++) {
         const hipError_t e = gft_lds_opt_in(k[i].fn, k[i].bytes, done[i]);
         if (e != hipSuccess) return e;
     }
@@ -1463,7 +1758,7 @@ static int arch_inputs(int xm, int tm)
 
 extern "C" int gft_deform_inputs(int xyz_multires, int t_multires) { return arch_inputs(xyz_multires, t_multires); }
 
-extern "C" size_t gft_deform_packed_bytes(void) { return (size_t)(DF_PACKED_FLOATS + DF_BF_FLOATS) * sizeof(float); }
+extern "C" size_t gft_deform_packed_bytes(void) { return (size_t)(DF_PACKED_FLOATS + DF_BF_FLOATS + DF_H_FLOATS) * sizeof(float); }
 
 extern "C" size_t gft_deform_saved_bytes(int64_t n)
 {
@@ -1500,6 +1795,9 @@ extern "C" int gft_deform_pack(void* hip_stream, int xyz_multires, int t_multire
     hipLaunchKernelGGL(k_deform_pack_bf, dim3((unsigned)((DF_BF_ELEMS + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
                        (const float*)packed, reinterpret_cast<__bf16*>((float*)packed + DF_PACKED_FLOATS));
     GFT_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_deform_pack_h, dim3((unsigned)((DF_F_TOTAL + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                       (const float*)packed, reinterpret_cast<_Float16*>((float*)packed + DF_PACKED_FLOATS + DF_BF_FLOATS));
+    GFT_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
@@ -1531,7 +1829,10 @@ extern "C" int gft_deform_forward(void* hip_stream, int xyz_multires, int t_mult
     a.d_sh = d_sh;
     // all padded rows are computed and saved: the weight-gradient GEMMs multiply them (by zero gradients)
     const dim3 grid((unsigned)(a.n_pad / (32 * DF_NR_FWD)));
-    if (bf16_planes()) {
+    if (bf16_planes() && fp16_forward()) {
+        if (saved) hipLaunchKernelGGL(k_deform_fwd_h<true>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_H_LDS, (hipStream_t)hip_stream, a);
+        else hipLaunchKernelGGL(k_deform_fwd_h<false>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_H_LDS, (hipStream_t)hip_stream, a);
+    } else if (bf16_planes()) {
         if (saved) hipLaunchKernelGGL(k_deform_fwd_bf<true>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);
         else hipLaunchKernelGGL(k_deform_fwd_bf<false>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);
     } else {
