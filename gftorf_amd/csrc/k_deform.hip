@@ -710,20 +710,29 @@ __global__ __launch_bounds__(64 * DF_FWD_WAVES) void k_deform_fwd_bf(FwdArgs a)
 
 // ---------------------------------------------------------------------------------------------
 // Forward walk on TWO fp16 planes (round 4).  The bf16 split needs three planes and six multiplies per product
-// because a bf16 carries 8 mantissa bits.  An fp16 carries 11: x = hi + lo 2^-11 with hi = fp16(x), lo = fp16((x - hi) 2^11)
-// holds 22 bits, and a product is hi*hi + (hi*lo + lo*hi) 2^-11 -- THREE v_mfma_f32_32x32x16_f16, the cross terms in an
-// accumulator of their own that is scaled once per layer (the dropped lo*lo is below 2^-22 of the product).  Measured
-// against float64 (numpy model of the arithmetic, K = 256): 4-6e-7 of the max-norm, where a plain fp32 GEMM has 4.6e-7 and
-// the six bf16 terms 2.2e-7; the parity tests and their tolerances did not change.  Half the multiplies, two thirds of
-// the operand bytes from L2 and LDS.  The price is fp16's range: an activation or weight beyond 65504 becomes inf (and
-// shows as inf / NaN in the outputs); lo is scaled so that small values keep their bits (an fp16 subnormal still
-// resolves 6e-8 absolutely, the scaled remainder below that).  GFT_DEFORM_FP16X2=0 keeps the bf16 walk.
+// because a bf16 carries 8 mantissa bits.  An fp16 carries 11: x = hi + lo with hi = fp16(x), lo = fp16(x - hi) holds 22
+// bits, and a product is hi*hi + hi*lo + lo*hi -- THREE v_mfma_f32_32x32x16_f16 into one fp32 accumulator (the dropped
+// lo*lo is below 2^-22 of the product).  fp16 has 5 exponent bits, so both operands are moved into its range first:
+// weights are stored times 2^10, activations times 2^4, and the accumulator is scaled by 2^-14 once per tile.  With that
+// a weight of magnitude 1e-4 .. 64 and an activation of 8e-3 .. 4094 have a NORMAL lo part (the full 22 bits); smaller
+// ones have a subnormal lo, which still resolves 6e-8 of the scaled value (4e-9 of an activation, 6e-11 of a weight:
+// absolute errors far below the fp32 rounding of the sums they enter) -- the matrix pipe honours fp16 subnormals
+// (profiles/experiments/mfma_f16_subnormal.hip).  Measured against float64 (numpy model of the arithmetic, K = 256):
+// 3-4e-7 of the max-norm, where a plain fp32 GEMM has 4.6e-7; the parity tests and their tolerances did not change.  Half
+// the multiplies of the bf16 walk, two thirds of its operand bytes from L2 and LDS, a third of its accumulators.  The
+// price is the range: a weight beyond 64 or an activation beyond 4094 becomes inf (and shows as inf / NaN in the
+// outputs).  GFT_DEFORM_FP16X2=0 keeps the bf16 walk, which has the fp32 range.
 // ---------------------------------------------------------------------------------------------
+#ifndef DF_ABL
+#define DF_ABL 0            // timing ablations of the fp16 forward (profiles/deform_ablate.sh): never set in the product build
+#endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-constexpr float DF_H_SCALE = 2048.0f, DF_H_INV = 1.0f / 2048.0f;
+constexpr float DF_H_WSCALE = 1024.0f, DF_H_ASCALE = 16.0f, DF_H_OUT = 1.0f / (1024.0f * 16.0f);
 constexpr int64_t DF_H_FLOATS = DF_F_TOTAL;                    // forward stream only: 2 planes x 2 bytes per weight
 constexpr size_t DF_FWD_H_LDS = 2 * DF_BF_ACT_PLANE + 2 * DF_BF_ENC_PLANE + (size_t)DF_BIAS_FLOATS * 4;   // 99584
+constexpr size_t DF_FWD_H_SAVE_LDS = 2 * DF_BF_ACT_PLANE + (size_t)DF_BIAS_FLOATS * 4;                    // 72960: two per CU
+constexpr int DF_FWD_H_SAVE_WAVES = 4;
 
 __device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b)
 {
@@ -747,31 +756,62 @@ __global__ __launch_bounds__(256) void k_deform_pack_h(const float* __restrict__
     const DfSeg sg = df_seg(sgi);
     const int64_t r = e - sg.off;
     const int kq = (int)(r / (sg.ncol * 4)), n = (int)((r >> 2) % sg.ncol), k = 4 * kq + (int)(r & 3);
-    const float x = packed[e];
+    const float x = packed[e] * DF_H_WSCALE;
     const _Float16 hi = (_Float16)x;
-    const _Float16 lo = (_Float16)((x - (float)hi) * DF_H_SCALE);
+    const _Float16 lo = (_Float16)(x - (float)hi);
     const int64_t plane = (int64_t)sg.K * sg.ncol;
     const int64_t o = 2 * sg.off + ((int64_t)(k >> 3) * sg.ncol + n) * 8 + (k & 7);
     out[o] = hi;
     out[o + plane] = lo;
 }
 
-__device__ __forceinline__ WSeg wseg_h(const _Float16* hf, int s, int lane_col, int hh)
+// Memory operands of this kernel go through buffer instructions: a resource in four scalar registers, a wave-uniform
+// byte offset in a fifth and this lane's 32-bit offset in ONE vector register (`buffer_load_dwordx4 v, v_off, s[rsrc],
+// s_off offen offset:imm`).  With flat pointers every (plane, tile) of the weights, of the saved activations and of the
+// encoding kept a 64-bit vector address alive across the walk -- dozens of registers that the accumulators and the
+// prefetched operands need.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, const float4& v)
+{
+    u32x4_t u;
+    __builtin_memcpy(&u, &v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, (int)soff, 0);
+}
+
+// a weight segment of the fp16 stream
+struct WSegH {
+    uint32_t off;                          // bytes from the start of the stream to plane 0, chunk 0 (wave-uniform)
+    uint32_t plane;                        // bytes between planes (wave-uniform)
+    uint32_t lane;                         // bytes: [h][first column + lane]
+};
+
+__device__ __forceinline__ WSegH wseg_h(int s, int lane_col, int hh)
 {
     const DfSeg sg = df_seg(s);
-    WSeg w;
-    w.p = reinterpret_cast<const uint4*>(hf + 2 * sg.off) + hh * sg.ncol + lane_col;
-    w.plane = sg.K * sg.ncol / 8;
+    WSegH w;
+    w.off = (uint32_t)sg.off * 4u;
+    w.plane = (uint32_t)(sg.K * sg.ncol) * 2u;
+    w.lane = (uint32_t)(hh * sg.ncol + lane_col) * 16u;
     return w;
 }
 
 template <int NC, int NCOL>
-__device__ __forceinline__ void load_wh(uint4 (&w)[2][NC], const WSeg& sgp, int chunk)
+__device__ __forceinline__ void load_wh(uint4 (&w)[2][NC], __amdgpu_buffer_rsrc_t rw, const WSegH& sgp, int chunk)
 {
 #pragma unroll
     for (int pl = 0; pl < 2; pl++)
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) w[pl][ct] = sgp.p[(size_t)pl * sgp.plane + (size_t)(2 * chunk) * NCOL + 32 * ct];
+        for (int ct = 0; ct < NC; ct++)
+            w[pl][ct] = buf_load16(rw, sgp.lane + 512u * ct, sgp.off + (uint32_t)pl * sgp.plane + (uint32_t)((DF_ABL & 2) ? (chunk & 1) : chunk) * (2 * NCOL * 16));
 }
 
 __device__ __forceinline__ f16x8 as_h(const uint4& v)
@@ -781,13 +821,13 @@ __device__ __forceinline__ f16x8 as_h(const uint4& v)
     return r;
 }
 
-// acc += hi * hi, accx += hi * lo + lo * hi over `nchunks` 16-k chunks (see stream_gemm_bf for the operand roles).  With
+// acc += hi * hi + hi * lo + lo * hi over `nchunks` 16-k chunks (see stream_gemm_bf for the operand roles).  With
 // three multiplies per tile and chunk instead of six, a prefetch distance of two chunks is half the cycles it was: the
 // weights of a chunk (from L2) are asked for THREE chunks ahead (w0 = current, w1, w2 in flight, the fourth set loaded
 // here), the activations (from LDS) one chunk ahead; the loads go between the multiplies.
 template <int NR, int NC, int NCOL>
-__device__ __forceinline__ void stream_gemm_h(f32x16 (&acc)[NR][NC], f32x16 (&accx)[NR][NC], const char* a_lane, int a_row_bytes,
-                                              size_t a_plane_bytes, int nchunks, const WSeg& cur, const WSeg* nxt, uint4 (&w0)[2][NC],
+__device__ __forceinline__ void stream_gemm_h(f32x16 (&acc)[NR][NC], const char* a_lane, int a_row_bytes,
+                                              size_t a_plane_bytes, int nchunks, __amdgpu_buffer_rsrc_t rw, const WSegH& cur, const WSegH* nxt, uint4 (&w0)[2][NC],
                                               uint4 (&w1)[2][NC], uint4 (&w2)[2][NC])
 {
     uint4 acur[2][NR];
@@ -800,22 +840,24 @@ __device__ __forceinline__ void stream_gemm_h(f32x16 (&acc)[NR][NC], f32x16 (&ac
         const bool last = c + 1 >= nchunks;
         uint4 w3[2][NC], anxt[2][NR];
         // (unconditional loads from valid addresses: conditionally filled arrays end up in scratch)
-        if (c + 3 < nchunks) load_wh<NC, NCOL>(w3, cur, c + 3);
-        else load_wh<NC, NCOL>(w3, nxt ? *nxt : cur, c + 3 - nchunks);
+        if (c + 3 < nchunks) load_wh<NC, NCOL>(w3, rw, cur, c + 3);
+        else load_wh<NC, NCOL>(w3, rw, nxt ? *nxt : cur, c + 3 - nchunks);
         const int cn = last ? c : c + 1;
 #pragma unroll
         for (int pl = 0; pl < 2; pl++)
 #pragma unroll
             for (int rt = 0; rt < NR; rt++)
                 anxt[pl][rt] = *reinterpret_cast<const uint4*>(a_lane + pl * a_plane_bytes + (size_t)rt * 32 * a_row_bytes + cn * 32);
+        // term-major: consecutive multiplies go to different accumulators
+        // term-major: consecutive multiplies go to different accumulators
 #pragma unroll
-        for (int rt = 0; rt < NR; rt++)
+        for (int term = 0; term < ((DF_ABL & 8) ? 1 : 3); term++)
 #pragma unroll
-            for (int ct = 0; ct < NC; ct++) {
-                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(w0[0][ct]), as_h(acur[0][rt]), acc[rt][ct], 0, 0, 0);
-                accx[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(w0[0][ct]), as_h(acur[1][rt]), accx[rt][ct], 0, 0, 0);
-                accx[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(w0[1][ct]), as_h(acur[0][rt]), accx[rt][ct], 0, 0, 0);
-            }
+            for (int rt = 0; rt < NR; rt++)
+#pragma unroll
+                for (int ct = 0; ct < NC; ct++)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(w0[term == 2 ? 1 : 0][ct]), as_h(acur[term == 1 ? 1 : 0][rt]),
+                                                                         acc[rt][ct], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2 * NC + 2 * NR; i++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
@@ -833,36 +875,181 @@ __device__ __forceinline__ void stream_gemm_h(f32x16 (&acc)[NR][NC], f32x16 (&ac
     }
 }
 
-// four consecutive fp32 values of one point -> 4 fp16 in each of the two planes (hi, scaled lo)
+// sin and cos of a moderate argument (the encoding's 2^f x with x in [0, 1]: below 2^15 here, beyond that the library
+// routine): three-constant Cody-Waite reduction by pi/2 with fused multiply-adds, then the Cephes single-precision
+// polynomials on [-pi/4, pi/4] -- about 1 ulp, a third of the instructions of the library's sincosf, which also carries
+// the large-argument reduction.  The encoding phase was a tenth of the kernel.
+__device__ __forceinline__ void sincos_enc(float a, float& sn, float& cs)
+{
+    if (!(fabsf(a) < 32768.f)) {
+        sincosf(a, &sn, &cs);
+        return;
+    }
+    const float k = rintf(a * 0.636619772367581343f);
+    float r = fmaf(-k, 1.57079625129699707031f, a);
+    r = fmaf(-k, 7.54978941586159635335e-08f, r);
+    r = fmaf(-k, 5.39030252995776476554e-15f, r);
+    const float z = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k;
+    const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+    sn = (q & 2) ? -s0 : s0;
+    cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// x - (float)h for the low / high half of a packed fp16 pair in ONE instruction (the mixed-precision fma converts the half)
+__device__ __forceinline__ float sub_f16_lo(float x, uint32_t h)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+    return r;
+}
+__device__ __forceinline__ float sub_f16_hi(float x, uint32_t h)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+    return r;
+}
+// 1 if the fp32 value is positive, else 0 (one v_med3_i32: -0 and +0 are not positive integers)
+__device__ __forceinline__ uint32_t positive_bit(float v)
+{
+    uint32_t b;
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(b) : "v"(v));      // (written as min / max the compiler makes it a compare and a select)
+    return b;
+}
+
+__device__ __forceinline__ float4 as_f4(const uint4& u)
+{
+    float4 f;
+    __builtin_memcpy(&f, &u, 16);
+    return f;
+}
+
+// eight consecutive fp32 values -> the two fp16 operand fragments (hi, lo of the scaled value), as store_split4_h writes them
+__device__ __forceinline__ void split8_h(float4 u, float4 v, uint4& hi, uint4& lo)
+{
+    u.x *= DF_H_ASCALE; u.y *= DF_H_ASCALE; u.z *= DF_H_ASCALE; u.w *= DF_H_ASCALE;
+    v.x *= DF_H_ASCALE; v.y *= DF_H_ASCALE; v.z *= DF_H_ASCALE; v.w *= DF_H_ASCALE;
+    hi.x = cvt_pk_f16(u.x, u.y);
+    hi.y = cvt_pk_f16(u.z, u.w);
+    hi.z = cvt_pk_f16(v.x, v.y);
+    hi.w = cvt_pk_f16(v.z, v.w);
+    lo.x = cvt_pk_f16(sub_f16_lo(u.x, hi.x), sub_f16_hi(u.y, hi.x));
+    lo.y = cvt_pk_f16(sub_f16_lo(u.z, hi.y), sub_f16_hi(u.w, hi.y));
+    lo.z = cvt_pk_f16(sub_f16_lo(v.x, hi.z), sub_f16_hi(v.y, hi.z));
+    lo.w = cvt_pk_f16(sub_f16_lo(v.z, hi.w), sub_f16_hi(v.w, hi.w));
+}
+
+// stream_gemm_h with the left operand read as fp32 rows of global memory (the saved encoding, written by this workgroup
+// before its first barrier) and split into the two planes in registers: the skip connection of layer 5 without the encoding
+// resident in LDS.  `re` = the workgroup's 64 rows, `e_lane` = byte offset of this lane's row of the first
+// 32-row tile at column 8 * (lane / 32).
+template <int NC, int NCOL>
+__device__ __forceinline__ void stream_gemm_h_emb(f32x16 (&acc)[2][NC], __amdgpu_buffer_rsrc_t re, uint32_t e_lane, int nchunks,
+                                                  __amdgpu_buffer_rsrc_t rw, const WSegH& cur, const WSegH* nxt, uint4 (&w0)[2][NC], uint4 (&w1)[2][NC],
+                                                  uint4 (&w2)[2][NC])
+{
+    uint4 raw[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++) {
+        raw[rt][0] = buf_load16(re, e_lane, rt * (32 * DF_EMB * 4));
+        raw[rt][1] = buf_load16(re, e_lane + 16, rt * (32 * DF_EMB * 4));
+    }
+    for (int c = 0; c < nchunks; c++) {
+        const bool last = c + 1 >= nchunks;
+        uint4 acur[2][2], w3[2][NC];
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) split8_h(as_f4(raw[rt][0]), as_f4(raw[rt][1]), acur[0][rt], acur[1][rt]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 3 < nchunks) load_wh<NC, NCOL>(w3, rw, cur, c + 3);
+        else load_wh<NC, NCOL>(w3, rw, nxt ? *nxt : cur, c + 3 - nchunks);
+        const int cn = last ? c : c + 1;
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+            raw[rt][0] = buf_load16(re, e_lane, rt * (32 * DF_EMB * 4) + cn * 64);
+            raw[rt][1] = buf_load16(re, e_lane + 16, rt * (32 * DF_EMB * 4) + cn * 64);
+        }
+#pragma unroll
+        for (int term = 0; term < 3; term++)
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+                for (int ct = 0; ct < NC; ct++)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(w0[term == 2 ? 1 : 0][ct]), as_h(acur[term == 1 ? 1 : 0][rt]),
+                                                                         acc[rt][ct], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * NC + 4; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                   // VMEM read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++) { w0[pl][ct] = w1[pl][ct]; w1[pl][ct] = w2[pl][ct]; w2[pl][ct] = w3[pl][ct]; }
+    }
+}
+
+// four consecutive fp32 values of one point, ALREADY times the activation scale -> 4 fp16 in each of the two planes (hi, lo)
 __device__ __forceinline__ void store_split4_h(char* plane0, size_t plane_bytes, size_t byte_off, const float4& v)
 {
     uint2 ph, pl;
     ph.x = cvt_pk_f16(v.x, v.y);
     ph.y = cvt_pk_f16(v.z, v.w);
-    pl.x = cvt_pk_f16((v.x - f16_lo(ph.x)) * DF_H_SCALE, (v.y - f16_hi(ph.x)) * DF_H_SCALE);
-    pl.y = cvt_pk_f16((v.z - f16_lo(ph.y)) * DF_H_SCALE, (v.w - f16_hi(ph.y)) * DF_H_SCALE);
+    pl.x = cvt_pk_f16(sub_f16_lo(v.x, ph.x), sub_f16_hi(v.y, ph.x));
+    pl.y = cvt_pk_f16(sub_f16_lo(v.z, ph.y), sub_f16_hi(v.w, ph.y));
     *reinterpret_cast<uint2*>(plane0 + byte_off) = ph;
     *reinterpret_cast<uint2*>(plane0 + plane_bytes + byte_off) = pl;
 }
 
-template <bool SAVE>
-__global__ __launch_bounds__(64 * DF_FWD_WAVES) void k_deform_fwd_h(FwdArgs a)
+// Two shapes of the same walk.  Inference (SAVE = false): 8 waves of 32 columns, the encoding resident in LDS for the skip
+// connection, one workgroup per CU.  Training (SAVE = true): the encoding is in global memory anyway (saved for the weight
+// gradients), so it is built in the activation rows for layer 0 and read back from there for layer 5; without its planes the
+// workgroup needs 73 KB of LDS and TWO fit a CU, as 4 waves of 64 columns each (the register budget of 2 waves per SIMD
+// stays): one workgroup's epilogue (bias, ReLU, split, stores: no matrix work, all its waves between the same two
+// barriers) now overlaps the other's multiplies, and a wave reads half the LDS bytes per multiply.
+template <bool SAVE, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_deform_fwd_h(FwdArgs a)
 {
     extern __shared__ float4 df_lds[];
+    constexpr bool ENC_LDS = !SAVE;
     char* hP = reinterpret_cast<char*>(df_lds);                  // activation planes [2][64][264] fp16
-    char* eP = hP + 2 * DF_BF_ACT_PLANE;                         // encoding planes   [2][64][104] fp16
-    float* bL = reinterpret_cast<float*>(eP + 2 * DF_BF_ENC_PLANE);
+    char* eP = ENC_LDS ? hP + 2 * DF_BF_ACT_PLANE : hP;          // encoding planes   [2][64][104] fp16, or in the activation rows
+    float* bL = reinterpret_cast<float*>(hP + 2 * DF_BF_ACT_PLANE + (ENC_LDS ? 2 * DF_BF_ENC_PLANE : 0));
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * 64;
-    constexpr int NC = DF_FWD_NC, NT = 64 * DF_FWD_WAVES;
+    constexpr int NC = 8 / NW, NT = 64 * NW;
+    constexpr int E_ROW = ENC_LDS ? DF_BE : DF_BH;               // fp16 per encoding row
+    constexpr size_t E_PLANE = ENC_LDS ? DF_BF_ENC_PLANE : DF_BF_ACT_PLANE;
     const int n0 = wave * 32 * NC;
-    const _Float16* hf = reinterpret_cast<const _Float16*>(a.packed + DF_PACKED_FLOATS + DF_BF_FLOATS);
-    WSeg seg = wseg_h(hf, 0, n0 + li, hh);
+    // (DF_ABL & 16: phase time stamps of every wave into the workgroup's d_sh rows instead of the results)
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (DF_ABL & 16) {
+            const uint64_t tt = __builtin_amdgcn_s_memtime();
+            if (lane == 0) reinterpret_cast<uint64_t*>(a.d_sh + p0 * 48)[wave * 48 + stamp_i] = tt;
+            stamp_i++;
+        }
+    };
+    stamp();
+    const __amdgpu_buffer_rsrc_t rw = buf_rsrc(a.packed + DF_PACKED_FLOATS + DF_BF_FLOATS, (uint32_t)DF_H_FLOATS * 4u);
+    WSegH seg = wseg_h(0, n0 + li, hh);
     uint4 wcur[2][NC], wnx1[2][NC], wnx2[2][NC];
-    load_wh<NC, DF_W>(wcur, seg, 0);
-    load_wh<NC, DF_W>(wnx1, seg, 1);
-    load_wh<NC, DF_W>(wnx2, seg, 2);
-    for (int q = tid; q < DF_BIAS_FLOATS; q += NT) bL[q] = a.packed[DF_BIAS_BASE + q];
+    load_wh<NC, DF_W>(wcur, rw, seg, 0);
+    load_wh<NC, DF_W>(wnx1, rw, seg, 1);
+    load_wh<NC, DF_W>(wnx2, rw, seg, 2);
+    // this thread's input of the encoding (asked for before anything waits) and the biases (all loads, then all stores)
+    const float enc_in = (p0 + (tid & 63)) < a.n ? (((tid >> 6) & 3) < 3 ? a.xyz[3 * (p0 + (tid & 63)) + ((tid >> 6) & 3)] : a.t[(p0 + (tid & 63)) * a.t_stride]) : 0.f;
+    {
+        constexpr int NB = (DF_BIAS_FLOATS + NT - 1) / NT;
+        float bv[NB];
+#pragma unroll
+        for (int q = 0; q < NB; q++) bv[q] = tid + q * NT < DF_BIAS_FLOATS ? a.packed[DF_BIAS_BASE + tid + q * NT] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NB; q++)
+            if (tid + q * NT < DF_BIAS_FLOATS) bL[tid + q * NT] = bv[q];
+    }
 
     // positional encoding (time_utils.py:24-53), split into the two planes; the fp32 values are saved for the
     // weight-gradient GEMMs
@@ -870,119 +1057,158 @@ __global__ __launch_bounds__(64 * DF_FWD_WAVES) void k_deform_fwd_h(FwdArgs a)
         const int pt = tid & 63, grp = tid >> 6;
         const int64_t p = p0 + pt;
         auto put = [&](int col, float v) {
-            const _Float16 h = (_Float16)v;
-            _Float16* e = reinterpret_cast<_Float16*>(eP) + pt * DF_BE + col;
+            const float vs = v * DF_H_ASCALE;
+            const _Float16 h = (_Float16)vs;
+            _Float16* e = reinterpret_cast<_Float16*>(eP) + pt * E_ROW + col;
             e[0] = h;
-            e[DF_BF_ENC_PLANE / 2] = (_Float16)((v - (float)h) * DF_H_SCALE);
+            e[E_PLANE / 2] = (_Float16)(vs - (float)h);
             if (SAVE) a.emb[p * DF_EMB + col] = v;
         };
-        if (grp > 3) {
-        } else if (grp < 3) {
-            const float v = p < a.n ? a.xyz[3 * p + grp] : 0.f;
-            put(grp, v);
-            for (int f = 0; f < a.xm; f++) {
+        // a 64-thread group per input (x, y, z, t); with 8 waves two groups share an input's octaves
+        constexpr int NH = NW / 4;
+        const int inp = grp & 3, half = grp >> 2;
+        if (inp < 3) {
+            const float v = enc_in;
+            if (half == 0) put(inp, v);
+            for (int f = a.xm * half / NH; f < a.xm * (half + 1) / NH; f++) {
                 float sn, cs;
-                sincosf(v * (float)(1 << f), &sn, &cs);
-                put(3 + 6 * f + grp, sn);
-                put(6 + 6 * f + grp, cs);
+                sincos_enc(v * (float)(1 << f), sn, cs);
+                put(3 + 6 * f + inp, sn);
+                put(6 + 6 * f + inp, cs);
             }
         } else {
-            const float v = p < a.n ? a.t[p * a.t_stride] : 0.f;
+            const float v = enc_in;
             const int t0 = 3 + 6 * a.xm;
-            put(t0, v);
-            for (int f = 0; f < a.tm; f++) {
+            if (half == 0) put(t0, v);
+            for (int f = a.tm * half / NH; f < a.tm * (half + 1) / NH; f++) {
                 float sn, cs;
-                sincosf(v * (float)(1 << f), &sn, &cs);
+                sincos_enc(v * (float)(1 << f), sn, cs);
                 put(t0 + 1 + 2 * f, sn);
                 put(t0 + 2 + 2 * f, cs);
             }
-            for (int c = t0 + 1 + 2 * a.tm; c < DF_INK; c++) put(c, 0.f);
+            if (half == NH - 1)
+                for (int c = t0 + 1 + 2 * a.tm; c < DF_INK; c++) put(c, 0.f);
         }
     }
+    stamp();
     __syncthreads();
+    stamp();
 
     const char* h_lane = hP + (size_t)li * DF_BH * 2 + 16 * hh;
-    const char* e_lane = eP + (size_t)li * DF_BE * 2 + 16 * hh;
-    f32x16 acc[2][NC], accx[2][NC];
+    const char* e_lane = eP + (size_t)li * E_ROW * 2 + 16 * hh;
+    f32x16 acc[2][NC];
     for (int l = 0; l < DF_D; l++) {
+        // (the accumulators start at zero and the bias is added in the epilogue: started AT the scaled bias the walk took
+        // 0.45 ms longer and its error against float64 grew five-fold -- measured, profiles/README)
         zero_acc(acc);
-        zero_acc(accx);
         if (l == 0) {
-            const WSeg nx = wseg_h(hf, 1, n0 + li, hh);
-            stream_gemm_h<2, NC, DF_W>(acc, accx, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur, wnx1, wnx2);
+            const WSegH nx = wseg_h(1, n0 + li, hh);
+            stream_gemm_h<2, NC, DF_W>(acc, e_lane, E_ROW * 2, E_PLANE, DF_INK / 16, rw, seg, &nx, wcur, wnx1, wnx2);
             seg = nx;
         } else {
             if (l == 5) {
-                const WSeg nx = wseg_h(hf, 6, n0 + li, hh);
-                stream_gemm_h<2, NC, DF_W>(acc, accx, e_lane, DF_BE * 2, DF_BF_ENC_PLANE, DF_INK / 16, seg, &nx, wcur, wnx1, wnx2);
+                const WSegH nx = wseg_h(6, n0 + li, hh);
+                if (ENC_LDS)
+                    stream_gemm_h<2, NC, DF_W>(acc, e_lane, E_ROW * 2, E_PLANE, DF_INK / 16, rw, seg, &nx, wcur, wnx1, wnx2);
+                else
+                    stream_gemm_h_emb<NC, DF_W>(acc, buf_rsrc(a.emb + p0 * DF_EMB, 64u * DF_EMB * 4u), (uint32_t)(li * DF_EMB + 8 * hh) * 4u, DF_INK / 16, rw, seg, &nx, wcur, wnx1, wnx2);
                 seg = nx;
             }
             const int s_next = l < 4 ? l + 1 : l == 4 ? 5 : l < 7 ? l + 2 : -1;
             if (s_next >= 0) {
-                const WSeg nx = wseg_h(hf, s_next, n0 + li, hh);
-                stream_gemm_h<2, NC, DF_W>(acc, accx, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, &nx, wcur, wnx1, wnx2);
+                const WSegH nx = wseg_h(s_next, n0 + li, hh);
+                stream_gemm_h<2, NC, DF_W>(acc, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, rw, seg, &nx, wcur, wnx1, wnx2);
                 seg = nx;
             } else {
-                stream_gemm_h<2, NC, DF_W>(acc, accx, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur, wnx1, wnx2);
+                stream_gemm_h<2, NC, DF_W>(acc, h_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, rw, seg, nullptr, wcur, wnx1, wnx2);
             }
         }
-        float4 bv[NC][4];
-#pragma unroll
-        for (int ct = 0; ct < NC; ct++)
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-                bv[ct][g] = *reinterpret_cast<const float4*>(bL + l * DF_W + n0 + 32 * ct + acc_col4(g, hh));
+        stamp();
         __syncthreads();      // every wave is past its last read of this layer's input
+        stamp();
+        // Sixteen 4-value groups per lane.  Every address below is ONE lane register plus an immediate: the registers are
+        // made opaque per layer so that the sixteen sums are not hoisted out of the layer loop as sixteen registers each
+        // (they were, and were spilled).
+        uint32_t st_lane = (uint32_t)(li * DF_BH + n0 + 4 * hh) * 2u;     // bytes into plane 0 of the activations
+        uint32_t sv_lane = (uint32_t)(li * DF_W + n0 + 4 * hh) * 4u;      // bytes into the workgroup's saved rows
+        asm volatile("" : "+v"(st_lane), "+v"(sv_lane));
+        char* st = hP + st_lane;
+        const __amdgpu_buffer_rsrc_t ra = buf_rsrc(SAVE ? a.acts + ((int64_t)l * a.n_pad + p0) * DF_W : nullptr, SAVE ? 64u * DF_W * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t rs =
+            buf_rsrc(SAVE ? a.signs + ((int64_t)l * a.n_pad + p0) * DF_SIGN_WORDS : nullptr, SAVE ? 64u * DF_SIGN_WORDS * 4u : 0u);
+        uint32_t b_lane = (uint32_t)(n0 + 4 * hh) * 4u;                   // bytes into the layer's biases
+        asm volatile("" : "+v"(b_lane));
+        const char* bq_l = reinterpret_cast<const char*>(bL + l * DF_W) + b_lane;
 #pragma unroll
-        for (int rt = 0; rt < 2; rt++)
+        for (int ct = 0; ct < NC; ct++) {
+            f32x2_t bq[4][2];
 #pragma unroll
-            for (int ct = 0; ct < NC; ct++) {
+            for (int g = 0; g < 4; g++) {
+                const float4 q = *reinterpret_cast<const float4*>(bq_l + (32 * ct + 8 * g) * 4);
+                bq[g][0] = f32x2_t{q.x, q.y};
+                bq[g][1] = f32x2_t{q.z, q.w};
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++) {
                 uint32_t bits = 0;
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int row = 32 * rt + li, col = n0 + 32 * ct + acc_col4(g, hh);
-                    float4 v;
-                    v.x = fmaxf(fmaf(accx[rt][ct][4 * g], DF_H_INV, acc[rt][ct][4 * g]) + bv[ct][g].x, 0.f);
-                    v.y = fmaxf(fmaf(accx[rt][ct][4 * g + 1], DF_H_INV, acc[rt][ct][4 * g + 1]) + bv[ct][g].y, 0.f);
-                    v.z = fmaxf(fmaf(accx[rt][ct][4 * g + 2], DF_H_INV, acc[rt][ct][4 * g + 2]) + bv[ct][g].z, 0.f);
-                    v.w = fmaxf(fmaf(accx[rt][ct][4 * g + 3], DF_H_INV, acc[rt][ct][4 * g + 3]) + bv[ct][g].w, 0.f);
-                    store_split4_h(hP, DF_BF_ACT_PLANE, ((size_t)row * DF_BH + col) * 2, v);
-                    if (SAVE) {
-                        *reinterpret_cast<float4*>(a.acts + ((int64_t)l * a.n_pad + p0 + row) * DF_W + col) = v;
-                        bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
-                                << acc_col4(g, hh);
+                for (int g = 3; g >= 0; g--) {
+                    const size_t lds_off = (size_t)(rt * 32 * DF_BH + 32 * ct + 8 * g) * 2;
+                    if (DF_ABL & 1) {
+                        uint2 ph;
+                        ph.x = cvt_pk_f16(acc[rt][ct][4 * g], acc[rt][ct][4 * g + 1]);
+                        ph.y = cvt_pk_f16(acc[rt][ct][4 * g + 2], acc[rt][ct][4 * g + 3]);
+                        *reinterpret_cast<uint2*>(st + lds_off) = ph;
+                        continue;
+                    }
+                    // activation = max(acc 2^-14 + bias, 0): packed fused multiply-adds, two values each
+                    const f32x2_t a01 = __builtin_elementwise_fma(f32x2_t{acc[rt][ct][4 * g], acc[rt][ct][4 * g + 1]}, f32x2_t{DF_H_OUT, DF_H_OUT}, bq[g][0]);
+                    const f32x2_t a23 = __builtin_elementwise_fma(f32x2_t{acc[rt][ct][4 * g + 2], acc[rt][ct][4 * g + 3]}, f32x2_t{DF_H_OUT, DF_H_OUT}, bq[g][1]);
+                    const float4 v = make_float4(fmaxf(a01.x, 0.f), fmaxf(a01.y, 0.f), fmaxf(a23.x, 0.f), fmaxf(a23.y, 0.f));
+                    const f32x2_t s01 = f32x2_t{v.x, v.y} * DF_H_ASCALE, s23 = f32x2_t{v.z, v.w} * DF_H_ASCALE;
+                    store_split4_h(st, DF_BF_ACT_PLANE, lds_off, make_float4(s01.x, s01.y, s23.x, s23.y));
+                    if (SAVE && !(DF_ABL & 4)) {
+                        // (the row tile goes into the lane offset, not into the scalar offset: a 16-byte buffer store with a
+                        // scalar-register offset was seen to pick up the NEXT values of its data registers in its last lanes
+                        // on gfx950 -- the compiler pads that hazard only for stores without one)
+                        buf_store16(ra, sv_lane + (uint32_t)(rt * 32 * DF_W + 32 * ct + 8 * g) * 4u, 0, v);
+                        // sign bits, highest column first: bit 8 g + 4 hh + j of the tile's word
+                        bits = (bits << 8) | (positive_bit(v.w) << 3) | (positive_bit(v.z) << 2) | (positive_bit(v.y) << 1) | positive_bit(v.x);
                     }
                 }
-                if (SAVE) {
+                if (SAVE && !(DF_ABL & 5)) {
+                    bits <<= 4 * hh;
                     bits |= (uint32_t)__shfl_xor((int)bits, 32);
-                    if (hh == 0) a.signs[((int64_t)l * a.n_pad + p0 + 32 * rt + li) * DF_SIGN_WORDS + NC * wave + ct] = bits;
+                    if (hh == 0)
+                        __builtin_amdgcn_raw_buffer_store_b32(bits, rs, (int)((uint32_t)(li * DF_SIGN_WORDS + NC * wave + ct) * 4u),
+                                                              rt * (32 * DF_SIGN_WORDS * 4), 0);
                 }
             }
+        }
+        stamp();
         __syncthreads();
+        stamp();
     }
     // heads: 64 columns, one 32 x 32 tile per wave (of the first four)
     if (wave < 4) {
         const int ct = wave & 1, r0 = 32 * (wave >> 1);
-        const WSeg hs = wseg_h(hf, 9, 32 * ct + li, hh);
+        const WSegH hs = wseg_h(9, 32 * ct + li, hh);
         uint4 hw[2][1], hw1[2][1], hw2[2][1];
-        load_wh<1, DF_HEAD>(hw, hs, 0);
-        load_wh<1, DF_HEAD>(hw1, hs, 1);
-        load_wh<1, DF_HEAD>(hw2, hs, 2);
-        f32x16 hacc[1][1], haccx[1][1];
+        load_wh<1, DF_HEAD>(hw, rw, hs, 0);
+        load_wh<1, DF_HEAD>(hw1, rw, hs, 1);
+        load_wh<1, DF_HEAD>(hw2, rw, hs, 2);
+        f32x16 hacc[1][1];
         zero_acc(hacc);
-        zero_acc(haccx);
-        stream_gemm_h<1, 1, DF_HEAD>(hacc, haccx, hP + (size_t)(r0 + li) * DF_BH * 2 + 16 * hh, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16,
-                                     hs, nullptr, hw, hw1, hw2);
+        stream_gemm_h<1, 1, DF_HEAD>(hacc, hP + (size_t)(r0 + li) * DF_BH * 2 + 16 * hh, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16,
+                                     rw, hs, nullptr, hw, hw1, hw2);
         const int64_t p = p0 + r0 + li;
-        if (p < a.n) {
+        if (p < a.n && !(DF_ABL & 16)) {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int col = 32 * ct + acc_col4(g, hh);
                 const float4 bq = *reinterpret_cast<const float4*>(bL + DF_D * DF_W + col);
-                const float4 v = make_float4(fmaf(haccx[0][0][4 * g], DF_H_INV, hacc[0][0][4 * g]) + bq.x,
-                                             fmaf(haccx[0][0][4 * g + 1], DF_H_INV, hacc[0][0][4 * g + 1]) + bq.y,
-                                             fmaf(haccx[0][0][4 * g + 2], DF_H_INV, hacc[0][0][4 * g + 2]) + bq.z,
-                                             fmaf(haccx[0][0][4 * g + 3], DF_H_INV, hacc[0][0][4 * g + 3]) + bq.w);
+                const float4 v = make_float4(fmaf(hacc[0][0][4 * g], DF_H_OUT, bq.x), fmaf(hacc[0][0][4 * g + 1], DF_H_OUT, bq.y),
+                                             fmaf(hacc[0][0][4 * g + 2], DF_H_OUT, bq.z), fmaf(hacc[0][0][4 * g + 3], DF_H_OUT, bq.w));
                 if (col < 48) {
                     *reinterpret_cast<float4*>(a.d_sh + p * 48 + col) = v;
                 } else if (col == 48) {
@@ -993,6 +1219,7 @@ __global__ __launch_bounds__(64 * DF_FWD_WAVES) void k_deform_fwd_h(FwdArgs a)
             }
         }
     }
+    stamp();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1692,8 +1919,8 @@ hipError_t set_attrs()
 {
     static std::atomic<uint64_t> done[8];
     struct { const void* fn; size_t bytes; } k[8] = {
-        {reinterpret_cast<const void*>(&k_deform_fwd_h<true>), DF_FWD_H_LDS},
-        {reinterpret_cast<const void*>(&k_deform_fwd_h<false>), DF_FWD_H_LDS},
+        {reinterpret_cast<const void*>(&k_deform_fwd_h<true, DF_FWD_H_SAVE_WAVES>), DF_FWD_H_SAVE_LDS},
+        {reinterpret_cast<const void*>(&k_deform_fwd_h<false, DF_FWD_WAVES>), DF_FWD_H_LDS},
         {reinterpret_cast<const void*>(&k_deform_bwd_bf), DF_BWD_BF_LDS},
         {reinterpret_cast<const void*>(&k_deform_fwd_bf<true>), DF_FWD_BF_LDS},
         {reinterpret_cast<const void*>(&k_deform_fwd_bf<false>), DF_FWD_BF_LDS},
@@ -1830,8 +2057,11 @@ extern "C" int gft_deform_forward(void* hip_stream, int xyz_multires, int t_mult
     // all padded rows are computed and saved: the weight-gradient GEMMs multiply them (by zero gradients)
     const dim3 grid((unsigned)(a.n_pad / (32 * DF_NR_FWD)));
     if (bf16_planes() && fp16_forward()) {
-        if (saved) hipLaunchKernelGGL(k_deform_fwd_h<true>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_H_LDS, (hipStream_t)hip_stream, a);
-        else hipLaunchKernelGGL(k_deform_fwd_h<false>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_H_LDS, (hipStream_t)hip_stream, a);
+        if (saved)
+            hipLaunchKernelGGL((k_deform_fwd_h<true, DF_FWD_H_SAVE_WAVES>), grid, dim3(64 * DF_FWD_H_SAVE_WAVES), DF_FWD_H_SAVE_LDS,
+                               (hipStream_t)hip_stream, a);
+        else
+            hipLaunchKernelGGL((k_deform_fwd_h<false, DF_FWD_WAVES>), grid, dim3(64 * DF_FWD_WAVES), DF_FWD_H_LDS, (hipStream_t)hip_stream, a);
     } else if (bf16_planes()) {
         if (saved) hipLaunchKernelGGL(k_deform_fwd_bf<true>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);
         else hipLaunchKernelGGL(k_deform_fwd_bf<false>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);

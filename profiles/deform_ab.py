@@ -4,6 +4,9 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
+if os.environ.get("GFT_ABL_LIB"):            # ablation builds (profiles/deform_ablate.sh)
+    from gftorf_amd import _lib as _l
+    _l.LIB_PATH = os.path.join(ROOT, os.environ["GFT_ABL_LIB"])
 from gftorf_amd import reference_network
 from oracle import deform_ref
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
