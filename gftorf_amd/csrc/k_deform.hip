@@ -73,6 +73,7 @@ struct PackArgs {
     gft_deform_params p;
     float* out;
     int in;                                // encoded inputs (<= DF_INK)
+    uint32_t* flag;                        // range flag of the fp16 stream, cleared here (k_deform_pack_h sets it)
 };
 
 // head column hc -> (weight row pointer, bias): columns 0..47 are d_sh[coefficient c][channel ch] = c*3+ch
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void k_deform_pack(PackArgs a)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= DF_PACKED_FLOATS) return;
+    if (e == 0) a.flag[0] = 0u;
     float v = 0.f;
     if (e < DF_F_TOTAL) {
         // forward stream: per segment [k/4][ncol][4], element (k, n) = W[n][k]
@@ -283,6 +285,8 @@ struct FwdArgs {
     float* acts;      // [8][n_pad][256] or null
     uint32_t* signs;  // [8][n_pad][8] or null: bit c of word w = activation 32 w + c is positive
     float* d_xyz; float* d_sh;
+    uint32_t gen;        // this forward call's number (fp16 walk: what it leaves in the range table when it cannot hold a value)
+    uint32_t only_if;    // bf16 walk: 0 = run; else run only if the fp16 walk of call `only_if` gave up (see df_range_table)
 };
 
 constexpr int DF_BIAS_FLOATS = DF_D * DF_W + DF_HEAD;      // 2368
@@ -555,6 +559,26 @@ __device__ __forceinline__ void store_split4(char* plane0, size_t plane_bytes, s
     *reinterpret_cast<uint2*>(plane0 + 2 * plane_bytes + byte_off) = pl;
 }
 
+constexpr int64_t DF_H_FLOATS = DF_F_TOTAL;                    // forward stream only: 2 planes x 2 bytes per weight
+constexpr int64_t DF_FLAG_FLOATS = 4;                          // behind it: word 0 != 0 = a weight is outside the fp16 planes' range
+constexpr int64_t DF_FLAG_OFF = DF_PACKED_FLOATS + DF_BF_FLOATS + DF_H_FLOATS;
+constexpr float DF_H_MAX = 65504.f;                            // largest fp16
+
+// The fp16 planes hold |weight| < 64 and |activation| < 4094 (fp16's 65504 over the plane scales).  The reference computes
+// in fp32, so a network outside that range must still come out right: the pack kernel flags such weights in the packed
+// buffer, the fp16 walk tracks the largest scaled activation it splits and, when one does not fit, writes its call's
+// number into this table; gft_deform_forward launches the bf16 walk (fp32 range) right behind it with that number, and its
+// workgroups return at once unless the flag or the table says the fp16 walk's results cannot be used -- then they
+// overwrite all of them.  A table of 64 entries by call number keeps concurrent calls on different streams apart.
+__device__ uint32_t df_range_table[64];
+
+__device__ __forceinline__ bool fp16_walk_gave_up(const float* packed, uint32_t gen)
+{
+    const uint32_t wflag = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(packed + DF_FLAG_OFF));
+    const uint32_t aflag = __hip_atomic_load(&df_range_table[gen & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return wflag != 0 || aflag == gen;
+}
+
 // DF_FWD_WAVES waves per workgroup: 4 (a wave owns 64 output columns, one wave per SIMD) or 8 (32 columns, two waves per
 // SIMD: the other wave multiplies while one waits for its weights or its LDS reads; 256 registers per wave).  Measured at
 // 300 k points: 2.15-2.2 ms with 4, 1.96-2.02 ms with 8.
@@ -564,6 +588,7 @@ template <bool SAVE>
 __global__ __launch_bounds__(64 * DF_FWD_WAVES) void k_deform_fwd_bf(FwdArgs a)
 {
     extern __shared__ float4 df_lds[];
+    if (a.only_if != 0u && !fp16_walk_gave_up(a.packed, a.only_if)) return;
     char* hP = reinterpret_cast<char*>(df_lds);                  // activation planes [3][64][264] bf16
     char* eP = hP + 3 * DF_BF_ACT_PLANE;                         // encoding planes   [3][64][88]  bf16
     float* bL = reinterpret_cast<float*>(eP + 3 * DF_BF_ENC_PLANE);
@@ -729,7 +754,6 @@ __global__ __launch_bounds__(64 * DF_FWD_WAVES) void k_deform_fwd_bf(FwdArgs a)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 constexpr float DF_H_WSCALE = 1024.0f, DF_H_ASCALE = 16.0f, DF_H_OUT = 1.0f / (1024.0f * 16.0f);
-constexpr int64_t DF_H_FLOATS = DF_F_TOTAL;                    // forward stream only: 2 planes x 2 bytes per weight
 constexpr size_t DF_FWD_H_LDS = 2 * DF_BF_ACT_PLANE + 2 * DF_BF_ENC_PLANE + (size_t)DF_BIAS_FLOATS * 4;   // 99584
 constexpr size_t DF_FWD_H_SAVE_LDS = 2 * DF_BF_ACT_PLANE + (size_t)DF_BIAS_FLOATS * 4;                    // 72960: two per CU
 constexpr int DF_FWD_H_SAVE_WAVES = 4;
@@ -746,7 +770,7 @@ __device__ __forceinline__ float f16_lo(uint32_t u) { f16x2_t h; __builtin_memcp
 __device__ __forceinline__ float f16_hi(uint32_t u) { f16x2_t h; __builtin_memcpy(&h, &u, 4); return (float)h.y; }
 
 // fp32 packed forward stream ([k/4][n][4] per segment) -> fp16 planes ([plane][k/8][n][8] per segment)
-__global__ __launch_bounds__(256) void k_deform_pack_h(const float* __restrict__ packed, _Float16* __restrict__ out)
+__global__ __launch_bounds__(256) void k_deform_pack_h(const float* __restrict__ packed, _Float16* __restrict__ out, uint32_t* __restrict__ flag)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= DF_F_TOTAL) return;
@@ -757,6 +781,7 @@ __global__ __launch_bounds__(256) void k_deform_pack_h(const float* __restrict__
     const int64_t r = e - sg.off;
     const int kq = (int)(r / (sg.ncol * 4)), n = (int)((r >> 2) % sg.ncol), k = 4 * kq + (int)(r & 3);
     const float x = packed[e] * DF_H_WSCALE;
+    if (!(fabsf(x) <= DF_H_MAX)) flag[0] = 1u;          // (NaN too)
     const _Float16 hi = (_Float16)x;
     const _Float16 lo = (_Float16)(x - (float)hi);
     const int64_t plane = (int64_t)sg.K * sg.ncol;
@@ -1013,6 +1038,9 @@ template <bool SAVE, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_deform_fwd_h(FwdArgs a)
 {
     extern __shared__ float4 df_lds[];
+    // a weight outside the planes' range: the bf16 walk launched behind this one does the work
+    if (__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.packed + DF_FLAG_OFF)) != 0u) return;
+    float top = 0.f;                   // largest scaled value this lane has split into the planes
     constexpr bool ENC_LDS = !SAVE;
     char* hP = reinterpret_cast<char*>(df_lds);                  // activation planes [2][64][264] fp16
     char* eP = ENC_LDS ? hP + 2 * DF_BF_ACT_PLANE : hP;          // encoding planes   [2][64][104] fp16, or in the activation rows
@@ -1058,6 +1086,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int64_t p = p0 + pt;
         auto put = [&](int col, float v) {
             const float vs = v * DF_H_ASCALE;
+            top = fmaxf(top, fabsf(vs));
             const _Float16 h = (_Float16)vs;
             _Float16* e = reinterpret_cast<_Float16*>(eP) + pt * E_ROW + col;
             e[0] = h;
@@ -1166,6 +1195,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     const f32x2_t a23 = __builtin_elementwise_fma(f32x2_t{acc[rt][ct][4 * g + 2], acc[rt][ct][4 * g + 3]}, f32x2_t{DF_H_OUT, DF_H_OUT}, bq[g][1]);
                     const float4 v = make_float4(fmaxf(a01.x, 0.f), fmaxf(a01.y, 0.f), fmaxf(a23.x, 0.f), fmaxf(a23.y, 0.f));
                     const f32x2_t s01 = f32x2_t{v.x, v.y} * DF_H_ASCALE, s23 = f32x2_t{v.z, v.w} * DF_H_ASCALE;
+                    top = fmaxf(fmaxf(top, fmaxf(s01.x, s01.y)), fmaxf(s23.x, s23.y));
                     store_split4_h(st, DF_BF_ACT_PLANE, lds_off, make_float4(s01.x, s01.y, s23.x, s23.y));
                     if (SAVE && !(DF_ABL & 4)) {
                         // (the row tile goes into the lane offset, not into the scalar offset: a 16-byte buffer store with a
@@ -1220,6 +1250,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     }
     stamp();
+    // (NaN counts as "does not fit": the comparison is written so that it is true for it)
+    if (!(top <= DF_H_MAX)) __hip_atomic_store(&df_range_table[a.gen & 63], a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1985,7 +2017,7 @@ static int arch_inputs(int xm, int tm)
 
 extern "C" int gft_deform_inputs(int xyz_multires, int t_multires) { return arch_inputs(xyz_multires, t_multires); }
 
-extern "C" size_t gft_deform_packed_bytes(void) { return (size_t)(DF_PACKED_FLOATS + DF_BF_FLOATS + DF_H_FLOATS) * sizeof(float); }
+extern "C" size_t gft_deform_packed_bytes(void) { return (size_t)(DF_PACKED_FLOATS + DF_BF_FLOATS + DF_H_FLOATS + DF_FLAG_FLOATS) * sizeof(float); }
 
 extern "C" size_t gft_deform_saved_bytes(int64_t n)
 {
@@ -2017,13 +2049,15 @@ extern "C" int gft_deform_pack(void* hip_stream, int xyz_multires, int t_multire
     a.p = *p;
     a.out = (float*)packed;
     a.in = in;
+    a.flag = reinterpret_cast<uint32_t*>((float*)packed + DF_FLAG_OFF);
     hipLaunchKernelGGL(k_deform_pack, dim3((unsigned)((DF_PACKED_FLOATS + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, a);
     GFT_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_deform_pack_bf, dim3((unsigned)((DF_BF_ELEMS + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
                        (const float*)packed, reinterpret_cast<__bf16*>((float*)packed + DF_PACKED_FLOATS));
     GFT_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_deform_pack_h, dim3((unsigned)((DF_F_TOTAL + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
-                       (const float*)packed, reinterpret_cast<_Float16*>((float*)packed + DF_PACKED_FLOATS + DF_BF_FLOATS));
+                       (const float*)packed, reinterpret_cast<_Float16*>((float*)packed + DF_PACKED_FLOATS + DF_BF_FLOATS),
+                       reinterpret_cast<uint32_t*>((float*)packed + DF_FLAG_OFF));
     GFT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -2056,12 +2090,21 @@ extern "C" int gft_deform_forward(void* hip_stream, int xyz_multires, int t_mult
     a.d_sh = d_sh;
     // all padded rows are computed and saved: the weight-gradient GEMMs multiply them (by zero gradients)
     const dim3 grid((unsigned)(a.n_pad / (32 * DF_NR_FWD)));
+    a.gen = 0;
+    a.only_if = 0;
     if (bf16_planes() && fp16_forward()) {
+        static std::atomic<uint32_t> calls{0};
+        do a.gen = ++calls; while (a.gen == 0);
         if (saved)
             hipLaunchKernelGGL((k_deform_fwd_h<true, DF_FWD_H_SAVE_WAVES>), grid, dim3(64 * DF_FWD_H_SAVE_WAVES), DF_FWD_H_SAVE_LDS,
                                (hipStream_t)hip_stream, a);
         else
             hipLaunchKernelGGL((k_deform_fwd_h<false, DF_FWD_WAVES>), grid, dim3(64 * DF_FWD_WAVES), DF_FWD_H_LDS, (hipStream_t)hip_stream, a);
+        GFT_CHECK_HIP(hipGetLastError());
+        // the fp32-range walk behind it: its workgroups return at once unless the fp16 planes could not hold a value
+        a.only_if = a.gen;
+        if (saved) hipLaunchKernelGGL(k_deform_fwd_bf<true>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);
+        else hipLaunchKernelGGL(k_deform_fwd_bf<false>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);
     } else if (bf16_planes()) {
         if (saved) hipLaunchKernelGGL(k_deform_fwd_bf<true>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);
         else hipLaunchKernelGGL(k_deform_fwd_bf<false>, grid, dim3(64 * DF_FWD_WAVES), DF_FWD_BF_LDS, (hipStream_t)hip_stream, a);

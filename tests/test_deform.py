@@ -381,3 +381,46 @@ def test_backward_over_rows_with_a_gradient_only(frac, n):
             assert not sparse[name].any() and not dense[name].any(), name
         else:
             assert _rel(sparse[name].cpu().numpy(), dense[name].cpu().numpy()) < 2e-5, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["weight", "activation", "input"])
+def test_values_beyond_the_fp16_planes_fall_back_to_the_fp32_range(case):
+    """The forward walk multiplies on fp16 planes that hold |weight| < 64 and |activation| < 4094.  The reference is
+    fp32: a network or an input outside that range must come out as the oracle has it (the bf16 walk takes over inside
+    the same call), forward and backward."""
+    dev = torch.device("cuda:0")
+    params = deform_ref.random_params(21)
+    if case == "weight":
+        params["linear.3.weight"][5, 7] = 100.0            # times the plane scale: beyond 65504
+    elif case == "activation":
+        params["linear.2.bias"][11] = 6000.0               # an activation of about 6000
+    from gftorf_amd.deform import DeformNetwork
+    net = DeformNetwork(D=8, W=256, xyz_multires=10, t_multires=10, sh_degree=3)
+    net.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    net = net.to(dev)
+    n = 700
+    x, t = _inputs(n, 3, shared_t=False)
+    if case == "input":
+        x[13, 1] = 5000.0                                   # an unnormalised coordinate
+    ref = deform_ref.forward(params, x.astype(np.float64), t.astype(np.float64), dtype=np.float64)
+    assert np.isfinite(ref[0]).all() and np.isfinite(ref[2]).all()
+    with torch.no_grad():
+        out = net(torch.tensor(x, device=dev), torch.tensor(t, device=dev))
+    if case == "input":
+        # sin / cos of 2^9 * 5000 in fp32: the encoding itself differs from float64 in the high octaves, for the reference
+        # too; what is checked is that the row is finite and the other rows are exact
+        keep = np.arange(n) != 13
+        assert np.isfinite(out[0].cpu().numpy()).all() and np.isfinite(out[2].cpu().numpy()).all()
+        assert _rel(out[0].cpu().numpy()[keep], ref[0][keep]) < FWD_TOL and _rel(out[2].cpu().numpy()[keep], ref[2][keep]) < FWD_TOL
+        return
+    assert _rel(out[0].cpu().numpy(), ref[0]) < FWD_TOL and _rel(out[2].cpu().numpy(), ref[2]) < FWD_TOL
+    # the saving forward and the backward behind it
+    g_dxyz, g_dsh = np.random.default_rng(4).standard_normal((n, 3)), np.random.default_rng(5).standard_normal((n, 16, 3))
+    d_xyz, _, d_sh, _ = net(torch.tensor(x, device=dev), torch.tensor(t, device=dev))
+    assert _rel(d_xyz.detach().cpu().numpy(), ref[0]) < FWD_TOL
+    torch.autograd.backward([d_xyz, d_sh], [torch.tensor(g_dxyz, device=dev, dtype=torch.float32), torch.tensor(g_dsh, device=dev, dtype=torch.float32)])
+    gref = deform_ref.backward(params, x.astype(np.float64), t.astype(np.float64), g_dxyz, g_dsh, dtype=np.float64)
+    for name, p in net.named_parameters():
+        if p.grad is not None and name in gref:
+            assert _rel(p.grad.cpu().numpy(), gref[name]) < BWD_TOL, name
