@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 DEFORM_MAX_INPUTS = 96          # GFT_DEFORM_MAX_INPUTS (include/gftorf_deform.h)
 ACC_STRIDE = 16
 
@@ -110,7 +110,7 @@ class AssembleIO(C.Structure):
 
 class AssembleBwdIO(C.Structure):
     _fields_ = ([(n, _fp) for n in ASSEMBLE_BWD_HEAD] + [("d_rot_scalar", C.c_float)] +
-                [(n, _fp) for n in ASSEMBLE_BWD_TAIL])
+                [(n, _fp) for n in ASSEMBLE_BWD_TAIL] + [("static_from_raw", C.c_int32)])
 
 
 class DeformParams(C.Structure):

@@ -54,10 +54,13 @@ class _AssembleInputs(torch.autograd.Function):
                                "there is no CPU path" % (dev,))
         P = xyz.size(0)
         M, M_p = feat_color.size(1), feat_phasor.size(1)
-        src = [_f32c(t, dev, n) for t, n in ((xyz, "xyz"), (screenspace, "screenspace_points"), (opacity, "opacity"),
-                                              (scaling, "scaling"), (rotation, "rotation"), (rotation_raw, "_rotation"),
-                                              (feat_color, "features_color"), (feat_phasor, "features_phasor"))]
+        src = [None if t is None else _f32c(t, dev, n)
+               for t, n in ((xyz, "xyz"), (screenspace, "screenspace_points"), (opacity, "opacity"),
+                            (scaling, "scaling"), (rotation, "rotation"), (rotation_raw, "_rotation"),
+                            (feat_color, "features_color"), (feat_phasor, "features_phasor"))]
         xyz_c, ssp_c, op_c, sc_c, rot_c, raw_c, fc_c, fp_c = src
+        if any(t is None for t in (xyz_c, ssp_c, op_c, sc_c, raw_c, fc_c, fp_c)):
+            raise RuntimeError("assemble_inputs: only `rotation` may be None (the static rows are then normalize(rotation_raw))")
         if motion_mask.dtype != torch.bool or motion_mask.numel() != P:
             raise RuntimeError("motion_mask must be a bool tensor with one entry per Gaussian")
         mask_c = motion_mask.to(dev).contiguous()
@@ -115,6 +118,7 @@ class _AssembleInputs(torch.autograd.Function):
         ctx.offs_scalar = [None if _is_tensor(v) else v for v in offs]
         ctx.off_rows = [v.size(0) if _is_tensor(v) else 0 for v in offs]
         ctx.opacity_shape = opacity.shape
+        ctx.static_from_raw = rot_c is None
         ctx.save_for_backward(raw_c, offs[1] if _is_tensor(offs[1]) else raw_c.new_empty(0), scratch)
         ctx.set_materialize_grads(False)
         return means3D, means2D, out_op, scales, rotations, shs, shs_p
@@ -151,6 +155,7 @@ class _AssembleInputs(torch.autograd.Function):
         io.g_xyz, io.g_screenspace, io.g_opacity_in, io.g_scaling = _p(g_xyz), _p(g_ssp), _p(g_op), _p(g_sc)
         io.g_rotation, io.g_rotation_raw, io.g_feat_color, io.g_feat_phasor = _p(g_rot), _p(g_raw), _p(g_fc), _p(g_fp)
         io.g_d_xyz, io.g_d_rot, io.g_d_sh, io.g_d_sh_p = _p(g_dxyz), _p(g_drot), _p(g_dsh), _p(g_dshp)
+        io.static_from_raw = int(ctx.static_from_raw)
         stream = _lib.raw_stream(dev)
         with _lib.on_device(dev):
             _lib.check(lib.gft_assemble_backward(stream, P, M, M_p, rs, rd, C.byref(io)))
@@ -165,7 +170,11 @@ def assemble_inputs(xyz, screenspace_points, opacity, scaling, rotation, rotatio
     of the reference's ``gaussian_renderer/__init__.py`` build them.  The ``d_*`` tensors must share one row
     count (checked on the host); a dynamic Gaussian beyond their last row gets NaN outputs and zero gradients
     (never an out-of-bounds access).  ``validate=True`` adds the reference's exact row-count check against the
-    number of True entries of the mask (one blocking read) and raises like the reference's masked assignment."""
+    number of True entries of the mask (one blocking read) and raises like the reference's masked assignment.
+
+    ``rotation=None``: the static rows' rotations are ``normalize(rotation_raw)`` computed inside the kernels (what
+    ``pc.get_rotation`` is), forward and backward -- the caller's eager normalize and its eight backward launches over
+    [P, 4] drop out; the gradient of those rows then arrives in ``rotation_raw.grad``."""
     return _AssembleInputs.apply(xyz, screenspace_points, opacity, scaling, rotation, rotation_raw,
                                  features_color, features_phasor, motion_mask, d_xyz, d_rot, d_sh, d_sh_p,
                                  "static" in render_regions, "dynamic" in render_regions, validate)

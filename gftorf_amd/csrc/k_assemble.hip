@@ -133,8 +133,13 @@ __global__ __launch_bounds__(ASM_RANK_ROWS) void k_assemble_rows(RowsArgs a)
             // torch.nn.functional.normalize: v / max(||v||_2, 1e-12)
             const float nrm = fmaxf(sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), 1e-12f);
             q = make_float4(r.x / nrm, r.y / nrm, r.z / nrm, r.w / nrm);
-        } else {
+        } else if (a.io.rotation) {
             q = reinterpret_cast<const float4*>(a.io.rotation)[i];
+        } else {
+            // no activated rotations given: pc.get_rotation = normalize(pc._rotation) (scene/gaussian_model.py) done here
+            const float4 r = reinterpret_cast<const float4*>(a.io.rotation_raw)[i];
+            const float nrm = fmaxf(sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), 1e-12f);
+            q = make_float4(r.x / nrm, r.y / nrm, r.z / nrm, r.w / nrm);
         }
     }
     a.io.out_means3D[3 * i] = x.x; a.io.out_means3D[3 * i + 1] = x.y; a.io.out_means3D[3 * i + 2] = x.z;
@@ -214,9 +219,10 @@ __global__ __launch_bounds__(ASM_BLOCK) void k_assemble_rows_bwd(RowsBwdArgs a)
         if (a.io.g_opacity) gop = a.io.g_opacity[i];
         if (a.io.g_scales) gsc = make_float3(a.io.g_scales[3 * i], a.io.g_scales[3 * i + 1], a.io.g_scales[3 * i + 2]);
         const float4 g = a.io.g_rotations ? reinterpret_cast<const float4*>(a.io.g_rotations)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m) {
+        if (m || a.io.static_from_raw) {
             float4 r = reinterpret_cast<const float4*>(a.io.rotation_raw)[i];
-            if (a.io.d_rot) {
+            if (!m) {
+            } else if (a.io.d_rot) {
                 const float4 d = reinterpret_cast<const float4*>(a.io.d_rot)[rank];
                 r.x += d.x; r.y += d.y; r.z += d.z; r.w += d.w;
             } else {
@@ -340,7 +346,7 @@ extern "C" int gft_assemble_forward(void* hip_stream, int32_t P, int32_t M, int3
     if (P < 0 || M < 0 || M_p < 0) return gft_fail("gft_assemble_forward: negative size");
     if (!io) return gft_fail("gft_assemble_forward: io is NULL");
     if (P == 0) return 0;
-    if (!io->xyz || !io->screenspace || !io->opacity || !io->scaling || !io->rotation || !io->rotation_raw ||
+    if (!io->xyz || !io->screenspace || !io->opacity || !io->scaling || !io->rotation_raw ||
         !io->motion_mask || !io->scratch || !io->out_means3D || !io->out_means2D || !io->out_opacity || !io->out_scales ||
         !io->out_rotations)
         return gft_fail("gft_assemble_forward: required pointer is NULL");

@@ -58,6 +58,13 @@ def _fill(struct, tensors):
     return struct
 
 
+def _prod(shape):
+    k = 1
+    for d in shape:
+        k *= int(d)
+    return k
+
+
 class _DeformFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xm, tm, x, t, *params):
@@ -110,7 +117,15 @@ class _DeformFn(torch.autograd.Function):
         if n > 0 and saved.numel() == 0:
             raise RuntimeError("DeformNetwork: backward through a forward that ran without gradients")
         f32 = dict(device=dev, dtype=torch.float32)
-        grads = [torch.empty(s, **f32) for s in ctx.shapes]
+        # the gradients are views of ONE flat buffer, in parameter order: the data-parallel bucket (flat_grad_bucket) is
+        # then this memory itself and the all-reduce needs no gather / scatter copies
+        # (each view starts on a 16-byte boundary, as a tensor of its own would; the few padding floats stay zero)
+        sizes = [_prod(s) for s in ctx.shapes]
+        flat = torch.zeros((sum((k + 3) // 4 * 4 for k in sizes),), **f32)
+        grads, o = [], 0
+        for shp, k in zip(ctx.shapes, sizes):
+            grads.append(flat[o:o + k].view(shp))
+            o += (k + 3) // 4 * 4
         gx = g_dxyz.float().contiguous() if g_dxyz is not None else None
         gs = g_dsh.float().contiguous() if g_dsh is not None else None
         last_backward_stats.update(points=n, points_processed=n)
@@ -232,7 +247,21 @@ def flat_grad_bucket(module):
     (reduced) bucket back:
     the unit of the data-parallel all-reduce over RCCL."""
     ps = [p for p in _param_list(module) if p.grad is not None]
-    flat = torch.cat([p.grad.reshape(-1) for p in ps]) if ps else torch.empty(0)
+    if not ps:
+        return torch.empty(0), (lambda bucket: None)
+    # the backward of this package leaves the gradients as consecutive views of one buffer: that buffer is the bucket
+    g0 = ps[0].grad
+    o, in_place = g0.storage_offset(), True
+    for p in ps:
+        g = p.grad
+        if not (g.dtype == torch.float32 and g.is_contiguous() and g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr()
+                and 0 <= g.storage_offset() - o < 4):
+            in_place = False
+            break
+        o = g.storage_offset() + g.numel()
+    if in_place:
+        return torch.as_strided(g0, (o - g0.storage_offset(),), (1,), g0.storage_offset()), (lambda bucket: None)
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
 
     def scatter_back(bucket):
         o = 0

@@ -64,7 +64,9 @@ class FrameStep:
         d_xyz, d_rot, d_sh, d_sh_p = self.net(self.x_norm, t)
         mark("network_forward")
         ssp = torch.zeros((g["xyz"].size(0), 3), device=dev, dtype=torch.float32, requires_grad=True)
-        rot = torch.nn.functional.normalize(g["rotation_raw"])
+        # pc.get_rotation: this package's assembly normalises the static rows itself (rotation=None); a stand-in gets the
+        # activated tensor as the reference's renderer does
+        rot = None if self.assemble is assemble_inputs else torch.nn.functional.normalize(g["rotation_raw"])
         m3, m2, op, sc, ro, shs, shp = self.assemble(g["xyz"], ssp, g["opacity"], g["scaling"], rot, g["rotation_raw"],
                                                      g["fc"], g["fp"], self.mask, d_xyz, d_rot, d_sh, d_sh_p)
         mark("assembly")

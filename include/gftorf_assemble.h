@@ -35,7 +35,9 @@ typedef struct gft_assemble_io {
     const float* screenspace;    /* [P,3]   screenspace_points (zeros; gradient sink) */
     const float* opacity;        /* [P,1]   pc.get_opacity   (activated) */
     const float* scaling;        /* [P,3]   pc.get_scaling   (activated) */
-    const float* rotation;       /* [P,4]   pc.get_rotation  (normalised; used for static rows) */
+    const float* rotation;       /* [P,4]   pc.get_rotation  (normalised; used for static rows), or NULL: the static rows
+                                  *          are normalize(rotation_raw) computed here -- no [P,4] tensor and no eager
+                                  *          normalize / backward (eight launches) for the caller */
     const float* rotation_raw;   /* [P,4]   pc._rotation     (used for dynamic rows) */
     const float* feat_color;     /* [P,M,3] pc.get_features_color,  NULL iff M == 0 */
     const float* feat_phasor;    /* [P,M_p,2] pc.get_features_phasor, NULL iff M_p == 0 */
@@ -90,6 +92,9 @@ typedef struct gft_assemble_bwd_io {
     float* g_d_rot;              /* [Nd,4] */
     float* g_d_sh;               /* [Nd,M,3] */
     float* g_d_sh_p;             /* [Nd,M_p,2] */
+    /* 1 = the forward ran with io.rotation == NULL: the static rows' gradient goes through the normalisation into
+     * g_rotation_raw as well (g_rotation, if given, is zeros) */
+    int32_t static_from_raw;
 } gft_assemble_bwd_io;
 
 size_t gft_assemble_scratch_bytes(int32_t P);

@@ -18,13 +18,16 @@
  * below 2^-23 of the product), accumulated in fp32: the error against a float64 product is that of an fp32 fma
  * chain (measured 5.4e-7 vs 5.5e-7 of the max-norm), at up to 2.7 x the rate of the fp32-operand MFMA.
  * GFT_DEFORM_BF16X3=0 in the environment selects `v_mfma_f32_32x32x2_f32` (fp32 operands) instead.
- * The forward walk goes one step further: its operands are split into two fp16 numbers, x = hi + lo * 2^-11 (hi =
- * fp16(x), lo = fp16((x - hi) * 2^11): 22 mantissa bits, the residual scaled so it stays a normal number), and a
- * product is three `v_mfma_f32_32x32x16_f16` terms (hi*hi; hi*lo + lo*hi accumulated apart and added with the
- * 2^-11 once per tile; lo*lo is below 2^-22 of the product and dropped).  Measured against float64 the outputs are
- * as close as the six-term bf16 walk's (1.5e-7 of the max-norm at 300 k points) at 0.77 x its time.  It needs
- * |weight| and |activation| < 65504 (the fp16 range; the reference's network sits 3-4 orders of magnitude below it);
- * GFT_DEFORM_FP16X2=0 keeps the forward on the bf16 planes, which have the fp32 range.
+ * The forward walk goes one step further: its operands are split into two fp16 numbers, x = hi + lo (hi = fp16(x),
+ * lo = fp16(x - hi): 22 mantissa bits), and a product is three `v_mfma_f32_32x32x16_f16` terms (hi*hi, hi*lo, lo*hi;
+ * lo*lo is below 2^-22 of the product and dropped) into one fp32 accumulator.  fp16 has five exponent bits, so weights
+ * are stored times 2^10 and activations times 2^4 (the accumulator is scaled back once per tile): a weight of 1e-4 .. 64
+ * and an activation of 8e-3 .. 4094 keep all 22 bits, smaller ones have a subnormal lo that still resolves 4e-9 of an
+ * activation (the matrix pipe honours fp16 subnormals).  Measured against float64 the outputs are as close as the
+ * six-term bf16 walk's (1.7e-7 of the max-norm at 300 k points) at 0.75 x its time.  A weight, activation or input beyond
+ * that range does not fit the planes: the pack kernel flags such weights, the walk notices such values, and the bf16 walk
+ * (fp32 range), launched behind the fp16 one in every call, then redoes the call -- its workgroups return at once
+ * otherwise.  GFT_DEFORM_FP16X2=0 runs the bf16 walk alone.
  *
  *   forward : one workgroup per 64 points walks all layers with the activations in LDS
  *             (weights streamed from L2), saving the post-ReLU activations for the backward

@@ -169,3 +169,43 @@ def test_hip_assembly_edge_cases(gpu):
     ref, _ = run(R.assemble_eager, c, "cpu", ("dynamic",), grad=False)
     got, _ = run(assemble_inputs, c, gpu, ("dynamic",), grad=False)
     np.testing.assert_array_equal(got[4], ref[4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regions", [("static", "dynamic"), ("static",), ("dynamic",)])
+def test_hip_assembly_normalises_the_static_rotations_itself(regions, gpu):
+    """rotation=None: the static rows are normalize(rotation_raw) (pc.get_rotation) inside the kernels, forward and
+    backward -- against the eager composition normalize -> assembly on the CPU."""
+    from gftorf_amd import assemble_inputs
+    c = make_case(seed=19, **CASES[list(CASES)[0]])
+    c["rotation_raw"][5] = 0.0                                   # a zero quaternion: the clamped denominator
+    rng = np.random.default_rng(23)
+    weights = None
+
+    def eager(*args, **kw):
+        a = list(args)
+        a[4] = torch.nn.functional.normalize(a[5])               # pc.get_rotation
+        return R.assemble_eager(*a, **kw)
+
+    def fused(*args, **kw):
+        a = list(args)
+        a[4] = None
+        return assemble_inputs(*a, **kw)
+
+    c_ref = dict(c)
+    ref, rg = run(eager, c_ref, "cpu", regions)
+    got, gg = run(fused, c, gpu, regions, validate=True)
+    for n, a, b in zip(OUTS, ref, got):
+        if n == "rotations":
+            np.testing.assert_allclose(b, a, rtol=3e-7, atol=1e-7, err_msg=n)
+        else:
+            np.testing.assert_array_equal(b, a, err_msg=n)
+    assert gg["rotation"] is None                                 # nothing flows to the tensor that was not given
+    for k in ORDER:
+        if k == "rotation" or rg[k] is None:
+            continue
+        if k in ("rotation_raw", "d_rot"):
+            # (row 5: g / 1e-12 in both)
+            np.testing.assert_allclose(gg[k], rg[k], rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(rg[k]).max()) * 1e-6), err_msg=k)
+        else:
+            np.testing.assert_array_equal(gg[k], rg[k], err_msg=k)

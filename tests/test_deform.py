@@ -424,3 +424,32 @@ def test_values_beyond_the_fp16_planes_fall_back_to_the_fp32_range(case):
     for name, p in net.named_parameters():
         if p.grad is not None and name in gref:
             assert _rel(p.grad.cpu().numpy(), gref[name]) < BWD_TOL, name
+
+
+@pytest.mark.gpu
+def test_gradients_are_views_of_the_data_parallel_bucket():
+    """The backward leaves the parameter gradients as consecutive views of one buffer: flat_grad_bucket returns that
+    memory itself (no gather, no scatter back), and what is reduced in it is what the optimizer reads."""
+    from gftorf_amd.deform import flat_grad_bucket
+    dev = torch.device("cuda:0")
+    net, _ = _net(4, dev)
+    x, t = _inputs(300, 6, shared_t=True)
+    d_xyz, _, d_sh, _ = net(torch.tensor(x, device=dev), torch.tensor(t, device=dev))
+    (d_xyz.sum() + d_sh.sum()).backward()
+    flat, scatter_back = flat_grad_bucket(net)
+    ps = [p for p in net.parameters() if p.grad is not None]
+    assert flat.untyped_storage().data_ptr() == ps[0].grad.untyped_storage().data_ptr()
+    assert sum(p.numel() for p in ps) <= flat.numel() < sum(p.numel() for p in ps) + 4 * len(ps)
+    before = [p.grad.clone() for p in ps]
+    flat *= 0.5                                   # stands for the all-reduce + average
+    scatter_back(flat)
+    for p, b in zip(ps, before):
+        assert torch.equal(p.grad, 0.5 * b)
+    # a gradient that is NOT in the bucket (set by hand) falls back to the gathered copy
+    ps[3].grad = ps[3].grad.clone()
+    flat2, scatter2 = flat_grad_bucket(net)
+    assert flat2.untyped_storage().data_ptr() != ps[0].grad.untyped_storage().data_ptr() and flat2.numel() == sum(p.numel() for p in ps)
+    flat2 *= 2.0
+    scatter2(flat2)
+    for p, b in zip(ps, before):
+        assert torch.equal(p.grad, b)

@@ -101,5 +101,7 @@ def test_single_rank_rccl_group_runs_the_exchange(gpu, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert res["backend"] == "nccl" and res["world"] == 1
-    assert res["bytes"] == (522055 - 5140) * 4
+    # the backward's gradients ARE the bucket (views of one buffer, each on a 16-byte boundary): the 516 915 values of the
+    # used parameters plus one padding float behind xyz_warp.bias (3 values)
+    assert res["bytes"] == (522055 - 5140 + 1) * 4
     assert res["nonzero"] and res["same"] and res["librccl_mapped"]
