@@ -135,7 +135,7 @@ EXPORTS = [
     "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi", "gft_adam_step_rows",
     "gft_deform_inputs", "gft_deform_packed_bytes", "gft_deform_saved_bytes", "gft_deform_scratch_bytes", "gft_deform_pack",
     "gft_deform_forward", "gft_deform_backward", "gft_deform_compact",
-    "gft_densify_stats", "gft_rows_rank_scratch_bytes", "gft_rows_rank", "gft_rows_gather",
+    "gft_densify_stats", "gft_rows_rank_scratch_bytes", "gft_rows_rank", "gft_rows_gather", "gft_rows_any_nonzero",
 ]
 
 
@@ -211,6 +211,8 @@ def load():
     lib.gft_rows_rank_scratch_bytes.argtypes = [C.c_int64]
     lib.gft_rows_rank.restype = C.c_int
     lib.gft_rows_rank.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.gft_rows_any_nonzero.restype = C.c_int
+    lib.gft_rows_any_nonzero.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.gft_rows_gather.restype = C.c_int
     lib.gft_rows_gather.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.gft_knn_scratch_bytes.restype = C.c_size_t

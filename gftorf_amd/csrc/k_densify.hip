@@ -178,6 +178,53 @@ extern "C" int gft_rows_rank(void* hip_stream, int64_t P, const uint8_t* mask, i
     return 0;
 }
 
+// mask[i] = 1 if row i of `a` ([P, ra] floats) or of `b` ([P, rb] floats) holds a value that is not zero (NaN counts,
+// -0 does not): four lanes per row, 16-byte pieces when a row is a whole number of them
+namespace {
+__device__ __forceinline__ bool row_part_nonzero(const float* __restrict__ t, int64_t row, int r, int q)
+{
+    bool any = false;
+    if (!t) return false;
+    const float* p = t + row * r;
+    if ((r & 3) == 0 && ((uintptr_t)t & 15) == 0) {
+        for (int v = q; v < (r >> 2); v += 4) {
+            const float4 x = reinterpret_cast<const float4*>(p)[v];
+            any |= (x.x != 0.f) | (x.y != 0.f) | (x.z != 0.f) | (x.w != 0.f);
+        }
+    } else {
+        for (int c = q; c < r; c += 4) any |= p[c] != 0.f;
+    }
+    return any;
+}
+
+__global__ __launch_bounds__(256) void k_rows_any_nonzero(int64_t P, int ra, const float* __restrict__ a, int rb,
+                                                          const float* __restrict__ b, uint8_t* __restrict__ mask)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t >> 2;
+    const int q = (int)(t & 3);
+    bool any = false;
+    if (row < P) any = row_part_nonzero(a, row, ra, q) | row_part_nonzero(b, row, rb, q);
+    int v = any ? 1 : 0;
+    v |= __shfl_xor(v, 1);
+    v |= __shfl_xor(v, 2);
+    if (row < P && q == 0) mask[row] = (uint8_t)v;
+}
+}  // namespace
+
+extern "C" int gft_rows_any_nonzero(void* hip_stream, int64_t P, int32_t row_floats_a, const float* a, int32_t row_floats_b,
+                                    const float* b, uint8_t* mask)
+{
+    if (P < 0 || row_floats_a < 0 || row_floats_b < 0) return gft_fail("gft_rows_any_nonzero: negative size");
+    if (P == 0) return 0;
+    if (!mask) return gft_fail("gft_rows_any_nonzero: mask is NULL");
+    if (P > ((int64_t)1 << 40)) return gft_fail("gft_rows_any_nonzero: P too large");
+    hipLaunchKernelGGL(k_rows_any_nonzero, dim3((unsigned)((4 * P + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, P,
+                       (int)row_floats_a, a, (int)row_floats_b, b, mask);
+    GFT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int gft_rows_gather(void* hip_stream, int64_t P, const uint8_t* mask, const int32_t* rank, const void* src, void* dst,
                                int64_t row_bytes)
 {

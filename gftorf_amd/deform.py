@@ -148,14 +148,15 @@ def _compact_rows(lib, n, saved, gx, gs):
     unchanged when most rows count.  `saved` = [n_pad, E] encoding | [8, n_pad, 256] activations | [8, n_pad, 8] ReLU sign
     words (gft_deform_saved_bytes), n_pad = n rounded up to 192."""
     from .densify import RowSelection
-    row_max = None
-    for g in (gx, gs):
-        if g is not None:
-            m = g.reshape(n, -1).abs().amax(dim=1)
-            row_max = m if row_max is None else torch.maximum(row_max, m)
-    # (a NaN upstream row compares False to everything: `~(== 0)` keeps it in the set, so a diverged step shows in the
-    # weight gradients as it does with the dense backward and in the reference)
-    sel = RowSelection(~(row_max == 0))
+    # rows with an upstream gradient: any value != 0 (a NaN row counts, so a diverged step shows in the weight gradients as
+    # it does with the dense backward and in the reference) -- one pass over the two tensors
+    dev = saved.device
+    mask = torch.empty((n,), device=dev, dtype=torch.uint8)
+    ptr0 = lambda t: t.data_ptr() if t is not None else None
+    with _lib.on_device(dev):
+        _lib.check(lib.gft_rows_any_nonzero(_lib.raw_stream(dev), n, 3 if gx is not None else 0, ptr0(gx),
+                                            48 if gs is not None else 0, ptr0(gs), mask.data_ptr()))
+    sel = RowSelection(mask.view(torch.bool))
     k = sel.count
     if k > _SPARSE_MAX_FRACTION * n:
         return n, saved, gx, gs

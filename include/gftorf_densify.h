@@ -45,6 +45,12 @@ int gft_densify_stats(void* hip_stream, int64_t P, const float* viewspace_grad, 
 size_t gft_rows_rank_scratch_bytes(int64_t P);
 int gft_rows_rank(void* hip_stream, int64_t P, const uint8_t* mask, int32_t* rank, void* scratch, int64_t* count);
 
+/* mask[i] = 1 if row i of a ([P, row_floats_a]) or of b ([P, row_floats_b]) holds a value != 0 (a NaN counts, -0 does
+ * not), else 0; either tensor may be NULL.  The rows of a backward that have an upstream gradient -- what
+ * `~((a.abs().amax(1).maximum(b.abs().amax(1))) == 0)` is in eight eager launches and two full-size temporaries. */
+int gft_rows_any_nonzero(void* hip_stream, int64_t P, int32_t row_floats_a, const float* a, int32_t row_floats_b,
+                         const float* b, uint8_t* mask);
+
 /* dst[rank[i]] = src[i] for every row i with mask[i] != 0; rows are row_bytes long (a multiple of 4),
  * src and dst 4-byte aligned (16-byte accesses are used when rows and both pointers allow). */
 int gft_rows_gather(void* hip_stream, int64_t P, const uint8_t* mask, const int32_t* rank, const void* src, void* dst,

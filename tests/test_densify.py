@@ -199,3 +199,36 @@ def test_densify_composites_like_the_reference(P, max_screen_size):
     for grp in a.optimizer.param_groups:
         grp["params"][0].grad = torch.zeros_like(grp["params"][0])
     a.optimizer.step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [0, 1, 63, 1000, 40_003])
+def test_rows_with_a_nonzero_value_match_the_eager_expression(P):
+    """gft_rows_any_nonzero against `~(max(a.abs().amax(1), b.abs().amax(1)) == 0)`: zero rows, -0, NaN, either tensor
+    absent, rows that are / are not a whole number of 16-byte pieces."""
+    from gftorf_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(P + 1)
+    a = torch.randn((P, 3), generator=g)
+    b = torch.randn((P, 16, 3), generator=g)
+    keep = torch.rand((P,), generator=g) < 0.1
+    a[~keep] = 0
+    b[~keep] = 0
+    if P > 10:
+        a[3] = 0; b[3] = 0; b[3, 7, 1] = float("nan")       # NaN counts
+        a[4] = 0; b[4] = 0; a[4, 2] = -0.0                      # -0 does not
+        a[5] = 0; b[5] = 0; b[5, 15, 2] = 1e-38                 # the last value of a row
+    for use_a, use_b in ((True, True), (True, False), (False, True)):
+        ta, tb = a.to(dev), b.to(dev)
+        m = None
+        for t, use in ((ta, use_a), (tb, use_b)):
+            if use:
+                r = t.reshape(P, -1).abs().amax(dim=1) if P else t.new_zeros((0,))
+                m = r if m is None else torch.maximum(m, r)
+        want = ~(m == 0)
+        mask = torch.full((P,), 7, device=dev, dtype=torch.uint8)
+        with _lib.on_device(dev):
+            _lib.check(lib.gft_rows_any_nonzero(_lib.raw_stream(dev), P, 3 if use_a else 0, ta.data_ptr() if (use_a and P) else None,
+                                                48 if use_b else 0, tb.data_ptr() if (use_b and P) else None, mask.data_ptr() if P else None))
+        assert torch.equal(mask.bool(), want) and (P == 0 or int(mask.max()) <= 1)
