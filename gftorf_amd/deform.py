@@ -35,7 +35,18 @@ _PAD = 192                       # DF_PAD: point counts are padded to multiples 
 sparse_backward = True
 _SPARSE_MIN_POINTS = 8192        # below this the dense backward is launch-bound anyway
 _SPARSE_MAX_FRACTION = 0.6       # above this the compaction costs more than it saves
-last_backward_stats = {"points": 0, "points_processed": 0}
+last_backward_stats = {"points": 0, "points_processed": 0, "recomputed": False}
+
+# Activations on demand.  A saving forward writes 8.4 KB per point for the backward (2.5 GB at 300 k points, a sixth of the
+# forward's time -- and of its energy: that kernel runs at the board's power limit).  When the last backward used few of
+# the rows (the usual training iteration: only Gaussians that a pixel blended carry a gradient), the next forward keeps
+# NOTHING; its backward gathers the inputs of the rows that count, runs the saving forward on those rows alone (a point's
+# activations do not depend on the batch it is in: bit-identical) and goes on as before -- no 2.5 GB, no compaction of them.
+# A backward that finds many rows with a gradient after all recomputes all of them (one extra forward, once) and the next
+# forward saves again.  `GFT_DEFORM_LAZY_SAVE=0` in the environment or `gftorf_amd.deform.lazy_save = False`: always save.
+import os as _os
+lazy_save = _os.environ.get("GFT_DEFORM_LAZY_SAVE", "1") != "0"
+_LAZY_MAX_FRACTION = 0.25        # recomputing that share of the rows costs less than saving all of them
 
 
 def _param_list(mod):
@@ -67,7 +78,7 @@ def _prod(shape):
 
 class _DeformFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xm, tm, x, t, *params):
+    def forward(ctx, xm, tm, state, x, t, *params):
         lib = _lib.load()
         dev = x.device
         if dev.type != "cuda":
@@ -89,12 +100,14 @@ class _DeformFn(torch.autograd.Function):
             if p.device != dev or p.dtype != torch.float32:
                 raise RuntimeError("DeformNetwork parameters must be float32 on %s" % (dev,))
             ps.append(p.detach().contiguous())
-        need_bw = any(ctx.needs_input_grad[4:])      # all False under torch.no_grad()
+        need_bw = any(ctx.needs_input_grad[5:])      # all False under torch.no_grad()
+        lazy = bool(need_bw and lazy_save and sparse_backward and n >= _SPARSE_MIN_POINTS and state is not None
+                    and state.get("fraction") is not None and state["fraction"] <= _LAZY_MAX_FRACTION)
         f32 = dict(device=dev, dtype=torch.float32)
         packed = torch.empty((lib.gft_deform_packed_bytes() // 4,), **f32)
         d_xyz = torch.empty((n, 3), **f32)
         d_sh = torch.empty((n, 16, 3), **f32)
-        saved = torch.empty((lib.gft_deform_saved_bytes(n) // 4,), **f32) if (need_bw and n > 0) else None
+        saved = torch.empty((lib.gft_deform_saved_bytes(n) // 4,), **f32) if (need_bw and n > 0 and not lazy) else None
         stream = _lib.raw_stream(dev)
         with _lib.on_device(dev):
             _lib.check(lib.gft_deform_pack(stream, xm, tm, C.byref(_fill(_lib.DeformParams(), ps)), packed.data_ptr()))
@@ -104,17 +117,27 @@ class _DeformFn(torch.autograd.Function):
         ctx.n = n
         ctx.arch = (xm, tm)
         ctx.shapes = [tuple(p.shape) for p in params]
-        ctx.save_for_backward(packed, saved if saved is not None else packed.new_empty(0))
+        ctx.state = state
+        ctx.lazy = lazy
+        if lazy:
+            ctx.t_stride = t_stride
+            ctx.save_for_backward(packed, x_c, t_c)
+        else:
+            ctx.save_for_backward(packed, saved if saved is not None else packed.new_empty(0))
         ctx.set_materialize_grads(False)
         return d_xyz, d_sh
 
     @staticmethod
     def backward(ctx, g_dxyz, g_dsh):
         lib = _lib.load()
-        packed, saved = ctx.saved_tensors
+        if ctx.lazy:
+            packed, x_c, t_c = ctx.saved_tensors
+            saved = None
+        else:
+            packed, saved = ctx.saved_tensors
         dev = packed.device
         n = ctx.n
-        if n > 0 and saved.numel() == 0:
+        if n > 0 and not ctx.lazy and saved.numel() == 0:
             raise RuntimeError("DeformNetwork: backward through a forward that ran without gradients")
         f32 = dict(device=dev, dtype=torch.float32)
         # the gradients are views of ONE flat buffer, in parameter order: the data-parallel bucket (flat_grad_bucket) is
@@ -128,10 +151,16 @@ class _DeformFn(torch.autograd.Function):
             o += (k + 3) // 4 * 4
         gx = g_dxyz.float().contiguous() if g_dxyz is not None else None
         gs = g_dsh.float().contiguous() if g_dsh is not None else None
-        last_backward_stats.update(points=n, points_processed=n)
-        if sparse_backward and n >= _SPARSE_MIN_POINTS and (gx is not None or gs is not None):
+        last_backward_stats.update(points=n, points_processed=n, recomputed=ctx.lazy)
+        n_all = n
+        if ctx.lazy:
+            n, saved, gx, gs = _recompute_rows(lib, ctx, n, packed, x_c, t_c, gx, gs)
+            last_backward_stats["points_processed"] = n
+        elif sparse_backward and n >= _SPARSE_MIN_POINTS and (gx is not None or gs is not None):
             n, saved, gx, gs = _compact_rows(lib, n, saved, gx, gs)
             last_backward_stats["points_processed"] = n
+        if ctx.state is not None and n_all >= _SPARSE_MIN_POINTS:
+            ctx.state["fraction"] = n / float(n_all)
         scratch = torch.empty((lib.gft_deform_scratch_bytes(n) // 4,), **f32)
         stream = _lib.raw_stream(dev)
         with _lib.on_device(dev):
@@ -140,23 +169,52 @@ class _DeformFn(torch.autograd.Function):
                                                gs.data_ptr() if (gs is not None and n) else None,
                                                scratch.data_ptr() if n else None,
                                                C.byref(_fill(_lib.DeformParams(), grads))))
-        return (None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[4:]))
+        return (None, None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[5:]))
+
+
+def _rows_with_gradient(lib, n, gx, gs, dev):
+    """RowSelection of the rows whose upstream gradient holds a value != 0 (a NaN row counts, so a diverged step shows in
+    the weight gradients as it does with the dense backward and in the reference): one pass over the two tensors."""
+    from .densify import RowSelection
+    mask = torch.empty((n,), device=dev, dtype=torch.uint8)
+    ptr0 = lambda t: t.data_ptr() if t is not None else None
+    with _lib.on_device(dev):
+        _lib.check(lib.gft_rows_any_nonzero(_lib.raw_stream(dev), n, 3 if gx is not None else 0, ptr0(gx),
+                                            48 if gs is not None else 0, ptr0(gs), mask.data_ptr()))
+    return RowSelection(mask.view(torch.bool))
+
+
+def _recompute_rows(lib, ctx, n, packed, x_c, t_c, gx, gs):
+    """The forward kept nothing (lazy_save): the saved activations of the rows with an upstream gradient, from a saving
+    forward over those rows alone (all rows when they turn out to be many), and the gradients of those rows."""
+    dev = packed.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    if n == 0 or (gx is None and gs is None):
+        return 0, None, None, None
+    sel = _rows_with_gradient(lib, n, gx, gs, dev)
+    k = sel.count
+    if k == 0:
+        return 0, None, None, None
+    if k > _SPARSE_MAX_FRACTION * n:
+        k, xs, ts = n, x_c, t_c                                      # dense after all: every row again
+    else:
+        xs = sel.take(x_c)
+        ts = t_c if ctx.t_stride == 0 else sel.take(t_c)
+        gx = sel.take(gx) if gx is not None else None
+        gs = sel.take(gs) if gs is not None else None
+    saved = torch.empty((lib.gft_deform_saved_bytes(k) // 4,), **f32)
+    d_xyz, d_sh = torch.empty((k, 3), **f32), torch.empty((k, 16, 3), **f32)
+    with _lib.on_device(dev):
+        _lib.check(lib.gft_deform_forward(_lib.raw_stream(dev), ctx.arch[0], ctx.arch[1], k, xs.data_ptr(), ts.data_ptr(),
+                                          ctx.t_stride, packed.data_ptr(), saved.data_ptr(), d_xyz.data_ptr(), d_sh.data_ptr()))
+    return k, saved, gx, gs
 
 
 def _compact_rows(lib, n, saved, gx, gs):
     """Rows of (saved activations, upstream gradients) whose upstream gradient is non-zero, compacted; everything
     unchanged when most rows count.  `saved` = [n_pad, E] encoding | [8, n_pad, 256] activations | [8, n_pad, 8] ReLU sign
     words (gft_deform_saved_bytes), n_pad = n rounded up to 192."""
-    from .densify import RowSelection
-    # rows with an upstream gradient: any value != 0 (a NaN row counts, so a diverged step shows in the weight gradients as
-    # it does with the dense backward and in the reference) -- one pass over the two tensors
-    dev = saved.device
-    mask = torch.empty((n,), device=dev, dtype=torch.uint8)
-    ptr0 = lambda t: t.data_ptr() if t is not None else None
-    with _lib.on_device(dev):
-        _lib.check(lib.gft_rows_any_nonzero(_lib.raw_stream(dev), n, 3 if gx is not None else 0, ptr0(gx),
-                                            48 if gs is not None else 0, ptr0(gs), mask.data_ptr()))
-    sel = RowSelection(mask.view(torch.bool))
+    sel = _rows_with_gradient(lib, n, gx, gs, saved.device)
     k = sel.count
     if k > _SPARSE_MAX_FRACTION * n:
         return n, saved, gx, gs
@@ -227,7 +285,9 @@ class DeformNetwork(nn.Module):
             nn.init.constant_(head.bias, 0.0)
 
     def forward(self, x, t):
-        d_xyz, d_sh = _DeformFn.apply(self.xyz_multires, self.t_multires, x, t, *_param_list(self))
+        if not hasattr(self, "_save_state"):
+            self._save_state = {"fraction": None}      # share of the rows the last backward used (lazy_save)
+        d_xyz, d_sh = _DeformFn.apply(self.xyz_multires, self.t_multires, self._save_state, x, t, *_param_list(self))
         n = x.size(0)
         zeros = lambda *shape: torch.zeros(shape, device=x.device, dtype=torch.float32)
         return d_xyz, zeros(n, 4), d_sh, zeros(n, self.num_shs, 2)
