@@ -284,10 +284,16 @@ class DeformNetwork(nn.Module):
             nn.init.normal_(head.weight, mean=0.0, std=1e-5)
             nn.init.constant_(head.bias, 0.0)
 
-    def forward(self, x, t):
+    def forward(self, x, t, zeros_as_scalars=False):
+        """``d_xyz, d_rot, d_sh, d_sh_p`` as the reference returns them (time_utils.py:127: the rotation and phasor offsets
+        are zeros).  ``zeros_as_scalars=True`` returns the Python float 0.0 for those two instead of [n, 4] and [n, 16, 2]
+        tensors of zeros -- what train.py:164 passes for a static scene, and what the renderer's additions and
+        ``assemble_inputs`` take as well: no 128 bytes per point filled, read and given a gradient for nothing."""
         if not hasattr(self, "_save_state"):
             self._save_state = {"fraction": None}      # share of the rows the last backward used (lazy_save)
         d_xyz, d_sh = _DeformFn.apply(self.xyz_multires, self.t_multires, self._save_state, x, t, *_param_list(self))
+        if zeros_as_scalars:
+            return d_xyz, 0.0, d_sh, 0.0
         n = x.size(0)
         zeros = lambda *shape: torch.zeros(shape, device=x.device, dtype=torch.float32)
         return d_xyz, zeros(n, 4), d_sh, zeros(n, self.num_shs, 2)

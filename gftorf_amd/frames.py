@@ -50,6 +50,8 @@ class FrameStep:
         self.exchanges = 0          # collectives issued so far: one per iteration
         self.exchanged_bytes = 0
         self.last = None
+        from .deform import DeformNetwork
+        self._scalar_zeros = isinstance(net, DeformNetwork) and assemble is assemble_inputs
         self.mark = None            # optional `mark(name)` called at the phase boundaries (bench.py records events there)
 
     def frame_time(self, frame_id):
@@ -61,7 +63,8 @@ class FrameStep:
         mark = self.mark or (lambda name: None)
         mark("start")
         t = torch.full((1, 1), self.frame_time(frame_id), device=dev, dtype=torch.float32).expand(n, -1)
-        d_xyz, d_rot, d_sh, d_sh_p = self.net(self.x_norm, t)
+        # (this package's network hands the two all-zero offsets over as the scalar 0.0, as train.py:164 does for a static scene)
+        d_xyz, d_rot, d_sh, d_sh_p = self.net(self.x_norm, t, zeros_as_scalars=True) if self._scalar_zeros else self.net(self.x_norm, t)
         mark("network_forward")
         ssp = torch.zeros((g["xyz"].size(0), 3), device=dev, dtype=torch.float32, requires_grad=True)
         # pc.get_rotation: this package's assembly normalises the static rows itself (rotation=None); a stand-in gets the
