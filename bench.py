@@ -1250,7 +1250,12 @@ def main():
                          "dominant": {"kernel": "k_deform_fwd_h" if fwd_terms == 3.0 else "k_deform_fwd_bf", "bound": "mfma", "achieved": tf_fwd,
                                       "peak": BF16_MFMA_PEAK_TFLOPS / fwd_terms,
                                       "unit": "TFLOP/s", "frac": tf_fwd / (BF16_MFMA_PEAK_TFLOPS / fwd_terms), "points": n_dyn,
-                                      "avg_launch_ms": phase.get("network_forward")}}
+                                      "avg_launch_ms": phase.get("network_forward"),
+                                      "note": "peak = 2500 TFLOP/s of fp16 MFMA at 2.4 GHz over the multiplies per fp32 product; the "
+                                              "kernel runs at the board's power limit (1372-1376 W of 1400, engine clock 1.5-2.1 GHz "
+                                              "while it runs: profiles/r04_power_clock_samples.txt, DESIGN 10.1) -- the gap to the peak "
+                                              "is energy per point, not issue slots; avg_launch_ms is the phase between two events "
+                                              "(the walk plus the three pack kernels of the call)"}}
         exchange = {"in_the_timed_step": True, "collectives_per_step": fs.exchanges / max(state["it"], 1),
                     "bucket_bytes": fs.exchanged_bytes, "backend": dist.get_backend() if dist is not None else None,
                     "ranks": dist.get_world_size() if dist is not None else 0,

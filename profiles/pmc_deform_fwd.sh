@@ -39,9 +39,9 @@ res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_deform_fwd" not in k:
+        if "k_deform_fwd_h" not in k:          # (not the bf16 walk's returning launches behind it)
             continue
-        k = "saving" if "Lb1" in k or "<true" in k else "inference"
+        k = "saving (k_deform_fwd_h<true, 4>)" if "Lb1" in k or "<true" in k else "inference (k_deform_fwd_h<false, 8>)"
         res[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if r["Counter_Name"] in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAIT_INST_LDS", "SQ_INST_CYCLES_VMEM", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum"):
             res[k]["dur_us:" + r["Counter_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
