@@ -264,7 +264,8 @@ size_t gft_geom_bytes(int32_t P);
 size_t gft_image_bytes(int32_t W, int32_t H);
 size_t gft_binning_bytes(int64_t R, int32_t W, int32_t H);
 size_t gft_acc_bytes(int32_t P);
-size_t gft_det_partials_bytes(int64_t binning_instances, int32_t W, int32_t H);   /* gft_backward_io.det_partials */
+size_t gft_det_partials_bytes(int64_t binning_instances, int32_t W, int32_t H);   /* gft_backward_io.det_partials: 256 bytes per list slot
+                                                                                   * (tiles x head slots + instances: 4.3 GB at 1080p) -- a test mode */
 /* instances a binning buffer of `bytes` bytes holds (inverse of gft_binning_bytes for multiples of 64) */
 int64_t gft_binning_capacity(size_t bytes, int32_t W, int32_t H);
 /* 1: tile-pull binning (default): ids to supertiles, every tile pulls and sorts the head of its own list, lists are
