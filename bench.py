@@ -1371,6 +1371,12 @@ def main():
             out["deform_exchange"] = exchange
         if composed_step is not None:
             out["composed_step"] = composed_step
+            # the composed step's dominant kernel is the network's forward walk (matrix-core bound), not a rasterizer kernel:
+            # `roofline` describes it; the rasterizer's own dominant kernel moves to `raster_roofline`
+            out["raster_roofline"] = out["roofline"]
+            out["roofline"] = dict(composed_step["dominant"], traffic=None)
+            out["metric"] = ("composed frame steps/sec: network query + input assembly + raster fwd+bwd + network backward + "
+                             "gradient all-reduce, 1M Gaussians (30 % dynamic) @ 640x480 ToF, one frame per rank")
         # (the measurements beside the headline belong to the metric workload; named explicitly they run on any workload's
         # scene, e.g. `--workload C5 --extras varying_views`)
         if world == 1 and not args.no_extras and (args.workload == "metric" or args.extras != "all"):
