@@ -77,6 +77,53 @@ def _worker_deform(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_deform_views(rank, world, port, q):
+    """As _worker_deform, with the gradients laid out as the HIP backward leaves them: consecutive views of ONE buffer, each
+    on a 16-byte boundary -- flat_grad_bucket must hand that memory to the all-reduce itself."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from gftorf_amd.deform import reference_network, allreduce_gradients, flat_grad_bucket, _param_list
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = reference_network()
+    ps = _param_list(net)
+    sizes = [p.numel() for p in ps]
+    buf = torch.zeros(sum((k + 3) // 4 * 4 for k in sizes))
+    g = torch.Generator().manual_seed(200 + rank)
+    o = 0
+    for p, k in zip(ps, sizes):
+        p.grad = buf[o:o + k].view(p.shape)
+        p.grad.copy_(torch.randn(p.shape, generator=g))
+        o += (k + 3) // 4 * 4
+    mine = buf.clone()
+    flat, _ = flat_grad_bucket(net)
+    in_place = flat.untyped_storage().data_ptr() == buf.untyped_storage().data_ptr() and flat.numel() == buf.numel() - (buf.numel() - o) - ((sizes[-1] + 3) // 4 * 4 - sizes[-1])
+    nbytes = allreduce_gradients(net, dist, average=True)
+    q.put((rank, nbytes, bool(in_place), mine.numpy(), buf.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_in_the_gradients_own_buffer():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_deform_views, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, nb0, ip0, mine0, red0), (_, nb1, ip1, mine1, red1) = res
+    assert ip0 and ip1                                        # no gathered copy was made
+    assert nb0 == nb1 == (522055 - 5140 + 1) * 4              # the used parameters + one padding float behind xyz_warp.bias
+    import numpy as np
+    np.testing.assert_allclose(red0, (mine0 + mine1) / 2, rtol=1e-6, atol=1e-7)
+    assert (red0 == red1).all()                               # p.grad of both replicas IS the reduced buffer
+
+
 def test_two_rank_deform_gradient_allreduce():
     """The one exchange step of the path: all-reduce of the deformation network's gradient
     bucket; here over gloo with two CPU ranks."""
