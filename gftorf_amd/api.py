@@ -328,6 +328,9 @@ class _Settings(NamedTuple):
     use_view_dependent_phase: bool
 
 
+_PLANE_SPLIT = (3, 7, 1, 3, 1, 1, 1, 1, 3)     # color, phasor, depth, normal, acc, entropy, depth_distortion, amp_distortion, distribution
+
+
 def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
                    cov3Ds_precomp, ph_off, dc_off, want_bw, with_acc, stream=None, hint_slot=0, share_grads=None,
                    pre_launch=None, acc_any_stream=False):
@@ -373,9 +376,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
 
     f32 = dict(device=dev, dtype=torch.float32)
     planes = torch.empty((21, H, W), **f32)
-    color, phasor, depth = planes[0:3], planes[3:10], planes[10:11]
-    normal, acc, entropy = planes[11:14], planes[14:15], planes[15:16]
-    depth_distortion, amp_distortion, distribution = planes[16:17], planes[17:18], planes[18:21]
+    # (one split instead of nine slices: host time)
+    color, phasor, depth, normal, acc, entropy, depth_distortion, amp_distortion, distribution = planes.split(_PLANE_SPLIT)
     radii = torch.empty((P,), device=dev, dtype=torch.int32)
     pixels = torch.empty((P, 1), **f32)
     geom = torch.empty((lib.gft_geom_bytes(P),), device=dev, dtype=torch.uint8)
@@ -568,14 +570,15 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
             buf = torch.empty((total,), **f32)
         if zero_fill:
             zero_buf = buf
-        g, o = {}, 0
-        for k, v in shapes.items():
-            if v is None:
-                g[k] = None
-            else:
-                g[k] = buf[o:o + _prod(v)].view(v)
-                o += sizes[k]
-        g["offsets"] = buf[o:o + 2]
+        # (one split into the padded pieces, then one view each: host time)
+        keys = [k for k, v in shapes.items() if v is not None]
+        pieces = buf.split([sizes[k] for k in keys] + [4])
+        g = dict.fromkeys(shapes)
+        for k, piece in zip(keys, pieces):
+            v = shapes[k]
+            n = _prod(v)
+            g[k] = (piece if n == sizes[k] else piece[:n]).view(v)
+        g["offsets"] = pieces[-1][:2]
         if entry is not None and not _USE_COUNT_API:
             entry["held"] = (buf, [t for t in g.values() if t is not None])
         if reused_grads and _GRADS_CHECK:
