@@ -1196,8 +1196,13 @@ def main():
     # tens of milliseconds of load, and W steps of 0.65 ms are over before that (an occasional 30 % slower
     # timed leg with normal per-kernel times in the profiled leg was the symptom).  Untimed.
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.spin_up:
-        step()
+    if composed and dist is not None and dist.get_world_size() > 1:
+        # (every composed step holds a collective: all ranks must run the same number of them, so a count, not a time)
+        for _ in range(max(1, int(args.spin_up / 0.003))):
+            step()
+    else:
+        while time.perf_counter() - t_spin < args.spin_up:
+            step()
     sync()
 
     elapsed = timed_steps(step, args.steps, args.warmup, sync, dist)

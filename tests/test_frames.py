@@ -1,5 +1,6 @@
 """BASELINE.json config 4's per-rank step (gftorf_amd.frames.FrameStep) on the GPU: the composed HIP step against the
 same step composed from the oracles, and the path's one collective through a real RCCL communicator."""
+import json
 import os
 import subprocess
 import sys
@@ -105,3 +106,26 @@ def test_single_rank_rccl_group_runs_the_exchange(gpu, tmp_path):
     # used parameters plus one padding float behind xyz_warp.bias (3 values)
     assert res["bytes"] == (522055 - 5140 + 1) * 4
     assert res["nonzero"] and res["same"] and res["librccl_mapped"]
+
+
+@pytest.mark.gpu
+def test_bench_c4_runs_with_two_ranks(tmp_path):
+    """`bench.py --workload C4 --gpus 2` as the driver launches it (torch.distributed.run), rehearsed with both ranks on
+    this one GPU over gloo (GFT_BENCH_REHEARSAL=1): every composed step holds a collective, so all ranks must run the same
+    number of steps in every leg -- a time-based spin-up once made the ranks' counts differ and the run hung."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.update(GFT_BENCH_REHEARSAL="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--workload", "C4", "--no-cpu-baseline", "--spin-up", "0.05"],
+                       env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0
+    assert line["deform_exchange"]["in_the_timed_step"] and line["deform_exchange"]["collectives_per_step"] == 1.0
+    assert line["deform_exchange"]["ranks"] == 2 and line["roofline"]["kernel"].startswith("k_deform_fwd")
