@@ -52,6 +52,7 @@ class FrameStep:
         self.last = None
         from .deform import DeformNetwork
         self._scalar_zeros = isinstance(net, DeformNetwork) and assemble is assemble_inputs
+        self._ssp = None
         self.mark = None            # optional `mark(name)` called at the phase boundaries (bench.py records events there)
 
     def frame_time(self, frame_id):
@@ -66,7 +67,12 @@ class FrameStep:
         # (this package's network hands the two all-zero offsets over as the scalar 0.0, as train.py:164 does for a static scene)
         d_xyz, d_rot, d_sh, d_sh_p = self.net(self.x_norm, t, zeros_as_scalars=True) if self._scalar_zeros else self.net(self.x_norm, t)
         mark("network_forward")
-        ssp = torch.zeros((g["xyz"].size(0), 3), device=dev, dtype=torch.float32, requires_grad=True)
+        # screenspace_points (gaussian_renderer/__init__.py:52-56): zeros whose only role is to receive a gradient -- the same
+        # leaf every step (its values are never written), the gradient of the last step dropped
+        ssp = self._ssp
+        if ssp is None or ssp.size(0) != g["xyz"].size(0) or ssp.device != dev:
+            ssp = self._ssp = torch.zeros((g["xyz"].size(0), 3), device=dev, dtype=torch.float32, requires_grad=True)
+        ssp.grad = None
         # pc.get_rotation: this package's assembly normalises the static rows itself (rotation=None); a stand-in gets the
         # activated tensor as the reference's renderer does
         rot = None if self.assemble is assemble_inputs else torch.nn.functional.normalize(g["rotation_raw"])
