@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 DEFORM_MAX_INPUTS = 96          # GFT_DEFORM_MAX_INPUTS (include/gftorf_deform.h)
 ACC_STRIDE = 16
 
@@ -63,7 +63,7 @@ PROFILE_FIELDS = ["preprocess_fwd_ms", "tile_count_ms", "tile_scatter_ms", "tile
 
 
 class ForwardIO(C.Structure):
-    _fields_ = [(n, _fp) for n in FORWARD_FIELDS] + [("grads_zero", _fp), ("grads_zero_bytes", C.c_size_t)]
+    _fields_ = [(n, _fp) for n in FORWARD_FIELDS] + [("grads_zero", _fp), ("grads_zero_bytes", C.c_size_t), ("tile_hints", _fp)]
 
 
 class BackwardIO(C.Structure):

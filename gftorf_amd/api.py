@@ -69,6 +69,22 @@ _ZERO_FILL = _os.environ.get("GFT_GRADS_ZERO_FILL", "0") != "0"
 # (bit-reproducible gradients; several times slower: for tests)
 _DETERMINISTIC = _os.environ.get("GFT_BWD_DETERMINISTIC", "0") != "0"
 _HINT_HEADROOM = 1.25
+# The other thing kept from frame to frame of a shape, on the device: one word per tile saying whether one of its
+# quadrants walked past where a sorted list head ends (gft_forward_io.tile_hints).  The next forward sorts such a tile's
+# whole list up front instead of head first / rest on demand -- a schedule like the buffer size above, never a result
+# (tests/test_gpu_parity.py::test_tile_hints_do_not_change_results).  GFT_TILE_HINTS=0 switches it off.  The buffers are
+# 4 bytes per tile and are never freed (a kernel of an earlier call may still read or write them).
+_TILE_HINTS = _os.environ.get("GFT_TILE_HINTS", "1") != "0"
+_tile_hints = {}
+
+
+def _tile_hint_buffer(key, dev, W, H):
+    if not _TILE_HINTS:
+        return None
+    buf = _tile_hints.get(key)
+    if buf is None and len(_tile_hints) < 1024:
+        buf = _tile_hints[key] = torch.zeros((((W + 15) // 16) * ((H + 15) // 16),), device=dev, dtype=torch.int32)
+    return buf
 # Gradient tensors kept from one backward to the next.  The operator returns dense gradient tensors (376 B per Gaussian
 # with SH colour + SH phasor of 16 coefficients) of which a dense frame fills a few per cent of the rows (the Gaussians
 # some pixel blended); writing the zeros of all the other rows is most of the backward's preprocess kernel (65 of 100 us at
@@ -101,6 +117,24 @@ _grad_pool = {}           # (device, P, layout) -> list of {buf, dirty, version,
 _DENSE_SHARE = 0.3        # rows written by the last rows-only backward / P above which the tensors are written in full
 _DENSE_RUN = 15           # ... for this many backwards, before a rows-only one counts again
 _GRAD_POOL_DEPTH = 3      # rasterizer calls of one iteration whose gradient tensors are alive at the same time
+
+
+_report_slab = []         # [pinned int32 array, next slot]
+
+
+def _report_slot():
+    """One pinned host word for a pool entry's row count (gft_backward_io.rows_report), as a 1-element view of a process-wide
+    array that is never freed: the backward that stores into it may still be in flight when its entry is dropped from the
+    pool (P changes with every densification), and a freed pinned block may be handed to another `pin_memory()` user.
+    Slots are reused round robin after 4096 entries; a stale store then lands in another entry's count -- a schedule
+    (rows-only or full write), never a value."""
+    if not _report_slab:
+        _report_slab.extend([torch.zeros((4096,), dtype=torch.int32).pin_memory(), 0])
+    i = _report_slab[1]
+    _report_slab[1] = (i + 1) % 4096
+    slot = _report_slab[0][i:i + 1]
+    slot.zero_()
+    return slot
 
 
 def _storage_refs(t):
@@ -430,6 +464,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         num_rendered = C.c_int64(0)
         hint_key = (dev.index, P, W, H) if not hint_slot else (dev.index, P, W, H, hint_slot)
         hint, list_hint = _instance_hint.get(hint_key, (None, 0))
+        tile_hints = _tile_hint_buffer(hint_key, dev, W, H)
+        io.tile_hints = _ptr(tile_hints)
         try:
             with _lib.on_device(dev):
                 if hint is None:
@@ -534,8 +570,14 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
                 free = [e for e in pool if _storage_refs(e["buf"]) == e["base"] and e["buf"]._version == e["version"]]
             else:
                 # (DLPack route: the references that kept autograd from taking the tensors over are dropped now; an alias
-                # nobody else holds dies right here and its deleter marks the entry free)
+                # nobody else holds dies right here and its deleter marks the entry free.  An entry that is still waiting for
+                # its backward -- forward A, forward B, A.backward(), B.backward() -- loses that protection before autograd
+                # has seen its tensors: they may become a leaf's `.grad` and take the other call's gradient in place, which
+                # an alias's dead version counter cannot show.  Such an entry is never trusted to be zero outside its marked
+                # rows again: `spoiled` keeps `valid` off, so its next user writes it in full.)
                 for e in pool:
+                    if e["held"] is not None and not e["valid"]:
+                        e["spoiled"] = True
                     e["held"] = None
                 free = [e for e in pool if e["free"]]
             # `valid`: the last backward into this buffer returned without error, so every row is defined -- zero or marked
@@ -552,7 +594,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
                 buf = torch.empty((total,), **f32)
                 # (`dirty`: a mark per Gaussian + the 144 bytes behind them in which the rows backward counts; `report`: pinned
                 # host word into which it stores the number of rows it wrote -- gft_backward_io.rows_report)
-                report = torch.zeros((4,), dtype=torch.int32).pin_memory()
+                report = _report_slot()
                 entry = dict(buf=buf, dirty=torch.zeros(((P + 3) // 4 * 4 + 144,), device=dev, dtype=torch.uint8), version=buf._version,
                              valid=False, report=report, report_np=report.numpy(), dense_left=0)
                 if _USE_COUNT_API:
@@ -564,6 +606,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
                 if len(_grad_pool) > 8:
                     _grad_pool.pop(next(iter(_grad_pool)))
             entry["valid"] = False        # until the backward of this forward has returned (run_backward)
+            entry["spoiled"] = False
             buf = entry["buf"] if _USE_COUNT_API else _dl_alias(entry)
             pool_entry = entry
         else:
@@ -695,7 +738,9 @@ def run_backward(prep, grads_out, geom, binning, img, debug=False):
             stream = _lib.raw_stream(dev)
             _lib.check(lib.gft_backward(stream, C.byref(prep["cfg"]), C.byref(io), cap))
         if pool_entry is not None and not prep["cfg"].grads_accumulate:
-            pool_entry["valid"] = True     # every row of the kept gradient tensors is defined now (api._grad_pool)
+            # every row of the kept gradient tensors is defined now (api._grad_pool) -- unless, on the DLPack route, another
+            # forward of the shape let go of them before this backward ran
+            pool_entry["valid"] = not pool_entry.get("spoiled", False)
         if lease is not None and prep["cfg"].acc_zeroed == 2:
             lease.zero, lease.stream = True, stream
             lease.give_back()

@@ -498,7 +498,10 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
         }
         {
             StageTimer t(s, ST_TILE_SORT);
-            GFT_STAGE(s, cfg, "tile_pull", gft_launch_tile_pull(s, *cfg, g, im, b, cap, clear, clear_bytes));
+            // (no schedule on frames whose forward blend is segment-parallel: see gft_launch_render_fwd)
+            const int T = ((cfg->W + GFT_TILE_X - 1) / GFT_TILE_X) * ((cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y);
+            GFT_STAGE(s, cfg, "tile_pull", gft_launch_tile_pull(s, *cfg, g, im, b, cap, clear, clear_bytes,
+                                                                gft_fwd_segmented(T) ? nullptr : io->tile_hints));
         }
         {
             StageTimer t(s, ST_PRE_FWD);

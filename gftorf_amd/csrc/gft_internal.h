@@ -73,6 +73,7 @@ struct BinView {
 #define GFT_CTRL_ENTRIES 5   // tile-pull binning: (Gaussian, supertile) entries
 #define GFT_CTRL_POOLCUR 6   // tile-pull binning: ids taken from the pool of completed lists
 #define GFT_CTRL_DONE2 7     // finished workgroups of k_tail_build (ticket for the backward's tile order)
+#define GFT_CTRL_WHOLEIDS 8  // tile-pull binning: ids of the lists that hinted tiles sorted whole (they lie in the pool: part of POOLCUR)
 #define GFT_CTRL_RSUM 9      // tile-pull binning: R as summed by the supertile count pass
 #define GFT_CTRL_ORDER_OK 11 // the forward computed the backward's heavy-first tile order
 #define GFT_CTRL_WORDS 16
@@ -86,6 +87,8 @@ struct BinView {
 #define GFT_SUPER_CELLS (GFT_SUPER_MAX * GFT_SLAB_MAX)
 #define GFT_DEPTH_BINS 4096  // depth bins a supertile entry carries (12 bits); slab = top bits of the bin
 #define GFT_HEAD_SLOT 2048u  // ids per tile head slot = longest sorted head
+#define GFT_HEAD_DIRECT 2048u // tile-pull binning: lists up to this length are sorted whole in the first place
+#define GFT_HEAD_TARGET 940u  // ... wanted length of the sorted head of a longer list
 #define GFT_NO_TAIL 0xffffffffu
 #define GFT_BLOCKHIST_TILES 2048
 // binning workgroup shape (k_binning.hip): 16 waves per workgroup keep one CU busy on their own
@@ -127,6 +130,8 @@ inline int gft_fwd_seg_waves(int T)
     return n < 1 ? 1 : (n > 8 ? 8 : n);
 }
 int gft_render_mode();      // -1: default (segments on under-filled frames), 0: one wave per quadrant, 1: segments (gft_set_render_mode / GFT_FWD_SEG)
+// does the first pass of a T-tile frame run the segment-parallel kernel?
+inline bool gft_fwd_segmented(int T) { return gft_render_mode() != 0 && gft_fwd_seg_waves(T) > 1; }
 #define GFT_SNAP_F4 3      // float4 per pixel and snapshot: {T, C0, C1, C2} {PR, PI, PA, Dd} {A, DD_D, DD_D2, -}
 
 void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* L);
@@ -171,7 +176,7 @@ SuperShape gft_super_shape(const gft_config& c);
 hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
                                 uint32_t* mail, uint32_t seq, int pass, uint32_t cap);
 hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
-                                uint32_t cap, float* clear, size_t clear_bytes);
+                                uint32_t cap, float* clear, size_t clear_bytes, const uint32_t* hints);
 hipError_t gft_launch_tail_build(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
                                  const ImgView& im, const BinView& b, uint32_t cap, bool want_order);
 // lazy: 0 = lists sorted whole, 1 = first pass over the sorted heads, 2 = resume pass of the flagged quadrants

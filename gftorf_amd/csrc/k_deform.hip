@@ -684,10 +684,12 @@ __global__ __launch_bounds__(64 * DF_FWD_WAVES) void k_deform_fwd_bf(FwdArgs a)
                 for (int g = 0; g < 4; g++) {
                     const int row = 32 * rt + li, col = n0 + 32 * ct + acc_col4(g, hh);
                     float4 v;
-                    v.x = fmaxf(acc[rt][ct][4 * g] + bv[ct][g].x, 0.f);
-                    v.y = fmaxf(acc[rt][ct][4 * g + 1] + bv[ct][g].y, 0.f);
-                    v.z = fmaxf(acc[rt][ct][4 * g + 2] + bv[ct][g].z, 0.f);
-                    v.w = fmaxf(acc[rt][ct][4 * g + 3] + bv[ct][g].w, 0.f);
+                    // (ReLU that keeps a NaN, as torch.relu does: fmaxf would turn it into 0)
+                    auto relu = [](float x) { return x < 0.f ? 0.f : x; };
+                    v.x = relu(acc[rt][ct][4 * g] + bv[ct][g].x);
+                    v.y = relu(acc[rt][ct][4 * g + 1] + bv[ct][g].y);
+                    v.z = relu(acc[rt][ct][4 * g + 2] + bv[ct][g].z);
+                    v.w = relu(acc[rt][ct][4 * g + 3] + bv[ct][g].w);
                     store_split4(hP, DF_BF_ACT_PLANE, ((size_t)row * DF_BH + col) * 2, v);
                     if (SAVE) {
                         *reinterpret_cast<float4*>(a.acts + ((int64_t)l * a.n_pad + p0 + row) * DF_W + col) = v;
@@ -1041,6 +1043,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // a weight outside the planes' range: the bf16 walk launched behind this one does the work
     if (__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.packed + DF_FLAG_OFF)) != 0u) return;
     float top = 0.f;                   // largest scaled value this lane has split into the planes
+    bool bad = false;                  // an encoded input that is NaN or beyond the planes' range
     constexpr bool ENC_LDS = !SAVE;
     char* hP = reinterpret_cast<char*>(df_lds);                  // activation planes [2][64][264] fp16
     char* eP = ENC_LDS ? hP + 2 * DF_BF_ACT_PLANE : hP;          // encoding planes   [2][64][104] fp16, or in the activation rows
@@ -1086,6 +1089,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int64_t p = p0 + pt;
         auto put = [&](int col, float v) {
             const float vs = v * DF_H_ASCALE;
+            // (fmaxf drops a NaN operand: an input that is NaN -- or infinite: its sine is NaN -- is caught by the comparison,
+            // which is false for it.  Activations need no such test: with finite inputs and weights a NaN can only come
+            // from values beyond the fp32 range, and those pass `top` on their way)
+            bad |= !(fabsf(vs) <= DF_H_MAX);
             top = fmaxf(top, fabsf(vs));
             const _Float16 h = (_Float16)vs;
             _Float16* e = reinterpret_cast<_Float16*>(eP) + pt * E_ROW + col;
@@ -1250,8 +1257,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     }
     stamp();
-    // (NaN counts as "does not fit": the comparison is written so that it is true for it)
-    if (!(top <= DF_H_MAX)) __hip_atomic_store(&df_range_table[a.gen & 63], a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a NaN input counts as "does not fit" through `bad`; the fp32-range walk behind this one then propagates it as
+    // torch.relu does)
+    if (bad || !(top <= DF_H_MAX)) __hip_atomic_store(&df_range_table[a.gen & 63], a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -43,12 +43,12 @@
 namespace {
 
 #define TPULL_KEYS GFT_HEAD_SLOT    // 16 KB of LDS for the head's keys
-#define HEAD_DIRECT 2048u           // lists (scanned hits) up to this length are sorted whole: a sparse frame (the reference's
+#define HEAD_DIRECT GFT_HEAD_DIRECT  // lists (scanned hits) up to this length are sorted whole: a sparse frame (the reference's
                                     // 100 k Gaussians at 320x240: ~1450 instances per tile, low opacities) saturates nowhere, every
                                     // quadrant of a tile with a tail would flag and every list be completed in a second pass
 #define PULL_GROUP_MAX 31u          // largest depth bin of a head whose keys are still ordered by looking through their bin (5-bit count)
 #define PULL_WINDOW 2048u           // depth bins, from the tile's first occupied one, that have a cursor
-#define HEAD_TARGET 940u            // wanted length of the sorted head of a longer list
+#define HEAD_TARGET GFT_HEAD_TARGET  // wanted length of the sorted head of a longer list
 #define TAIL_LDS_KEYS 4096u         // culled tails are sorted in LDS in runs of at most this many keys (whole depth bins)
 #define TAIL_ITEMS 4                  // entries per thread and scan trip (8: no faster, 196 registers)
 #define TAIL_THREADS 512              // (1024 threads leave 128 registers per lane: the appearance evaluation then spills)
@@ -265,9 +265,15 @@ struct PullArgs {
     uint32_t* __restrict__ tile_cnt;
     uint32_t* __restrict__ tile_cut;
     uint8_t* __restrict__ need;
-    const uint32_t* __restrict__ ctrl;
+    uint32_t* ctrl;
     uint32_t cap;
     float4* __restrict__ clear; size_t clear_vec4;
+    // Schedule from the caller's previous frame of this shape (gft_forward_io.tile_hints; NULL: none): a non-zero word = some
+    // quadrant of the tile walked past where a sorted head would have ended.  Such a tile sorts its WHOLE list here, in
+    // chunks of whole depth bins, instead of a head now and the rest through flag -> k_tail_build -> resume pass.  What
+    // the hint says never changes a result: the blend walks the same entries in the same order either way.
+    const uint32_t* __restrict__ hints;
+    uint32_t pool_base;                      // first pool slot inside point_list (= T * GFT_HEAD_SLOT)
     int dbg;
 };
 
@@ -290,17 +296,18 @@ __device__ __forceinline__ bool pull_tile_of_block(const SuperShape& sh, int b, 
     return true;
 }
 
-__global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
+// (five waves per SIMD keep a 1200-tile frame resident in one round; left alone the allocator takes 97 registers: four)
+__global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_tile_pull(PullArgs a)
 {
     // the depth-bin histogram of pass A and the keys of pass B share 16 KB of LDS (the histogram is done with once the head
     // is chosen): nine workgroups per CU instead of four -- a frame's tiles are resident in one round
     __shared__ uint64_t sk[SORT_SLOTS(TPULL_KEYS)];
     static_assert(sizeof(uint64_t) * SORT_SLOTS(TPULL_KEYS) >= sizeof(uint32_t) * GFT_DEPTH_BINS, "histogram fits the key buffer");
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(sk);
-    __shared__ uint32_t s_n, s_cut, s_kf, s_gmax, s_gmax2, s_bmin, s_bmax;
+    __shared__ uint32_t s_n, s_cut, s_kf, s_gmax, s_gmax2, s_bmin, s_bmax, s_pool;
     __shared__ uint32_t s_wt[GFT_BLOCK / 64];
-    // 16-bit cursors, one per depth bin of a window of PULL_WINDOW bins from the tile's first occupied one (two per word):
-    // place of the bin's next key in the head (11 bits) | keys in the bin (5 bits).  Pass B places the keys grouped by
+    // 16-bit cursors, one per depth bin of a window of PULL_WINDOW bins from the first occupied one (two per word):
+    // place of the bin's next key (11 bits) | keys in the bin (5 bits).  Pass B places the keys grouped by
     // bin: the order of the bins IS the order of the sort, what is left is the order inside a bin.
     __shared__ uint32_t s_cur[PULL_WINDOW / 2];
     if (a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
@@ -319,16 +326,18 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
     uint32_t lx, ly;
     if (!pull_tile_of_block(a.sh, (int)blockIdx.x, tile, q, lx, ly)) { clear_slice(); return; }
     const int K = a.sh.K;
+    const bool hinted = a.hints != nullptr && a.hints[tile] != 0u;       // uniform over the workgroup
     for (int i = tid; i < GFT_DEPTH_BINS; i += GFT_BLOCK) s_hist[i] = 0;
     if (tid == 0) s_n = 0;
     __syncthreads();
 
-    uint32_t win_base = 0;                               // first depth bin with a cursor (set behind pass A)
+    uint32_t win_base = 0;                               // first depth bin with a cursor (set per placement)
     uint32_t cshift = 0;                                 // a cursor serves 1 << cshift depth bins (a whole list may span more bins than there are cursors)
     // pass over one entry list of the supertile.  MODE 0: count the tile's hits and histogram them over the depth bins;
-    // MODE 1: keys (gathered depth bits, id) of the hits in front of bin `first_tail` -> LDS in the order they come;
+    // MODE 1: keys (gathered depth bits, id) of the hits with depth bin in [blo, bhi) -> LDS in the order they come;
     // MODE 2: the same keys, each to the next free place of its depth bin (s_cur)
-    auto scan = [&](const uint64_t* __restrict__ list, uint32_t ln, int mode, uint32_t first_tail) {
+    auto scan = [&](const int tid, const uint64_t* __restrict__ list, uint32_t ln, int mode, uint32_t blo, uint32_t bhi) {
+        const int lane = tid & 63;
         // (loads unconditionally -- index clamped --, selects afterwards: a load under a lane condition is waited for where
         // its branch joins, which made the four loads two or four round trips in a row; and one trip ahead: a trip is a
         // memory round trip and a little work)
@@ -349,7 +358,8 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
             uint32_t off[4], cnt = 0;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                hit[u] = entry_hits(e4[u], lx, ly) && (mode == 0 || entry_bin(e4[u]) < first_tail);
+                const uint32_t eb = entry_bin(e4[u]);
+                hit[u] = entry_hits(e4[u], lx, ly) && (mode == 0 || (eb >= blo && eb < bhi));
                 hm[u] = __builtin_amdgcn_ballot_w64(hit[u]);
                 off[u] = cnt;
                 cnt += (uint32_t)__popcll(hm[u]);
@@ -390,31 +400,30 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
                 const uint32_t id = (uint32_t)e4[u];
                 const uint32_t pos = hb + off[u] + (uint32_t)__popcll(hm[u] & ((1ull << lane) - 1ull));
                 if (pos < TPULL_KEYS) sk[pos] = ((uint64_t)d4[u] << 32) | id;
-                // (the head's Gaussians are marked as needed behind the scan, from the keys: a store in this loop was
+                // (the Gaussians are marked as needed behind the scan, from the keys: a store in this loop was
                 // waited for by the next entry's LDS write -- one HBM write acknowledgement per entry and trip)
             }
         }
     };
 
-    // pass A: slabs front to back until the head is covered (one slab = the whole list when K == 1)
+    // pass A: slabs front to back until the head is covered (one slab = the whole list when K == 1); a hinted tile,
+    // which may sort its whole list, looks at all of them
     int kstop = K - 1;
     uint32_t n = 0;                                      // hits in the slabs that were scanned
     for (int k = 0; k < K; k++) {
         const uint32_t ln = a.st_cnt[q * K + k];
-        if (ln) scan(a.sl_ent + a.st_start[q * K + k], ln, 0, 0u);
+        if (ln) scan(tid, a.sl_ent + a.st_start[q * K + k], ln, 0, 0u, 0u);
         __syncthreads();
         n = s_n;
         __syncthreads();                                 // (everybody has read the count before the next slab adds to it)
-        if (n >= HEAD_TARGET) { kstop = k; break; }
+        if (!hinted && n >= HEAD_TARGET) { kstop = k; break; }
     }
     if (a.dbg == 1) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     bool more_slabs = false;
     for (int k = kstop + 1; k < K; k++) more_slabs |= a.st_cnt[q * K + k] != 0u;
-    // the head: whole bins up to the one where the running count reaches HEAD_TARGET.  That bin is taken if the head then
-    // still sorts as one 1024-key unit; a bin that overshoots is left out unless the head would otherwise be shorter than
-    // 512 and the bin fits the 2048-key sorter.  first_tail = first bin outside the head.
-    uint32_t first_tail = (uint32_t)(kstop + 1) << a.sh.kshift, kf = n;
-    uint32_t h[16], sum = 0, run0;
+    // the histogram, 16 bins per thread, and its running count: run0 = hits in the bins in front of this thread's sixteen,
+    // xin = hits up to and including them
+    uint32_t h[16], sum = 0, run0, xin;
     {
 #pragma unroll
         for (int k = 0; k < 16; k++) { h[k] = s_hist[16 * tid + k]; sum += h[k]; }
@@ -425,151 +434,240 @@ __global__ __launch_bounds__(GFT_BLOCK) void k_tile_pull(PullArgs a)
             if (lane >= d) x += y;
         }
         if (lane == 63) s_wt[wave] = x;
-        if (tid == 0) { s_gmax = 0; s_gmax2 = 0; s_bmin = GFT_DEPTH_BINS; s_bmax = 0; }
+        if (tid == 0) { s_gmax = 0; s_cut = GFT_DEPTH_BINS; s_kf = 0; }
         __syncthreads();
         for (int w = 0; w < wave; w++) x += s_wt[w];
-        run0 = x - sum;                                              // hits in the bins in front of this thread's sixteen
-        if (n > HEAD_DIRECT) {
-            uint32_t run = run0;
-            if (run < HEAD_TARGET && x >= HEAD_TARGET) {             // exactly one thread: the crossing lies in its 16 bins
+        xin = x;
+        run0 = x - sum;
+    }
+    // A hinted tile with a list beyond one placement sorts it whole, in chunks of whole depth bins of fewer than TPULL_KEYS
+    // keys each (a chunk is one placement: cursors of 11 bits) -- unless a single bin holds more than 255 keys (the bin
+    // counts are then carried as bytes): such a tile takes the lazy route, whose tail builder sorts anything.
+    bool whole = hinted && n > HEAD_DIRECT;
+    if (whole) {
+        uint32_t gm = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) gm = max(gm, h[k]);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) gm = max(gm, (uint32_t)__shfl_xor((int)gm, d, 64));
+        if (lane == 0 && gm) atomicMax(&s_gmax, gm);
+        __syncthreads();
+        whole = s_gmax <= 255u;
+        __syncthreads();                                 // (s_gmax is set anew by every placement)
+    }
+    // the head (a tile that does not sort its whole list): whole bins up to the one where the running count reaches
+    // HEAD_TARGET.  That bin is taken if the head then still sorts as one 1024-key unit; a bin that overshoots is left out
+    // unless the head would otherwise be shorter than 512 and the bin fits the 2048-key sorter.  first_tail = first bin
+    // outside the head.
+    uint32_t first_tail = (uint32_t)(kstop + 1) << a.sh.kshift, kf = n;
+    if (!whole && n > HEAD_DIRECT) {
+        uint32_t run = run0;
+        if (run < HEAD_TARGET && xin >= HEAD_TARGET) {           // exactly one thread: the crossing lies in its 16 bins
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t before = run;
+                run += h[k];
+                if (before < HEAD_TARGET && run >= HEAD_TARGET) {
+                    const bool take = run <= 1024u || (before < 512u && run <= TPULL_KEYS);
+                    s_cut = (uint32_t)(16 * tid + k) + (take ? 1u : 0u);
+                    s_kf = take ? run : before;
+                }
+            }
+        }
+        __syncthreads();
+        first_tail = s_cut;
+        kf = s_kf;
+        __syncthreads();
+    }
+    // From here on the sixteen bin counts of a thread travel as bytes (saturated at 255): what follows needs them exactly
+    // only where they are small -- cursors of bins with at most PULL_GROUP_MAX keys, chunks of a whole list (all bins
+    // <= 255: checked above) -- and a whole list keeps them over every chunk's sort: four registers instead of sixteen.
+    uint32_t hp[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+        hp[w] = min(h[4 * w], 255u) | (min(h[4 * w + 1], 255u) << 8) | (min(h[4 * w + 2], 255u) << 16) | (min(h[4 * w + 3], 255u) << 24);
+    auto hcnt = [&](int k) -> uint32_t { return (hp[k >> 2] >> (8 * (k & 3))) & 255u; };
+
+    if (a.dbg == 2) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
+    // the tile's bookkeeping words (stored by its first placement, behind the scans: a store in front of them holds up
+    // the wave's loads) and where its ids go: the tile's head slot, or -- a whole list -- n ids of the pool (over all
+    // tiles the pool holds R >= every list it can be asked for)
+    uint32_t start = (uint32_t)tile * GFT_HEAD_SLOT;
+    if (whole) {
+        if (tid == 0) {
+            s_pool = atomicAdd(&a.ctrl[GFT_CTRL_POOLCUR], n);
+            atomicAdd(&a.ctrl[GFT_CTRL_WHOLEIDS], n);
+        }
+        __syncthreads();
+        start = a.pool_base + s_pool;
+        kf = n;
+    }
+    const bool has_tail = !whole && (kf < n || more_slabs);
+    const uint2 bk_range = kf ? make_uint2(start, start + kf) : make_uint2(0u, 0u);   // (empty: (0,0) like the reference)
+    const uint32_t bk_cut = has_tail ? first_tail : GFT_NO_TAIL;
+    const int k_last = whole ? K - 1 : kstop;
+    uint32_t* const list = a.heads + start;
+
+    // One placement per round: the tile's keys with depth bin in [lo, hi) -- c of them, `done` keys in the bins in front of
+    // lo -- are collected in LDS, sorted, and their ids written to list[done, done + c); their Gaussians are marked for an
+    // appearance.  A head is one round; a whole list takes rounds of whole bins with fewer than TPULL_KEYS - 1 keys.
+    // The bins' start places (running count of the histogram) become cursors; the largest bin of the range and the span of
+    // its bins decide whether the order inside the bins is found by looking through a key's bin (the usual case: ~940
+    // keys spread over hundreds of bins) or the keys are sorted as a whole.
+    uint32_t done = 0, lo = 0;
+    for (;;) {
+        uint32_t hi = first_tail, c = kf;
+        // (the thread id and the packed bin counts behind an opaque move: everything the loop body derives from them -- bin
+        // numbers, unpacked counts, dozens of LDS addresses of the sorters -- would otherwise be computed once in front of the
+        // loop and kept in registers across it: 205 of them, two waves per SIMD)
+        int tl = tid;
+        asm volatile("" : "+v"(tl), "+v"(hp[0]), "+v"(hp[1]), "+v"(hp[2]), "+v"(hp[3]));
+        const int ll = tl & 63;
+        if (whole) {
+            // the thread whose sixteen bins hold the crossing finds the bin (every bin alone fits)
+            if (tl == 0) { s_cut = GFT_DEPTH_BINS; s_kf = n - done; }
+            __syncthreads();
+            const uint32_t lim = done + (TPULL_KEYS - 1u);
+            if (run0 < lim && xin >= lim) {                          // exactly one thread, or none (the rest fits)
+                uint32_t run = run0;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const uint32_t before = run;
-                    run += h[k];
-                    if (before < HEAD_TARGET && run >= HEAD_TARGET) {
-                        const bool take = run <= 1024u || (before < 512u && run <= TPULL_KEYS);
-                        s_cut = (uint32_t)(16 * tid + k) + (take ? 1u : 0u);
-                        s_kf = take ? run : before;
-                    }
+                    run += hcnt(k);
+                    if (before < lim && run >= lim) { s_cut = (uint32_t)(16 * tl + k); s_kf = before - done; }
                 }
             }
             __syncthreads();
-            first_tail = s_cut;
-            kf = s_kf;
+            hi = s_cut;
+            c = s_kf;
         }
-    }
-    // Placement of the head's keys: the bins' start places (running count of the histogram) become cursors; the largest
-    // bin inside the head and the span of its bins decide whether the order inside the bins is found by looking through a
-    // key's bin (the usual case: a head of ~940 keys spreads over hundreds of bins) or the keys are sorted as a whole.
-    {
-        uint32_t gm = 0, gm2 = 0, first = GFT_DEPTH_BINS, last1 = 0;     // gm2: largest pair of bins; last1 = last occupied bin + 1
-#pragma unroll
-        for (int k = 15; k >= 0; k--) {
-            const uint32_t b = (uint32_t)(16 * tid + k);
-            if (b < first_tail) gm = max(gm, h[k]);
-            if (!(k & 1) && b < first_tail) gm2 = max(gm2, h[k] + h[k + 1]);
-            if (h[k]) { first = b; last1 = max(last1, b + 1u); }
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            gm = max(gm, (uint32_t)__shfl_xor((int)gm, d, 64));
-            gm2 = max(gm2, (uint32_t)__shfl_xor((int)gm2, d, 64));
-            first = min(first, (uint32_t)__shfl_xor((int)first, d, 64));
-            last1 = max(last1, (uint32_t)__shfl_xor((int)last1, d, 64));
-        }
-        if (lane == 0) {
-            if (gm) atomicMax(&s_gmax, gm);
-            if (gm2) atomicMax(&s_gmax2, gm2);
-            atomicMin(&s_bmin, first);
-            atomicMax(&s_bmax, last1);
-        }
-    }
-    __syncthreads();
-    win_base = s_bmin & ~15u;                                        // (a thread's sixteen bins lie inside or outside the window together)
-    // (the head's bins end at first_tail or, a whole list, at its last occupied bin; the bins are at most twice the cursors)
-    cshift = min(first_tail, s_bmax) > win_base + PULL_WINDOW ? 1u : 0u;
-    const bool grouped = (cshift ? s_gmax2 : s_gmax) <= PULL_GROUP_MAX && kf < 2048u;     // (places of 11 bits)
-    if (grouped && (uint32_t)(16 * tid) >= win_base && (uint32_t)(16 * tid) < win_base + (PULL_WINDOW << cshift)) {
-        uint32_t r = run0;
-        if (cshift == 0u) {
-#pragma unroll
-            for (int k = 0; k < 16; k += 2) {
-                const uint32_t b = (uint32_t)(16 * tid + k) - win_base;
-                const uint32_t lo = (r & 0x7ffu) | (min(h[k], 31u) << 11);
-                r += h[k];
-                const uint32_t hi = (r & 0x7ffu) | (min(h[k + 1], 31u) << 11);
-                r += h[k + 1];
-                s_cur[b >> 1] = lo | (hi << 16);                     // (places beyond the head are never used)
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k += 4) {
-                const uint32_t c = ((uint32_t)(16 * tid + k) - win_base) >> 1;       // cursor of the bins k, k + 1; the next one of k + 2, k + 3
-                const uint32_t n0 = h[k] + h[k + 1], n1 = h[k + 2] + h[k + 3];
-                const uint32_t lo = (r & 0x7ffu) | (min(n0, 31u) << 11);
-                r += n0;
-                const uint32_t hi = (r & 0x7ffu) | (min(n1, 31u) << 11);
-                r += n1;
-                s_cur[c >> 1] = lo | (hi << 16);
-            }
-        }
-    }
-    __syncthreads();
-    if (a.dbg == 2) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    // pass B: the head's keys
-    if (kf) {
-        for (int k = 0; k <= kstop; k++) {
-            if (((uint32_t)k << a.sh.kshift) >= first_tail) break;
-            const uint32_t ln = a.st_cnt[q * K + k];
-            if (ln) scan(a.sl_ent + a.st_start[q * K + k], ln, grouped ? 2 : 1, first_tail);
-        }
-    }
-    const bool has_tail = kf < n || more_slabs;
-    const uint32_t start = (uint32_t)tile * GFT_HEAD_SLOT;
-    if (tid == 0) {
-        a.ranges[tile] = kf ? make_uint2(start, start + kf) : make_uint2(0u, 0u);     // (empty: (0,0) like the reference)
-        a.front_len[tile] = kf;
-        a.tile_cnt[tile] = n;
-        a.tile_cut[tile] = has_tail ? first_tail : GFT_NO_TAIL;
-    }
-    if (tid < 4) a.unit_flag[4 * tile + tid] = 0;        // (behind the scans: a store in front of them holds up the wave's loads)
-    __syncthreads();
-    // the Gaussians of the head get an appearance (k_appearance): marked here, where only LDS work and stores follow
-    for (uint32_t i = tid; i < kf; i += GFT_BLOCK) a.need[(uint32_t)sk[i]] = 1;
-    clear_slice();
-    if (a.dbg == 3) { if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
-    if (kf == 0u) return;
-    uint32_t* ids = a.heads + start;
-    if (grouped) {
-        // the keys stand grouped by depth bin, the bins in ascending order: a key's place = start of its bin's group + the
-        // number of smaller keys in the group (keys are distinct: the id is their low half).  The bin's cursor now holds
-        // the end of its group and its size.
-        for (uint32_t p = tid; p < kf; p += GFT_BLOCK) {
-            const uint64_t key = sk[p];
-            const uint32_t b = (gft_depth_bin((uint32_t)(key >> 32), a.sh.near_bits, a.sh.bin_shift) - win_base) >> cshift;
-            const uint32_t w = s_cur[b >> 1];
-            const uint32_t half = (b & 1u) ? (w >> 16) : (w & 0xffffu);
-            const uint32_t end = half & 0x7ffu, g = half >> 11, lo = end - g;
-            uint32_t below = 0;
-            for (uint32_t qd = 0; qd < g; qd++) below += sk[lo + qd] < key ? 1u : 0u;
-            ids[lo + below] = (uint32_t)key;
-        }
-        return;
-    }
-    if (kf <= 1024u) {
-        const uint32_t npad = next_pow2(kf < 2u ? 2u : kf);
-        for (uint32_t i = tid + kf; i < npad; i += GFT_BLOCK) sk[i] = ~0ull;
+        if (tl == 0) { s_gmax = 0; s_gmax2 = 0; s_bmin = GFT_DEPTH_BINS; s_bmax = 0; s_n = 0; }
         __syncthreads();
-        if (npad == 1024u) sort1024_by_rank_and_store(sk, kf, tid, ids);
-        else head_sort_and_store(sk, kf, npad, tid, ids);
-        return;
-    }
-    // 1025 .. 2048 keys: the register-blocked network wants them at their swizzled slots
-    static_assert(TPULL_KEYS == 2048u, "k_tile_pull sorts at most 2048 keys");
-    uint64_t mine[TPULL_KEYS / GFT_BLOCK];
+        {
+            uint32_t gm = 0, gm2 = 0, first = GFT_DEPTH_BINS, last1 = 0;     // gm2: largest pair of bins; last1 = last occupied bin + 1
 #pragma unroll
-    for (int k = 0; k < (int)(TPULL_KEYS / GFT_BLOCK); k++) {
-        const uint32_t i = tid + k * GFT_BLOCK;
-        mine[k] = i < kf ? sk[i] : ~0ull;
-    }
-    __syncthreads();
+            for (int k = 15; k >= 0; k--) {
+                const uint32_t b = (uint32_t)(16 * tl + k);
+                const uint32_t hb = (b >= lo && b < hi) ? hcnt(k) : 0u;
+                gm = max(gm, hb);
+                if (!(k & 1)) gm2 = max(gm2, hb + ((b + 1u >= lo && b + 1u < hi) ? hcnt(k + 1) : 0u));
+                if (hb) { first = b; last1 = max(last1, b + 1u); }
+            }
 #pragma unroll
-    for (int k = 0; k < (int)(TPULL_KEYS / GFT_BLOCK); k++) sk[sort_slot(tid + k * GFT_BLOCK)] = mine[k];
-    __syncthreads();
-    bitonic_blocked<3, 8>(sk, tid);
-    for (uint32_t i = tid; i < kf; i += GFT_BLOCK) ids[i] = (uint32_t)sk[sort_slot(i)];
+            for (int d = 32; d > 0; d >>= 1) {
+                gm = max(gm, (uint32_t)__shfl_xor((int)gm, d, 64));
+                gm2 = max(gm2, (uint32_t)__shfl_xor((int)gm2, d, 64));
+                first = min(first, (uint32_t)__shfl_xor((int)first, d, 64));
+                last1 = max(last1, (uint32_t)__shfl_xor((int)last1, d, 64));
+            }
+            if (ll == 0) {
+                if (gm) atomicMax(&s_gmax, gm);
+                if (gm2) atomicMax(&s_gmax2, gm2);
+                atomicMin(&s_bmin, first);
+                atomicMax(&s_bmax, last1);
+            }
+        }
+        __syncthreads();
+        win_base = s_bmin & ~15u;                                        // (a thread's sixteen bins lie inside or outside the window together)
+        // (the range's occupied bins span at most twice the cursors)
+        cshift = s_bmax > win_base + PULL_WINDOW ? 1u : 0u;
+        const bool grouped = (cshift ? s_gmax2 : s_gmax) <= PULL_GROUP_MAX && c < 2048u;     // (places of 11 bits)
+        if (grouped && (uint32_t)(16 * tl) >= win_base && (uint32_t)(16 * tl) < win_base + (PULL_WINDOW << cshift)) {
+            // keys of [lo, hi) in front of this thread's bins (a thread whose bins straddle lo starts at place 0)
+            uint32_t r = (uint32_t)(16 * tl) >= lo ? run0 - done : 0u;
+            auto hb = [&](int k) -> uint32_t {
+                const uint32_t b = (uint32_t)(16 * tl + k);
+                return (b >= lo && b < hi) ? hcnt(k) : 0u;
+            };
+            if (cshift == 0u) {
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) {
+                    const uint32_t b = (uint32_t)(16 * tl + k) - win_base;
+                    const uint32_t c0 = (r & 0x7ffu) | (min(hb(k), 31u) << 11);
+                    r += hb(k);
+                    const uint32_t c1 = (r & 0x7ffu) | (min(hb(k + 1), 31u) << 11);
+                    r += hb(k + 1);
+                    s_cur[b >> 1] = c0 | (c1 << 16);                     // (places beyond the range are never used)
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k += 4) {
+                    const uint32_t cw = ((uint32_t)(16 * tl + k) - win_base) >> 1;      // cursor of the bins k, k + 1; the next one of k + 2, k + 3
+                    const uint32_t n0 = hb(k) + hb(k + 1), n1 = hb(k + 2) + hb(k + 3);
+                    const uint32_t c0 = (r & 0x7ffu) | (min(n0, 31u) << 11);
+                    r += n0;
+                    const uint32_t c1 = (r & 0x7ffu) | (min(n1, 31u) << 11);
+                    r += n1;
+                    s_cur[cw >> 1] = c0 | (c1 << 16);
+                }
+            }
+        }
+        __syncthreads();
+        // pass B: the keys of the range
+        if (c) {
+            for (int k = 0; k <= k_last; k++) {
+                if (((uint32_t)k << a.sh.kshift) >= hi || (((uint32_t)k + 1u) << a.sh.kshift) <= lo) continue;   // slab outside [lo, hi)
+                const uint32_t ln = a.st_cnt[q * K + k];
+                if (ln) scan(tl, a.sl_ent + a.st_start[q * K + k], ln, grouped ? 2 : 1, lo, hi);
+            }
+        }
+        if (done == 0u) {
+            if (tl == 0) {
+                a.ranges[tile] = bk_range;
+                a.front_len[tile] = kf;
+                a.tile_cnt[tile] = n;
+                a.tile_cut[tile] = bk_cut;
+            }
+            if (tl < 4) a.unit_flag[4 * tile + tl] = 0;
+        }
+        __syncthreads();
+        // these Gaussians get an appearance (k_appearance): marked here, where only LDS work and stores follow
+        for (uint32_t i = tl; i < c; i += GFT_BLOCK) a.need[(uint32_t)sk[i]] = 1;
+        if (done == 0u) clear_slice();
+        uint32_t* __restrict__ ids = list + done;
+        if (c == 0u) {
+        } else if (grouped) {
+            // the keys stand grouped by depth bin, the bins in ascending order: a key's place = start of its bin's group + the
+            // number of smaller keys in the group (keys are distinct: the id is their low half).  The bin's cursor now holds
+            // the end of its group and its size.
+            for (uint32_t p = (uint32_t)tl; p < c; p += GFT_BLOCK) {
+                const uint64_t key = sk[p];
+                const uint32_t b = (gft_depth_bin((uint32_t)(key >> 32), a.sh.near_bits, a.sh.bin_shift) - win_base) >> cshift;
+                const uint32_t w = s_cur[b >> 1];
+                const uint32_t half = (b & 1u) ? (w >> 16) : (w & 0xffffu);
+                const uint32_t end = half & 0x7ffu, g = half >> 11, l0 = end - g;
+                uint32_t below = 0;
+                for (uint32_t qd = 0; qd < g; qd++) below += sk[l0 + qd] < key ? 1u : 0u;
+                ids[l0 + below] = (uint32_t)key;
+            }
+        } else if (c <= 1024u) {
+            const uint32_t npad = next_pow2(c < 2u ? 2u : c);
+            for (uint32_t i = (uint32_t)tl + c; i < npad; i += GFT_BLOCK) sk[i] = ~0ull;
+            __syncthreads();
+            if (npad == 1024u) sort1024_by_rank_and_store(sk, c, tl, ids);
+            else head_sort_and_store(sk, c, npad, tl, ids);
+        } else {
+            // 1025 .. 2048 keys: the register-blocked network wants them at their swizzled slots
+            static_assert(TPULL_KEYS == 2048u, "k_tile_pull sorts at most 2048 keys at a time");
+            uint64_t mine[TPULL_KEYS / GFT_BLOCK];
+#pragma unroll
+            for (int k = 0; k < (int)(TPULL_KEYS / GFT_BLOCK); k++) {
+                const uint32_t i = (uint32_t)tl + k * GFT_BLOCK;
+                mine[k] = i < c ? sk[i] : ~0ull;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < (int)(TPULL_KEYS / GFT_BLOCK); k++) sk[sort_slot((uint32_t)tl + k * GFT_BLOCK)] = mine[k];
+            __syncthreads();
+            bitonic_blocked<3, 8>(sk, tl);
+            for (uint32_t i = (uint32_t)tl; i < c; i += GFT_BLOCK) ids[i] = (uint32_t)sk[sort_slot(i)];
+        }
+        if (!whole) break;
+        done += c;
+        lo = hi;
+        if (done >= n) break;
+        __syncthreads();                                 // (the ids are out of LDS before the next chunk's keys come in)
+    }
 }
 
 // ---- lists completed on demand --------------------------------------------------------------------------------
@@ -768,7 +866,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
         if (tid == 0) s_pool = atomicAdd(&a.ctrl[GFT_CTRL_POOLCUR], kf + m);
         __syncthreads();
         uint32_t* list = a.point_list + a.pool_base + s_pool;
-        const uint32_t* head = a.point_list + (size_t)tile * GFT_HEAD_SLOT;
+        const uint32_t* head = a.point_list + a.ranges[tile].x;        // (where k_tile_pull put the sorted head)
         for (uint32_t i = tid; i < kf; i += TAIL_THREADS) list[i] = head[i];
         if (m <= TAIL_LDS_KEYS) {
             finish_lds(m, list + kf);
@@ -886,7 +984,7 @@ hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomVi
 }
 
 hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
-                                uint32_t cap, float* clear, size_t clear_bytes)
+                                uint32_t cap, float* clear, size_t clear_bytes, const uint32_t* hints)
 {
     PullArgs a;
     a.sh = gft_super_shape(c);
@@ -897,6 +995,7 @@ hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomVi
     a.tile_cnt = im.tile_cnt; a.tile_cut = im.tile_cut; a.need = g.need;
     a.ctrl = im.ctrl; a.cap = cap;
     a.clear = reinterpret_cast<float4*>(clear); a.clear_vec4 = clear_bytes / 16;
+    a.hints = hints; a.pool_base = (uint32_t)a.sh.T * GFT_HEAD_SLOT;
     static const int dbg = [] { const char* e = getenv("GFT_PULL_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
     if (dbg == 4) { a.clear = nullptr; a.dbg = 0; }

@@ -122,6 +122,9 @@ struct RenderFwdArgs {
     uint32_t* nflag;
     float4* __restrict__ resume_state;
     int resume;                               // second pass: continue the flagged quadrants behind the head
+    // tile-pull binning with a caller-kept schedule (gft_forward_io.tile_hints): byte v = did quadrant v walk past where a
+    // sorted head ends -- it flagged, or (list sorted whole) its deepest contributor lies beyond GFT_HEAD_TARGET
+    uint8_t* __restrict__ hint_out;
 };
 
 __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
@@ -342,6 +345,10 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
     if (lane == 0) a.quad_max[v] = mx;
+    if (a.hint_out && !a.resume && lane == 0) {
+        const bool flagged = (head < full || more) && done_m != ~0ull;
+        a.hint_out[v] = (flagged || (head > (int)GFT_HEAD_DIRECT && mx > GFT_HEAD_TARGET)) ? 1 : 0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -794,6 +801,10 @@ __global__ __launch_bounds__(64 * FSEG_WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
     if (lane == 0) a.quad_max[v] = mx;
+    if (a.hint_out && lane == 0) {
+        const bool flagged = (head < full || more) && done_m != ~0ull;
+        a.hint_out[v] = (flagged || (head > (int)GFT_HEAD_DIRECT && mx > GFT_HEAD_TARGET)) ? 1 : 0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1195,6 +1206,9 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     a.ctrl = check_cap ? im.ctrl : nullptr;
     a.cap = cap;
     a.tile_cut = pull ? im.tile_cut : nullptr;
+    // (the segment-parallel kernel cuts a list by the length of its sorted part -- what the schedule changes: its sums would
+    // depend on it in the last bit.  Frames that run it keep no schedule; their lists rarely exceed one placement anyway)
+    a.hint_out = (pull && lazy == 1 && !gft_fwd_segmented(a.T)) ? reinterpret_cast<uint8_t*>(io.tile_hints) : nullptr;
     a.W = c.W; a.H = c.H;
     a.gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X;
     const int gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
@@ -1217,8 +1231,7 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     const int blocks = 8 * ((a.T * 4 + 7) / 8);
     // segmented: up to FSEG_WAVES waves per quadrant (first pass only; the resume pass of flagged quadrants stays one
     // wave per quadrant).  GFT_FWD_SEG=0 / 1 in the environment forces one of the two kernels for every frame.
-    const int force = gft_render_mode();
-    const bool seg = (force < 0 ? segmented : force == 1) && !a.resume && gft_fwd_seg_waves(a.T) > 1;
+    const bool seg = segmented && !a.resume && gft_fwd_segmented(a.T);
     if (seg) {
         switch (gft_fwd_seg_waves(a.T)) {
         case 2: hipLaunchKernelGGL(k_render_fwd_seg<2>, dim3(blocks), dim3(64 * 2), 0, s, a); break;

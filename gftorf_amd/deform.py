@@ -42,6 +42,10 @@ last_backward_stats = {"points": 0, "points_processed": 0, "recomputed": False}
 # the rows (the usual training iteration: only Gaussians that a pixel blended carry a gradient), the next forward keeps
 # NOTHING; its backward gathers the inputs of the rows that count, runs the saving forward on those rows alone (a point's
 # activations do not depend on the batch it is in: bit-identical) and goes on as before -- no 2.5 GB, no compaction of them.
+# (Bit-identical while the call stays inside the fp16 planes' range, which is every network the reference trains: the
+# library decides per CALL whether the fp16 walk's results stand or the fp32-range walk overwrites them (k_deform.hip,
+# range guard).  A forward that fell back because of a row WITHOUT a gradient is recomputed on the rows with one by the fp16
+# walk: the two walks agree to ~1e-7, a ReLU input within that of zero may change side.)
 # A backward that finds many rows with a gradient after all recomputes all of them (one extra forward, once) and the next
 # forward saves again.  `GFT_DEFORM_LAZY_SAVE=0` in the environment or `gftorf_amd.deform.lazy_save = False`: always save.
 import os as _os

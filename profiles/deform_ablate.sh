@@ -9,7 +9,10 @@ cd "$(dirname "$0")/.."
 VARS="${VARS:-0 1 2 3 4 8 10 11 16}"
 if [ "${1:-}" = build ]; then
     mkdir -p gftorf_amd/_abl
+    # the variants are built over the product library: whatever happens, it comes back (a failed or interrupted build
+    # must not leave a wrong-by-design library installed) and the objects are rebuilt from the unflagged sources
     cp gftorf_amd/libgftorf_rast.so /tmp/libgft_keep.so
+    trap 'cp /tmp/libgft_keep.so gftorf_amd/libgftorf_rast.so; touch gftorf_amd/csrc/k_deform.hip' EXIT INT TERM
     for v in $VARS; do
         touch gftorf_amd/csrc/k_deform.hip
         GFT_EXTRA_FLAGS="-DDF_ABL=$v" python3 -c "from gftorf_amd import build; build.build()" && cp gftorf_amd/libgftorf_rast.so gftorf_amd/_abl/lib_$v.so && echo built $v

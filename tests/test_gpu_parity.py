@@ -21,9 +21,10 @@ GRAD_RTOL = 3e-4       # gradients: fp32 atomics/reduction order + T recovered b
 
 
 # ---------------------------------------------------------------------------
-def raw_forward(scene, dev, inputs=None, mode=None):
+def raw_forward(scene, dev, inputs=None, mode=None, hints=None):
     """Drive the C ABI directly so the scratch buffers can be inspected.  mode: 1 = tile-pull binning, 0 = whole-frame
-    binning (gft_set_binning_mode), None = the library's default."""
+    binning (gft_set_binning_mode), None = the library's default.  hints: int32[T] device tensor handed over as
+    gft_forward_io.tile_hints (the forward overwrites it; returned as st["hints"])."""
     from gftorf_amd import _lib
     lib = _lib.load()
     g = dict(scene["gaussians"])
@@ -62,6 +63,7 @@ def raw_forward(scene, dev, inputs=None, mode=None):
     for n, a in zip(names, sl[:-1]):
         setattr(io, n, planes[a].data_ptr())
     io.pixels, io.radii = p(pixels), p(radii)
+    io.tile_hints = p(hints)
     R = C.c_int64(0)
     MX = C.c_int64(0)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -104,6 +106,7 @@ def raw_forward(scene, dev, inputs=None, mode=None):
         front_len=view_of(img, L.img_front_len, Tn, torch.int32).astype(np.uint32),
         unit_flag=view_of(img, L.img_unit_flag, Tn * 4, torch.int32).astype(np.uint32).reshape(Tn, 4),
         lazy=bool(lib.gft_lazy_sort()),
+        hints=None if hints is None else hints.cpu().numpy().view(np.uint8).reshape(Tn, 4),
         point_list=view_of(binning, L.bin_point_list, Tn * 2048 + R, torch.int32).astype(np.uint32) if R else np.zeros(0, np.uint32),
     )
     del keep
@@ -654,6 +657,101 @@ def test_tile_pull_structure(gpu, oracle):
     assert (st["ranges"][:, 1] - st["ranges"][:, 0] == st["front_len"]).all()
 
 
+def test_hinted_tiles_sort_their_whole_list(gpu, oracle):
+    """gft_forward_io.tile_hints: a tile whose word is non-zero and whose list is longer than one placement sorts it WHOLE
+    in k_tile_pull (chunks of whole depth bins, into the pool): the list is the oracle's, no quadrant flags, nothing is
+    completed on demand; the forward leaves the next frame's words -- per quadrant, did it walk past where a head ends."""
+    from gftorf_amd import _lib
+    if not _lib.load().gft_lazy_sort():
+        pytest.skip("GFT_LAZY_SORT=0: whole-frame binning only")
+    # (one wave per quadrant throughout: the segment-parallel forward cuts a list by the length of its sorted part, which is
+    # what the schedule changes -- its sums would agree to rounding, not bit for bit)
+    with render_mode(0):
+        fog = Hh.small_scene(seed=21, P=40000, W=64, H=64, scale_lo=0.01, scale_hi=0.05, opacity=0.02)
+        f, _ = Hh.run_oracle(oracle, fog, backward=False)
+        lens = (f.ranges[:, 1] - f.ranges[:, 0]).astype(np.int64)
+        T = lens.size
+        long_tiles = lens > 2048
+        assert long_tiles.any()
+        # no schedule yet (all zero): the lazy route, and the words it leaves say "every long tile walked past its head"
+        h = torch.zeros((T,), device=gpu, dtype=torch.int32)
+        st0 = raw_forward(fog, gpu, mode=1, hints=h)
+        assert st0["pull"] and st0["unit_flag"].any(1)[long_tiles].all()
+        assert (st0["hints"][long_tiles] != 0).all() and not st0["hints"][~long_tiles].any()
+        # with that schedule
+        st = raw_forward(fog, gpu, mode=1, hints=h)
+        assert not st["unit_flag"].any() and int(st["ctrl"][4]) == 0                   # nobody flags
+        assert (st["tile_cut"][long_tiles] == 0xffffffff).all()
+        np.testing.assert_array_equal(st["front_len"], lens)                           # every list complete after the pull kernel
+        assert (st["ranges"][long_tiles, 0] >= T * 2048).all()                         # whole lists live in the pool
+        assert int(st["ctrl"][6]) == int(lens[long_tiles].sum()) == int(st["ctrl"][8])
+        for t in range(T):
+            a, e = int(st["ranges"][t, 0]), int(st["ranges"][t, 1])
+            np.testing.assert_array_equal(st["point_list"][a:e], f.point_list[int(f.ranges[t, 0]):int(f.ranges[t, 1])], err_msg="tile %d" % t)
+        assert (st["hints"][long_tiles] != 0).any(1).all()                             # still nothing saturates: the schedule stays
+        np.testing.assert_array_equal(st["planes"], st0["planes"])
+        np.testing.assert_array_equal(st["pixels"], st0["pixels"])
+        # a frame that saturates early under the same (now wrong) schedule: whole lists all the same, and the words go back to 0
+        opaque = Hh.small_scene(seed=21, P=30000, W=64, H=64, scale_lo=0.02, scale_hi=0.1, opacity=0.9)
+        fo, _ = Hh.run_oracle(oracle, opaque, backward=False)
+        lo = (fo.ranges[:, 1] - fo.ranges[:, 0]).astype(np.int64)
+        assert (lo > 2048).any()
+        h.fill_(0x01010101)
+        so = raw_forward(opaque, gpu, mode=1, hints=h)
+        np.testing.assert_array_equal(so["front_len"], lo)
+        assert not so["hints"].any() and not so["unit_flag"].any()
+        ref = raw_forward(opaque, gpu, mode=1)
+        np.testing.assert_array_equal(so["planes"], ref["planes"])
+        np.testing.assert_array_equal(so["pixels"], ref["pixels"])
+        # a single depth bin with more keys than the bin counts carry (bytes): the hinted tile takes the lazy route
+        flat = Hh.small_scene(seed=23, **SCENES["long_lists_flat"])
+        h2 = torch.full((4,), 0x01010101, device=gpu, dtype=torch.int32)
+        sf = raw_forward(flat, gpu, mode=1, hints=h2)
+        ref = raw_forward(flat, gpu, mode=1)
+        np.testing.assert_array_equal(sf["front_len"], ref["front_len"])
+        np.testing.assert_array_equal(sf["planes"], ref["planes"])
+
+
+@pytest.mark.parametrize("name", list(BIN_CASES))
+def test_tile_hints_do_not_change_results(name, oracle, gpu):
+    """The per-tile schedule the operator keeps from frame to frame (api._tile_hints -> gft_forward_io.tile_hints) against
+    no schedule, an all-ones one and a random one: every output bit-identical (the blend walks the same entries in the
+    same order whether a list was sorted whole up front or head first / rest on demand), gradients equal up to the order
+    of the atomic sums."""
+    from gftorf_amd import _lib, api
+    if not _lib.load().gft_lazy_sort():
+        pytest.skip("GFT_LAZY_SORT=0: whole-frame binning only")
+    scene = Hh.small_scene(seed=23, **BIN_CASES[name])
+    rng = np.random.default_rng(5)
+    with render_mode(0):
+        keep = api._TILE_HINTS
+        try:
+            api._TILE_HINTS = False
+            api._instance_hint.clear()
+            Hh.run_gpu(scene, gpu)
+            ref_out, ref_grads, _ = Hh.run_gpu(scene, gpu)
+        finally:
+            api._TILE_HINTS = keep
+        api._tile_hints.clear()
+        for frame in range(5):
+            if frame >= 2:
+                # frames 0, 1: the schedule as the operator builds it; then forced: all ones, random, random
+                for hbuf in api._tile_hints.values():
+                    if frame == 2:
+                        hbuf.fill_(0x01010101)
+                    else:
+                        hbuf.copy_(torch.tensor(rng.integers(0, 2, hbuf.numel()), dtype=torch.int32))
+            out, grads, _ = Hh.run_gpu(scene, gpu)
+            for k in ref_out:
+                np.testing.assert_array_equal(out[k], ref_out[k], err_msg="%s frame %d" % (k, frame))
+            for k in ref_grads:
+                if ref_grads[k] is not None:
+                    Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
+    f, b = Hh.run_oracle(oracle, scene)
+    check_outputs(f, out)
+    check_grads(b, grads, scene)
+
+
 LAZY_CASES = {
     # lists of 1.2k..5k keys per tile: the sorted head (~940 keys) is not enough for the far pixels
     "thin_fog": dict(P=40000, W=64, H=64, scale_lo=0.01, scale_hi=0.05, opacity=0.02),            # nothing saturates: every quadrant resumes
@@ -967,6 +1065,57 @@ def test_gradient_tensors_are_reused_without_the_private_use_count(oracle, gpu):
             check_grads(bw, grads, sc)
             del out, grads, t
         assert api.last_call_stats["grads_reused"] is True
+    finally:
+        api._USE_COUNT_API = keep
+        api._grad_pool.clear()
+
+
+def test_two_pending_backwards_on_the_dlpack_route(oracle, gpu):
+    """DLPack route (no private use count): forward A, forward B of one shape, then A.backward(), B.backward() into the SAME
+    leaves.  The second forward lets go of A's gradient tensors before autograd has seen them, so they become the leaves'
+    `.grad` and B's gradient is added into A's pool buffer in place -- rows A's marks do not cover.  The entry must not be
+    taken as "zero but for its marked rows" afterwards: the next renders' gradients are the oracle's."""
+    from gftorf_amd import api, GaussianRasterizer
+    if not api._GRADS_REUSE:
+        pytest.skip("gradient-tensor reuse is off")
+    a = Hh.small_scene(P=3000, seed=61)
+    b = Hh.small_scene(P=3000, seed=62, opacity=0.7)
+    c = Hh.small_scene(P=3000, seed=63, opacity=0.9, scale_lo=0.005, scale_hi=0.02)      # blends few Gaussians: most rows must be zero
+    fa, ba = Hh.run_oracle(oracle, a)
+    fb, bb = Hh.run_oracle(oracle, b)
+    fc, bc = Hh.run_oracle(oracle, c)
+    keep = api._USE_COUNT_API
+    api._USE_COUNT_API = False
+    api._grad_pool.clear()
+    try:
+        # shared leaves: the Gaussians of scene a rendered from the cameras of a and b
+        g = dict(a["gaussians"])
+        leaf = {k: torch.tensor(v, dtype=torch.float32, device=gpu, requires_grad=True) for k, v in g.items() if v is not None}
+        m2 = torch.zeros((3000, 3), device=gpu, requires_grad=True)
+
+        def render(scene):
+            o = GaussianRasterizer(raster_settings=Hh.gpu_settings(scene, gpu))(
+                means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf["shs"], shs_p=leaf["shs_p"],
+                scales=leaf["scales"], rotations=leaf["rotations"], phase_offset=scene["phase_offset"], dc_offset=scene["dc_offset"])
+            gr = scene["grads"]
+            return sum((o[i] * torch.tensor(gr[k], device=gpu)).sum() for i, k in ((0, "color"), (1, "phasor"), (2, "depth"), (4, "acc"), (6, "depth_distortion")))
+        b_on_a = dict(b, gaussians=a["gaussians"])
+        fba, bba = Hh.run_oracle(oracle, b_on_a)
+        la = render(a)
+        lb = render(b_on_a)
+        la.backward()
+        lb.backward()
+        want = np.asarray(ba["dL_dmeans3D"], np.float64) + np.asarray(bba["dL_dmeans3D"], np.float64)
+        Hh.assert_close("sum of the two calls", want, leaf["means3D"].grad.cpu().numpy(), rtol_max=GRAD_RTOL)
+        for v in leaf.values():
+            v.grad = None
+        m2.grad = None
+        del la, lb
+        # whatever buffers come round now: every gradient the oracle's
+        for sc, bw in ((c, bc), (a, ba), (c, bc), (b, bb), (c, bc)):
+            out, grads, t = Hh.run_gpu(sc, gpu)
+            check_grads(bw, grads, sc)
+            del out, grads, t
     finally:
         api._USE_COUNT_API = keep
         api._grad_pool.clear()
