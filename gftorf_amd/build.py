@@ -42,7 +42,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, save_temps=False):
+def build(force=False, verbose=False, save_temps=False, tag=None, extra_flags=()):
+    """tag=None: the product library.  tag="x": an experiment build (``extra_flags``, e.g. -DGFT_SOMETHING=0) with its own
+    objects in _obj_x/ and its output in _abl/lib_x.so -- the product library and its objects are not touched
+    (profiles/bench_with_lib.py runs the benches on such a library)."""
+    OBJ, LIB = globals()["OBJ"], globals()["LIB"]
+    if tag:
+        OBJ = os.path.join(HERE, "_obj_" + tag)
+        os.makedirs(os.path.join(HERE, "_abl"), exist_ok=True)
+        LIB = os.path.join(HERE, "_abl", "lib_%s.so" % tag)
     os.makedirs(OBJ, exist_ok=True)
     import glob
     headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))) + [os.path.abspath(__file__)]
@@ -52,7 +60,7 @@ def build(force=False, verbose=False, save_temps=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            cmd = [cc] + flags() + FILE_FLAGS.get(src, []) + ["-c", s, "-o", o]
+            cmd = [cc] + flags() + list(extra_flags) + FILE_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if save_temps:
                 cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
             jobs.append(cmd)
@@ -74,7 +82,10 @@ def build(force=False, verbose=False, save_temps=False):
 
 
 if __name__ == "__main__":
-    lib, logs = build(force="--force" in sys.argv, verbose=True, save_temps="--save-temps" in sys.argv)
+    # python -m gftorf_amd.build [--force] [--save-temps] [--tag NAME -DFLAG ...]
+    tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else None
+    lib, logs = build(force="--force" in sys.argv, verbose=True, save_temps="--save-temps" in sys.argv, tag=tag,
+                      extra_flags=[a for a in sys.argv[1:] if a.startswith("-D")])
     for l in logs:
         if l.strip():
             print(l)

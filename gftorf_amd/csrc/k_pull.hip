@@ -42,7 +42,9 @@
 
 namespace {
 
-#define TPULL_KEYS GFT_HEAD_SLOT    // 16 KB of LDS for the head's keys
+#define TPULL_KEYS GFT_HEAD_SLOT    // keys of a head / a chunk that may have to go through a sorting network (16 KB of LDS)
+#define TPULL_KEYS_BIG 3072u        // keys of a chunk of a whole list whose bins are all small (placed by cursors, never by a network): 24 KB
+                                    // (five workgroups per CU is what the kernel's registers allow: 5 x 28.6 KB of LDS fit)
 #define HEAD_DIRECT GFT_HEAD_DIRECT  // lists (scanned hits) up to this length are sorted whole: a sparse frame (the reference's
                                     // 100 k Gaussians at 320x240: ~1450 instances per tile, low opacities) saturates nowhere, every
                                     // quadrant of a tile with a tail would flag and every list be completed in a second pass
@@ -301,13 +303,14 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
 {
     // the depth-bin histogram of pass A and the keys of pass B share 16 KB of LDS (the histogram is done with once the head
     // is chosen): nine workgroups per CU instead of four -- a frame's tiles are resident in one round
-    __shared__ uint64_t sk[SORT_SLOTS(TPULL_KEYS)];
-    static_assert(sizeof(uint64_t) * SORT_SLOTS(TPULL_KEYS) >= sizeof(uint32_t) * GFT_DEPTH_BINS, "histogram fits the key buffer");
+    __shared__ uint64_t sk[SORT_SLOTS(TPULL_KEYS_BIG)];
+    static_assert(sizeof(uint64_t) * SORT_SLOTS(TPULL_KEYS_BIG) >= sizeof(uint32_t) * GFT_DEPTH_BINS, "histogram fits the key buffer");
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(sk);
     __shared__ uint32_t s_n, s_cut, s_kf, s_gmax, s_gmax2, s_bmin, s_bmax, s_pool;
     __shared__ uint32_t s_wt[GFT_BLOCK / 64];
     // 16-bit cursors, one per depth bin of a window of PULL_WINDOW bins from the first occupied one (two per word):
-    // place of the bin's next key (11 bits) | keys in the bin (5 bits).  Pass B places the keys grouped by
+    // place of the bin's next key (11 bits; 12 in the big chunks of a whole list) | keys in the bin (5 bits; 4).  Pass B
+    // places the keys grouped by
     // bin: the order of the bins IS the order of the sort, what is left is the order inside a bin.
     __shared__ uint32_t s_cur[PULL_WINDOW / 2];
     if (a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
@@ -326,13 +329,14 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
     uint32_t lx, ly;
     if (!pull_tile_of_block(a.sh, (int)blockIdx.x, tile, q, lx, ly)) { clear_slice(); return; }
     const int K = a.sh.K;
-    const bool hinted = a.hints != nullptr && a.hints[tile] != 0u;       // uniform over the workgroup
+    const bool hinted = (a.dbg & 16) || (a.hints != nullptr && a.hints[tile] != 0u);      // uniform over the workgroup
     for (int i = tid; i < GFT_DEPTH_BINS; i += GFT_BLOCK) s_hist[i] = 0;
     if (tid == 0) s_n = 0;
     __syncthreads();
 
     uint32_t win_base = 0;                               // first depth bin with a cursor (set per placement)
     uint32_t cshift = 0;                                 // a cursor serves 1 << cshift depth bins (a whole list may span more bins than there are cursors)
+    uint32_t pbits = 11, pmask = 0x7ffu;                 // bits of a cursor's place
     // pass over one entry list of the supertile.  MODE 0: count the tile's hits and histogram them over the depth bins;
     // MODE 1: keys (gathered depth bits, id) of the hits with depth bin in [blo, bhi) -> LDS in the order they come;
     // MODE 2: the same keys, each to the next free place of its depth bin (s_cur)
@@ -375,8 +379,8 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
                     if (!hit[u]) continue;
                     const uint32_t b = (entry_bin(e4[u]) - win_base) >> cshift;
                     const uint32_t w = atomicAdd(&s_cur[b >> 1], (b & 1u) ? 0x10000u : 1u);
-                    const uint32_t pos = ((b & 1u) ? (w >> 16) : w) & 0x7ffu;
-                    if (pos < TPULL_KEYS) sk[pos] = ((uint64_t)d4[u] << 32) | (uint32_t)e4[u];
+                    const uint32_t pos = ((b & 1u) ? (w >> 16) : w) & pmask;
+                    if (pos < TPULL_KEYS_BIG) sk[pos] = ((uint64_t)d4[u] << 32) | (uint32_t)e4[u];
                 }
                 continue;
             }
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
         __syncthreads();                                 // (everybody has read the count before the next slab adds to it)
         if (!hinted && n >= HEAD_TARGET) { kstop = k; break; }
     }
-    if (a.dbg == 1) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
+    if ((a.dbg & 15) == 1) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     bool more_slabs = false;
     for (int k = kstop + 1; k < K; k++) more_slabs |= a.st_cnt[q * K + k] != 0u;
     // the histogram, 16 bins per thread, and its running count: run0 = hits in the bins in front of this thread's sixteen,
@@ -453,6 +457,9 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
         if (lane == 0 && gm) atomicMax(&s_gmax, gm);
         __syncthreads();
         whole = s_gmax <= 255u;
+        // every bin small enough for a 4-bit count, pairs of bins included: chunks of up to TPULL_KEYS_BIG - 1 keys with 12-bit
+        // places -- a 3000-key list in one round instead of two
+        if (whole && s_gmax <= 7u) { pbits = 12; pmask = 0xfffu; }
         __syncthreads();                                 // (s_gmax is set anew by every placement)
     }
     // the head (a tile that does not sort its whole list): whole bins up to the one where the running count reaches
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
         hp[w] = min(h[4 * w], 255u) | (min(h[4 * w + 1], 255u) << 8) | (min(h[4 * w + 2], 255u) << 16) | (min(h[4 * w + 3], 255u) << 24);
     auto hcnt = [&](int k) -> uint32_t { return (hp[k >> 2] >> (8 * (k & 3))) & 255u; };
 
-    if (a.dbg == 2) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
+    if ((a.dbg & 15) == 2) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     // the tile's bookkeeping words (stored by its first placement, behind the scans: a store in front of them holds up
     // the wave's loads) and where its ids go: the tile's head slot, or -- a whole list -- n ids of the pool (over all
     // tiles the pool holds R >= every list it can be asked for)
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
             // the thread whose sixteen bins hold the crossing finds the bin (every bin alone fits)
             if (tl == 0) { s_cut = GFT_DEPTH_BINS; s_kf = n - done; }
             __syncthreads();
-            const uint32_t lim = done + (TPULL_KEYS - 1u);
+            const uint32_t lim = done + ((pbits == 12u ? TPULL_KEYS_BIG : TPULL_KEYS) - 1u);
             if (run0 < lim && xin >= lim) {                          // exactly one thread, or none (the rest fits)
                 uint32_t run = run0;
 #pragma unroll
@@ -571,7 +578,8 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
         win_base = s_bmin & ~15u;                                        // (a thread's sixteen bins lie inside or outside the window together)
         // (the range's occupied bins span at most twice the cursors)
         cshift = s_bmax > win_base + PULL_WINDOW ? 1u : 0u;
-        const bool grouped = (cshift ? s_gmax2 : s_gmax) <= PULL_GROUP_MAX && c < 2048u;     // (places of 11 bits)
+        const uint32_t cmax = 0xffffu >> pbits;                                          // largest bin a cursor can count
+        const bool grouped = (cshift ? s_gmax2 : s_gmax) <= cmax && c <= pmask;
         if (grouped && (uint32_t)(16 * tl) >= win_base && (uint32_t)(16 * tl) < win_base + (PULL_WINDOW << cshift)) {
             // keys of [lo, hi) in front of this thread's bins (a thread whose bins straddle lo starts at place 0)
             uint32_t r = (uint32_t)(16 * tl) >= lo ? run0 - done : 0u;
@@ -583,9 +591,9 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
 #pragma unroll
                 for (int k = 0; k < 16; k += 2) {
                     const uint32_t b = (uint32_t)(16 * tl + k) - win_base;
-                    const uint32_t c0 = (r & 0x7ffu) | (min(hb(k), 31u) << 11);
+                    const uint32_t c0 = (r & pmask) | (min(hb(k), cmax) << pbits);
                     r += hb(k);
-                    const uint32_t c1 = (r & 0x7ffu) | (min(hb(k + 1), 31u) << 11);
+                    const uint32_t c1 = (r & pmask) | (min(hb(k + 1), cmax) << pbits);
                     r += hb(k + 1);
                     s_cur[b >> 1] = c0 | (c1 << 16);                     // (places beyond the range are never used)
                 }
@@ -594,9 +602,9 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
                 for (int k = 0; k < 16; k += 4) {
                     const uint32_t cw = ((uint32_t)(16 * tl + k) - win_base) >> 1;      // cursor of the bins k, k + 1; the next one of k + 2, k + 3
                     const uint32_t n0 = hb(k) + hb(k + 1), n1 = hb(k + 2) + hb(k + 3);
-                    const uint32_t c0 = (r & 0x7ffu) | (min(n0, 31u) << 11);
+                    const uint32_t c0 = (r & pmask) | (min(n0, cmax) << pbits);
                     r += n0;
-                    const uint32_t c1 = (r & 0x7ffu) | (min(n1, 31u) << 11);
+                    const uint32_t c1 = (r & pmask) | (min(n1, cmax) << pbits);
                     r += n1;
                     s_cur[cw >> 1] = c0 | (c1 << 16);
                 }
@@ -613,10 +621,11 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
         }
         if (done == 0u) {
             if (tl == 0) {
-                a.ranges[tile] = bk_range;
-                a.front_len[tile] = kf;
+                const bool cut_short = (a.dbg & 15) == 5;        // (timing experiment without the sorters: nobody may read the ids)
+                a.ranges[tile] = cut_short ? make_uint2(0u, 0u) : bk_range;
+                a.front_len[tile] = cut_short ? 0u : kf;
                 a.tile_cnt[tile] = n;
-                a.tile_cut[tile] = bk_cut;
+                a.tile_cut[tile] = cut_short ? GFT_NO_TAIL : bk_cut;
             }
             if (tl < 4) a.unit_flag[4 * tile + tl] = 0;
         }
@@ -625,7 +634,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
         for (uint32_t i = tl; i < c; i += GFT_BLOCK) a.need[(uint32_t)sk[i]] = 1;
         if (done == 0u) clear_slice();
         uint32_t* __restrict__ ids = list + done;
-        if (c == 0u) {
+        if (c == 0u || (a.dbg & 15) == 5) {
         } else if (grouped) {
             // the keys stand grouped by depth bin, the bins in ascending order: a key's place = start of its bin's group + the
             // number of smaller keys in the group (keys are distinct: the id is their low half).  The bin's cursor now holds
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
                 const uint32_t b = (gft_depth_bin((uint32_t)(key >> 32), a.sh.near_bits, a.sh.bin_shift) - win_base) >> cshift;
                 const uint32_t w = s_cur[b >> 1];
                 const uint32_t half = (b & 1u) ? (w >> 16) : (w & 0xffffu);
-                const uint32_t end = half & 0x7ffu, g = half >> 11, l0 = end - g;
+                const uint32_t end = half & pmask, g = half >> pbits, l0 = end - g;
                 uint32_t below = 0;
                 for (uint32_t qd = 0; qd < g; qd++) below += sk[l0 + qd] < key ? 1u : 0u;
                 ids[l0 + below] = (uint32_t)key;
@@ -998,7 +1007,7 @@ hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomVi
     a.hints = hints; a.pool_base = (uint32_t)a.sh.T * GFT_HEAD_SLOT;
     static const int dbg = [] { const char* e = getenv("GFT_PULL_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
-    if (dbg == 4) { a.clear = nullptr; a.dbg = 0; }
+    if ((dbg & 15) == 4) { a.clear = nullptr; a.dbg = dbg & 16; }     // (+16: every tile counts as hinted)
     const int Np = a.sh.NS << (2 * a.sh.sshift);
     hipLaunchKernelGGL(k_tile_pull, dim3(8 * ((Np + 7) / 8)), dim3(GFT_BLOCK), 0, s, a);
     return hipGetLastError();

@@ -932,10 +932,10 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     // GFT_SEG_LEN entries: the wave of segment s walks [256 s, 256 (s + 1)) back to front, starting from the blend
     // state the forward saved in front of entry 256 (s + 1) -- what lies behind it is (final sums - sums up to there) --;
     // the last segment walks from the final state as a single wave would.  The same arithmetic per (pixel, splat) as
-    // one wave, other summation order of the atomics only.  Workgroups of segment 0 first, then segment 1, ...
+    // one wave, other summation order of the atomics only.  Workgroups of the last segment first, then segment 0, 1, ...
     const int per_seg = (int)gridDim.x / a.nseg;
-    const int seg = (int)blockIdx.x / per_seg;
-    const int bid = (int)blockIdx.x - seg * per_seg;
+    const int sgroup = (int)blockIdx.x / per_seg;          // launch group: the workgroups of group 0 start first
+    const int bid = (int)blockIdx.x - sgroup * per_seg;
     const int xcd = bid & 7, qslot = bid >> 3;
     const int rank = 8 * (qslot >> 2) + xcd;
     if (rank >= a.T) return;
@@ -952,7 +952,11 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
         ncut = lim > 0 ? (lim - 1) / GFT_SEG_LEN : 0;                       // cuts at 256, ..., 256 ncut < lim
         if (ncut > a.nseg - 1) ncut = a.nseg - 1;
     }
-    if (seg > ncut) return;
+    // Group 0 walks the LAST segment of its quadrant, group g > 0 segment g - 1: the last segment is the one that is not cut
+    // to GFT_SEG_LEN entries -- behind the last snapshot of a list that was sorted whole it is 1200 entries of a
+    // 3000-entry walk, and a chain of that length must not be the one that starts last.
+    const int seg = sgroup == 0 ? ncut : sgroup - 1;
+    if (sgroup > 0 && seg >= ncut) return;
     const int lo_last = seg * GFT_SEG_LEN;                                  // list range [lo_last, hi_first) of this segment
     const int hi_first = seg == ncut ? tmax : lo_last + GFT_SEG_LEN;
     const int tile = v_unit >> 2, quad = v_unit & 3;
