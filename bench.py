@@ -166,8 +166,11 @@ def walked_instances(dev, radii=None):
             "gaussians_with_appearance": int((need != 0).sum().item()) if pull else None,
             # bookkeeping of that forward (ctrl words, gft_internal.h): entries dealt to supertiles, ids sorted into list
             # heads, quadrants that walked past their head, ids in the lists that were completed for them
+            # (ctrl[8]: ids of the lists that hinted tiles sorted whole -- they lie in the pool like the completed lists and are
+            # counted in ctrl[6] as well as in the tiles' sorted lengths: taken out of the completed ones here)
             "supertile_entries": ctrl[5] if pull else None, "head_ids": int(heads.sum().item()) if pull else None,
-            "flagged_quadrants": ctrl[4], "completed_list_ids": ctrl[6] if pull else None}
+            "flagged_quadrants": ctrl[4], "completed_list_ids": (ctrl[6] - ctrl[8]) if pull else None,
+            "whole_list_ids": ctrl[8] if pull else None}
 
 
 def build_scene(workload, rank, world):
@@ -429,8 +432,9 @@ def deform_extra(dev, n=300_000, steps=10, warmup=3):
     import numpy as np
     import torch
     from gftorf_amd import reference_network, _lib
-    from oracle import deform_ref
-    params = deform_ref.random_params(3)
+    from gftorf_amd import synth
+    from oracle import deform_ref           # the eager / CPU baseline legs below; the HIP leg's inputs come from synth
+    params = synth.random_deform_params(3)
     net = reference_network()
     net.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
     net = net.to(dev)
@@ -643,7 +647,8 @@ def train_iteration_extra(dev, scene, steps=10, warmup=3, only_fused=False):
     rast = GaussianRasterizer(settings)
     rng = np.random.default_rng(21)
     mask = torch.tensor(rng.random(P) < 0.3, device=dev)
-    params = deform_ref.random_params(9, head_std=1e-3)
+    from gftorf_amd import synth
+    params = synth.random_deform_params(9, head_std=1e-3)
     gr = {k: t(v) for k, v in scene["grads"].items()}
 
     def build(fused, pair=False):
@@ -1207,6 +1212,18 @@ def main():
 
     elapsed = timed_steps(step, args.steps, args.warmup, sync, dist)
 
+    # ---- median leg ("median of 100"): the same K steps once more with one event per step on the launch stream;
+    # `ms_per_step` stays the mean of the timed region above, `ms_per_step_median` is the median of these device-side step times
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
+    for i in range(args.steps):
+        step()
+        marks[i + 1].record()
+    sync()
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if per_step else None
+    del marks
+
     # ---- roofline leg: the same K steps again with per-stage HIP events on the launch stream
     _lib.profile_reset()
     _lib.profile_enable(True)
@@ -1272,6 +1289,13 @@ def main():
         except Exception as e:                            # reported, never fatal for the headline line
             exchange = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    my_calls = max(prof["forward_calls"], 1)
+    my_stage_ms = {k[:-3]: prof[k] / my_calls for k in prof if k.endswith("_ms")}
+    per_rank_stage_ms = None
+    if dist is not None and dist.get_world_size() > 1:
+        per_rank_stage_ms = [None] * dist.get_world_size()
+        dist.all_gather_object(per_rank_stage_ms, my_stage_ms)
+
     if env["rank"] == 0:
         fo = bool(cfg.get("forward_only"))
         # SURVEY 8(d) as written (reference algorithm) and the same constants on the units the launches process
@@ -1331,7 +1355,7 @@ def main():
         out = {
             "metric": "train iters/sec (fwd+bwd raster) + Mpix/s, 1M Gaussians @ 640x480 ToF",
             "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "ms_per_step_median": median_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             # ranks of the process group the timed region's barriers ran on (backend nccl = RCCL; gloo in a rehearsal)
             "rccl_ranks": dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else (1 if dist is None else 0),
@@ -1372,8 +1396,14 @@ def main():
                                                          "completed_list_ids", "gaussians_with_appearance")} if walked else None,
             "stage_ms": stage_ms,
         }
+        if per_rank_stage_ms is not None:
+            out["per_rank_stage_ms"] = per_rank_stage_ms
         if exchange is not None:
             out["deform_exchange"] = exchange
+            # (the N > 1 line's exchange figures where a reader of the top level finds them)
+            for k in ("allreduce_alone_ms", "replicas_identical"):
+                if k in exchange:
+                    out[k] = exchange[k]
         if composed_step is not None:
             out["composed_step"] = composed_step
             # the composed step's dominant kernel is the network's forward walk (matrix-core bound), not a rasterizer kernel:
@@ -1397,6 +1427,18 @@ def main():
                 if want is None or name in want:
                     out["extras"][name] = fn()
                     torch.cuda.empty_cache()
+            # the training-representative figures beside the repeated-frame headline, at the top level of the line: shuffled
+            # views (every frame another camera), a caller that keeps its gradients (dense gradient writes), the frame in
+            # which nothing saturates (every list walked whole) and that frame's share of the HBM roofline by units processed
+            ex = out["extras"]
+            if "varying_views" in ex:
+                out["varying_views_it_per_s"] = ex["varying_views"]["it_per_s"]
+            if "grads_kept" in ex:
+                out["grads_kept_it_per_s"] = ex["grads_kept"]["it_per_s"]
+            if "fog" in ex:
+                out["fog_it_per_s"] = ex["fog"]["it_per_s"]
+                out["fog_ms_per_step"] = ex["fog"]["ms_per_step"]
+                out["fog_path_frac"] = ex["fog"]["path_roofline"]["frac"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, budget_s=args.cpu_budget, forward_only=fo)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]

@@ -129,7 +129,7 @@ class AdamTensor(C.Structure):
 
 EXPORTS = [
     "gft_abi_version", "gft_lazy_sort", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes", "gft_acc_bytes",
-    "gft_det_partials_bytes", "gft_get_layout", "gft_binning_capacity", "gft_set_binning_mode", "gft_binning_mode", "gft_set_render_mode", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_backward", "gft_grads_rezero",
+    "gft_det_partials_bytes", "gft_get_layout", "gft_binning_capacity", "gft_set_binning_mode", "gft_binning_mode", "gft_set_render_mode", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_forward_enqueue", "gft_backward", "gft_grads_rezero",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
     "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi", "gft_adam_step_rows",
@@ -233,6 +233,8 @@ def load():
     lib.gft_forward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.POINTER(ForwardHints),
                                 C.POINTER(ForwardReport)]
     lib.gft_forward_render.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.c_int64, C.c_int64]
+    lib.gft_forward_enqueue.restype = C.c_int
+    lib.gft_forward_enqueue.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(ForwardIO), C.POINTER(ForwardHints), C.c_void_p]
     lib.gft_backward.restype = C.c_int
     lib.gft_backward.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(BackwardIO), C.c_int64]
     lib.gft_grads_rezero.restype = C.c_int

@@ -78,6 +78,39 @@ _TILE_HINTS = _os.environ.get("GFT_TILE_HINTS", "1") != "0"
 _tile_hints = {}
 
 
+# The forward without a host read (gft_forward_enqueue): taken automatically while the current stream is being captured into
+# a graph (torch.cuda.graphs around a fixed-shape iteration: at the reference's own scene size the host, not the kernels,
+# bounds the loop), and for every call with `gftorf_amd.api.no_host_read = True` / GFT_NO_HOST_READ=1.  The binning buffer is
+# sized from the shape's earlier frames as always; a frame whose instance count exceeds it is NOT re-rendered (nobody reads
+# the count while it runs): its outputs are undefined, and the next call of the shape -- which finds the device's posting of
+# the earlier frame in pinned memory -- raises.  `enqueue_status()` returns the postings (after a graph replay, say).
+no_host_read = _os.environ.get("GFT_NO_HOST_READ", "0") != "0"
+_status = {}              # hint key -> dict(dev=int32[16] on the device, host=its pinned copy, cap=instances of the last enqueue)
+
+
+def _status_of(key, dev, create):
+    st = _status.get(key)
+    if st is None and create and len(_status) < 1024:
+        st = _status[key] = dict(dev=torch.zeros((16,), device=dev, dtype=torch.int32),
+                                 host=torch.zeros((16,), dtype=torch.int32).pin_memory(), cap=0, key=key)
+        st["np"] = st["host"].numpy()
+    return st
+
+
+def enqueue_status(synchronize=True):
+    """What the device posted for the most recent no-host-read forward of every shape: a list of dicts(key=(device, P, W, H
+    [, slot]), posted, num_rendered, binning_instances, overflow).  ``overflow``: that frame did not fit its binning buffer
+    and its outputs are undefined -- render it again eagerly (the blocking flow re-sizes the buffer)."""
+    if synchronize and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    out = []
+    for key, st in _status.items():
+        a = st["np"]
+        out.append(dict(key=key, posted=bool(a[3]), num_rendered=int(a[0]), binning_instances=int(st["cap"]),
+                        overflow=bool(a[3]) and int(a[0]) > int(st["cap"]), prefiltered_point_culled=bool(a[1] & 1)))
+    return out
+
+
 def _tile_hint_buffer(key, dev, W, H):
     if not _TILE_HINTS:
         return None
@@ -207,16 +240,17 @@ _ACC_POOL_DEPTH = 3
 
 class _AccLease:
     """One accumulator buffer on its way through a forward and (maybe) a backward."""
-    __slots__ = ("buf", "key", "stream", "zero", "was_zero")
+    __slots__ = ("buf", "key", "stream", "zero", "was_zero", "pooled")
 
     def __init__(self, buf, key, stream, was_zero):
         self.buf, self.key, self.stream = buf, key, stream
+        self.pooled = True
         self.was_zero = was_zero      # taken from the pool: the forward clears nothing
         self.zero = False             # the buffer is (in stream order) all zero and nobody is going to write to it
 
     def give_back(self):
         buf, self.buf = self.buf, None
-        if buf is None or not self.zero or not _ACC_REUSE:
+        if buf is None or not self.zero or not _ACC_REUSE or not self.pooled:
             return
         pool = _acc_pool.setdefault(self.key, [])
         pool.append((buf, self.stream))
@@ -232,15 +266,22 @@ class _AccLease:
             pass
 
 
-def _take_acc(lib, dev, P, stream, any_stream=False):
+def _take_acc(lib, dev, P, stream, any_stream=False, pooled=True, prezero=False):
     key = (dev.index, P)
-    pool = _acc_pool.get(key) if _ACC_REUSE else None
+    pool = _acc_pool.get(key) if (_ACC_REUSE and pooled) else None
     if pool:
         for i, (buf, st) in enumerate(pool):
             if st == stream or any_stream:
                 del pool[i]
                 return _AccLease(buf, key, stream, True)
-    return _AccLease(torch.empty((lib.gft_acc_bytes(P) // 4,), device=dev, dtype=torch.float32), key, stream, False)
+    if prezero:
+        # (a forward that is queued without a host read may turn out not to fit its binning buffer: its kernels -- the one that
+        # clears the accumulator as a side job among them -- then do nothing, and a buffer that counts as zero afterwards must be)
+        lease = _AccLease(torch.zeros((lib.gft_acc_bytes(P) // 4,), device=dev, dtype=torch.float32), key, stream, True)
+    else:
+        lease = _AccLease(torch.empty((lib.gft_acc_bytes(P) // 4,), device=dev, dtype=torch.float32), key, stream, False)
+    lease.pooled = pooled          # (a buffer allocated while a graph is captured belongs to the graph's pool: never kept)
+    return lease
 _LIST_HEADROOM = 1.2      # longest tile list of the previous frame -> guess for this one
 
 
@@ -367,7 +408,7 @@ _PLANE_SPLIT = (3, 7, 1, 3, 1, 1, 1, 1, 3)     # color, phasor, depth, normal, a
 
 def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
                    cov3Ds_precomp, ph_off, dc_off, want_bw, with_acc, stream=None, hint_slot=0, share_grads=None,
-                   pre_launch=None, acc_any_stream=False):
+                   pre_launch=None, acc_any_stream=False, nowait=None):
     """One forward of the native rasterizer (``RasterizeGaussiansCUDA``, rasterize_points.cu:42-165): allocates the
     outputs and the three scratch buffers, runs the C ABI on torch's current stream.  ``s`` holds the settings fields
     (``GaussianRasterizationSettings`` or ``_Settings``), ``ph_off`` / ``dc_off`` are floats.  Returns a dict.
@@ -385,6 +426,12 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
     if dev.type != "cuda":
         raise RuntimeError("gftorf_amd: the rasterizer runs on a HIP device only (means3D is on %s); "
                            "there is no CPU path" % (dev,))
+    # under graph capture nothing may be read from the device and no buffer of the eager pools may be baked into the graph
+    capturing = torch.cuda.is_current_stream_capturing()
+    if nowait is None:
+        nowait = capturing or no_host_read
+    if capturing and s.debug:
+        raise RuntimeError("gftorf_amd: raster_settings.debug synchronises after every stage and cannot be captured in a graph")
     P = means3D.size(0)
     H, W = int(s.image_height), int(s.image_width)
 
@@ -434,7 +481,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
     # buffers that the last backward left zero (_AccLease)
     lease = None
     if want_bw and with_acc and P:
-        lease = _take_acc(lib, dev, P, stream if stream is not None else _lib.raw_stream(dev), acc_any_stream)
+        lease = _take_acc(lib, dev, P, stream if stream is not None else _lib.raw_stream(dev), acc_any_stream, pooled=not capturing,
+                          prezero=nowait and not capturing)
     acc_buf = lease.buf if lease is not None else None
     io.acc = None if (lease is not None and lease.was_zero) else _ptr(acc_buf)
 
@@ -444,7 +492,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         prep = prepare_backward(s, means3D_c, opac_c, sh_c, sh_p_c, scales_c, rot_c, cov_c, radii, geom, img,
                                 (bg_c, bsc, bsy, bsx), (view_c, proj_c, campos_c), ph_off, dc_off, acc_buf,
                                 colors_c is not None, cov_c is not None, want_bw, pixels,
-                                zero_fill=_ZERO_FILL and share_grads is None, share_grads=share_grads, acc_lease=lease)
+                                zero_fill=_ZERO_FILL and share_grads is None, share_grads=share_grads, acc_lease=lease,
+                                pooled=not capturing)
         if prep["zero_buf"] is not None:
             io.grads_zero = prep["zero_buf"].data_ptr()
             io.grads_zero_bytes = prep["zero_buf"].numel() * 4
@@ -464,14 +513,47 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         num_rendered = C.c_int64(0)
         hint_key = (dev.index, P, W, H) if not hint_slot else (dev.index, P, W, H, hint_slot)
         hint, list_hint = _instance_hint.get(hint_key, (None, 0))
-        tile_hints = _tile_hint_buffer(hint_key, dev, W, H)
+        # (a schedule buffer made during a capture would live in the graph's private pool: only one that exists already)
+        tile_hints = _tile_hints.get(hint_key) if capturing else _tile_hint_buffer(hint_key, dev, W, H)
         io.tile_hints = _ptr(tile_hints)
         try:
             with _lib.on_device(dev):
-                if hint is None:
+                if nowait:
+                    if hint is None:
+                        raise RuntimeError("gftorf_amd: the forward without a host read (graph capture, no_host_read) sizes its "
+                                           "binning buffer from earlier frames of the shape: render one frame of this shape "
+                                           "(%d Gaussians, %dx%d) eagerly first" % (P, W, H))
+                    st = _status_of(hint_key, dev, create=not capturing)
+                    if st is None:
+                        raise RuntimeError("gftorf_amd: no status block for this shape: render one frame of it with "
+                                           "gftorf_amd.api.no_host_read = True before capturing")
+                    a = st["np"]
+                    if a[3]:
+                        # the posting of the shape's previous no-host-read frame (its kernels are long done)
+                        prev_R, prev_cap = int(a[0]), int(st["cap"])
+                        a[3] = 0
+                        if a[1] & 1:
+                            raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+                        prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
+                        _instance_hint[hint_key] = (max(prev_R, int((prev_r or 0) * 0.95)), prev_l)
+                        hint = _instance_hint[hint_key][0]
+                        if prev_R > prev_cap:
+                            raise RuntimeError("gftorf_amd: the previous no-host-read forward of this shape had %d instances for a "
+                                               "binning buffer of %d: its outputs were undefined (the buffer has been enlarged "
+                                               "for the following frames)" % (prev_R, prev_cap))
+                    cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
+                    binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
+                    io.binning = binning.data_ptr()
+                    hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1)
+                    _lib.check(lib.gft_forward_enqueue(stream, C.byref(cfg), C.byref(io), C.byref(hints), st["dev"].data_ptr()))
+                    st["cap"] = cap
+                    st["host"].copy_(st["dev"], non_blocking=True)
+                    R = -1                     # (not known to the host)
+                elif hint is None:
                     # first frame of this shape: size the buffer after the one blocking
                     # read, like the reference's resize callback
                     # (rasterize_points.cu:27-33, rasterizer_impl.cu:311-315)
+                    _status_of(hint_key, dev, create=True)      # (so that a later capture of this shape finds its status block)
                     _lib.check(lib.gft_forward_preprocess(stream, C.byref(cfg), C.byref(io),
                                                           C.byref(num_rendered), C.byref(max_list)))
                     R = int(num_rendered.value)
@@ -498,10 +580,11 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                         _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, int(max_list.value)))
                 # slowly decaying maximum: alternating views of one scene (colour / ToF camera,
                 # random training views) keep the larger count as the guess
-                prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
-                _instance_hint[hint_key] = (max(R, int((prev_r or 0) * 0.95)), max(int(max_list.value), int(prev_l * 0.95)))
-                if len(_instance_hint) > 64:
-                    _instance_hint.pop(next(iter(_instance_hint)))
+                if not nowait:
+                    prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
+                    _instance_hint[hint_key] = (max(R, int((prev_r or 0) * 0.95)), max(int(max_list.value), int(prev_l * 0.95)))
+                    if len(_instance_hint) > 64:
+                        _instance_hint.pop(next(iter(_instance_hint)))
         except Exception as ex:
             if s.debug:
                 torch.save(cpu_args, "snapshot_fw.dump")
@@ -526,7 +609,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
 
 def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii, geom, img, bg, consts, ph_off, dc_off,
                      acc, want_colors, want_cov, want_bw_records=True, pixels=None, zero_fill=False, share_grads=None,
-                     acc_lease=None):
+                     acc_lease=None, pooled=True):
     """Everything of a backward that does not depend on the upstream gradients: the gradient tensors, the argument
     block, the config.  The forward calls it BEFORE it queues its kernels, so that this host work overlaps the device's
     previous work instead of sitting between the forward's last kernel and the backward's first one."""
@@ -560,7 +643,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         sizes = {k: (_prod(v) + 3) // 4 * 4 for k, v in shapes.items() if v is not None}
         total = sum(sizes.values()) + 4
         entry = None
-        if _GRADS_REUSE and P and pixels is not None and want_bw_records and not zero_fill:
+        if _GRADS_REUSE and pooled and P and pixels is not None and want_bw_records and not zero_fill:
             key = (dev.index, P, tuple(sorted(sizes.items())))
             pool = _grad_pool.setdefault(key, [])
             if _USE_COUNT_API:
@@ -638,7 +721,7 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         acc = torch.empty((lib.gft_acc_bytes(P) // 4,), **f32)
     cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw_records)
     # (2: the backward leaves the accumulator zero again -- the buffer goes back to the pool, _AccLease)
-    cfg.acc_zeroed = 2 if (acc_zeroed and acc_lease is not None and _ACC_REUSE) else int(acc_zeroed)
+    cfg.acc_zeroed = 2 if (acc_zeroed and acc_lease is not None and _ACC_REUSE and acc_lease.pooled) else int(acc_zeroed)
     # A kept set of gradient tensors is rewritten row by row only while few rows are written (a dense frame blends a few
     # per cent of its Gaussians): the rows kernel stores its rows straight from the lanes, and from about a third of the
     # Gaussians on the full write through LDS -- coalesced, zeros included -- is faster (C3-shaped frame, 96 % blended: 16 vs
@@ -725,6 +808,10 @@ def run_backward(prep, grads_out, geom, binning, img, debug=False):
     cap = binning_capacity(binning, W, H) if P else 0
     if _DETERMINISTIC and P and cap:
         # test mode: partial rows per (list entry, quadrant), added in a fixed order (gft_backward_io.det_partials)
+        if torch.cuda.is_current_stream_capturing():
+            # (two deterministic backwards in one captured graph gave wrong sums from the second replay on -- the mode's
+            # 250-byte-per-list-slot scratch and its memset nodes; not run down: it is a test mode)
+            raise RuntimeError("gftorf_amd: GFT_BWD_DETERMINISTIC is a test mode of the eager flows and cannot be captured in a graph")
         det = torch.empty((lib.gft_det_partials_bytes(cap, W, H) // 4,), dtype=torch.float32, device=dev)
         io.det_partials = det.data_ptr()
     if debug:

@@ -652,6 +652,46 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     return 0;
 }
 
+// ---- forward, queued only ------------------------------------------------------------
+// Both stages back to back and no read of anything the device computes: the call is pure launch work, so a caller may
+// capture it in a HIP graph (torch.cuda.graphs) or simply not stall.  What the blocking flows learn from the mailbox the
+// device posts into `status` instead (GFT_STATUS_WORDS words of pinned host or device memory owned by the caller, cleared
+// here on the stream): status[0] = R, status[1] bit 0 = "prefiltered point culled", status[3] = 1 once stage 1 has
+// posted.  The stage-2 kernels compare R with the buffer themselves and do nothing when it does not fit: the caller reads
+// `status` whenever the stream has passed -- typically in front of its next call -- and re-renders with a larger buffer.
+static_assert(GFT_STATUS_WORDS == GFT_CTRL_WORDS, "the status block is a mailbox slot");
+extern "C" int gft_forward_enqueue(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
+                                   const gft_forward_hints* hints, uint32_t* status)
+{
+    if (check_config(cfg)) return 1;
+    if (!io || !hints) return gft_fail("gft_forward_enqueue: NULL argument");
+    if (cfg->debug) return gft_fail("gft_forward_enqueue: cfg.debug synchronises after every stage; use gft_forward");
+    if (check_stage2(io, "gft_forward_enqueue")) return 1;
+    const int64_t binning_instances = hints->binning_instances;
+    if (binning_instances < 0 || binning_instances > 0xffffffffll) return gft_fail("gft_forward_enqueue: bad instance count");
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (status) GFT_CHECK_HIP(hipMemsetAsync(status, 0, GFT_STATUS_WORDS * sizeof(uint32_t), s));
+    if (cfg->P == 0) {
+        // (no kernel posts anything: R = 0 fits every buffer)
+        if (status) GFT_CHECK_HIP(hipMemsetAsync(status + GFT_CTRL_SEQ, 1, 1, s));
+        return gft_forward_render(hip_stream, cfg, io, 0, 0);
+    }
+    if (check_stage1(cfg, io, "gft_forward_enqueue")) return 1;
+    if (binning_instances > 0 && !io->binning) return gft_fail("gft_forward_enqueue: binning buffer is NULL");
+    gft_layout L;
+    gft_compute_layout(cfg->P, cfg->W, cfg->H, binning_instances, &L);
+    GeomView g = gft_geom_view(io->geom, L);
+    ImgView im = gft_img_view(io->img, L);
+    BinView b = gft_bin_view(io->binning, L);
+    const bool pull = pull_enabled(cfg);
+    if (enqueue_stage1(s, cfg, io, g, im, status, 1u, pull)) return 1;
+    if (pull && binning_instances == 0) {
+        const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
+        GFT_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s));
+    }
+    return enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, (uint32_t)binning_instances, pull);
+}
+
 // ---- backward -----------------------------------------------------------------
 extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_backward_io* io, int64_t num_rendered)
 {
@@ -669,6 +709,7 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
         return gft_fail("gft_backward: required pointer is NULL");
     if ((io->dL_dphase_offset == nullptr) != (io->dL_ddc_offset == nullptr))
         return gft_fail("gft_backward: dL_dphase_offset and dL_ddc_offset are wanted together or not at all");
+    if (num_rendered < 0 || num_rendered > 0xffffffffll) return gft_fail("gft_backward: bad instance count");
     if (num_rendered > 0 && !io->binning) return gft_fail("gft_backward: binning buffer is NULL");
     if ((io->shs != nullptr) != (cfg->M > 0) || (io->shs_p != nullptr) != (cfg->M_p > 0))
         return gft_fail("M / M_p do not match the presence of shs / shs_p");
@@ -705,7 +746,7 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     }
     if (num_rendered > 0) {
         StageTimer t(s, ST_RENDER_BWD);
-        GFT_STAGE(s, cfg, "render_bwd", gft_launch_render_bwd(s, *cfg, *io, g, im, b, lazy_sort_enabled()));
+        GFT_STAGE(s, cfg, "render_bwd", gft_launch_render_bwd(s, *cfg, *io, g, im, b, lazy_sort_enabled(), (uint32_t)num_rendered));
     }
     {
         StageTimer t(s, ST_PRE_BWD);

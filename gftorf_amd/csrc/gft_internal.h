@@ -184,7 +184,7 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
                                  const GeomView& g, const ImgView& im, const BinView& b, bool check_cap, uint32_t cap,
                                  int lazy, bool pull, bool segmented = true);
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
-                                 const GeomView& g, const ImgView& im, const BinView& b, bool lazy);
+                                 const GeomView& g, const ImgView& im, const BinView& b, bool lazy, uint32_t cap);
 hipError_t gft_launch_preprocess_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io,
                                      const GeomView& g);
 hipError_t gft_launch_grads_rezero(hipStream_t s, const gft_config& c, const gft_backward_io& io);

@@ -828,6 +828,8 @@ struct RenderBwdArgs {
     const uint32_t* __restrict__ order_ok;  // ctrl word: the forward computed `order` (NULL: it is valid)
     const float* __restrict__ g_color; const float* __restrict__ g_phasor; const float* __restrict__ g_depth;
     const float* __restrict__ g_acc; const float* __restrict__ g_dd;
+    const uint32_t* __restrict__ ctrl;   // the forward's ctrl words
+    uint32_t cap;                        // instances the binning buffer holds: a forward that counted more has binned nothing
     float* acc;   // [P][GFT_ACC_STRIDE]
     float* det;   // deterministic mode: [binning instance][quadrant][16] partial rows instead of atomics (NULL: atomics)
 };
@@ -933,6 +935,9 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     // state the forward saved in front of entry 256 (s + 1) -- what lies behind it is (final sums - sums up to there) --;
     // the last segment walks from the final state as a single wave would.  The same arithmetic per (pixel, splat) as
     // one wave, other summation order of the atomics only.  Workgroups of the last segment first, then segment 0, 1, ...
+    // (a forward that was queued without a host read and did not fit its buffer has left no lists: nothing to walk -- its
+    // caller learns of it from the status block, gft_forward_enqueue)
+    if (a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
     const int per_seg = (int)gridDim.x / a.nseg;
     const int sgroup = (int)blockIdx.x / per_seg;          // launch group: the workgroups of group 0 start first
     const int bid = (int)blockIdx.x - sgroup * per_seg;
@@ -1171,8 +1176,10 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
 __global__ __launch_bounds__(1024) void k_acc_reduce_det(int T, const uint2* __restrict__ ranges,
                                                          const uint32_t* __restrict__ quad_max,
                                                          const uint32_t* __restrict__ point_list,
-                                                         const float* __restrict__ det, float* acc)
+                                                         const float* __restrict__ det, float* acc,
+                                                         const uint32_t* __restrict__ ctrl, uint32_t cap)
 {
+    if (ctrl[GFT_CTRL_TOTAL] > cap) return;
     const int tid = threadIdx.x;
     for (int tile = 0; tile < T; tile++) {
         const uint4 qm = reinterpret_cast<const uint4*>(quad_max)[tile];
@@ -1252,9 +1259,10 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
 }
 
 hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_backward_io& io, const GeomView& g,
-                                 const ImgView& im, const BinView& b, bool lazy)
+                                 const ImgView& im, const BinView& b, bool lazy, uint32_t cap)
 {
     RenderBwdArgs a;
+    a.ctrl = im.ctrl; a.cap = cap;
     a.W = c.W; a.H = c.H;
     a.gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X;
     const int gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
@@ -1286,6 +1294,6 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     hipLaunchKernelGGL(k_render_bwd, dim3(blocks), dim3(64), 0, s, a);
     if (a.det)
         hipLaunchKernelGGL(k_acc_reduce_det, dim3(1), dim3(1024), 0, s, a.T, im.ranges, im.tile_max, b.point_list,
-                           a.det, io.acc);
+                           a.det, io.acc, im.ctrl, cap);
     return hipGetLastError();
 }

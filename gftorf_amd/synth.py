@@ -136,3 +136,35 @@ def make_scene(name_or_cfg, seed=1234, w2c=None, P=None):
                 grads=make_pixel_grads(cfg["W"], cfg["H"], seed),
                 depth_range=10.0, phase_offset=0.1, dc_offset=0.05,
                 use_view_dependent_phase=True)
+
+
+# ---- deformation network: seeded parameters (synthetic data, like the scenes above) ----------------------------
+def deform_param_shapes(t_multires=10, xyz_multires=10, D=8, W=256, num_shs=16):
+    """``state_dict`` names -> shapes of the reference's ``DeformNetwork`` (utils/time_utils.py:68-81): D hidden layers of
+    width W, the encoded input re-injected behind layer D // 2, heads xyz_warp 3, rot 4, r / g / b / a num_shs."""
+    n_in = 3 + 6 * xyz_multires + 1 + 2 * t_multires
+    s = {}
+    for i in range(D):
+        fan_in = n_in if i == 0 else (W + n_in if i == D // 2 + 1 else W)
+        s["linear.%d.weight" % i] = (W, fan_in)
+        s["linear.%d.bias" % i] = (W,)
+    for name, out in (("xyz_warp", 3), ("rot", 4), ("r", num_shs), ("g", num_shs), ("b", num_shs), ("a", num_shs)):
+        s[name + ".weight"] = (out, W)
+        s[name + ".bias"] = (out,)
+    return s
+
+
+def random_deform_params(seed, head_std=0.05, t_multires=10):
+    """Seeded parameters of a usable magnitude (Xavier-like trunk; heads larger than the reference's 1e-5 initialisation so
+    that outputs and gradients are well away from zero): numpy arrays under the reference's ``state_dict`` names, torch's
+    ``[out, in]`` layout."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, shape in deform_param_shapes(t_multires).items():
+        if name.endswith(".bias"):
+            p[name] = rng.normal(0.0, 0.02, shape).astype(np.float32)
+        elif name.startswith("linear."):
+            p[name] = rng.normal(0.0, np.sqrt(2.0 / (shape[0] + shape[1])), shape).astype(np.float32)
+        else:
+            p[name] = rng.normal(0.0, head_std, shape).astype(np.float32)
+    return p

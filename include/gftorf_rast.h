@@ -338,6 +338,20 @@ typedef struct gft_forward_report {
 int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
                 const gft_forward_hints* hints, gft_forward_report* report /*host*/);
 
+/* The forward queued only: both stages back to back and NO read of anything the device computes -- the call is launch
+ * work alone, so it can be captured in a HIP graph (torch.cuda.graphs around a fixed-shape training iteration) and never
+ * stalls the host.  What gft_forward() reads from the device while it runs, the device posts into `status` instead:
+ * GFT_STATUS_WORDS uint32 of pinned host memory or device memory owned by the caller (may be NULL), cleared by this call
+ * on the stream and written when stage 1 ends: status[0] = R (num_rendered), status[1] bit 0 = "prefiltered point was
+ * culled" (the reference's error, rasterizer_impl.cu: trap), status[2] = longest tile list (whole-frame binning),
+ * status[3] = 1 once posted, status[5] = list entries.  If R > hints->binning_instances the stage-2 kernels have done
+ * nothing (they compare the count on the device): the outputs of that frame are undefined and the caller, reading
+ * `status` once the stream has passed (in front of its next call, say), renders again with a larger buffer.  Same kernels,
+ * same results as gft_forward().  cfg->debug is refused (it synchronises). */
+#define GFT_STATUS_WORDS 16
+int gft_forward_enqueue(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
+                        const gft_forward_hints* hints, uint32_t* status /*device-accessible, may be NULL*/);
+
 /* The backward of the forward whose scratch buffers `io` carries.  Gradient sums are added with float atomics
  * (as in the reference), so two runs agree to rounding, not bit for bit.  GFT_BWD_SPLIT=0 in the environment
  * keeps one wave per pixel quadrant (default: deep quadrants are walked by up to eight waves).

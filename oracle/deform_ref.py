@@ -67,17 +67,11 @@ def arch_of(params):
 
 
 def random_params(seed, head_std=0.05, t_multires=T_MULTIRES):
-    """Seeded parameters of a usable magnitude (Xavier-like trunk; heads larger than the reference's
-    1e-5 initialisation so that outputs and gradients are well away from zero)."""
-    rng = np.random.default_rng(seed)
-    p = {}
-    for name, shape in param_shapes(t_multires).items():
-        if name.endswith(".bias"):
-            p[name] = rng.normal(0.0, 0.02, shape).astype(np.float32)
-        elif name.startswith("linear."):
-            p[name] = rng.normal(0.0, np.sqrt(2.0 / (shape[0] + shape[1])), shape).astype(np.float32)
-        else:
-            p[name] = rng.normal(0.0, head_std, shape).astype(np.float32)
+    """Seeded parameters (synthetic data: the generator lives with the other synthetic inputs in ``gftorf_amd.synth``, so that
+    the benches' HIP legs need nothing from this package; re-exported here for the tests)."""
+    from gftorf_amd import synth
+    p = synth.random_deform_params(seed, head_std=head_std, t_multires=t_multires)
+    assert {k: v.shape for k, v in p.items()} == param_shapes(t_multires)
     return p
 
 

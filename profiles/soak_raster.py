@@ -1,89 +1,14 @@
 """Randomised soak of the rasterizer (public API -> C ABI -> kernels) against the C oracle with the parity tests' own
-checks: random sizes, image shapes (ragged tiles), SH degrees, opacity regimes (saturating ... fog), splat sizes (deep
-lists, heads of 940 exceeded), ToF on / off, both binning modes and both forward blend kernels.
-`python profiles/soak_raster.py [seconds]` -> one JSON line."""
-import json, os, sys, time
+checks; the generator and the mode product it walks live in tests/soak_cases.py (a seeded 200-frame slice of it runs in the
+GPU suite: tests/test_gpu_soak.py).  `python profiles/soak_raster.py [seconds] [seed]` -> one JSON line."""
+import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np, torch
-import helpers as Hh
-import test_gpu_parity as T
+import torch
+import soak_cases
 from oracle import oracle as O
-from gftorf_amd import _lib
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-dev = torch.device("cuda:0")
-lib = _lib.load()
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 77
 O.build(); O.lib()
-rng = np.random.default_rng(77)
-t0 = time.time()
-n = 0
-kinds = {}
-deepest = 0
-edge_flips = 0
-flip_cases = 0
-while time.time() - t0 < budget:
-    P = int(rng.choice([1, 7, 64, 300, 1200, 5000, 20000]))
-    # (at least 2000 pixels: the tests allow 1e-3 of an image's elements to sit on a blend edge, and one pixel of a smaller
-    # image is already more than that)
-    W, H = int(rng.integers(41, 200)), int(rng.integers(50, 130))
-    D, M = [(0, 16), (1, 16), (2, 16), (3, 16), (1, 4), (2, 9), (0, 1)][int(rng.integers(7))]
-    tof = bool(rng.random() < 0.8)
-    opacity = [None, 0.05, 0.1, 0.6, 0.99][int(rng.integers(5))]
-    scale_hi = float(rng.choice([0.03, 0.12, 0.5]))
-    seed = int(rng.integers(1 << 30))
-    tilted = bool(rng.random() < 0.7)
-    scene = Hh.small_scene(P=P, W=W, H=H, seed=seed, D=D, sh_coeffs=M, scale_lo=0.01, scale_hi=scale_hi,
-                           tof=tof, opacity=opacity, w2c="tilted" if tilted else None)
-    bin_mode, render_mode = int(rng.integers(2)), int(rng.integers(2))
-    lib.gft_set_binning_mode(bin_mode); lib.gft_set_render_mode(render_mode)
-    try:
-        f, b = Hh.run_oracle(O, scene)
-        out, grads, _ = Hh.run_gpu(scene, dev, optimize_offsets=tof)
-        try:
-            T.check_outputs(f, out)
-        except AssertionError as e:
-            # a pixel whose alpha sits on the 1/255 or T = 1e-4 edge may count for one more / one fewer Gaussian: with a few
-            # hundred Gaussians one such Gaussian is already more than the tests' 2e-3 of them
-            if "pixels mismatch" not in str(e):
-                raise
-            diff = np.abs(out["pixels"].reshape(-1) - f.pixels.reshape(-1))
-            assert (diff > 0).sum() <= 2 and diff.max() <= 3, str(e)
-            edge_flips += 1
-        # (splats of half the scene's depth cover thousands of pixels: the fp32 sums behind a rotation gradient cancel more)
-        # ... and a Gaussian that counts one pixel more or fewer than in the oracle (same edge) has that pixel's finite
-        # contribution more or less in its gradient rows: those rows are left out, the others keep the tests' tolerance
-        diff_rows = np.nonzero(out["pixels"].reshape(-1) != f.pixels.reshape(-1))[0]
-        flip_cases += int(diff_rows.size > 0)
-        if diff_rows.size:
-            b = dict(b)
-            for kb, kg in (("dL_dmeans3D", "means3D"), ("dL_dmeans2D", "means2D"), ("dL_dopacity", "opacities"), ("dL_dsh", "shs"),
-                           ("dL_dsh_p", "shs_p"), ("dL_dscales", "scales"), ("dL_drotations", "rotations")):
-                if b.get(kb) is not None and grads.get(kg) is not None:
-                    rb = np.array(b[kb], copy=True).reshape(P, -1); rb[diff_rows] = 0; b[kb] = rb.reshape(np.shape(b[kb]))
-                    rg = np.array(grads[kg], copy=True).reshape(P, -1); rg[diff_rows] = 0; grads[kg] = rg.reshape(np.shape(grads[kg]))
-            for kb in ("dL_dphase_offset", "dL_ddc_offset"):          # sums over all Gaussians: the flipped pixel is in them
-                if b.get(kb) is not None:
-                    grads.pop({"dL_dphase_offset": "phase_offset", "dL_ddc_offset": "dc_offset"}[kb], None)
-        # the two offset gradients are sums over all Gaussians that may cancel to a small total: absolute band 1e-4 here
-        for kb, kg in (("dL_dphase_offset", "phase_offset"), ("dL_ddc_offset", "dc_offset")):
-            if grads.get(kg) is not None and b.get(kb) is not None:
-                got = float(np.asarray(grads.pop(kg)).reshape(-1)[0]); ref = float(np.asarray(b[kb]).reshape(-1)[0])
-                assert abs(got - ref) <= 2e-3 * abs(ref) + 1e-4, "%s: %g vs %g" % (kb, got, ref)
-        # (the Gaussians in front of and behind the flipped pixel's extra / missing layer see a transmittance that differs by
-        # its alpha -- 1/255 at the skip edge, up to 0.99 at the termination edge of an opaque scene: 1e-2 for the remaining rows
-        # of such a frame)
-        T.check_grads(b, grads, scene, rtol=2e-2 if scale_hi >= 0.5 else (1e-2 if diff_rows.size else T.GRAD_RTOL))
-    except AssertionError as e:
-        print(json.dumps({"FAILED": str(e)[:300], "case": dict(seed=seed, tilted=tilted, P=P, W=W, H=H, D=D, M=M, tof=tof, opacity=opacity, scale_hi=scale_hi,
-                                                                bin_mode=bin_mode, render_mode=render_mode), "after_cases": n}))
-        raise
-    finally:
-        lib.gft_set_binning_mode(-1); lib.gft_set_render_mode(-1)
-    n += 1
-    k = "bin%d_render%d" % (bin_mode, render_mode)
-    kinds[k] = kinds.get(k, 0) + 1
-    from gftorf_amd import api
-    deepest = max(deepest, int(api.last_call_stats.get("max_tile_list", 0)))
-print(json.dumps({"seconds": round(time.time() - t0, 1), "cases": n, "by_mode": kinds, "deepest_tile_list": deepest, "cases_beyond_the_tests_pixel_count_band": edge_flips, "cases_with_a_pixel_count_difference (those Gaussians' gradient rows left out, 1e-2 for the frame's other rows)": flip_cases,
-                  "checks": "tests/test_gpu_parity.py::check_outputs / check_grads (images L1 and max-norm, radii bit-exact, pixels, every gradient)"}))
+print(json.dumps(soak_cases.run(torch.device("cuda:0"), O, seed=seed, seconds=budget)))

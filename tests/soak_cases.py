@@ -1,0 +1,146 @@
+"""Randomised frames of the rasterizer against the C oracle, with the parity tests' own checks (check_outputs / check_grads
+of test_gpu_parity.py).  One generator for the builder's long soak (profiles/soak_raster.py, minutes) and for the slice of
+it that runs inside the GPU suite (tests/test_gpu_soak.py, ~200 frames): sizes, ragged image shapes, SH degrees, opacity
+regimes (saturating ... fog), splat sizes (deep lists, heads of 940 exceeded), ToF on / off -- and the mode product of the
+operator: both binning structures, both forward blend kernels, the per-tile schedule (none / as the frames leave it / all
+ones / random), gradient tensors fresh / kept (rows or full rewrite) on the use-count or the DLPack route, accumulator kept
+or cleared."""
+import json
+import time
+
+import numpy as np
+import torch
+
+import helpers as Hh
+
+
+def draw_case(rng):
+    D, M = [(0, 16), (1, 16), (2, 16), (3, 16), (1, 4), (2, 9), (0, 1)][int(rng.integers(7))]
+    return dict(
+        P=int(rng.choice([1, 7, 64, 300, 1200, 5000, 20000])),
+        # (at least 2000 pixels: the tests allow 1e-3 of an image's elements to sit on a blend edge, and one pixel of a smaller
+        # image is already more than that)
+        W=int(rng.integers(41, 200)), H=int(rng.integers(50, 130)), D=D, M=M,
+        tof=bool(rng.random() < 0.8),
+        opacity=[None, 0.05, 0.1, 0.6, 0.99][int(rng.integers(5))],
+        scale_hi=float(rng.choice([0.03, 0.12, 0.5])),
+        seed=int(rng.integers(1 << 30)),
+        tilted=bool(rng.random() < 0.7),
+        bin_mode=int(rng.integers(2)), render_mode=int(rng.integers(2)),
+        hints=["off", "keep", "ones", "random"][int(rng.integers(4))],
+        grads=["fresh", "kept", "kept_full"][int(rng.integers(3))],
+        dlpack=bool(rng.random() < 0.25),
+        acc_kept=bool(rng.random() < 0.7))
+
+
+def run_case(case, dev, oracle, rng):
+    """One frame through the oracle and through the public API in the case's modes; raises AssertionError on a mismatch.
+    Returns (pixel counts beyond the tests' band, frames with any pixel-count difference)."""
+    import test_gpu_parity as T
+    from gftorf_amd import _lib, api
+    lib = _lib.load()
+    c = case
+    P = c["P"]
+    scene = Hh.small_scene(P=P, W=c["W"], H=c["H"], seed=c["seed"], D=c["D"], sh_coeffs=c["M"], scale_lo=0.01, scale_hi=c["scale_hi"],
+                           tof=c["tof"], opacity=c["opacity"], w2c="tilted" if c["tilted"] else None)
+    keep = (api._TILE_HINTS, api._GRADS_REUSE, api._USE_COUNT_API, api._ACC_REUSE)
+    lib.gft_set_binning_mode(c["bin_mode"])
+    lib.gft_set_render_mode(c["render_mode"])
+    edge_flips = flip_cases = 0
+    try:
+        api._TILE_HINTS = c["hints"] != "off"
+        api._GRADS_REUSE = c["grads"] != "fresh"
+        api._ACC_REUSE = c["acc_kept"]
+        want_use_count = keep[2] and not c["dlpack"]
+        if api._USE_COUNT_API != want_use_count:
+            api._grad_pool.clear()                      # (an entry belongs to the route that made it)
+            api._USE_COUNT_API = want_use_count
+        if len(api._tile_hints) > 512:                  # (the operator never frees them; a soak makes a new shape per frame)
+            torch.cuda.synchronize()
+            api._tile_hints.clear()
+        if c["hints"] in ("ones", "random"):
+            hb = api._tile_hint_buffer((dev.index, P, c["W"], c["H"]), dev, c["W"], c["H"])
+            if c["hints"] == "ones":
+                hb.fill_(0x01010101)
+            else:
+                hb.copy_(torch.tensor(rng.integers(0, 2, hb.numel()), dtype=torch.int32))
+        if c["grads"] == "kept_full":
+            for pool in api._grad_pool.values():
+                for e in pool:
+                    e["dense_left"] = 2                 # the next backwards into these tensors write them in full
+        f, b = Hh.run_oracle(oracle, scene)
+        if c["hints"] == "keep":
+            # the schedule as the operator builds it: the frame once more, on the words its first rendering left
+            out, grads, _ = Hh.run_gpu(scene, dev, optimize_offsets=c["tof"])
+            T.check_outputs(f, out) if not (out["pixels"] != f.pixels).any() else None
+            del out, grads
+        out, grads, _ = Hh.run_gpu(scene, dev, optimize_offsets=c["tof"])
+        try:
+            T.check_outputs(f, out)
+        except AssertionError as e:
+            # a pixel whose alpha sits on the 1/255 or T = 1e-4 edge may count for one more / one fewer Gaussian: with a few
+            # hundred Gaussians one such Gaussian is already more than the tests' 2e-3 of them
+            if "pixels mismatch" not in str(e):
+                raise
+            diff = np.abs(out["pixels"].reshape(-1) - f.pixels.reshape(-1))
+            assert (diff > 0).sum() <= 2 and diff.max() <= 3, str(e)
+            edge_flips = 1
+        # a Gaussian that counts one pixel more or fewer than in the oracle (same edge) has that pixel's finite contribution
+        # more or less in its gradient rows: those rows are left out, the others keep the tests' tolerance
+        diff_rows = np.nonzero(out["pixels"].reshape(-1) != f.pixels.reshape(-1))[0]
+        flip_cases = int(diff_rows.size > 0)
+        if diff_rows.size:
+            b = dict(b)
+            for kb, kg in (("dL_dmeans3D", "means3D"), ("dL_dmeans2D", "means2D"), ("dL_dopacity", "opacities"), ("dL_dsh", "shs"),
+                           ("dL_dsh_p", "shs_p"), ("dL_dscales", "scales"), ("dL_drotations", "rotations")):
+                if b.get(kb) is not None and grads.get(kg) is not None:
+                    rb = np.array(b[kb], copy=True).reshape(P, -1); rb[diff_rows] = 0; b[kb] = rb.reshape(np.shape(b[kb]))
+                    rg = np.array(grads[kg], copy=True).reshape(P, -1); rg[diff_rows] = 0; grads[kg] = rg.reshape(np.shape(grads[kg]))
+            for kb in ("dL_dphase_offset", "dL_ddc_offset"):          # sums over all Gaussians: the flipped pixel is in them
+                if b.get(kb) is not None:
+                    grads.pop({"dL_dphase_offset": "phase_offset", "dL_ddc_offset": "dc_offset"}[kb], None)
+        # the two offset gradients are sums over all Gaussians that may cancel to a small total: absolute band 1e-4 here
+        for kb, kg in (("dL_dphase_offset", "phase_offset"), ("dL_ddc_offset", "dc_offset")):
+            if grads.get(kg) is not None and b.get(kb) is not None:
+                got = float(np.asarray(grads.pop(kg)).reshape(-1)[0]); ref = float(np.asarray(b[kb]).reshape(-1)[0])
+                assert abs(got - ref) <= 2e-3 * abs(ref) + 1e-4, "%s: %g vs %g" % (kb, got, ref)
+        # (splats of half the scene's depth cover thousands of pixels: the fp32 sums behind a rotation gradient cancel more; the
+        # Gaussians in front of and behind a flipped pixel's extra / missing layer see a transmittance that differs by its
+        # alpha -- 1/255 at the skip edge, up to 0.99 at the termination edge of an opaque scene: 1e-2 for the remaining rows
+        # of such a frame)
+        T.check_grads(b, grads, scene, rtol=2e-2 if c["scale_hi"] >= 0.5 else (1e-2 if diff_rows.size else T.GRAD_RTOL))
+        del out, grads
+    finally:
+        lib.gft_set_binning_mode(-1)
+        lib.gft_set_render_mode(-1)
+        if api._USE_COUNT_API != keep[2]:
+            api._grad_pool.clear()
+        api._TILE_HINTS, api._GRADS_REUSE, api._USE_COUNT_API, api._ACC_REUSE = keep
+    return edge_flips, flip_cases
+
+
+def run(dev, oracle, seed=77, cases=None, seconds=None):
+    """Frames until `cases` are done or `seconds` have passed.  Returns the record; raises on the first mismatch with the
+    case in the message."""
+    from gftorf_amd import api
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    n = edge = flips = deepest = 0
+    kinds = {}
+    while (cases is None or n < cases) and (seconds is None or time.time() - t0 < seconds):
+        case = draw_case(rng)
+        try:
+            e, fl = run_case(case, dev, oracle, rng)
+        except AssertionError as ex:
+            raise AssertionError("soak case %d failed: %s\ncase: %s" % (n, str(ex)[:400], json.dumps(case))) from ex
+        edge += e
+        flips += fl
+        n += 1
+        k = "bin%d_render%d_hints-%s_grads-%s%s%s" % (case["bin_mode"], case["render_mode"], case["hints"], case["grads"],
+                                                     "_dlpack" if case["dlpack"] else "", "" if case["acc_kept"] else "_acc-cleared")
+        kinds[k] = kinds.get(k, 0) + 1
+        deepest = max(deepest, int(api.last_call_stats.get("max_tile_list", 0)))
+    return {"seconds": round(time.time() - t0, 1), "cases": n, "modes_met": len(kinds), "by_mode": kinds, "deepest_tile_list": deepest,
+            "cases_beyond_the_tests_pixel_count_band": edge,
+            "cases_with_a_pixel_count_difference (those Gaussians' gradient rows left out, 1e-2 for the frame's other rows)": flips,
+            "checks": "tests/test_gpu_parity.py::check_outputs / check_grads (images L1 and max-norm, radii bit-exact, pixels, every gradient)"}
