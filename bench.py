@@ -973,6 +973,77 @@ def fog_extra(dev, steps=50, warmup=15):
             "path_roofline": {"algorithmic_bytes_per_step": whole, "frac": gbs(whole, ms) / HBM_PEAK_GBS}}
 
 
+def graph_pair_extra(dev, steps=200, warmup=30):
+    """The two rasterizer calls of a C3-shaped iteration (100 k Gaussians at 320 x 240, opacity 0.1, two cameras on the same
+    Gaussians) with their backward: eagerly through the blocking flow (the reference's call pattern: at this size the host --
+    Python, autograd, the wait for the instance count -- bounds the loop, not the kernels), eagerly without the host read
+    (`api.no_host_read`), and captured once in a torch.cuda.CUDAGraph and replayed (gft_forward_enqueue: no host read, so the
+    iteration is capturable)."""
+    import numpy as np
+    import torch
+    from gftorf_amd import GaussianRasterizationSettings, GaussianRasterizer, api, synth
+    P, W, H = 100_000, 320, 240
+    cfg = dict(P=P, W=W, H=H, D=3, sh_coeffs=16, tof=True, opacity_range=(0.1, 0.1))
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
+    scenes = [synth.make_scene(cfg, seed=77, w2c=synth.look_at_w2c(yaw=y, pitch=p_, t=(tx, 0.0, 0.0))) for y, p_, tx in ((0.03, -0.01, 0.02), (-0.05, 0.02, -0.04))]
+    g = scenes[0]["gaussians"]
+    leaf = {k: t(v).requires_grad_(True) for k, v in g.items() if v is not None}
+    m2 = torch.zeros((P, 3), device=dev, requires_grad=True)
+    rasts, ups = [], []
+    for sc in scenes:
+        cam = sc["cam"]
+        rasts.append(GaussianRasterizer(GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t(sc["bg"]), scale_modifier=1.0,
+            viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=3, campos=t(cam["campos"]), prefiltered=False,
+            debug=False, near_n=cam["znear"], far_n=cam["zfar"], depth_range=sc["depth_range"], use_view_dependent_phase=True)))
+        ups += [t(sc["grads"][k]) for k in ("color", "phasor", "depth", "acc", "depth_distortion")]
+    sc0 = scenes[0]
+
+    def iteration():
+        for v in leaf.values():
+            v.grad = None
+        m2.grad = None
+        outs = [r(means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf["shs"], shs_p=leaf["shs_p"],
+                  scales=leaf["scales"], rotations=leaf["rotations"], phase_offset=sc0["phase_offset"], dc_offset=sc0["dc_offset"]) for r in rasts]
+        torch.autograd.backward([x for o in outs for x in (o[0], o[1], o[2], o[4], o[6])], ups)
+
+    sync = lambda: torch.cuda.synchronize(dev)
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / steps * 1e3
+    eager_ms = timed(iteration)
+    keep = api.no_host_read
+    api.no_host_read = True
+    try:
+        nowait_ms = timed(iteration)
+    finally:
+        api.no_host_read = keep
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        iteration()
+    torch.cuda.current_stream().wait_stream(side)
+    sync()
+    for v in leaf.values():
+        v.grad = None
+    m2.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        iteration()
+    replay_ms = timed(graph.replay)
+    st = [x for x in api.enqueue_status() if x["key"][1:4] == (P, W, H)]
+    return {"what": "two rasterizer calls + backward of a C3-shaped iteration (%d Gaussians, %dx%d, opacity 0.1), ms per iteration" % (P, W, H),
+            "eager_blocking_ms": eager_ms, "eager_no_host_read_ms": nowait_ms, "graph_replay_ms": replay_ms,
+            "speedup_replay_over_eager": eager_ms / replay_ms, "overflow": any(x["overflow"] for x in st)}
+
+
 def views_roofline(stage_ms, P, N, T, R, R_walk):
     """`roofline` object of the varying-view step: dominant stage by HIP events, SURVEY 8(d) bytes x units processed
     (mean instance count / walked entries over the sampled frames; every visible Gaussian charged as P)."""
@@ -1418,7 +1489,7 @@ def main():
             del state, step
             torch.cuda.empty_cache()
             table = [("train_iteration", lambda: train_iteration_extra(dev, scene)), ("render_pair", lambda: pair_extra(dev, scene)),
-                     ("varying_views", lambda: views_extra(dev, scene)), ("fog", lambda: fog_extra(dev)), ("grads_kept", lambda: grads_kept_extra(dev, scene)), ("assemble_inputs", lambda: assemble_extra(dev)),
+                     ("varying_views", lambda: views_extra(dev, scene)), ("fog", lambda: fog_extra(dev)), ("graph_pair", lambda: graph_pair_extra(dev)), ("grads_kept", lambda: grads_kept_extra(dev, scene)), ("assemble_inputs", lambda: assemble_extra(dev)),
                      ("knn", lambda: knn_extra(dev)), ("adam", lambda: adam_extra(dev)), ("deform_network", lambda: deform_extra(dev)),
                      ("densify", lambda: densify_extra(dev))]
             want = None if args.extras == "all" else set(args.extras.split(","))
@@ -1435,6 +1506,9 @@ def main():
                 out["varying_views_it_per_s"] = ex["varying_views"]["it_per_s"]
             if "grads_kept" in ex:
                 out["grads_kept_it_per_s"] = ex["grads_kept"]["it_per_s"]
+            if "graph_pair" in ex:
+                out["c3_pair_eager_ms"] = ex["graph_pair"]["eager_blocking_ms"]
+                out["c3_pair_graph_replay_ms"] = ex["graph_pair"]["graph_replay_ms"]
             if "fog" in ex:
                 out["fog_it_per_s"] = ex["fog"]["it_per_s"]
                 out["fog_ms_per_step"] = ex["fog"]["ms_per_step"]

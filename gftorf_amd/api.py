@@ -15,6 +15,7 @@ streams and autograd plumbing only.  There is no CPU path: tensors must live on
 a HIP device and the library must be built, otherwise this raises.
 """
 import ctypes as C
+import struct as _struct
 from typing import NamedTuple, Optional
 
 import torch
@@ -349,18 +350,18 @@ def _bg_strides(bg, H, W, dev):
         % (tuple(bg.shape),))
 
 
+_CFG_FMT = "=6i8f7i4x3q"       # gft_config field by field (include/gftorf_rast.h); checked against the ctypes struct below
+assert _struct.calcsize(_CFG_FMT) == C.sizeof(_lib.Config)
+
+
 def _make_config(s, P, M, M_p, H, W, phase_offset, dc_offset, bgs, want_backward):
     c = _lib.Config()
-    c.P, c.D, c.M, c.M_p, c.W, c.H = P, int(s.sh_degree), M, M_p, W, H
-    c.tanfovx, c.tanfovy = float(s.tanfovx), float(s.tanfovy)
-    c.scale_modifier = float(s.scale_modifier)
-    c.near_n, c.far_n, c.depth_range = float(s.near_n), float(s.far_n), float(s.depth_range)
-    c.phase_offset, c.dc_offset = phase_offset, dc_offset
-    c.use_view_dependent_phase = int(bool(s.use_view_dependent_phase))
-    c.prefiltered = int(bool(s.prefiltered))
-    c.debug = int(bool(s.debug))
-    c.want_backward = int(bool(want_backward))
-    c.bg_stride_c, c.bg_stride_y, c.bg_stride_x = bgs
+    # (one pack into the struct's buffer instead of twenty-four attribute stores: host time; acc_zeroed, grads_zeroed and
+    # grads_accumulate start at 0)
+    _struct.pack_into(_CFG_FMT, c, 0, P, int(s.sh_degree), M, M_p, W, H, float(s.tanfovx), float(s.tanfovy),
+                      float(s.scale_modifier), float(s.near_n), float(s.far_n), float(s.depth_range), phase_offset, dc_offset,
+                      1 if s.use_view_dependent_phase else 0, 1 if s.prefiltered else 0, 1 if s.debug else 0,
+                      1 if want_backward else 0, 0, 0, 0, bgs[0], bgs[1], bgs[2])
     return c
 
 
@@ -404,6 +405,18 @@ class _Settings(NamedTuple):
 
 
 _PLANE_SPLIT = (3, 7, 1, 3, 1, 1, 1, 1, 3)     # color, phasor, depth, normal, acc, entropy, depth_distortion, amp_distortion, distribution
+_PLANE_FIRST = (0, 3, 10, 11, 14, 15, 16, 17, 18)   # first plane of each output inside the [21, H, W] allocation
+_bw_plans = {}
+_geom_bytes, _image_bytes = {}, {}              # gft_geom_bytes(P), gft_image_bytes(W, H): one library call per size
+_FWD_FMT = "=%dQ" % len(_lib.ForwardIO._fields_)
+_BWD_FMT = "=%dQ" % len(_lib.BackwardIO._fields_)
+assert _struct.calcsize(_FWD_FMT) == C.sizeof(_lib.ForwardIO) and _struct.calcsize(_BWD_FMT) == C.sizeof(_lib.BackwardIO)
+_FWD_AT = {n: i for i, (n, _t) in enumerate(_lib.ForwardIO._fields_)}
+_BWD_AT = {n: i for i, (n, _t) in enumerate(_lib.BackwardIO._fields_)}
+
+
+def _p0(t):
+    return 0 if t is None else t.data_ptr()
 
 
 def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacities, scales, rotations,
@@ -461,22 +474,26 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
     color, phasor, depth, normal, acc, entropy, depth_distortion, amp_distortion, distribution = planes.split(_PLANE_SPLIT)
     radii = torch.empty((P,), device=dev, dtype=torch.int32)
     pixels = torch.empty((P, 1), **f32)
-    geom = torch.empty((lib.gft_geom_bytes(P),), device=dev, dtype=torch.uint8)
-    img = torch.empty((lib.gft_image_bytes(W, H),), device=dev, dtype=torch.uint8)
+    gb = _geom_bytes.get(P)
+    if gb is None:
+        gb = _geom_bytes[P] = int(lib.gft_geom_bytes(P))
+    ib = _image_bytes.get((W, H))
+    if ib is None:
+        ib = _image_bytes[(W, H)] = int(lib.gft_image_bytes(W, H))
+    geom = torch.empty((gb,), device=dev, dtype=torch.uint8)
+    img = torch.empty((ib,), device=dev, dtype=torch.uint8)
 
     cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw)
     io = _lib.ForwardIO()
-    io.bg, io.means3D = _ptr(bg_c), _ptr(means3D_c) if P else None
-    io.colors_precomp, io.phasors_precomp, io.opacities = _ptr(colors_c), _ptr(phasors_c), _ptr(opac_c)
-    io.scales, io.rotations, io.cov3D_precomp = _ptr(scales_c), _ptr(rot_c), _ptr(cov_c)
-    io.viewmatrix, io.projmatrix, io.campos = _ptr(view_c), _ptr(proj_c), _ptr(campos_c)
-    io.shs, io.shs_p = _ptr(sh_c), _ptr(sh_p_c)
-    io.geom, io.img, io.binning = _ptr(geom), _ptr(img), None
-    io.out_color, io.out_phasor, io.out_depth = color.data_ptr(), phasor.data_ptr(), depth.data_ptr()
-    io.out_normal, io.out_acc, io.out_entropy = normal.data_ptr(), acc.data_ptr(), entropy.data_ptr()
-    io.out_depth_distortion, io.out_amp_distortion = depth_distortion.data_ptr(), amp_distortion.data_ptr()
-    io.out_distribution = distribution.data_ptr()
-    io.pixels, io.radii = _ptr(pixels) if P else None, _ptr(radii) if P else None
+    # (the argument block in one pack -- field order of gft_forward_io --, the outputs' addresses from the one allocation
+    # they are planes of: host time; binning, acc, grads_zero, tile_hints follow below)
+    pl, hw4 = planes.data_ptr(), 4 * H * W
+    _struct.pack_into(_FWD_FMT, io, 0,
+                      _p0(bg_c), means3D_c.data_ptr() if P else 0, _p0(colors_c), _p0(phasors_c), _p0(opac_c), _p0(scales_c),
+                      _p0(rot_c), _p0(cov_c), view_c.data_ptr(), proj_c.data_ptr(), campos_c.data_ptr(), _p0(sh_c), _p0(sh_p_c),
+                      geom.data_ptr(), img.data_ptr(), 0,
+                      pl, pl + 3 * hw4, pl + 10 * hw4, pl + 11 * hw4, pl + 14 * hw4, pl + 15 * hw4, pl + 16 * hw4, pl + 17 * hw4,
+                      pixels.data_ptr() if P else 0, pl + 18 * hw4, radii.data_ptr() if P else 0, 0, 0, 0, 0)
     # the backward's accumulator: cleared by the forward beside its binning kernels -- unless it comes from the pool of
     # buffers that the last backward left zero (_AccLease)
     lease = None
@@ -590,7 +607,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
             raise ex
-        assert binning_capacity(binning, W, H) == cap
+    if prep is not None:
+        prep["cap"] = cap
     if lease is not None:
         lease.zero = True          # (cleared by this forward, or zero since its last backward)
 
@@ -623,10 +641,21 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
     M = sh.size(1) if has_sh else 0
     M_p = sh_p.size(1) if has_sh_p else 0
     f32 = dict(device=dev, dtype=torch.float32)
-    shapes = dict(means3D=(P, 3), means2D=(P, 3), opacities=(P, 1), colors=(P, 3) if want_colors else None,
-                  cov3D=(P, 6) if want_cov else None, sh=(P, M, 3) if has_sh else None,
-                  sh_p=(P, M_p, 2) if has_sh_p else None, scales=(P, 3) if has_scales else None,
-                  rotations=(P, 4) if has_scales else None)
+    # (shapes, padded sizes and split of the gradient buffer: the same for every call of a training loop -- computed once)
+    plan_key = (P, M, M_p, want_colors, want_cov, has_sh, has_sh_p, has_scales)
+    plan = _bw_plans.get(plan_key)
+    if plan is None:
+        shapes = dict(means3D=(P, 3), means2D=(P, 3), opacities=(P, 1), colors=(P, 3) if want_colors else None,
+                      cov3D=(P, 6) if want_cov else None, sh=(P, M, 3) if has_sh else None,
+                      sh_p=(P, M_p, 2) if has_sh_p else None, scales=(P, 3) if has_scales else None,
+                      rotations=(P, 4) if has_scales else None)
+        sizes = {k: (_prod(v) + 3) // 4 * 4 for k, v in shapes.items() if v is not None}
+        keys = [k for k, v in shapes.items() if v is not None]
+        if len(_bw_plans) > 64:
+            _bw_plans.clear()
+        plan = _bw_plans[plan_key] = (shapes, sizes, sum(sizes.values()) + 4, keys, [sizes[k] for k in keys] + [4],
+                                      tuple(sorted(sizes.items())), [_prod(shapes[k]) for k in keys])
+    shapes, sizes, total, keys, split_sizes, layout_key, numels = plan
     zero_buf = None
     entry, reused_grads = None, False
     pool_entry = None              # the kept set of gradient tensors this backward writes (or, second view of a pair, adds to)
@@ -640,11 +669,9 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         # offset gradients at its end): ten torch.empty calls less per forward, which at the reference's scene size
         # (100 k Gaussians, 0.1 ms of kernels per call) is host time the device waits for.  With the zero-fill switch
         # the forward clears it beside its binning kernels and the backward writes only the rows of blended Gaussians.
-        sizes = {k: (_prod(v) + 3) // 4 * 4 for k, v in shapes.items() if v is not None}
-        total = sum(sizes.values()) + 4
         entry = None
         if _GRADS_REUSE and pooled and P and pixels is not None and want_bw_records and not zero_fill:
-            key = (dev.index, P, tuple(sorted(sizes.items())))
+            key = (dev.index, P, layout_key)
             pool = _grad_pool.setdefault(key, [])
             if _USE_COUNT_API:
                 # (a buffer somebody wrote to through a tensor -- autograd's in-place sum of two calls' gradients, clipping
@@ -697,13 +724,10 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         if zero_fill:
             zero_buf = buf
         # (one split into the padded pieces, then one view each: host time)
-        keys = [k for k, v in shapes.items() if v is not None]
-        pieces = buf.split([sizes[k] for k in keys] + [4])
+        pieces = buf.split(split_sizes)
         g = dict.fromkeys(shapes)
-        for k, piece in zip(keys, pieces):
-            v = shapes[k]
-            n = _prod(v)
-            g[k] = (piece if n == sizes[k] else piece[:n]).view(v)
+        for k, piece, n in zip(keys, pieces, numels):
+            g[k] = (piece if n == sizes[k] else piece[:n]).view(shapes[k])
         g["offsets"] = pieces[-1][:2]
         if entry is not None and not _USE_COUNT_API:
             entry["held"] = (buf, [t for t in g.values() if t is not None])
@@ -750,31 +774,25 @@ def prepare_backward(s, means3D, opac, sh, sh_p, scales, rotations, cov3D, radii
         # second view of a pair: its rows are added to the first view's tensors and marked in the same array
         entry = dict(dirty=share_grads["dirty"])
     io = _lib.BackwardIO()
-    io.bg, io.means3D, io.radii = _ptr(bg_c), _ptr(means3D) if P else None, _ptr(radii) if P else None
-    io.scales = _ptr(scales) if has_scales else None
-    io.rotations = _ptr(rotations) if has_scales else None
-    io.cov3D_precomp = _ptr(cov3D) if has_cov else None
-    io.viewmatrix, io.projmatrix, io.campos = _ptr(view_c), _ptr(proj_c), _ptr(campos_c)
-    io.shs = _ptr(sh) if has_sh else None
-    io.shs_p = _ptr(sh_p) if has_sh_p else None
-    io.opacities = _ptr(opac) if (P and opac is not None) else None
-    io.pixels = _ptr(pixels) if (P and pixels is not None) else None
-    io.geom, io.img = _ptr(geom), _ptr(img)
-    io.acc = _ptr(acc) if P else None
-    io.dL_dmeans3D, io.dL_dmeans2D = _ptr(g["means3D"]) if P else None, _ptr(g["means2D"]) if P else None
-    io.dL_dcolors, io.dL_dopacity, io.dL_dcov3D = _ptr(g["colors"]), _ptr(g["opacities"]) if P else None, _ptr(g["cov3D"])
-    io.dL_dsh, io.dL_dsh_p = _ptr(g["sh"]), _ptr(g["sh_p"])
-    io.dL_dscales, io.dL_drotations = _ptr(g["scales"]), _ptr(g["rotations"])
     # the two scalar gradients cost a reduction launch: only when the caller optimises an offset (the reference returns
     # None for them otherwise, __init__.py:202-203); the pybind-level route always returns them
-    if getattr(s, "optimize_phase_offset", True) or getattr(s, "optimize_dc_offset", True):
-        io.dL_dphase_offset = g["offsets"].data_ptr()
-        io.dL_ddc_offset = g["offsets"].data_ptr() + 4
-    if entry is not None:
-        # (cfg.grads_zeroed = 3: the backward zeroes the rows the previous one wrote and this one does not, then writes its own)
-        io.dirty_rows = entry["dirty"].data_ptr()
-        if sample and entry.get("report") is not None:
-            io.rows_report = entry["report"].data_ptr()
+    want_off = getattr(s, "optimize_phase_offset", True) or getattr(s, "optimize_dc_offset", True)
+    off_ptr = g["offsets"].data_ptr() if want_off else 0
+    # (cfg.grads_zeroed = 3: the backward zeroes the rows the previous one wrote and this one does not, then writes its own)
+    dirty_ptr = entry["dirty"].data_ptr() if entry is not None else 0
+    report_ptr = entry["report"].data_ptr() if (entry is not None and sample and entry.get("report") is not None) else 0
+    # (the argument block in one pack, field order of gft_backward_io; the upstream gradients, binning and det_partials follow
+    # in run_backward)
+    _struct.pack_into(_BWD_FMT, io, 0,
+                      _p0(bg_c), means3D.data_ptr() if P else 0, radii.data_ptr() if P else 0,
+                      _p0(scales) if has_scales else 0, _p0(rotations) if has_scales else 0, _p0(cov3D) if has_cov else 0,
+                      view_c.data_ptr(), proj_c.data_ptr(), campos_c.data_ptr(), _p0(sh) if has_sh else 0, _p0(sh_p) if has_sh_p else 0,
+                      _p0(opac) if P else 0, _p0(pixels) if P else 0,
+                      0, 0, 0, 0, 0,
+                      geom.data_ptr(), img.data_ptr(), 0, acc.data_ptr() if P else 0,
+                      g["means3D"].data_ptr() if P else 0, g["means2D"].data_ptr() if P else 0, _p0(g["colors"]),
+                      g["opacities"].data_ptr() if P else 0, _p0(g["cov3D"]), _p0(g["sh"]), _p0(g["sh_p"]), _p0(g["scales"]),
+                      _p0(g["rotations"]), off_ptr, off_ptr + 4 if off_ptr else 0, 0, dirty_ptr, report_ptr)
     last_call_stats["grads_reused"] = bool(reused_grads)
     last_call_stats["grads_rows_only"] = bool(rows_only)
     return dict(grads=g, cfg=cfg, io=io, acc=acc, acc_lease=acc_lease, pixels=pixels, zero_buf=zero_buf, dev=dev, P=P, H=H, W=W,
@@ -805,7 +823,9 @@ def run_backward(prep, grads_out, geom, binning, img, debug=False):
     io.dL_dout_depth, io.dL_dout_acc, io.dL_dout_depth_distortion = _ptr(keep[2]), _ptr(keep[3]), _ptr(keep[4])
     io.geom, io.img, io.binning = _ptr(geom), _ptr(img), _ptr(binning)
     det = None
-    cap = binning_capacity(binning, W, H) if P else 0
+    cap = prep.get("cap")              # (known to the forward that made `prep`; else read back from the buffer's size)
+    if cap is None:
+        cap = binning_capacity(binning, W, H) if P else 0
     if _DETERMINISTIC and P and cap:
         # test mode: partial rows per (list entry, quadrant), added in a fixed order (gft_backward_io.det_partials)
         if torch.cuda.is_current_stream_capturing():
