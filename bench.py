@@ -159,6 +159,10 @@ def walked_instances(dev, radii=None):
     ctrl = b["img"][L.img_ctrl:L.img_ctrl + 64].view(torch.int32).cpu().tolist()
     need = b["geom"][L.geom_need:L.geom_need + b["P"]]
     heads = b["img"][L.img_front_len:L.img_front_len + 4 * T].view(torch.int32)
+    # lists that hinted tiles sorted whole: in the pool (behind the T head slots of 2048 ids) and without a tail
+    rng0 = b["img"][L.img_ranges:L.img_ranges + 8 * T].view(torch.int32).reshape(T, 2)[:, 0].long() & 0xffffffff
+    cut = b["img"][L.img_tile_cut:L.img_tile_cut + 4 * T].view(torch.int32)
+    whole_ids = int(heads[(rng0 >= T * 2048) & (cut == -1)].sum().item())
     pull = bool(ctrl[5])          # (Gaussian, supertile) entries: only the tile-pull count pass writes them
     return {"per_tile_deepest": int(tm.max(dim=1).values.sum().item()), "per_quadrant_sum": int(tm.sum().item()),
             "tile_pull": pull,
@@ -166,11 +170,11 @@ def walked_instances(dev, radii=None):
             "gaussians_with_appearance": int((need != 0).sum().item()) if pull else None,
             # bookkeeping of that forward (ctrl words, gft_internal.h): entries dealt to supertiles, ids sorted into list
             # heads, quadrants that walked past their head, ids in the lists that were completed for them
-            # (ctrl[8]: ids of the lists that hinted tiles sorted whole -- they lie in the pool like the completed lists and are
-            # counted in ctrl[6] as well as in the tiles' sorted lengths: taken out of the completed ones here)
+            # (the lists that hinted tiles sorted whole lie in the pool like the completed ones and are counted in ctrl[6] as well
+            # as in the tiles' sorted lengths: taken out of the completed ones here)
             "supertile_entries": ctrl[5] if pull else None, "head_ids": int(heads.sum().item()) if pull else None,
-            "flagged_quadrants": ctrl[4], "completed_list_ids": (ctrl[6] - ctrl[8]) if pull else None,
-            "whole_list_ids": ctrl[8] if pull else None}
+            "flagged_quadrants": ctrl[4], "completed_list_ids": (ctrl[6] - whole_ids) if pull else None,
+            "whole_list_ids": whole_ids if pull else None}
 
 
 def build_scene(workload, rank, world):

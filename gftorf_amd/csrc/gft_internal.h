@@ -73,7 +73,6 @@ struct BinView {
 #define GFT_CTRL_ENTRIES 5   // tile-pull binning: (Gaussian, supertile) entries
 #define GFT_CTRL_POOLCUR 6   // tile-pull binning: ids taken from the pool of completed lists
 #define GFT_CTRL_DONE2 7     // finished workgroups of k_tail_build (ticket for the backward's tile order)
-#define GFT_CTRL_WHOLEIDS 8  // tile-pull binning: ids of the lists that hinted tiles sorted whole (they lie in the pool: part of POOLCUR)
 #define GFT_CTRL_RSUM 9      // tile-pull binning: R as summed by the supertile count pass
 #define GFT_CTRL_ORDER_OK 11 // the forward computed the backward's heavy-first tile order
 #define GFT_CTRL_WORDS 16

@@ -43,8 +43,8 @@
 namespace {
 
 #define TPULL_KEYS GFT_HEAD_SLOT    // keys of a head / a chunk that may have to go through a sorting network (16 KB of LDS)
-#define TPULL_KEYS_BIG 3072u        // keys of a chunk of a whole list whose bins are all small (placed by cursors, never by a network): 24 KB
-                                    // (five workgroups per CU is what the kernel's registers allow: 5 x 28.6 KB of LDS fit)
+#define TPULL_KEYS_BIG 3328u        // keys of a chunk of a whole list whose bins are all small (placed by cursors, never by a network): 26 KB
+                                    // (five workgroups per CU is what the kernel's registers allow: 5 x 30.8 KB of LDS fit the CU's 160 KB)
 #define HEAD_DIRECT GFT_HEAD_DIRECT  // lists (scanned hits) up to this length are sorted whole: a sparse frame (the reference's
                                     // 100 k Gaussians at 320x240: ~1450 instances per tile, low opacities) saturates nowhere, every
                                     // quadrant of a tile with a tail would flag and every list be completed in a second pass
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
                 // grouped placement: a key goes to the next free place of its depth bin
                 uint32_t d4[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) d4[u] = __float_as_uint(a.depth[hit[u] ? (uint32_t)e4[u] : 0u]);
+                for (int u = 0; u < 4; u++) d4[u] = (a.dbg & 32) ? (uint32_t)e4[u] : __float_as_uint(a.depth[hit[u] ? (uint32_t)e4[u] : 0u]);
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (!hit[u]) continue;
@@ -502,8 +502,10 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
     uint32_t start = (uint32_t)tile * GFT_HEAD_SLOT;
     if (whole) {
         if (tid == 0) {
-            s_pool = atomicAdd(&a.ctrl[GFT_CTRL_POOLCUR], n);
-            atomicAdd(&a.ctrl[GFT_CTRL_WHOLEIDS], n);
+            // (ONE returning atomic: the frame's tiles arrive here together and queue on the counter's cache line, ~10 ns each --
+            // a second counter beside it, kept for statistics, doubled the 10 us the last of 1200 tiles waits)
+            if (a.dbg & 256) s_pool = 0;      // (timing experiment, with the sorters cut off: nobody writes or reads the ids)
+            else s_pool = atomicAdd(&a.ctrl[GFT_CTRL_POOLCUR], n);
         }
         __syncthreads();
         start = a.pool_base + s_pool;
@@ -631,8 +633,8 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
         }
         __syncthreads();
         // these Gaussians get an appearance (k_appearance): marked here, where only LDS work and stores follow
-        for (uint32_t i = tl; i < c; i += GFT_BLOCK) a.need[(uint32_t)sk[i]] = 1;
-        if (done == 0u) clear_slice();
+        if (!(a.dbg & 64)) for (uint32_t i = tl; i < c; i += GFT_BLOCK) a.need[(uint32_t)sk[i]] = 1;
+        if (done == 0u && !(a.dbg & 128)) clear_slice();
         uint32_t* __restrict__ ids = list + done;
         if (c == 0u || (a.dbg & 15) == 5) {
         } else if (grouped) {
