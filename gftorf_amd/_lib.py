@@ -76,12 +76,12 @@ class Layout(C.Structure):
 
 class ForwardHints(C.Structure):
     """gft_forward_hints"""
-    _fields_ = [("binning_instances", C.c_int64), ("max_tile_list", C.c_int64)]
+    _fields_ = [("binning_instances", C.c_int64), ("max_tile_list", C.c_int64), ("whole_lists", C.c_int64)]
 
 
 class ForwardReport(C.Structure):
     """gft_forward_report"""
-    _fields_ = [("num_rendered", C.c_int64), ("max_tile_list", C.c_int64), ("list_entries", C.c_int64)]
+    _fields_ = [("num_rendered", C.c_int64), ("max_tile_list", C.c_int64), ("list_entries", C.c_int64), ("hinted_tiles", C.c_int64)]
 
 
 class Profile(C.Structure):

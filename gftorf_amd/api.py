@@ -77,6 +77,19 @@ _HINT_HEADROOM = 1.25
 # 4 bytes per tile and are never freed (a kernel of an earlier call may still read or write them).
 _TILE_HINTS = _os.environ.get("GFT_TILE_HINTS", "1") != "0"
 _tile_hints = {}
+# ... and how many tiles the schedule marked when the shape's last frame read it (gft_forward_report.hinted_tiles): from a
+# sixteenth of the tiles on the next forward runs the build of the pull kernel that sorts hinted tiles' whole lists
+# (gft_forward_hints.whole_lists) -- fewer are served as well by the heads-only build, which keeps seven workgroups per CU,
+# and the on-demand completion of their lists
+_hinted_tiles = {}
+_WHOLE_SHARE = 16
+_force_whole_lists = None      # tests: True / False overrides the choice of the build
+
+
+def _whole_lists(key, n_tiles):
+    if _force_whole_lists is not None:
+        return int(bool(_force_whole_lists))
+    return int(_hinted_tiles.get(key, 0) * _WHOLE_SHARE >= n_tiles)
 
 
 # The forward without a host read (gft_forward_enqueue): taken automatically while the current stream is being captured into
@@ -531,6 +544,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         hint_key = (dev.index, P, W, H) if not hint_slot else (dev.index, P, W, H, hint_slot)
         hint, list_hint = _instance_hint.get(hint_key, (None, 0))
         # (a schedule buffer made during a capture would live in the graph's private pool: only one that exists already)
+        n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
         tile_hints = _tile_hints.get(hint_key) if capturing else _tile_hint_buffer(hint_key, dev, W, H)
         io.tile_hints = _ptr(tile_hints)
         try:
@@ -549,6 +563,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                         # the posting of the shape's previous no-host-read frame (its kernels are long done)
                         prev_R, prev_cap = int(a[0]), int(st["cap"])
                         a[3] = 0
+                        _hinted_tiles[hint_key] = int(a[8])
                         if a[1] & 1:
                             raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
                         prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
@@ -561,7 +576,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
-                    hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1)
+                    hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
+                                              whole_lists=_whole_lists(hint_key, n_tiles))
                     _lib.check(lib.gft_forward_enqueue(stream, C.byref(cfg), C.byref(io), C.byref(hints), st["dev"].data_ptr()))
                     st["cap"] = cap
                     st["host"].copy_(st["dev"], non_blocking=True)
@@ -584,10 +600,12 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
-                    hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1)
+                    hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
+                                              whole_lists=_whole_lists(hint_key, n_tiles))
                     report = _lib.ForwardReport()
                     _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), C.byref(hints), C.byref(report)))
                     R = int(report.num_rendered)
+                    _hinted_tiles[hint_key] = int(report.hinted_tiles)
                     max_list.value = int(report.max_tile_list)
                     if R > cap:
                         restarted = True

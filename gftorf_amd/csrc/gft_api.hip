@@ -469,7 +469,9 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
         if (pull) {
             BinView none;
             none.keys = nullptr; none.point_list = nullptr;
-            GFT_STAGE(s, cfg, "super_count", gft_launch_super_bin(s, *cfg, g, im, none, mail_dev, seq, 0, 0u));
+            const int T = ((cfg->W + GFT_TILE_X - 1) / GFT_TILE_X) * ((cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y);
+            GFT_STAGE(s, cfg, "super_count", gft_launch_super_bin(s, *cfg, g, im, none, mail_dev, seq, 0, 0u,
+                                                                  gft_fwd_segmented(T) ? nullptr : io->tile_hints));
         } else {
             GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im, mail_dev, seq));
         }
@@ -481,7 +483,7 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
 // count against it and do nothing on overflow.
 static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
                           const ImgView& im, const BinView& b, bool binned, int64_t max_tile_list, bool check_cap,
-                          uint32_t cap, bool pull)
+                          uint32_t cap, bool pull, bool whole_lists)
 {
     // The backward's accumulator clear (64 B per Gaussian of pure HBM writes) rides along with the
     // per-tile sort kernels, whose workgroups are bound by LDS and VALU: each writes a slice of zeros first.
@@ -500,8 +502,8 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
             StageTimer t(s, ST_TILE_SORT);
             // (no schedule on frames whose forward blend is segment-parallel: see gft_launch_render_fwd)
             const int T = ((cfg->W + GFT_TILE_X - 1) / GFT_TILE_X) * ((cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y);
-            GFT_STAGE(s, cfg, "tile_pull", gft_launch_tile_pull(s, *cfg, g, im, b, cap, clear, clear_bytes,
-                                                                gft_fwd_segmented(T) ? nullptr : io->tile_hints));
+            const uint32_t* th = gft_fwd_segmented(T) ? nullptr : io->tile_hints;
+            GFT_STAGE(s, cfg, "tile_pull", gft_launch_tile_pull(s, *cfg, g, im, b, cap, clear, clear_bytes, th, whole_lists && th));
         }
         {
             StageTimer t(s, ST_PRE_FWD);
@@ -598,7 +600,9 @@ extern "C" int gft_forward_render(void* hip_stream, const gft_config* cfg, const
         GFT_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s));
         if (cfg->P == 0) GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, GFT_CTRL_WORDS * sizeof(uint32_t), s));
     }
-    return enqueue_stage2(s, cfg, io, g, im, b, R > 0, max_tile_list, cfg->P > 0, (uint32_t)R, pull);
+    // (two stages: the first frame of a shape, a frame that outgrew its buffer, a caller that drives the C ABI itself -- the
+    // build of k_tile_pull that honours a schedule whenever one is handed over)
+    return enqueue_stage2(s, cfg, io, g, im, b, R > 0, max_tile_list, cfg->P > 0, (uint32_t)R, pull, io->tile_hints != nullptr);
 }
 
 // ---- forward, one call ------------------------------------------------------------
@@ -631,7 +635,7 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     }
     // stage 2 is queued before R is known; its kernels check R against the buffer themselves
     const uint32_t cap = (uint32_t)binning_instances;
-    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, cap, pull))
+    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, cap, pull, hints->whole_lists != 0))
         return 1;
     uint32_t host[GFT_CTRL_WORDS];
     if (mailbox_wait(s, mail_host, seq, host)) return 1;
@@ -640,6 +644,7 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     report->num_rendered = (int64_t)host[GFT_CTRL_TOTAL];
     report->max_tile_list = (int64_t)host[GFT_CTRL_MAXCNT];
     report->list_entries = pull ? (int64_t)host[GFT_CTRL_ENTRIES] : (int64_t)host[GFT_CTRL_TOTAL];
+    report->hinted_tiles = pull ? (int64_t)host[GFT_CTRL_NHINT] : 0;
     // The hint said "no tile list longer than the short-sort limit" and the frame has one: its
     // tiles were rendered unsorted.  Sort them and render again (the contributing-pixel counters
     // are the only accumulated output).
@@ -689,7 +694,8 @@ extern "C" int gft_forward_enqueue(void* hip_stream, const gft_config* cfg, cons
         const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
         GFT_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s));
     }
-    return enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, (uint32_t)binning_instances, pull);
+    return enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, (uint32_t)binning_instances, pull,
+                          hints->whole_lists != 0);
 }
 
 // ---- backward -----------------------------------------------------------------

@@ -73,6 +73,7 @@ struct BinView {
 #define GFT_CTRL_ENTRIES 5   // tile-pull binning: (Gaussian, supertile) entries
 #define GFT_CTRL_POOLCUR 6   // tile-pull binning: ids taken from the pool of completed lists
 #define GFT_CTRL_DONE2 7     // finished workgroups of k_tail_build (ticket for the backward's tile order)
+#define GFT_CTRL_NHINT 8     // tile-pull binning: non-zero words of the caller's per-tile schedule (gft_forward_io.tile_hints), also in the mailbox
 #define GFT_CTRL_RSUM 9      // tile-pull binning: R as summed by the supertile count pass
 #define GFT_CTRL_ORDER_OK 11 // the forward computed the backward's heavy-first tile order
 #define GFT_CTRL_WORDS 16
@@ -173,9 +174,9 @@ bool gft_tile_pull_ok(const gft_config& c);      // the frame's tile grid fits t
 struct SuperShape { int gx, gy, T, sshift, sgx, sgy, NS, K, kshift; uint32_t near_bits; int bin_shift; };
 SuperShape gft_super_shape(const gft_config& c);
 hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
-                                uint32_t* mail, uint32_t seq, int pass, uint32_t cap);
+                                uint32_t* mail, uint32_t seq, int pass, uint32_t cap, const uint32_t* hints = nullptr);
 hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
-                                uint32_t cap, float* clear, size_t clear_bytes, const uint32_t* hints);
+                                uint32_t cap, float* clear, size_t clear_bytes, const uint32_t* hints, bool whole_lists);
 hipError_t gft_launch_tail_build(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
                                  const ImgView& im, const BinView& b, uint32_t cap, bool want_order);
 // lazy: 0 = lists sorted whole, 1 = first pass over the sorted heads, 2 = resume pass of the flagged quadrants

@@ -80,6 +80,7 @@ struct SuperArgs {
     uint32_t* ctrl;
     uint32_t* mail; uint32_t seq;
     uint32_t cap;
+    const uint32_t* __restrict__ hints;      // pass 0: the caller's per-tile schedule (may be NULL): its non-zero words are counted for the host
 };
 
 template <int PASS>      // 0: count (+ R, mailbox), 1: scatter
@@ -214,15 +215,28 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
             if (tid == BIN_THREADS - 1) s_carry = carry + woff + x;
             __syncthreads();
         }
+        // tiles the schedule marks (as the previous frame of the shape left it): the host picks the next frame's build of
+        // k_tile_pull by it
+        uint32_t nh = 0;
+        if (a.hints) {
+            for (int t = tid; t < a.sh.T; t += BIN_THREADS) nh += a.hints[t] != 0u ? 1u : 0u;
+            nh = gft_wave_sum_u32_to_lane63(nh);
+            if (tid == 0) s_sum = 0;
+            __syncthreads();
+            if (lane == 63 && nh) atomicAdd(&s_sum, nh);
+            __syncthreads();
+        }
         if (tid == 0) {
             const uint32_t R = __hip_atomic_load(&a.ctrl[GFT_CTRL_RSUM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.ctrl[GFT_CTRL_TOTAL] = R;
             a.ctrl[GFT_CTRL_ENTRIES] = s_carry;
             a.ctrl[GFT_CTRL_MAXCNT] = 0u;              // (the tile lists are never formed)
+            a.ctrl[GFT_CTRL_NHINT] = a.hints ? s_sum : 0u;
             if (a.mail) {
                 a.mail[GFT_CTRL_TOTAL] = R;            // (GFT_CTRL_FLAGS of the slot belongs to the preprocess kernel)
                 a.mail[GFT_CTRL_MAXCNT] = 0u;
                 a.mail[GFT_CTRL_ENTRIES] = s_carry;
+                a.mail[GFT_CTRL_NHINT] = a.hints ? s_sum : 0u;
                 __hip_atomic_store(&a.mail[GFT_CTRL_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -298,13 +312,18 @@ __device__ __forceinline__ bool pull_tile_of_block(const SuperShape& sh, int b, 
     return true;
 }
 
-// (five waves per SIMD keep a 1200-tile frame resident in one round; left alone the allocator takes 97 registers: four)
-__global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_tile_pull(PullArgs a)
+// Two builds of one kernel.  WHOLE = false: heads only (no schedule is read): 20.5 KB of LDS and few registers, seven
+// workgroups per CU -- what a frame without hinted tiles runs (the 8160 tiles of a 1080p frame take 184 us with it, 220 with
+// the other build).  WHOLE = true: hinted tiles sort their whole lists, in chunks: 30.8 KB, 96 registers (five waves per
+// SIMD keep a 1200-tile frame resident in one round; left alone the allocator takes 97: four).  Which one a frame runs is
+// the caller's schedule (gft_forward_hints.whole_lists, from the count of hinted tiles the previous frame reported).
+template <bool WHOLE>
+__global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(WHOLE ? 5 : 7, 8))) void k_tile_pull(PullArgs a)
 {
     // the depth-bin histogram of pass A and the keys of pass B share 16 KB of LDS (the histogram is done with once the head
     // is chosen): nine workgroups per CU instead of four -- a frame's tiles are resident in one round
-    __shared__ uint64_t sk[SORT_SLOTS(TPULL_KEYS_BIG)];
-    static_assert(sizeof(uint64_t) * SORT_SLOTS(TPULL_KEYS_BIG) >= sizeof(uint32_t) * GFT_DEPTH_BINS, "histogram fits the key buffer");
+    __shared__ uint64_t sk[SORT_SLOTS(WHOLE ? TPULL_KEYS_BIG : TPULL_KEYS)];
+    static_assert(sizeof(uint64_t) * SORT_SLOTS(TPULL_KEYS) >= sizeof(uint32_t) * GFT_DEPTH_BINS, "histogram fits the key buffer");
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(sk);
     __shared__ uint32_t s_n, s_cut, s_kf, s_gmax, s_gmax2, s_bmin, s_bmax, s_pool;
     __shared__ uint32_t s_wt[GFT_BLOCK / 64];
@@ -329,7 +348,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
     uint32_t lx, ly;
     if (!pull_tile_of_block(a.sh, (int)blockIdx.x, tile, q, lx, ly)) { clear_slice(); return; }
     const int K = a.sh.K;
-    const bool hinted = (a.dbg & 16) || (a.hints != nullptr && a.hints[tile] != 0u);      // uniform over the workgroup
+    const bool hinted = WHOLE && ((a.dbg & 16) || (a.hints != nullptr && a.hints[tile] != 0u));      // uniform over the workgroup
     for (int i = tid; i < GFT_DEPTH_BINS; i += GFT_BLOCK) s_hist[i] = 0;
     if (tid == 0) s_n = 0;
     __syncthreads();
@@ -380,7 +399,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
                     const uint32_t b = (entry_bin(e4[u]) - win_base) >> cshift;
                     const uint32_t w = atomicAdd(&s_cur[b >> 1], (b & 1u) ? 0x10000u : 1u);
                     const uint32_t pos = ((b & 1u) ? (w >> 16) : w) & pmask;
-                    if (pos < TPULL_KEYS_BIG) sk[pos] = ((uint64_t)d4[u] << 32) | (uint32_t)e4[u];
+                    if (pos < (WHOLE ? TPULL_KEYS_BIG : TPULL_KEYS)) sk[pos] = ((uint64_t)d4[u] << 32) | (uint32_t)e4[u];
                 }
                 continue;
             }
@@ -448,7 +467,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
     // keys each (a chunk is one placement: cursors of 11 bits) -- unless a single bin holds more than 255 keys (the bin
     // counts are then carried as bytes): such a tile takes the lazy route, whose tail builder sorts anything.
     bool whole = hinted && n > HEAD_DIRECT;
-    if (whole) {
+    if (WHOLE && whole) {
         uint32_t gm = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++) gm = max(gm, h[k]);
@@ -500,7 +519,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
     // the wave's loads) and where its ids go: the tile's head slot, or -- a whole list -- n ids of the pool (over all
     // tiles the pool holds R >= every list it can be asked for)
     uint32_t start = (uint32_t)tile * GFT_HEAD_SLOT;
-    if (whole) {
+    if (WHOLE && whole) {
         if (tid == 0) {
             // (ONE returning atomic: the frame's tiles arrive here together and queue on the counter's cache line, ~10 ns each --
             // a second counter beside it, kept for statistics, doubled the 10 us the last of 1200 tiles waits)
@@ -526,13 +545,13 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
     uint32_t done = 0, lo = 0;
     for (;;) {
         uint32_t hi = first_tail, c = kf;
-        // (the thread id and the packed bin counts behind an opaque move: everything the loop body derives from them -- bin
+        // (WHOLE: the thread id and the packed bin counts behind an opaque move: everything the loop body derives from them -- bin
         // numbers, unpacked counts, dozens of LDS addresses of the sorters -- would otherwise be computed once in front of the
         // loop and kept in registers across it: 205 of them, two waves per SIMD)
         int tl = tid;
-        asm volatile("" : "+v"(tl), "+v"(hp[0]), "+v"(hp[1]), "+v"(hp[2]), "+v"(hp[3]));
+        if (WHOLE) asm volatile("" : "+v"(tl), "+v"(hp[0]), "+v"(hp[1]), "+v"(hp[2]), "+v"(hp[3]));
         const int ll = tl & 63;
-        if (whole) {
+        if (WHOLE && whole) {
             // the thread whose sixteen bins hold the crossing finds the bin (every bin alone fits)
             if (tl == 0) { s_cut = GFT_DEPTH_BINS; s_kf = n - done; }
             __syncthreads();
@@ -673,7 +692,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)
             bitonic_blocked<3, 8>(sk, tl);
             for (uint32_t i = (uint32_t)tl; i < c; i += GFT_BLOCK) ids[i] = (uint32_t)sk[sort_slot(i)];
         }
-        if (!whole) break;
+        if (!WHOLE || !whole) break;
         done += c;
         lo = hi;
         if (done >= n) break;
@@ -966,9 +985,10 @@ bool gft_tile_pull_ok(const gft_config& c) { return gft_super_shape(c).sshift <=
 
 // pass 0: count (+ R, mailbox); pass 1: scatter of the entries to their (supertile, slab) lists
 hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
-                                uint32_t* mail, uint32_t seq, int pass, uint32_t cap)
+                                uint32_t* mail, uint32_t seq, int pass, uint32_t cap, const uint32_t* hints)
 {
     SuperArgs a;
+    a.hints = pass == 0 ? hints : nullptr;
     a.P = c.P;
     a.sh = gft_super_shape(c);
     a.rect = g.rect; a.depth = g.depth;
@@ -995,7 +1015,7 @@ hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomVi
 }
 
 hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
-                                uint32_t cap, float* clear, size_t clear_bytes, const uint32_t* hints)
+                                uint32_t cap, float* clear, size_t clear_bytes, const uint32_t* hints, bool whole_lists)
 {
     PullArgs a;
     a.sh = gft_super_shape(c);
@@ -1011,7 +1031,8 @@ hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomVi
     a.dbg = dbg;
     if ((dbg & 15) == 4) { a.clear = nullptr; a.dbg = dbg & 16; }     // (+16: every tile counts as hinted)
     const int Np = a.sh.NS << (2 * a.sh.sshift);
-    hipLaunchKernelGGL(k_tile_pull, dim3(8 * ((Np + 7) / 8)), dim3(GFT_BLOCK), 0, s, a);
+    if (whole_lists || (a.dbg & 16)) hipLaunchKernelGGL(k_tile_pull<true>, dim3(8 * ((Np + 7) / 8)), dim3(GFT_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(k_tile_pull<false>, dim3(8 * ((Np + 7) / 8)), dim3(GFT_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

@@ -316,6 +316,11 @@ int gft_forward_render(void* hip_stream, const gft_config* cfg,
 typedef struct gft_forward_hints {
     int64_t binning_instances;   /* instances `io->binning` holds (the caller's guess of R plus headroom) */
     int64_t max_tile_list;       /* whole-frame binning without the lazy sort: guess of the longest per-tile list (<= 0 = unknown) */
+    int64_t whole_lists;         /* tile-pull binning with io->tile_hints: non-zero = run the build of the pull kernel that sorts hinted
+                                  * tiles' whole lists (30.8 KB of LDS, five workgroups per CU); 0 = the heads-only build (20.5 KB, seven
+                                  * per CU), which ignores the schedule.  A caller sets it when the previous frame of the shape
+                                  * reported enough hinted tiles (gft_forward_report.hinted_tiles; api.py: a sixteenth of the tiles) --
+                                  * a schedule like the hints themselves: results do not depend on it */
 } gft_forward_hints;
 
 /* What the device reported while the forward was running. */
@@ -323,6 +328,7 @@ typedef struct gft_forward_report {
     int64_t num_rendered;        /* R, the number of (Gaussian, tile) instances of the frame (reference: num_rendered) */
     int64_t max_tile_list;       /* longest per-tile list (whole-frame binning; 0 with tile-pull binning) */
     int64_t list_entries;        /* entries that were scattered: (Gaussian, supertile) pairs with tile-pull binning, else R */
+    int64_t hinted_tiles;        /* non-zero words of io->tile_hints as this frame found them (tile-pull binning; else 0) */
 } gft_forward_report;
 
 /* The forward in one call, for callers that can guess R (a training loop: R of the
@@ -344,7 +350,7 @@ int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* i
  * GFT_STATUS_WORDS uint32 of pinned host memory or device memory owned by the caller (may be NULL), cleared by this call
  * on the stream and written when stage 1 ends: status[0] = R (num_rendered), status[1] bit 0 = "prefiltered point was
  * culled" (the reference's error, rasterizer_impl.cu: trap), status[2] = longest tile list (whole-frame binning),
- * status[3] = 1 once posted, status[5] = list entries.  If R > hints->binning_instances the stage-2 kernels have done
+ * status[3] = 1 once posted, status[5] = list entries, status[8] = hinted tiles.  If R > hints->binning_instances the stage-2 kernels have done
  * nothing (they compare the count on the device): the outputs of that frame are undefined and the caller, reading
  * `status` once the stream has passed (in front of its next call, say), renders again with a larger buffer.  Same kernels,
  * same results as gft_forward().  cfg->debug is refused (it synchronises). */

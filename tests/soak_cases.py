@@ -44,6 +44,8 @@ def run_case(case, dev, oracle, rng):
     scene = Hh.small_scene(P=P, W=c["W"], H=c["H"], seed=c["seed"], D=c["D"], sh_coeffs=c["M"], scale_lo=0.01, scale_hi=c["scale_hi"],
                            tof=c["tof"], opacity=c["opacity"], w2c="tilted" if c["tilted"] else None)
     keep = (api._TILE_HINTS, api._GRADS_REUSE, api._USE_COUNT_API, api._ACC_REUSE)
+    # (the build of the pull kernel that honours the schedule, whenever the case hands one over; "keep": the operator's choice)
+    api._force_whole_lists = True if c["hints"] in ("ones", "random") else None
     lib.gft_set_binning_mode(c["bin_mode"])
     lib.gft_set_render_mode(c["render_mode"])
     edge_flips = flip_cases = 0
@@ -116,6 +118,7 @@ def run_case(case, dev, oracle, rng):
         if api._USE_COUNT_API != keep[2]:
             api._grad_pool.clear()
         api._TILE_HINTS, api._GRADS_REUSE, api._USE_COUNT_API, api._ACC_REUSE = keep
+        api._force_whole_lists = None
     return edge_flips, flip_cases
 
 

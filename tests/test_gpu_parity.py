@@ -733,20 +733,24 @@ def test_tile_hints_do_not_change_results(name, oracle, gpu):
         finally:
             api._TILE_HINTS = keep
         api._tile_hints.clear()
-        for frame in range(5):
-            if frame >= 2:
-                # frames 0, 1: the schedule as the operator builds it; then forced: all ones, random, random
+        api._hinted_tiles.clear()
+        for frame in range(7):
+            if frame >= 3:
+                # frames 0 - 2: the schedule and the choice of the pull kernel's build as the operator makes them; then forced:
+                # all ones, random, random with the whole-list build, random with the heads-only build (which ignores it)
                 for hbuf in api._tile_hints.values():
-                    if frame == 2:
+                    if frame == 3:
                         hbuf.fill_(0x01010101)
                     else:
                         hbuf.copy_(torch.tensor(rng.integers(0, 2, hbuf.numel()), dtype=torch.int32))
+                api._force_whole_lists = frame != 6
             out, grads, _ = Hh.run_gpu(scene, gpu)
             for k in ref_out:
                 np.testing.assert_array_equal(out[k], ref_out[k], err_msg="%s frame %d" % (k, frame))
             for k in ref_grads:
                 if ref_grads[k] is not None:
                     Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
+    api._force_whole_lists = None
     f, b = Hh.run_oracle(oracle, scene)
     check_outputs(f, out)
     check_grads(b, grads, scene)
