@@ -40,6 +40,9 @@ WORKLOADS = {
     # Gaussian at 0.1), so no pixel saturates, every tile list is walked whole and most visible Gaussians are blended
     "fog": dict(P=1_000_000, W=640, H=480, D=3, sh_coeffs=16, tof=True, opacity_range=(0.05, 0.1),
                 label="fog: 1M Gaussians with opacity 0.05-0.1 (nothing saturates), 640x480, SH deg 3, RGB+ToF phasor, forward+backward"),
+    # ... and the same regime at the largest shape: 8160 tiles with lists of ~9000 entries, every one walked whole
+    "C5fog": dict(P=5_000_000, W=1920, H=1080, D=3, sh_coeffs=16, tof=True, opacity_range=(0.05, 0.1),
+                  label="C5 fog: 5M Gaussians with opacity 0.05-0.1 (nothing saturates), 1920x1080, SH deg 3, RGB+ToF phasor, forward+backward"),
     "clustered": dict(P=1_000_000, W=640, H=480, D=3, sh_coeffs=16, tof=True, cluster=0.4,
                       label="1M Gaussians concentrated at the image centre, 640x480 (load-balance check)"),
     "tiny": dict(P=20_000, W=256, H=256, D=3, sh_coeffs=16, tof=True,

@@ -1,6 +1,8 @@
 """Full-size GPU checks (BASELINE.json configs): parity against the oracle where the oracle
 finishes in seconds on the GPU box's host cores, and size-independent properties at the
 largest shapes."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -103,8 +105,11 @@ def test_c1_10k_256_deg0_rgb_forward_vs_oracle(oracle, gpu):
 def test_fog_1m_vs_oracle(oracle, gpu):
     """The metric frame in the regime the reference's scenes start in (opacity 0.05-0.1, arguments/__init__.py:99): no pixel
     saturates, every tile list (~3000 entries) is walked whole by forward and backward, most visible Gaussians are blended
-    -- lists behind the sorted heads are completed for every tile.  Forward + backward against the oracle at full size."""
-    from gftorf_amd import api
+    -- lists behind the sorted heads are completed for every tile.  Forward + backward against the oracle at full size, over
+    four frames: the first two complete every list on demand (no schedule yet; then one the heads-only build of the pull kernel
+    ignores), from the third on every tile sorts its whole list up front (gft_forward_io.tile_hints + the whole-list build)
+    and no quadrant flags."""
+    from gftorf_amd import _lib, api
     sc = _scene("fog")
     assert float(sc["gaussians"]["opacities"].max()) <= 0.1
     f, b = Hh.run_oracle(oracle, sc)
@@ -112,9 +117,17 @@ def test_fog_1m_vs_oracle(oracle, gpu):
     assert float((f.pixels[vis] > 0).mean()) > 0.8                 # most visible Gaussians are blended by some pixel
     assert float(f.img["final_T"].min()) > 1e-4                     # ... and nothing saturates
     api._instance_hint.clear()
-    for frame in range(2):
+    api._tile_hints.clear()
+    api._hinted_tiles.clear()
+    keep = api.keep_last_buffers
+    api.keep_last_buffers = True
+    flagged = []
+    for frame in range(4):
         out, grads, _ = Hh.run_gpu(sc, gpu, optimize_offsets=True)
         assert api.last_call_stats["num_rendered"] == f.num_rendered
+        bufs = api.last_call_buffers
+        L = _lib.get_layout(bufs["P"], bufs["W"], bufs["H"], bufs["cap"])
+        flagged.append(int(bufs["img"][L.img_ctrl:L.img_ctrl + 64].view(torch.int32)[4].item()))
         np.testing.assert_array_equal(out["radii"], f.radii)
         for k in ["color", "phasor", "depth", "acc", "depth_distortion"]:
             l1 = float(np.abs(out[k].astype(np.float64) - f[k]).mean())
@@ -129,6 +142,10 @@ def test_fog_1m_vs_oracle(oracle, gpu):
             Hh.assert_close(name, ref, got, rtol_max=5e-4, atol=1e-6, frac_bad=1e-5)
         Hh.assert_close("phase_offset", b["dL_dphase_offset"], grads["phase_offset"], rtol_max=1e-3, atol=1e-3)
         Hh.assert_close("dc_offset", b["dL_ddc_offset"], grads["dc_offset"], rtol_max=1e-3, atol=1e-3)
+    api.keep_last_buffers = keep
+    api.last_call_buffers.clear()
+    if _lib.load().gft_lazy_sort() and _lib.load().gft_binning_mode(C.byref(_lib.Config(P=1, W=640, H=480))):
+        assert flagged[0] > 4000 and flagged[1] > 4000 and flagged[2] == 0 and flagged[3] == 0, flagged
 
 
 def test_c5_5m_1080p_vs_oracle(oracle, gpu):
@@ -160,6 +177,53 @@ def test_c5_5m_1080p_vs_oracle(oracle, gpu):
         Hh.assert_close("phase_offset", b["dL_dphase_offset"], grads["phase_offset"], rtol_max=1e-3, atol=1e-3)
         Hh.assert_close("dc_offset", b["dL_ddc_offset"], grads["dc_offset"], rtol_max=1e-3, atol=1e-3)
         del out, grads
+
+
+def test_c5_fog_whole_lists_equal_lists_completed_on_demand(gpu):
+    """5 M Gaussians @ 1920x1080 at opacity 0.05-0.1: 8160 tiles with lists of ~9000 entries of which no pixel saturates.
+    The per-tile schedule's two routes at that size -- every list completed on demand (heads-only build of the pull kernel,
+    4 depth slabs per supertile of 4 x 4 tiles, `k_tail_build`, resume pass) and every list sorted whole up front (the
+    whole-list build: chunks of whole depth bins over all slabs, the pool filled by 8160 tiles) -- give the same frame bit
+    for bit and the same gradients up to the order of their sums."""
+    from gftorf_amd import _lib, api
+    if not _lib.load().gft_lazy_sort():
+        pytest.skip("GFT_LAZY_SORT=0: whole-frame binning only")
+    cfg = dict(synth.CONFIGS["C5"], opacity_range=(0.05, 0.1))
+    sc = synth.make_scene(cfg, seed=1234)
+    W, H = cfg["W"], cfg["H"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    api._instance_hint.clear()
+    api._tile_hints.clear()
+    api._hinted_tiles.clear()
+    keep = api.keep_last_buffers
+    api.keep_last_buffers = True
+    res = {}
+    try:
+        for route in ("first", "on_demand", "whole", "whole_again"):
+            api._force_whole_lists = None if route == "first" else route != "on_demand"
+            out, grads, _ = Hh.run_gpu(sc, gpu)
+            bufs = api.last_call_buffers
+            L = _lib.get_layout(bufs["P"], bufs["W"], bufs["H"], bufs["cap"])
+            ctrl = bufs["img"][L.img_ctrl:L.img_ctrl + 64].view(torch.int32).cpu().tolist()
+            fl = bufs["img"][L.img_front_len:L.img_front_len + 4 * T].view(torch.int32)
+            res[route] = (out, grads, ctrl[4], int(fl.sum().item()), int(api.last_call_stats["num_rendered"]))
+            del out, grads
+    finally:
+        api._force_whole_lists = None
+        api.keep_last_buffers = keep
+        api.last_call_buffers.clear()
+    R = res["first"][4]
+    assert R > 70_000_000
+    assert res["on_demand"][2] > 3 * T and res["whole"][2] == 0 and res["whole_again"][2] == 0      # flagged quadrants
+    assert res["whole"][3] == R and res["whole_again"][3] == R                                    # every instance sorted up front
+    ref_out, ref_grads = res["on_demand"][:2]
+    for route in ("first", "whole", "whole_again"):
+        out, grads = res[route][:2]
+        for k in ref_out:
+            np.testing.assert_array_equal(out[k], ref_out[k], err_msg="%s %s" % (route, k))
+        for k in ref_grads:
+            if ref_grads[k] is not None:
+                Hh.assert_close("%s %s" % (route, k), ref_grads[k], grads[k], rtol_max=2e-5, atol=1e-7)
 
 
 def test_c5_5m_1080p_with_deform_offsets_tile_pull_vs_whole_frame(gpu):
