@@ -545,7 +545,10 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         hint, list_hint = _instance_hint.get(hint_key, (None, 0))
         # (a schedule buffer made during a capture would live in the graph's private pool: only one that exists already)
         n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
-        tile_hints = _tile_hints.get(hint_key) if capturing else _tile_hint_buffer(hint_key, dev, W, H)
+        # (the per-tile schedule is about regions of the image: it is kept per image size, not per number of Gaussians, and so
+        # survives the densification steps of a training loop, which change P every hundred iterations)
+        tiles_key = (dev.index, W, H, hint_slot)
+        tile_hints = _tile_hints.get(tiles_key) if capturing else _tile_hint_buffer(tiles_key, dev, W, H)
         io.tile_hints = _ptr(tile_hints)
         try:
             with _lib.on_device(dev):
@@ -563,7 +566,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                         # the posting of the shape's previous no-host-read frame (its kernels are long done)
                         prev_R, prev_cap = int(a[0]), int(st["cap"])
                         a[3] = 0
-                        _hinted_tiles[hint_key] = int(a[8])
+                        _hinted_tiles[tiles_key] = int(a[8])
                         if a[1] & 1:
                             raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
                         prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
@@ -577,7 +580,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
                     hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
-                                              whole_lists=_whole_lists(hint_key, n_tiles))
+                                              whole_lists=_whole_lists(tiles_key, n_tiles))
                     _lib.check(lib.gft_forward_enqueue(stream, C.byref(cfg), C.byref(io), C.byref(hints), st["dev"].data_ptr()))
                     st["cap"] = cap
                     st["host"].copy_(st["dev"], non_blocking=True)
@@ -601,11 +604,11 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
                     hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
-                                              whole_lists=_whole_lists(hint_key, n_tiles))
+                                              whole_lists=_whole_lists(tiles_key, n_tiles))
                     report = _lib.ForwardReport()
                     _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), C.byref(hints), C.byref(report)))
                     R = int(report.num_rendered)
-                    _hinted_tiles[hint_key] = int(report.hinted_tiles)
+                    _hinted_tiles[tiles_key] = int(report.hinted_tiles)
                     max_list.value = int(report.max_tile_list)
                     if R > cap:
                         restarted = True

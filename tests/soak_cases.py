@@ -61,7 +61,7 @@ def run_case(case, dev, oracle, rng):
             torch.cuda.synchronize()
             api._tile_hints.clear()
         if c["hints"] in ("ones", "random"):
-            hb = api._tile_hint_buffer((dev.index, P, c["W"], c["H"]), dev, c["W"], c["H"])
+            hb = api._tile_hint_buffer((dev.index, c["W"], c["H"], 0), dev, c["W"], c["H"])
             if c["hints"] == "ones":
                 hb.fill_(0x01010101)
             else:
