@@ -76,6 +76,7 @@ _HINT_HEADROOM = 1.25
 # (tests/test_gpu_parity.py::test_tile_hints_do_not_change_results).  GFT_TILE_HINTS=0 switches it off.  The buffers are
 # 4 bytes per tile and are never freed (a kernel of an earlier call may still read or write them).
 _TILE_HINTS = _os.environ.get("GFT_TILE_HINTS", "1") != "0"
+_TILE_HINTS_PER_CAMERA = _os.environ.get("GFT_TILE_HINTS_PER_CAMERA", "1") != "0"
 _tile_hints = {}
 # ... and how many tiles the schedule marked when the shape's last frame read it (gft_forward_report.hinted_tiles): from a
 # sixteenth of the tiles on the next forward runs the build of the pull kernel that sorts hinted tiles' whole lists
@@ -545,9 +546,15 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         hint, list_hint = _instance_hint.get(hint_key, (None, 0))
         # (a schedule buffer made during a capture would live in the graph's private pool: only one that exists already)
         n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
-        # (the per-tile schedule is about regions of the image: it is kept per image size, not per number of Gaussians, and so
-        # survives the densification steps of a training loop, which change P every hundred iterations)
-        tiles_key = (dev.index, W, H, hint_slot)
+        # (the per-tile schedule is about regions of the image as ONE CAMERA sees them -- which tiles hold the scene's
+        # silhouette differs from view to view: it is kept per image size and camera, the camera being known by the address
+        # of its view matrix (the reference's Camera objects keep theirs for the whole run, scene/cameras.py; a caller that
+        # builds new matrices every call gets a fresh, empty schedule each time -- and, from 1024 of them on, one shared per
+        # image size).  Not per number of Gaussians: it survives the densification steps, which change P every hundred
+        # iterations.)
+        tiles_key = (dev.index, W, H, hint_slot, s.viewmatrix.data_ptr() if _TILE_HINTS_PER_CAMERA else 0)
+        if tiles_key not in _tile_hints and len(_tile_hints) >= 1000:
+            tiles_key = (dev.index, W, H, hint_slot, 0)
         tile_hints = _tile_hints.get(tiles_key) if capturing else _tile_hint_buffer(tiles_key, dev, W, H)
         io.tile_hints = _ptr(tile_hints)
         try:

@@ -348,7 +348,9 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(WHOLE
     uint32_t lx, ly;
     if (!pull_tile_of_block(a.sh, (int)blockIdx.x, tile, q, lx, ly)) { clear_slice(); return; }
     const int K = a.sh.K;
-    const bool hinted = WHOLE && ((a.dbg & 16) || (a.hints != nullptr && a.hints[tile] != 0u));      // uniform over the workgroup
+    // (both builds read the schedule: the whole-list build sorts a hinted tile's list whole, the heads-only build gives it the
+    // longest head one placement holds -- 2047 keys instead of ~940: most quadrants that walk past a normal head end inside it)
+    const bool hinted = (a.dbg & 16) || (a.hints != nullptr && a.hints[tile] != 0u);      // uniform over the workgroup
     for (int i = tid; i < GFT_DEPTH_BINS; i += GFT_BLOCK) s_hist[i] = 0;
     if (tid == 0) s_n = 0;
     __syncthreads();
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(WHOLE
         __syncthreads();
         n = s_n;
         __syncthreads();                                 // (everybody has read the count before the next slab adds to it)
-        if (!hinted && n >= HEAD_TARGET) { kstop = k; break; }
+        if (n >= (hinted ? (WHOLE ? 0xffffffffu : HEAD_DIRECT + 1u) : HEAD_TARGET)) { kstop = k; break; }
     }
     if ((a.dbg & 15) == 1) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     bool more_slabs = false;
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(WHOLE
     // A hinted tile with a list beyond one placement sorts it whole, in chunks of whole depth bins of fewer than TPULL_KEYS
     // keys each (a chunk is one placement: cursors of 11 bits) -- unless a single bin holds more than 255 keys (the bin
     // counts are then carried as bytes): such a tile takes the lazy route, whose tail builder sorts anything.
-    bool whole = hinted && n > HEAD_DIRECT;
+    bool whole = WHOLE && hinted && n > HEAD_DIRECT;
     if (WHOLE && whole) {
         uint32_t gm = 0;
 #pragma unroll
@@ -484,17 +486,18 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(WHOLE
     // the head (a tile that does not sort its whole list): whole bins up to the one where the running count reaches
     // HEAD_TARGET.  That bin is taken if the head then still sorts as one 1024-key unit; a bin that overshoots is left out
     // unless the head would otherwise be shorter than 512 and the bin fits the 2048-key sorter.  first_tail = first bin
-    // outside the head.
+    // outside the head.  A hinted tile: whole bins while they fit one placement (fewer than 2048 keys).
     uint32_t first_tail = (uint32_t)(kstop + 1) << a.sh.kshift, kf = n;
     if (!whole && n > HEAD_DIRECT) {
+        const uint32_t tgt = hinted ? HEAD_DIRECT : HEAD_TARGET;
         uint32_t run = run0;
-        if (run < HEAD_TARGET && xin >= HEAD_TARGET) {           // exactly one thread: the crossing lies in its 16 bins
+        if (run < tgt && xin >= tgt) {                           // exactly one thread: the crossing lies in its 16 bins
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t before = run;
                 run += h[k];
-                if (before < HEAD_TARGET && run >= HEAD_TARGET) {
-                    const bool take = run <= 1024u || (before < 512u && run <= TPULL_KEYS);
+                if (before < tgt && run >= tgt) {
+                    const bool take = !hinted && (run <= 1024u || (before < 512u && run <= TPULL_KEYS));
                     s_cut = (uint32_t)(16 * tid + k) + (take ? 1u : 0u);
                     s_kf = take ? run : before;
                 }

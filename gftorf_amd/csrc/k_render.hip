@@ -123,7 +123,8 @@ struct RenderFwdArgs {
     float4* __restrict__ resume_state;
     int resume;                               // second pass: continue the flagged quadrants behind the head
     // tile-pull binning with a caller-kept schedule (gft_forward_io.tile_hints): byte v = did quadrant v walk past where a
-    // sorted head ends -- it flagged, or (list sorted whole) its deepest contributor lies beyond GFT_HEAD_TARGET
+    // normal sorted head ends -- it flagged, or (a hinted tile's long head or whole list: more than 1024 sorted entries) its
+    // deepest contributor lies beyond GFT_HEAD_TARGET
     uint8_t* __restrict__ hint_out;
 };
 
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     if (lane == 0) a.quad_max[v] = mx;
     if (a.hint_out && !a.resume && lane == 0) {
         const bool flagged = (head < full || more) && done_m != ~0ull;
-        a.hint_out[v] = (flagged || (head > (int)GFT_HEAD_DIRECT && mx > GFT_HEAD_TARGET)) ? 1 : 0;
+        a.hint_out[v] = (flagged || (head > 1024 && mx > GFT_HEAD_TARGET)) ? 1 : 0;
     }
 }
 
@@ -803,7 +804,7 @@ __global__ __launch_bounds__(64 * FSEG_WAVES) __attribute__((amdgpu_waves_per_eu
     if (lane == 0) a.quad_max[v] = mx;
     if (a.hint_out && lane == 0) {
         const bool flagged = (head < full || more) && done_m != ~0ull;
-        a.hint_out[v] = (flagged || (head > (int)GFT_HEAD_DIRECT && mx > GFT_HEAD_TARGET)) ? 1 : 0;
+        a.hint_out[v] = (flagged || (head > 1024 && mx > GFT_HEAD_TARGET)) ? 1 : 0;
     }
 }
 

@@ -137,7 +137,9 @@ typedef struct gft_forward_io {
      * before the first; T = tiles).  A SCHEDULE, never a result: every forward stores, per 8x8 pixel quadrant (one byte
      * each), whether that quadrant walked past where the sorted head of its tile's list ends (about 940 entries); the next
      * forward sorts the WHOLE list of a tile with a non-zero word up front -- one pass of k_tile_pull in chunks of whole
-     * depth bins -- instead of a head now and the rest on demand (flag, k_tail_build, resume pass).  A frame in which
+     * depth bins (gft_forward_hints.whole_lists) -- or, with the heads-only build of that kernel, gives it the longest head
+     * one placement holds (2047 entries), instead of a head now and the rest on demand (flag, k_tail_build, resume pass:
+     * the silhouette tiles of a dense view, whose quadrants mostly end inside such a head).  A frame in which
      * nothing saturates (the reference's scenes right after an opacity reset, arguments/__init__.py:99) has every tile
      * take the on-demand route: 0.57 ms of a 1.8 ms step at 1 M Gaussians.  Images, counts and gradients do not depend
      * on the hints (the blend walks the same entries in the same order either way).  Frames whose forward blend is

@@ -44,6 +44,7 @@ def run_case(case, dev, oracle, rng):
     scene = Hh.small_scene(P=P, W=c["W"], H=c["H"], seed=c["seed"], D=c["D"], sh_coeffs=c["M"], scale_lo=0.01, scale_hi=c["scale_hi"],
                            tof=c["tof"], opacity=c["opacity"], w2c="tilted" if c["tilted"] else None)
     keep = (api._TILE_HINTS, api._GRADS_REUSE, api._USE_COUNT_API, api._ACC_REUSE)
+    keep_cam, api._TILE_HINTS_PER_CAMERA = api._TILE_HINTS_PER_CAMERA, False      # (a frame's camera tensors are new every case)
     # (the build of the pull kernel that honours the schedule, whenever the case hands one over; "keep": the operator's choice)
     api._force_whole_lists = True if c["hints"] in ("ones", "random") else None
     lib.gft_set_binning_mode(c["bin_mode"])
@@ -61,7 +62,7 @@ def run_case(case, dev, oracle, rng):
             torch.cuda.synchronize()
             api._tile_hints.clear()
         if c["hints"] in ("ones", "random"):
-            hb = api._tile_hint_buffer((dev.index, c["W"], c["H"], 0), dev, c["W"], c["H"])
+            hb = api._tile_hint_buffer((dev.index, c["W"], c["H"], 0, 0), dev, c["W"], c["H"])
             if c["hints"] == "ones":
                 hb.fill_(0x01010101)
             else:
@@ -119,6 +120,7 @@ def run_case(case, dev, oracle, rng):
             api._grad_pool.clear()
         api._TILE_HINTS, api._GRADS_REUSE, api._USE_COUNT_API, api._ACC_REUSE = keep
         api._force_whole_lists = None
+        api._TILE_HINTS_PER_CAMERA = keep_cam
     return edge_flips, flip_cases
 
 

@@ -214,7 +214,9 @@ def test_c5_fog_whole_lists_equal_lists_completed_on_demand(gpu):
         api.last_call_buffers.clear()
     R = res["first"][4]
     assert R > 70_000_000
-    assert res["on_demand"][2] > 3 * T and res["whole"][2] == 0 and res["whole_again"][2] == 0      # flagged quadrants
+    # flagged quadrants: most of them after the first frame's heads of ~940 entries; with the long heads the schedule gives the
+    # heads-only build (2047 entries: at this density part of the pixels saturate inside them) still thousands; none with whole lists
+    assert res["first"][2] > 3 * T and res["on_demand"][2] > T // 2 and res["whole"][2] == 0 and res["whole_again"][2] == 0
     assert res["whole"][3] == R and res["whole_again"][3] == R                                    # every instance sorted up front
     ref_out, ref_grads = res["on_demand"][:2]
     for route in ("first", "whole", "whole_again"):

@@ -756,6 +756,71 @@ def test_tile_hints_do_not_change_results(name, oracle, gpu):
     check_grads(b, grads, scene)
 
 
+def test_schedules_are_kept_per_camera(oracle, gpu):
+    """Two cameras on the same Gaussians, drawn alternately (a training loop's access pattern): each keeps its own per-tile
+    schedule, keyed by the address of its view matrix -- the silhouette tiles of one view are not the other's.  A thin cloud
+    whose edge crosses the image: some quadrants walk past a normal head.  With the schedule, such a tile gets a long head
+    (or its whole list) at the camera's next visit and flags less; results equal the schedule-free ones bit for bit."""
+    from gftorf_amd import GaussianRasterizer, _lib, api, synth
+    if not _lib.load().gft_lazy_sort():
+        pytest.skip("GFT_LAZY_SORT=0: whole-frame binning only")
+    kw = dict(P=30000, W=96, H=64, scale_lo=0.005, scale_hi=0.05, spread=0.55)
+    cams = [synth.look_at_w2c(0.15, -0.1, 0.05, (0.1, -0.05, 0.2)), synth.look_at_w2c(-0.2, 0.12, -0.04, (-0.15, 0.05, 0.25))]
+    scenes = [Hh.small_scene(seed=23, w2c=c, **kw) for c in cams]
+    g = scenes[0]["gaussians"]
+    leaf = {k: torch.tensor(v, dtype=torch.float32, device=gpu, requires_grad=True) for k, v in g.items() if v is not None}
+    m2 = torch.zeros((kw["P"], 3), device=gpu, requires_grad=True)
+    rasts = [GaussianRasterizer(raster_settings=Hh.gpu_settings(sc, gpu)) for sc in scenes]       # persistent camera tensors
+
+    def render(i):
+        for v in leaf.values():
+            v.grad = None
+        sc = scenes[i]
+        o = rasts[i](means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf["shs"], shs_p=leaf["shs_p"],
+                     scales=leaf["scales"], rotations=leaf["rotations"], phase_offset=sc["phase_offset"], dc_offset=sc["dc_offset"])
+        gr = sc["grads"]
+        sum((o[j] * torch.tensor(gr[k], device=gpu)).sum() for j, k in ((0, "color"), (1, "phasor"), (2, "depth"), (4, "acc"), (6, "depth_distortion"))).backward()
+        torch.cuda.synchronize()
+        bufs = api.last_call_buffers
+        L = _lib.get_layout(bufs["P"], bufs["W"], bufs["H"], bufs["cap"])
+        flagged = int(bufs["img"][L.img_ctrl:L.img_ctrl + 64].view(torch.int32)[4].item())
+        return [t.detach().cpu().numpy() for t in o], leaf["means3D"].grad.cpu().numpy(), flagged
+
+    keep = (api._TILE_HINTS, api._TILE_HINTS_PER_CAMERA, api.keep_last_buffers)
+    api.keep_last_buffers = True
+    try:
+        with render_mode(0):
+            api._TILE_HINTS = False
+            api._instance_hint.clear()
+            render(0), render(1)
+            ref = [render(0), render(1)]
+            assert ref[0][2] > 0 and ref[1][2] > 0, "the case must have quadrants that walk past their heads"
+            api._TILE_HINTS, api._TILE_HINTS_PER_CAMERA = True, True
+            api._tile_hints.clear()
+            api._hinted_tiles.clear()
+            flagged = []
+            for visit in range(3):
+                for i in (0, 1):
+                    o, gm, fl = render(i)
+                    flagged.append(fl)
+                    for a, e in zip(o, ref[i][0]):
+                        np.testing.assert_array_equal(a, e)
+                    Hh.assert_close("means3D", ref[i][1], gm, rtol_max=1e-5)
+            keys = [k for k in api._tile_hints if k[1:3] == (96, 64)]
+            assert len(keys) == 2 and len({k[4] for k in keys}) == 2                  # one schedule per camera
+            a, b = (api._tile_hints[k].cpu().numpy() for k in keys)
+            assert (a != 0).any() and (b != 0).any() and ((a != 0) != (b != 0)).any()    # ... and they differ
+            # first visits: no schedule yet; later visits: the marked tiles got long heads and flag less
+            assert flagged[0] == ref[0][2] and flagged[1] == ref[1][2]
+            assert flagged[2] < flagged[0] and flagged[3] < flagged[1], flagged
+    finally:
+        api._TILE_HINTS, api._TILE_HINTS_PER_CAMERA, api.keep_last_buffers = keep
+        api.last_call_buffers.clear()
+        api._instance_hint.clear()
+    f, b = Hh.run_oracle(oracle, dict(scenes[1], gaussians=g), backward=False)      # (camera 1 on the shared Gaussians)
+    check_outputs(f, dict(zip(Hh.OUT_NAMES, o)))
+
+
 LAZY_CASES = {
     # lists of 1.2k..5k keys per tile: the sorted head (~940 keys) is not enough for the far pixels
     "thin_fog": dict(P=40000, W=64, H=64, scale_lo=0.01, scale_hi=0.05, opacity=0.02),            # nothing saturates: every quadrant resumes
