@@ -63,7 +63,7 @@ PROFILE_FIELDS = ["preprocess_fwd_ms", "tile_count_ms", "tile_scatter_ms", "tile
 
 
 class ForwardIO(C.Structure):
-    _fields_ = [(n, _fp) for n in FORWARD_FIELDS] + [("grads_zero", _fp), ("grads_zero_bytes", C.c_size_t), ("tile_hints", _fp)]
+    _fields_ = [(n, _fp) for n in FORWARD_FIELDS] + [("grads_zero", _fp), ("grads_zero_bytes", C.c_size_t), ("tile_hints", _fp), ("tile_weights", _fp)]
 
 
 class BackwardIO(C.Structure):

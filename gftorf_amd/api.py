@@ -78,6 +78,8 @@ _HINT_HEADROOM = 1.25
 _TILE_HINTS = _os.environ.get("GFT_TILE_HINTS", "1") != "0"
 _TILE_HINTS_PER_CAMERA = _os.environ.get("GFT_TILE_HINTS_PER_CAMERA", "1") != "0"
 _tile_hints = {}
+_tile_weights = {}
+_FWD_ORDER = _os.environ.get("GFT_FWD_ORDER", "1") != "0"
 # ... and how many tiles the schedule marked when the shape's last frame read it (gft_forward_report.hinted_tiles): from a
 # sixteenth of the tiles on the next forward runs the build of the pull kernel that sorts hinted tiles' whole lists
 # (gft_forward_hints.whole_lists) -- fewer are served as well by the heads-only build, which keeps seven workgroups per CU,
@@ -507,7 +509,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                       _p0(rot_c), _p0(cov_c), view_c.data_ptr(), proj_c.data_ptr(), campos_c.data_ptr(), _p0(sh_c), _p0(sh_p_c),
                       geom.data_ptr(), img.data_ptr(), 0,
                       pl, pl + 3 * hw4, pl + 10 * hw4, pl + 11 * hw4, pl + 14 * hw4, pl + 15 * hw4, pl + 16 * hw4, pl + 17 * hw4,
-                      pixels.data_ptr() if P else 0, pl + 18 * hw4, radii.data_ptr() if P else 0, 0, 0, 0, 0)
+                      pixels.data_ptr() if P else 0, pl + 18 * hw4, radii.data_ptr() if P else 0, 0, 0, 0, 0, 0)
     # the backward's accumulator: cleared by the forward beside its binning kernels -- unless it comes from the pool of
     # buffers that the last backward left zero (_AccLease)
     lease = None
@@ -557,6 +559,13 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
             tiles_key = (dev.index, W, H, hint_slot, 0)
         tile_hints = _tile_hints.get(tiles_key) if capturing else _tile_hint_buffer(tiles_key, dev, W, H)
         io.tile_hints = _ptr(tile_hints)
+        # ... and beside it the quadrants' walk lengths of the camera's last frame, by which the forward blend deals its waves
+        # heaviest tile first (gft_forward_io.tile_weights)
+        if tile_hints is not None and _FWD_ORDER:
+            tw = _tile_weights.get(tiles_key)
+            if tw is None and not capturing:
+                tw = _tile_weights[tiles_key] = torch.zeros((4 * n_tiles + 4,), device=dev, dtype=torch.int32)
+            io.tile_weights = _ptr(tw)
         try:
             with _lib.on_device(dev):
                 if nowait:

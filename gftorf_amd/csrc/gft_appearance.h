@@ -19,6 +19,11 @@ struct PreFwdArgs {
     float focal_x, focal_y, dist2phase;
     int gx, gy;
     int stage_sh, stage_shp;   // SH rows staged through LDS (M == 16)
+    // k_appearance, workgroup 0: the forward blend's heavy-first tile order from the caller's quadrant walk lengths of the
+    // previous frame of this camera (gft_forward_io.tile_weights; NULL: none)
+    const uint32_t* prev_w;
+    uint32_t* fwd_order;
+    int T;
 };
 
 inline PreFwdArgs gft_pre_fwd_args(const gft_config& c, const gft_forward_io& io, const GeomView& g, const ImgView& im,
@@ -43,6 +48,7 @@ inline PreFwdArgs gft_pre_fwd_args(const gft_config& c, const gft_forward_io& io
     a.gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X;
     a.gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     a.stage_sh = a.stage_shp = 0;
+    a.prev_w = nullptr; a.fwd_order = nullptr; a.T = a.gx * a.gy;
     return a;
 }
 

@@ -75,6 +75,7 @@ struct BinView {
 #define GFT_CTRL_DONE2 7     // finished workgroups of k_tail_build (ticket for the backward's tile order)
 #define GFT_CTRL_NHINT 8     // tile-pull binning: non-zero words of the caller's per-tile schedule (gft_forward_io.tile_hints), also in the mailbox
 #define GFT_CTRL_RSUM 9      // tile-pull binning: R as summed by the supertile count pass
+#define GFT_CTRL_FWDORDER 10 // this frame's forward has a heavy-first tile order of its own (from the caller's tile_weights), in tile_cursor
 #define GFT_CTRL_ORDER_OK 11 // the forward computed the backward's heavy-first tile order
 #define GFT_CTRL_WORDS 16
 // Behind the ctrl words: first-level ticket counters of the count pass.  Its ~1000 workgroups are resident together and all
@@ -132,6 +133,11 @@ inline int gft_fwd_seg_waves(int T)
 int gft_render_mode();      // -1: default (segments on under-filled frames), 0: one wave per quadrant, 1: segments (gft_set_render_mode / GFT_FWD_SEG)
 // does the first pass of a T-tile frame run the segment-parallel kernel?
 inline bool gft_fwd_segmented(int T) { return gft_render_mode() != 0 && gft_fwd_seg_waves(T) > 1; }
+// The forward's heavy-first dealing (gft_forward_io.tile_weights) pays where the quadrant waves make few rounds over the chip's
+// wave slots: measured -5..-9 us at 1200 tiles (the metric frame, 500 k Gaussians; -8 us per view over 30 cameras), +-0 on the fog frame, +65 us at 8160 tiles (5 M Gaussians at 1080p: 16
+// rounds balance by themselves, and neighbouring tiles no longer share an XCD's L2).  Off above 4096 tiles.
+#define GFT_FWD_ORDER_MAX_TILES 4096
+inline bool gft_fwd_ordered(int T) { return !gft_fwd_segmented(T) && T <= GFT_FWD_ORDER_MAX_TILES; }
 #define GFT_SNAP_F4 3      // float4 per pixel and snapshot: {T, C0, C1, C2} {PR, PI, PA, Dd} {A, DD_D, DD_D2, -}
 
 void gft_compute_layout(int32_t P, int32_t W, int32_t H, int64_t R, gft_layout* L);

@@ -324,6 +324,14 @@ __global__ __launch_bounds__(APP_THREADS) void k_appearance(PreFwdArgs a, uint32
     __shared__ uint32_t s_n;
     if (a.ctrl[GFT_CTRL_TOTAL] > cap) return;
     const int tid = threadIdx.x, lane = tid & 63;
+    // Workgroup 0, on the side: the heavy-first order in which the forward blend deals its quadrant waves, from the walk
+    // lengths the previous frame of this camera left with the caller (any contents give a permutation of the tiles; no
+    // lengths yet: tiles stay in image order, whose runs per XCD share their L2).  The blend kernel is the next launch.
+    if (blockIdx.x == 0 && a.prev_w != nullptr && a.prev_w[4 * a.T] == 1u) {       // (uniform over the workgroup)
+        gft_tile_order_block(a.T, a.prev_w, a.fwd_order);
+        __syncthreads();
+        if (tid == 0) a.ctrl[GFT_CTRL_FWDORDER] = 1u;
+    }
     if (tid == 0) s_n = 0;
     __syncthreads();
     const int base = blockIdx.x * APP_CHUNK;
@@ -1024,6 +1032,9 @@ hipError_t gft_launch_appearance(hipStream_t s, const gft_config& c, const gft_f
                                  const ImgView& im, uint32_t cap)
 {
     PreFwdArgs a = gft_pre_fwd_args(c, io, g, im, nullptr, true);
+    // (frames whose forward blend is segment-parallel keep no schedule)
+    a.prev_w = gft_fwd_ordered(a.T) ? io.tile_weights : nullptr;
+    a.fwd_order = im.tile_cursor;          // (tile-pull binning has no other use for these T words)
     if (c.P >= 3000000) {
         hipLaunchKernelGGL(k_appearance<4>, dim3((c.P + APP_CHUNK_OF(4) - 1) / APP_CHUNK_OF(4)), dim3(APP_THREADS), 0, s, a, cap);
     } else {

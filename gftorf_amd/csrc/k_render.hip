@@ -126,6 +126,9 @@ struct RenderFwdArgs {
     // normal sorted head ends -- it flagged, or (a hinted tile's long head or whole list: more than 1024 sorted entries) its
     // deepest contributor lies beyond GFT_HEAD_TARGET
     uint8_t* __restrict__ hint_out;
+    // first pass with a caller-kept schedule: the heavy-first tile order k_appearance derived for this frame (NULL: none)
+    const uint32_t* __restrict__ fwd_order;
+    const uint32_t* __restrict__ fwd_order_ok;
 };
 
 __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
@@ -137,7 +140,18 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
     if (a.ctrl && a.ctrl[GFT_CTRL_TOTAL] > a.cap) return;
     if (a.resume && *a.nflag == 0u) return;               // no quadrant asked for its tail
     const int V = a.T * 4;
-    const int v = unit_of_block(blockIdx.x, V);
+    int v;
+    if (a.fwd_order && *a.fwd_order_ok) {
+        // dealt as the backward's are: block b on XCD b & 7 takes quadrant (slot & 3) of the tile of weight rank
+        // 8 (slot >> 2) + xcd -- heaviest tiles first, by the walk lengths of this camera's previous frame (k_appearance)
+        const int xcd = (int)blockIdx.x & 7, qslot = (int)blockIdx.x >> 3;
+        const int rank = 8 * (qslot >> 2) + xcd;
+        if (rank >= a.T) return;
+        v = (int)a.fwd_order[rank] * 4 + (qslot & 3);
+    } else {
+        if (((int)blockIdx.x >> 3) >= ((V + 7) >> 3)) return;      // (the grid is sized for the ordered dealing: a few blocks more)
+        v = unit_of_block(blockIdx.x, V);
+    }
     if (v >= V) return;
     const int tile = v >> 2, quad = v & 3;
     const int lane = threadIdx.x;
@@ -1240,7 +1254,10 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     a.nflag = im.ctrl + GFT_CTRL_NFLAG;
     a.resume_state = im.resume_state;
     a.resume = lazy == 2;
-    const int blocks = 8 * ((a.T * 4 + 7) / 8);
+    const bool ordered = pull && lazy == 1 && io.tile_weights != nullptr && gft_fwd_ordered(a.T);
+    a.fwd_order = ordered ? im.tile_cursor : nullptr;
+    a.fwd_order_ok = im.ctrl + GFT_CTRL_FWDORDER;
+    const int blocks = ordered ? 32 * ((a.T + 7) / 8) : 8 * ((a.T * 4 + 7) / 8);
     // segmented: up to FSEG_WAVES waves per quadrant (first pass only; the resume pass of flagged quadrants stays one
     // wave per quadrant).  GFT_FWD_SEG=0 / 1 in the environment forces one of the two kernels for every frame.
     const bool seg = segmented && !a.resume && gft_fwd_segmented(a.T);

@@ -146,6 +146,15 @@ typedef struct gft_forward_io {
      * segment-parallel (fewer than 768 tiles, gft_set_render_mode) neither read nor write it: that kernel cuts a list by
      * the length of its sorted part.  NULL: no schedule. */
     uint32_t* tile_hints;
+    /* optional, beside tile_hints (same owner, same lifetime, zero before the first use): uint32[4 T + 4].  The forward
+     * leaves every 8x8 quadrant's walk length there (and sets word 4 T to 1); the next forward of this image size and
+     * camera deals its quadrant waves to the chip heaviest tile first by those lengths, as the backward always does by the
+     * lengths of its own frame -- all quadrant waves of a 640x480 frame are resident together, so the order decides which
+     * waves share a SIMD, and equal shares end together.  The order is derived anew on the device from whatever the words
+     * hold (any contents give a permutation of the tiles): a schedule, never a result.  Neither read nor written on frames
+     * of more than 4096 tiles (their many rounds of waves balance by themselves, and image order keeps neighbouring tiles on
+     * one XCD's L2: measured) or with the segment-parallel forward.  NULL: tiles in image order. */
+    uint32_t* tile_weights;
 } gft_forward_io;
 
 /* Tensors of the backward call (RAST/rasterize_points.cu:167-198). */

@@ -733,6 +733,7 @@ def test_tile_hints_do_not_change_results(name, oracle, gpu):
         finally:
             api._TILE_HINTS = keep
         api._tile_hints.clear()
+        api._tile_weights.clear()
         api._hinted_tiles.clear()
         for frame in range(7):
             if frame >= 3:
@@ -743,6 +744,10 @@ def test_tile_hints_do_not_change_results(name, oracle, gpu):
                         hbuf.fill_(0x01010101)
                     else:
                         hbuf.copy_(torch.tensor(rng.integers(0, 2, hbuf.numel()), dtype=torch.int32))
+                # ... and whatever walk lengths the forward's heavy-first dealing is derived from
+                for wbuf in api._tile_weights.values():
+                    wbuf.copy_(torch.tensor(rng.integers(0, 3000 if frame != 4 else 2 ** 31 - 1, wbuf.numel()), dtype=torch.int32))
+                    wbuf[-4] = 1
                 api._force_whole_lists = frame != 6
             out, grads, _ = Hh.run_gpu(scene, gpu)
             for k in ref_out:
