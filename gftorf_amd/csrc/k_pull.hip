@@ -81,15 +81,20 @@ struct SuperArgs {
     uint32_t* mail; uint32_t seq;
     uint32_t cap;
     const uint32_t* __restrict__ hints;      // pass 0: the caller's per-tile schedule (may be NULL): its non-zero words are counted for the host
+    // pass 1 on big tile grids: the workgroup's entries are grouped by cell in LDS first (`stage_cap` of them: 8 bytes + a
+    // 16-bit cell each behind the three cell tables) and leave as runs of consecutive lanes.  0: every entry is written
+    // from where it was made.
+    uint32_t stage_cap;
 };
 
 template <int PASS>      // 0: count (+ R, mailbox), 1: scatter
 __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
 {
-    extern __shared__ uint32_t sb_dyn[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t sb_dyn[];
     const int cells = a.sh.NS * a.sh.K;
     uint32_t* s_cnt = sb_dyn;                 // [cells]
     uint32_t* s_first = sb_dyn + cells;       // [cells] pass 1: first entry of this workgroup's chunk
+    uint32_t* s_loc = sb_dyn + 2 * cells;     // [cells] pass 1, staged: first staging slot of the cell
     __shared__ uint32_t s_last, s_sum, s_carry;
     __shared__ uint32_t s_wt[BIN_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -243,6 +248,41 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         return;
     }
     // scatter: one chunk per (workgroup, supertile, slab)
+    // Staged (big tile grids: 2040 cells at 1080p, five or six entries per workgroup and cell): made where its Gaussian
+    // sits, an entry is an 8-byte store of its own -- 64 lanes, 64 cache lines, each leaving the L2 as a 32-byte sector
+    // (5 M @ 1080p: 441 MB written for 107 MB of entries, the kernel stalled on its store queue 0.65 of the time).
+    // Grouped by cell in LDS first, the entries of a cell leave as one run of consecutive lanes.
+    uint32_t* s_stage_cell_base = sb_dyn + 3 * cells;                  // staging area: entries, then their cells
+    uint64_t* stage_ent = reinterpret_cast<uint64_t*>(s_stage_cell_base + (cells & 1));
+    uint16_t* stage_cell = reinterpret_cast<uint16_t*>(stage_ent + a.stage_cap);
+    bool staged = false;
+    uint32_t n_wg = 0;
+    if (a.stage_cap) {
+        // exclusive scan of the cell counts (PERC consecutive cells per thread)
+        const int PERC = (cells + BIN_THREADS - 1) / BIN_THREADS;
+        const int c0 = tid * PERC;
+        uint32_t sum = 0;
+        for (int k = 0; k < PERC; k++) sum += c0 + k < cells ? s_cnt[c0 + k] : 0u;
+        uint32_t x = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_wt[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int w = 0; w < BIN_THREADS / 64; w++) {
+            if (w < wave) woff += s_wt[w];
+            tot += s_wt[w];
+        }
+        uint32_t run = woff + x - sum;
+        for (int k = 0; k < PERC; k++)
+            if (c0 + k < cells) { s_loc[c0 + k] = run; run += s_cnt[c0 + k]; }
+        n_wg = min(tot, a.stage_cap);                                // (entries past the staging area go the direct way)
+        staged = true;
+        __syncthreads();
+    }
     for (int i = tid; i < cells; i += BIN_THREADS) {
         const uint32_t c = s_cnt[i];
         s_first[i] = c ? atomicAdd(&a.cur_copy[(size_t)(blockIdx.x & (a.copies - 1)) * cells + i], c) : 0u;
@@ -263,8 +303,23 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
                 const uint32_t x0 = (uint32_t)max((int)r4[u].x - ox, 0), x1 = (uint32_t)min((int)r4[u].z - ox, S);
                 const uint32_t y0 = (uint32_t)max((int)r4[u].y - oy, 0), y1 = (uint32_t)min((int)r4[u].w - oy, S);
                 const uint32_t hi = x0 | (y0 << 5) | (x1 << 10) | (y1 << 15) | (bin[u] << 20);
-                a.sl_ent[s_first[cell] + atomicAdd(&s_cnt[cell], 1u)] = ((uint64_t)hi << 32) | idx;
+                const uint32_t rank = atomicAdd(&s_cnt[cell], 1u);
+                const uint64_t e = ((uint64_t)hi << 32) | idx;
+                const uint32_t pos = staged ? s_loc[cell] + rank : ~0u;
+                if (pos < a.stage_cap) {
+                    stage_ent[pos] = e;
+                    stage_cell[pos] = (uint16_t)cell;
+                } else {
+                    a.sl_ent[s_first[cell] + rank] = e;
+                }
             }
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t i = (uint32_t)tid; i < n_wg; i += BIN_THREADS) {
+            const uint32_t cell = stage_cell[i];
+            a.sl_ent[s_first[cell] + (i - s_loc[cell])] = stage_ent[i];
+        }
     }
 }
 
@@ -1003,6 +1058,10 @@ SuperShape gft_super_shape(const gft_config& c)
 // the rectangle of an entry relative to its supertile is packed into 4 x 5 bits: supertiles of at most 16 x 16 tiles
 bool gft_tile_pull_ok(const gft_config& c) { return gft_super_shape(c).sshift <= 4; }
 
+// dynamic LDS the scatter pass may ask for: the CU's 160 KB less the kernel's few static words
+constexpr size_t SUPER_SCATTER_LDS = 160 * 1024 - 256;
+static_assert(SUPER_SCATTER_LDS >= (size_t)GFT_SUPER_CELLS * 8, "the direct scatter's two cell tables");
+
 // pass 0: count (+ R, mailbox); pass 1: scatter of the entries to their (supertile, slab) lists
 hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
                                 uint32_t* mail, uint32_t seq, int pass, uint32_t cap, const uint32_t* hints)
@@ -1022,11 +1081,20 @@ hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomVi
     a.sl_ent = pass == 1 ? b.keys : nullptr;
     a.ctrl = im.ctrl; a.mail = mail; a.seq = seq; a.cap = cap;
     const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
-    const size_t lds = (size_t)a.sh.NS * a.sh.K * 2 * sizeof(uint32_t);
+    // staging (scatter pass, from 1024 cells on): what is left of the CU's LDS behind the three cell tables, 10 bytes per entry
+    const int cells = a.sh.NS * a.sh.K;
+    static const int env_stage = [] { const char* e = getenv("GFT_SUPER_STAGE"); return e ? atoi(e) : 1; }();
+    a.stage_cap = 0;
+    if (pass == 1 && env_stage && cells >= 1024 && cells <= 4096) {
+        const size_t room = SUPER_SCATTER_LDS - ((size_t)cells * 12 + 8);
+        a.stage_cap = (uint32_t)((room / 10) & ~(size_t)3);
+    }
+    const size_t lds = a.stage_cap ? (size_t)cells * 12 + 8 + (size_t)a.stage_cap * 10
+                                   : (size_t)cells * 2 * sizeof(uint32_t);
     {
         static std::atomic<uint64_t> done[2];
         hipError_t e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<0>), (size_t)GFT_SUPER_CELLS * 8, done[0]);
-        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<1>), (size_t)GFT_SUPER_CELLS * 8, done[1]);
+        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<1>), SUPER_SCATTER_LDS, done[1]);
         if (e != hipSuccess) return e;
     }
     if (pass == 0) hipLaunchKernelGGL(k_super_bin<0>, dim3(blocks), dim3(BIN_THREADS), lds, s, a);
