@@ -87,7 +87,7 @@ struct SuperArgs {
     uint32_t stage_cap;
 };
 
-template <int PASS>      // 0: count (+ R, mailbox), 1: scatter
+template <int PASS, bool STAGED = false>      // 0: count (+ R, mailbox), 1: scatter (STAGED: through LDS, big tile grids)
 __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sb_dyn[];
@@ -255,9 +255,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
     uint32_t* s_stage_cell_base = sb_dyn + 3 * cells;                  // staging area: entries, then their cells
     uint64_t* stage_ent = reinterpret_cast<uint64_t*>(s_stage_cell_base + (cells & 1));
     uint16_t* stage_cell = reinterpret_cast<uint16_t*>(stage_ent + a.stage_cap);
-    bool staged = false;
     uint32_t n_wg = 0;
-    if (a.stage_cap) {
+    if (STAGED) {
         // exclusive scan of the cell counts (PERC consecutive cells per thread)
         const int PERC = (cells + BIN_THREADS - 1) / BIN_THREADS;
         const int c0 = tid * PERC;
@@ -280,7 +279,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         for (int k = 0; k < PERC; k++)
             if (c0 + k < cells) { s_loc[c0 + k] = run; run += s_cnt[c0 + k]; }
         n_wg = min(tot, a.stage_cap);                                // (entries past the staging area go the direct way)
-        staged = true;
         __syncthreads();
     }
     for (int i = tid; i < cells; i += BIN_THREADS) {
@@ -305,8 +303,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
                 const uint32_t hi = x0 | (y0 << 5) | (x1 << 10) | (y1 << 15) | (bin[u] << 20);
                 const uint32_t rank = atomicAdd(&s_cnt[cell], 1u);
                 const uint64_t e = ((uint64_t)hi << 32) | idx;
-                const uint32_t pos = staged ? s_loc[cell] + rank : ~0u;
-                if (pos < a.stage_cap) {
+                const uint32_t pos = STAGED ? s_loc[cell] + rank : ~0u;
+                if (STAGED && pos < a.stage_cap) {
                     stage_ent[pos] = e;
                     stage_cell[pos] = (uint16_t)cell;
                 } else {
@@ -314,7 +312,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
                 }
             }
     }
-    if (staged) {
+    if (STAGED) {
         __syncthreads();
         for (uint32_t i = (uint32_t)tid; i < n_wg; i += BIN_THREADS) {
             const uint32_t cell = stage_cell[i];
@@ -1092,12 +1090,14 @@ hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomVi
     const size_t lds = a.stage_cap ? (size_t)cells * 12 + 8 + (size_t)a.stage_cap * 10
                                    : (size_t)cells * 2 * sizeof(uint32_t);
     {
-        static std::atomic<uint64_t> done[2];
+        static std::atomic<uint64_t> done[3];
         hipError_t e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<0>), (size_t)GFT_SUPER_CELLS * 8, done[0]);
-        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<1>), SUPER_SCATTER_LDS, done[1]);
+        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<1>), (size_t)GFT_SUPER_CELLS * 8, done[1]);
+        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<1, true>), SUPER_SCATTER_LDS, done[2]);
         if (e != hipSuccess) return e;
     }
     if (pass == 0) hipLaunchKernelGGL(k_super_bin<0>, dim3(blocks), dim3(BIN_THREADS), lds, s, a);
+    else if (a.stage_cap) hipLaunchKernelGGL((k_super_bin<1, true>), dim3(blocks), dim3(BIN_THREADS), lds, s, a);
     else hipLaunchKernelGGL(k_super_bin<1>, dim3(blocks), dim3(BIN_THREADS), lds, s, a);
     return hipGetLastError();
 }

@@ -29,7 +29,9 @@ ALL_STAGES = ("preprocess_fwd", "tile_count", "tile_scatter", "tile_sort", "rend
 
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-    return n if n.startswith("k_super_bin<") else n.split("<")[0]      # (the two passes of k_super_bin are two stages)
+    if n.startswith("k_super_bin<"):                                    # (the two passes of k_super_bin are two stages;
+        return "k_super_bin<%s>" % n[len("k_super_bin<")]               #  k_super_bin<1, true> = the scatter pass through LDS)
+    return n.split("<")[0]
 
 
 def source_sha():
