@@ -13,6 +13,10 @@ from gftorf_amd import _lib  # noqa: E402
 if os.environ.get("GFT_ABL_LIB"):
     _lib.LIB_PATH = os.path.join(ROOT, os.environ["GFT_ABL_LIB"])
     print("library:", _lib.LIB_PATH, file=sys.stderr)
+    if os.environ.get("GFT_ABL_ANY_ABI"):
+        # (an older build whose argument blocks are the same: A/B across an ABI bump that only changed what a buffer holds)
+        import ctypes
+        _lib.ABI_VERSION = ctypes.CDLL(_lib.LIB_PATH).gft_abi_version()
 import bench  # noqa: E402
 
 bench.main()
