@@ -1300,6 +1300,20 @@ def main():
     else:
         while time.perf_counter() - t_spin < args.spin_up:
             step()
+        sync()
+        # ... and until two consecutive chunks of 16 steps take the same time to 1 % (at most 1.5 s more): the ramp is not
+        # equally long on every box / after every idle period (a default run read 0.4265 ms over its timed leg with a median of
+        # 0.3884 in the leg behind it; 80 legs of 20 steps on another box: 0.387-0.390, one at 0.407)
+        prev = None
+        while time.perf_counter() - t_spin < args.spin_up + 1.5:
+            t0 = time.perf_counter()
+            for _ in range(16):
+                step()
+            sync()
+            cur = time.perf_counter() - t0
+            if prev is not None and abs(cur - prev) <= 0.01 * prev:
+                break
+            prev = cur
     sync()
 
     elapsed = timed_steps(step, args.steps, args.warmup, sync, dist)
