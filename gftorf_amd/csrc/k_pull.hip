@@ -773,7 +773,6 @@ struct TailArgs {
     uint32_t cap;
     const uint32_t* __restrict__ quad_max;
     uint32_t* __restrict__ order;
-    uint32_t* __restrict__ weights_out;      // the caller's tile_weights (may be NULL): every quadrant's walk length of this frame
     int dbg;
 };
 
@@ -802,25 +801,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
     const int T = a.sh.T;
     // The backward's heavy-first tile order rides on this launch (no separate launch in the backward): by the deepest
     // contributors of the first render pass; a tile with a flagged quadrant, whose walk goes on, counts as heaviest.
-    if (a.order && blockIdx.x == 0) {
+    // (not where the frame has the forward's order -- by the walk lengths of the camera's previous frame --: the backward
+    // deals by that one, and this launch has nothing to do on a frame that flagged nothing)
+    if (a.order && blockIdx.x == 0 && a.ctrl[GFT_CTRL_FWDORDER] == 0u) {
         gft_tile_order_block(T, a.quad_max, a.order, nflag ? a.unit_flag : nullptr);
         if (threadIdx.x == 0) a.ctrl[GFT_CTRL_ORDER_OK] = 1u;
-    }
-    // ... and the quadrants' walk lengths go to the caller, for the forward of this camera's next frame (a flagged quadrant,
-    // whose walk goes on in the resume pass, counts as the longest)
-    if (a.weights_out && blockIdx.x == 0) {
-        for (int t = threadIdx.x; t < T; t += TAIL_THREADS) {
-            uint4 w = reinterpret_cast<const uint4*>(a.quad_max)[t];
-            if (nflag) {
-                const uint4 f = reinterpret_cast<const uint4*>(a.unit_flag)[t];
-                if (f.x) w.x = 0xfffffffeu;
-                if (f.y) w.y = 0xfffffffeu;
-                if (f.z) w.z = 0xfffffffeu;
-                if (f.w) w.w = 0xfffffffeu;
-            }
-            reinterpret_cast<uint4*>(a.weights_out)[t] = w;
-        }
-        if (threadIdx.x == 0) a.weights_out[4 * T] = 1u;
     }
     if (nflag == 0u) return;                                 // the common case: every quadrant saturated inside its head
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1136,7 +1121,6 @@ hipError_t gft_launch_tail_build(hipStream_t s, const gft_config& c, const gft_f
     a.front_len = im.front_len; a.unit_flag = im.unit_flag; a.tile_cut = im.tile_cut;
     a.ctrl = im.ctrl; a.cap = cap;
     a.quad_max = im.tile_max; a.order = want_order ? im.tile_order : nullptr;
-    a.weights_out = gft_fwd_ordered(a.sh.T) ? io.tile_weights : nullptr;
     static const int tdbg = [] { const char* e = getenv("GFT_TAIL_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = tdbg;
     const size_t lds = (size_t)SORT_SLOTS(TAIL_LDS_KEYS) * 8;

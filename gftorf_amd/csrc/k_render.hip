@@ -129,6 +129,9 @@ struct RenderFwdArgs {
     // first pass with a caller-kept schedule: the heavy-first tile order k_appearance derived for this frame (NULL: none)
     const uint32_t* __restrict__ fwd_order;
     const uint32_t* __restrict__ fwd_order_ok;
+    // the caller's tile_weights (may be NULL): every quadrant leaves its walk length there for the camera's next frame (the
+    // first pass: a flagged quadrant the longest there is, until its resume pass writes the final one), word 4 T = "valid"
+    uint32_t* __restrict__ weights_out;
 };
 
 __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
@@ -360,6 +363,11 @@ __global__ __launch_bounds__(64) void k_render_fwd(RenderFwdArgs a)
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
     if (lane == 0) a.quad_max[v] = mx;
+    if (a.weights_out && lane == 0) {
+        const bool open = !a.resume && (head < full || more) && done_m != ~0ull;
+        a.weights_out[v] = open ? 0xfffffffeu : mx;
+        if (v == 0 && !a.resume) a.weights_out[4 * a.T] = 1u;
+    }
     if (a.hint_out && !a.resume && lane == 0) {
         const bool flagged = (head < full || more) && done_m != ~0ull;
         a.hint_out[v] = (flagged || (head > 1024 && mx > GFT_HEAD_TARGET)) ? 1 : 0;
@@ -841,6 +849,10 @@ struct RenderBwdArgs {
     const uint32_t* __restrict__ quad_max;
     const uint32_t* __restrict__ order;     // tiles, heaviest first
     const uint32_t* __restrict__ order_ok;  // ctrl word: the forward computed `order` (NULL: it is valid)
+    // the order the forward blend dealt its own waves in (by the walk lengths of this camera's previous frame: k_appearance);
+    // where the frame has one, the backward deals by it too and k_tail_build derives none
+    const uint32_t* __restrict__ order_fwd;
+    const uint32_t* __restrict__ order_fwd_ok;
     const float* __restrict__ g_color; const float* __restrict__ g_phasor; const float* __restrict__ g_depth;
     const float* __restrict__ g_acc; const float* __restrict__ g_dd;
     const uint32_t* __restrict__ ctrl;   // the forward's ctrl words
@@ -959,8 +971,10 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     const int xcd = bid & 7, qslot = bid >> 3;
     const int rank = 8 * (qslot >> 2) + xcd;
     if (rank >= a.T) return;
-    const bool ordered = a.order && (a.order_ok == nullptr || *a.order_ok != 0u);
-    const int v_unit = (int)(ordered ? a.order[rank] : (uint32_t)rank) * 4 + (qslot & 3);
+    const uint32_t* order = a.order;
+    bool ordered = order && (a.order_ok == nullptr || *a.order_ok != 0u);
+    if (order && a.order_fwd && *a.order_fwd_ok != 0u) { order = a.order_fwd; ordered = true; }
+    const int v_unit = (int)(ordered ? order[rank] : (uint32_t)rank) * 4 + (qslot & 3);
     const int tmax = (int)a.quad_max[v_unit];
     if (tmax == 0) return;
     // cuts: at multiples of GFT_SEG_LEN in front of tmax that the forward's first pass walked over (it saved no state
@@ -1257,6 +1271,7 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     const bool ordered = pull && lazy == 1 && io.tile_weights != nullptr && gft_fwd_ordered(a.T);
     a.fwd_order = ordered ? im.tile_cursor : nullptr;
     a.fwd_order_ok = im.ctrl + GFT_CTRL_FWDORDER;
+    a.weights_out = (pull && lazy != 0 && gft_fwd_ordered(a.T)) ? io.tile_weights : nullptr;
     const int blocks = ordered ? 32 * ((a.T + 7) / 8) : 8 * ((a.T * 4 + 7) / 8);
     // segmented: up to FSEG_WAVES waves per quadrant (first pass only; the resume pass of flagged quadrants stays one
     // wave per quadrant).  GFT_FWD_SEG=0 / 1 in the environment forces one of the two kernels for every frame.
@@ -1298,6 +1313,8 @@ hipError_t gft_launch_render_bwd(hipStream_t s, const gft_config& c, const gft_b
     // with the lazy sort the forward's k_tile_tail launch has computed the order (unless a quadrant was flagged: the
     // deepest contributors were not final then; those frames walk in tile order)
     a.order_ok = lazy ? im.ctrl + GFT_CTRL_ORDER_OK : nullptr;
+    a.order_fwd = lazy ? im.tile_cursor : nullptr;          // (tile-pull binning: see gft_launch_appearance)
+    a.order_fwd_ok = im.ctrl + GFT_CTRL_FWDORDER;
     if (order_on && !lazy) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, a.T, im.tile_max, im.tile_order);
     a.pix_sums = im.pix_sums;
     static const int split_on = [] { const char* e = getenv("GFT_BWD_SPLIT"); return e ? atoi(e) != 0 : 1; }();

@@ -148,8 +148,8 @@ typedef struct gft_forward_io {
     uint32_t* tile_hints;
     /* optional, beside tile_hints (same owner, same lifetime, zero before the first use): uint32[4 T + 4].  The forward
      * leaves every 8x8 quadrant's walk length there (and sets word 4 T to 1); the next forward of this image size and
-     * camera deals its quadrant waves to the chip heaviest tile first by those lengths, as the backward always does by the
-     * lengths of its own frame -- all quadrant waves of a 640x480 frame are resident together, so the order decides which
+     * camera deals its quadrant waves to the chip heaviest tile first by those lengths -- and so does that frame's
+     * backward, which otherwise goes by the lengths of its own frame -- all quadrant waves of a 640x480 frame are resident together, so the order decides which
      * waves share a SIMD, and equal shares end together.  The order is derived anew on the device from whatever the words
      * hold (any contents give a permutation of the tiles): a schedule, never a result.  Neither read nor written on frames
      * of more than 4096 tiles (their many rounds of waves balance by themselves, and image order keeps neighbouring tiles on
