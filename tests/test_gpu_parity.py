@@ -543,6 +543,11 @@ BIN_CASES = {
     # thin lists of ~1500 entries over an image that ends inside its last quadrants: segments with the backward's cuts
     # inside them, blended speculatively, with lanes outside the image (their snapshots must not carry a zero transmittance)
     "ragged_thin_deep": dict(P=6000, W=50, H=37, scale_lo=0.03, scale_hi=0.2, opacity=0.04),
+    # a tile grid of 2040 (supertile, slab) cells: the scatter pass groups a workgroup's entries by cell in LDS -- all of them
+    # (small splats: a few thousand entries per workgroup) or the first ~13.9 k with the rest written directly (large splats:
+    # ~45 supertiles per Gaussian)
+    "big_grid_small_splats": dict(P=20000, W=1920, H=1080, scale_lo=0.003, scale_hi=0.02),
+    "big_grid_large_splats": dict(P=6000, W=1920, H=1080, scale_lo=0.02, scale_hi=0.12, opacity=0.2),
 }
 
 
