@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 DEFORM_MAX_INPUTS = 96          # GFT_DEFORM_MAX_INPUTS (include/gftorf_deform.h)
 ACC_STRIDE = 16
 
@@ -63,7 +63,8 @@ PROFILE_FIELDS = ["preprocess_fwd_ms", "tile_count_ms", "tile_scatter_ms", "tile
 
 
 class ForwardIO(C.Structure):
-    _fields_ = [(n, _fp) for n in FORWARD_FIELDS] + [("grads_zero", _fp), ("grads_zero_bytes", C.c_size_t), ("tile_hints", _fp), ("tile_weights", _fp)]
+    _fields_ = [(n, _fp) for n in FORWARD_FIELDS] + [("grads_zero", _fp), ("grads_zero_bytes", C.c_size_t), ("tile_hints", _fp), ("tile_weights", _fp),
+                                                           ("cell_sched", _fp)]
 
 
 class BackwardIO(C.Structure):
@@ -76,12 +77,14 @@ class Layout(C.Structure):
 
 class ForwardHints(C.Structure):
     """gft_forward_hints"""
-    _fields_ = [("binning_instances", C.c_int64), ("max_tile_list", C.c_int64), ("whole_lists", C.c_int64)]
+    _fields_ = [("binning_instances", C.c_int64), ("max_tile_list", C.c_int64), ("whole_lists", C.c_int64),
+                ("use_cell_sched", C.c_int64)]
 
 
 class ForwardReport(C.Structure):
     """gft_forward_report"""
-    _fields_ = [("num_rendered", C.c_int64), ("max_tile_list", C.c_int64), ("list_entries", C.c_int64), ("hinted_tiles", C.c_int64)]
+    _fields_ = [("num_rendered", C.c_int64), ("max_tile_list", C.c_int64), ("list_entries", C.c_int64), ("hinted_tiles", C.c_int64),
+                ("sched_misses", C.c_int64)]
 
 
 class Profile(C.Structure):
@@ -128,7 +131,7 @@ class AdamTensor(C.Structure):
                 ("step", C.c_int64)]
 
 EXPORTS = [
-    "gft_abi_version", "gft_lazy_sort", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_binning_bytes", "gft_acc_bytes",
+    "gft_abi_version", "gft_lazy_sort", "gft_last_error", "gft_geom_bytes", "gft_image_bytes", "gft_cell_sched_words", "gft_binning_bytes", "gft_acc_bytes",
     "gft_det_partials_bytes", "gft_get_layout", "gft_binning_capacity", "gft_set_binning_mode", "gft_binning_mode", "gft_set_render_mode", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_forward_enqueue", "gft_backward", "gft_grads_rezero",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
@@ -158,6 +161,8 @@ def load():
     lib.gft_geom_bytes.argtypes = [C.c_int32]
     lib.gft_image_bytes.restype = C.c_size_t
     lib.gft_image_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.gft_cell_sched_words.restype = C.c_size_t
+    lib.gft_cell_sched_words.argtypes = [C.c_int32, C.c_int32]
     lib.gft_binning_bytes.restype = C.c_size_t
     lib.gft_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.gft_acc_bytes.restype = C.c_size_t

@@ -79,6 +79,11 @@ _TILE_HINTS = _os.environ.get("GFT_TILE_HINTS", "1") != "0"
 _TILE_HINTS_PER_CAMERA = _os.environ.get("GFT_TILE_HINTS_PER_CAMERA", "1") != "0"
 _tile_hints = {}
 _tile_weights = {}
+_cell_sched = {}
+_cell_sched_seen = set()       # cameras whose schedule a counted frame has written
+_cell_sched_streak = {}        # consecutive frames whose lists did not fit the schedule
+_CELL_SCHED = _os.environ.get("GFT_CELL_SCHED", "1") != "0"
+_force_cell_sched = None       # tests: True = bin by whatever the words hold
 _FWD_ORDER = _os.environ.get("GFT_FWD_ORDER", "1") != "0"
 # ... and how many tiles the schedule marked when the shape's last frame read it (gft_forward_report.hinted_tiles): from a
 # sixteenth of the tiles on the next forward runs the build of the pull kernel that sorts hinted tiles' whole lists
@@ -509,7 +514,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                       _p0(rot_c), _p0(cov_c), view_c.data_ptr(), proj_c.data_ptr(), campos_c.data_ptr(), _p0(sh_c), _p0(sh_p_c),
                       geom.data_ptr(), img.data_ptr(), 0,
                       pl, pl + 3 * hw4, pl + 10 * hw4, pl + 11 * hw4, pl + 14 * hw4, pl + 15 * hw4, pl + 16 * hw4, pl + 17 * hw4,
-                      pixels.data_ptr() if P else 0, pl + 18 * hw4, radii.data_ptr() if P else 0, 0, 0, 0, 0, 0)
+                      pixels.data_ptr() if P else 0, pl + 18 * hw4, radii.data_ptr() if P else 0, 0, 0, 0, 0, 0, 0)
     # the backward's accumulator: cleared by the forward beside its binning kernels -- unless it comes from the pool of
     # buffers that the last backward left zero (_AccLease)
     lease = None
@@ -561,6 +566,18 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         io.tile_hints = _ptr(tile_hints)
         # ... and beside it the quadrants' walk lengths of the camera's last frame, by which the forward blend deals its waves
         # heaviest tile first (gft_forward_io.tile_weights)
+        # ... and the camera's list schedule: where the (supertile, slab) lists of its next frame start and how much they hold,
+        # left on the device by every frame's binning front end; from the camera's second frame on the forward appends to those
+        # lists directly and runs no count pass (gft_forward_io.cell_sched; GFT_CELL_SCHED=0 off)
+        use_sched = 0
+        if tile_hints is not None and _CELL_SCHED:
+            cs = _cell_sched.get(tiles_key)
+            if cs is None and not capturing:
+                words = int(lib.gft_cell_sched_words(W, H))
+                cs = _cell_sched[tiles_key] = torch.zeros((words,), device=dev, dtype=torch.int32) if words else False
+            if cs is not None and cs is not False:
+                io.cell_sched = cs.data_ptr()
+                use_sched = int(_force_cell_sched if _force_cell_sched is not None else (tiles_key in _cell_sched_seen))
         if tile_hints is not None and _FWD_ORDER:
             tw = _tile_weights.get(tiles_key)
             if tw is None and not capturing:
@@ -620,10 +637,21 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
                     hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
-                                              whole_lists=_whole_lists(tiles_key, n_tiles))
+                                              whole_lists=_whole_lists(tiles_key, n_tiles), use_cell_sched=use_sched)
                     report = _lib.ForwardReport()
                     _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), C.byref(hints), C.byref(report)))
                     R = int(report.num_rendered)
+                    if use_sched:
+                        # (a camera whose lists keep outgrowing what its last frame left -- its tensors shared by scenes of
+                        # different sizes, say -- pays the counted flow ON TOP of the failed attempt: after four misses in a row
+                        # it goes back to counting)
+                        if report.sched_misses:
+                            last_call_stats["sched_misses"] = last_call_stats.get("sched_misses", 0) + 1
+                            _cell_sched_streak[tiles_key] = _cell_sched_streak.get(tiles_key, 0) + 1
+                            if _cell_sched_streak[tiles_key] >= 4 and _force_cell_sched is None:
+                                _cell_sched[tiles_key] = False
+                        else:
+                            _cell_sched_streak[tiles_key] = 0
                     _hinted_tiles[tiles_key] = int(report.hinted_tiles)
                     max_list.value = int(report.max_tile_list)
                     if R > cap:
@@ -644,6 +672,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
             raise ex
+    if P and io.cell_sched:
+        _cell_sched_seen.add(tiles_key)
     if prep is not None:
         prep["cap"] = cap
     if lease is not None:

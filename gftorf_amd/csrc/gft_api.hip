@@ -150,6 +150,14 @@ extern "C" size_t gft_image_bytes(int32_t W, int32_t H)
     return L.img_total + GFT_ALIGN;
 }
 
+extern "C" size_t gft_cell_sched_words(int32_t W, int32_t H)
+{
+    gft_config c;
+    memset(&c, 0, sizeof(c));
+    c.W = W; c.H = H; c.near_n = 0.01f; c.far_n = 100.f;
+    return (W > 0 && H > 0 && gft_tile_pull_ok(c)) ? gft_cell_sched_words_of(c) : 0;
+}
+
 extern "C" size_t gft_binning_bytes(int64_t R, int32_t W, int32_t H)
 {
     gft_layout L;
@@ -442,8 +450,12 @@ int gft_render_mode()
 }
 
 // preprocess + instance counting; the totals arrive in the mailbox slot
+static int enqueue_count(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g, const ImgView& im,
+                         uint32_t* mail_dev, uint32_t seq, bool pull);
+
+// `count` = false: geometry only; the scatter pass of stage 2 bins by the caller's list schedule and posts the totals
 static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
-                          const ImgView& im, uint32_t* mail_dev, uint32_t seq, bool pull)
+                          const ImgView& im, uint32_t* mail_dev, uint32_t seq, bool pull, bool count = true)
 {
     {
         // (the preprocess kernel also zeroes the ctrl words, the tile counters and the supertile tables for the binning
@@ -464,17 +476,21 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
         GFT_CHECK_HIP(hipEventRecord(f->filled, f->stream));
         f->pending = true;
     }
-    {
-        StageTimer t(s, ST_TILE_COUNT);
-        if (pull) {
-            BinView none;
-            none.keys = nullptr; none.point_list = nullptr;
-            const int T = ((cfg->W + GFT_TILE_X - 1) / GFT_TILE_X) * ((cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y);
-            GFT_STAGE(s, cfg, "super_count", gft_launch_super_bin(s, *cfg, g, im, none, mail_dev, seq, 0, 0u,
-                                                                  gft_fwd_segmented(T) ? nullptr : io->tile_hints));
-        } else {
-            GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im, mail_dev, seq));
-        }
+    return count ? enqueue_count(s, cfg, io, g, im, mail_dev, seq, pull) : 0;
+}
+
+static int enqueue_count(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g, const ImgView& im,
+                         uint32_t* mail_dev, uint32_t seq, bool pull)
+{
+    StageTimer t(s, ST_TILE_COUNT);
+    if (pull) {
+        BinView none;
+        none.keys = nullptr; none.point_list = nullptr;
+        const int T = ((cfg->W + GFT_TILE_X - 1) / GFT_TILE_X) * ((cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y);
+        GFT_STAGE(s, cfg, "super_count", gft_launch_super_bin(s, *cfg, g, im, none, mail_dev, seq, 0, 0u,
+                                                              gft_fwd_segmented(T) ? nullptr : io->tile_hints, io->cell_sched));
+    } else {
+        GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im, mail_dev, seq));
     }
     return 0;
 }
@@ -483,7 +499,7 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
 // count against it and do nothing on overflow.
 static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
                           const ImgView& im, const BinView& b, bool binned, int64_t max_tile_list, bool check_cap,
-                          uint32_t cap, bool pull, bool whole_lists)
+                          uint32_t cap, bool pull, bool whole_lists, uint32_t* sched_mail = nullptr, uint32_t sched_seq = 0u)
 {
     // The backward's accumulator clear (64 B per Gaussian of pure HBM writes) rides along with the
     // per-tile sort kernels, whose workgroups are bound by LDS and VALU: each writes a slice of zeros first.
@@ -496,7 +512,14 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
         // Gaussians in a head get their appearance
         {
             StageTimer t(s, ST_TILE_SCATTER);
-            GFT_STAGE(s, cfg, "super_scatter", gft_launch_super_bin(s, *cfg, g, im, b, nullptr, 0u, 1, cap));
+            if (sched_mail) {
+                // no count pass ran: the entries go where the caller's list schedule puts them, this pass posts the totals
+                const int T0 = ((cfg->W + GFT_TILE_X - 1) / GFT_TILE_X) * ((cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y);
+                GFT_STAGE(s, cfg, "super_append", gft_launch_super_bin(s, *cfg, g, im, b, sched_mail, sched_seq, 2, cap,
+                                                                       gft_fwd_segmented(T0) ? nullptr : io->tile_hints, io->cell_sched));
+            } else {
+                GFT_STAGE(s, cfg, "super_scatter", gft_launch_super_bin(s, *cfg, g, im, b, nullptr, 0u, 1, cap));
+            }
         }
         {
             StageTimer t(s, ST_TILE_SORT);
@@ -627,7 +650,9 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     uint32_t* mail_dev; volatile uint32_t* mail_host; uint32_t seq;
     if (mailbox_acquire(&mail_dev, &mail_host, &seq)) return 1;
     const bool pull = pull_enabled(cfg);
-    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq, pull)) return 1;
+    // with a list schedule of this camera's earlier frame: no count pass, the scatter pass appends by it and posts the totals
+    const bool by_sched = pull && binning_instances > 0 && io->cell_sched != nullptr && hints->use_cell_sched != 0;
+    if (enqueue_stage1(s, cfg, io, g, im, mail_dev, seq, pull, !by_sched)) return 1;
     if (pull && binning_instances == 0) {
         // (no buffer: stage 2 renders empty lists, which is right only if R turns out to be 0 -- else the caller re-runs it)
         const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
@@ -635,10 +660,29 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     }
     // stage 2 is queued before R is known; its kernels check R against the buffer themselves
     const uint32_t cap = (uint32_t)binning_instances;
-    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, cap, pull, hints->whole_lists != 0))
+    if (enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, cap, pull, hints->whole_lists != 0,
+                       by_sched ? mail_dev : nullptr, seq))
         return 1;
     uint32_t host[GFT_CTRL_WORDS];
     if (mailbox_wait(s, mail_host, seq, host)) return 1;
+    if (by_sched && ((host[GFT_CTRL_FLAGS] & 2u) || host[GFT_CTRL_TOTAL] > cap)) {
+        // A list outgrew the schedule's capacity (or the words were no schedule): the device has binned and rendered nothing
+        // (ctrl[TOTAL] = 0xffffffff stopped every kernel behind the scatter pass).  The counted flow, in this call: clear what
+        // the front end accumulates into, count (which also leaves the next frame's schedule), stage 2 again.
+        const size_t T = (size_t)((cfg->W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y);
+        GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, (GFT_CTRL_WORDS + GFT_TICKET_WORDS + 2 * T + GFT_SUPER_CELLS) * sizeof(uint32_t), s));
+        if (mailbox_acquire(&mail_dev, &mail_host, &seq)) return 1;
+        mail_host[GFT_CTRL_FLAGS] = host[GFT_CTRL_FLAGS] & 1u;
+        // (... or the frame has more instances than the binning buffer holds: the caller's gft_forward_render with a larger one
+        // needs the counted lists' tables as well)
+        const bool render_again = host[GFT_CTRL_TOTAL] <= cap;
+        if (enqueue_count(s, cfg, io, g, im, mail_dev, seq, pull)) return 1;
+        if (render_again &&
+            enqueue_stage2(s, cfg, io, g, im, b, true, hints->max_tile_list, true, cap, pull, hints->whole_lists != 0))
+            return 1;
+        if (mailbox_wait(s, mail_host, seq, host)) return 1;
+        report->sched_misses = 1;
+    }
     if (host[GFT_CTRL_FLAGS] & 1u)
         return gft_fail("Point is filtered although prefiltered is set. This shouldn't happen!");
     report->num_rendered = (int64_t)host[GFT_CTRL_TOTAL];

@@ -180,7 +180,9 @@ bool gft_tile_pull_ok(const gft_config& c);      // the frame's tile grid fits t
 struct SuperShape { int gx, gy, T, sshift, sgx, sgy, NS, K, kshift; uint32_t near_bits; int bin_shift; };
 SuperShape gft_super_shape(const gft_config& c);
 hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
-                                uint32_t* mail, uint32_t seq, int pass, uint32_t cap, const uint32_t* hints = nullptr);
+                                uint32_t* mail, uint32_t seq, int pass, uint32_t cap, const uint32_t* hints = nullptr,
+                                uint32_t* sched = nullptr);
+size_t gft_cell_sched_words_of(const gft_config& c);
 hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
                                 uint32_t cap, float* clear, size_t clear_bytes, const uint32_t* hints, bool whole_lists);
 hipError_t gft_launch_tail_build(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,

@@ -85,9 +85,54 @@ struct SuperArgs {
     // 16-bit cell each behind the three cell tables) and leave as runs of consecutive lanes.  0: every entry is written
     // from where it was made.
     uint32_t stage_cap;
+    // The caller's list schedule of this camera (gft_forward_io.cell_sched; may be NULL): start[cells] | capacity[cells] |
+    // {cells, valid}.  Pass 0 (and pass 2) leave the next frame's there: every list's count of this frame plus a quarter
+    // plus 64, starts = their prefix sums.  Pass 2 = the scatter WITHOUT a count pass in front of it: entries are appended to
+    // the lists where the schedule puts them; a list that outgrew its capacity (or a schedule that is not one) makes the
+    // frame's binning invalid -- ctrl[TOTAL] = 0xffffffff, every later kernel of the frame returns, the host runs the
+    // counted flow.  Whatever the words hold, nothing is written outside the entry array and nothing wrong is rendered.
+    uint32_t* sched;
 };
 
-template <int PASS, bool STAGED = false>      // 0: count (+ R, mailbox), 1: scatter (STAGED: through LDS, big tile grids)
+// next frame's schedule from this frame's list counts (all threads of one workgroup; counts read with device-scope loads)
+__device__ inline void super_write_sched(uint32_t* sched, const uint32_t* counts, int cells, uint32_t* s_wt, uint32_t* s_carry)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = 4;
+    if (tid == 0) *s_carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < cells; c0 += PER * BIN_THREADS) {
+        const int first = c0 + tid * PER;
+        uint32_t cap[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const uint32_t c = first + k < cells ? __hip_atomic_load(&counts[first + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            cap[k] = first + k < cells ? c + (c >> 2) + 64u : 0u;
+            sum += cap[k];
+        }
+        uint32_t x = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_wt[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += s_wt[w];
+        const uint32_t carry = *s_carry;
+        uint32_t run = carry + woff + x - sum;
+#pragma unroll
+        for (int k = 0; k < PER; k++)
+            if (first + k < cells) { sched[first + k] = run; sched[cells + first + k] = cap[k]; run += cap[k]; }
+        __syncthreads();
+        if (tid == BIN_THREADS - 1) *s_carry = carry + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0) { sched[2 * cells] = (uint32_t)cells; sched[2 * cells + 1] = 1u; }
+}
+
+template <int PASS, bool STAGED = false>      // 0: count (+ R, mailbox), 1: scatter (STAGED: through LDS, big tile grids), 2: scatter by the caller's schedule, no count pass
 __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sb_dyn[];
@@ -102,6 +147,14 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
     for (int i = tid; i < cells; i += BIN_THREADS) s_cnt[i] = 0;
     if (tid == 0) s_sum = 0;
     __syncthreads();
+    if (PASS == 2 && blockIdx.x == 0 && a.hints) {
+        // (pass 2, on the side and up front: the schedule's marked tiles for the host -- the workgroup that closes the pass has
+        // the frame's critical path behind it)
+        uint32_t nh = 0;
+        for (int t = tid; t < a.sh.T; t += BIN_THREADS) nh += a.hints[t] != 0u ? 1u : 0u;
+        nh = gft_wave_sum_u32_to_lane63(nh);
+        if (lane == 63 && nh) atomicAdd(&a.ctrl[GFT_CTRL_NHINT], nh);
+    }
     const int base = blockIdx.x * BIN_CHUNK;
     const int K = a.sh.K, sgx = a.sh.sgx, ss = a.sh.sshift;
     ushort4 r4[BIN_ITEMS];
@@ -125,7 +178,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         bin[u] = tiles ? gft_depth_bin(dbits[u], a.sh.near_bits, a.sh.bin_shift) : 0u;
         mine += tiles;
     }
-    if (PASS == 0) {
+    if (PASS != 1) {
         mine = gft_wave_sum_u32_to_lane63(mine);
         if (lane == 63 && mine) atomicAdd(&s_sum, mine);
     }
@@ -220,6 +273,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
             if (tid == BIN_THREADS - 1) s_carry = carry + woff + x;
             __syncthreads();
         }
+        const uint32_t entries_total = s_carry;
+        if (a.sched) super_write_sched(a.sched, a.st_cnt, cells, s_wt, &s_carry);
         // tiles the schedule marks (as the previous frame of the shape left it): the host picks the next frame's build of
         // k_tile_pull by it
         uint32_t nh = 0;
@@ -234,13 +289,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         if (tid == 0) {
             const uint32_t R = __hip_atomic_load(&a.ctrl[GFT_CTRL_RSUM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.ctrl[GFT_CTRL_TOTAL] = R;
-            a.ctrl[GFT_CTRL_ENTRIES] = s_carry;
+            a.ctrl[GFT_CTRL_ENTRIES] = entries_total;
             a.ctrl[GFT_CTRL_MAXCNT] = 0u;              // (the tile lists are never formed)
             a.ctrl[GFT_CTRL_NHINT] = a.hints ? s_sum : 0u;
             if (a.mail) {
                 a.mail[GFT_CTRL_TOTAL] = R;            // (GFT_CTRL_FLAGS of the slot belongs to the preprocess kernel)
                 a.mail[GFT_CTRL_MAXCNT] = 0u;
-                a.mail[GFT_CTRL_ENTRIES] = s_carry;
+                a.mail[GFT_CTRL_ENTRIES] = entries_total;
                 a.mail[GFT_CTRL_NHINT] = a.hints ? s_sum : 0u;
                 __hip_atomic_store(&a.mail[GFT_CTRL_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -283,7 +338,20 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
     }
     for (int i = tid; i < cells; i += BIN_THREADS) {
         const uint32_t c = s_cnt[i];
-        s_first[i] = c ? atomicAdd(&a.cur_copy[(size_t)(blockIdx.x & (a.copies - 1)) * cells + i], c) : 0u;
+        if (PASS == 2) {
+            // by the caller's schedule: the list of cell i starts at sched[i] and holds sched[cells + i] entries; this
+            // workgroup's chunk follows what the others have taken so far (plane 0 of the counters = the lists' lengths of
+            // this frame).  A chunk that does not fit is not written at all: the frame is rendered by the counted flow then.
+            uint32_t first = 0xffffffffu;
+            if (c) {
+                const uint32_t rel = atomicAdd(&a.cnt_copy[i], c);
+                const uint64_t st = a.sched[i], room = a.sched[cells + i];
+                if ((uint64_t)rel + c <= room && st + rel + c <= (uint64_t)a.cap) first = (uint32_t)(st + rel);
+            }
+            s_first[i] = first;
+        } else {
+            s_first[i] = c ? atomicAdd(&a.cur_copy[(size_t)(blockIdx.x & (a.copies - 1)) * cells + i], c) : 0u;
+        }
         s_cnt[i] = 0;
     }
     __syncthreads();
@@ -307,7 +375,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
                 if (STAGED && pos < a.stage_cap) {
                     stage_ent[pos] = e;
                     stage_cell[pos] = (uint16_t)cell;
-                } else {
+                } else if (PASS != 2 || s_first[cell] != 0xffffffffu) {
                     a.sl_ent[s_first[cell] + rank] = e;
                 }
             }
@@ -316,7 +384,61 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         __syncthreads();
         for (uint32_t i = (uint32_t)tid; i < n_wg; i += BIN_THREADS) {
             const uint32_t cell = stage_cell[i];
-            a.sl_ent[s_first[cell] + (i - s_loc[cell])] = stage_ent[i];
+            if (PASS != 2 || s_first[cell] != 0xffffffffu) a.sl_ent[s_first[cell] + (i - s_loc[cell])] = stage_ent[i];
+        }
+    }
+    if (PASS != 2) return;
+    // ---- pass 2: the workgroup that draws the last ticket closes the frame's binning front end (what the count pass's does)
+    if (tid == 0 && s_sum) atomicAdd(&a.ctrl[GFT_CTRL_RSUM], s_sum);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t G = min((uint32_t)GFT_TICKET_WORDS, gridDim.x), grp = blockIdx.x % G;
+        const uint32_t members = (gridDim.x - grp + G - 1u) / G;
+        uint32_t last = 0u;
+        if (atomicAdd(&a.ctrl[GFT_CTRL_WORDS + grp], 1u) == members - 1u)
+            last = atomicAdd(&a.ctrl[GFT_CTRL_DONE], 1u) == G - 1u ? 1u : 0u;
+        s_last = last;
+        s_sum = 0;                 // from here: the frame's entries
+        s_carry = 1;               // ... and "the schedule was one and every list fitted"
+    }
+    __syncthreads();
+    if (!s_last) return;
+    {
+        uint32_t ent = 0;
+        bool ok = a.sched[2 * cells] == (uint32_t)cells && a.sched[2 * cells + 1] == 1u;
+        for (int i = tid; i < cells; i += BIN_THREADS) {
+            const uint32_t c = __hip_atomic_load(&a.cnt_copy[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t st = a.sched[i], room = a.sched[cells + i];
+            const uint64_t nxt = i + 1 < cells ? (uint64_t)a.sched[i + 1] : (uint64_t)a.cap;
+            ok = ok && c <= room && st + room <= nxt;
+            a.st_cnt[i] = c;
+            a.st_start[i] = (uint32_t)st;
+            ent += c;
+        }
+        ent = gft_wave_sum_u32_to_lane63(ent);
+        if (lane == 63 && ent) atomicAdd(&s_sum, ent);
+        if (!ok) s_carry = 0;      // (any lane)
+        __syncthreads();
+    }
+    const uint32_t entries_total = s_sum;
+    const bool fits = s_carry != 0u;
+    __syncthreads();
+    super_write_sched(a.sched, a.st_cnt, cells, s_wt, &s_carry);
+    if (tid == 0) {
+        const uint32_t R = __hip_atomic_load(&a.ctrl[GFT_CTRL_RSUM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (workgroup 0 added them before it drew its ticket)
+        const uint32_t nhint = __hip_atomic_load(&a.ctrl[GFT_CTRL_NHINT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.ctrl[GFT_CTRL_TOTAL] = fits ? R : 0xffffffffu;       // (not binned: every later kernel of the frame returns on it)
+        a.ctrl[GFT_CTRL_ENTRIES] = entries_total;
+        a.ctrl[GFT_CTRL_MAXCNT] = 0u;
+        if (a.mail) {
+            a.mail[GFT_CTRL_TOTAL] = R;
+            a.mail[GFT_CTRL_MAXCNT] = 0u;
+            a.mail[GFT_CTRL_ENTRIES] = entries_total;
+            a.mail[GFT_CTRL_NHINT] = nhint;
+            if (!fits) __hip_atomic_fetch_or(&a.mail[GFT_CTRL_FLAGS], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&a.mail[GFT_CTRL_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -1045,12 +1167,18 @@ bool gft_tile_pull_ok(const gft_config& c) { return gft_super_shape(c).sshift <=
 constexpr size_t SUPER_SCATTER_LDS = 160 * 1024 - 256;
 static_assert(SUPER_SCATTER_LDS >= (size_t)GFT_SUPER_CELLS * 8, "the direct scatter's two cell tables");
 
-// pass 0: count (+ R, mailbox); pass 1: scatter of the entries to their (supertile, slab) lists
+// words of a camera's list schedule (gft_forward_io.cell_sched) at this image size: start | capacity per cell, {cells, valid, -, -}
+size_t gft_cell_sched_words_of(const gft_config& c) { const SuperShape sh = gft_super_shape(c); return 2 * (size_t)sh.NS * sh.K + 4; }
+
+// pass 0: count (+ R, mailbox); pass 1: scatter of the entries to their (supertile, slab) lists; pass 2: the scatter by the
+// caller's schedule, without a count pass in front (+ R, mailbox)
 hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
-                                uint32_t* mail, uint32_t seq, int pass, uint32_t cap, const uint32_t* hints)
+                                uint32_t* mail, uint32_t seq, int pass, uint32_t cap, const uint32_t* hints, uint32_t* sched)
 {
     SuperArgs a;
-    a.hints = pass == 0 ? hints : nullptr;
+    a.hints = pass != 1 ? hints : nullptr;
+    a.sched = pass != 1 ? sched : nullptr;
+    if (pass == 2 && !sched) return hipErrorInvalidValue;
     a.P = c.P;
     a.sh = gft_super_shape(c);
     a.rect = g.rect; a.depth = g.depth;
@@ -1061,27 +1189,31 @@ hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomVi
     while (a.copies > 1 && (size_t)a.copies * a.sh.NS * a.sh.K > (size_t)GFT_SUPER_CELLS) a.copies >>= 1;
     // the entry lists live in the key array (`cap` 8-byte slots: there are at most as many (Gaussian, supertile) pairs as
     // (Gaussian, tile) instances)
-    a.sl_ent = pass == 1 ? b.keys : nullptr;
+    a.sl_ent = pass != 0 ? b.keys : nullptr;
     a.ctrl = im.ctrl; a.mail = mail; a.seq = seq; a.cap = cap;
     const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
     // staging (scatter pass, from 1024 cells on): what is left of the CU's LDS behind the three cell tables, 10 bytes per entry
     const int cells = a.sh.NS * a.sh.K;
     static const int env_stage = [] { const char* e = getenv("GFT_SUPER_STAGE"); return e ? atoi(e) : 1; }();
     a.stage_cap = 0;
-    if (pass == 1 && env_stage && cells >= 1024 && cells <= 4096) {
+    if (pass != 0 && env_stage && cells >= 1024 && cells <= 4096) {
         const size_t room = SUPER_SCATTER_LDS - ((size_t)cells * 12 + 8);
         a.stage_cap = (uint32_t)((room / 10) & ~(size_t)3);
     }
     const size_t lds = a.stage_cap ? (size_t)cells * 12 + 8 + (size_t)a.stage_cap * 10
                                    : (size_t)cells * 2 * sizeof(uint32_t);
     {
-        static std::atomic<uint64_t> done[3];
+        static std::atomic<uint64_t> done[5];
         hipError_t e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<0>), (size_t)GFT_SUPER_CELLS * 8, done[0]);
         if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<1>), (size_t)GFT_SUPER_CELLS * 8, done[1]);
         if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<1, true>), SUPER_SCATTER_LDS, done[2]);
+        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<2>), (size_t)GFT_SUPER_CELLS * 8, done[3]);
+        if (e == hipSuccess) e = gft_lds_opt_in(reinterpret_cast<const void*>(&k_super_bin<2, true>), SUPER_SCATTER_LDS, done[4]);
         if (e != hipSuccess) return e;
     }
     if (pass == 0) hipLaunchKernelGGL(k_super_bin<0>, dim3(blocks), dim3(BIN_THREADS), lds, s, a);
+    else if (pass == 2 && a.stage_cap) hipLaunchKernelGGL((k_super_bin<2, true>), dim3(blocks), dim3(BIN_THREADS), lds, s, a);
+    else if (pass == 2) hipLaunchKernelGGL(k_super_bin<2>, dim3(blocks), dim3(BIN_THREADS), lds, s, a);
     else if (a.stage_cap) hipLaunchKernelGGL((k_super_bin<1, true>), dim3(blocks), dim3(BIN_THREADS), lds, s, a);
     else hipLaunchKernelGGL(k_super_bin<1>, dim3(blocks), dim3(BIN_THREADS), lds, s, a);
     return hipGetLastError();

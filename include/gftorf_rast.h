@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GFT_ABI_VERSION 10
+#define GFT_ABI_VERSION 11
 
 /* compile-time constants of the reference (RAST/cuda_rasterizer/config.h:15-23) */
 #define GFT_NUM_CHANNELS 3
@@ -155,6 +155,14 @@ typedef struct gft_forward_io {
      * of more than 4096 tiles (their many rounds of waves balance by themselves, and image order keeps neighbouring tiles on
      * one XCD's L2: measured) or with the segment-parallel forward.  NULL: tiles in image order. */
     uint32_t* tile_weights;
+    /* optional, tile-pull binning (same owner and lifetime as tile_hints, zero before the first use):
+     * uint32[gft_cell_sched_words(W, H)] -- where every (supertile, depth slab) list of the camera's next frame starts in the
+     * entry array and how many entries it may take: this frame's counts plus a quarter plus 64, written by whichever pass
+     * closes the frame's binning front end.  With gft_forward_hints.use_cell_sched the forward appends its entries to
+     * those lists directly and runs no count pass (14 us of a 0.38 ms step at 1 M Gaussians); a list that outgrows its
+     * capacity, or words that are no schedule, are found on the device: nothing is rendered from them, gft_forward runs the
+     * counted flow in the same call.  Any contents are safe.  NULL: count, then scatter, every frame. */
+    uint32_t* cell_sched;
 } gft_forward_io;
 
 /* Tensors of the backward call (RAST/rasterize_points.cu:167-198). */
@@ -284,6 +292,8 @@ const char* gft_last_error(void);   /* host string, thread local */
 
 size_t gft_geom_bytes(int32_t P);
 size_t gft_image_bytes(int32_t W, int32_t H);
+/* words of gft_forward_io.cell_sched for this image size (tile-pull binning; 0 where it does not apply) */
+size_t gft_cell_sched_words(int32_t W, int32_t H);
 size_t gft_binning_bytes(int64_t R, int32_t W, int32_t H);
 size_t gft_acc_bytes(int32_t P);
 size_t gft_det_partials_bytes(int64_t binning_instances, int32_t W, int32_t H);   /* gft_backward_io.det_partials: 256 bytes per list slot
@@ -332,6 +342,8 @@ typedef struct gft_forward_hints {
                                   * per CU), which ignores the schedule.  A caller sets it when the previous frame of the shape
                                   * reported enough hinted tiles (gft_forward_report.hinted_tiles; api.py: a sixteenth of the tiles) --
                                   * a schedule like the hints themselves: results do not depend on it */
+    int64_t use_cell_sched;      /* non-zero = io->cell_sched was left by an earlier frame of this camera and image size: bin by it
+                                  * without a count pass (gft_forward only; gft_forward_enqueue, which cannot fall back, counts) */
 } gft_forward_hints;
 
 /* What the device reported while the forward was running. */
@@ -340,6 +352,7 @@ typedef struct gft_forward_report {
     int64_t max_tile_list;       /* longest per-tile list (whole-frame binning; 0 with tile-pull binning) */
     int64_t list_entries;        /* entries that were scattered: (Gaussian, supertile) pairs with tile-pull binning, else R */
     int64_t hinted_tiles;        /* non-zero words of io->tile_hints as this frame found them (tile-pull binning; else 0) */
+    int64_t sched_misses;        /* 1: hints->use_cell_sched was set and the schedule did not hold the frame's lists -- the counted flow ran */
 } gft_forward_report;
 
 /* The forward in one call, for callers that can guess R (a training loop: R of the

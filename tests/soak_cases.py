@@ -62,6 +62,8 @@ def run_case(case, dev, oracle, rng):
             torch.cuda.synchronize()
             api._tile_hints.clear()
             api._tile_weights.clear()
+            api._cell_sched.clear()
+            api._cell_sched_seen.clear()
         if c["hints"] in ("ones", "random"):
             hb = api._tile_hint_buffer((dev.index, c["W"], c["H"], 0, 0), dev, c["W"], c["H"])
             if c["hints"] == "ones":
@@ -76,6 +78,18 @@ def run_case(case, dev, oracle, rng):
                 wb = api._tile_weights[key] = torch.zeros((4 * T_ + 4,), device=dev, dtype=torch.int32)
             wb.copy_(torch.tensor(rng.integers(0, 5000, wb.numel()), dtype=torch.int32))
             wb[-4] = int(rng.integers(0, 2))
+            # ... and an arbitrary list schedule, which the scatter pass is told to bin by (half of these cases)
+            words = int(lib.gft_cell_sched_words(c["W"], c["H"]))
+            if words and c["seed"] & 2:
+                sb = api._cell_sched.get(key)
+                if sb is None or sb is False:
+                    sb = api._cell_sched[key] = torch.zeros((words,), device=dev, dtype=torch.int32)
+                kind = int(rng.integers(0, 3))
+                if kind == 0:
+                    sb.copy_(torch.tensor(rng.integers(0, 2 ** 31 - 1, words), dtype=torch.int32))
+                elif kind == 1:
+                    sb.zero_()
+                api._force_cell_sched = True
         if c["grads"] == "kept_full":
             for pool in api._grad_pool.values():
                 for e in pool:
@@ -137,6 +151,7 @@ def run_case(case, dev, oracle, rng):
             api._grad_pool.clear()
         api._TILE_HINTS, api._GRADS_REUSE, api._USE_COUNT_API, api._ACC_REUSE = keep
         api._force_whole_lists = None
+        api._force_cell_sched = None
         api._TILE_HINTS_PER_CAMERA = keep_cam
     return edge_flips, flip_cases
 

@@ -740,6 +740,8 @@ def test_tile_hints_do_not_change_results(name, oracle, gpu):
         api._tile_hints.clear()
         api._tile_weights.clear()
         api._hinted_tiles.clear()
+        api._cell_sched.clear()
+        api._cell_sched_seen.clear()
         for frame in range(7):
             if frame >= 3:
                 # frames 0 - 2: the schedule and the choice of the pull kernel's build as the operator makes them; then forced:
@@ -754,13 +756,36 @@ def test_tile_hints_do_not_change_results(name, oracle, gpu):
                     wbuf.copy_(torch.tensor(rng.integers(0, 3000 if frame != 4 else 2 ** 31 - 1, wbuf.numel()), dtype=torch.int32))
                     wbuf[-4] = 1
                 api._force_whole_lists = frame != 6
+                # ... and the camera's list schedule (where the binning's scatter pass appends without a count pass in front):
+                # garbage, zeros, capacities of 1 -- found on the device, the counted flow runs in the same call
+                for sbuf in api._cell_sched.values():
+                    if sbuf is False:
+                        continue
+                    if frame == 4:
+                        sbuf.copy_(torch.tensor(rng.integers(0, 2 ** 31 - 1, sbuf.numel()), dtype=torch.int32))
+                    elif frame == 5:
+                        sbuf.zero_()
+                    elif frame == 6:
+                        cells = (sbuf.numel() - 4) // 2
+                        sbuf[:cells] = torch.arange(cells, dtype=torch.int32, device=sbuf.device)
+                        sbuf[cells:2 * cells] = 1
+                        sbuf[2 * cells] = cells
+                        sbuf[2 * cells + 1] = 1
+                api._force_cell_sched = True if frame in (4, 5, 6) else None
+            misses = api.last_call_stats.get("sched_misses", 0)
             out, grads, _ = Hh.run_gpu(scene, gpu)
+            if api._cell_sched and not any(v is False for v in api._cell_sched.values()) and api._CELL_SCHED:
+                if frame in (4, 5, 6):
+                    assert api.last_call_stats.get("sched_misses", 0) > misses, frame
+                elif frame in (1, 2, 3):
+                    assert api.last_call_stats.get("sched_misses", 0) == misses, frame
             for k in ref_out:
                 np.testing.assert_array_equal(out[k], ref_out[k], err_msg="%s frame %d" % (k, frame))
             for k in ref_grads:
                 if ref_grads[k] is not None:
                     Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
     api._force_whole_lists = None
+    api._force_cell_sched = None
     f, b = Hh.run_oracle(oracle, scene)
     check_outputs(f, out)
     check_grads(b, grads, scene)
