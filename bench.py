@@ -906,6 +906,8 @@ def views_extra(dev, scene, steps=90, warmup=30, views=30):
     return {"what": "headline step over %d views on an arc in shuffled order, %d Gaussians, %dx%d, forward + backward" % (views, P, W, H),
             "it_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
             "restarted_forwards": stats["restarted"],
+            # frames whose lists did not fit the camera's list schedule (binned again by the counted flow) in this process so far
+            "list_schedule_misses": int(api.last_call_stats.get("sched_misses", 0)),
             # of the sampled frames (every tenth): frames in which a quadrant walked past the sorted head of its list (the
             # silhouette quadrants of a view: their lists are completed on demand), and the means per sampled frame
             "sampled_frames": n_units, "sampled_frames_with_flagged_quadrants": flag_frames,
@@ -1494,7 +1496,8 @@ def main():
                               "counter_bytes_per_step": path_traffic,
                               "counter_frac": (gbs(path_traffic, ms_per_step) / HBM_PEAK_GBS) if path_traffic else None,
                               "gpu_ms_sum_of_stages": sum(stage_ms.values())},
-            "binning_restarts": {"restarted_forwards": restarts[0], "forwards": restarts[1]},
+            "binning_restarts": {"restarted_forwards": restarts[0], "forwards": restarts[1],
+                                 "list_schedule_misses": int(api.last_call_stats.get("sched_misses", 0))},
             # gradient tensors kept from one backward to the next (their written rows re-zeroed) instead of 376 B of zeros
             # per Gaussian written in every backward; only when no tensor aliases them any more and nobody wrote to them
             "gradient_tensors_reused": bool(api.last_call_stats.get("grads_reused")),
