@@ -1,6 +1,8 @@
 // k_pull.hip -- tile-pull instance binning (gfx950): what is binned, sorted and given an appearance is what
-// can be seen, decided from THIS frame (no hints from earlier frames: a training loop draws another camera
-// every iteration, train.py:155-163).
+// can be seen, decided from THIS frame (a training loop draws another camera every iteration, train.py:155-163).
+// What a camera's earlier frame may leave with the caller are SCHEDULES -- which tiles sort their whole list up front,
+// in which order the blend's waves are dealt, where the supertile lists start -- that change when and where work is done,
+// never a value: any contents of those words give the same results (gft_forward_io.tile_hints / tile_weights / cell_sched).
 //
 // A pixel stops reading its tile list once its transmittance is below 1e-4 (reference forward.cu:560-565), so
 // in a dense frame most (Gaussian, tile) instances are never read (1 M metric frame: 3.6 M instances, 0.6 M up
@@ -11,6 +13,9 @@
 //                      8-byte entry `id | rectangle relative to the supertile (4 x 5 bits) | depth bin (12 bits)`
 //                      per (Gaussian, supertile); count pass (+ R, mailbox), then scatter with one reserved chunk
 //                      per (workgroup, supertile, depth slab)                      [8 B per entry, ~0.5 per instance]
+//   k_super_bin<2>   : the scatter alone, appending to lists whose starts and capacities the camera's last frame left
+//                      (+ R, mailbox, the checks that the lists fitted, the next frame's schedule); big tile grids group
+//                      a workgroup's entries by list in LDS first (k_super_bin<1 / 2, true>)
 //   k_tile_pull      : one workgroup per tile scans its supertile's entries (L2), histograms its hits over the
 //                      depth bins, takes the nearest ~940 (whole bins) as the HEAD of its list: gathers their
 //                      depths, places the (depth bits, id) keys in LDS GROUPED BY DEPTH BIN (the histogram's running
