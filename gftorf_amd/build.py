@@ -21,7 +21,8 @@ ARCH = "gfx950"
 # v_mov to pair registers: measured +12 us per render kernel on the metric frame.
 # (k_preprocess.hip: the vectoriser pairs scalar multiplies of the appearance maths into v_pk_mul_f32 behind four register moves
 # each: preprocess_fwd stage 57.3 -> 54.7 us on the metric frame, 129 -> 126 fog, 132.6 -> 130.1 at 5 M @ 1080p without it)
-FILE_FLAGS = {"k_render.hip": ["-fno-slp-vectorize"], "k_preprocess.hip": ["-fno-slp-vectorize"]}
+# (k_pull.hip: it compiles the forward blend's walk too -- gft_render_walk.h -- and must do so exactly as k_render.hip does)
+FILE_FLAGS = {"k_render.hip": ["-fno-slp-vectorize"], "k_preprocess.hip": ["-fno-slp-vectorize"], "k_pull.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():

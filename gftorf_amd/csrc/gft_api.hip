@@ -561,7 +561,7 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
             else
                 GFT_STAGE(s, cfg, "tile_tail", gft_launch_tile_tail(s, *cfg, g, im, b, cap, cfg->want_backward != 0));
         }
-        {
+        if (!(pull && gft_tail_resumes())) {      // (tile-pull binning: the tail builder's workgroups resume their quadrants themselves)
             StageTimer t(s, ST_RENDER_FWD);
             GFT_STAGE(s, cfg, "render_resume", gft_launch_render_fwd(s, *cfg, *io, g, im, b, check_cap, cap, 2, pull));
         }

@@ -177,6 +177,7 @@ hipError_t gft_launch_tile_sort_long(hipStream_t s, const gft_config& c, const I
 // tile-pull binning (k_binning.hip, k_tail.hip): ids to supertiles, every tile pulls and sorts the head of its list,
 // lists are completed on demand for the tiles with a flagged quadrant
 bool gft_tile_pull_ok(const gft_config& c);      // the frame's tile grid fits the supertile tables
+bool gft_tail_resumes();                         // k_tail_build resumes its tiles' flagged quadrants itself (no resume launch)
 struct SuperShape { int gx, gy, T, sshift, sgx, sgy, NS, K, kshift; uint32_t near_bits; int bin_shift; };
 SuperShape gft_super_shape(const gft_config& c);
 hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,

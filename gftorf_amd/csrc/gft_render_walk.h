@@ -3,6 +3,51 @@
 #pragma once
 #include "gft_internal.h"
 
+struct RenderFwdArgs {
+    int W, H, gx, T;
+    const uint2* __restrict__ ranges;
+    const uint32_t* __restrict__ point_list;
+    const float4* __restrict__ rec_a;
+    const float4* __restrict__ rec_b;
+    const float* __restrict__ bg;
+    int64_t bsc, bsy, bsx;
+    float dc_offset;
+    float4* __restrict__ pix_state;
+    float4* __restrict__ pix_sums;
+    uint32_t* __restrict__ quad_max;
+    float* out_color; float* out_phasor; float* out_depth; float* out_normal; float* out_acc;
+    float* out_entropy; float* out_dd; float* out_ad; float* out_distribution;
+    float* pixels;
+    const uint32_t* __restrict__ ctrl;   // NULL: no instance-count check
+    uint32_t cap;
+    // tile-pull binning (k_pull.hip): `ranges` holds the sorted head of the tile's list; tile_cut[tile] != GFT_NO_TAIL: the
+    // list goes on behind it (completed by k_tail_build for the tiles with a flagged quadrant).  NULL: whole-frame binning
+    const uint32_t* __restrict__ tile_cut;
+    float4* __restrict__ snaps;               // blend-state snapshots for the backward (NULL: no backward follows)
+    int nsnap;                                // snapshots per quadrant (list positions 256, 512, ...)
+    // lazy sort (k_binning.hip, k_tile_front): only the head of every id list is sorted
+    const uint32_t* __restrict__ front_len;   // NULL: lists are sorted whole
+    uint32_t* __restrict__ unit_flag;
+    uint32_t* nflag;
+    float4* __restrict__ resume_state;
+    int resume;                               // second pass: continue the flagged quadrants behind the head
+    // tile-pull binning with a caller-kept schedule (gft_forward_io.tile_hints): byte v = did quadrant v walk past where a
+    // normal sorted head ends -- it flagged, or (a hinted tile's long head or whole list: more than 1024 sorted entries) its
+    // deepest contributor lies beyond GFT_HEAD_TARGET
+    uint8_t* __restrict__ hint_out;
+    // first pass with a caller-kept schedule: the heavy-first tile order k_appearance derived for this frame (NULL: none)
+    const uint32_t* __restrict__ fwd_order;
+    const uint32_t* __restrict__ fwd_order_ok;
+    // the caller's tile_weights (may be NULL): every quadrant leaves its walk length there for the camera's next frame (the
+    // first pass: a flagged quadrant the longest there is, until its resume pass writes the final one), word 4 T = "valid"
+    uint32_t* __restrict__ weights_out;
+};
+
+// the arguments of one forward blend pass (lazy: 0 = lists sorted whole, 1 = first pass over the sorted heads, 2 = resume pass);
+// k_render.hip
+RenderFwdArgs gft_render_fwd_args(const gft_config& c, const gft_forward_io& io, const GeomView& g, const ImgView& im,
+                                  const BinView& b, bool check_cap, uint32_t cap, int lazy, bool pull);
+
 namespace {
 
 #define RB 64                // splats per staged batch = lanes per wave
@@ -62,45 +107,6 @@ __device__ __forceinline__ bool stage_splat(uint32_t id, int slot, const float4*
     return gft_splat_reaches_box(a0, a1, box.x, box.y, box.z, box.w);
 }
 
-struct RenderFwdArgs {
-    int W, H, gx, T;
-    const uint2* __restrict__ ranges;
-    const uint32_t* __restrict__ point_list;
-    const float4* __restrict__ rec_a;
-    const float4* __restrict__ rec_b;
-    const float* __restrict__ bg;
-    int64_t bsc, bsy, bsx;
-    float dc_offset;
-    float4* __restrict__ pix_state;
-    float4* __restrict__ pix_sums;
-    uint32_t* __restrict__ quad_max;
-    float* out_color; float* out_phasor; float* out_depth; float* out_normal; float* out_acc;
-    float* out_entropy; float* out_dd; float* out_ad; float* out_distribution;
-    float* pixels;
-    const uint32_t* __restrict__ ctrl;   // NULL: no instance-count check
-    uint32_t cap;
-    // tile-pull binning (k_pull.hip): `ranges` holds the sorted head of the tile's list; tile_cut[tile] != GFT_NO_TAIL: the
-    // list goes on behind it (completed by k_tail_build for the tiles with a flagged quadrant).  NULL: whole-frame binning
-    const uint32_t* __restrict__ tile_cut;
-    float4* __restrict__ snaps;               // blend-state snapshots for the backward (NULL: no backward follows)
-    int nsnap;                                // snapshots per quadrant (list positions 256, 512, ...)
-    // lazy sort (k_binning.hip, k_tile_front): only the head of every id list is sorted
-    const uint32_t* __restrict__ front_len;   // NULL: lists are sorted whole
-    uint32_t* __restrict__ unit_flag;
-    uint32_t* nflag;
-    float4* __restrict__ resume_state;
-    int resume;                               // second pass: continue the flagged quadrants behind the head
-    // tile-pull binning with a caller-kept schedule (gft_forward_io.tile_hints): byte v = did quadrant v walk past where a
-    // normal sorted head ends -- it flagged, or (a hinted tile's long head or whole list: more than 1024 sorted entries) its
-    // deepest contributor lies beyond GFT_HEAD_TARGET
-    uint8_t* __restrict__ hint_out;
-    // first pass with a caller-kept schedule: the heavy-first tile order k_appearance derived for this frame (NULL: none)
-    const uint32_t* __restrict__ fwd_order;
-    const uint32_t* __restrict__ fwd_order_ok;
-    // the caller's tile_weights (may be NULL): every quadrant leaves its walk length there for the camera's next frame (the
-    // first pass: a flagged quadrant the longest there is, until its resume pass writes the final one), word 4 T = "valid"
-    uint32_t* __restrict__ weights_out;
-};
 
 // The forward blend's walk of one 8x8 quadrant (one wave): list positions [0, head) in the first pass, [head, full) of a
 // flagged quadrant in the resume pass.  A function of its own, in a header, because two kernels run it: k_render_fwd
@@ -118,7 +124,15 @@ __device__ __forceinline__ void render_fwd_walk(const RenderFwdArgs& a, const in
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = a.ranges[tile];
+    // (resume pass inside k_tail_build: the tile's range was rewritten by this very workgroup a moment ago -- read it past
+    // the L1, which may still hold the line as the workgroup read it before)
+    uint2 range;
+    if (a.resume) {
+        range.x = __hip_atomic_load(&a.ranges[tile].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        range.y = __hip_atomic_load(&a.ranges[tile].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        range = a.ranges[tile];
+    }
     const int full = (int)(range.y - range.x);
     const int head = a.front_len ? (int)a.front_len[tile] : full;
     // first pass: list positions [0, head); resume pass: [head, full) of the flagged quadrants (whole-frame binning: the

@@ -40,6 +40,7 @@
 // sorted list.
 #include "gft_internal.h"
 #include "gft_sort.h"
+#include "gft_render_walk.h"     // (in front of the next one: the blend walk is compiled with contraction on, as in k_render.hip)
 #include "gft_appearance.h"      // (floating-point contraction is off from here on)
 
 #include <cstdlib>
@@ -947,13 +948,18 @@ struct TailArgs {
     uint32_t cap;
     const uint32_t* __restrict__ quad_max;
     uint32_t* __restrict__ order;
+    RenderFwdArgs render;                    // the resume pass of the forward blend, run by this kernel's workgroups
+    int resume_here;
     int dbg;
 };
 
 __device__ __forceinline__ void tail_appearance(const TailArgs& a, uint32_t id)
 {
-    if (a.pre.g.need[id]) return;            // (another tile may do the same at the same time: the same bits are written)
-    a.pre.g.need[id] = 1;
+    // 1 = it has its appearance from k_appearance.  3 = some tile's tail builder is giving (or has given) it one in THIS launch:
+    // that does not help the tile at hand -- its resumed walk reads the records a moment from now and cannot wait for another
+    // workgroup's stores -- so it evaluates the Gaussian as well (the same bits are written).
+    if (a.pre.g.need[id] == 1) return;
+    a.pre.g.need[id] = 3;
     const float px = a.pre.io.means3D[3 * id], py = a.pre.io.means3D[3 * id + 1], pz = a.pre.io.means3D[3 * id + 2];
     const Mat16 V = load_mat(a.pre.io.viewmatrix);
     // the same expressions as in k_preprocess_fwd / k_appearance: the same distance bit for bit
@@ -1167,11 +1173,31 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
             }
         }
         if (tid == 0) a.ranges[tile] = make_uint2(a.pool_base + s_pool, a.pool_base + s_pool + kf + m);
+        // The list is complete: the tile's flagged quadrants go on from where the first pass parked them, here, a wave each
+        // -- the resume pass without a launch of its own (3.5 us on every frame, flagged or not).  What this workgroup has
+        // written (list, range, the newcomers' appearance) is made visible first; the key buffer is free for the staging.
+        __threadfence();
         __syncthreads();
+        if (a.resume_here) {
+            const int w = tid >> 6;
+            const uint32_t fl = w == 0 ? f.x : w == 1 ? f.y : w == 2 ? f.z : f.w;
+            if (w < 4 && fl != 0u) {
+                float4* stage = reinterpret_cast<float4*>(sk_dyn) + (size_t)w * (RB * 4);
+                render_fwd_walk(a.render, 4 * tile + w, lane, stage, stage + RB * 2);
+            }
+        }
     }
 }
 
 }  // namespace
+
+// does k_tail_build run the forward blend's resume pass itself (GFT_TAIL_RESUME=0: a launch of k_render_fwd behind it, as with
+// whole-frame binning)?
+bool gft_tail_resumes()
+{
+    static const bool on = [] { const char* e = getenv("GFT_TAIL_RESUME"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
 
 // supertile side: the smallest power of two >= 2 tiles that leaves at most GFT_SUPER_MAX supertiles; depth slabs per
 // supertile list: 4 on big tile grids (S >= 4: sixteen tiles share a list several times their own length; a tile then
@@ -1305,6 +1331,8 @@ hipError_t gft_launch_tail_build(hipStream_t s, const gft_config& c, const gft_f
     a.front_len = im.front_len; a.unit_flag = im.unit_flag; a.tile_cut = im.tile_cut;
     a.ctrl = im.ctrl; a.cap = cap;
     a.quad_max = im.tile_max; a.order = want_order ? im.tile_order : nullptr;
+    a.resume_here = gft_tail_resumes() ? 1 : 0;
+    a.render = gft_render_fwd_args(c, io, g, im, b, true, cap, 2, true);
     static const int tdbg = [] { const char* e = getenv("GFT_TAIL_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = tdbg;
     const size_t lds = (size_t)SORT_SLOTS(TAIL_LDS_KEYS) * 8;

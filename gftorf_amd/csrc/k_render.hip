@@ -925,11 +925,12 @@ __global__ __launch_bounds__(1024) void k_acc_reduce_det(int T, const uint2* __r
 
 }  // namespace
 
-hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
-                                 const ImgView& im, const BinView& b, bool check_cap, uint32_t cap, int lazy, bool pull,
-                                 bool segmented)
+RenderFwdArgs gft_render_fwd_args(const gft_config& c, const gft_forward_io& io, const GeomView& g, const ImgView& im,
+                                  const BinView& b, bool check_cap, uint32_t cap, int lazy, bool pull)
 {
     RenderFwdArgs a;
+    a.gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X;
+    a.T = a.gx * ((c.H + GFT_TILE_Y - 1) / GFT_TILE_Y);            // (first: the choices below depend on it)
     a.nsnap = gft_bwd_segments((size_t)((c.W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((c.H + GFT_TILE_Y - 1) / GFT_TILE_Y)) - 1;
     a.snaps = (c.want_backward && a.nsnap > 0) ? im.snaps : nullptr;
     a.ctrl = check_cap ? im.ctrl : nullptr;
@@ -961,6 +962,15 @@ hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_f
     a.fwd_order = ordered ? im.tile_cursor : nullptr;
     a.fwd_order_ok = im.ctrl + GFT_CTRL_FWDORDER;
     a.weights_out = (pull && lazy != 0 && gft_fwd_ordered(a.T)) ? io.tile_weights : nullptr;
+    return a;
+}
+
+hipError_t gft_launch_render_fwd(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
+                                 const ImgView& im, const BinView& b, bool check_cap, uint32_t cap, int lazy, bool pull,
+                                 bool segmented)
+{
+    const RenderFwdArgs a = gft_render_fwd_args(c, io, g, im, b, check_cap, cap, lazy, pull);
+    const bool ordered = a.fwd_order != nullptr;
     const int blocks = ordered ? 32 * ((a.T + 7) / 8) : 8 * ((a.T * 4 + 7) / 8);
     // segmented: up to FSEG_WAVES waves per quadrant (first pass only; the resume pass of flagged quadrants stays one
     // wave per quadrant).  GFT_FWD_SEG=0 / 1 in the environment forces one of the two kernels for every frame.
