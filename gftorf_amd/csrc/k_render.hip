@@ -678,8 +678,15 @@ __global__ __launch_bounds__(64) void k_render_bwd(RenderBwdArgs a)
     // Group 0 walks the LAST segment of its quadrant, group g > 0 segment g - 1: the last segment is the one that is not cut
     // to GFT_SEG_LEN entries -- behind the last snapshot of a list that was sorted whole it is 1200 entries of a
     // 3000-entry walk, and a chain of that length must not be the one that starts last.
-    const int seg = sgroup == 0 ? ncut : sgroup - 1;
-    if (sgroup > 0 && seg >= ncut) return;
+    // ... unless it is a SHORT one on a frame whose waves make many rounds over the chip (more than 4096 tiles): there the
+    // front segment, with every pixel still open, is the heavier of the two and goes first, group 1 takes the last one
+    // (5 M @ 1080p: 538 -> 505 us).  Where nearly all waves are resident at once the same swap costs (metric frame: 153.6 ->
+    // 164 us): the light segments between the heavy ones are what keeps the SIMDs mixed.
+    const bool front_first = a.T > GFT_FWD_ORDER_MAX_TILES && ncut >= 1 && tmax - ncut * GFT_SEG_LEN <= GFT_SEG_LEN;
+    int seg;
+    if (sgroup == 0) seg = front_first ? 0 : ncut;
+    else if (sgroup == 1) { if (ncut < 1) return; seg = front_first ? ncut : 0; }
+    else { seg = sgroup - 1; if (seg >= ncut) return; }
     const int lo_last = seg * GFT_SEG_LEN;                                  // list range [lo_last, hi_first) of this segment
     const int hi_first = seg == ncut ? tmax : lo_last + GFT_SEG_LEN;
     const int tile = v_unit >> 2, quad = v_unit & 3;
