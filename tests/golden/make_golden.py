@@ -5,6 +5,8 @@ files themselves never travel; only the input/output vectors written here do.
 
   sh_color.npz   : utils/sh_utils.py eval_sh (lines 57-112) on random
                    coefficients/directions, degrees 0..3
+  sh_phasor.npz  : the same helper on TWO channels ([P, 16, 2] coefficients: phase, amplitude) -- the polynomial of
+                   forward.cu:73-125 computePhasorFromSH before its "+0.5", DC removal and amplitude clamp
   camera.npz     : utils/graphics_utils.py getProjectionMatrix (55-75),
                    getProjectionMatrixShift (77-109), getWorld2View2 (38-49)
   deform.npz     : utils/time_utils.py DeformNetwork (56-127) constructed as scene/deform_model.py:9-16 does,
@@ -100,6 +102,14 @@ def main():
     np.savez(os.path.join(HERE, "sh_color.npz"), sh=sh, dirs=dirs,
              rgb2sh_in=x, rgb2sh_out=RGB2SH(torch.tensor(x)).numpy(),
              pa2sh_out=PA2SH(torch.tensor(x)).numpy(), **out)
+
+    # computePhasorFromSH (forward.cu:73-125) is eval_sh on two channels; amplitude DCs on both sides of the clamp
+    sh_p = rng.normal(0, 0.3, (n, 16, 2)).astype(np.float32)
+    sh_p[:, 0, 1] = rng.uniform(-2.5, 1.5, n).astype(np.float32)
+    outp = {}
+    for deg in range(4):
+        outp[f"deg{deg}"] = eval_sh(deg, torch.tensor(sh_p).permute(0, 2, 1), torch.tensor(dirs)).numpy().astype(np.float32)
+    np.savez(os.path.join(HERE, "sh_phasor.npz"), sh_p=sh_p, dirs=dirs, **outp)
 
     cams = {}
     for name, (W, H, fovx_deg, zn, zf) in {

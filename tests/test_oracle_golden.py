@@ -13,9 +13,10 @@ from gftorf_amd import synth
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _render_one_sh(oracle, sh, direction, deg):
+def _render_one_sh(oracle, sh, direction, deg, sh_p=None):
     """Run the oracle's K1 on one Gaussian placed along `direction` from the camera and
-    return rgb (after +0.5 and clamp) and the clamp flags."""
+    return rgb (after +0.5 and clamp) and the clamp flags; with `sh_p` ([16, 2] phase / amplitude coefficients) the
+    (phase_sh, amplitude) pair and the amplitude's clamp flag instead."""
     campos = np.zeros(3, np.float32)
     p = (direction / np.linalg.norm(direction) * 3.0).astype(np.float32)
     # camera looking along +z with the point in front: rotate world so that p maps to +z
@@ -28,12 +29,16 @@ def _render_one_sh(oracle, sh, direction, deg):
     w2c = np.eye(4, dtype=np.float32)
     w2c[:3, :3] = np.stack([x, y, z], 0)
     cam = synth.make_camera(64, 64, w2c=w2c)
-    cfg = oracle.make_config(1, deg, 16, 0, 64, 64, cam["tanfovx"], cam["tanfovy"], near_n=0.45, far_n=6.05)
+    cfg = oracle.make_config(1, deg, 16, 0 if sh_p is None else 16, 64, 64, cam["tanfovx"], cam["tanfovy"], near_n=0.45,
+                             far_n=6.05, use_view_dependent_phase=sh_p is not None)
     g = oracle.preprocess_fwd(cfg, p[None].copy(), np.full((1, 3), 0.05, np.float32),
                               np.array([[1, 0, 0, 0]], np.float32), np.array([0.5], np.float32),
-                              np.ascontiguousarray(sh[None]), None, None, None, None,
+                              np.ascontiguousarray(sh[None]), None if sh_p is None else np.ascontiguousarray(sh_p[None]),
+                              None, None, None,
                               cam["viewmatrix"].reshape(-1), cam["projmatrix"].reshape(-1), campos)
     assert g["radii"][0] > 0
+    if sh_p is not None:
+        return g["phase_amp"][0].copy(), bool(g["clamped_p"][0])
     return g["rgb"][0], g["clamped"][0]
 
 
@@ -48,6 +53,31 @@ def test_sh_colour_matches_reference_eval_sh(oracle):
             np.testing.assert_allclose(rgb, np.maximum(want, 0.0), rtol=0, atol=3e-6)
             ok = np.abs(want) > 1e-5
             np.testing.assert_array_equal(clamped[ok].astype(bool), (want < 0)[ok])
+
+
+def test_sh_phasor_matches_reference_eval_sh(oracle):
+    """computePhasorFromSH (forward.cu:73-125) is the helper's polynomial on two channels: `+0.5` on both, then the
+    phase loses `0.5 + C0 sh_p[0].x` again (only the view-dependent residual is left) and the amplitude is clamped at 0
+    with its flag (forward.cu:113-124).  Pinned against utils/sh_utils.py:57-112 eval_sh, degrees 0-3."""
+    d = np.load(os.path.join(GOLD, "sh_phasor.npz"))
+    sh_p, dirs = d["sh_p"], d["dirs"]
+    sh = np.zeros((16, 3), np.float32)
+    seen = set()
+    for deg in range(4):
+        ref = d["deg%d" % deg]              # eval_sh output [n, 2], before +0.5
+        for i in range(0, sh_p.shape[0], 2):
+            (phase, amp), clamped = _render_one_sh(oracle, sh, dirs[i], deg, sh_p=sh_p[i])
+            want_phase = ref[i, 0] - synth.SH_C0 * sh_p[i, 0, 0]
+            want_amp = ref[i, 1] + 0.5
+            np.testing.assert_allclose(phase, want_phase, rtol=0, atol=3e-6)
+            np.testing.assert_allclose(amp, max(want_amp, 0.0), rtol=0, atol=3e-6)
+            if abs(want_amp) > 1e-5:
+                assert clamped == (want_amp < 0)
+                seen.add(bool(clamped))
+        if deg == 0:
+            # degree 0: the phase residual is exactly the rounding of (C0 x + 0.5) - 0.5 - C0 x
+            assert np.abs(ref[::2, 0] - synth.SH_C0 * sh_p[::2, 0, 0]).max() < 1e-6
+    assert seen == {False, True}            # both sides of the amplitude clamp were met
 
 
 def test_survey_known_answers(oracle):
