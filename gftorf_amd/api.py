@@ -104,32 +104,41 @@ def _whole_lists(key, n_tiles):
 # a graph (torch.cuda.graphs around a fixed-shape iteration: at the reference's own scene size the host, not the kernels,
 # bounds the loop), and for every call with `gftorf_amd.api.no_host_read = True` / GFT_NO_HOST_READ=1.  The binning buffer is
 # sized from the shape's earlier frames as always; a frame whose instance count exceeds it is NOT re-rendered (nobody reads
-# the count while it runs): its outputs are undefined, and the next call of the shape -- which finds the device's posting of
-# the earlier frame in pinned memory -- raises.  `enqueue_status()` returns the postings (after a graph replay, say).
+# the count while it runs): its outputs are undefined, and a later call of the shape -- which finds the device's count of
+# overflowed frames in pinned memory: a word the library never clears, so a host that runs several frames ahead cannot miss
+# it -- raises.  `enqueue_status()` returns the postings (after a graph replay, say).  Outside a capture, a shape that has
+# no size hint yet (the first frame of the process, a new P after densification) takes the blocking two-stage flow once.
 no_host_read = _os.environ.get("GFT_NO_HOST_READ", "0") != "0"
-_status = {}              # hint key -> dict(dev=int32[16] on the device, host=its pinned copy, cap=instances of the last enqueue)
+_status = {}              # hint key -> dict(dev=int32[16] on the device, host=its pinned copy, seen=overflows reported so far)
+_ST_CAP, _ST_OVERFLOWS, _ST_MAX_R = 12, 13, 14      # include/gftorf_rast.h: GFT_STATUS_CAP / _OVERFLOWS / _MAX_R
 
 
 def _status_of(key, dev, create):
     st = _status.get(key)
     if st is None and create and len(_status) < 1024:
         st = _status[key] = dict(dev=torch.zeros((16,), device=dev, dtype=torch.int32),
-                                 host=torch.zeros((16,), dtype=torch.int32).pin_memory(), cap=0, key=key)
+                                 host=torch.zeros((16,), dtype=torch.int32).pin_memory(), seen=0, key=key)
         st["np"] = st["host"].numpy()
     return st
 
 
 def enqueue_status(synchronize=True):
-    """What the device posted for the most recent no-host-read forward of every shape: a list of dicts(key=(device, P, W, H
-    [, slot]), posted, num_rendered, binning_instances, overflow).  ``overflow``: that frame did not fit its binning buffer
-    and its outputs are undefined -- render it again eagerly (the blocking flow re-sizes the buffer)."""
+    """What the device posted for the no-host-read forwards of every shape: a list of dicts(key=(device, P, W, H[, slot]),
+    posted, num_rendered, binning_instances -- of the most recent frame, both from the device's posting --, overflow,
+    overflows, max_overflow_instances).  ``overflow``: the most recent frame did not fit its binning buffer and its outputs
+    are undefined -- render it again eagerly (the blocking flow re-sizes the buffer); ``overflows``: how many frames of the
+    shape did not, since the process started (a count the device keeps and nothing clears: frames whose posting a later
+    frame has overwritten are in it)."""
     if synchronize and torch.cuda.is_available():
         torch.cuda.synchronize()
+        for st in _status.values():
+            st["host"].copy_(st["dev"])
     out = []
     for key, st in _status.items():
         a = st["np"]
-        out.append(dict(key=key, posted=bool(a[3]), num_rendered=int(a[0]), binning_instances=int(st["cap"]),
-                        overflow=bool(a[3]) and int(a[0]) > int(st["cap"]), prefiltered_point_culled=bool(a[1] & 1)))
+        out.append(dict(key=key, posted=bool(a[3]), num_rendered=int(a[0]), binning_instances=int(a[_ST_CAP]),
+                        overflow=bool(a[3]) and int(a[0]) > int(a[_ST_CAP]), overflows=int(a[_ST_OVERFLOWS]),
+                        max_overflow_instances=int(a[_ST_MAX_R]), prefiltered_point_culled=bool(a[1] & 1)))
     return out
 
 
@@ -585,19 +594,33 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
             io.tile_weights = _ptr(tw)
         try:
             with _lib.on_device(dev):
+                st = None
                 if nowait:
-                    if hint is None:
-                        raise RuntimeError("gftorf_amd: the forward without a host read (graph capture, no_host_read) sizes its "
-                                           "binning buffer from earlier frames of the shape: render one frame of this shape "
-                                           "(%d Gaussians, %dx%d) eagerly first" % (P, W, H))
-                    st = _status_of(hint_key, dev, create=not capturing)
-                    if st is None:
-                        raise RuntimeError("gftorf_amd: no status block for this shape: render one frame of it with "
-                                           "gftorf_amd.api.no_host_read = True before capturing")
+                    st = _status_of(hint_key, dev, create=not capturing) if hint is not None else None
+                    if capturing and hint is None:
+                        raise RuntimeError("gftorf_amd: a forward captured in a graph sizes its binning buffer from earlier "
+                                           "frames of the shape: render one frame of this shape (%d Gaussians, %dx%d) eagerly "
+                                           "first" % (P, W, H))
+                    if capturing and st is None:
+                        raise RuntimeError("gftorf_amd: no status block for this shape: render one frame of it eagerly before "
+                                           "capturing")
+                    # (not capturing and nothing known about the shape yet -- the first frame of the process, a new P after a
+                    # densification step --: the blocking two-stage flow below, once; it leaves the hint and the status block)
+                if st is not None:
                     a = st["np"]
+                    if int(a[_ST_OVERFLOWS]) != st["seen"]:
+                        # some earlier no-host-read frame of the shape did not fit its buffer (the device counts them in a word
+                        # nothing clears: the posting of the frame itself may have been overwritten by a later frame's already)
+                        n_over, st["seen"] = int(a[_ST_OVERFLOWS]) - st["seen"], int(a[_ST_OVERFLOWS])
+                        worst = int(a[_ST_MAX_R])
+                        prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
+                        _instance_hint[hint_key] = (max(worst, prev_r or 0), prev_l)
+                        raise RuntimeError("gftorf_amd: %d earlier no-host-read forward(s) of this shape had up to %d instances, "
+                                           "more than their binning buffer held: their outputs were undefined (the buffer has "
+                                           "been enlarged for the following frames)" % (n_over, worst))
                     if a[3]:
-                        # the posting of the shape's previous no-host-read frame (its kernels are long done)
-                        prev_R, prev_cap = int(a[0]), int(st["cap"])
+                        # the posting of an earlier no-host-read frame of the shape (whichever the copy in pinned memory holds)
+                        prev_R = int(a[0])
                         a[3] = 0
                         _hinted_tiles[tiles_key] = int(a[8])
                         if a[1] & 1:
@@ -605,17 +628,12 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                         prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
                         _instance_hint[hint_key] = (max(prev_R, int((prev_r or 0) * 0.95)), prev_l)
                         hint = _instance_hint[hint_key][0]
-                        if prev_R > prev_cap:
-                            raise RuntimeError("gftorf_amd: the previous no-host-read forward of this shape had %d instances for a "
-                                               "binning buffer of %d: its outputs were undefined (the buffer has been enlarged "
-                                               "for the following frames)" % (prev_R, prev_cap))
                     cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
                     binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
                     io.binning = binning.data_ptr()
                     hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
                                               whole_lists=_whole_lists(tiles_key, n_tiles))
                     _lib.check(lib.gft_forward_enqueue(stream, C.byref(cfg), C.byref(io), C.byref(hints), st["dev"].data_ptr()))
-                    st["cap"] = cap
                     st["host"].copy_(st["dev"], non_blocking=True)
                     R = -1                     # (not known to the host)
                 elif hint is None:
@@ -662,7 +680,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                         _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, int(max_list.value)))
                 # slowly decaying maximum: alternating views of one scene (colour / ToF camera,
                 # random training views) keep the larger count as the guess
-                if not nowait:
+                if st is None:
                     prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
                     _instance_hint[hint_key] = (max(R, int((prev_r or 0) * 0.95)), max(int(max_list.value), int(prev_l * 0.95)))
                     if len(_instance_hint) > 64:

@@ -451,11 +451,11 @@ int gft_render_mode()
 
 // preprocess + instance counting; the totals arrive in the mailbox slot
 static int enqueue_count(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g, const ImgView& im,
-                         uint32_t* mail_dev, uint32_t seq, bool pull);
+                         uint32_t* mail_dev, uint32_t seq, bool pull, int64_t status_cap = -1);
 
 // `count` = false: geometry only; the scatter pass of stage 2 bins by the caller's list schedule and posts the totals
 static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g,
-                          const ImgView& im, uint32_t* mail_dev, uint32_t seq, bool pull, bool count = true)
+                          const ImgView& im, uint32_t* mail_dev, uint32_t seq, bool pull, bool count = true, int64_t status_cap = -1)
 {
     {
         // (the preprocess kernel also zeroes the ctrl words, the tile counters and the supertile tables for the binning
@@ -476,11 +476,11 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
         GFT_CHECK_HIP(hipEventRecord(f->filled, f->stream));
         f->pending = true;
     }
-    return count ? enqueue_count(s, cfg, io, g, im, mail_dev, seq, pull) : 0;
+    return count ? enqueue_count(s, cfg, io, g, im, mail_dev, seq, pull, status_cap) : 0;
 }
 
 static int enqueue_count(hipStream_t s, const gft_config* cfg, const gft_forward_io* io, const GeomView& g, const ImgView& im,
-                         uint32_t* mail_dev, uint32_t seq, bool pull)
+                         uint32_t* mail_dev, uint32_t seq, bool pull, int64_t status_cap)
 {
     StageTimer t(s, ST_TILE_COUNT);
     if (pull) {
@@ -488,9 +488,9 @@ static int enqueue_count(hipStream_t s, const gft_config* cfg, const gft_forward
         none.keys = nullptr; none.point_list = nullptr;
         const int T = ((cfg->W + GFT_TILE_X - 1) / GFT_TILE_X) * ((cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y);
         GFT_STAGE(s, cfg, "super_count", gft_launch_super_bin(s, *cfg, g, im, none, mail_dev, seq, 0, 0u,
-                                                              gft_fwd_segmented(T) ? nullptr : io->tile_hints, io->cell_sched));
+                                                              gft_fwd_segmented(T) ? nullptr : io->tile_hints, io->cell_sched, status_cap));
     } else {
-        GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im, mail_dev, seq));
+        GFT_STAGE(s, cfg, "tile_count", gft_launch_tile_count(s, *cfg, g, im, mail_dev, seq, status_cap));
     }
     return 0;
 }
@@ -704,8 +704,8 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
 // ---- forward, queued only ------------------------------------------------------------
 // Both stages back to back and no read of anything the device computes: the call is pure launch work, so a caller may
 // capture it in a HIP graph (torch.cuda.graphs) or simply not stall.  What the blocking flows learn from the mailbox the
-// device posts into `status` instead (GFT_STATUS_WORDS words of pinned host or device memory owned by the caller, cleared
-// here on the stream): status[0] = R, status[1] bit 0 = "prefiltered point culled", status[3] = 1 once stage 1 has
+// device posts into `status` instead (GFT_STATUS_WORDS words of pinned host or device memory owned by the caller, its first
+// GFT_STATUS_STICKY words cleared here on the stream): status[0] = R, status[1] bit 0 = "prefiltered point culled", status[3] = 1 once stage 1 has
 // posted.  The stage-2 kernels compare R with the buffer themselves and do nothing when it does not fit: the caller reads
 // `status` whenever the stream has passed -- typically in front of its next call -- and re-renders with a larger buffer.
 static_assert(GFT_STATUS_WORDS == GFT_CTRL_WORDS, "the status block is a mailbox slot");
@@ -719,7 +719,9 @@ extern "C" int gft_forward_enqueue(void* hip_stream, const gft_config* cfg, cons
     const int64_t binning_instances = hints->binning_instances;
     if (binning_instances < 0 || binning_instances > 0xffffffffll) return gft_fail("gft_forward_enqueue: bad instance count");
     hipStream_t s = (hipStream_t)hip_stream;
-    if (status) GFT_CHECK_HIP(hipMemsetAsync(status, 0, GFT_STATUS_WORDS * sizeof(uint32_t), s));
+    // (the words from GFT_STATUS_STICKY on are the owner's to clear: overflow count, largest overflowing R -- a caller that runs
+    // ahead of the device finds them whichever frame's posting the first words hold by then)
+    if (status) GFT_CHECK_HIP(hipMemsetAsync(status, 0, GFT_STATUS_STICKY * sizeof(uint32_t), s));
     if (cfg->P == 0) {
         // (no kernel posts anything: R = 0 fits every buffer)
         if (status) GFT_CHECK_HIP(hipMemsetAsync(status + GFT_CTRL_SEQ, 1, 1, s));
@@ -733,7 +735,7 @@ extern "C" int gft_forward_enqueue(void* hip_stream, const gft_config* cfg, cons
     ImgView im = gft_img_view(io->img, L);
     BinView b = gft_bin_view(io->binning, L);
     const bool pull = pull_enabled(cfg);
-    if (enqueue_stage1(s, cfg, io, g, im, status, 1u, pull)) return 1;
+    if (enqueue_stage1(s, cfg, io, g, im, status, 1u, pull, true, status ? binning_instances : -1)) return 1;
     if (pull && binning_instances == 0) {
         const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
         GFT_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s));

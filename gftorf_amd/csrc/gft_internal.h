@@ -78,6 +78,17 @@ struct BinView {
 #define GFT_CTRL_FWDORDER 10 // this frame's forward has a heavy-first tile order of its own (from the caller's tile_weights), in tile_cursor
 #define GFT_CTRL_ORDER_OK 11 // the forward computed the backward's heavy-first tile order
 #define GFT_CTRL_WORDS 16
+// status block of gft_forward_enqueue (a mailbox slot the caller owns): the sticky words, kept by the kernel that posts R
+// (`post` = binning_instances + 1 of the frame, 0 = `mail` is no status block)
+__device__ __forceinline__ void gft_status_sticky(uint32_t* mail, uint32_t post, uint32_t R)
+{
+    if (!post) return;
+    mail[GFT_STATUS_CAP] = post - 1u;
+    if (R > post - 1u) {
+        __hip_atomic_fetch_add(&mail[GFT_STATUS_OVERFLOWS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_max(&mail[GFT_STATUS_MAX_R], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 // Behind the ctrl words: first-level ticket counters of the count pass.  Its ~1000 workgroups are resident together and all
 // draw a ticket at about the same time; returning atomics on ONE address are served one after the other (~10 ns each):
 // the workgroup that draws the last ticket -- the one that scans -- waited ~10 us for its answer.  Workgroup b draws from
@@ -162,8 +173,10 @@ hipError_t gft_launch_preprocess_fwd(hipStream_t s, const gft_config& c, const g
 hipError_t gft_launch_appearance(hipStream_t s, const gft_config& c, const gft_forward_io& io, const GeomView& g,
                                  const ImgView& im, uint32_t cap);
 // whole-frame binning (reference structure: every instance counted, scattered and sorted)
+// (status_cap >= 0: `mail` is a status block of gft_forward_enqueue, the binning buffer holds that many instances: the poster
+// also keeps the block's sticky words -- include/gftorf_rast.h, GFT_STATUS_OVERFLOWS)
 hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                 uint32_t* mail, uint32_t seq);
+                                 uint32_t* mail, uint32_t seq, int64_t status_cap = -1);
 hipError_t gft_launch_tile_scatter(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
                                    const BinView& b, uint32_t cap, int64_t expect);
 hipError_t gft_launch_tile_sort(hipStream_t s, const gft_config& c, int64_t max_tile_list, const ImgView& im,
@@ -182,7 +195,7 @@ struct SuperShape { int gx, gy, T, sshift, sgx, sgy, NS, K, kshift; uint32_t nea
 SuperShape gft_super_shape(const gft_config& c);
 hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
                                 uint32_t* mail, uint32_t seq, int pass, uint32_t cap, const uint32_t* hints = nullptr,
-                                uint32_t* sched = nullptr);
+                                uint32_t* sched = nullptr, int64_t status_cap = -1);
 size_t gft_cell_sched_words_of(const gft_config& c);
 hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
                                 uint32_t cap, float* clear, size_t clear_bytes, const uint32_t* hints, bool whole_lists);

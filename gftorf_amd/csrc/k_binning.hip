@@ -102,6 +102,7 @@ struct CountArgs {
     uint32_t* __restrict__ cursor;
     uint32_t* ctrl;
     uint32_t* mail; uint32_t seq;
+    uint32_t post;                  // `mail` is a status block of gft_forward_enqueue: its binning_instances + 1 (0: a mailbox slot)
     uint16_t* __restrict__ blockhist;
 };
 
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_tile_count(CountArgs a)
         if (a.mail) {
             a.mail[GFT_CTRL_TOTAL] = total;          // (GFT_CTRL_FLAGS of the slot belongs to the preprocess kernel)
             a.mail[GFT_CTRL_MAXCNT] = longest;
+            gft_status_sticky(a.mail, a.post, total);
             __hip_atomic_store(&a.mail[GFT_CTRL_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(SORT_BIG_THREADS) void k_tile_tail(int T, const uin
 #define SORT_LDS_LARGE_BYTES (SORT_SLOTS(SORT_LDS_LARGE) * 8)
 
 hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im,
-                                 uint32_t* mail, uint32_t seq)
+                                 uint32_t* mail, uint32_t seq, int64_t status_cap)
 {
     const int gx = (c.W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (c.H + GFT_TILE_Y - 1) / GFT_TILE_Y;
     const int T = gx * gy;
@@ -665,6 +667,7 @@ hipError_t gft_launch_tile_count(hipStream_t s, const gft_config& c, const GeomV
     a.tile_cnt = im.tile_cnt;
     a.ranges = im.ranges;
     a.cursor = im.tile_cursor; a.ctrl = im.ctrl; a.mail = mail; a.seq = seq;
+    a.post = (status_cap >= 0 && mail) ? (uint32_t)status_cap + 1u : 0u;
     a.blockhist = (T <= BIN_LDS_MAX_TILES && T <= GFT_BLOCKHIST_TILES) ? g.blockhist : nullptr;
     if (T <= BIN_LDS_MAX_TILES) hipLaunchKernelGGL((k_tile_count<true>), dim3(blocks), dim3(BIN_THREADS), (size_t)T * 4, s, a);
     else hipLaunchKernelGGL((k_tile_count<false>), dim3(blocks), dim3(BIN_THREADS), 0, s, a);

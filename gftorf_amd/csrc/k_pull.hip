@@ -86,6 +86,7 @@ struct SuperArgs {
     uint32_t* ctrl;
     uint32_t* mail; uint32_t seq;
     uint32_t cap;
+    uint32_t post;                  // `mail` is a status block of gft_forward_enqueue: its binning_instances + 1 (0: a mailbox slot)
     const uint32_t* __restrict__ hints;      // pass 0: the caller's per-tile schedule (may be NULL): its non-zero words are counted for the host
     // pass 1 on big tile grids: the workgroup's entries are grouped by cell in LDS first (`stage_cap` of them: 8 bytes + a
     // 16-bit cell each behind the three cell tables) and leave as runs of consecutive lanes.  0: every entry is written
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_super_bin(SuperArgs a)
                 a.mail[GFT_CTRL_MAXCNT] = 0u;
                 a.mail[GFT_CTRL_ENTRIES] = entries_total;
                 a.mail[GFT_CTRL_NHINT] = a.hints ? s_sum : 0u;
+                gft_status_sticky(a.mail, a.post, R);
                 __hip_atomic_store(&a.mail[GFT_CTRL_SEQ], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -1251,9 +1253,11 @@ size_t gft_cell_sched_words_of(const gft_config& c) { const SuperShape sh = gft_
 // pass 0: count (+ R, mailbox); pass 1: scatter of the entries to their (supertile, slab) lists; pass 2: the scatter by the
 // caller's schedule, without a count pass in front (+ R, mailbox)
 hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomView& g, const ImgView& im, const BinView& b,
-                                uint32_t* mail, uint32_t seq, int pass, uint32_t cap, const uint32_t* hints, uint32_t* sched)
+                                uint32_t* mail, uint32_t seq, int pass, uint32_t cap, const uint32_t* hints, uint32_t* sched,
+                                int64_t status_cap)
 {
     SuperArgs a;
+    a.post = (status_cap >= 0 && mail) ? (uint32_t)status_cap + 1u : 0u;
     a.hints = pass != 1 ? hints : nullptr;
     a.sched = pass != 1 ? sched : nullptr;
     if (pass == 2 && !sched) return hipErrorInvalidValue;

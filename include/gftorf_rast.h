@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GFT_ABI_VERSION 11
+#define GFT_ABI_VERSION 12
 
 /* compile-time constants of the reference (RAST/cuda_rasterizer/config.h:15-23) */
 #define GFT_NUM_CHANNELS 3
@@ -376,9 +376,18 @@ int gft_forward(void* hip_stream, const gft_config* cfg, const gft_forward_io* i
  * culled" (the reference's error, rasterizer_impl.cu: trap), status[2] = longest tile list (whole-frame binning),
  * status[3] = 1 once posted, status[5] = list entries, status[8] = hinted tiles.  If R > hints->binning_instances the stage-2 kernels have done
  * nothing (they compare the count on the device): the outputs of that frame are undefined and the caller, reading
- * `status` once the stream has passed (in front of its next call, say), renders again with a larger buffer.  Same kernels,
- * same results as gft_forward().  cfg->debug is refused (it synchronises). */
+ * `status` once the stream has passed (in front of its next call, say), renders again with a larger buffer.
+ * A caller that runs ahead of the device (the purpose of the mode) may find the posting of frame N overwritten by frame
+ * N + 1's before it looks: the words from GFT_STATUS_STICKY on are therefore NEVER cleared by the library -- the owner zeroes
+ * the block once -- and only ever grow: status[GFT_STATUS_OVERFLOWS] counts the frames that posted R > their
+ * binning_instances, status[GFT_STATUS_MAX_R] is the largest such R; status[GFT_STATUS_CAP] is the binning_instances of the
+ * frame that posted status[0] (so the pair is self-consistent whichever frame it belongs to).  Same kernels, same results as
+ * gft_forward().  cfg->debug is refused (it synchronises). */
 #define GFT_STATUS_WORDS 16
+#define GFT_STATUS_STICKY 12     /* words [12, 16) survive gft_forward_enqueue's clear */
+#define GFT_STATUS_CAP 12
+#define GFT_STATUS_OVERFLOWS 13
+#define GFT_STATUS_MAX_R 14
 int gft_forward_enqueue(void* hip_stream, const gft_config* cfg, const gft_forward_io* io,
                         const gft_forward_hints* hints, uint32_t* status /*device-accessible, may be NULL*/);
 

@@ -63,6 +63,35 @@ def test_forward_without_a_host_read(oracle, gpu):
             for k in ref_grads:
                 if ref_grads[k] is not None:
                     Hh.assert_close(k, ref_grads[k], grads[k], rtol_max=1e-5)
+        # A host that runs AHEAD of the device: frame N overflows, the host has not seen its posting when it queues frame
+        # N + 1 (which fits and overwrites the posting), and looks for the first time in front of frame N + 2.  The overflow
+        # count is a word of the status block that nothing clears: frame N is still reported.
+        st = api._status[key]
+        good_hint = api._instance_hint[key]
+        api._instance_hint[key] = (64, 0)
+        Hh.run_gpu(scene, gpu)                                      # frame N: does not fit
+        st["np"][3] = 0
+        st["np"][13] = st["seen"]                                   # (as if the copy of its posting had not arrived yet)
+        api._instance_hint[key] = good_hint
+        Hh.run_gpu(scene, gpu)                                      # frame N + 1: fits, its posting replaces frame N's
+        torch.cuda.synchronize()
+        rep = [x for x in api.enqueue_status() if x["key"] == key][0]
+        assert not rep["overflow"] and rep["overflows"] == 2 and rep["max_overflow_instances"] == f.num_rendered
+        with pytest.raises(RuntimeError, match="outputs were undefined"):
+            Hh.run_gpu(scene, gpu)                                  # frame N + 2 finds the count
+        out, grads, _ = Hh.run_gpu(scene, gpu)
+        for k in ref_out:
+            np.testing.assert_array_equal(out[k], ref_out[k], err_msg=k)
+        # ... and a shape the operator has never seen (the first frame of a process, a new P after a densification step)
+        # takes the blocking flow once instead of raising, then goes on without host reads
+        other = Hh.small_scene(P=5000, W=96, H=64, seed=32, scale_lo=0.02, scale_hi=0.1)
+        fo, _bo = Hh.run_oracle(oracle, other)
+        first, _g, _ = Hh.run_gpu(other, gpu)
+        assert api.last_call_stats["num_rendered"] == fo.num_rendered
+        second, _g, _ = Hh.run_gpu(other, gpu)
+        assert api.last_call_stats["num_rendered"] == -1
+        for k in first:
+            np.testing.assert_array_equal(first[k], second[k], err_msg=k)
     finally:
         api.no_host_read = keep
         api._instance_hint.clear()
