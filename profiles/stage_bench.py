@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np     # noqa: E402
 import torch           # noqa: E402
 from gftorf_amd import _lib, api, synth   # noqa: E402
+if os.environ.get("GFT_ABL_LIB"):          # an experiment build (python -m gftorf_amd.build --tag ...), as profiles/bench_with_lib.py
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["GFT_ABL_LIB"])
 import helpers as Hh   # noqa: E402
 
 
