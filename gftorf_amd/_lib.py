@@ -135,7 +135,7 @@ EXPORTS = [
     "gft_det_partials_bytes", "gft_get_layout", "gft_binning_capacity", "gft_set_binning_mode", "gft_binning_mode", "gft_set_render_mode", "gft_forward_preprocess", "gft_forward_render", "gft_forward", "gft_forward_enqueue", "gft_backward", "gft_grads_rezero",
     "gft_mark_visible", "gft_profile_enable", "gft_profile_reset", "gft_profile_read",
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
-    "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi", "gft_adam_step_rows",
+    "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi", "gft_adam_step_rows", "gft_adam_step_multi_dev",
     "gft_deform_inputs", "gft_deform_packed_bytes", "gft_deform_saved_bytes", "gft_deform_scratch_bytes", "gft_deform_pack",
     "gft_deform_forward", "gft_deform_backward", "gft_deform_compact",
     "gft_densify_stats", "gft_rows_rank_scratch_bytes", "gft_rows_rank", "gft_rows_gather", "gft_rows_any_nonzero",
@@ -189,6 +189,9 @@ def load():
     lib.gft_adam_step_multi.restype = C.c_int
     lib.gft_adam_step_multi.argtypes = [C.c_void_p, C.c_int32, C.POINTER(AdamTensor), C.c_double, C.c_double, C.c_double,
                                         C.c_double]
+    lib.gft_adam_step_multi_dev.restype = C.c_int
+    lib.gft_adam_step_multi_dev.argtypes = [C.c_void_p, C.c_int32, C.POINTER(AdamTensor), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                            C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
     lib.gft_adam_step_rows.restype = C.c_int
     lib.gft_adam_step_rows.argtypes = [C.c_void_p, C.c_int32, C.POINTER(AdamTensor), C.c_int64, C.c_void_p, C.c_double, C.c_double,
                                        C.c_double, C.c_double]

@@ -64,7 +64,30 @@ struct AdamMultiArgs {
     struct T { float* p; const float* g; float* m; float* v; int64_t n; float step_size, bias2_sqrt; uint32_t first_block; uint32_t pad; } t[GFT_ADAM_MAX_TENSORS];
 };
 
-__global__ __launch_bounds__(ADAM_BLOCK) void k_adam_multi(AdamMultiArgs a)
+// Learning rates and step counts on the device (gft_adam_step_multi_dev): one workgroup, thread c advances step[c] and leaves
+// the two derived factors of tensor c where the update kernel behind it reads them.
+struct AdamTickArgs {
+    int count;
+    double beta1, beta2;
+    float* factors;
+    const double* lr[GFT_ADAM_MAX_TENSORS];
+    float* step[GFT_ADAM_MAX_TENSORS];
+};
+
+__global__ __launch_bounds__(64) void k_adam_tick(AdamTickArgs a)
+{
+    const int c = threadIdx.x;
+    if (c >= a.count) return;
+    const float t = *a.step[c] + 1.0f;
+    *a.step[c] = t;
+    const double lr = *a.lr[c];
+    // torch/optim/adam.py: step_size = lr / (1 - beta1 ** step); bias_correction2_sqrt = (1 - beta2 ** step) ** 0.5
+    a.factors[2 * c] = (float)(lr / (1.0 - pow(a.beta1, (double)t)));
+    a.factors[2 * c + 1] = (float)sqrt(1.0 - pow(a.beta2, (double)t));
+}
+
+template <bool DEV>
+__global__ __launch_bounds__(ADAM_BLOCK) void k_adam_multi(AdamMultiArgs a, const float* __restrict__ factors)
 {
     int k = 0;
 #pragma unroll 1
@@ -74,6 +97,10 @@ __global__ __launch_bounds__(ADAM_BLOCK) void k_adam_multi(AdamMultiArgs a)
     s.n = a.t[k].n; s.p = a.t[k].p; s.g = a.t[k].g; s.m = a.t[k].m; s.v = a.t[k].v;
     s.one_m_beta1 = a.one_m_beta1; s.beta2 = a.beta2; s.one_m_beta2 = a.one_m_beta2; s.step_size = a.t[k].step_size;
     s.bias2_sqrt = a.t[k].bias2_sqrt; s.eps = a.eps; s.weight_decay = a.weight_decay;
+    if (DEV) {          // (t[k].pad: the tensor's index in the caller's table = its slot in `factors`)
+        s.step_size = factors[2 * a.t[k].pad];
+        s.bias2_sqrt = factors[2 * a.t[k].pad + 1];
+    }
     const uint32_t blk = blockIdx.x - a.t[k].first_block;
     const int64_t n4 = s.n >> 2;
     // ADAM_ITEMS 16-byte groups per thread, all their loads issued before the arithmetic (index clamped, the stores
@@ -179,7 +206,8 @@ __global__ __launch_bounds__(ADAM_BLOCK) void k_adam_rows(AdamRowsArgs a)
 
 // fills the per-tensor table of a launch from tensors[c0 ...]; returns the number of entries (< 0: error)
 static int adam_table(AdamMultiArgs& a, const gft_adam_tensor* tensors, int32_t c0, int32_t count, double beta1, double beta2,
-                      double eps, double weight_decay, uint64_t* blocks_out, int64_t rows, uint32_t* row_floats, const char* who)
+                      double eps, double weight_decay, uint64_t* blocks_out, int64_t rows, uint32_t* row_floats, const char* who,
+                      bool dev = false)
 {
     a.one_m_beta1 = (float)(1.0 - beta1);
     a.beta2 = (float)beta2;
@@ -192,7 +220,7 @@ static int adam_table(AdamMultiArgs& a, const gft_adam_tensor* tensors, int32_t 
         const gft_adam_tensor& t = tensors[c];
         if (t.n < 0) { gft_fail("%s: tensor %d has n < 0", who, c); return -1; }
         if (t.n == 0) continue;
-        if (t.step < 1) { gft_fail("%s: tensor %d: step must be >= 1", who, c); return -1; }
+        if (!dev && t.step < 1) { gft_fail("%s: tensor %d: step must be >= 1", who, c); return -1; }
         if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq) { gft_fail("%s: tensor %d has a NULL pointer", who, c); return -1; }
         if ((((uintptr_t)t.param | (uintptr_t)t.grad | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq) & 15) != 0) {
             gft_fail("%s: pointers of tensor %d are not 16-byte aligned", who, c);
@@ -203,9 +231,9 @@ static int adam_table(AdamMultiArgs& a, const gft_adam_tensor* tensors, int32_t 
             row_floats[k] = (uint32_t)(t.n / rows);
         }
         a.t[k].p = t.param; a.t[k].g = t.grad; a.t[k].m = t.exp_avg; a.t[k].v = t.exp_avg_sq; a.t[k].n = t.n;
-        a.t[k].step_size = (float)(t.lr / (1.0 - pow(beta1, (double)t.step)));
-        a.t[k].bias2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t.step));
-        a.t[k].first_block = (uint32_t)blocks; a.t[k].pad = 0;
+        a.t[k].step_size = dev ? 0.f : (float)(t.lr / (1.0 - pow(beta1, (double)t.step)));
+        a.t[k].bias2_sqrt = dev ? 1.f : (float)sqrt(1.0 - pow(beta2, (double)t.step));
+        a.t[k].first_block = (uint32_t)blocks; a.t[k].pad = (uint32_t)(c - c0);
         const int64_t n4 = t.n >> 2;
         const int64_t per_block = (int64_t)ADAM_BLOCK * (row_floats ? 1 : ADAM_ITEMS);       // 16-byte groups per workgroup
         blocks += n4 > 0 ? (uint64_t)((n4 + per_block - 1) / per_block) : 1;
@@ -249,9 +277,40 @@ extern "C" int gft_adam_step_multi(void* hip_stream, int32_t count, const gft_ad
         const int k = adam_table(a, tensors, c0, count, beta1, beta2, eps, weight_decay, &blocks, 0, nullptr, "gft_adam_step_multi");
         if (k < 0) return 1;
         if (k == 0) continue;
-        hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)blocks), dim3(ADAM_BLOCK), 0, (hipStream_t)hip_stream, a);
+        hipLaunchKernelGGL(k_adam_multi<false>, dim3((unsigned)blocks), dim3(ADAM_BLOCK), 0, (hipStream_t)hip_stream, a, (const float*)nullptr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return gft_fail("gft_adam_step_multi: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
+
+extern "C" int gft_adam_step_multi_dev(void* hip_stream, int32_t count, const gft_adam_tensor* tensors, const double* const* lr,
+                                       float* const* step, float* factors, double beta1, double beta2, double eps,
+                                       double weight_decay)
+{
+    if (count < 0) return gft_fail("gft_adam_step_multi_dev: count < 0");
+    if (count == 0) return 0;
+    if (!tensors || !lr || !step || !factors) return gft_fail("gft_adam_step_multi_dev: NULL argument");
+    for (int32_t c0 = 0; c0 < count; c0 += GFT_ADAM_MAX_TENSORS) {
+        const int32_t c1 = count < c0 + GFT_ADAM_MAX_TENSORS ? count : c0 + GFT_ADAM_MAX_TENSORS;
+        AdamTickArgs tick;
+        tick.count = c1 - c0; tick.beta1 = beta1; tick.beta2 = beta2; tick.factors = factors + 2 * (size_t)c0;
+        for (int32_t c = c0; c < c1; c++) {
+            if (!lr[c] || !step[c]) return gft_fail("gft_adam_step_multi_dev: tensor %d: lr / step pointer is NULL", c);
+            tick.lr[c - c0] = lr[c]; tick.step[c - c0] = step[c];
+        }
+        AdamMultiArgs a;
+        uint64_t blocks = 0;
+        const int k = adam_table(a, tensors, c0, count, beta1, beta2, eps, weight_decay, &blocks, 0, nullptr, "gft_adam_step_multi_dev", true);
+        if (k < 0) return 1;
+        // (the counts advance for every tensor of the table, as torch's capturable Adam advances state["step"] -- also for an
+        // empty tensor, which takes no update)
+        hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, tick);
+        if (k > 0)
+            hipLaunchKernelGGL(k_adam_multi<true>, dim3((unsigned)blocks), dim3(ADAM_BLOCK), 0, (hipStream_t)hip_stream, a,
+                               (const float*)(factors + 2 * (size_t)c0));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return gft_fail("gft_adam_step_multi_dev: %s", hipGetErrorString(e));
     }
     return 0;
 }

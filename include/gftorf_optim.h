@@ -55,6 +55,20 @@ int gft_adam_step_multi(void* hip_stream, int32_t count, const gft_adam_tensor* 
 int gft_adam_step_rows(void* hip_stream, int32_t count, const gft_adam_tensor* tensors /*host*/, int64_t rows,
                        const uint8_t* row_mask, double beta1, double beta2, double eps, double weight_decay);
 
+/* The same launch with the learning rates and step counts ON THE DEVICE: nothing the update depends on is baked into the
+ * call, so it can be captured in a HIP graph (torch.cuda.graphs around a whole training iteration) and replayed while the
+ * schedule moves the learning rates.  tensors[c].lr / .step are ignored; lr[c] (device, double: the Python float the
+ * reference's scheduler computes, scene/gaussian_model.py:294-310) and step[c] (device, fp32 count of updates DONE, as
+ * torch's capturable Adam keeps it) are read by a one-workgroup kernel in front of the update, which adds 1 to every
+ * step[c] and derives lr / (1 - beta1^t) and sqrt(1 - beta2^t) in double precision, rounded to fp32 once -- the factors
+ * gft_adam_step_multi forms on the host, to the rounding of the device's double pow -- into factors[2 c], factors[2 c + 1]
+ * (device scratch, 2 * count floats).
+ * lr and step are given per tensor (arrays of device pointers, host) because optimizer state is edited tensor by tensor
+ * (scene/gaussian_model.py:456-540). */
+int gft_adam_step_multi_dev(void* hip_stream, int32_t count, const gft_adam_tensor* tensors /*host*/,
+                            const double* const* lr /*host array of device pointers*/, float* const* step /*host array of device pointers*/,
+                            float* factors /*device, 2 * count floats*/, double beta1, double beta2, double eps, double weight_decay);
+
 #ifdef __cplusplus
 }
 #endif

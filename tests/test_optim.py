@@ -148,3 +148,61 @@ def test_gradient_view_at_an_odd_offset_and_row_params(gpu):
     opt.step(visibility=vis, row_params=[x])
     assert (w.detach() != 1.0).all()                                  # dense step
     assert (x.detach()[1:6] == 1.0).all() and (x.detach()[0] != 1.0).all()
+
+
+@pytest.mark.gpu
+def test_capturable_adam_equals_the_eager_one_and_replays(gpu):
+    """FusedAdam(capturable=True): step counts and learning rates on the device.  Eager steps equal the non-capturable ones
+    bit for bit (the bias corrections are the same doubles rounded once); a step captured in a graph and replayed follows
+    the learning rates the scheduler writes between replays (refresh_lr) and new gradient VALUES in the static tensors."""
+    from gftorf_amd import FusedAdam
+    ref = run(FusedAdam, gpu, steps=5)
+    got = run(FusedAdam, gpu, steps=5, capturable=True)
+    for gr, gg in zip(ref.param_groups, got.param_groups):
+        pr, pg = gr["params"][0], gg["params"][0]
+        sr, sg = ref.state[pr], got.state[pg]
+        assert sg["step"].is_cuda and float(sr["step"]) == float(sg["step"])
+        for name, a, b in (("param", pr, pg), ("exp_avg", sr["exp_avg"], sg["exp_avg"]), ("exp_avg_sq", sr["exp_avg_sq"], sg["exp_avg_sq"])):
+            assert torch.equal(a, b), "%s of group %s" % (name, gr["name"])
+    # ---- under a graph: static gradient tensors, learning rates that move between replays
+    gen = torch.Generator().manual_seed(7)
+    sched = lambda it, base: base * (0.9 ** it)
+
+    def make(capturable):
+        gs = groups(gpu, seed=3)
+        opt = FusedAdam(gs, lr=0.0, eps=1e-15, capturable=capturable)
+        for g in opt.param_groups:
+            g["base_lr"] = g["lr"]
+            g["params"][0].grad = torch.zeros_like(g["params"][0])
+        return opt
+    eager, cap = make(False), make(True)
+    grads = [[torch.randn(g["params"][0].shape, generator=gen).to(gpu) for g in eager.param_groups] for _ in range(6)]
+
+    def load(opt, it):
+        for g, gr in zip(opt.param_groups, grads[it]):
+            g["params"][0].grad.copy_(gr)
+            g["lr"] = sched(it, g["base_lr"])
+    load(eager, 0), load(cap, 0)
+    eager.step(), cap.step()                          # the state is created outside the graph
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        load(cap, 1)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            cap.step()
+    torch.cuda.current_stream().wait_stream(side)
+    # (the capture itself ran nothing: iteration 1 is the first replay)
+    for it in range(1, 6):
+        load(eager, it)
+        eager.step()
+        load(cap, it)
+        cap.refresh_lr()
+        graph.replay()
+    torch.cuda.synchronize()
+    for ge, gc in zip(eager.param_groups, cap.param_groups):
+        pe, pc = ge["params"][0], gc["params"][0]
+        assert float(eager.state[pe]["step"]) == float(cap.state[pc]["step"]) == 6.0
+        assert torch.equal(pe, pc), ge["name"]
+        assert torch.equal(eager.state[pe]["exp_avg_sq"], cap.state[pc]["exp_avg_sq"])
