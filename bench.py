@@ -1223,6 +1223,10 @@ def main():
     ap.add_argument("--extras", default="all", help="comma list of extras to run (render_pair, varying_views, assemble_inputs, knn, "
                                                     "adam, deform_network, densify, train_iteration) or `all`")
     ap.add_argument("--spin-up", type=float, default=0.3, help="seconds of untimed steps before the warm-up")
+    ap.add_argument("--torch-loss", action="store_true", help="--workload C3: the loss's SSIM and L2 terms as stock torch (eight "
+                    "convolutions + elementwise launches) instead of gftorf_amd.loss.ssim_l2")
+    ap.add_argument("--graph", action="store_true", help="--workload C3: the iteration's device work captured in a HIP graph per "
+                    "(SH degree, network on / off) and replayed (bench_loop.build_loop(graph=True)); eager is the default")
     ap.add_argument("--pair", action="store_true", help="--workload C3: the two rasterizer calls of an iteration as one "
                                                          "GaussianRasterizerPair (opt-in API; default: two calls, as the reference)")
     args = ap.parse_args()
@@ -1572,7 +1576,7 @@ def main_loop(args, env, world, dev, dist):
     def region(step_fn, n):
         holder["step"] = step_fn
         return timed_steps(step_fn, n, args.warmup, sync, dist)
-    elapsed, rep, info = bench_loop.run(dev, args.steps, sync, region, pair=args.pair)
+    elapsed, rep, info = bench_loop.run(dev, args.steps, sync, region, pair=args.pair, graph=args.graph, fused_loss=not args.torch_loss)
     # roofline leg: per-stage HIP events of the rasterizer calls over 200 more iterations
     _lib.profile_reset()
     _lib.profile_enable(True)
@@ -1608,6 +1612,8 @@ def main_loop(args, env, world, dev, dist):
                                "activations, input assembly, colour + ToF rasterizer forward, ToF loss (L2 + SSIM), backward, "
                                "densification statistics, Adam (Gaussians + network)",
                        "rasterizer_calls": "GaussianRasterizerPair" if args.pair else "two GaussianRasterizer calls",
+                       "iteration_runs_as": "HIP graph replay per (SH degree, network on / off), captured after 3 eager iterations of "
+                                            "the configuration" if args.graph else "eager launches",
                        "parallelism": "replicas x%d" % world},
             "mpix_per_s": value * 2 * N / 1e6,
             "loop": rep,

@@ -64,11 +64,23 @@ C3 = dict(P=100_000, W=320, H=240, views=30, sh_degree=3, warm_up=2000, depth_ra
                 "deform network on after warm_up 2000, colour + ToF rasterizer call per iteration")
 
 
-def build_loop(dev, cfg=C3, seed=1236, pair=False):
-    """Returns (iteration_fn, info): iteration_fn(it) runs iteration `it` (1-based) and returns the loss tensor."""
+def build_loop(dev, cfg=C3, seed=1236, pair=False, graph=False, fused_loss=True):
+    """Returns (iteration_fn, info): iteration_fn(it) runs iteration `it` (1-based) and returns the loss tensor.
+
+    ``graph=True``: the iteration's device work -- deform query, activations, input assembly, both rasterizer calls, loss,
+    backward, densification statistics, both Adam steps -- is captured once per (active SH degree, network on / off) with
+    ``torch.cuda.graph`` and replayed; what changes from one iteration to the next reaches the replay through static
+    tensors (the drawn view's camera matrices, time and ground truth are copied in, the background is drawn into its
+    tensor) and through pinned memory (the learning rates: ``FusedAdam(capturable=True)``).  The same statements in the
+    same order on the same values as the eager loop; the first iterations of every configuration run eagerly.
+
+    ``fused_loss=True`` (default): the two image terms of the loss -- ``l2_loss`` and ``ssim`` of utils/loss_utils.py -- from
+    ``gftorf_amd.loss.ssim_l2`` (one launch forward, one backward) instead of eight torch convolutions and ~25 elementwise
+    launches; ``False``: stock torch, as the reference has it."""
     import torch
     from gftorf_amd import (FusedAdam, GaussianRasterizationSettings, GaussianRasterizer, GaussianRasterizerPair,
                             assemble_inputs, densify, reference_network, synth)
+    from gftorf_amd import loss as gft_loss
     P, W, H, V = cfg["P"], cfg["W"], cfg["H"], cfg["views"]
     t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
 
@@ -123,7 +135,7 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False):
                phase_f_dc=cfg["feature_phase_lr"] * ext, phase_f_rest=cfg["feature_phase_lr"] * ext / 20.0,
                amp_f_dc=cfg["feature_amp_lr"] * ext ** 2, amp_f_rest=cfg["feature_amp_lr"] * ext ** 2 / 20.0,
                opacity=cfg["opacity_lr"], scaling=cfg["scaling_lr"], rotation=cfg["rotation_lr"])
-    opt = FusedAdam([{"params": [par[k]], "lr": lrs[k], "name": k} for k in lrs], lr=0.0, eps=1e-15)
+    opt = FusedAdam([{"params": [par[k]], "lr": lrs[k], "name": k} for k in lrs], lr=0.0, eps=1e-15, capturable=graph)
     xyz_lr = expon_lr(cfg["position_lr_init"] * ext, cfg["position_lr_final"] * ext, cfg["position_lr_max_steps"])
 
     class _Args:      # DeformNetwork.initialize_weights reads two flags (time_utils.py:83-101)
@@ -133,7 +145,8 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False):
     net = reference_network()
     net.initialize_weights(_Args())
     net = net.to(dev)
-    opt_net = FusedAdam([{"params": list(net.parameters()), "lr": cfg["deform_lr_init"], "name": "deform"}], lr=0.0, eps=1e-15)
+    opt_net = FusedAdam([{"params": list(net.parameters()), "lr": cfg["deform_lr_init"], "name": "deform"}], lr=0.0, eps=1e-15,
+                        capturable=graph)
     net_lr = expon_lr(cfg["deform_lr_init"], cfg["deform_lr_final"], cfg["position_lr_max_steps"] - cfg["warm_up"])
 
     mask = torch.ones((P,), dtype=torch.bool, device=dev)           # torf: every Gaussian is dynamic
@@ -146,24 +159,10 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False):
         state["ssim_ok"] = False
     pyrng = random.Random(seed)
 
-    def iteration(it):
-        # background seeded by the iteration, generator state kept (train.py:120-129)
-        rs = torch.random.get_rng_state()
-        torch.manual_seed(it)
-        bg_map = torch.rand((7, H, W), dtype=torch.float32, device=dev) * 2 - 1
-        torch.random.set_rng_state(rs)
-        for gr in opt.param_groups:                                  # gaussian_model.py:294-310
-            if gr["name"] == "xyz":
-                gr["lr"] = xyz_lr(it)
-        opt_net.param_groups[0]["lr"] = net_lr(it - cfg["warm_up"])
-        if it % 1000 == 0 and state["degree"] < cfg["sh_degree"]:
-            state["degree"] += 1
-        if not state["stack"]:
-            state["stack"] = list(range(V))
-        v = state["stack"].pop(pyrng.randint(0, len(state["stack"]) - 1))
+    def body(cc, ct, bg_map, gt_v, tt, degree, net_on):
+        """The device work of one iteration on the given camera pair, background, ground truth and time tensor."""
         d_xyz, d_rot, d_sh, d_sh_p = 0.0, 0.0, 0.0, 0.0
-        if it > cfg["warm_up"]:                                      # gaussian_model.py:170-174
-            tt = torch.full((1, 1), v / (V - 1), device=dev).expand(P, -1)
+        if net_on:                                                   # gaussian_model.py:170-174
             d_xyz, d_rot, d_sh, d_sh_p = net(par["xyz"].detach(), tt)
         # activations (gaussian_model.py:123-153)
         scaling = torch.exp(par["scaling"])
@@ -175,21 +174,24 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False):
         ssp = torch.zeros((P, 3), device=dev, requires_grad=True)
         m3, m2, op, sc, ro, shs, shp = assemble_inputs(par["xyz"], ssp, opacity, scaling, rotation, par["rotation"], feat_c, feat_p,
                                                       mask, d_xyz, d_rot, d_sh, d_sh_p, render_regions=("dynamic",))
-        cc, ct = cams[v]
         if pair:      # opt-in: both calls as one node (gftorf_amd/pair.py); same outputs
-            out_c, out_t = GaussianRasterizerPair(settings(cc, bg_map, state["degree"], False), settings(ct, bg_map, state["degree"], True))(
+            out_c, out_t = GaussianRasterizerPair(settings(cc, bg_map, degree, False), settings(ct, bg_map, degree, True))(
                 means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro,
                 phase_offset=(0.0, phase_offset), dc_offset=(0.0, 0.0))
         else:
-            out_c = GaussianRasterizer(settings(cc, bg_map, state["degree"], False))(
+            out_c = GaussianRasterizer(settings(cc, bg_map, degree, False))(
                 means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro)
-            out_t = GaussianRasterizer(settings(ct, bg_map, state["degree"], True))(
+            out_t = GaussianRasterizer(settings(ct, bg_map, degree, True))(
                 means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro, phase_offset=phase_offset,
                 dc_offset=0.0)
         tof = out_t[1][:cfg["num_phasor_channels"]]
-        l2 = ((tof - gt[v]) ** 2).mean()
-        loss = cfg["lambda_tof"] * ((1.0 - cfg["lambda_dssim"]) * l2 +
-                                    (cfg["lambda_dssim"] * (1.0 - state["ssim"](tof, gt[v])) if state["ssim_ok"] else 0.0))
+        if fused_loss:
+            s_val, l2 = gft_loss.ssim_l2(tof, gt_v)
+            loss = cfg["lambda_tof"] * ((1.0 - cfg["lambda_dssim"]) * l2 + cfg["lambda_dssim"] * (1.0 - s_val))
+        else:
+            l2 = ((tof - gt_v) ** 2).mean()
+            loss = cfg["lambda_tof"] * ((1.0 - cfg["lambda_dssim"]) * l2 +
+                                        (cfg["lambda_dssim"] * (1.0 - state["ssim"](tof, gt_v)) if state["ssim_ok"] else 0.0))
         # (render() always makes the colour-camera call, gaussian_renderer/__init__.py:107; with lambda_color = 0 its
         # outputs reach no loss, train.py:206, so autograd never runs its backward -- as in the reference)
         del out_c
@@ -199,19 +201,86 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False):
             densify.add_densification_stats(stats[0], stats[1], stats[2], ssp.grad, radii > 0, out_t[8], radii)
             opt.step()
             opt.zero_grad(set_to_none=True)
-            if it > cfg["warm_up"]:
+            if net_on:
                 opt_net.step()
                 opt_net.zero_grad(set_to_none=True)
         return loss.detach()
 
-    info = dict(P=P, W=W, H=H, views=V, ssim=state["ssim_ok"], frame=dict(cams=cams, g0=g0))
+    # ---- graph mode: what an iteration reads that changes from one to the next, as static tensors
+    if graph:
+        K = 80       # floats per view: colour camera {view 16, proj 16, campos 3 + 1}, ToF camera the same, time, padding
+        table = torch.zeros((V, K), device=dev)
+        for v, (cc, ct) in enumerate(cams):
+            for o, cam in ((0, cc), (36, ct)):
+                table[v, o:o + 16] = cam["_view"].reshape(-1)
+                table[v, o + 16:o + 32] = cam["_proj"].reshape(-1)
+                table[v, o + 32:o + 35] = cam["_campos"].reshape(-1)
+            table[v, 72] = v / (V - 1)
+        s_row = torch.zeros((K,), device=dev)
+        s_gt = torch.zeros_like(gt[0])
+        s_bg = torch.zeros((7, H, W), device=dev)
+        gt_all = torch.stack(gt).contiguous()
+        static_cams = []
+        for o, cam in ((0, cams[0][0]), (36, cams[0][1])):               # (the views share their intrinsics)
+            sc_ = dict(cam)
+            sc_["_view"], sc_["_proj"], sc_["_campos"] = s_row[o:o + 16].view(4, 4), s_row[o + 16:o + 32].view(4, 4), s_row[o + 32:o + 35]
+            static_cams.append(sc_)
+        s_tt = s_row[72:73].view(1, 1).expand(P, -1)
+        graphs = {}          # (degree, network on) -> [eager iterations so far, CUDAGraph or None, static loss]
+        EAGER_FIRST = 3      # iterations of a configuration that run eagerly before it is captured
+
+    def iteration(it):
+        for gr in opt.param_groups:                                  # gaussian_model.py:294-310
+            if gr["name"] == "xyz":
+                gr["lr"] = xyz_lr(it)
+        opt_net.param_groups[0]["lr"] = net_lr(it - cfg["warm_up"])
+        if it % 1000 == 0 and state["degree"] < cfg["sh_degree"]:
+            state["degree"] += 1
+        if not state["stack"]:
+            state["stack"] = list(range(V))
+        v = state["stack"].pop(pyrng.randint(0, len(state["stack"]) - 1))
+        net_on = it > cfg["warm_up"]
+        # background seeded by the iteration, generator state kept (train.py:120-129)
+        rs = torch.random.get_rng_state()
+        torch.manual_seed(it)
+        if not graph:
+            bg_map = torch.rand((7, H, W), dtype=torch.float32, device=dev) * 2 - 1
+            torch.random.set_rng_state(rs)
+            tt = torch.full((1, 1), v / (V - 1), device=dev).expand(P, -1) if net_on else None
+            cc, ct = cams[v]
+            return body(cc, ct, bg_map, gt[v], tt, state["degree"], net_on)
+        torch.rand((7, H, W), out=s_bg)
+        s_bg.mul_(2).sub_(1)
+        torch.random.set_rng_state(rs)
+        s_row.copy_(table[v])
+        s_gt.copy_(gt_all[v])
+        key = (state["degree"], net_on)
+        g = graphs.setdefault(key, [0, None, None])
+        if g[1] is None:
+            if g[0] < EAGER_FIRST:
+                g[0] += 1
+                return body(static_cams[0], static_cams[1], s_bg, s_gt, s_tt, state["degree"], net_on)
+            # torch's recipe for a whole-iteration capture: no gradient tensors alive, capture on a side stream
+            torch.cuda.synchronize()
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                g[2] = body(static_cams[0], static_cams[1], s_bg, s_gt, s_tt, state["degree"], net_on)
+            g[1] = cg
+            # (the capture ran nothing: this iteration is the first replay)
+        opt.refresh_lr()
+        opt_net.refresh_lr()
+        g[1].replay()
+        return g[2]
+
+    info = dict(P=P, W=W, H=H, views=V, ssim=state["ssim_ok"], frame=dict(cams=cams, g0=g0), par=par, net=net,
+                graphs=(lambda: {k: v[1] is not None for k, v in graphs.items()}) if graph else (lambda: {}))
     return iteration, info
 
 
-def run(dev, iters, sync, timed_region, cfg=C3, pair=False):
+def run(dev, iters, sync, timed_region, cfg=C3, pair=False, graph=False, fused_loss=True):
     """Runs `iters` iterations inside timed_region(step_fn, n) -> seconds.  Returns (seconds, report dict)."""
     import torch
-    iteration, info = build_loop(dev, cfg, pair=pair)
+    iteration, info = build_loop(dev, cfg, pair=pair, graph=graph, fused_loss=fused_loss)
     counter = dict(it=0)
     losses = []
 
@@ -219,8 +288,11 @@ def run(dev, iters, sync, timed_region, cfg=C3, pair=False):
         counter["it"] += 1
         l = iteration(counter["it"])
         if counter["it"] % 500 == 0 or counter["it"] == 1:
-            losses.append((counter["it"], l))
+            losses.append((counter["it"], l.clone()))        # (graph mode returns one static tensor every iteration)
     secs = timed_region(step, iters)
-    rep = dict(iterations=counter["it"], ssim_in_loss=info["ssim"],
+    rep = dict(iterations=counter["it"], ssim_in_loss=info["ssim"] or fused_loss,
+               loss_terms="gftorf_amd.loss.ssim_l2 (one launch forward, one backward)" if fused_loss else "torch: conv2d SSIM + elementwise L2",
                loss_trace=[(i, float(l.item())) for i, l in losses])
+    if graph:
+        rep["graphs_captured"] = {"degree %d, network %s" % (k[0], "on" if k[1] else "off"): v for k, v in info["graphs"]().items()}
     return secs, rep, info

@@ -13,6 +13,7 @@ from .knn import distCUDA2  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
 from .deform import DeformNetwork, REFERENCE_ARCH, reference_network  # noqa: F401
 from . import densify  # noqa: F401
+from . import loss  # noqa: F401
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "GaussianRasterizerPair", "render_pair", "assemble_inputs", "distCUDA2", "FusedAdam",
            "DeformNetwork", "REFERENCE_ARCH", "reference_network", "densify"]

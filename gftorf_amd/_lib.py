@@ -138,6 +138,7 @@ EXPORTS = [
     "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi", "gft_adam_step_rows", "gft_adam_step_multi_dev",
     "gft_deform_inputs", "gft_deform_packed_bytes", "gft_deform_saved_bytes", "gft_deform_scratch_bytes", "gft_deform_pack",
     "gft_deform_forward", "gft_deform_backward", "gft_deform_compact",
+    "gft_ssim_blocks", "gft_ssim_l2_forward", "gft_ssim_l2_backward",
     "gft_densify_stats", "gft_rows_rank_scratch_bytes", "gft_rows_rank", "gft_rows_gather", "gft_rows_any_nonzero",
 ]
 
@@ -213,6 +214,14 @@ def load():
                                         C.POINTER(DeformParams)]
     lib.gft_deform_compact.restype = C.c_int
     lib.gft_deform_compact.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 9
+    lib.gft_ssim_blocks.restype = C.c_int64
+    lib.gft_ssim_blocks.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.gft_ssim_l2_forward.restype = C.c_int
+    lib.gft_ssim_l2_forward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_float),
+                                        C.c_void_p, C.c_void_p]
+    lib.gft_ssim_l2_backward.restype = C.c_int
+    lib.gft_ssim_l2_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_float),
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
     lib.gft_densify_stats.restype = C.c_int
     lib.gft_densify_stats.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8
     lib.gft_rows_rank_scratch_bytes.restype = C.c_size_t

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libgftorf_rast.so")
-SOURCES = ["gft_api.hip", "k_preprocess.hip", "k_binning.hip", "k_pull.hip", "k_render.hip", "k_assemble.hip", "k_knn.hip", "k_adam.hip", "k_deform.hip", "k_densify.hip"]
+SOURCES = ["gft_api.hip", "k_preprocess.hip", "k_binning.hip", "k_pull.hip", "k_render.hip", "k_assemble.hip", "k_knn.hip", "k_adam.hip", "k_deform.hip", "k_densify.hip", "k_loss.hip"]
 ARCH = "gfx950"
 # The SLP vectoriser packs the render kernels' scalar fp32 maths into v_pk_* ops that need extra
 # v_mov to pair registers: measured +12 us per render kernel on the metric frame.

@@ -105,8 +105,12 @@ class _DeformFn(torch.autograd.Function):
                 raise RuntimeError("DeformNetwork parameters must be float32 on %s" % (dev,))
             ps.append(p.detach().contiguous())
         need_bw = any(ctx.needs_input_grad[5:])      # all False under torch.no_grad()
+        # (while the stream is being captured into a graph nothing may be read from the device: the backward's row selection
+        # reads a row count, so a captured call saves its activations and runs the dense backward -- the same gradients up
+        # to summation order)
+        capturing = torch.cuda.is_current_stream_capturing()
         lazy = bool(need_bw and lazy_save and sparse_backward and n >= _SPARSE_MIN_POINTS and state is not None
-                    and state.get("fraction") is not None and state["fraction"] <= _LAZY_MAX_FRACTION)
+                    and state.get("fraction") is not None and state["fraction"] <= _LAZY_MAX_FRACTION and not capturing)
         f32 = dict(device=dev, dtype=torch.float32)
         packed = torch.empty((lib.gft_deform_packed_bytes() // 4,), **f32)
         d_xyz = torch.empty((n, 3), **f32)
@@ -160,10 +164,11 @@ class _DeformFn(torch.autograd.Function):
         if ctx.lazy:
             n, saved, gx, gs = _recompute_rows(lib, ctx, n, packed, x_c, t_c, gx, gs)
             last_backward_stats["points_processed"] = n
-        elif sparse_backward and n >= _SPARSE_MIN_POINTS and (gx is not None or gs is not None):
+        elif (sparse_backward and n >= _SPARSE_MIN_POINTS and (gx is not None or gs is not None)
+              and not torch.cuda.is_current_stream_capturing()):
             n, saved, gx, gs = _compact_rows(lib, n, saved, gx, gs)
             last_backward_stats["points_processed"] = n
-        if ctx.state is not None and n_all >= _SPARSE_MIN_POINTS:
+        if ctx.state is not None and n_all >= _SPARSE_MIN_POINTS and not torch.cuda.is_current_stream_capturing():
             ctx.state["fraction"] = n / float(n_all)
         scratch = torch.empty((lib.gft_deform_scratch_bytes(n) // 4,), **f32)
         stream = _lib.raw_stream(dev)

@@ -16,10 +16,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 graph = "--graph" in sys.argv
 cfg = dict(bench_loop.C3, warm_up=0 if phase == "net" else 10 ** 9)
 dev = torch.device("cuda:0")
-if graph:
-    iteration, info = bench_loop.build_loop(dev, cfg, graph=True)
-else:
-    iteration, info = bench_loop.build_loop(dev, cfg)
+iteration, info = bench_loop.build_loop(dev, cfg, graph=graph, fused_loss="--torch-loss" not in sys.argv)
 for it in range(1, 41):
     iteration(it)
 torch.cuda.synchronize()

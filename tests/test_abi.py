@@ -25,7 +25,7 @@ def lib():
 
 HEADERS = [HEADER, os.path.join(ROOT, "include", "gftorf_assemble.h"), os.path.join(ROOT, "include", "gftorf_knn.h"),
            os.path.join(ROOT, "include", "gftorf_optim.h"), os.path.join(ROOT, "include", "gftorf_deform.h"),
-           os.path.join(ROOT, "include", "gftorf_densify.h")]
+           os.path.join(ROOT, "include", "gftorf_densify.h"), os.path.join(ROOT, "include", "gftorf_loss.h")]
 
 
 def declared_functions():
