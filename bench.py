@@ -348,7 +348,8 @@ def _cpu_baseline(oracle, Hh, scene, budget_s, max_iters, forward_only, one_core
 
 def load_counters(stage, workload):
     """Counter summary of one stage from the committed rocprofv3 --pmc passes (profiles/collect_pmc.sh +
-    make_counters.py -> profiles/counters.json): HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE), VALU
+    make_counters.py -> profiles/counters.json): HBM bytes per launch (factor*FETCH_SIZE + WRITE_SIZE, the factor calibrated per
+    access kind: profiles/fetch_factors.py), VALU
     wave-instructions per launch, resident waves per SIMD, VALU issue share.  None when the workload was not profiled."""
     path = os.path.join(ROOT, "profiles", "counters.json")
     try:
@@ -1444,6 +1445,9 @@ def main():
                     "algorithmic_bytes_per_launch": per_kernel[dom], "avg_launch_ms": dom_ms,
                     "units_processed": units,
                     "counter_frac": (gbs(traffic, dom_ms) / HBM_PEAK_GBS) if (traffic and dom_ms > 0) else None,
+                    # traffic = factor x FETCH_SIZE + WRITE_SIZE, the factor by the kernel's access kind as calibrated on the box
+                    # (profiles/fetch_factors.py, profiles/r06_fetch_calibration.json): 2 for wide streams, 1 for record gathers
+                    "traffic_fetch_factor": cnt.get("fetch_factors") if cnt else None,
                     "counter_source": cnt["source"] if cnt else None,
                     # the counter passes were taken from these kernel sources / the sources that ran now
                     "counter_source_sha": cnt.get("kernel_source_sha") if cnt else None, "kernel_source_sha": kernel_source_sha(),

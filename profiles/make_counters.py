@@ -4,14 +4,18 @@
 
 usage: make_counters.py <pmc dir> <tag> <workload>      e.g.  make_counters.py gpurun_out/pmc_C5 r02_v3 C5
 
-Writes profiles/<tag>_<workload>_pmc_traffic.json (HBM bytes per launch per kernel = 2*FETCH_SIZE + WRITE_SIZE: on
-gfx950 FETCH_SIZE counts a wide coalesced read at half its bytes, MI355X_MICROARCH.md HBM section; both counters are
-reported in KiB), profiles/<tag>_<workload>_sq_table.json (SQ passes: resident waves per SIMD, VALU issue share,
+Writes profiles/<tag>_<workload>_pmc_traffic.json (HBM bytes per launch per kernel = factor * FETCH_SIZE + WRITE_SIZE with
+the factor of the kernel's access kind as calibrated on this box -- profiles/fetch_factors.py: 2 for wide coalesced
+streams, which FETCH_SIZE counts at half their bytes (MI355X_MICROARCH.md HBM section), 1 for the record gathers of the
+blend kernels, whose 64-byte lines it counts exactly; both counters are reported in KiB), profiles/<tag>_<workload>_sq_table.json (SQ passes: resident waves per SIMD, VALU issue share,
 wait / stall shares, VALU wave-instructions per launch) and the entry counters.json[workload].  A stage that runs
 several kernels per step (tile_sort = head + tail launch, render_fwd = first pass + resume launch) sums them.
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fetch_factors
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CLOCK_GHZ, SIMDS = 2.4, 1024
@@ -68,11 +72,14 @@ def main():
         if not k.startswith("k_") or "deform" in k:
             continue
         f, w = mean(fetch[k]["FETCH_SIZE"]) * 1024, mean(write[k]["WRITE_SIZE"]) * 1024
-        traffic[k] = {"FETCH_SIZE_bytes_raw": f, "WRITE_SIZE_bytes": w, "hbm_bytes_corrected": 2 * f + w,
+        hb, kind, fac = fetch_factors.hbm_bytes(k, f, w)
+        traffic[k] = {"FETCH_SIZE_bytes_raw": f, "WRITE_SIZE_bytes": w, "hbm_bytes_corrected": hb, "access_kind": kind,
+                      "fetch_factor": fac, "hbm_bytes_if_all_streams": 2 * f + w,
                       "launches_seen": len(fetch[k]["FETCH_SIZE"]) or len(write[k]["WRITE_SIZE"])}
     t_name = "%s_%s_pmc_traffic.json" % (tag, workload)
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (collect_pmc.sh), mean per launch over "
-                       "bench.py --workload %s --steps 3 --warmup 1; hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE" % workload,
+                       "bench.py --workload %s --steps 3 --warmup 1; hbm_bytes = fetch_factor*FETCH_SIZE + WRITE_SIZE, the factor by "
+                       "the kernel's access kind (profiles/fetch_factors.py, calibrated: profiles/r06_fetch_calibration.json)" % workload,
                "per_kernel": traffic}, open(os.path.join(HERE, t_name), "w"), indent=1)
 
     v1, d1 = read(root, "sq1")
@@ -100,7 +107,7 @@ def main():
                "per_kernel": sq}, open(os.path.join(HERE, s_name), "w"), indent=1)
 
     # per stage: the kernels of a stage summed, weighted by their launches per step
-    stages = defaultdict(lambda: {"hbm_bytes": 0.0, "valu_insts": 0.0, "us_profiled": 0.0, "kernels": []})
+    stages = defaultdict(lambda: {"hbm_bytes": 0.0, "valu_insts": 0.0, "us_profiled": 0.0, "kernels": [], "fetch_factors": {}})
     # launches per forward call: count dispatches relative to k_preprocess_fwd in the same pass
     ref_n = max(len(d1.get("k_preprocess_fwd", [])), 1)
     for k, st in STAGE_OF.items():
@@ -110,6 +117,8 @@ def main():
         s = stages[st]
         s["kernels"].append(k)
         s["hbm_bytes"] += traffic.get(k, {}).get("hbm_bytes_corrected", 0.0) * per_step
+        if k in traffic:
+            s["fetch_factors"][k] = "%s x%g" % (traffic[k]["access_kind"], traffic[k]["fetch_factor"])
         if k in sq:
             s["valu_insts"] += (sq[k]["valu_insts"] or 0.0) * per_step
             s["us_profiled"] += sq[k]["us_profiled"] * per_step

@@ -4,10 +4,14 @@
 usage: make_traffic.py <pmc dir> <out json> [--update-traffic-json]
 
 rocprofv3 reports both counters in KiB.  On gfx950 FETCH_SIZE counts wide coalesced reads at
-half their size (MI355X_MICROARCH.md, HBM / rocprofv3 section), hence hbm = 2*FETCH + WRITE.
+half their size (MI355X_MICROARCH.md, HBM / rocprofv3 section) and the 64-byte lines of scattered record
+reads exactly (calibrated: profiles/fetch_factors.py), hence hbm = factor(kernel) * FETCH + WRITE.
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fetch_factors
 
 STAGE_OF = {"k_preprocess_fwd": "preprocess_fwd", "k_tile_count": "tile_count", "k_tile_scatter": "tile_scatter",
             "k_tile_sort_small": "tile_sort", "k_tile_front": "tile_sort", "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd",
@@ -37,9 +41,10 @@ def main():
         if not k.startswith("k_"):
             continue
         f, w = fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
-        per[k] = {"FETCH_SIZE_bytes_raw": f, "WRITE_SIZE_bytes": w, "hbm_bytes_corrected": 2 * f + w}
+        hb, kind, fac = fetch_factors.hbm_bytes(k, f, w)
+        per[k] = {"FETCH_SIZE_bytes_raw": f, "WRITE_SIZE_bytes": w, "hbm_bytes_corrected": hb, "access_kind": kind, "fetch_factor": fac}
     doc = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, mean per launch over bench.py "
-                   "--steps 3 --warmup 1 (metric workload); hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE",
+                   "--steps 3 --warmup 1 (metric workload); hbm_bytes = fetch_factor*FETCH_SIZE + WRITE_SIZE (profiles/fetch_factors.py)",
            "per_kernel": per}
     json.dump(doc, open(out, "w"), indent=1)
     if "--update-traffic-json" in sys.argv:
