@@ -227,7 +227,8 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False, graph=False, fused_loss=True)
             static_cams.append(sc_)
         s_tt = s_row[72:73].view(1, 1).expand(P, -1)
         graphs = {}          # (degree, network on) -> [eager iterations so far, CUDAGraph or None, static loss]
-        EAGER_FIRST = 3      # iterations of a configuration that run eagerly before it is captured
+        import os
+        EAGER_FIRST = int(os.environ.get("GFT_LOOP_EAGER_FIRST", "3"))      # iterations of a configuration that run eagerly before it is captured
 
     def iteration(it):
         for gr in opt.param_groups:                                  # gaussian_model.py:294-310
@@ -272,7 +273,7 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False, graph=False, fused_loss=True)
         g[1].replay()
         return g[2]
 
-    info = dict(P=P, W=W, H=H, views=V, ssim=state["ssim_ok"], frame=dict(cams=cams, g0=g0), par=par, net=net,
+    info = dict(P=P, W=W, H=H, views=V, ssim=state["ssim_ok"], frame=dict(cams=cams, g0=g0), par=par, net=net, opt=opt, opt_net=opt_net,
                 graphs=(lambda: {k: v[1] is not None for k, v in graphs.items()}) if graph else (lambda: {}))
     return iteration, info
 

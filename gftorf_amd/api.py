@@ -409,6 +409,30 @@ def _canonical_cap(n):
     return (int(n) + 63) // 64 * 64
 
 
+_STABLE_CAPS = _os.environ.get("GFT_STABLE_CAPS", "1") != "0"
+_POISON = _os.environ.get("GFT_POISON_SCRATCH", "0") != "0"
+
+
+def _guess_cap(hint):
+    """Capacity of the binning buffer for a frame whose instance count is guessed from recent frames: the guess plus 25 %,
+    rounded UP to four significant bits (steps of at most 6 %).  Over changing views the guess moves a little every frame;
+    without the rounding every frame asks the allocator for a buffer of another size, which torch's caching allocator
+    answers with a fresh hipMalloc (and, sooner or later, a synchronising hipFree): measured on the 30-view leg of bench.py as
+    0.57 ms of wall time per step for 0.42 ms of kernels."""
+    n = int(hint * _HINT_HEADROOM) + 4096
+    if _STABLE_CAPS and n > 16:
+        sh = n.bit_length() - 4
+        n = ((n + (1 << sh) - 1) >> sh) << sh
+    return _canonical_cap(n)
+
+
+def _scratch(nbytes, dev):
+    t = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+    if _POISON:
+        t.fill_(0x7f)
+    return t
+
+
 def binning_capacity(binning, W, H):
     """Instances a binning buffer allocated by :func:`native_forward` for a W x H frame holds."""
     return int(_lib.load().gft_binning_capacity(binning.numel(), int(W), int(H)))
@@ -512,6 +536,12 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         ib = _image_bytes[(W, H)] = int(lib.gft_image_bytes(W, H))
     geom = torch.empty((gb,), device=dev, dtype=torch.uint8)
     img = torch.empty((ib,), device=dev, dtype=torch.uint8)
+    if _POISON:
+        # debug (GFT_POISON_SCRATCH=1): the scratch buffers start as 0x7f bytes (3.4e38 as a float, 2139062143 as an index) instead
+        # of whatever the allocator's block held -- usually the previous frame's plausible values --, so a kernel that reads a field
+        # no kernel of this frame wrote shows up in the parity tests
+        geom.fill_(0x7f)
+        img.fill_(0x7f)
 
     cfg = _make_config(s, P, M, M_p, H, W, ph_off, dc_off, (bsc, bsy, bsx), want_bw)
     io = _lib.ForwardIO()
@@ -628,8 +658,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                         prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
                         _instance_hint[hint_key] = (max(prev_R, int((prev_r or 0) * 0.95)), prev_l)
                         hint = _instance_hint[hint_key][0]
-                    cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
-                    binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
+                    cap = _guess_cap(hint)
+                    binning = _scratch(lib.gft_binning_bytes(cap, W, H), dev)
                     io.binning = binning.data_ptr()
                     hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
                                               whole_lists=_whole_lists(tiles_key, n_tiles))
@@ -645,14 +675,14 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                                                           C.byref(num_rendered), C.byref(max_list)))
                     R = int(num_rendered.value)
                     cap = _canonical_cap(R)
-                    binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
+                    binning = _scratch(lib.gft_binning_bytes(cap, W, H), dev)
                     io.binning = binning.data_ptr()
                     _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, int(max_list.value)))
                 else:
                     # later frames: the buffer is sized from the recent frames' instance counts (the only thing taken
                     # from earlier frames), both stages are queued back to back
-                    cap = _canonical_cap(int(hint * _HINT_HEADROOM) + 4096)
-                    binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
+                    cap = _guess_cap(hint)
+                    binning = _scratch(lib.gft_binning_bytes(cap, W, H), dev)
                     io.binning = binning.data_ptr()
                     hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
                                               whole_lists=_whole_lists(tiles_key, n_tiles), use_cell_sched=use_sched)
@@ -675,7 +705,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     if R > cap:
                         restarted = True
                         cap = _canonical_cap(R)
-                        binning = torch.empty((lib.gft_binning_bytes(cap, W, H),), device=dev, dtype=torch.uint8)
+                        binning = _scratch(lib.gft_binning_bytes(cap, W, H), dev)
                         io.binning = binning.data_ptr()
                         _lib.check(lib.gft_forward_render(stream, C.byref(cfg), C.byref(io), cap, int(max_list.value)))
                 # slowly decaying maximum: alternating views of one scene (colour / ToF camera,
@@ -913,10 +943,9 @@ def run_backward(prep, grads_out, geom, binning, img, debug=False):
         cap = binning_capacity(binning, W, H) if P else 0
     if _DETERMINISTIC and P and cap:
         # test mode: partial rows per (list entry, quadrant), added in a fixed order (gft_backward_io.det_partials)
-        if torch.cuda.is_current_stream_capturing():
-            # (two deterministic backwards in one captured graph gave wrong sums from the second replay on -- the mode's
-            # 250-byte-per-list-slot scratch and its memset nodes; not run down: it is a test mode)
-            raise RuntimeError("gftorf_amd: GFT_BWD_DETERMINISTIC is a test mode of the eager flows and cannot be captured in a graph")
+        # (capturable since round 6: what gave wrong sums from the second replay on was the library's hipMemsetAsync of this
+        # buffer -- a large memset node is not ordered against its neighbours when a graph is replayed on this platform; the
+        # library clears with a kernel now, gft_api.hip gft_zero_async)
         det = torch.empty((lib.gft_det_partials_bytes(cap, W, H) // 4,), dtype=torch.float32, device=dev)
         io.det_partials = det.data_ptr()
     if debug:

@@ -298,6 +298,43 @@ static SideFill* side_of_current_device()
         }                                                                                    \
     } while (0)
 
+// Zero fill as a KERNEL, not hipMemsetAsync.  On this platform (ROCm 7.0 / torch 2.10) a hipMemsetAsync captured into a HIP
+// graph fills with the right value only the first time the graph is replayed; from the second replay on the buffer holds
+// garbage (profiles/experiments/graph_memset_node_repro.py: fill with ones -> memset 0 -> sum, 1 MiB and 160 MiB, pure
+// torch + HIP).  The deterministic backward's clear of its partial rows fell to it (wrong sums "from the second replay
+// on", parked in round 5; tests/test_gpu_graph.py::test_two_deterministic_backwards_in_one_graph), and every small clear of
+// a ticket or status word on a captured path was exposed to it.  The library issues no memset nodes.
+__global__ __launch_bounds__(256) void k_zero_fill(uint4* __restrict__ p16, size_t n16, uint8_t* __restrict__ tail, size_t ntail)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) p16[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+__global__ void k_post_empty(uint32_t* status) { status[GFT_CTRL_SEQ] = 1u; }      // gft_forward_enqueue with P == 0: "posted", R = 0
+
+hipError_t gft_zero_async(void* ptr, size_t bytes, hipStream_t s)
+{
+    if (!ptr || !bytes) return hipSuccess;
+    uint8_t* p = static_cast<uint8_t*>(ptr);
+    // (head up to a 16-byte boundary and tail byte-wise by the first workgroup; every caller's buffers are at least 4-byte
+    // aligned and mostly 256)
+    const size_t head = (16 - ((uintptr_t)p & 15)) & 15;
+    if (head && head < bytes) {
+        hipLaunchKernelGGL(k_zero_fill, dim3(1), dim3(256), 0, s, (uint4*)nullptr, (size_t)0, p, head);
+        p += head; bytes -= head;
+    } else if (head) {
+        hipLaunchKernelGGL(k_zero_fill, dim3(1), dim3(256), 0, s, (uint4*)nullptr, (size_t)0, p, bytes);
+        return hipGetLastError();
+    }
+    const size_t n16 = bytes / 16, ntail = bytes % 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_zero_fill, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(p), n16, p + n16 * 16, ntail);
+    return hipGetLastError();
+}
+
 static int check_config(const gft_config* c)
 {
     if (!c) return gft_fail("config is NULL");
@@ -472,7 +509,7 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
         if (!f) return gft_fail("forward: no side stream for the gradient fill");
         GFT_CHECK_HIP(hipEventRecord(f->after_main, s));
         GFT_CHECK_HIP(hipStreamWaitEvent(f->stream, f->after_main, 0));
-        GFT_CHECK_HIP(hipMemsetAsync(io->grads_zero, 0, io->grads_zero_bytes, f->stream));
+        GFT_CHECK_HIP(gft_zero_async(io->grads_zero, io->grads_zero_bytes, f->stream));
         GFT_CHECK_HIP(hipEventRecord(f->filled, f->stream));
         f->pending = true;
     }
@@ -545,7 +582,7 @@ static int enqueue_stage2(hipStream_t s, const gft_config* cfg, const gft_forwar
                 GFT_STAGE(s, cfg, "tile_sort", gft_launch_tile_sort(s, *cfg, max_tile_list, im, b, cap, clear, clear_bytes));
         }
     } else if (clear) {
-        GFT_CHECK_HIP(hipMemsetAsync(clear, 0, clear_bytes, s));
+        GFT_CHECK_HIP(gft_zero_async(clear, clear_bytes, s));
     }
     {
         StageTimer t(s, ST_RENDER_FWD);
@@ -620,8 +657,8 @@ extern "C" int gft_forward_render(void* hip_stream, const gft_config* cfg, const
         // no stage 1 ran (or its tile-pull count pass, which leaves the per-tile tables to the pull kernel): every tile
         // list is empty, all totals are zero
         const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
-        GFT_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s));
-        if (cfg->P == 0) GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, GFT_CTRL_WORDS * sizeof(uint32_t), s));
+        GFT_CHECK_HIP(gft_zero_async(im.ranges, (size_t)gx * gy * sizeof(uint2), s));
+        if (cfg->P == 0) GFT_CHECK_HIP(gft_zero_async(im.ctrl, GFT_CTRL_WORDS * sizeof(uint32_t), s));
     }
     // (two stages: the first frame of a shape, a frame that outgrew its buffer, a caller that drives the C ABI itself -- the
     // build of k_tile_pull that honours a schedule whenever one is handed over)
@@ -656,7 +693,7 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     if (pull && binning_instances == 0) {
         // (no buffer: stage 2 renders empty lists, which is right only if R turns out to be 0 -- else the caller re-runs it)
         const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
-        GFT_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s));
+        GFT_CHECK_HIP(gft_zero_async(im.ranges, (size_t)gx * gy * sizeof(uint2), s));
     }
     // stage 2 is queued before R is known; its kernels check R against the buffer themselves
     const uint32_t cap = (uint32_t)binning_instances;
@@ -670,7 +707,7 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
         // (ctrl[TOTAL] = 0xffffffff stopped every kernel behind the scatter pass).  The counted flow, in this call: clear what
         // the front end accumulates into, count (which also leaves the next frame's schedule), stage 2 again.
         const size_t T = (size_t)((cfg->W + GFT_TILE_X - 1) / GFT_TILE_X) * (size_t)((cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y);
-        GFT_CHECK_HIP(hipMemsetAsync(im.ctrl, 0, (GFT_CTRL_WORDS + GFT_TICKET_WORDS + 2 * T + GFT_SUPER_CELLS) * sizeof(uint32_t), s));
+        GFT_CHECK_HIP(gft_zero_async(im.ctrl, (GFT_CTRL_WORDS + GFT_TICKET_WORDS + 2 * T + GFT_SUPER_CELLS) * sizeof(uint32_t), s));
         if (mailbox_acquire(&mail_dev, &mail_host, &seq)) return 1;
         mail_host[GFT_CTRL_FLAGS] = host[GFT_CTRL_FLAGS] & 1u;
         // (... or the frame has more instances than the binning buffer holds: the caller's gft_forward_render with a larger one
@@ -694,7 +731,7 @@ extern "C" int gft_forward(void* hip_stream, const gft_config* cfg, const gft_fo
     // are the only accumulated output).
     if (!lazy_sort_enabled() && hints->max_tile_list > 0 && hints->max_tile_list <= GFT_SHORT_LIST_MAX &&
         host[GFT_CTRL_MAXCNT] > GFT_SHORT_LIST_MAX && host[GFT_CTRL_TOTAL] <= cap && binning_instances > 0) {
-        GFT_CHECK_HIP(hipMemsetAsync(io->pixels, 0, (size_t)cfg->P * sizeof(float), s));
+        GFT_CHECK_HIP(gft_zero_async(io->pixels, (size_t)cfg->P * sizeof(float), s));
         GFT_STAGE(s, cfg, "tile_sort_long", gft_launch_tile_sort_long(s, *cfg, im, b, cap));
         GFT_STAGE(s, cfg, "render_fwd", gft_launch_render_fwd(s, *cfg, *io, g, im, b, true, cap, 0, false));
     }
@@ -721,10 +758,10 @@ extern "C" int gft_forward_enqueue(void* hip_stream, const gft_config* cfg, cons
     hipStream_t s = (hipStream_t)hip_stream;
     // (the words from GFT_STATUS_STICKY on are the owner's to clear: overflow count, largest overflowing R -- a caller that runs
     // ahead of the device finds them whichever frame's posting the first words hold by then)
-    if (status) GFT_CHECK_HIP(hipMemsetAsync(status, 0, GFT_STATUS_STICKY * sizeof(uint32_t), s));
+    if (status) GFT_CHECK_HIP(gft_zero_async(status, GFT_STATUS_STICKY * sizeof(uint32_t), s));
     if (cfg->P == 0) {
         // (no kernel posts anything: R = 0 fits every buffer)
-        if (status) GFT_CHECK_HIP(hipMemsetAsync(status + GFT_CTRL_SEQ, 1, 1, s));
+        if (status) hipLaunchKernelGGL(k_post_empty, dim3(1), dim3(1), 0, s, status);
         return gft_forward_render(hip_stream, cfg, io, 0, 0);
     }
     if (check_stage1(cfg, io, "gft_forward_enqueue")) return 1;
@@ -738,7 +775,7 @@ extern "C" int gft_forward_enqueue(void* hip_stream, const gft_config* cfg, cons
     if (enqueue_stage1(s, cfg, io, g, im, status, 1u, pull, true, status ? binning_instances : -1)) return 1;
     if (pull && binning_instances == 0) {
         const int gx = (cfg->W + GFT_TILE_X - 1) / GFT_TILE_X, gy = (cfg->H + GFT_TILE_Y - 1) / GFT_TILE_Y;
-        GFT_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s));
+        GFT_CHECK_HIP(gft_zero_async(im.ranges, (size_t)gx * gy * sizeof(uint2), s));
     }
     return enqueue_stage2(s, cfg, io, g, im, b, binning_instances > 0, hints->max_tile_list, true, (uint32_t)binning_instances, pull,
                           hints->whole_lists != 0);
@@ -752,8 +789,8 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     hipStream_t s = (hipStream_t)hip_stream;
     // k_offset_reduce overwrites both scalars whenever shs_p is given
     if (cfg->P == 0 || io->shs_p == nullptr) {
-        if (io->dL_dphase_offset) GFT_CHECK_HIP(hipMemsetAsync(io->dL_dphase_offset, 0, sizeof(float), s));
-        if (io->dL_ddc_offset) GFT_CHECK_HIP(hipMemsetAsync(io->dL_ddc_offset, 0, sizeof(float), s));
+        if (io->dL_dphase_offset) GFT_CHECK_HIP(gft_zero_async(io->dL_dphase_offset, sizeof(float), s));
+        if (io->dL_ddc_offset) GFT_CHECK_HIP(gft_zero_async(io->dL_ddc_offset, sizeof(float), s));
     }
     if (cfg->P == 0) return 0;
     if (!io->means3D || !io->radii || !io->viewmatrix || !io->projmatrix || !io->campos || !io->geom || !io->img ||
@@ -789,12 +826,12 @@ extern "C" int gft_backward(void* hip_stream, const gft_config* cfg, const gft_b
     if (cfg->acc_zeroed < 0 || cfg->acc_zeroed > 2) return gft_fail("gft_backward: cfg.acc_zeroed must be 0, 1 or 2");
     if (!cfg->acc_zeroed) {
         StageTimer t(s, ST_MEMSET);
-        GFT_CHECK_HIP(hipMemsetAsync(io->acc, 0, (size_t)cfg->P * GFT_ACC_STRIDE * sizeof(float), s));
+        GFT_CHECK_HIP(gft_zero_async(io->acc, (size_t)cfg->P * GFT_ACC_STRIDE * sizeof(float), s));
     }
     if (num_rendered > 0 && io->det_partials) {
         // deterministic mode: slots of (entry, quadrant) pairs that store no row must read as zero
         StageTimer t(s, ST_MEMSET);
-        GFT_CHECK_HIP(hipMemsetAsync(io->det_partials, 0, gft_det_partials_bytes(num_rendered, cfg->W, cfg->H), s));
+        GFT_CHECK_HIP(gft_zero_async(io->det_partials, gft_det_partials_bytes(num_rendered, cfg->W, cfg->H), s));
     }
     if (num_rendered > 0) {
         StageTimer t(s, ST_RENDER_BWD);

@@ -157,6 +157,8 @@ ImgView gft_img_view(void* base, const gft_layout& L);
 BinView gft_bin_view(void* base, const gft_layout& L);
 
 int gft_fail(const char* fmt, ...);
+// zero fill by a kernel (gft_api.hip: hipMemsetAsync nodes misbehave in replayed graphs on this platform)
+hipError_t gft_zero_async(void* ptr, size_t bytes, hipStream_t s);
 #define GFT_CHECK_HIP(expr)                                                          \
     do {                                                                             \
         hipError_t e_ = (expr);                                                      \

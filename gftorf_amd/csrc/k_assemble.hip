@@ -359,7 +359,7 @@ extern "C" int gft_assemble_forward(void* hip_stream, int32_t P, int32_t M, int3
     hipStream_t s = (hipStream_t)hip_stream;
     uint32_t *rank, *sums, *ticket, *ndyn;
     assemble_scratch(io->scratch, P, &rank, &sums, &ticket, &ndyn);
-    GFT_CHECK_HIP(hipMemsetAsync(ticket, 0, 8, s));
+    GFT_CHECK_HIP(gft_zero_async(ticket, 8, s));
     const int nrb = (P + ASM_RANK_ROWS - 1) / ASM_RANK_ROWS;
     hipLaunchKernelGGL(k_assemble_rank, dim3(nrb), dim3(ASM_RANK_ROWS), 0, s, P, io->motion_mask, sums, ticket, ndyn);
     RowsArgs a;

@@ -2142,16 +2142,16 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
     if (n == 0) {
         for (int l = 0; l < DF_D; l++) {
             const size_t in = l == 0 ? DF_IN : l == 5 ? DF_W + DF_IN : DF_W;
-            GFT_CHECK_HIP(hipMemsetAsync(g->linear_w[l], 0, (size_t)DF_W * in * sizeof(float), s));
-            GFT_CHECK_HIP(hipMemsetAsync(g->linear_b[l], 0, DF_W * sizeof(float), s));
+            GFT_CHECK_HIP(gft_zero_async(g->linear_w[l], (size_t)DF_W * in * sizeof(float), s));
+            GFT_CHECK_HIP(gft_zero_async(g->linear_b[l], DF_W * sizeof(float), s));
         }
-        GFT_CHECK_HIP(hipMemsetAsync(g->xyz_w, 0, 3 * DF_W * sizeof(float), s));
-        GFT_CHECK_HIP(hipMemsetAsync(g->xyz_b, 0, 3 * sizeof(float), s));
+        GFT_CHECK_HIP(gft_zero_async(g->xyz_w, 3 * DF_W * sizeof(float), s));
+        GFT_CHECK_HIP(gft_zero_async(g->xyz_b, 3 * sizeof(float), s));
         float* hw[3] = {g->r_w, g->g_w, g->b_w};
         float* hb[3] = {g->r_b, g->g_b, g->b_b};
         for (int c = 0; c < 3; c++) {
-            GFT_CHECK_HIP(hipMemsetAsync(hw[c], 0, 16 * DF_W * sizeof(float), s));
-            GFT_CHECK_HIP(hipMemsetAsync(hb[c], 0, 16 * sizeof(float), s));
+            GFT_CHECK_HIP(gft_zero_async(hw[c], 16 * DF_W * sizeof(float), s));
+            GFT_CHECK_HIP(gft_zero_async(hb[c], 16 * sizeof(float), s));
         }
         return 0;
     }

@@ -379,7 +379,7 @@ extern "C" int gft_knn_mean_dist2(void* hip_stream, int32_t P, const float* poin
     Bounds* partial = (Bounds*)b;                 b += 256 * sizeof(Bounds);
     Bounds* bounds = (Bounds*)b;                  b += sizeof(Bounds);
     uint32_t* ticket = (uint32_t*)b;
-    GFT_CHECK_HIP(hipMemsetAsync(ticket, 0, 4, s));
+    GFT_CHECK_HIP(gft_zero_async(ticket, 4, s));
     const int blocks = (P + KNN_BLOCK - 1) / KNN_BLOCK;
     hipLaunchKernelGGL(k_knn_bounds, dim3(blocks < 256 ? blocks : 256), dim3(KNN_BLOCK), 0, s, P, points, partial, ticket, bounds);
     hipLaunchKernelGGL(k_knn_codes, dim3(blocks), dim3(KNN_BLOCK), 0, s, P, points, bounds, codes, order);

@@ -238,3 +238,63 @@ def test_graph_replay_follows_its_inputs(gpu):
         assert st and not st[0]["overflow"]
     finally:
         api._instance_hint.clear()
+
+
+def test_two_deterministic_backwards_in_one_graph(gpu):
+    """The deterministic backward (fixed-order sums, bit-reproducible) inside a captured iteration of two views: every replay
+    equals the eager deterministic run bit for bit.  Round 5 had parked this as "wrong sums from the second replay on"; the
+    cause was not in the mode: the library cleared the mode's partial rows with hipMemsetAsync, and a large memset node in
+    a replayed graph is not ordered against its neighbours on this platform (ROCm 7.0 / torch 2.10) -- the first replay met
+    fresh zero pages and was right, later ones were not.  The library clears with a kernel now (gft_zero_async); with the
+    memset in place this test fails at `replay 1`."""
+    from gftorf_amd import api, synth, GaussianRasterizer
+    P, W, H = 20_000, 128, 96
+    cams = [synth.look_at_w2c(0.05, -0.02, 0.0, (0.05, 0.0, 0.1)), synth.look_at_w2c(-0.08, 0.03, 0.01, (-0.1, 0.02, 0.15))]
+    scenes = [Hh.small_scene(P=P, W=W, H=H, seed=41, scale_lo=0.004, scale_hi=0.03, opacity=0.1, w2c=c) for c in cams]
+    leaf, m2 = _leaves(scenes[0], gpu)
+    rasts = [GaussianRasterizer(raster_settings=Hh.gpu_settings(sc, gpu)) for sc in scenes]
+    ups = [[torch.tensor(sc["grads"][k], device=gpu) for k in Hh.GRAD_KEYS] for sc in scenes]
+
+    def iteration():
+        outs = [_render(r, leaf, m2, sc) for r, sc in zip(rasts, scenes)]
+        torch.autograd.backward([t for o in outs for t in (o[0], o[1], o[2], o[4], o[6])], [u for up in ups for u in up])
+
+    def clear():
+        for v in leaf.values():
+            v.grad = None
+        m2.grad = None
+
+    def eager():
+        clear()
+        iteration()
+        torch.cuda.synchronize()
+        return {k: v.grad.clone() for k, v in leaf.items()}
+
+    keep = api._DETERMINISTIC
+    api._DETERMINISTIC = True
+    api._instance_hint.clear()
+    try:
+        eager()
+        ref, again = eager(), eager()
+        for k in ref:
+            assert torch.equal(ref[k], again[k]), k                  # the mode's promise, eagerly
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            clear()
+            iteration()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        clear()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            iteration()
+        static = {k: v.grad for k, v in leaf.items()}
+        for rep in range(4):
+            graph.replay()
+            torch.cuda.synchronize()
+            for k in ref:
+                assert torch.equal(static[k], ref[k]), "replay %d: %s" % (rep, k)
+    finally:
+        api._DETERMINISTIC = keep
+        api._instance_hint.clear()
