@@ -54,50 +54,102 @@ last_call_stats = {"num_rendered": 0, "binning_instances": 0, "restarted": False
 keep_last_buffers = False
 last_call_buffers = {}
 
-# Instance count (and longest tile list) of the recent forwards per (device, P, W, H).  A training loop renders
-# frames of similar size back to back, so the binning buffer can be sized before the device has
-# counted (gft_forward: no host round trip in the middle of the forward); a frame that needs
-# more than the guess re-runs stage 2 with the exact size.  Nothing else is taken from earlier frames: what is
-# binned, sorted and given an appearance is decided by the device from the frame itself (tile-pull binning).
-_instance_hint = {}
-# Tuning switch, off: GFT_GRADS_ZERO_FILL=1 makes the forward zero-fill the backward's gradient tensors on a side stream
-# so that the backward writes only the rows of blended Gaussians.  Measured on MI355X (metric frame): the backward's
-# preprocess kernel 108 -> 74 us, but the fill (376 MB) takes whatever runs beside it down with it -- +63 us beside the
-# render kernel, +48 us beside the binning kernels: HBM time is conserved, the fill is not free anywhere.
 import os as _os
-_ZERO_FILL = _os.environ.get("GFT_GRADS_ZERO_FILL", "0") != "0"
+from collections import OrderedDict as _OrderedDict
+
+
+class _CameraSchedule:
+    """What the device keeps for ONE camera (image size + address of its view matrix) from one frame to the next -- schedules,
+    never results: any contents give the same outputs (tests/test_gpu_parity.py::test_tile_hints_do_not_change_results).
+
+    tile_hints    one word per tile: did a quadrant walk past where a sorted list head ends (gft_forward_io.tile_hints)?  The next
+                  forward sorts such a tile's whole list up front instead of head first / rest on demand.
+    tile_weights  the quadrants' walk lengths: the next forward blend deals its waves heaviest tile first (gft_forward_io.tile_weights).
+    cell_sched    where the (supertile, slab) lists of the next frame start and how much they hold: no count pass from the
+                  camera's second frame on (gft_forward_io.cell_sched); `sched_seen`: a counted frame has written it;
+                  `miss_streak` / `sched_off_until`: after four frames in a row whose lists did not fit, the camera counts
+                  again for 64 frames, then tries the schedule anew.
+    hinted_tiles  how many tiles the schedule marked when the last frame read it (gft_forward_report.hinted_tiles): from a
+                  sixteenth of the tiles on the next forward runs the whole-list build of the pull kernel.
+    A camera is meant to be rendered on ONE stream at a time: the forward's closing workgroup rewrites the words in place, so
+    two forwards of the same camera running concurrently on two streams would bin by each other's half-written schedule
+    (harmless for values, a guaranteed schedule miss for time).  The 256 most recently used cameras are kept; an evicted
+    camera's buffers are freed by torch in stream order behind the forwards that used them."""
+    __slots__ = ("tile_hints", "tile_weights", "cell_sched", "sched_seen", "miss_streak", "sched_off_until", "hinted_tiles", "frames")
+
+    def __init__(self):
+        self.tile_hints = self.tile_weights = self.cell_sched = None
+        self.sched_seen = False
+        self.miss_streak = self.sched_off_until = self.hinted_tiles = self.frames = 0
+
+
+class _OperatorState:
+    """Everything the operator keeps between calls, in one place (`gftorf_amd.api.state`; `state.reset()` drops all of it --
+    tests, or a caller that switches scenes).  Sizes and schedules only, never a result:
+
+    instance_hint  (device, P, W, H[, slot]) -> (instance count, longest tile list) of the recent forwards: the binning buffer
+                   is sized before the device has counted (gft_forward: no host round trip in the middle of the forward); a frame
+                   that needs more re-runs stage 2 with the exact size.  The 64 most recent shapes.
+    cameras        tiles_key -> _CameraSchedule, least recently used first, at most MAX_CAMERAS.
+    status         hint key -> status block of the no-host-read flow (device words + pinned copy), the 64 most recent shapes.
+    grad_pool, acc_pool   gradient tensors / accumulators kept from one backward to the next (see below).
+    bw_plans, geom_bytes, image_bytes   host-side caches of shapes and sizes."""
+    MAX_CAMERAS = 256
+    MAX_SHAPES = 64
+
+    def __init__(self):
+        self.instance_hint = {}
+        self.cameras = _OrderedDict()
+        self.status = _OrderedDict()
+        self.grad_pool = {}
+        self.acc_pool = {}
+        self.bw_plans = {}
+        self.geom_bytes, self.image_bytes = {}, {}
+
+    def reset(self):
+        for d in (self.instance_hint, self.cameras, self.status, self.grad_pool, self.acc_pool, self.bw_plans, self.geom_bytes,
+                  self.image_bytes):
+            d.clear()
+
+    def reset_schedules(self):
+        """Forget every camera's schedules (the size hints stay)."""
+        self.cameras.clear()
+
+    def camera(self, key, create=True):
+        cam = self.cameras.get(key)
+        if cam is None:
+            if not create:
+                return None
+            cam = self.cameras[key] = _CameraSchedule()
+            while len(self.cameras) > self.MAX_CAMERAS:
+                self.cameras.popitem(last=False)
+        else:
+            self.cameras.move_to_end(key)
+        return cam
+
+
+state = _OperatorState()
+_instance_hint = state.instance_hint          # (the same objects under the names the tests and bench.py have always used)
 # GFT_BWD_DETERMINISTIC=1: the backward forms its per-Gaussian sums in a fixed order instead of with float atomics
 # (bit-reproducible gradients; several times slower: for tests)
 _DETERMINISTIC = _os.environ.get("GFT_BWD_DETERMINISTIC", "0") != "0"
 _HINT_HEADROOM = 1.25
-# The other thing kept from frame to frame of a shape, on the device: one word per tile saying whether one of its
-# quadrants walked past where a sorted list head ends (gft_forward_io.tile_hints).  The next forward sorts such a tile's
-# whole list up front instead of head first / rest on demand -- a schedule like the buffer size above, never a result
-# (tests/test_gpu_parity.py::test_tile_hints_do_not_change_results).  GFT_TILE_HINTS=0 switches it off.  The buffers are
-# 4 bytes per tile and are never freed (a kernel of an earlier call may still read or write them).
+# Schedule switches (all on; each one off gives the same results slower: INTEGRATION.md section J)
 _TILE_HINTS = _os.environ.get("GFT_TILE_HINTS", "1") != "0"
 _TILE_HINTS_PER_CAMERA = _os.environ.get("GFT_TILE_HINTS_PER_CAMERA", "1") != "0"
-_tile_hints = {}
-_tile_weights = {}
-_cell_sched = {}
-_cell_sched_seen = set()       # cameras whose schedule a counted frame has written
-_cell_sched_streak = {}        # consecutive frames whose lists did not fit the schedule
 _CELL_SCHED = _os.environ.get("GFT_CELL_SCHED", "1") != "0"
-_force_cell_sched = None       # tests: True = bin by whatever the words hold
 _FWD_ORDER = _os.environ.get("GFT_FWD_ORDER", "1") != "0"
-# ... and how many tiles the schedule marked when the shape's last frame read it (gft_forward_report.hinted_tiles): from a
-# sixteenth of the tiles on the next forward runs the build of the pull kernel that sorts hinted tiles' whole lists
-# (gft_forward_hints.whole_lists) -- fewer are served as well by the heads-only build, which keeps seven workgroups per CU,
-# and the on-demand completion of their lists
-_hinted_tiles = {}
+_force_cell_sched = None       # tests: True = bin by whatever the words hold
 _WHOLE_SHARE = 16
 _force_whole_lists = None      # tests: True / False overrides the choice of the build
+_SCHED_MISSES_OFF = 4          # frames in a row whose lists did not fit the camera's schedule before it counts again ...
+_SCHED_OFF_FRAMES = 64         # ... for this many frames
 
 
-def _whole_lists(key, n_tiles):
+def _whole_lists(cam, n_tiles):
     if _force_whole_lists is not None:
         return int(bool(_force_whole_lists))
-    return int(_hinted_tiles.get(key, 0) * _WHOLE_SHARE >= n_tiles)
+    return int((cam.hinted_tiles if cam is not None else 0) * _WHOLE_SHARE >= n_tiles)
 
 
 # The forward without a host read (gft_forward_enqueue): taken automatically while the current stream is being captured into
@@ -109,16 +161,20 @@ def _whole_lists(key, n_tiles):
 # it -- raises.  `enqueue_status()` returns the postings (after a graph replay, say).  Outside a capture, a shape that has
 # no size hint yet (the first frame of the process, a new P after densification) takes the blocking two-stage flow once.
 no_host_read = _os.environ.get("GFT_NO_HOST_READ", "0") != "0"
-_status = {}              # hint key -> dict(dev=int32[16] on the device, host=its pinned copy, seen=overflows reported so far)
+_status = state.status    # hint key -> dict(dev=int32[16] on the device, host=its pinned copy, seen=overflows reported so far)
 _ST_CAP, _ST_OVERFLOWS, _ST_MAX_R = 12, 13, 14      # include/gftorf_rast.h: GFT_STATUS_CAP / _OVERFLOWS / _MAX_R
 
 
 def _status_of(key, dev, create):
     st = _status.get(key)
-    if st is None and create and len(_status) < 1024:
+    if st is None and create:
         st = _status[key] = dict(dev=torch.zeros((16,), device=dev, dtype=torch.int32),
                                  host=torch.zeros((16,), dtype=torch.int32).pin_memory(), seen=0, key=key)
         st["np"] = st["host"].numpy()
+        while len(_status) > state.MAX_SHAPES:       # (P changes with every densification step: the most recent shapes)
+            _status.popitem(last=False)
+    elif st is not None:
+        _status.move_to_end(key)
     return st
 
 
@@ -142,13 +198,6 @@ def enqueue_status(synchronize=True):
     return out
 
 
-def _tile_hint_buffer(key, dev, W, H):
-    if not _TILE_HINTS:
-        return None
-    buf = _tile_hints.get(key)
-    if buf is None and len(_tile_hints) < 1024:
-        buf = _tile_hints[key] = torch.zeros((((W + 15) // 16) * ((H + 15) // 16),), device=dev, dtype=torch.int32)
-    return buf
 # Gradient tensors kept from one backward to the next.  The operator returns dense gradient tensors (376 B per Gaussian
 # with SH colour + SH phasor of 16 coefficients) of which a dense frame fills a few per cent of the rows (the Gaussians
 # some pixel blended); writing the zeros of all the other rows is most of the backward's preprocess kernel (65 of 100 us at
@@ -177,7 +226,7 @@ _GRADS_CHECK = _os.environ.get("GFT_GRADS_REUSE_CHECK", "0") != "0"
 # to the handed-out tensors until the next forward of the shape: autograd then copies into `.grad` instead of taking them
 # (a copy per directly fed leaf: the price of the fallback), everything else is the contract above.
 _USE_COUNT_API = hasattr(torch._C, "_storage_Use_Count") and _os.environ.get("GFT_GRADS_LIFETIME", "") != "dlpack"
-_grad_pool = {}           # (device, P, layout) -> list of {buf, dirty, version, base}
+_grad_pool = state.grad_pool       # (device, P, layout) -> list of {buf, dirty, version, base}
 _DENSE_SHARE = 0.3        # rows written by the last rows-only backward / P above which the tensors are written in full
 _DENSE_RUN = 15           # ... for this many backwards, before a rows-only one counts again
 _GRAD_POOL_DEPTH = 3      # rasterizer calls of one iteration whose gradient tensors are alive at the same time
@@ -265,7 +314,7 @@ def _dl_alias(entry):
 # whose backward never ran (its clear or its predecessor's zeroing stands), or a backward that returned without error.
 # GFT_ACC_REUSE=0 switches it off (every forward then clears a fresh buffer, as before).
 _ACC_REUSE = _os.environ.get("GFT_ACC_REUSE", "1") != "0"
-_acc_pool = {}            # (device, P) -> list of (buffer whose rows are zero, stream of its last kernels)
+_acc_pool = state.acc_pool         # (device, P) -> list of (buffer whose rows are zero, stream of its last kernels)
 _ACC_POOL_DEPTH = 3
 
 
@@ -460,8 +509,8 @@ class _Settings(NamedTuple):
 
 _PLANE_SPLIT = (3, 7, 1, 3, 1, 1, 1, 1, 3)     # color, phasor, depth, normal, acc, entropy, depth_distortion, amp_distortion, distribution
 _PLANE_FIRST = (0, 3, 10, 11, 14, 15, 16, 17, 18)   # first plane of each output inside the [21, H, W] allocation
-_bw_plans = {}
-_geom_bytes, _image_bytes = {}, {}              # gft_geom_bytes(P), gft_image_bytes(W, H): one library call per size
+_bw_plans = state.bw_plans
+_geom_bytes, _image_bytes = state.geom_bytes, state.image_bytes      # gft_geom_bytes(P), gft_image_bytes(W, H): one library call per size
 _FWD_FMT = "=%dQ" % len(_lib.ForwardIO._fields_)
 _BWD_FMT = "=%dQ" % len(_lib.BackwardIO._fields_)
 assert _struct.calcsize(_FWD_FMT) == C.sizeof(_lib.ForwardIO) and _struct.calcsize(_BWD_FMT) == C.sizeof(_lib.BackwardIO)
@@ -569,7 +618,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         prep = prepare_backward(s, means3D_c, opac_c, sh_c, sh_p_c, scales_c, rot_c, cov_c, radii, geom, img,
                                 (bg_c, bsc, bsy, bsx), (view_c, proj_c, campos_c), ph_off, dc_off, acc_buf,
                                 colors_c is not None, cov_c is not None, want_bw, pixels,
-                                zero_fill=_ZERO_FILL and share_grads is None, share_grads=share_grads, acc_lease=lease,
+                                share_grads=share_grads, acc_lease=lease,
                                 pooled=not capturing)
         if prep["zero_buf"] is not None:
             io.grads_zero = prep["zero_buf"].data_ptr()
@@ -592,36 +641,32 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
         hint, list_hint = _instance_hint.get(hint_key, (None, 0))
         # (a schedule buffer made during a capture would live in the graph's private pool: only one that exists already)
         n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
-        # (the per-tile schedule is about regions of the image as ONE CAMERA sees them -- which tiles hold the scene's
-        # silhouette differs from view to view: it is kept per image size and camera, the camera being known by the address
-        # of its view matrix (the reference's Camera objects keep theirs for the whole run, scene/cameras.py; a caller that
-        # builds new matrices every call gets a fresh, empty schedule each time -- and, from 1024 of them on, one shared per
-        # image size).  Not per number of Gaussians: it survives the densification steps, which change P every hundred
-        # iterations.)
+        # (the schedules are about regions of the image as ONE CAMERA sees them -- which tiles hold the scene's silhouette
+        # differs from view to view: they are kept per image size and camera (_CameraSchedule), the camera being known by the
+        # address of its view matrix (the reference's Camera objects keep theirs for the whole run, scene/cameras.py; a
+        # caller that builds new matrices every call gets a fresh, empty schedule each time and evicts the oldest).  Not per
+        # number of Gaussians: they survive the densification steps, which change P every hundred iterations.)
         tiles_key = (dev.index, W, H, hint_slot, s.viewmatrix.data_ptr() if _TILE_HINTS_PER_CAMERA else 0)
-        if tiles_key not in _tile_hints and len(_tile_hints) >= 1000:
-            tiles_key = (dev.index, W, H, hint_slot, 0)
-        tile_hints = _tile_hints.get(tiles_key) if capturing else _tile_hint_buffer(tiles_key, dev, W, H)
-        io.tile_hints = _ptr(tile_hints)
-        # ... and beside it the quadrants' walk lengths of the camera's last frame, by which the forward blend deals its waves
-        # heaviest tile first (gft_forward_io.tile_weights)
-        # ... and the camera's list schedule: where the (supertile, slab) lists of its next frame start and how much they hold,
-        # left on the device by every frame's binning front end; from the camera's second frame on the forward appends to those
-        # lists directly and runs no count pass (gft_forward_io.cell_sched; GFT_CELL_SCHED=0 off)
+        # (a schedule buffer made during a capture would live in the graph's private pool: only what exists already)
+        cam = state.camera(tiles_key, create=not capturing) if _TILE_HINTS else None
         use_sched = 0
-        if tile_hints is not None and _CELL_SCHED:
-            cs = _cell_sched.get(tiles_key)
-            if cs is None and not capturing:
-                words = int(lib.gft_cell_sched_words(W, H))
-                cs = _cell_sched[tiles_key] = torch.zeros((words,), device=dev, dtype=torch.int32) if words else False
-            if cs is not None and cs is not False:
-                io.cell_sched = cs.data_ptr()
-                use_sched = int(_force_cell_sched if _force_cell_sched is not None else (tiles_key in _cell_sched_seen))
-        if tile_hints is not None and _FWD_ORDER:
-            tw = _tile_weights.get(tiles_key)
-            if tw is None and not capturing:
-                tw = _tile_weights[tiles_key] = torch.zeros((4 * n_tiles + 4,), device=dev, dtype=torch.int32)
-            io.tile_weights = _ptr(tw)
+        if cam is not None:
+            cam.frames += 1
+            if cam.tile_hints is None and not capturing:
+                cam.tile_hints = torch.zeros((n_tiles,), device=dev, dtype=torch.int32)
+            io.tile_hints = _ptr(cam.tile_hints)
+            if cam.tile_hints is not None and _CELL_SCHED:
+                if cam.cell_sched is None and not capturing:
+                    words = int(lib.gft_cell_sched_words(W, H))
+                    cam.cell_sched = torch.zeros((words,), device=dev, dtype=torch.int32) if words else False
+                if cam.cell_sched is not None and cam.cell_sched is not False:
+                    io.cell_sched = cam.cell_sched.data_ptr()
+                    use_sched = int(_force_cell_sched if _force_cell_sched is not None
+                                    else (cam.sched_seen and cam.frames >= cam.sched_off_until))
+            if cam.tile_hints is not None and _FWD_ORDER:
+                if cam.tile_weights is None and not capturing:
+                    cam.tile_weights = torch.zeros((4 * n_tiles + 4,), device=dev, dtype=torch.int32)
+                io.tile_weights = _ptr(cam.tile_weights)
         try:
             with _lib.on_device(dev):
                 st = None
@@ -652,7 +697,8 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                         # the posting of an earlier no-host-read frame of the shape (whichever the copy in pinned memory holds)
                         prev_R = int(a[0])
                         a[3] = 0
-                        _hinted_tiles[tiles_key] = int(a[8])
+                        if cam is not None:
+                            cam.hinted_tiles = int(a[8])
                         if a[1] & 1:
                             raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
                         prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
@@ -662,7 +708,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     binning = _scratch(lib.gft_binning_bytes(cap, W, H), dev)
                     io.binning = binning.data_ptr()
                     hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
-                                              whole_lists=_whole_lists(tiles_key, n_tiles))
+                                              whole_lists=_whole_lists(cam, n_tiles))
                     _lib.check(lib.gft_forward_enqueue(stream, C.byref(cfg), C.byref(io), C.byref(hints), st["dev"].data_ptr()))
                     st["host"].copy_(st["dev"], non_blocking=True)
                     R = -1                     # (not known to the host)
@@ -685,22 +731,26 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                     binning = _scratch(lib.gft_binning_bytes(cap, W, H), dev)
                     io.binning = binning.data_ptr()
                     hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,
-                                              whole_lists=_whole_lists(tiles_key, n_tiles), use_cell_sched=use_sched)
+                                              whole_lists=_whole_lists(cam, n_tiles), use_cell_sched=use_sched)
                     report = _lib.ForwardReport()
                     _lib.check(lib.gft_forward(stream, C.byref(cfg), C.byref(io), C.byref(hints), C.byref(report)))
                     R = int(report.num_rendered)
                     if use_sched:
                         # (a camera whose lists keep outgrowing what its last frame left -- its tensors shared by scenes of
                         # different sizes, say -- pays the counted flow ON TOP of the failed attempt: after four misses in a row
-                        # it goes back to counting)
+                        # it counts again for 64 frames, then tries anew.  A frame that did not fit the BINNING BUFFER either is
+                        # re-rendered below whatever the schedule said: not the schedule's miss.)
                         if report.sched_misses:
                             last_call_stats["sched_misses"] = last_call_stats.get("sched_misses", 0) + 1
-                            _cell_sched_streak[tiles_key] = _cell_sched_streak.get(tiles_key, 0) + 1
-                            if _cell_sched_streak[tiles_key] >= 4 and _force_cell_sched is None:
-                                _cell_sched[tiles_key] = False
+                            if R <= cap:
+                                cam.miss_streak += 1
+                                if cam.miss_streak >= _SCHED_MISSES_OFF and _force_cell_sched is None:
+                                    cam.miss_streak = 0
+                                    cam.sched_off_until = cam.frames + _SCHED_OFF_FRAMES
                         else:
-                            _cell_sched_streak[tiles_key] = 0
-                    _hinted_tiles[tiles_key] = int(report.hinted_tiles)
+                            cam.miss_streak = 0
+                    if cam is not None:
+                        cam.hinted_tiles = int(report.hinted_tiles)
                     max_list.value = int(report.max_tile_list)
                     if R > cap:
                         restarted = True
@@ -713,7 +763,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                 if st is None:
                     prev_r, prev_l = _instance_hint.get(hint_key, (0, 0))
                     _instance_hint[hint_key] = (max(R, int((prev_r or 0) * 0.95)), max(int(max_list.value), int(prev_l * 0.95)))
-                    if len(_instance_hint) > 64:
+                    if len(_instance_hint) > state.MAX_SHAPES:
                         _instance_hint.pop(next(iter(_instance_hint)))
         except Exception as ex:
             if s.debug:
@@ -721,7 +771,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
             raise ex
     if P and io.cell_sched:
-        _cell_sched_seen.add(tiles_key)
+        cam.sched_seen = True
     if prep is not None:
         prep["cap"] = cap
     if lease is not None:

@@ -501,7 +501,8 @@ static int enqueue_stage1(hipStream_t s, const gft_config* cfg, const gft_forwar
         GFT_STAGE(s, cfg, "preprocess_fwd", gft_launch_preprocess_fwd(s, *cfg, *io, g, im, mail_dev, pull));
     }
     if (io->grads_zero && io->grads_zero_bytes) {
-        // Test / tuning switch (GFT_GRADS_ZERO_FILL=1 in api.py, off by default): zero fill of the backward's gradient
+        // Optional (gft_forward_io.grads_zero; the Python operator does not use it: the fill costs beside the other kernels what
+        // it saves the backward -- HBM time is conserved --, measured in round 2): zero fill of the backward's gradient
         // tensors on the side stream, behind the preprocess kernel.  HAZARD, which is why it stays a switch: only
         // gft_backward makes the caller's stream wait for the fill; a caller that drops the graph without running the
         // backward may hand the buffer to other work while the fill is still pending.

@@ -46,6 +46,15 @@
 #include <cstdlib>
 #include <cstring>
 
+// Timing experiments on the phases of k_tile_pull / k_tail_build (profiles/pull_phases.py): only in an experiment build
+// (python -m gftorf_amd.build --tag phases -DGFT_PHASE_DBG=1; GFT_PULL_DBG / GFT_TAIL_DBG in the environment then truncate the
+// kernels -- results are NOT valid).  The product library has no such switch: the expressions below are the constant 0.
+#ifdef GFT_PHASE_DBG
+#define PHASE_DBG(a) ((a).dbg)
+#else
+#define PHASE_DBG(a) 0
+#endif
+
 namespace {
 
 #define TPULL_KEYS GFT_HEAD_SLOT    // keys of a head / a chunk that may have to go through a sorting network (16 KB of LDS)
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(WHOLE
     const int K = a.sh.K;
     // (both builds read the schedule: the whole-list build sorts a hinted tile's list whole, the heads-only build gives it the
     // longest head one placement holds -- 2047 keys instead of ~940: most quadrants that walk past a normal head end inside it)
-    const bool hinted = (a.dbg & 16) || (a.hints != nullptr && a.hints[tile] != 0u);      // uniform over the workgroup
+    const bool hinted = (PHASE_DBG(a) & 16) || (a.hints != nullptr && a.hints[tile] != 0u);      // uniform over the workgroup
     for (int i = tid; i < GFT_DEPTH_BINS; i += GFT_BLOCK) s_hist[i] = 0;
     if (tid == 0) s_n = 0;
     __syncthreads();
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(WHOLE
                 // grouped placement: a key goes to the next free place of its depth bin
                 uint32_t d4[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) d4[u] = (a.dbg & 32) ? (uint32_t)e4[u] : __float_as_uint(a.depth[hit[u] ? (uint32_t)e4[u] : 0u]);
+                for (int u = 0; u < 4; u++) d4[u] = (PHASE_DBG(a) & 32) ? (uint32_t)e4[u] : __float_as_uint(a.depth[hit[u] ? (uint32_t)e4[u] : 0u]);
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (!hit[u]) continue;
@@ -673,7 +682,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(WHOLE
         __syncthreads();                                 // (everybody has read the count before the next slab adds to it)
         if (n >= (hinted ? (WHOLE ? 0xffffffffu : HEAD_DIRECT + 1u) : HEAD_TARGET)) { kstop = k; break; }
     }
-    if ((a.dbg & 15) == 1) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
+    if ((PHASE_DBG(a) & 15) == 1) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     bool more_slabs = false;
     for (int k = kstop + 1; k < K; k++) more_slabs |= a.st_cnt[q * K + k] != 0u;
     // the histogram, 16 bins per thread, and its running count: run0 = hits in the bins in front of this thread's sixteen,
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(WHOLE
         hp[w] = min(h[4 * w], 255u) | (min(h[4 * w + 1], 255u) << 8) | (min(h[4 * w + 2], 255u) << 16) | (min(h[4 * w + 3], 255u) << 24);
     auto hcnt = [&](int k) -> uint32_t { return (hp[k >> 2] >> (8 * (k & 3))) & 255u; };
 
-    if ((a.dbg & 15) == 2) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
+    if ((PHASE_DBG(a) & 15) == 2) { if (tid < 4) a.unit_flag[4 * tile + tid] = 0; if (tid == 0) { a.ranges[tile] = make_uint2(0u, 0u); a.front_len[tile] = 0; a.tile_cut[tile] = GFT_NO_TAIL; } return; }
     // the tile's bookkeeping words (stored by its first placement, behind the scans: a store in front of them holds up
     // the wave's loads) and where its ids go: the tile's head slot, or -- a whole list -- n ids of the pool (over all
     // tiles the pool holds R >= every list it can be asked for)
@@ -756,7 +765,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(WHOLE
         if (tid == 0) {
             // (ONE returning atomic: the frame's tiles arrive here together and queue on the counter's cache line, ~10 ns each --
             // a second counter beside it, kept for statistics, doubled the 10 us the last of 1200 tiles waits)
-            if (a.dbg & 256) s_pool = 0;      // (timing experiment, with the sorters cut off: nobody writes or reads the ids)
+            if (PHASE_DBG(a) & 256) s_pool = 0;      // (timing experiment, with the sorters cut off: nobody writes or reads the ids)
             else s_pool = atomicAdd(&a.ctrl[GFT_CTRL_POOLCUR], n);
         }
         __syncthreads();
@@ -875,7 +884,7 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(WHOLE
         }
         if (done == 0u) {
             if (tl == 0) {
-                const bool cut_short = (a.dbg & 15) == 5;        // (timing experiment without the sorters: nobody may read the ids)
+                const bool cut_short = (PHASE_DBG(a) & 15) == 5;        // (timing experiment without the sorters: nobody may read the ids)
                 a.ranges[tile] = cut_short ? make_uint2(0u, 0u) : bk_range;
                 a.front_len[tile] = cut_short ? 0u : kf;
                 a.tile_cnt[tile] = n;
@@ -885,10 +894,10 @@ __global__ __launch_bounds__(GFT_BLOCK) __attribute__((amdgpu_waves_per_eu(WHOLE
         }
         __syncthreads();
         // these Gaussians get an appearance (k_appearance): marked here, where only LDS work and stores follow
-        if (!(a.dbg & 64)) for (uint32_t i = tl; i < c; i += GFT_BLOCK) a.need[(uint32_t)sk[i]] = 1;
-        if (done == 0u && !(a.dbg & 128)) clear_slice();
+        if (!(PHASE_DBG(a) & 64)) for (uint32_t i = tl; i < c; i += GFT_BLOCK) a.need[(uint32_t)sk[i]] = 1;
+        if (done == 0u && !(PHASE_DBG(a) & 128)) clear_slice();
         uint32_t* __restrict__ ids = list + done;
-        if (c == 0u || (a.dbg & 15) == 5) {
+        if (c == 0u || (PHASE_DBG(a) & 15) == 5) {
         } else if (grouped) {
             // the keys stand grouped by depth bin, the bins in ascending order: a key's place = start of its bin's group + the
             // number of smaller keys in the group (keys are distinct: the id is their low half).  The bin's cursor now holds
@@ -1084,8 +1093,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
         // sorts the n keys in LDS (n <= TAIL_LDS_KEYS), gives their Gaussians an appearance, writes the ids
         auto finish_lds = [&](uint32_t n, uint32_t* dst) {
             __syncthreads();
-            if (a.dbg != 3) for (uint32_t i = tid; i < n; i += TAIL_THREADS) tail_appearance(a, (uint32_t)sk[sort_slot(i)]);
-            if (a.dbg == 4) return;
+            if (PHASE_DBG(a) != 3) for (uint32_t i = tid; i < n; i += TAIL_THREADS) tail_appearance(a, (uint32_t)sk[sort_slot(i)]);
+            if (PHASE_DBG(a) == 4) return;
             if (n <= 1024u) {
                 // a short tail (the usual case: a few hundred survivors): runs of 256 keys are sorted by one wave each in
                 // registers (no workgroup barrier), the runs are merged by rank -- a key's place = its place in its own run +
@@ -1127,11 +1136,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_build(TailArgs a)
             for (uint32_t i = tid; i < n; i += TAIL_THREADS) dst[i] = (uint32_t)sk[sort_slot(i)];
             __syncthreads();
         };
-        if (a.dbg == 1) return;
+        if (PHASE_DBG(a) == 1) return;
         scan(0, first_tail, GFT_DEPTH_BINS - 1u, nullptr);
         __syncthreads();
         const uint32_t m = s_m;
-        if (a.dbg == 2) return;
+        if (PHASE_DBG(a) == 2) return;
         // the completed list (head copy + culled tail) takes kf + m pool slots; over all tiles that is at most R <= cap
         if (tid == 0) s_pool = atomicAdd(&a.ctrl[GFT_CTRL_POOLCUR], kf + m);
         __syncthreads();
@@ -1276,9 +1285,8 @@ hipError_t gft_launch_super_bin(hipStream_t s, const gft_config& c, const GeomVi
     const int blocks = (c.P + BIN_CHUNK - 1) / BIN_CHUNK;
     // staging (scatter pass, from 1024 cells on): what is left of the CU's LDS behind the three cell tables, 10 bytes per entry
     const int cells = a.sh.NS * a.sh.K;
-    static const int env_stage = [] { const char* e = getenv("GFT_SUPER_STAGE"); return e ? atoi(e) : 1; }();
     a.stage_cap = 0;
-    if (pass != 0 && env_stage && cells >= 1024 && cells <= 4096) {
+    if (pass != 0 && cells >= 1024 && cells <= 4096) {
         const size_t room = SUPER_SCATTER_LDS - ((size_t)cells * 12 + 8);
         a.stage_cap = (uint32_t)((room / 10) & ~(size_t)3);
     }
@@ -1314,11 +1322,14 @@ hipError_t gft_launch_tile_pull(hipStream_t s, const gft_config& c, const GeomVi
     a.ctrl = im.ctrl; a.cap = cap;
     a.clear = reinterpret_cast<float4*>(clear); a.clear_vec4 = clear_bytes / 16;
     a.hints = hints; a.pool_base = (uint32_t)a.sh.T * GFT_HEAD_SLOT;
+    a.dbg = 0;
+#ifdef GFT_PHASE_DBG
     static const int dbg = [] { const char* e = getenv("GFT_PULL_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
     if ((dbg & 15) == 4) { a.clear = nullptr; a.dbg = dbg & 16; }     // (+16: every tile counts as hinted)
+#endif
     const int Np = a.sh.NS << (2 * a.sh.sshift);
-    if (whole_lists || (a.dbg & 16)) hipLaunchKernelGGL(k_tile_pull<true>, dim3(8 * ((Np + 7) / 8)), dim3(GFT_BLOCK), 0, s, a);
+    if (whole_lists || (PHASE_DBG(a) & 16)) hipLaunchKernelGGL(k_tile_pull<true>, dim3(8 * ((Np + 7) / 8)), dim3(GFT_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(k_tile_pull<false>, dim3(8 * ((Np + 7) / 8)), dim3(GFT_BLOCK), 0, s, a);
     return hipGetLastError();
 }
@@ -1337,8 +1348,11 @@ hipError_t gft_launch_tail_build(hipStream_t s, const gft_config& c, const gft_f
     a.quad_max = im.tile_max; a.order = want_order ? im.tile_order : nullptr;
     a.resume_here = gft_tail_resumes() ? 1 : 0;
     a.render = gft_render_fwd_args(c, io, g, im, b, true, cap, 2, true);
+    a.dbg = 0;
+#ifdef GFT_PHASE_DBG
     static const int tdbg = [] { const char* e = getenv("GFT_TAIL_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = tdbg;
+#endif
     const size_t lds = (size_t)SORT_SLOTS(TAIL_LDS_KEYS) * 8;
     {
         static std::atomic<uint64_t> done{0};

@@ -14,8 +14,12 @@
  *        -> gft_mark_visible()
  *
  * Plain pointers and sizes only, no torch types.  All pointers are DEVICE
- * pointers unless a comment says "host".  The library keeps no state between
- * calls: the caller owns every buffer, including the three scratch buffers
+ * pointers unless a comment says "host".  The library keeps no RESULT between
+ * calls -- what it owns is plumbing: a pinned mailbox through which the device
+ * posts counts to gft_forward / gft_forward_preprocess, one side stream with its
+ * events per device (the opt-in gradient fill), the event pool of the opt-in
+ * profiler, the process-wide mode switches below --; the caller owns every buffer,
+ * schedules included (tile_hints, tile_weights, cell_sched), and the three scratch buffers
  * (reference: geomBuffer / binningBuffer / imgBuffer, RAST/rasterize_points.cu:
  * 94-101), which must survive from forward to backward.  A NULL input pointer
  * means "tensor absent" (reference: `.data<float>()` of an empty tensor is

@@ -58,32 +58,29 @@ def run_case(case, dev, oracle, rng):
         if api._USE_COUNT_API != want_use_count:
             api._grad_pool.clear()                      # (an entry belongs to the route that made it)
             api._USE_COUNT_API = want_use_count
-        if len(api._tile_hints) > 512:                  # (the operator never frees them; a soak makes a new shape per frame)
-            torch.cuda.synchronize()
-            api._tile_hints.clear()
-            api._tile_weights.clear()
-            api._cell_sched.clear()
-            api._cell_sched_seen.clear()
         if c["hints"] in ("ones", "random"):
-            hb = api._tile_hint_buffer((dev.index, c["W"], c["H"], 0, 0), dev, c["W"], c["H"])
+            # (the schedule of the image size: a frame's camera tensors are new every case, so the per-camera key is off)
+            T_ = ((c["W"] + 15) // 16) * ((c["H"] + 15) // 16)
+            cam = api.state.camera((dev.index, c["W"], c["H"], 0, 0))
+            if cam.tile_hints is None:
+                cam.tile_hints = torch.zeros((T_,), device=dev, dtype=torch.int32)
+            hb = cam.tile_hints
             if c["hints"] == "ones":
                 hb.fill_(0x01010101)
             else:
                 hb.copy_(torch.tensor(rng.integers(0, 2, hb.numel()), dtype=torch.int32))
             # ... and arbitrary walk lengths for the forward's heavy-first dealing (the operator makes the buffer at the call)
-            key = (dev.index, c["W"], c["H"], 0, 0)
-            T_ = hb.numel()
-            wb = api._tile_weights.get(key)
+            wb = cam.tile_weights
             if wb is None:
-                wb = api._tile_weights[key] = torch.zeros((4 * T_ + 4,), device=dev, dtype=torch.int32)
+                wb = cam.tile_weights = torch.zeros((4 * T_ + 4,), device=dev, dtype=torch.int32)
             wb.copy_(torch.tensor(rng.integers(0, 5000, wb.numel()), dtype=torch.int32))
             wb[-4] = int(rng.integers(0, 2))
             # ... and an arbitrary list schedule, which the scatter pass is told to bin by (half of these cases)
             words = int(lib.gft_cell_sched_words(c["W"], c["H"]))
             if words and c["seed"] & 2:
-                sb = api._cell_sched.get(key)
+                sb = cam.cell_sched
                 if sb is None or sb is False:
-                    sb = api._cell_sched[key] = torch.zeros((words,), device=dev, dtype=torch.int32)
+                    sb = cam.cell_sched = torch.zeros((words,), device=dev, dtype=torch.int32)
                 kind = int(rng.integers(0, 3))
                 if kind == 0:
                     sb.copy_(torch.tensor(rng.integers(0, 2 ** 31 - 1, words), dtype=torch.int32))

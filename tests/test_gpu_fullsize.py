@@ -117,8 +117,7 @@ def test_fog_1m_vs_oracle(oracle, gpu):
     assert float((f.pixels[vis] > 0).mean()) > 0.8                 # most visible Gaussians are blended by some pixel
     assert float(f.img["final_T"].min()) > 1e-4                     # ... and nothing saturates
     api._instance_hint.clear()
-    api._tile_hints.clear()
-    api._hinted_tiles.clear()
+    api.state.reset_schedules()
     keep = api.keep_last_buffers
     api.keep_last_buffers = True
     flagged = []
@@ -193,8 +192,7 @@ def test_c5_fog_whole_lists_equal_lists_completed_on_demand(gpu):
     W, H = cfg["W"], cfg["H"]
     T = ((W + 15) // 16) * ((H + 15) // 16)
     api._instance_hint.clear()
-    api._tile_hints.clear()
-    api._hinted_tiles.clear()
+    api.state.reset_schedules()
     keep = api.keep_last_buffers
     api.keep_last_buffers = True
     res = {}

@@ -720,7 +720,7 @@ def test_hinted_tiles_sort_their_whole_list(gpu, oracle):
 
 @pytest.mark.parametrize("name", list(BIN_CASES))
 def test_tile_hints_do_not_change_results(name, oracle, gpu):
-    """The per-tile schedule the operator keeps from frame to frame (api._tile_hints -> gft_forward_io.tile_hints) against
+    """The schedules the operator keeps per camera from frame to frame (api.state.cameras -> gft_forward_io.tile_hints, ...) against
     no schedule, an all-ones one and a random one: every output bit-identical (the blend walks the same entries in the
     same order whether a list was sorted whole up front or head first / rest on demand), gradients equal up to the order
     of the atomic sums."""
@@ -738,29 +738,26 @@ def test_tile_hints_do_not_change_results(name, oracle, gpu):
             ref_out, ref_grads, _ = Hh.run_gpu(scene, gpu)
         finally:
             api._TILE_HINTS = keep
-        api._tile_hints.clear()
-        api._tile_weights.clear()
-        api._hinted_tiles.clear()
-        api._cell_sched.clear()
-        api._cell_sched_seen.clear()
+        api.state.reset_schedules()
         for frame in range(7):
             if frame >= 3:
                 # frames 0 - 2: the schedule and the choice of the pull kernel's build as the operator makes them; then forced:
                 # all ones, random, random with the whole-list build, random with the heads-only build (which ignores it)
-                for hbuf in api._tile_hints.values():
+                cams = list(api.state.cameras.values())
+                for hbuf in (c.tile_hints for c in cams if c.tile_hints is not None):
                     if frame == 3:
                         hbuf.fill_(0x01010101)
                     else:
                         hbuf.copy_(torch.tensor(rng.integers(0, 2, hbuf.numel()), dtype=torch.int32))
                 # ... and whatever walk lengths the forward's heavy-first dealing is derived from
-                for wbuf in api._tile_weights.values():
+                for wbuf in (c.tile_weights for c in cams if c.tile_weights is not None):
                     wbuf.copy_(torch.tensor(rng.integers(0, 3000 if frame != 4 else 2 ** 31 - 1, wbuf.numel()), dtype=torch.int32))
                     wbuf[-4] = 1
                 api._force_whole_lists = frame != 6
                 # ... and the camera's list schedule (where the binning's scatter pass appends without a count pass in front):
                 # garbage, zeros, capacities of 1 -- found on the device, the counted flow runs in the same call
-                for sbuf in api._cell_sched.values():
-                    if sbuf is False:
+                for sbuf in (c.cell_sched for c in cams):
+                    if sbuf is False or sbuf is None:
                         continue
                     if frame == 4:
                         sbuf.copy_(torch.tensor(rng.integers(0, 2 ** 31 - 1, sbuf.numel()), dtype=torch.int32))
@@ -775,7 +772,8 @@ def test_tile_hints_do_not_change_results(name, oracle, gpu):
                 api._force_cell_sched = True if frame in (4, 5, 6) else None
             misses = api.last_call_stats.get("sched_misses", 0)
             out, grads, _ = Hh.run_gpu(scene, gpu)
-            if api._cell_sched and not any(v is False for v in api._cell_sched.values()) and api._CELL_SCHED:
+            scheds = [c.cell_sched for c in api.state.cameras.values()]
+            if scheds and not any(v is False or v is None for v in scheds) and api._CELL_SCHED:
                 if frame in (4, 5, 6):
                     assert api.last_call_stats.get("sched_misses", 0) > misses, frame
                 elif frame in (1, 2, 3):
@@ -834,8 +832,7 @@ def test_schedules_are_kept_per_camera(oracle, gpu):
             ref = [render(0), render(1)]
             assert ref[0][2] > 0 and ref[1][2] > 0, "the case must have quadrants that walk past their heads"
             api._TILE_HINTS, api._TILE_HINTS_PER_CAMERA = True, True
-            api._tile_hints.clear()
-            api._hinted_tiles.clear()
+            api.state.reset_schedules()
             flagged = []
             for visit in range(3):
                 for i in (0, 1):
@@ -844,9 +841,9 @@ def test_schedules_are_kept_per_camera(oracle, gpu):
                     for a, e in zip(o, ref[i][0]):
                         np.testing.assert_array_equal(a, e)
                     Hh.assert_close("means3D", ref[i][1], gm, rtol_max=1e-5)
-            keys = [k for k in api._tile_hints if k[1:3] == (96, 64)]
+            keys = [k for k in api.state.cameras if k[1:3] == (96, 64)]
             assert len(keys) == 2 and len({k[4] for k in keys}) == 2                  # one schedule per camera
-            a, b = (api._tile_hints[k].cpu().numpy() for k in keys)
+            a, b = (api.state.cameras[k].tile_hints.cpu().numpy() for k in keys)
             assert (a != 0).any() and (b != 0).any() and ((a != 0) != (b != 0)).any()    # ... and they differ
             # first visits: no schedule yet; later visits: the marked tiles got long heads and flag less
             assert flagged[0] == ref[0][2] and flagged[1] == ref[1][2]
