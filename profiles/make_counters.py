@@ -27,7 +27,9 @@ STAGE_OF = {"k_preprocess_fwd": "preprocess_fwd", "k_appearance": "preprocess_fw
             # gradient tensors kept between backwards: rows of blended Gaussians only (the training call's kernel)
             "k_preprocess_bwd_rows": "preprocess_bwd", "k_grads_rezero": "preprocess_bwd",
             # tile-pull binning (k_pull.hip): count pass, scatter pass, per-tile pull + sort, lists completed on demand
-            "k_super_bin<0>": "tile_count", "k_super_bin<1>": "tile_scatter", "k_tile_pull": "tile_sort", "k_tail_build": "tile_sort"}
+            "k_super_bin<0>": "tile_count", "k_super_bin<1>": "tile_scatter",
+            # (<2>: the scatter by the camera's list schedule, no count pass in front)
+            "k_super_bin<2>": "tile_scatter", "k_tile_pull": "tile_sort", "k_tail_build": "tile_sort"}
 ALL_STAGES = ("preprocess_fwd", "tile_count", "tile_scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
 
 
