@@ -23,3 +23,5 @@ for w in ("full","C1","C2","C5","C3","C3_pair","C4","fog"):
         print("   ",k,{x:(round(v[x],3) if isinstance(v[x],float) else v[x]) for x in keys})
     if "cpu_baseline" in d: print("    cpu", d["cpu_baseline"])
 PY
+python3 bench.py --workload C3 --graph --no-cpu-baseline > gpurun_out/${T}_bench_C3_graph.json 2>/dev/null && echo c3graph ok
+python3 bench.py --workload C3 --torch-loss --no-cpu-baseline > gpurun_out/${T}_bench_C3_torch_loss.json 2>/dev/null && echo c3torch ok
