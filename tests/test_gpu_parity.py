@@ -897,6 +897,32 @@ def test_lazy_sort_resume_paths(name, oracle, gpu):
         check_grads(b, grads, scene)
 
 
+@pytest.mark.parametrize("name", ["thin_fog", "mixed"])
+def test_scratch_buffers_may_start_as_anything(name, oracle, gpu):
+    """No kernel reads a field of the scratch buffers that no kernel of ITS frame wrote: with the three buffers poisoned
+    (api._POISON, GFT_POISON_SCRATCH=1: 0x7f bytes -- 3.4e38 as a float, an out-of-range index as an integer -- instead of
+    the allocator's block, which usually holds the previous frame's plausible values) the lazy paths, both binning modes
+    and both forward blend kernels still meet the oracle.  (The whole `-m gpu` suite and a soak pass with the switch set:
+    profiles/r06_soak_raster_poisoned.json.)"""
+    from gftorf_amd import api
+    scene = Hh.small_scene(seed=21, **LAZY_CASES[name])
+    f, b = Hh.run_oracle(oracle, scene)
+    keep = api._POISON
+    api._POISON = True
+    try:
+        for mode in (0, 1):
+            for rm in (0, -1):
+                with binning_mode(mode), render_mode(rm):
+                    api._instance_hint.clear()                        # (the first frame's two-stage flow and the one-call flow)
+                    for _ in range(2):
+                        out, grads, _ = Hh.run_gpu(scene, gpu)
+                        check_outputs(f, out)
+                        check_grads(b, grads, scene)
+    finally:
+        api._POISON = keep
+        api._instance_hint.clear()
+
+
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_random_configurations(seed, oracle, gpu):
     """Seeded sweep over frame shapes, densities, SH degrees, camera poses and scale modifiers:
