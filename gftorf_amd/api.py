@@ -462,13 +462,15 @@ _STABLE_CAPS = _os.environ.get("GFT_STABLE_CAPS", "1") != "0"
 _POISON = _os.environ.get("GFT_POISON_SCRATCH", "0") != "0"
 
 
-def _guess_cap(hint):
+def _guess_cap(hint, sched_cells=0):
     """Capacity of the binning buffer for a frame whose instance count is guessed from recent frames: the guess plus 25 %,
     rounded UP to four significant bits (steps of at most 6 %).  Over changing views the guess moves a little every frame;
-    without the rounding every frame asks the allocator for a buffer of another size, which torch's caching allocator
-    answers with a fresh hipMalloc (and, sooner or later, a synchronising hipFree): measured on the 30-view leg of bench.py as
-    0.57 ms of wall time per step for 0.42 ms of kernels."""
-    n = int(hint * _HINT_HEADROOM) + 4096
+    without the rounding every frame asks the allocator for a buffer of another size -- a cache miss of torch's allocator
+    whenever the size class changes (a guard: +-0 on a box with a fast host, 2364 -> 2408 it/s over 30 views).
+    `sched_cells`: lists of the camera's list schedule -- every list reserves its last count plus a quarter plus 64 entries,
+    and the schedule is only accepted if all of that fits the entry array: on a small scene (entries ~ instances) or a
+    grid of many cells the 64 per list are more than the 4096 spare instances, and the camera would miss every frame."""
+    n = int(hint * _HINT_HEADROOM) + 4096 + 64 * int(sched_cells)
     if _STABLE_CAPS and n > 16:
         sh = n.bit_length() - 4
         n = ((n + (1 << sh) - 1) >> sh) << sh
@@ -727,7 +729,7 @@ def native_forward(s, means3D, sh, sh_p, colors_precomp, phasors_precomp, opacit
                 else:
                     # later frames: the buffer is sized from the recent frames' instance counts (the only thing taken
                     # from earlier frames), both stages are queued back to back
-                    cap = _guess_cap(hint)
+                    cap = _guess_cap(hint, (cam.cell_sched.numel() - 4) // 2 if (cam is not None and use_sched) else 0)
                     binning = _scratch(lib.gft_binning_bytes(cap, W, H), dev)
                     io.binning = binning.data_ptr()
                     hints = _lib.ForwardHints(binning_instances=cap, max_tile_list=int(list_hint * _LIST_HEADROOM) + 1,

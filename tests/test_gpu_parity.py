@@ -792,6 +792,36 @@ def test_tile_hints_do_not_change_results(name, oracle, gpu):
     check_grads(b, grads, scene)
 
 
+def test_list_schedule_fits_small_scenes(oracle, gpu):
+    """A scene of few, small Gaussians on a grid of many (supertile, slab) lists: every list's reserve of `count + count / 4 +
+    64` entries adds up to more than the binning buffer's 4096 spare instances -- the operator sizes the buffer for the
+    schedule's slack too, so the camera's second and later frames bin by the schedule instead of missing it every time."""
+    from gftorf_amd import _lib, api
+    if not _lib.load().gft_lazy_sort() or not api._CELL_SCHED:
+        pytest.skip("no list schedule in this configuration")
+    scene = Hh.small_scene(P=2500, W=640, H=480, seed=9, scale_lo=0.002, scale_hi=0.004)
+    f, b = Hh.run_oracle(oracle, scene)
+    keep = api._TILE_HINTS_PER_CAMERA
+    api._TILE_HINTS_PER_CAMERA = False                 # (run_gpu builds new camera tensors per call: one schedule per image size)
+    api._instance_hint.clear()
+    api.state.reset_schedules()
+    try:
+        with render_mode(0):
+            for frame in range(5):
+                misses = api.last_call_stats.get("sched_misses", 0)
+                out, grads, _ = Hh.run_gpu(scene, gpu)
+                check_outputs(f, out)
+                if frame >= 2:
+                    assert api.last_call_stats.get("sched_misses", 0) == misses, frame
+            cam = next(iter(api.state.cameras.values()))
+            assert cam.sched_seen and cam.cell_sched is not None and cam.cell_sched is not False and cam.sched_off_until == 0
+        check_grads(b, grads, scene)
+    finally:
+        api._TILE_HINTS_PER_CAMERA = keep
+        api._instance_hint.clear()
+        api.state.reset_schedules()
+
+
 def test_schedules_are_kept_per_camera(oracle, gpu):
     """Two cameras on the same Gaussians, drawn alternately (a training loop's access pattern): each keeps its own per-tile
     schedule, keyed by the address of its view matrix -- the silhouette tiles of one view are not the other's.  A thin cloud
