@@ -559,7 +559,7 @@ __device__ __forceinline__ void store_split4(char* plane0, size_t plane_bytes, s
     *reinterpret_cast<uint2*>(plane0 + 2 * plane_bytes + byte_off) = pl;
 }
 
-constexpr int64_t DF_H_FLOATS = DF_F_TOTAL;                    // forward stream only: 2 planes x 2 bytes per weight
+constexpr int64_t DF_H_FLOATS = DF_BF_ELEMS;                   // both streams (round 6: the backward walk too): 2 planes x 2 bytes per weight
 constexpr int64_t DF_FLAG_FLOATS = 4;                          // behind it: word 0 != 0 = a weight is outside the fp16 planes' range
 constexpr int64_t DF_FLAG_OFF = DF_PACKED_FLOATS + DF_BF_FLOATS + DF_H_FLOATS;
 constexpr float DF_H_MAX = 65504.f;                            // largest fp16
@@ -771,13 +771,13 @@ __device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b)
 __device__ __forceinline__ float f16_lo(uint32_t u) { f16x2_t h; __builtin_memcpy(&h, &u, 4); return (float)h.x; }
 __device__ __forceinline__ float f16_hi(uint32_t u) { f16x2_t h; __builtin_memcpy(&h, &u, 4); return (float)h.y; }
 
-// fp32 packed forward stream ([k/4][n][4] per segment) -> fp16 planes ([plane][k/8][n][8] per segment)
+// fp32 packed streams ([k/4][n][4] per segment) -> fp16 planes ([plane][k/8][n][8] per segment)
 __global__ __launch_bounds__(256) void k_deform_pack_h(const float* __restrict__ packed, _Float16* __restrict__ out, uint32_t* __restrict__ flag)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= DF_F_TOTAL) return;
+    if (e >= DF_BF_ELEMS) return;
     int sgi = 0;
-    for (int q = 1; q <= 9; q++)
+    for (int q = 1; q < DF_NSEG; q++)
         if (e >= df_seg(q).off) sgi = q;
     const DfSeg sg = df_seg(sgi);
     const int64_t r = e - sg.off;
@@ -1272,6 +1272,7 @@ struct BwdArgs {
     const float* g_dxyz; const float* g_dsh;
     float* dz;              // [8][n_pad][256]
     float* dzh;             // [n_pad][64]
+    int only_if_wflag;      // k_deform_bwd_bf behind k_deform_bwd_h: run only if a weight is outside the fp16 planes' range
 };
 
 __global__ __launch_bounds__(256) void k_deform_bwd(BwdArgs a)
@@ -1350,6 +1351,7 @@ constexpr int DF_BWD_NC = 8 / DF_BWD_WAVES;
 __global__ __launch_bounds__(64 * DF_BWD_WAVES) void k_deform_bwd_bf(BwdArgs a)
 {
     extern __shared__ float4 df_lds[];
+    if (a.only_if_wflag && __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.packed + DF_FLAG_OFF)) == 0u) return;
     char* gP = reinterpret_cast<char*>(df_lds);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * 64;
@@ -1427,6 +1429,169 @@ __global__ __launch_bounds__(64 * DF_BWD_WAVES) void k_deform_bwd_bf(BwdArgs a)
             seg = nx;
         } else {
             stream_gemm_bf<2, NC, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, seg, nullptr, wcur, wnx1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward walk on TWO fp16 planes (round 6): k_deform_bwd_bf's walk with k_deform_fwd_h's arithmetic -- three
+// v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones, two thirds of the operand bytes, 68 KB of LDS (two
+// workgroups per CU; the three bf16 planes allowed one).  Weights: the fp16 planes of the backward stream (times 2^10; a
+// weight >= 64 sets the pack kernel's flag, this kernel returns and k_deform_bwd_bf behind it does the work).  Gradients
+// have no fixed range (1e-12 early in a run, 1e+2 under a large loss scale), so every point's row of the tile carries
+// its own power-of-two scale: the largest magnitude of the row goes to [2^13, 2^14) before the split, and the
+// accumulator of that point -- a point is a lane of the MFMA's output -- is multiplied by the inverse (times 2^-10 for
+// the weights) when it is read.  Powers of two: the scaling itself is exact; entries down to 2^-27 of their row's largest
+// keep a normal hi part and 22 bits, smaller ones fade out against a sum (the next layer's gradient, the weight
+// gradients) that the large entries of the same row dominate.  Measured against float64: tests/test_deform.py.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t DF_BWD_H_LDS = 2 * DF_BF_ACT_PLANE + (size_t)(DF_BWD_WAVES + 1) * 64 * 4;   // planes + the rows' maxima per wave + the head tile's
+
+// m = f 2^e with f in [0.5, 1): e (0 for 0, inf, NaN), kept where 2^(14 - e) and 2^(e - 24) are normal floats
+__device__ __forceinline__ int grad_exp(float m)
+{
+    const int e = __builtin_amdgcn_frexp_expf(m);
+    return e < -100 ? -100 : e;
+}
+__device__ __forceinline__ float pow2_f(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
+
+__global__ __launch_bounds__(64 * DF_BWD_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_deform_bwd_h(BwdArgs a)
+{
+    extern __shared__ float4 df_lds[];
+    if (__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.packed + DF_FLAG_OFF)) != 0u) return;
+    char* gP = reinterpret_cast<char*>(df_lds);                               // gradient planes [2][64][264] fp16
+    float* pm = reinterpret_cast<float*>(gP + 2 * DF_BF_ACT_PLANE);           // [waves][64]: a row's largest magnitude in each wave's columns
+    float* hm = pm + DF_BWD_WAVES * 64;                                       // [64]: the same for the head tile
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    constexpr int NC = DF_BWD_NC, NT = 64 * DF_BWD_WAVES;
+    static_assert(NT == 256, "the head tile's rows are read by 16 consecutive lanes each");
+    const int n0 = wave * 32 * NC;
+    const __amdgpu_buffer_rsrc_t rw = buf_rsrc(a.packed + DF_PACKED_FLOATS + DF_BF_FLOATS, (uint32_t)DF_H_FLOATS * 4u);
+    WSegH seg = wseg_h(10, n0 + li, hh);
+    uint4 wcur[2][NC], wnx1[2][NC], wnx2[2][NC];
+    load_wh<NC, DF_W>(wcur, rw, seg, 0);
+    load_wh<NC, DF_W>(wnx1, rw, seg, 1);
+    load_wh<NC, DF_W>(wnx2, rw, seg, 2);
+
+    // upstream gradients as the head's output tile: [d_sh (48) | d_xyz (3) | 0], in the first 64 columns; a row is read
+    // by 16 consecutive lanes, which agree on its scale among themselves
+    {
+        float4 hv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = (tid >> 4) + 16 * i, col = (tid & 15) * 4;
+            const int64_t p = p0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < a.n) {
+                if (col < 48) {
+                    if (a.g_dsh) v = *reinterpret_cast<const float4*>(a.g_dsh + p * 48 + col);
+                } else if (col == 48 && a.g_dxyz) {
+                    v.x = a.g_dxyz[p * 3]; v.y = a.g_dxyz[p * 3 + 1]; v.z = a.g_dxyz[p * 3 + 2];
+                }
+            }
+            hv[i] = v;
+            *reinterpret_cast<float4*>(a.dzh + p * DF_HEAD + col) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = (tid >> 4) + 16 * i, col = (tid & 15) * 4;
+            float m = fmaxf(fmaxf(fabsf(hv[i].x), fabsf(hv[i].y)), fmaxf(fabsf(hv[i].z), fabsf(hv[i].w)));
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            m = fmaxf(m, __shfl_xor(m, 4));
+            m = fmaxf(m, __shfl_xor(m, 8));
+            const float sc = pow2_f(14 - grad_exp(m));
+            float4 v = hv[i];
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+            store_split4_h(gP, DF_BF_ACT_PLANE, ((size_t)row * DF_BH + col) * 2, v);
+            if ((tid & 15) == 0) hm[row] = m;
+        }
+    }
+    __syncthreads();
+
+    const char* g_lane = gP + (size_t)li * DF_BH * 2 + 16 * hh;
+    f32x16 acc[2][NC];
+    uint32_t sg[2][NC];
+    float inv[2];                      // what turns the accumulator of this lane's two points into the gradient: 1 / (row scale * 2^10)
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++) inv[rt] = pow2_f(grad_exp(hm[32 * rt + li]) - 24);
+    auto load_signs = [&](int l) {
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++)
+                sg[rt][ct] = a.signs[((int64_t)l * a.n_pad + p0 + 32 * rt + li) * DF_SIGN_WORDS + NC * wave + ct];
+    };
+    load_signs(DF_D - 1);
+    zero_acc(acc);
+    {
+        const WSegH nx = wseg_h(11, n0 + li, hh);
+        stream_gemm_h<2, NC, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_HEAD / 16, rw, seg, &nx, wcur, wnx1, wnx2);   // dh_7
+        seg = nx;
+    }
+    for (int l = DF_D - 1; l >= 0; l--) {
+        // dz_l in place of the accumulators, and the largest magnitude of each of the lane's two rows
+        float mx[2] = {0.f, 0.f};
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++) {
+                const uint32_t word = sg[rt][ct];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t m = word >> acc_col4(g, hh);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float v = (m & (1u << k)) ? acc[rt][ct][4 * g + k] * inv[rt] : 0.f;
+                        acc[rt][ct][4 * g + k] = v;
+                        mx[rt] = fmaxf(mx[rt], fabsf(v));
+                    }
+                }
+            }
+            mx[rt] = fmaxf(mx[rt], __shfl_xor(mx[rt], 32));
+            if (l > 0 && hh == 0) pm[wave * 64 + 32 * rt + li] = mx[rt];
+        }
+        __syncthreads();      // every wave is past its last read of the previous gradient tile; the rows' maxima are complete
+        float sc[2] = {1.f, 1.f};
+        if (l > 0) {
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++) {
+                float m = pm[32 * rt + li];
+#pragma unroll
+                for (int w = 1; w < DF_BWD_WAVES; w++) m = fmaxf(m, pm[w * 64 + 32 * rt + li]);
+                const int e = grad_exp(m);
+                sc[rt] = pow2_f(14 - e);
+                inv[rt] = pow2_f(e - 24);
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++) {
+                const int row = 32 * rt + li;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int col = n0 + 32 * ct + acc_col4(g, hh);
+                    const float4 v = make_float4(acc[rt][ct][4 * g], acc[rt][ct][4 * g + 1], acc[rt][ct][4 * g + 2], acc[rt][ct][4 * g + 3]);
+                    if (l > 0) {
+                        const float4 u = make_float4(v.x * sc[rt], v.y * sc[rt], v.z * sc[rt], v.w * sc[rt]);
+                        store_split4_h(gP, DF_BF_ACT_PLANE, ((size_t)row * DF_BH + col) * 2, u);
+                    }
+                    *reinterpret_cast<float4*>(a.dz + ((int64_t)l * a.n_pad + p0 + row) * DF_W + col) = v;
+                }
+            }
+        if (l == 0) break;
+        __syncthreads();
+        load_signs(l - 1);
+        zero_acc(acc);
+        // segment of W_l in the backward stream: 11 + (7 - l); the walk ends with W_1
+        if (l > 1) {
+            const WSegH nx = wseg_h(11 + (7 - l) + 1, n0 + li, hh);
+            stream_gemm_h<2, NC, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, rw, seg, &nx, wcur, wnx1, wnx2);   // dh_{l-1}
+            seg = nx;
+        } else {
+            stream_gemm_h<2, NC, DF_W>(acc, g_lane, DF_BH * 2, DF_BF_ACT_PLANE, DF_W / 16, rw, seg, nullptr, wcur, wnx1, wnx2);
         }
     }
 }
@@ -1954,11 +2119,19 @@ bool fp16_forward()
     return on;
 }
 
+// GFT_DEFORM_BWD_FP16=0: the backward walk on three bf16 planes (six multiplies per product) instead of two fp16 planes
+bool fp16_backward()
+{
+    static const bool on = [] { const char* e = getenv("GFT_DEFORM_BWD_FP16"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
+
 // the walks' dynamic-LDS opt-in, per device (gft_lds_opt_in)
 hipError_t set_attrs()
 {
-    static std::atomic<uint64_t> done[8];
-    struct { const void* fn; size_t bytes; } k[8] = {
+    static std::atomic<uint64_t> done[9];
+    struct { const void* fn; size_t bytes; } k[9] = {
+        {reinterpret_cast<const void*>(&k_deform_bwd_h), DF_BWD_H_LDS},
         {reinterpret_cast<const void*>(&k_deform_fwd_h<true, DF_FWD_H_SAVE_WAVES>), DF_FWD_H_SAVE_LDS},
         {reinterpret_cast<const void*>(&k_deform_fwd_h<false, DF_FWD_WAVES>), DF_FWD_H_LDS},
         {reinterpret_cast<const void*>(&k_deform_bwd_bf), DF_BWD_BF_LDS},
@@ -1967,7 +2140,7 @@ hipError_t set_attrs()
         {reinterpret_cast<const void*>(&k_deform_fwd<true>), DF_FWD_LDS},
         {reinterpret_cast<const void*>(&k_deform_fwd<false>), DF_FWD_LDS},
         {reinterpret_cast<const void*>(&k_deform_bwd), DF_BWD_LDS}};
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 9; i++) {
         const hipError_t e = gft_lds_opt_in(k[i].fn, k[i].bytes, done[i]);
         if (e != hipSuccess) return e;
     }
@@ -2063,7 +2236,7 @@ extern "C" int gft_deform_pack(void* hip_stream, int xyz_multires, int t_multire
     hipLaunchKernelGGL(k_deform_pack_bf, dim3((unsigned)((DF_BF_ELEMS + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
                        (const float*)packed, reinterpret_cast<__bf16*>((float*)packed + DF_PACKED_FLOATS));
     GFT_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_deform_pack_h, dim3((unsigned)((DF_F_TOTAL + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+    hipLaunchKernelGGL(k_deform_pack_h, dim3((unsigned)((DF_BF_ELEMS + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
                        (const float*)packed, reinterpret_cast<_Float16*>((float*)packed + DF_PACKED_FLOATS + DF_BF_FLOATS),
                        reinterpret_cast<uint32_t*>((float*)packed + DF_FLAG_OFF));
     GFT_CHECK_HIP(hipGetLastError());
@@ -2170,7 +2343,14 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
         a.signs = reinterpret_cast<const uint32_t*>(acts + n_pad * DF_D * DF_W);
         a.g_dxyz = g_d_xyz; a.g_dsh = g_d_sh;
         a.dz = dz; a.dzh = dzh;
-        if (bf16_planes()) hipLaunchKernelGGL(k_deform_bwd_bf, dim3((unsigned)(n_pad / 64)), dim3(64 * DF_BWD_WAVES), DF_BWD_BF_LDS, s, a);
+        a.only_if_wflag = 0;
+        if (bf16_planes() && fp16_backward()) {
+            hipLaunchKernelGGL(k_deform_bwd_h, dim3((unsigned)(n_pad / 64)), dim3(64 * DF_BWD_WAVES), DF_BWD_H_LDS, s, a);
+            GFT_CHECK_HIP(hipGetLastError());
+            // the fp32-range walk behind it: its workgroups return at once unless a weight does not fit the fp16 planes
+            a.only_if_wflag = 1;
+            hipLaunchKernelGGL(k_deform_bwd_bf, dim3((unsigned)(n_pad / 64)), dim3(64 * DF_BWD_WAVES), DF_BWD_BF_LDS, s, a);
+        } else if (bf16_planes()) hipLaunchKernelGGL(k_deform_bwd_bf, dim3((unsigned)(n_pad / 64)), dim3(64 * DF_BWD_WAVES), DF_BWD_BF_LDS, s, a);
         else hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(n_pad / (32 * DF_NR_BWD))), dim3(256), DF_BWD_LDS, s, a);
         GFT_CHECK_HIP(hipGetLastError());
     }

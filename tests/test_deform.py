@@ -342,6 +342,60 @@ def test_fp32_mfma_walks_still_match():
 
 
 @pytest.mark.gpu
+def test_bf16_backward_walk_still_matches():
+    """GFT_DEFORM_BWD_FP16=0 keeps the backward walk on three bf16 planes (six MFMAs per product; the default since round 6
+    multiplies two fp16 planes, three MFMAs): it is also what runs when a weight does not fit the fp16 planes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_deform.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "backward_against_oracle or backward_matches_reference or gradient_only"],
+                       env=dict(os.environ, GFT_DEFORM_BWD_FP16="0"), cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_backward_carries_any_gradient_magnitude():
+    """The fp16 planes of the backward walk hold each point's gradient row times its own power of two (k_deform_bwd_h), so
+    the upstream gradient's magnitude is free: times 2^-60 or 2^40 the parameter gradients are the SAME BITS times that
+    power (every scaling in the walk is exact), and rows of very different magnitude in one tile keep their own digits."""
+    dev = torch.device("cuda:0")
+    net, params = _net(31, dev)
+    n = 3000
+    x, t = _inputs(n + 400, 17, False)
+    far = np.sort(np.argsort(-deform_ref.relu_margin(params, x, t))[:n])
+    x, t = x[far], t[far]
+    rng = np.random.default_rng(8)
+    g_dxyz, g_dsh = rng.normal(size=(n, 3)).astype(np.float32), rng.normal(size=(n, 16, 3)).astype(np.float32)
+    xs, ts = torch.tensor(x, device=dev), torch.tensor(t, device=dev)
+
+    def grads(gx, gs):
+        net.zero_grad(set_to_none=True)
+        d_xyz, _, d_sh, _ = net(xs, ts)
+        torch.autograd.backward([d_xyz, d_sh], [torch.tensor(gx, device=dev), torch.tensor(gs, device=dev)])
+        return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    base = grads(g_dxyz, g_dsh)
+    for k in (-60, 40):
+        f = np.float32(2.0 ** k)
+        scaled = grads(g_dxyz * f, g_dsh * f)
+        for name, g in base.items():
+            assert torch.equal(scaled[name], g * float(f)), (k, name)
+    # rows of one 64-point tile 2^36 apart: against float64, and the small rows alone (the large ones zero) as exactly as before
+    row = (np.float32(2.0) ** rng.integers(-18, 19, size=n)).astype(np.float32)
+    mixed = grads(g_dxyz * row[:, None], g_dsh * row[:, None, None])
+    ref = deform_ref.backward(params, x, t, g_dxyz * row[:, None], g_dsh * row[:, None, None], dtype=np.float64)
+    for name, g in mixed.items():
+        assert _rel(g.cpu().numpy(), ref[name]) < BWD_TOL, name
+    small = np.where(row < 2.0 ** -6, row, 0).astype(np.float32)
+    part = grads(g_dxyz * small[:, None], g_dsh * small[:, None, None])
+    ref = deform_ref.backward(params, x, t, g_dxyz * small[:, None], g_dsh * small[:, None, None], dtype=np.float64)
+    for name, g in part.items():
+        assert _rel(g.cpu().numpy(), ref[name]) < BWD_TOL, name
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("frac,n", [(0.1, 40_000), (0.0, 20_000), (0.5, 12_345), (0.9, 20_000)])
 def test_backward_over_rows_with_a_gradient_only(frac, n):
     """In a training iteration only the Gaussians some pixel blended hand a non-zero (d_xyz, d_sh) gradient row to the
