@@ -1273,6 +1273,8 @@ struct BwdArgs {
     float* dz;              // [8][n_pad][256]
     float* dzh;             // [n_pad][64]
     int only_if_wflag;      // k_deform_bwd_bf behind k_deform_bwd_h: run only if a weight is outside the fp16 planes' range
+    float* rowmax;          // [8][n_pad]: k_deform_bwd_h leaves the largest |dz_l| of every point (layers 1..7) for k_deform_dw_h's scales
+    uint32_t* xflag;        // cleared by k_deform_bwd_h; k_deform_dw_h sets it when an activation does not fit its fp16 planes
 };
 
 __global__ __launch_bounds__(256) void k_deform_bwd(BwdArgs a)
@@ -1467,6 +1469,7 @@ __global__ __launch_bounds__(64 * DF_BWD_WAVES) __attribute__((amdgpu_waves_per_
     constexpr int NC = DF_BWD_NC, NT = 64 * DF_BWD_WAVES;
     static_assert(NT == 256, "the head tile's rows are read by 16 consecutive lanes each");
     const int n0 = wave * 32 * NC;
+    if (blockIdx.x == 0 && tid == 0) a.xflag[0] = 0u;
     const __amdgpu_buffer_rsrc_t rw = buf_rsrc(a.packed + DF_PACKED_FLOATS + DF_BF_FLOATS, (uint32_t)DF_H_FLOATS * 4u);
     WSegH seg = wseg_h(10, n0 + li, hh);
     uint4 wcur[2][NC], wnx1[2][NC], wnx2[2][NC];
@@ -1563,6 +1566,7 @@ __global__ __launch_bounds__(64 * DF_BWD_WAVES) __attribute__((amdgpu_waves_per_
                 const int e = grad_exp(m);
                 sc[rt] = pow2_f(14 - e);
                 inv[rt] = pow2_f(e - 24);
+                if (wave == 0 && hh == 0) a.rowmax[(int64_t)l * a.n_pad + p0 + 32 * rt + li] = m;
             }
         }
 #pragma unroll
@@ -1616,6 +1620,10 @@ struct DwArgs {
     int first_block;        // the launch covers workgroups first_block ... of the job table (heavy jobs, then light ones)
     const float* emb; const float* acts; const float* dz; const float* dzh;
     float* part;            // [splits][DW_PART_FLOATS]
+    const float* packed;    // (the fp16 planes' weight flag)
+    const float* rowmax;    // [8][n_pad] from k_deform_bwd_h
+    uint32_t* xflag;        // k_deform_dw_h: set when an activation does not fit the planes
+    int only_if;            // k_deform_dw_bf's hidden-layer launch behind k_deform_dw_h: run only if that one could not
 };
 
 // V consecutive floats as one load / store (V = 2, 3, 4: global_load_dwordx2/x3/x4)
@@ -1985,8 +1993,186 @@ __device__ __forceinline__ void dw_job_bf_shared(const float* A, const float* B,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The hidden layers' dW on TWO fp16 planes (round 6): dw_job_bf_shared's pipeline with three multiplies per product.
+// Scales: an activation goes into the planes times 2^4 as in the forward walk (one beyond 4094 raises `xflag` and the
+// bf16 job launched behind this kernel redoes the work); a gradient has no fixed range, and the sum runs over the
+// points, so the scale must be one per accumulation: the workgroup takes the largest |dz| of ITS points from the row
+// maxima k_deform_bwd_h left (a power of two that puts it in [2^13, 2^14)) and divides its partial sums by it.  Two
+// planes: 64 KB of LDS instead of 96 (still one workgroup per CU: its waves hold 256 accumulator registers each).
+// ---------------------------------------------------------------------------------------------
+constexpr int DW_H_BLOCK_BYTES = 4 * 2 * 64 * 16;                  // [x 4][plane 2][lane 64] x 16 B
+constexpr int DW_H_LDS = 2 * 4 * DW_H_BLOCK_BYTES + 64;            // two buffers of four operand blocks + the scale exchange: 65600 B
+__device__ __forceinline__ void dw_job_h_shared(const float* A, const float* B, const float* rowmax, float* out, float* bias_out,
+                                                int64_t p_begin, int64_t p_end, int wave, int lane, char* lds, uint32_t* xflag)
+{
+    const int li = lane & 31, hh = lane >> 5;
+    // the scale of this workgroup's gradients
+    float* ex = reinterpret_cast<float*>(lds + 2 * 4 * DW_H_BLOCK_BYTES);
+    {
+        float m = 0.f;
+        for (int64_t p = p_begin + wave * 64 + lane; p < p_end; p += 256) m = fmaxf(m, rowmax[p]);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+        if (lane == 0) ex[wave] = m;
+    }
+    __syncthreads();
+    const int e_dz = grad_exp(fmaxf(fmaxf(ex[0], ex[1]), fmaxf(ex[2], ex[3])));
+    const float scale = wave < 2 ? pow2_f(14 - e_dz) : DF_H_ASCALE;
+    f32x16 acc[4][4];
+    zero_acc(acc);
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float top = 0.f;
+    const float* S = (wave < 2 ? A : B) + (p_begin + 8 * hh) * DF_W + 128 * (wave & 1) + li;
+    const bool sum_bias = wave < 2;
+    const int64_t nsteps = (p_end - p_begin) / 16;       // a multiple of 4 (the ranges are multiples of 64 points)
+    const float* S_last = S + (nsteps > 0 ? nsteps - 1 : 0) * 16 * DF_W;
+    float rawA[4][8], rawB[4][8];
+    auto fetch = [&](float (&raw)[4][8]) {
+        S = S > S_last ? S_last : S;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) raw[x][j] = S[(int64_t)j * DF_W + 32 * x];
+        S += 16 * DF_W;
+    };
+    // a pair of values -> their packed hi and lo halves
+    auto split2 = [&](float v0, float v1, uint32_t& hi, uint32_t& lo) {
+        const float s0 = v0 * scale, s1 = v1 * scale;
+        top = fmaxf(top, fmaxf(fabsf(s0), fabsf(s1)));
+        hi = cvt_pk_f16(s0, s1);
+        lo = cvt_pk_f16(sub_f16_lo(s0, hi), sub_f16_hi(s1, hi));
+    };
+    if (nsteps > 0) {
+        fetch(rawA);                        // step 0
+        uint4* dst = reinterpret_cast<uint4*>(lds + wave * DW_H_BLOCK_BYTES) + lane;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            uint32_t ph[4], pl[4];
+            float add = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                add += rawA[x][j] + rawA[x][j + 1];
+                split2(rawA[x][j], rawA[x][j + 1], ph[j >> 1], pl[j >> 1]);
+            }
+            bsum[x] += sum_bias ? add : 0.f;
+            dst[(x * 2 + 0) * 64] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+            dst[(x * 2 + 1) * 64] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        }
+        fetch(rawA);                        // step 1
+        fetch(rawB);                        // step 2
+    }
+    __syncthreads();
+    const int ablk = wave & 1, bblk = 2 + (wave >> 1);
+    // One step: the planes of step k are in buffer k & 1; `raw` holds step k + 1 and is refilled with step k + 3.  A chunk =
+    // three multiplies, the split of one pair of raw values, the loads that refill them and a share of the LDS traffic.
+    auto step = [&](int64_t k, float (&raw)[4][8]) {
+        char* cur = lds + (k & 1) * 4 * DW_H_BLOCK_BYTES;
+        char* nxt = lds + ((k + 1) & 1) * 4 * DW_H_BLOCK_BYTES;
+        const uint4* sa = reinterpret_cast<const uint4*>(cur + ablk * DW_H_BLOCK_BYTES) + lane;
+        const uint4* sb = reinterpret_cast<const uint4*>(cur + bblk * DW_H_BLOCK_BYTES) + lane;
+        uint4* dst = reinterpret_cast<uint4*>(nxt + wave * DW_H_BLOCK_BYTES) + lane;
+        const bool live = k + 1 < nsteps;        // (behind the end: planes that are never read, no bias share)
+        S = S > S_last ? S_last : S;
+        f16x8 pa[4][2], pb[4][2];
+        auto read_a = [&](int q) {
+#pragma unroll
+            for (int x = 0; x < 4; x++) { const uint4 v = sa[(x * 2 + q) * 64]; __builtin_memcpy(&pa[x][q], &v, 16); }
+        };
+        auto read_b = [&](int q) {
+#pragma unroll
+            for (int x = 0; x < 4; x++) { const uint4 v = sb[(x * 2 + q) * 64]; __builtin_memcpy(&pb[x][q], &v, 16); }
+        };
+        read_a(0);
+        read_b(0);
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t ph[4], pl[4];                   // the two planes of one 32-column block: 8 fp16 per lane each
+        float add = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int x = c >> 2, j = (c & 3) * 2;
+            if (c == 0) read_b(1);               // term 1: hi x lo (from multiply 16)
+            if (c == 4) read_a(1);               // term 2: lo x hi (from 32)
+#pragma unroll
+            for (int m = 3 * c; m < 3 * c + 3; m++) {
+                const int term = m >> 4, mx = (m >> 2) & 3, my = m & 3;
+                acc[mx][my] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[mx][term == 2 ? 1 : 0], pb[my][term == 1 ? 1 : 0], acc[mx][my], 0, 0, 0);
+            }
+            {
+                const float v0 = raw[x][j], v1 = raw[x][j + 1];
+                add += v0;
+                add += v1;
+                split2(v0, v1, ph[j >> 1], pl[j >> 1]);
+                // every use of the old values stays in front of the loads that refill their registers
+                asm volatile("" : "+v"(add), "+v"(ph[j >> 1]), "+v"(pl[j >> 1]), "+v"(top) : : "memory");
+                raw[x][j] = S[(int64_t)j * DF_W + 32 * x];
+                raw[x][j + 1] = S[(int64_t)(j + 1) * DF_W + 32 * x];
+            }
+            if (j == 6) {
+                bsum[x] += (sum_bias && live) ? add : 0.f;
+                add = 0.f;
+                dst[(x * 2 + 0) * 64] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                dst[(x * 2 + 1) * 64] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+                if (i == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+                if (i == 1) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);   // DS write
+                if (i == 2) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // VMEM read
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        S += 16 * DF_W;
+        __syncthreads();      // everyone has read `cur` and written `nxt`
+    };
+    for (int64_t k = 0; k < nsteps; k += 2) {
+        step(k, rawA);
+        step(k + 1, rawB);
+    }
+    // (an activation beyond the planes: NaN counts -- the comparison is false for it)
+    if (!sum_bias && !(top <= DF_H_MAX)) __hip_atomic_store(xflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float inv = pow2_f(e_dz - 18);          // 1 / (2^(14 - e) 2^4)
+    const int n_base = 128 * (wave & 1), k_base = 128 * (wave >> 1);
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                out[(int64_t)(n_base + 32 * x + acc_row(q, hh)) * DF_W + k_base + 32 * y + li] = acc[x][y][q] * inv;
+    if (sum_bias) {
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const float tot = bsum[x] + __shfl_xor(bsum[x], 32);
+            if (hh == 0) bias_out[n_base + 32 * x + li] = tot;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_deform_dw_h(DwArgs a)
+{
+    extern __shared__ float4 df_lds[];
+    if (__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.packed + DF_FLAG_OFF)) != 0u) return;
+    const int wg = (int)blockIdx.x;
+    const int job = wg % 7, split = wg / 7;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t p_begin = (int64_t)split * a.tiles_per_split * DF_DW_TILE;
+    int64_t p_end = p_begin + (int64_t)a.tiles_per_split * DF_DW_TILE;
+    if (p_end > a.n_pad) p_end = a.n_pad;
+    float* part = a.part + (int64_t)split * DW_PART_FLOATS;
+    const int64_t plane = a.n_pad * DF_W;
+    const int l = 7 - job;
+    dw_job_h_shared(a.dz + l * plane, a.acts + (l - 1) * plane, a.rowmax + (int64_t)l * a.n_pad, part + DW_OFF_L(l), part + DW_OFF_BIAS + l * DF_W,
+                    p_begin, p_end, wave, lane, reinterpret_cast<char*>(df_lds), a.xflag);
+}
+
 __global__ __launch_bounds__(256) void k_deform_dw_bf(DwArgs a)
 {
+    if (a.only_if && __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.packed + DF_FLAG_OFF)) == 0u &&
+        __hip_atomic_load(a.xflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        return;
     int job, split;
     const int wg = (int)blockIdx.x + a.first_block;
     if (wg < 7 * a.splits) {
@@ -2212,7 +2398,8 @@ extern "C" size_t gft_deform_scratch_bytes(int64_t n)
     const int64_t n_pad = pad_points(n);
     int tps;
     const int splits = dw_splits(n_pad, &tps);
-    return ((size_t)n_pad * (DF_D * DF_W + DF_HEAD) + (size_t)splits * DW_PART_FLOATS) * sizeof(float);
+    // dz | dzh | the splits' partial sums | the points' largest |dz| per layer | the range flag of k_deform_dw_h
+    return ((size_t)n_pad * (DF_D * DF_W + DF_HEAD) + (size_t)splits * DW_PART_FLOATS + (size_t)n_pad * DF_D + 4) * sizeof(float);
 }
 
 extern "C" int gft_deform_pack(void* hip_stream, int xyz_multires, int t_multires, const gft_deform_params* p, void* packed)
@@ -2336,6 +2523,11 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
     float* dz = (float*)scratch;
     float* dzh = dz + n_pad * DF_D * DF_W;
     float* part = dzh + n_pad * DF_HEAD;
+    int tps;
+    const int splits = dw_splits(n_pad, &tps);
+    float* rowmax = part + (int64_t)splits * DW_PART_FLOATS;
+    uint32_t* xflag = reinterpret_cast<uint32_t*>(rowmax + n_pad * DF_D);
+    const bool h_planes = bf16_planes() && fp16_backward();
     {
         BwdArgs a;
         a.n = n; a.n_pad = n_pad;
@@ -2344,7 +2536,8 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
         a.g_dxyz = g_d_xyz; a.g_dsh = g_d_sh;
         a.dz = dz; a.dzh = dzh;
         a.only_if_wflag = 0;
-        if (bf16_planes() && fp16_backward()) {
+        a.rowmax = rowmax; a.xflag = xflag;
+        if (h_planes) {
             hipLaunchKernelGGL(k_deform_bwd_h, dim3((unsigned)(n_pad / 64)), dim3(64 * DF_BWD_WAVES), DF_BWD_H_LDS, s, a);
             GFT_CHECK_HIP(hipGetLastError());
             // the fp32-range walk behind it: its workgroups return at once unless a weight does not fit the fp16 planes
@@ -2354,8 +2547,6 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
         else hipLaunchKernelGGL(k_deform_bwd, dim3((unsigned)(n_pad / (32 * DF_NR_BWD))), dim3(256), DF_BWD_LDS, s, a);
         GFT_CHECK_HIP(hipGetLastError());
     }
-    int tps;
-    const int splits = dw_splits(n_pad, &tps);
     {
         DwArgs a;
         a.n_pad = n_pad;
@@ -2364,6 +2555,7 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
         a.emb = emb; a.acts = acts; a.dz = dz; a.dzh = dzh;
         a.part = part;
         a.first_block = 0;
+        a.packed = (const float*)packed; a.rowmax = rowmax; a.xflag = xflag; a.only_if = 0;
         if (bf16_planes()) {
             // Two launches of the same kernel: the hidden-layer jobs (7 x splits workgroups, one wave per SIMD, 96 KB
             // of LDS), then the light jobs (dW of layer 0, of the encoding rows of layer 5, of the heads), which need no
@@ -2372,8 +2564,18 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
             // heavy waves' hand-placed schedule has no room for a guest), light first 1.54 ms.
             static std::atomic<uint64_t> done{0};
             GFT_CHECK_HIP(gft_lds_opt_in(reinterpret_cast<const void*>(&k_deform_dw_bf), DW_SH_LDS, done));
+            if (h_planes) {
+                // the hidden layers on two fp16 planes; the bf16 job behind it returns at once unless a weight or an
+                // activation did not fit them
+                static std::atomic<uint64_t> done_h{0};
+                GFT_CHECK_HIP(gft_lds_opt_in(reinterpret_cast<const void*>(&k_deform_dw_h), DW_H_LDS, done_h));
+                hipLaunchKernelGGL(k_deform_dw_h, dim3(7 * splits), dim3(256), DW_H_LDS, s, a);
+                GFT_CHECK_HIP(hipGetLastError());
+                a.only_if = 1;
+            }
             hipLaunchKernelGGL(k_deform_dw_bf, dim3(7 * splits), dim3(256), DW_SH_LDS, s, a);
             GFT_CHECK_HIP(hipGetLastError());
+            a.only_if = 0;
             DwArgs light = a;
             light.first_block = 7 * splits;
             hipLaunchKernelGGL(k_deform_dw_bf, dim3(3 * splits), dim3(256), 0, s, light);
