@@ -12,7 +12,7 @@ results of ``forward(x, t)``:
 as under the reference's autograd, never receive a gradient).
 
 The arithmetic is done by hand-written MFMA kernels (``csrc/k_deform.hip``) behind the C ABI of
-``include/gftorf_deform.h`` -- fp32 results from three bf16 planes per operand, or fp32-operand MFMA with
+``include/gftorf_deform.h`` -- fp32 results from two fp16 (or three bf16) planes per operand, or fp32-operand MFMA with
 ``GFT_DEFORM_BF16X3=0``; there is no CPU path and no torch GEMM in it.  Inputs are not
 differentiated: the reference passes detached positions (``scene/gaussian_model.py:172``).
 """

@@ -173,9 +173,9 @@ def test_bench_refuses_to_run_without_gpu():
 def test_deform_size_queries_and_argument_errors(lib):
     from gftorf_amd import _lib
     # 2 x 96*256 (layer 0, encoding rows of layer 5) + 7*65536 + 16384 forward, 16384 + 7*65536 backward, 2112 biases
-    # + three bf16 planes of both weight streams + two fp16 planes of the forward stream (524288 weights, 2 x 2 bytes each)
-    # + the range flag's four words
-    assert lib.gft_deform_packed_bytes() == (1001536 + 999424 * 3 // 2 + 524288 + 4) * 4
+    # + three bf16 planes of both weight streams + two fp16 planes of both (999424 weights, 2 x 2 bytes each; the backward
+    # stream's since round 6) + the range flag's four words
+    assert lib.gft_deform_packed_bytes() == (1001536 + 999424 * 3 // 2 + 999424 + 4) * 4
     assert lib.gft_deform_inputs(10, 10) == 84 and lib.gft_deform_inputs(10, 6) == 76      # reference config / class default
     assert lib.gft_deform_inputs(10, 16) == 96 == _lib.DEFORM_MAX_INPUTS and lib.gft_deform_inputs(10, 17) == -1
     assert lib.gft_deform_inputs(-1, 6) == -1
