@@ -510,20 +510,26 @@ def deform_extra(dev, n=300_000, steps=10, warmup=3):
     tf = 2.0 * macs * n / (ms * 1e-3) / 1e12
     tf_fwd = 2.0 * macs_fwd * n / (fwd_ms * 1e-3) / 1e12
     # matrix-pipe multiplies per fp32 product: the forward walk takes 3 (two fp16 planes per operand; GFT_DEFORM_FP16X2=0: 6,
-    # three bf16 planes), the backward walk and the weight-gradient kernel 6
+    # three bf16 planes); since round 6 so do the backward walk and the hidden layers' weight gradients
+    # (GFT_DEFORM_BWD_FP16=0: 6); the first layer's, the skip rows' and the heads' weight gradients take 6
     fwd_terms = 3.0 if os.environ.get("GFT_DEFORM_FP16X2", "1") != "0" else 6.0
+    bwd_terms = 3.0 if os.environ.get("GFT_DEFORM_BWD_FP16", "1") != "0" else 6.0
     peak_fwd = BF16_MFMA_PEAK_TFLOPS / fwd_terms
-    peak_all = macs / (macs_fwd / peak_fwd + (macs - macs_fwd) / (BF16_MFMA_PEAK_TFLOPS / 6.0))
-    return {"what": "deformation network fwd+bwd (SURVEY 8(f)#2), %d points, fp32 results from the fp16 / bf16 matrix pipe: three "
-                    "fp16 MFMAs per product in the forward walk, six bf16 MFMAs in the backward kernels "
-                    "(GFT_DEFORM_FP16X2=0: six in the forward too; GFT_DEFORM_BF16X3=0: fp32-operand MFMA)" % n,
+    macs_light = 2 * n_in * 256 + 51 * 256                      # dW of layer 0, of layer 5's encoding rows, of the heads
+    macs_bwd_h = (macs - macs_fwd) - macs_light                 # the backward walk + the hidden layers' dW
+    peak_all = macs / (macs_fwd / peak_fwd + macs_bwd_h / (BF16_MFMA_PEAK_TFLOPS / bwd_terms) + macs_light / (BF16_MFMA_PEAK_TFLOPS / 6.0))
+    return {"what": "deformation network fwd+bwd (SURVEY 8(f)#2), %d points, fp32 results from the 16-bit matrix pipe: three "
+                    "fp16 MFMAs per product in the forward walk, the backward walk and the hidden layers' weight gradients, six "
+                    "bf16 MFMAs in the other weight gradients (GFT_DEFORM_FP16X2=0 / GFT_DEFORM_BWD_FP16=0: six bf16 ones in the "
+                    "forward / backward; GFT_DEFORM_BF16X3=0: fp32-operand MFMA)" % n,
             "fwd_bwd_ms": ms, "inference_fwd_ms": fwd_ms, "eager_torch_ms": eager_ms, "speedup_vs_eager": eager_ms / ms,
             "algorithmic_flops": 2.0 * macs * n, "achieved_TFLOPs": tf, "inference_TFLOPs": tf_fwd,
             "architecture": dict(D=net.D, W=net.W, xyz_multires=net.xyz_multires, t_multires=net.t_multires,
                                  encoded_inputs=n_in, parameters=sum(p.numel() for p in net.parameters())),
             "roofline": {"bound": "mfma", "achieved": tf, "peak": peak_all, "unit": "TFLOP/s", "frac": tf / peak_all,
                          "note": "fp32 products on the 16-bit matrix pipe (2500 TFLOP/s dense): %d multiplies each in the forward "
-                                 "walk, 6 in the backward kernels; peak = the flop-weighted mix" % int(fwd_terms)},
+                                 "walk, %d in the backward walk and the hidden layers' weight gradients, 6 in the other "
+                                 "weight gradients; peak = the flop-weighted mix" % (int(fwd_terms), int(bwd_terms))},
             "inference_frac": tf_fwd / peak_fwd, "inference_peak_TFLOPs": peak_fwd,
             "ratio_to_fp32_operand_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS,
             "points_per_s": n / (ms * 1e-3),
