@@ -21,10 +21,15 @@ The work is done by hand-written gfx950 kernels (``csrc/k_assemble.hip``) throug
 ``include/gftorf_assemble.h``; there is no CPU path.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib
+
+
+# GFT_ASSEMBLE_ALIAS_SH=0: the backward copies the SH rows' gradient into a tensor of its own (rounds 3-5)
+_ALIAS_SH_GRADS = os.environ.get("GFT_ASSEMBLE_ALIAS_SH", "1") != "0"
 
 
 def _is_tensor(x):
@@ -135,7 +140,15 @@ class _AssembleInputs(torch.autograd.Function):
         g_xyz, g_ssp = new(need[0], (P, 3)), new(need[1], (P, 3))
         g_op, g_sc = new(need[2], tuple(ctx.opacity_shape)), new(need[3], (P, 3))
         g_rot, g_raw = new(need[4], (P, 4)), new(need[5], (P, 4))
-        g_fc, g_fp = new(need[6], (P, M, 3)), new(need[7], (P, M_p, 2))
+        # The SH rows: shs = features (+ d_sh on the dynamic rows), so with both regions rendered the features' gradient IS
+        # the incoming one, row for row -- it is handed on as it is (no [P, M, 3] tensor allocated, no 320 bytes per
+        # Gaussian read and written again; the kernel then only gathers the dynamic rows for d_sh).  With a region left
+        # out its rows must come out zero whatever arrives: the copy stays.
+        alias = bool(rs and rd) and _ALIAS_SH_GRADS
+        alias_fc = alias and need[6] and g_shs is not None and g_shs.dtype == torch.float32 and g_shs.is_contiguous()
+        alias_fp = alias and need[7] and g_shs_p is not None and g_shs_p.dtype == torch.float32 and g_shs_p.is_contiguous()
+        g_fc = None if alias_fc else new(need[6], (P, M, 3))
+        g_fp = None if alias_fp else new(need[7], (P, M_p, 2))
         nd = ctx.off_rows
         g_dxyz = new(need[9] and nd[0] >= 0 and ctx.offs_scalar[0] is None, (nd[0], 3))
         g_drot = new(need[10] and ctx.offs_scalar[1] is None, (nd[1], 4))
@@ -159,6 +172,10 @@ class _AssembleInputs(torch.autograd.Function):
         stream = _lib.raw_stream(dev)
         with _lib.on_device(dev):
             _lib.check(lib.gft_assemble_backward(stream, P, M, M_p, rs, rd, C.byref(io)))
+        if alias_fc:
+            g_fc = g_shs if tuple(g_shs.shape) == (P, M, 3) else g_shs.view(P, M, 3)
+        if alias_fp:
+            g_fp = g_shs_p if tuple(g_shs_p.shape) == (P, M_p, 2) else g_shs_p.view(P, M_p, 2)
         return (g_xyz, g_ssp, g_op, g_sc, g_rot, g_raw, g_fc, g_fp, None, g_dxyz, g_drot, g_dsh, g_dshp,
                 None, None, None)
 

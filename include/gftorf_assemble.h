@@ -86,6 +86,9 @@ typedef struct gft_assemble_bwd_io {
     float* g_scaling;            /* [P,3] */
     float* g_rotation;           /* [P,4]  static rows, zeros elsewhere */
     float* g_rotation_raw;       /* [P,4]  dynamic rows (through the normalisation), zeros elsewhere */
+    /* shs = features (+ d_sh on the dynamic rows): with both regions rendered the features' gradient is g_shs itself, row
+     * for row.  A caller that hands g_shs on as that gradient passes NULL here and saves the copy (320 bytes per Gaussian
+     * read and written at M = 16); only the dynamic rows are then read, for g_d_sh / g_d_sh_p. */
     float* g_feat_color;         /* [P,M,3] */
     float* g_feat_phasor;        /* [P,M_p,2] */
     float* g_d_xyz;              /* [Nd,3] */

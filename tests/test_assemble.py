@@ -209,3 +209,28 @@ def test_hip_assembly_normalises_the_static_rotations_itself(regions, gpu):
             np.testing.assert_allclose(gg[k], rg[k], rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(rg[k]).max()) * 1e-6), err_msg=k)
         else:
             np.testing.assert_array_equal(gg[k], rg[k], err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regions", [("static", "dynamic"), ("static",)])
+def test_sh_gradients_are_handed_on_without_a_copy(regions, gpu):
+    """shs = features (+ d_sh on the dynamic rows): with both regions rendered the features' gradient is the incoming
+    gradient itself, and the backward returns THAT tensor (no [P, M, 3] copy); the dynamic rows are gathered for d_sh.
+    With a region left out its rows must be zero whatever arrives: a tensor of its own."""
+    from gftorf_amd import assemble_inputs
+    P, M = 5000, 16
+    gen = torch.Generator().manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(gpu)
+    mask = (torch.rand(P, generator=gen) < 0.3).to(gpu)
+    nd = int(mask.sum())
+    fc, fp = rnd(P, M, 3).requires_grad_(), rnd(P, M, 2).requires_grad_()
+    d_sh, d_sh_p = rnd(nd, M, 3).requires_grad_(), rnd(nd, M, 2).requires_grad_()
+    xyz, ssp, op, sc, raw = rnd(P, 3), torch.zeros(P, 3, device=gpu), rnd(P, 1), rnd(P, 3), rnd(P, 4)
+    outs = assemble_inputs(xyz, ssp, op, sc, None, raw, fc, fp, mask, 0.0, 0.0, d_sh, d_sh_p, render_regions=regions)
+    g_shs, g_shp = rnd(P, M, 3), rnd(P, M, 2)
+    g_fc, g_fp, g_d, g_dp = torch.autograd.grad([outs[5], outs[6]], [fc, fp, d_sh, d_sh_p], [g_shs, g_shp])
+    both = len(regions) == 2
+    assert (g_fc.data_ptr() == g_shs.data_ptr()) == both and (g_fp.data_ptr() == g_shp.data_ptr()) == both
+    on = torch.ones(P, dtype=torch.bool, device=gpu) if both else ~mask
+    assert torch.equal(g_fc, g_shs * on[:, None, None]) and torch.equal(g_fp, g_shp * on[:, None, None])
+    assert torch.equal(g_d, g_shs[mask] * float(both)) and torch.equal(g_dp, g_shp[mask] * float(both))
