@@ -700,7 +700,9 @@ def train_iteration_extra(dev, scene, steps=10, warmup=3, only_fused=False):
 
         def iteration():
             tt = torch.full((1, 1), 0.4, device=dev).expand(x_n.size(0), -1)
-            d = net(x_n, tt) if fused else deform_ref.deform_eager(net, x_n, tt)
+            # (this package's network hands its two all-zero offsets over as the scalar 0.0, which assemble_inputs takes like
+            # train.py:164's -- no [n, 4] / [n, 16, 2] zero tensors filled, added and given a gradient)
+            d = net(x_n, tt, zeros_as_scalars=True) if fused else deform_ref.deform_eager(net, x_n, tt)
             # render() (gaussian_renderer/__init__.py:81-128): one input assembly, then the colour-camera and the
             # ToF-camera rasterizer calls on the same tensors
             ssp = torch.zeros((P, 3), device=dev, requires_grad=True)

@@ -375,9 +375,10 @@ extern "C" int gft_assemble_forward(void* hip_stream, int32_t P, int32_t M, int3
         !io->motion_mask || !io->scratch || !io->out_means3D || !io->out_means2D || !io->out_opacity || !io->out_scales ||
         !io->out_rotations)
         return gft_fail("gft_assemble_forward: required pointer is NULL");
-    if ((M > 0) != (io->feat_color != nullptr) || (M > 0) != (io->out_shs != nullptr))
+    // (out_shs / out_shs_p may be NULL with M, M_p > 0: the caller uses the feature tensor itself -- a zero offset, both regions)
+    if ((M > 0) != (io->feat_color != nullptr) || (M == 0 && io->out_shs != nullptr))
         return gft_fail("gft_assemble_forward: M does not match feat_color / out_shs");
-    if ((M_p > 0) != (io->feat_phasor != nullptr) || (M_p > 0) != (io->out_shs_p != nullptr))
+    if ((M_p > 0) != (io->feat_phasor != nullptr) || (M_p == 0 && io->out_shs_p != nullptr))
         return gft_fail("gft_assemble_forward: M_p does not match feat_phasor / out_shs_p");
     if ((io->d_xyz || io->d_rot || io->d_sh || io->d_sh_p) && (io->num_offset_rows < 0 || io->num_offset_rows > P))
         return gft_fail("gft_assemble_forward: the offset tensors have %lld rows for %d Gaussians", (long long)io->num_offset_rows, P);

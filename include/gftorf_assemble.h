@@ -57,8 +57,8 @@ typedef struct gft_assemble_io {
     float* out_opacity;          /* [P,1] */
     float* out_scales;           /* [P,3] */
     float* out_rotations;        /* [P,4] */
-    float* out_shs;              /* [P,M,3] */
-    float* out_shs_p;            /* [P,M_p,2] */
+    float* out_shs;              /* [P,M,3]; NULL = not wanted (a scalar offset of 0 with both regions rendered: the */
+    float* out_shs_p;            /* [P,M_p,2]  output would be the feature tensor, which the caller then uses itself)  */
     /* Nd: rows of the d_* tensors that are given (all share it; 0 <= Nd <= P; ignored when all four are scalars).
      * A dynamic Gaussian whose rank among the dynamic ones is >= Nd has no offset row -- the reference's masked
      * assignment raises for such shapes -- : nothing is read or written out of bounds, that Gaussian's outputs are

@@ -234,3 +234,30 @@ def test_sh_gradients_are_handed_on_without_a_copy(regions, gpu):
     on = torch.ones(P, dtype=torch.bool, device=gpu) if both else ~mask
     assert torch.equal(g_fc, g_shs * on[:, None, None]) and torch.equal(g_fp, g_shp * on[:, None, None])
     assert torch.equal(g_d, g_shs[mask] * float(both)) and torch.equal(g_dp, g_shp[mask] * float(both))
+
+
+@pytest.mark.gpu
+def test_zero_scalar_offsets_return_the_feature_tensors_themselves(gpu):
+    """d_sh_p is always the scalar 0.0 from this package's network (the reference's network returns zeros there,
+    time_utils.py:127), d_sh too before warm-up ends (train.py:164): with both regions rendered shs / shs_p are then the
+    feature tensors, handed back as they are -- and their gradient arrives in the features' .grad."""
+    from gftorf_amd import assemble_inputs
+    P, M = 4000, 16
+    gen = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(gpu)
+    mask = (torch.rand(P, generator=gen) < 0.3).to(gpu)
+    nd = int(mask.sum())
+    fc, fp = rnd(P, M, 3).requires_grad_(), rnd(P, M, 2).requires_grad_()
+    d_sh = rnd(nd, M, 3).requires_grad_()
+    xyz, ssp, op, sc, raw = rnd(P, 3), torch.zeros(P, 3, device=gpu), rnd(P, 1), rnd(P, 3), rnd(P, 4)
+    outs = assemble_inputs(xyz, ssp, op, sc, None, raw, fc, fp, mask, 0.0, 0.0, d_sh, 0.0)
+    assert outs[6].data_ptr() == fp.data_ptr() and outs[5].data_ptr() != fc.data_ptr()
+    want = fc.detach().clone()
+    want[mask] += d_sh.detach()
+    assert torch.equal(outs[5], want)
+    g_shs, g_shp = rnd(P, M, 3), rnd(P, M, 2)
+    torch.autograd.backward([outs[5], outs[6]], [g_shs, g_shp])
+    assert torch.equal(fp.grad, g_shp) and torch.equal(fc.grad, g_shs) and torch.equal(d_sh.grad, g_shs[mask])
+    # a region left out: zeros there, so a tensor of its own
+    outs = assemble_inputs(xyz, ssp, op, sc, None, raw, fc, fp, mask, 0.0, 0.0, 0.0, 0.0, render_regions=("static",))
+    assert outs[6].data_ptr() != fp.data_ptr() and not outs[6][mask].any() and torch.equal(outs[6][~mask], fp.detach()[~mask])
