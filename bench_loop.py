@@ -163,7 +163,7 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False, graph=False, fused_loss=True)
         """The device work of one iteration on the given camera pair, background, ground truth and time tensor."""
         d_xyz, d_rot, d_sh, d_sh_p = 0.0, 0.0, 0.0, 0.0
         if net_on:                                                   # gaussian_model.py:170-174
-            d_xyz, d_rot, d_sh, d_sh_p = net(par["xyz"].detach(), tt)
+            d_xyz, d_rot, d_sh, d_sh_p = net(par["xyz"].detach(), tt, zeros_as_scalars=True)      # (0.0 for the two all-zero offsets, as line above)
         # activations (gaussian_model.py:123-153)
         scaling = torch.exp(par["scaling"])
         rotation = torch.nn.functional.normalize(par["rotation"])
