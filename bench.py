@@ -390,7 +390,8 @@ def assemble_extra(dev, P=1_000_000, frac=0.3, M=16, steps=20, warmup=5):
     against the reference's eager-PyTorch glue (gaussian_renderer/__init__.py:81-105, restated in
     oracle/assemble_ref.py) on the same device.  Algorithmic bytes per Gaussian at M = 16, fp32:
     forward reads 12+12+4+12+16+192+128 = 376 (+ 348 of offsets for a dynamic row) and writes 388;
-    backward reads 388 and writes 392 (+ 348 for a dynamic row)."""
+    backward reads 388 and writes 392 (+ 348 for a dynamic row) -- since round 6 without the 320 bytes of SH gradient, which the
+    backward hands on as they are."""
     import numpy as np
     import torch
     from gftorf_amd import assemble_inputs
@@ -407,12 +408,25 @@ def assemble_extra(dev, P=1_000_000, frac=0.3, M=16, steps=20, warmup=5):
         t.requires_grad_(True)
     gout = None
 
+    class _FromRasterizer(torch.autograd.Function):
+        # The gradients reach the assembly as the rasterizer's backward hands them over: tensors nobody else holds, which
+        # autograd may keep as a leaf's .grad.  (Gradients the caller holds -- a plain backward(outs, gout) -- are cloned
+        # by autograd on their way into .grad: 320 bytes per Gaussian of torch's, not of the op's.)
+        @staticmethod
+        def forward(ctx, x, g):
+            ctx.g = g
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, _):
+            return ctx.g.view_as(ctx.g), None
+
     def step(fn):
         nonlocal gout
         outs = fn(*src, mask, *offs)
         if gout is None:
             gout = [torch.randn_like(o) for o in outs]
-        torch.autograd.backward(outs, gout)
+        torch.autograd.backward([_FromRasterizer.apply(o, g) for o, g in zip(outs, gout)], gout)
         for t in src + offs:
             t.grad = None
 
@@ -430,7 +444,9 @@ def assemble_extra(dev, P=1_000_000, frac=0.3, M=16, steps=20, warmup=5):
 
     fused_ms = timed(assemble_inputs, steps, warmup)
     eager_ms = timed(assemble_ref.assemble_eager, max(3, steps // 4), 2)
-    bytes_alg = P * (376 + 388 + 388 + 392) + nd * (348 + 348)
+    # (round 6: the backward hands the SH rows' gradient on instead of copying it -- 320 bytes per Gaussian neither read nor
+    # written again; the dynamic rows are read once more for d_sh / d_sh_p)
+    bytes_alg = P * (376 + 388 + (388 - 320) + (392 - 320)) + nd * (348 + 348 + 320)
     return {"what": "fused input assembly fwd+bwd (SURVEY 8(f)#1), %d Gaussians, %d dynamic, SH 16" % (P, nd),
             "fused_ms": fused_ms, "eager_torch_ms": eager_ms, "speedup_vs_eager": eager_ms / fused_ms,
             "algorithmic_bytes": bytes_alg, "achieved_GBs": bytes_alg / (fused_ms * 1e-3) / 1e9,
