@@ -64,7 +64,7 @@ C3 = dict(P=100_000, W=320, H=240, views=30, sh_degree=3, warm_up=2000, depth_ra
                 "deform network on after warm_up 2000, colour + ToF rasterizer call per iteration")
 
 
-def build_loop(dev, cfg=C3, seed=1236, pair=False, graph=False, fused_loss=True):
+def build_loop(dev, cfg=C3, seed=1236, pair=False, graph=False, fused_loss=True, fused_params=None):
     """Returns (iteration_fn, info): iteration_fn(it) runs iteration `it` (1-based) and returns the loss tensor.
 
     ``graph=True``: the iteration's device work -- deform query, activations, input assembly, both rasterizer calls, loss,
@@ -74,15 +74,21 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False, graph=False, fused_loss=True)
     tensor) and through pinned memory (the learning rates: ``FusedAdam(capturable=True)``).  The same statements in the
     same order on the same values as the eager loop; the first iterations of every configuration run eagerly.
 
+    ``fused_params`` (default: on; ``GFT_LOOP_TORCH_ACTIVATIONS=1`` or ``--torch-loss`` runs: off): the activations and
+    concatenations of ``pc.get_*`` inside the assembly (``gftorf_amd.assemble_parameters``) instead of ~25 eager launches.
+
     ``fused_loss=True`` (default): the two image terms of the loss -- ``l2_loss`` and ``ssim`` of utils/loss_utils.py -- from
     ``gftorf_amd.loss.ssim_l2`` (one launch forward, one backward) instead of eight torch convolutions and ~25 elementwise
     launches; ``False``: stock torch, as the reference has it."""
     import torch
     from gftorf_amd import (FusedAdam, GaussianRasterizationSettings, GaussianRasterizer, GaussianRasterizerPair,
-                            assemble_inputs, densify, reference_network, synth)
+                            assemble_inputs, assemble_parameters, densify, reference_network, synth)
     from gftorf_amd import loss as gft_loss
     P, W, H, V = cfg["P"], cfg["W"], cfg["H"], cfg["views"]
     t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
+    if fused_params is None:       # (the stock-torch variant of the loop keeps the reference's eager activations too)
+        import os
+        fused_params = fused_loss and os.environ.get("GFT_LOOP_TORCH_ACTIVATIONS", "0") != "1"
 
     # 30 views on a small arc; the ToF sensor sits beside the colour camera (its own pose, cameras.py:121-146)
     base_cam = synth.make_camera(W, H)
@@ -164,16 +170,23 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False, graph=False, fused_loss=True)
         d_xyz, d_rot, d_sh, d_sh_p = 0.0, 0.0, 0.0, 0.0
         if net_on:                                                   # gaussian_model.py:170-174
             d_xyz, d_rot, d_sh, d_sh_p = net(par["xyz"].detach(), tt, zeros_as_scalars=True)      # (0.0 for the two all-zero offsets, as line above)
-        # activations (gaussian_model.py:123-153)
-        scaling = torch.exp(par["scaling"])
-        rotation = torch.nn.functional.normalize(par["rotation"])
-        opacity = torch.sigmoid(par["opacity"])
-        feat_c = torch.cat((par["f_dc_color"], par["f_rest_color"]), dim=1)
-        feat_p = torch.cat((torch.cat((par["phase_f_dc"], par["phase_f_rest"]), dim=1),
-                            torch.cat((par["amp_f_dc"], par["amp_f_rest"]), dim=1)), dim=2)
         ssp = torch.zeros((P, 3), device=dev, requires_grad=True)
-        m3, m2, op, sc, ro, shs, shp = assemble_inputs(par["xyz"], ssp, opacity, scaling, rotation, par["rotation"], feat_c, feat_p,
-                                                      mask, d_xyz, d_rot, d_sh, d_sh_p, render_regions=("dynamic",))
+        if fused_params:
+            # pc.get_* (gaussian_model.py:123-153: exp, normalize, sigmoid, the concatenations of the feature tensors) inside the
+            # assembly's kernels, forward and backward: gftorf_amd.assemble_parameters
+            m3, m2, op, sc, ro, shs, shp = assemble_parameters(
+                par["xyz"], ssp, par["opacity"], par["scaling"], par["rotation"], par["f_dc_color"], par["f_rest_color"], par["phase_f_dc"],
+                par["phase_f_rest"], par["amp_f_dc"], par["amp_f_rest"], mask, d_xyz, d_rot, d_sh, d_sh_p, render_regions=("dynamic",))
+        else:
+            # activations (gaussian_model.py:123-153), eagerly as the reference has them
+            scaling = torch.exp(par["scaling"])
+            rotation = torch.nn.functional.normalize(par["rotation"])
+            opacity = torch.sigmoid(par["opacity"])
+            feat_c = torch.cat((par["f_dc_color"], par["f_rest_color"]), dim=1)
+            feat_p = torch.cat((torch.cat((par["phase_f_dc"], par["phase_f_rest"]), dim=1),
+                                torch.cat((par["amp_f_dc"], par["amp_f_rest"]), dim=1)), dim=2)
+            m3, m2, op, sc, ro, shs, shp = assemble_inputs(par["xyz"], ssp, opacity, scaling, rotation, par["rotation"], feat_c, feat_p,
+                                                          mask, d_xyz, d_rot, d_sh, d_sh_p, render_regions=("dynamic",))
         if pair:      # opt-in: both calls as one node (gftorf_amd/pair.py); same outputs
             out_c, out_t = GaussianRasterizerPair(settings(cc, bg_map, degree, False), settings(ct, bg_map, degree, True))(
                 means3D=m3, means2D=m2, opacities=op, shs=shs, shs_p=shp, scales=sc, rotations=ro,
@@ -273,7 +286,7 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False, graph=False, fused_loss=True)
         g[1].replay()
         return g[2]
 
-    info = dict(P=P, W=W, H=H, views=V, ssim=state["ssim_ok"], frame=dict(cams=cams, g0=g0), par=par, net=net, opt=opt, opt_net=opt_net,
+    info = dict(P=P, W=W, H=H, views=V, ssim=state["ssim_ok"], activations="gftorf_amd.assemble_parameters (inside the assembly)" if fused_params else "torch: exp / sigmoid / normalize / cat, eagerly", frame=dict(cams=cams, g0=g0), par=par, net=net, opt=opt, opt_net=opt_net,
                 graphs=(lambda: {k: v[1] is not None for k, v in graphs.items()}) if graph else (lambda: {}))
     return iteration, info
 
@@ -293,6 +306,7 @@ def run(dev, iters, sync, timed_region, cfg=C3, pair=False, graph=False, fused_l
     secs = timed_region(step, iters)
     rep = dict(iterations=counter["it"], ssim_in_loss=info["ssim"] or fused_loss,
                loss_terms="gftorf_amd.loss.ssim_l2 (one launch forward, one backward)" if fused_loss else "torch: conv2d SSIM + elementwise L2",
+               activations=info["activations"],
                loss_trace=[(i, float(l.item())) for i, l in losses])
     if graph:
         rep["graphs_captured"] = {"degree %d, network %s" % (k[0], "on" if k[1] else "off"): v for k, v in info["graphs"]().items()}

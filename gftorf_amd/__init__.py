@@ -8,12 +8,12 @@ operator API, hand-written gfx950 HIP kernels behind a C ABI
 from .api import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians,  # noqa: F401
                   _RasterizeGaussians)
 from .pair import GaussianRasterizerPair, render_pair  # noqa: F401
-from .assemble import assemble_inputs  # noqa: F401
+from .assemble import assemble_inputs, assemble_parameters  # noqa: F401
 from .knn import distCUDA2  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
 from .deform import DeformNetwork, REFERENCE_ARCH, reference_network  # noqa: F401
 from . import densify  # noqa: F401
 from . import loss  # noqa: F401
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "GaussianRasterizerPair", "render_pair", "assemble_inputs", "distCUDA2", "FusedAdam",
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "GaussianRasterizerPair", "render_pair", "assemble_inputs", "assemble_parameters", "distCUDA2", "FusedAdam",
            "DeformNetwork", "REFERENCE_ARCH", "reference_network", "densify"]

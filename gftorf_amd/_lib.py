@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgftorf_rast.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 DEFORM_MAX_INPUTS = 96          # GFT_DEFORM_MAX_INPUTS (include/gftorf_deform.h)
 ACC_STRIDE = 16
 
@@ -98,22 +98,26 @@ ASSEMBLE_PTRS_IN = ["xyz", "screenspace", "opacity", "scaling", "rotation", "rot
 ASSEMBLE_SCALARS = ["d_xyz_scalar", "d_rot_scalar", "d_sh_scalar", "d_sh_p_scalar"]
 ASSEMBLE_PTRS_OUT = ["scratch", "out_means3D", "out_means2D", "out_opacity", "out_scales", "out_rotations",
                      "out_shs", "out_shs_p"]
-ASSEMBLE_FIELDS = ASSEMBLE_PTRS_IN + ASSEMBLE_SCALARS + ASSEMBLE_PTRS_OUT + ["num_offset_rows"]
+ASSEMBLE_RAW_FLAGS = ["opacity_is_raw", "scaling_is_raw"]          # (round 6: the model's own tensors as sources)
+ASSEMBLE_PARTS = ["feat_dc_color", "feat_rest_color", "phase_dc", "phase_rest", "amp_dc", "amp_rest"]
+ASSEMBLE_FIELDS = ASSEMBLE_PTRS_IN + ASSEMBLE_SCALARS + ASSEMBLE_PTRS_OUT + ["num_offset_rows"] + ASSEMBLE_RAW_FLAGS + ASSEMBLE_PARTS
 ASSEMBLE_BWD_HEAD = ["scratch", "rotation_raw", "d_rot"]
 ASSEMBLE_BWD_TAIL = ["g_means3D", "g_means2D", "g_opacity", "g_scales", "g_rotations", "g_shs", "g_shs_p",
                      "g_xyz", "g_screenspace", "g_opacity_in", "g_scaling", "g_rotation", "g_rotation_raw",
                      "g_feat_color", "g_feat_phasor", "g_d_xyz", "g_d_rot", "g_d_sh", "g_d_sh_p"]
-ASSEMBLE_BWD_FIELDS = ASSEMBLE_BWD_HEAD + ["d_rot_scalar"] + ASSEMBLE_BWD_TAIL
+ASSEMBLE_BWD_RAW = ["opacity_raw", "scaling_raw", "g_feat_dc_color", "g_feat_rest_color", "g_phase_dc", "g_phase_rest", "g_amp_dc", "g_amp_rest"]
+ASSEMBLE_BWD_FIELDS = ASSEMBLE_BWD_HEAD + ["d_rot_scalar"] + ASSEMBLE_BWD_TAIL + ["static_from_raw"] + ASSEMBLE_BWD_RAW
 
 
 class AssembleIO(C.Structure):
     _fields_ = ([(n, _fp) for n in ASSEMBLE_PTRS_IN] + [(n, C.c_float) for n in ASSEMBLE_SCALARS] +
-                [(n, _fp) for n in ASSEMBLE_PTRS_OUT] + [("num_offset_rows", C.c_int64)])
+                [(n, _fp) for n in ASSEMBLE_PTRS_OUT] + [("num_offset_rows", C.c_int64)] +
+                [(n, C.c_int32) for n in ASSEMBLE_RAW_FLAGS] + [(n, _fp) for n in ASSEMBLE_PARTS])
 
 
 class AssembleBwdIO(C.Structure):
     _fields_ = ([(n, _fp) for n in ASSEMBLE_BWD_HEAD] + [("d_rot_scalar", C.c_float)] +
-                [(n, _fp) for n in ASSEMBLE_BWD_TAIL] + [("static_from_raw", C.c_int32)])
+                [(n, _fp) for n in ASSEMBLE_BWD_TAIL] + [("static_from_raw", C.c_int32)] + [(n, _fp) for n in ASSEMBLE_BWD_RAW])
 
 
 class DeformParams(C.Structure):

@@ -202,3 +202,126 @@ def assemble_inputs(xyz, screenspace_points, opacity, scaling, rotation, rotatio
     return _AssembleInputs.apply(xyz, screenspace_points, opacity, scaling, rotation, rotation_raw,
                                  features_color, features_phasor, motion_mask, d_xyz, d_rot, d_sh, d_sh_p,
                                  "static" in render_regions, "dynamic" in render_regions, validate)
+
+
+class _AssembleParameters(torch.autograd.Function):
+    """assemble_inputs over the tensors the model keeps: the activations and concatenations of ``pc.get_*`` are done in the
+    assembly's kernels, forward and backward (include/gftorf_assemble.h: opacity_is_raw, scaling_is_raw, feat_dc_color ...)."""
+
+    @staticmethod
+    def forward(ctx, xyz, screenspace, opacity_raw, scaling_raw, rotation_raw, f_dc, f_rest, phase_dc, phase_rest, amp_dc, amp_rest,
+                motion_mask, d_xyz, d_rot, d_sh, d_sh_p, render_static, render_dynamic):
+        lib = _lib.load()
+        dev = xyz.device
+        if dev.type != "cuda":
+            raise RuntimeError("gftorf_amd.assemble_parameters runs on a HIP device only (xyz is on %s); there is no CPU path" % (dev,))
+        P = xyz.size(0)
+        M, M_p = f_dc.size(1) + f_rest.size(1), phase_dc.size(1) + phase_rest.size(1)
+        if f_dc.size(1) != 1 or phase_dc.size(1) != 1 or amp_dc.size(1) != 1 or amp_dc.size(1) + amp_rest.size(1) != M_p:
+            raise RuntimeError("assemble_parameters: the dc tensors hold one coefficient, phase and amplitude the same number")
+        names = ("xyz", "screenspace_points", "_opacity", "_scaling", "_rotation", "_features_dc_color", "_features_rest_color",
+                 "phase_f_dc", "phase_f_rest", "amp_f_dc", "amp_f_rest")
+        src = [_f32c(t, dev, n) for t, n in zip((xyz, screenspace, opacity_raw, scaling_raw, rotation_raw, f_dc, f_rest, phase_dc,
+                                                 phase_rest, amp_dc, amp_rest), names)]
+        xyz_c, ssp_c, op_c, sc_c, raw_c, fdc_c, frest_c, pdc_c, prest_c, adc_c, arest_c = src
+        if motion_mask.dtype != torch.bool or motion_mask.numel() != P:
+            raise RuntimeError("motion_mask must be a bool tensor with one entry per Gaussian")
+        mask_c = motion_mask.to(dev).contiguous()
+        offs = []
+        for t, n, shape in ((d_xyz, "d_xyz", (3,)), (d_rot, "d_rot", (4,)), (d_sh, "d_sh", (M, 3)), (d_sh_p, "d_sh_p", (M_p, 2))):
+            if _is_tensor(t):
+                if tuple(t.shape[1:]) != shape:
+                    raise RuntimeError("%s has shape %s, expected (num_dynamic, %s)" % (n, tuple(t.shape), ", ".join(map(str, shape))))
+                offs.append(_f32c(t, dev, n))
+            else:
+                offs.append(float(t))
+        rows = {n: v.size(0) for v, n in zip(offs, ("d_xyz", "d_rot", "d_sh", "d_sh_p")) if _is_tensor(v)}
+        if len(set(rows.values())) > 1:
+            raise RuntimeError("shape mismatch: the offset tensors disagree on the number of dynamic Gaussians: %s" % (rows,))
+        n_off = next(iter(rows.values())) if rows else 0
+        if n_off > P:
+            raise RuntimeError("shape mismatch: the offset tensors have %d rows for %d Gaussians" % (n_off, P))
+        f32 = dict(device=dev, dtype=torch.float32)
+        outs = [torch.empty(s, **f32) for s in ((P, 3), (P, 3), tuple(opacity_raw.shape), (P, 3), (P, 4), (P, M, 3), (P, M_p, 2))]
+        scratch = torch.empty((lib.gft_assemble_scratch_bytes(P),), device=dev, dtype=torch.uint8)
+        io = _lib.AssembleIO()
+        io.xyz, io.screenspace, io.opacity, io.scaling, io.rotation_raw = _p(xyz_c), _p(ssp_c), _p(op_c), _p(sc_c), _p(raw_c)
+        io.opacity_is_raw = io.scaling_is_raw = 1
+        io.feat_dc_color, io.feat_rest_color = _p(fdc_c), _p(frest_c)
+        io.phase_dc, io.phase_rest, io.amp_dc, io.amp_rest = _p(pdc_c), _p(prest_c), _p(adc_c), _p(arest_c)
+        io.motion_mask = _p(mask_c)
+        for name, v in zip(("d_xyz", "d_rot", "d_sh", "d_sh_p"), offs):
+            if _is_tensor(v):
+                setattr(io, name, _p(v))
+            else:
+                setattr(io, name + "_scalar", v)
+        io.num_offset_rows = n_off
+        io.scratch = scratch.data_ptr()
+        (io.out_means3D, io.out_means2D, io.out_opacity, io.out_scales, io.out_rotations, io.out_shs, io.out_shs_p) = [_p(t) for t in outs]
+        with _lib.on_device(dev):
+            _lib.check(lib.gft_assemble_forward(_lib.raw_stream(dev), P, M, M_p, int(render_static), int(render_dynamic), C.byref(io)))
+        ctx.sizes = (P, M, M_p, int(render_static), int(render_dynamic))
+        ctx.offs_scalar = [None if _is_tensor(v) else v for v in offs]
+        ctx.off_rows = [v.size(0) if _is_tensor(v) else 0 for v in offs]
+        ctx.shapes = [tuple(t.shape) for t in (opacity_raw, f_dc, f_rest, phase_dc, phase_rest, amp_dc, amp_rest)]
+        ctx.save_for_backward(raw_c, offs[1] if _is_tensor(offs[1]) else raw_c.new_empty(0), scratch, op_c, sc_c)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_means3D, g_means2D, g_opacity, g_scales, g_rotations, g_shs, g_shs_p):
+        lib = _lib.load()
+        raw_c, d_rot_c, scratch, op_c, sc_c = ctx.saved_tensors
+        P, M, M_p, rs, rd = ctx.sizes
+        dev = raw_c.device
+        need = ctx.needs_input_grad
+        f32 = dict(device=dev, dtype=torch.float32)
+        new = lambda want, shape: torch.empty(shape, **f32) if want else None
+        op_shape, fdc_s, frest_s, pdc_s, prest_s, adc_s, arest_s = ctx.shapes
+        g_xyz, g_ssp = new(need[0], (P, 3)), new(need[1], (P, 3))
+        g_op, g_sc, g_raw = new(need[2], op_shape), new(need[3], (P, 3)), new(need[4], (P, 4))
+        g_fdc, g_frest = new(need[5], fdc_s), new(need[6], frest_s)
+        g_pdc, g_prest, g_adc, g_arest = new(need[7], pdc_s), new(need[8], prest_s), new(need[9], adc_s), new(need[10], arest_s)
+        nd = ctx.off_rows
+        g_dxyz = new(need[12] and ctx.offs_scalar[0] is None, (nd[0], 3))
+        g_drot = new(need[13] and ctx.offs_scalar[1] is None, (nd[1], 4))
+        g_dsh = new(need[14] and ctx.offs_scalar[2] is None, (nd[2], M, 3))
+        g_dshp = new(need[15] and ctx.offs_scalar[3] is None, (nd[3], M_p, 2))
+        gc = lambda t, n: None if t is None else _f32c(t, dev, "grad_" + n)
+        gs = [gc(t, n) for t, n in ((g_means3D, "means3D"), (g_means2D, "means2D"), (g_opacity, "opacity"),
+                                    (g_scales, "scales"), (g_rotations, "rotations"), (g_shs, "shs"), (g_shs_p, "shs_p"))]
+        io = _lib.AssembleBwdIO()
+        io.scratch, io.rotation_raw = scratch.data_ptr(), _p(raw_c)
+        if ctx.offs_scalar[1] is None:
+            io.d_rot = _p(d_rot_c)
+        else:
+            io.d_rot_scalar = ctx.offs_scalar[1]
+        (io.g_means3D, io.g_means2D, io.g_opacity, io.g_scales, io.g_rotations, io.g_shs, io.g_shs_p) = [_p(t) for t in gs]
+        io.g_xyz, io.g_screenspace, io.g_opacity_in, io.g_scaling, io.g_rotation_raw = _p(g_xyz), _p(g_ssp), _p(g_op), _p(g_sc), _p(g_raw)
+        io.opacity_raw, io.scaling_raw = _p(op_c), _p(sc_c)
+        io.g_feat_dc_color, io.g_feat_rest_color = _p(g_fdc), _p(g_frest)
+        io.g_phase_dc, io.g_phase_rest, io.g_amp_dc, io.g_amp_rest = _p(g_pdc), _p(g_prest), _p(g_adc), _p(g_arest)
+        io.g_d_xyz, io.g_d_rot, io.g_d_sh, io.g_d_sh_p = _p(g_dxyz), _p(g_drot), _p(g_dsh), _p(g_dshp)
+        io.static_from_raw = 1
+        with _lib.on_device(dev):
+            _lib.check(lib.gft_assemble_backward(_lib.raw_stream(dev), P, M, M_p, rs, rd, C.byref(io)))
+        return (g_xyz, g_ssp, g_op, g_sc, g_raw, g_fdc, g_frest, g_pdc, g_prest, g_adc, g_arest, None, g_dxyz, g_drot, g_dsh, g_dshp,
+                None, None)
+
+
+def assemble_parameters(xyz, screenspace_points, opacity_raw, scaling_raw, rotation_raw, features_dc_color, features_rest_color,
+                        phase_f_dc, phase_f_rest, amp_f_dc, amp_f_rest, motion_mask, d_xyz=0.0, d_rot=0.0, d_sh=0.0, d_sh_p=0.0,
+                        render_regions=("static", "dynamic")):
+    """``assemble_inputs`` fed with the tensors the model keeps instead of the activated ones -- what ``pc.get_opacity``
+    (sigmoid), ``pc.get_scaling`` (exp), ``pc.get_rotation`` (normalize), ``pc.get_features_color`` (cat of dc and rest) and
+    ``pc.get_features_phasor`` (cat of cat) compute (scene/gaussian_model.py:123-153) is done inside the assembly's kernels,
+    forward and backward: the same seven outputs, gradients in the raw tensors' ``.grad``; about twenty-five eager launches per
+    iteration and the activated copies they leave drop out.
+
+        means3D, means2D, opacity, scales, rotations, shs, shs_p = assemble_parameters(
+            pc._xyz, screenspace_points, pc._opacity, pc._scaling, pc._rotation, pc._features_dc_color, pc._features_rest_color,
+            pc.phase_f_dc, pc.phase_f_rest, pc.amp_f_dc, pc.amp_f_rest, pc.get_motion_mask, d_xyz, d_rot, d_sh, d_sh_p, render_regions)
+    """
+    return _AssembleParameters.apply(xyz, screenspace_points, opacity_raw, scaling_raw, rotation_raw, features_dc_color,
+                                     features_rest_color, phase_f_dc, phase_f_rest, amp_f_dc, amp_f_rest, motion_mask, d_xyz, d_rot,
+                                     d_sh, d_sh_p, "static" in render_regions, "dynamic" in render_regions)

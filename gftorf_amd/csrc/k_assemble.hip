@@ -113,6 +113,10 @@ __global__ __launch_bounds__(ASM_RANK_ROWS) void k_assemble_rows(RowsArgs a)
         s2 = make_float3(a.io.screenspace[3 * i], a.io.screenspace[3 * i + 1], a.io.screenspace[3 * i + 2]);
         op = a.io.opacity[i];
         sc = make_float3(a.io.scaling[3 * i], a.io.scaling[3 * i + 1], a.io.scaling[3 * i + 2]);
+        // the model's own tensors: pc.get_opacity = sigmoid(_opacity), pc.get_scaling = exp(_scaling) (scene/gaussian_model.py:
+        // 123-131), in torch's expressions
+        if (a.io.opacity_is_raw) op = 1.0f / (1.0f + expf(-op));
+        if (a.io.scaling_is_raw) sc = make_float3(expf(sc.x), expf(sc.y), expf(sc.z));
         if (oob) {
             const float nan = __builtin_nanf("");
             x = make_float3(nan, nan, nan);
@@ -194,6 +198,78 @@ __global__ __launch_bounds__(ASM_BLOCK) void k_assemble_wide(size_t total_vec, i
     }
 }
 
+// The SH rows read from / handed back to the tensors the model keeps (scene/gaussian_model.py:141-153):
+//   kind 0, colour: cat((dc [P,1,3], rest [P,M-1,3]), dim=1)                           a0 = dc, a1 = rest
+//   kind 1, phasor: cat((cat((phase_dc, phase_rest), 1), cat((amp_dc, amp_rest), 1)), dim=2)  a = phase, b = amp; [P,1,1] / [P,M-1,1]
+template <typename T>
+struct SplitPtrs { T* a0; T* a1; T* b0; T* b1; int M; int kind; };
+template <typename T>
+__device__ __forceinline__ T* split_at(const SplitPtrs<T>& s, size_t row, int c)
+{
+    if (s.kind == 0) return c < 3 ? s.a0 + row * 3 + c : s.a1 + row * (size_t)(3 * (s.M - 1)) + (c - 3);
+    const int k = c >> 1;
+    T* dc = (c & 1) ? s.b0 : s.a0;
+    T* rest = (c & 1) ? s.b1 : s.a1;
+    return k == 0 ? dc + row : rest + row * (size_t)(s.M - 1) + (k - 1);
+}
+
+// k_assemble_wide with the feature row gathered from its parts (VEC floats per thread: 4 when the row allows, else 1)
+template <int VEC>
+__global__ __launch_bounds__(ASM_BLOCK) void k_assemble_wide_split(size_t total_vec, int row_vec, SplitPtrs<const float> f,
+                                                                  const float* __restrict__ d, float d_scalar,
+                                                                  const uint32_t* __restrict__ dyn_rank, int render_static,
+                                                                  int render_dynamic, float* __restrict__ out)
+{
+    const size_t e = (size_t)blockIdx.x * ASM_BLOCK + threadIdx.x;
+    if (e >= total_vec) return;
+    const size_t row = e / (size_t)row_vec;
+    const int col = (int)(e - row * (size_t)row_vec);
+    const uint32_t rank = dyn_rank[row];
+    const bool m = rank != ASM_STATIC;
+    const bool on = m ? render_dynamic != 0 : render_static != 0;
+    float v[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) v[k] = 0.f;
+    if (m && (rank & ASM_OOB)) {              // no row in the offset tensors: see k_assemble_rows
+#pragma unroll
+        for (int k = 0; k < VEC; k++) v[k] = __builtin_nanf("");
+    } else if (on) {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            v[k] = *split_at(f, row, VEC * col + k);
+            if (m) v[k] += d ? d[((size_t)rank * row_vec + col) * VEC + k] : d_scalar;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; k++) out[e * VEC + k] = v[k];
+}
+
+// k_assemble_wide_bwd with the features' gradient scattered to its parts
+template <int VEC>
+__global__ __launch_bounds__(ASM_BLOCK) void k_assemble_wide_bwd_split(size_t total_vec, int row_vec, const float* __restrict__ g,
+                                                                      const uint32_t* __restrict__ dyn_rank, int render_static,
+                                                                      int render_dynamic, SplitPtrs<float> g_f, float* __restrict__ g_d)
+{
+    const size_t e = (size_t)blockIdx.x * ASM_BLOCK + threadIdx.x;
+    if (e >= total_vec) return;
+    const size_t row = e / (size_t)row_vec;
+    const int col = (int)(e - row * (size_t)row_vec);
+    const uint32_t rank_w = dyn_rank[row];
+    const bool oob = rank_w != ASM_STATIC && (rank_w & ASM_OOB);
+    const bool m = rank_w != ASM_STATIC && !oob;
+    const bool on = (rank_w != ASM_STATIC ? render_dynamic != 0 : render_static != 0) && !oob;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+        const float v = (on && g) ? g[e * VEC + k] : 0.f;
+        float* dst = split_at(g_f, row, VEC * col + k);
+        // (a part nobody wants: its base pointer is NULL -- test the base, not the element's address)
+        const float* base = g_f.kind == 0 ? (VEC * col + k < 3 ? g_f.a0 : g_f.a1)
+                                          : (((VEC * col + k) & 1) ? ((VEC * col + k) >> 1 ? g_f.b1 : g_f.b0) : ((VEC * col + k) >> 1 ? g_f.a1 : g_f.a0));
+        if (base) *dst = v;
+        if (m && g_d) g_d[((size_t)rank_w * row_vec + col) * VEC + k] = v;
+    }
+}
+
 struct RowsBwdArgs {
     int P;
     int render_static, render_dynamic;
@@ -243,6 +319,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void k_assemble_rows_bwd(RowsBwdArgs a)
         } else {
             gq = g;
         }
+    }
+    if (on && a.io.opacity_raw) {          // sigmoid_backward: g (1 - y) y
+        const float y = 1.0f / (1.0f + expf(-a.io.opacity_raw[i]));
+        gop = gop * ((1.0f - y) * y);
+    }
+    if (on && a.io.scaling_raw) {          // exp's backward: g y
+        gsc.x *= expf(a.io.scaling_raw[3 * i]); gsc.y *= expf(a.io.scaling_raw[3 * i + 1]); gsc.z *= expf(a.io.scaling_raw[3 * i + 2]);
     }
     if (a.io.g_xyz) { a.io.g_xyz[3 * i] = gx.x; a.io.g_xyz[3 * i + 1] = gx.y; a.io.g_xyz[3 * i + 2] = gx.z; }
     if (a.io.g_screenspace) { a.io.g_screenspace[3 * i] = gs.x; a.io.g_screenspace[3 * i + 1] = gs.y; a.io.g_screenspace[3 * i + 2] = gs.z; }
@@ -343,6 +426,38 @@ int launch_wide_bwd(hipStream_t s, int P, int row_floats, const float* g, const 
     return 0;
 }
 
+int launch_wide_split(hipStream_t s, int P, int row_floats, const SplitPtrs<const float>& f, const float* d, float d_scalar,
+                      const uint32_t* rank, int rs, int rd, float* out)
+{
+    if (!f.a0 || !out || row_floats <= 0 || P <= 0) return 0;
+    if (row_floats % 4 == 0) {
+        const size_t total = (size_t)P * (row_floats / 4);
+        hipLaunchKernelGGL(k_assemble_wide_split<4>, dim3((unsigned)((total + ASM_BLOCK - 1) / ASM_BLOCK)), dim3(ASM_BLOCK), 0, s, total,
+                           row_floats / 4, f, d, d_scalar, rank, rs, rd, out);
+    } else {
+        const size_t total = (size_t)P * row_floats;
+        hipLaunchKernelGGL(k_assemble_wide_split<1>, dim3((unsigned)((total + ASM_BLOCK - 1) / ASM_BLOCK)), dim3(ASM_BLOCK), 0, s, total,
+                           row_floats, f, d, d_scalar, rank, rs, rd, out);
+    }
+    return 0;
+}
+
+int launch_wide_bwd_split(hipStream_t s, int P, int row_floats, const float* g, const uint32_t* rank, int rs, int rd,
+                          const SplitPtrs<float>& g_f, float* g_d)
+{
+    if (row_floats <= 0 || P <= 0) return 0;
+    if (row_floats % 4 == 0) {
+        const size_t total = (size_t)P * (row_floats / 4);
+        hipLaunchKernelGGL(k_assemble_wide_bwd_split<4>, dim3((unsigned)((total + ASM_BLOCK - 1) / ASM_BLOCK)), dim3(ASM_BLOCK), 0, s,
+                           total, row_floats / 4, g, rank, rs, rd, g_f, g_d);
+    } else {
+        const size_t total = (size_t)P * row_floats;
+        hipLaunchKernelGGL(k_assemble_wide_bwd_split<1>, dim3((unsigned)((total + ASM_BLOCK - 1) / ASM_BLOCK)), dim3(ASM_BLOCK), 0, s,
+                           total, row_floats, g, rank, rs, rd, g_f, g_d);
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" size_t gft_assemble_scratch_bytes(int32_t P)
@@ -376,10 +491,15 @@ extern "C" int gft_assemble_forward(void* hip_stream, int32_t P, int32_t M, int3
         !io->out_rotations)
         return gft_fail("gft_assemble_forward: required pointer is NULL");
     // (out_shs / out_shs_p may be NULL with M, M_p > 0: the caller uses the feature tensor itself -- a zero offset, both regions)
-    if ((M > 0) != (io->feat_color != nullptr) || (M == 0 && io->out_shs != nullptr))
+    // (the feature tensors whole, or in the parts the model keeps: gft_assemble_io.feat_dc_color ...)
+    const bool color_parts = !io->feat_color && io->feat_dc_color, phasor_parts = !io->feat_phasor && io->phase_dc;
+    if ((M > 0) != (io->feat_color != nullptr || color_parts) || (M == 0 && io->out_shs != nullptr))
         return gft_fail("gft_assemble_forward: M does not match feat_color / out_shs");
-    if ((M_p > 0) != (io->feat_phasor != nullptr) || (M_p == 0 && io->out_shs_p != nullptr))
+    if ((M_p > 0) != (io->feat_phasor != nullptr || phasor_parts) || (M_p == 0 && io->out_shs_p != nullptr))
         return gft_fail("gft_assemble_forward: M_p does not match feat_phasor / out_shs_p");
+    if (color_parts && M > 1 && !io->feat_rest_color) return gft_fail("gft_assemble_forward: feat_rest_color is NULL with M > 1");
+    if (phasor_parts && (!io->amp_dc || (M_p > 1 && (!io->phase_rest || !io->amp_rest))))
+        return gft_fail("gft_assemble_forward: the phasor features' parts are incomplete");
     if ((io->d_xyz || io->d_rot || io->d_sh || io->d_sh_p) && (io->num_offset_rows < 0 || io->num_offset_rows > P))
         return gft_fail("gft_assemble_forward: the offset tensors have %lld rows for %d Gaussians", (long long)io->num_offset_rows, P);
     hipStream_t s = (hipStream_t)hip_stream;
@@ -396,8 +516,14 @@ extern "C" int gft_assemble_forward(void* hip_stream, int32_t P, int32_t M, int3
     a.dyn_rank = rank;
     a.block_sums = sums;
     hipLaunchKernelGGL(k_assemble_rows, dim3(nrb), dim3(ASM_RANK_ROWS), 0, s, a);
-    launch_wide(s, P, M * 3, io->feat_color, io->d_sh, io->d_sh_scalar, rank, render_static, render_dynamic, io->out_shs);
-    launch_wide(s, P, M_p * 2, io->feat_phasor, io->d_sh_p, io->d_sh_p_scalar, rank, render_static, render_dynamic, io->out_shs_p);
+    if (color_parts)
+        launch_wide_split(s, P, M * 3, SplitPtrs<const float>{io->feat_dc_color, io->feat_rest_color, nullptr, nullptr, M, 0}, io->d_sh,
+                          io->d_sh_scalar, rank, render_static, render_dynamic, io->out_shs);
+    else launch_wide(s, P, M * 3, io->feat_color, io->d_sh, io->d_sh_scalar, rank, render_static, render_dynamic, io->out_shs);
+    if (phasor_parts)
+        launch_wide_split(s, P, M_p * 2, SplitPtrs<const float>{io->phase_dc, io->phase_rest, io->amp_dc, io->amp_rest, M_p, 1}, io->d_sh_p,
+                          io->d_sh_p_scalar, rank, render_static, render_dynamic, io->out_shs_p);
+    else launch_wide(s, P, M_p * 2, io->feat_phasor, io->d_sh_p, io->d_sh_p_scalar, rank, render_static, render_dynamic, io->out_shs_p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gft_fail("gft_assemble_forward: %s", hipGetErrorString(e));
     return 0;
@@ -433,8 +559,14 @@ extern "C" int gft_assemble_backward(void* hip_stream, int32_t P, int32_t M, int
     a.io = *io;
     a.dyn_rank = rank;
     hipLaunchKernelGGL(k_assemble_rows_bwd, dim3((P + ASM_BLOCK - 1) / ASM_BLOCK), dim3(ASM_BLOCK), 0, s, a);
-    launch_wide_bwd(s, P, M * 3, io->g_shs, rank, render_static, render_dynamic, io->g_feat_color, io->g_d_sh);
-    launch_wide_bwd(s, P, M_p * 2, io->g_shs_p, rank, render_static, render_dynamic, io->g_feat_phasor, io->g_d_sh_p);
+    if (io->g_feat_dc_color || io->g_feat_rest_color)
+        launch_wide_bwd_split(s, P, M * 3, io->g_shs, rank, render_static, render_dynamic,
+                              SplitPtrs<float>{io->g_feat_dc_color, io->g_feat_rest_color, nullptr, nullptr, M, 0}, io->g_d_sh);
+    else launch_wide_bwd(s, P, M * 3, io->g_shs, rank, render_static, render_dynamic, io->g_feat_color, io->g_d_sh);
+    if (io->g_phase_dc || io->g_phase_rest || io->g_amp_dc || io->g_amp_rest)
+        launch_wide_bwd_split(s, P, M_p * 2, io->g_shs_p, rank, render_static, render_dynamic,
+                              SplitPtrs<float>{io->g_phase_dc, io->g_phase_rest, io->g_amp_dc, io->g_amp_rest, M_p, 1}, io->g_d_sh_p);
+    else launch_wide_bwd(s, P, M_p * 2, io->g_shs_p, rank, render_static, render_dynamic, io->g_feat_phasor, io->g_d_sh_p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gft_fail("gft_assemble_backward: %s", hipGetErrorString(e));
     return 0;

@@ -64,6 +64,17 @@ typedef struct gft_assemble_io {
      * assignment raises for such shapes -- : nothing is read or written out of bounds, that Gaussian's outputs are
      * NaN and its gradients zero.  gft_assemble_num_dynamic() gives the exact count for a host-side check. */
     int64_t num_offset_rows;
+    /* ---- (round 6) the model's own tensors as sources: what pc.get_* computes from them before render() reads it
+     * (scene/gaussian_model.py:123-153) is then done here, forward and backward -- no eager exp / sigmoid / cat and no
+     * activated copies for the caller.  All zero / NULL: the fields above hold the activated tensors, as before. ---- */
+    int32_t opacity_is_raw;        /* 1: `opacity` holds pc._opacity; used: sigmoid(opacity) = 1 / (1 + exp(-x)) */
+    int32_t scaling_is_raw;        /* 1: `scaling` holds pc._scaling; used: exp(scaling) */
+    const float* feat_dc_color;    /* [P,1,3]     } with feat_color == NULL and M > 0: pc.get_features_color =           */
+    const float* feat_rest_color;  /* [P,M-1,3]   }   cat((dc, rest), dim=1), read from its two parts                     */
+    const float* phase_dc;         /* [P,1,1]     } with feat_phasor == NULL and M_p > 0: pc.get_features_phasor =        */
+    const float* phase_rest;       /* [P,M_p-1,1] }   cat((cat((phase_dc, phase_rest), 1), cat((amp_dc, amp_rest), 1)), 2) */
+    const float* amp_dc;           /* [P,1,1]     }   read from its four parts                                            */
+    const float* amp_rest;         /* [P,M_p-1,1] }                                                                       */
 } gft_assemble_io;
 
 typedef struct gft_assemble_bwd_io {
@@ -98,6 +109,15 @@ typedef struct gft_assemble_bwd_io {
     /* 1 = the forward ran with io.rotation == NULL: the static rows' gradient goes through the normalisation into
      * g_rotation_raw as well (g_rotation, if given, is zeros) */
     int32_t static_from_raw;
+    /* ---- (round 6) a forward over the model's own tensors: the gradients go back through the activations ---- */
+    const float* opacity_raw;      /* [P,1] pc._opacity (the forward ran with opacity_is_raw): g_opacity_in = g sigmoid'(x); NULL: plain */
+    const float* scaling_raw;      /* [P,3] pc._scaling (scaling_is_raw): g_scaling = g exp(x); NULL: plain */
+    float* g_feat_dc_color;        /* [P,1,3]     } the parts' gradients (give them instead of g_feat_color;   */
+    float* g_feat_rest_color;      /* [P,M-1,3]   }  NULL = not wanted)                                         */
+    float* g_phase_dc;             /* [P,1,1]     } (instead of g_feat_phasor)                                  */
+    float* g_phase_rest;           /* [P,M_p-1,1] }                                                             */
+    float* g_amp_dc;               /* [P,1,1]     }                                                             */
+    float* g_amp_rest;             /* [P,M_p-1,1] }                                                             */
 } gft_assemble_bwd_io;
 
 size_t gft_assemble_scratch_bytes(int32_t P);

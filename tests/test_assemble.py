@@ -261,3 +261,60 @@ def test_zero_scalar_offsets_return_the_feature_tensors_themselves(gpu):
     # a region left out: zeros there, so a tensor of its own
     outs = assemble_inputs(xyz, ssp, op, sc, None, raw, fc, fp, mask, 0.0, 0.0, 0.0, 0.0, render_regions=("static",))
     assert outs[6].data_ptr() != fp.data_ptr() and not outs[6][mask].any() and torch.equal(outs[6][~mask], fp.detach()[~mask])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regions", [("static", "dynamic"), ("dynamic",)])
+@pytest.mark.parametrize("offsets", ["tensors", "scalars"])
+def test_assembly_over_the_models_own_tensors(regions, offsets, gpu):
+    """assemble_parameters = assemble_inputs behind pc.get_* (scene/gaussian_model.py:123-153: sigmoid, exp, normalize, the two
+    concatenations), forward and backward, in the assembly's own kernels: the same outputs as the eager statements feeding
+    assemble_inputs (copies and single adds bit for bit, the activations to an ulp) and the same gradients in the raw tensors."""
+    from gftorf_amd import assemble_inputs, assemble_parameters
+    P, M = 3001, 16
+    gen = torch.Generator().manual_seed(9)
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(gpu)
+    mask = (torch.rand(P, generator=gen) < 0.4).to(gpu)
+    nd = int(mask.sum())
+    raw = dict(xyz=rnd(P, 3), opacity=rnd(P, 1), scaling=rnd(P, 3) - 2.0, rotation=rnd(P, 4), f_dc=rnd(P, 1, 3), f_rest=rnd(P, M - 1, 3),
+               phase_dc=rnd(P, 1, 1), phase_rest=rnd(P, M - 1, 1), amp_dc=rnd(P, 1, 1), amp_rest=rnd(P, M - 1, 1))
+    d = [rnd(nd, 3), rnd(nd, 4), rnd(nd, M, 3), rnd(nd, M, 2)] if offsets == "tensors" else [0.0, 0.0, 0.0, 0.0]
+    gout = [rnd(P, 3), rnd(P, 3), rnd(P, 1), rnd(P, 3), rnd(P, 4), rnd(P, M, 3), rnd(P, M, 2)]
+
+    def run(fused):
+        leaves = {k: v.clone().requires_grad_() for k, v in raw.items()}
+        ssp = torch.zeros(P, 3, device=gpu, requires_grad=True)
+        dd = [t.clone().requires_grad_() if torch.is_tensor(t) else t for t in d]
+        if fused:
+            outs = assemble_parameters(leaves["xyz"], ssp, leaves["opacity"], leaves["scaling"], leaves["rotation"], leaves["f_dc"],
+                                       leaves["f_rest"], leaves["phase_dc"], leaves["phase_rest"], leaves["amp_dc"], leaves["amp_rest"],
+                                       mask, *dd, render_regions=regions)
+        else:
+            fc = torch.cat((leaves["f_dc"], leaves["f_rest"]), dim=1)
+            fp = torch.cat((torch.cat((leaves["phase_dc"], leaves["phase_rest"]), dim=1),
+                            torch.cat((leaves["amp_dc"], leaves["amp_rest"]), dim=1)), dim=2)
+            outs = assemble_inputs(leaves["xyz"], ssp, torch.sigmoid(leaves["opacity"]), torch.exp(leaves["scaling"]), None,
+                                   leaves["rotation"], fc, fp, mask, *dd, render_regions=regions)
+        torch.autograd.backward(list(outs), gout)
+        grads = {k: v.grad for k, v in leaves.items()}
+        grads["ssp"] = ssp.grad
+        for i, t in enumerate(dd):
+            if torch.is_tensor(t):
+                grads["d%d" % i] = t.grad
+        return [o.detach() for o in outs], grads
+
+    o_ref, g_ref = run(False)
+    o_got, g_got = run(True)
+    for i, (a, b) in enumerate(zip(o_ref, o_got)):
+        if i in (2, 3):            # opacity, scales: sigmoid / exp (the same expressions as torch's kernels; an ulp for the library calls)
+            torch.testing.assert_close(b, a, rtol=3e-7, atol=0)
+        else:
+            assert torch.equal(b, a), i
+    assert set(g_ref) == set(g_got)
+    for k in g_ref:
+        if g_ref[k] is None:
+            assert g_got[k] is None or not g_got[k].any(), k
+        elif k in ("opacity", "scaling"):
+            torch.testing.assert_close(g_got[k], g_ref[k], rtol=1e-6, atol=1e-30)
+        else:
+            assert torch.equal(g_got[k], g_ref[k]), k
