@@ -199,8 +199,8 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False, graph=False, fused_loss=True,
                 dc_offset=0.0)
         tof = out_t[1][:cfg["num_phasor_channels"]]
         if fused_loss:
-            s_val, l2 = gft_loss.ssim_l2(tof, gt_v)
-            loss = cfg["lambda_tof"] * ((1.0 - cfg["lambda_dssim"]) * l2 + cfg["lambda_dssim"] * (1.0 - s_val))
+            # lambda_tof * ((1 - lambda_dssim) * l2 + lambda_dssim * (1 - ssim)) as one tensor (train.py:196-231)
+            loss = gft_loss.weighted_loss(tof, gt_v, cfg["lambda_tof"] * (1.0 - cfg["lambda_dssim"]), cfg["lambda_tof"] * cfg["lambda_dssim"])
         else:
             l2 = ((tof - gt_v) ** 2).mean()
             loss = cfg["lambda_tof"] * ((1.0 - cfg["lambda_dssim"]) * l2 +

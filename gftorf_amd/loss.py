@@ -68,6 +68,64 @@ class _SsimL2(torch.autograd.Function):
         return grad.view(in_shape), None
 
 
+class _WeightedLoss(torch.autograd.Function):
+    """w_l2 * l2_loss + w_dssim * (1 - ssim) as ONE tensor: the kernels of _SsimL2, the weights folded into the partial sums'
+    combination (one dot product) and into the backward kernel's scales -- none of the eager scalar arithmetic around the two
+    terms (train.py:196-231: five launches forward, six backward)."""
+
+    @staticmethod
+    def forward(ctx, img1, img2, w_l2, w_dssim):
+        lib = _lib.load()
+        a, b = _img(img1, "img1"), _img(img2.detach(), "img2")
+        if a.shape != b.shape or a.device != b.device:
+            raise RuntimeError("gftorf_amd.loss: images differ in shape or device: %s, %s" % (tuple(a.shape), tuple(b.shape)))
+        Cn, H, W = (int(s) for s in a.shape)
+        need_bw = ctx.needs_input_grad[0]
+        blocks = int(lib.gft_ssim_blocks(Cn, H, W))
+        partials = torch.empty((blocks, 2), device=a.device, dtype=torch.float32)
+        maps = torch.empty((3, Cn, H, W), device=a.device, dtype=torch.float32) if need_bw else None
+        a_d = a.detach()
+        with _lib.on_device(a.device):
+            _lib.check(lib.gft_ssim_l2_forward(_lib.raw_stream(a.device), Cn, H, W, a_d.data_ptr(), b.data_ptr(), _WEIGHTS,
+                                               maps.data_ptr() if maps is not None else None, partials.data_ptr()))
+        n = float(Cn * H * W)
+        key = (a.device, blocks, float(w_l2), float(w_dssim), n)
+        wv = _WeightedLoss._weights.get(key)
+        if wv is None:          # (per block: [ssim sum, l2 sum] -> -w_dssim / n, w_l2 / n)
+            if len(_WeightedLoss._weights) > 16:
+                _WeightedLoss._weights.clear()
+            wv = _WeightedLoss._weights[key] = torch.tensor([-float(w_dssim) / n, float(w_l2) / n], device=a.device).repeat(blocks)
+        loss = torch.dot(partials.view(-1), wv) + float(w_dssim)
+        ctx.shape = (Cn, H, W, tuple(img1.shape), float(w_l2), float(w_dssim))
+        if need_bw:
+            ctx.save_for_backward(a_d, b, maps)
+        return loss
+
+    _weights = {}
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b, maps = ctx.saved_tensors
+        Cn, H, W, in_shape, w_l2, w_dssim = ctx.shape
+        grad = torch.empty_like(a)
+        gp = g.detach().float().reshape(1).contiguous()
+        n = float(Cn * H * W)
+        with _lib.on_device(a.device):
+            _lib.check(lib.gft_ssim_l2_backward(_lib.raw_stream(a.device), Cn, H, W, a.data_ptr(), b.data_ptr(), _WEIGHTS,
+                                                maps.data_ptr(), gp.data_ptr(), gp.data_ptr(), -w_dssim / n, w_l2 / n, grad.data_ptr()))
+        return grad.view(in_shape), None, None, None
+
+
+def weighted_loss(img1, img2, w_l2, w_dssim):
+    """``w_l2 * l2_loss(img1, img2) + w_dssim * (1 - ssim(img1, img2))`` -- the combination train.py:196-231 forms from the two
+    terms (``w_l2 = lambda * (1 - lambda_dssim)``, ``w_dssim = lambda * lambda_dssim``) -- as one 0-dim tensor: one launch
+    forward + one dot product, one launch backward."""
+    if isinstance(img2, torch.Tensor) and img2.requires_grad:
+        raise NotImplementedError("gftorf_amd.loss: gradients flow to the first image only")
+    return _WeightedLoss.apply(img1, img2, float(w_l2), float(w_dssim))
+
+
 def ssim_l2(img1, img2):
     """``(ssim(img1, img2), l2_loss(img1, img2))`` of utils/loss_utils.py as two 0-dim tensors from one launch."""
     if isinstance(img2, torch.Tensor) and img2.requires_grad:

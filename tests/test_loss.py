@@ -55,3 +55,27 @@ def test_ssim_l2_matches_the_reference_formulas(shape, gpu):
     a2 = torch.tensor(a_np, device=gpu, requires_grad=True)
     loss.ssim_l2(a2, torch.tensor(b_np, device=gpu))[1].backward()
     np.testing.assert_allclose(a2.grad.cpu().numpy(), 2.0 * (a_np - b_np) / a_np.size, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_weighted_loss_is_the_combination_of_the_two_terms(gpu):
+    """weighted_loss(img, gt, w_l2, w_dssim) = w_l2 * l2 + w_dssim * (1 - ssim) (train.py:196-231's combination) as one tensor:
+    the value and the image gradient of the two-term form, and of the float64 formulas."""
+    from gftorf_amd import loss
+    gen = torch.Generator().manual_seed(21)
+    shape = (2, 96, 128)
+    gt = torch.rand(shape, generator=gen).to(gpu)
+    img0 = (gt.cpu() + 0.1 * torch.randn(shape, generator=gen)).to(gpu)
+    w_l2, w_d = 1.0 * (1.0 - 0.2), 1.0 * 0.2
+    a = img0.clone().requires_grad_()
+    s_val, l2 = loss.ssim_l2(a, gt)
+    two = w_l2 * l2 + w_d * (1.0 - s_val)
+    two.backward()
+    b = img0.clone().requires_grad_()
+    one = loss.weighted_loss(b, gt, w_l2, w_d)
+    assert one.dim() == 0
+    (3.0 * one).backward()          # (an upstream gradient other than 1)
+    torch.testing.assert_close(one, two.detach(), rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(b.grad, 3.0 * a.grad, rtol=2e-5, atol=1e-9)
+    rs, rl = ref_ssim_l2(img0.double().cpu(), gt.double().cpu())
+    assert abs(float(one) - float(w_l2 * rl + w_d * (1 - rs))) < 2e-6
