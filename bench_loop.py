@@ -165,12 +165,17 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False, graph=False, fused_loss=True,
         state["ssim_ok"] = False
     pyrng = random.Random(seed)
 
+    ssp_leaf = torch.zeros((P, 3), device=dev, requires_grad=True)
+
     def body(cc, ct, bg_map, gt_v, tt, degree, net_on):
         """The device work of one iteration on the given camera pair, background, ground truth and time tensor."""
         d_xyz, d_rot, d_sh, d_sh_p = 0.0, 0.0, 0.0, 0.0
         if net_on:                                                   # gaussian_model.py:170-174
             d_xyz, d_rot, d_sh, d_sh_p = net(par["xyz"].detach(), tt, zeros_as_scalars=True)      # (0.0 for the two all-zero offsets, as line above)
-        ssp = torch.zeros((P, 3), device=dev, requires_grad=True)
+        # screenspace_points (gaussian_renderer/__init__.py:52-56): zeros whose only role is to receive a gradient -- the same
+        # leaf every iteration (its values are never written), the last gradient dropped
+        ssp = ssp_leaf
+        ssp.grad = None
         if fused_params:
             # pc.get_* (gaussian_model.py:123-153: exp, normalize, sigmoid, the concatenations of the feature tensors) inside the
             # assembly's kernels, forward and backward: gftorf_amd.assemble_parameters
@@ -258,13 +263,12 @@ def build_loop(dev, cfg=C3, seed=1236, pair=False, graph=False, fused_loss=True,
         rs = torch.random.get_rng_state()
         torch.manual_seed(it)
         if not graph:
-            bg_map = torch.rand((7, H, W), dtype=torch.float32, device=dev) * 2 - 1
+            bg_map = torch.empty((7, H, W), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0)      # = torch.rand(...) * 2 - 1, bit for bit, in one launch
             torch.random.set_rng_state(rs)
             tt = torch.full((1, 1), v / (V - 1), device=dev).expand(P, -1) if net_on else None
             cc, ct = cams[v]
             return body(cc, ct, bg_map, gt[v], tt, state["degree"], net_on)
-        torch.rand((7, H, W), out=s_bg)
-        s_bg.mul_(2).sub_(1)
+        s_bg.uniform_(-1.0, 1.0)
         torch.random.set_rng_state(rs)
         s_row.copy_(table[v])
         s_gt.copy_(gt_all[v])
