@@ -141,9 +141,9 @@ EXPORTS = [
     "gft_assemble_scratch_bytes", "gft_assemble_forward", "gft_assemble_num_dynamic", "gft_assemble_backward",
     "gft_knn_scratch_bytes", "gft_knn_mean_dist2", "gft_adam_step", "gft_adam_step_multi", "gft_adam_step_rows", "gft_adam_step_multi_dev",
     "gft_deform_inputs", "gft_deform_packed_bytes", "gft_deform_saved_bytes", "gft_deform_scratch_bytes", "gft_deform_pack",
-    "gft_deform_forward", "gft_deform_backward", "gft_deform_compact",
+    "gft_deform_forward", "gft_deform_backward", "gft_deform_compact", "gft_deform_rows_work_bytes", "gft_deform_backward_rows",
     "gft_ssim_blocks", "gft_ssim_l2_forward", "gft_ssim_l2_backward",
-    "gft_densify_stats", "gft_rows_rank_scratch_bytes", "gft_rows_rank", "gft_rows_gather", "gft_rows_any_nonzero",
+    "gft_densify_stats", "gft_rows_rank_scratch_bytes", "gft_rows_rank", "gft_rows_rank_dev", "gft_rows_gather", "gft_rows_any_nonzero",
 ]
 
 
@@ -218,6 +218,11 @@ def load():
                                         C.POINTER(DeformParams)]
     lib.gft_deform_compact.restype = C.c_int
     lib.gft_deform_compact.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 9
+    lib.gft_deform_rows_work_bytes.restype = C.c_size_t
+    lib.gft_deform_rows_work_bytes.argtypes = [C.c_int64]
+    lib.gft_deform_backward_rows.restype = C.c_int
+    lib.gft_deform_backward_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.POINTER(DeformParams), C.c_void_p]
     lib.gft_ssim_blocks.restype = C.c_int64
     lib.gft_ssim_blocks.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.gft_ssim_l2_forward.restype = C.c_int
@@ -232,6 +237,8 @@ def load():
     lib.gft_rows_rank_scratch_bytes.argtypes = [C.c_int64]
     lib.gft_rows_rank.restype = C.c_int
     lib.gft_rows_rank.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.gft_rows_rank_dev.restype = C.c_int
+    lib.gft_rows_rank_dev.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gft_rows_any_nonzero.restype = C.c_int
     lib.gft_rows_any_nonzero.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.gft_rows_gather.restype = C.c_int

@@ -10,6 +10,7 @@
 // weight-gradient kernel reads both operands straight from global memory.
 #include "gft_internal.h"
 #include "gftorf_deform.h"
+#include "gftorf_densify.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -274,9 +275,23 @@ __device__ __forceinline__ int acc_col4(int g, int hh) { return 8 * g + 4 * hh; 
 __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
 // ---------------------------------------------------------------------------------------------
+// Point counts that only the device knows (gft_deform_backward_rows: the rows with an upstream gradient are counted by a
+// kernel and nothing is read back, so the call can be captured in a HIP graph).  The launches are sized for the capacity
+// (every buffer keeps the capacity's plane stride, `n_pad` of the argument structs); a kernel that is handed a plan takes
+// its extents from it and its surplus workgroups return at once.  Written by k_deform_plan.
+// ---------------------------------------------------------------------------------------------
+struct DevPlan {
+    int64_t n;              // points
+    int64_t n_ext;          // points padded to DF_PAD: the rows the walks compute and the weight-gradient sums run over
+    int tiles_per_split;    // dw_splits() of n_ext
+    int splits;
+};
+
+// ---------------------------------------------------------------------------------------------
 // forward walk
 // ---------------------------------------------------------------------------------------------
 struct FwdArgs {
+    const DevPlan* plan;    // NULL: n is the host's
     int64_t n, n_pad, t_stride;
     int xm, tm;       // octaves of the xyz / t encodings (time_utils.py:64-65)
     const float* xyz; const float* t;
@@ -298,6 +313,10 @@ template <bool SAVE>
 __global__ __launch_bounds__(256) void k_deform_fwd(FwdArgs a)
 {
     extern __shared__ float4 df_lds[];
+    if (a.plan) {      // counts the device keeps (DevPlan): the launch is the capacity's, surplus workgroups return
+        if ((int64_t)blockIdx.x * (32 * DF_NR_FWD) >= a.plan->n_ext) return;
+        a.n = a.plan->n;
+    }
     float* hA = reinterpret_cast<float*>(df_lds);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * (32 * DF_NR_FWD);
@@ -589,6 +608,10 @@ __global__ __launch_bounds__(64 * DF_FWD_WAVES) void k_deform_fwd_bf(FwdArgs a)
 {
     extern __shared__ float4 df_lds[];
     if (a.only_if != 0u && !fp16_walk_gave_up(a.packed, a.only_if)) return;
+    if (a.plan) {      // counts the device keeps (DevPlan): the launch is the capacity's, surplus workgroups return
+        if ((int64_t)blockIdx.x * 64 >= a.plan->n_ext) return;
+        a.n = a.plan->n;
+    }
     char* hP = reinterpret_cast<char*>(df_lds);                  // activation planes [3][64][264] bf16
     char* eP = hP + 3 * DF_BF_ACT_PLANE;                         // encoding planes   [3][64][88]  bf16
     float* bL = reinterpret_cast<float*>(eP + 3 * DF_BF_ENC_PLANE);
@@ -1042,6 +1065,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     extern __shared__ float4 df_lds[];
     // a weight outside the planes' range: the bf16 walk launched behind this one does the work
     if (__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.packed + DF_FLAG_OFF)) != 0u) return;
+    if (a.plan) {      // counts the device keeps (DevPlan): the launch is the capacity's, surplus workgroups return
+        if ((int64_t)blockIdx.x * 64 >= a.plan->n_ext) return;
+        a.n = a.plan->n;
+    }
     float top = 0.f;                   // largest scaled value this lane has split into the planes
     bool bad = false;                  // an encoded input that is NaN or beyond the planes' range
     constexpr bool ENC_LDS = !SAVE;
@@ -1266,6 +1293,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // backward walk: dz_l = dh_l * [act_l > 0], dh_{l-1} = dz_l W_l
 // ---------------------------------------------------------------------------------------------
 struct BwdArgs {
+    const DevPlan* plan;    // NULL: n is the host's
     int64_t n, n_pad;
     const float* packed;
     const uint32_t* signs;  // [8][n_pad][8]
@@ -1280,6 +1308,10 @@ struct BwdArgs {
 __global__ __launch_bounds__(256) void k_deform_bwd(BwdArgs a)
 {
     extern __shared__ float4 df_lds[];
+    if (a.plan) {      // counts the device keeps (DevPlan): the launch is the capacity's, surplus workgroups return
+        if ((int64_t)blockIdx.x * (32 * DF_NR_BWD) >= a.plan->n_ext) return;
+        a.n = a.plan->n;
+    }
     float* gA = reinterpret_cast<float*>(df_lds);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * (32 * DF_NR_BWD);
@@ -1354,6 +1386,10 @@ __global__ __launch_bounds__(64 * DF_BWD_WAVES) void k_deform_bwd_bf(BwdArgs a)
 {
     extern __shared__ float4 df_lds[];
     if (a.only_if_wflag && __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.packed + DF_FLAG_OFF)) == 0u) return;
+    if (a.plan) {      // counts the device keeps (DevPlan): the launch is the capacity's, surplus workgroups return
+        if ((int64_t)blockIdx.x * 64 >= a.plan->n_ext) return;
+        a.n = a.plan->n;
+    }
     char* gP = reinterpret_cast<char*>(df_lds);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * 64;
@@ -1470,6 +1506,10 @@ __global__ __launch_bounds__(64 * DF_BWD_WAVES) __attribute__((amdgpu_waves_per_
     static_assert(NT == 256, "the head tile's rows are read by 16 consecutive lanes each");
     const int n0 = wave * 32 * NC;
     if (blockIdx.x == 0 && tid == 0) a.xflag[0] = 0u;
+    if (a.plan) {      // counts the device keeps (DevPlan): the launch is the capacity's, surplus workgroups return
+        if ((int64_t)blockIdx.x * 64 >= a.plan->n_ext) return;
+        a.n = a.plan->n;
+    }
     const __amdgpu_buffer_rsrc_t rw = buf_rsrc(a.packed + DF_PACKED_FLOATS + DF_BF_FLOATS, (uint32_t)DF_H_FLOATS * 4u);
     WSegH seg = wseg_h(10, n0 + li, hh);
     uint4 wcur[2][NC], wnx1[2][NC], wnx2[2][NC];
@@ -1614,7 +1654,9 @@ constexpr int64_t DW_OFF_BIAS = DW_OFF_HEAD + (int64_t)DF_HEAD * DF_W;   // [8][
 constexpr int64_t DW_PART_FLOATS = DW_OFF_BIAS + DF_D * DF_W + DF_HEAD;
 
 struct DwArgs {
-    int64_t n_pad;
+    const DevPlan* plan;    // NULL: the extent is n_pad, the splits are the host's
+    int64_t n_pad;          // plane stride of acts / dz / rowmax (the capacity's under a plan)
+    int64_t n_ext;          // rows the sums run over (= n_pad without a plan)
     int tiles_per_split;    // 64-point tiles per split
     int splits;
     int first_block;        // the launch covers workgroups first_block ... of the job table (heavy jobs, then light ones)
@@ -2175,10 +2217,14 @@ __global__ __launch_bounds__(256) void k_deform_dw_h(DwArgs a)
     if (__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.packed + DF_FLAG_OFF)) != 0u) return;
     const int wg = (int)blockIdx.x;
     const int job = wg % 7, split = wg / 7;
+    if (a.plan) {      // counts the device keeps (DevPlan): the launch is the capacity's, surplus workgroups return
+        if (split >= a.plan->splits) return;
+        a.tiles_per_split = a.plan->tiles_per_split; a.n_ext = a.plan->n_ext;
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t p_begin = (int64_t)split * a.tiles_per_split * DF_DW_TILE;
     int64_t p_end = p_begin + (int64_t)a.tiles_per_split * DF_DW_TILE;
-    if (p_end > a.n_pad) p_end = a.n_pad;
+    if (p_end > a.n_ext) p_end = a.n_ext;
     float* part = a.part + (int64_t)split * DW_PART_FLOATS;
     const int64_t plane = a.n_pad * DF_W;
     const int l = 7 - job;
@@ -2192,6 +2238,10 @@ __global__ __launch_bounds__(256) void k_deform_dw_bf(DwArgs a)
         __hip_atomic_load(a.xflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
         return;
     int job, split;
+    if (a.plan) {      // counts the device keeps (DevPlan): the launch is the capacity's, surplus workgroups return below
+        a.splits = a.plan->splits; a.tiles_per_split = a.plan->tiles_per_split; a.n_ext = a.plan->n_ext;
+        if (a.first_block) a.first_block = 7 * a.splits;      // (the light jobs' launch: behind the heavy jobs of THESE splits)
+    }
     const int wg = (int)blockIdx.x + a.first_block;
     if (wg < 7 * a.splits) {
         job = wg % 7;
@@ -2201,10 +2251,11 @@ __global__ __launch_bounds__(256) void k_deform_dw_bf(DwArgs a)
         job = 7 + r % 3;
         split = r / 3;
     }
+    if (split >= a.splits) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int64_t p_begin = (int64_t)split * a.tiles_per_split * DF_DW_TILE;
     int64_t p_end = p_begin + (int64_t)a.tiles_per_split * DF_DW_TILE;
-    if (p_end > a.n_pad) p_end = a.n_pad;
+    if (p_end > a.n_ext) p_end = a.n_ext;
     float* part = a.part + (int64_t)split * DW_PART_FLOATS;
     const int64_t plane = a.n_pad * DF_W;
     if (job < 7) {
@@ -2229,6 +2280,7 @@ __global__ __launch_bounds__(256) void k_deform_dw(DwArgs a)
     // heavy jobs first: the 7 hidden-layer GEMMs of every split (7 x splits workgroups, one resident per CU at
     // a time), then the three light jobs, which fill the CUs as they run out of heavy ones
     int job, split;
+    if (a.plan) { a.splits = a.plan->splits; a.tiles_per_split = a.plan->tiles_per_split; a.n_ext = a.plan->n_ext; }
     if ((int)blockIdx.x < 7 * a.splits) {
         job = blockIdx.x % 7;
         split = blockIdx.x / 7;
@@ -2237,10 +2289,11 @@ __global__ __launch_bounds__(256) void k_deform_dw(DwArgs a)
         job = 7 + r % 3;
         split = r / 3;
     }
+    if (split >= a.splits) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int64_t p_begin = (int64_t)split * a.tiles_per_split * DF_DW_TILE;
     int64_t p_end = p_begin + (int64_t)a.tiles_per_split * DF_DW_TILE;
-    if (p_end > a.n_pad) p_end = a.n_pad;
+    if (p_end > a.n_ext) p_end = a.n_ext;
     float* part = a.part + (int64_t)split * DW_PART_FLOATS;
     const int64_t plane = a.n_pad * DF_W;
     if (job < 7) {
@@ -2271,6 +2324,7 @@ struct ReduceSeg {
 };
 constexpr int DF_MAX_SEGS = 32;
 struct ReduceArgs {
+    const DevPlan* plan;    // NULL: splits is the host's
     const float* part;
     int splits, nseg;
     ReduceSeg seg[DF_MAX_SEGS];
@@ -2279,25 +2333,26 @@ struct ReduceArgs {
 __global__ __launch_bounds__(256) void k_deform_reduce(ReduceArgs a)
 {
     const ReduceSeg& sg = a.seg[blockIdx.y];
+    const int splits = a.plan ? a.plan->splits : a.splits;      // (DevPlan: the splits that ran)
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (int64_t)sg.rows * sg.cols) return;
     const int row = (int)(e / sg.cols), col = (int)(e - (int64_t)row * sg.cols);
     const float* src = a.part + sg.src_off + (int64_t)(row * sg.row_mul + sg.row_add) * sg.src_ld + col;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int s = 0;
-    for (; s + 4 <= a.splits; s += 4) {
+    for (; s + 4 <= splits; s += 4) {
         s0 += src[(int64_t)s * DW_PART_FLOATS];
         s1 += src[(int64_t)(s + 1) * DW_PART_FLOATS];
         s2 += src[(int64_t)(s + 2) * DW_PART_FLOATS];
         s3 += src[(int64_t)(s + 3) * DW_PART_FLOATS];
     }
-    for (; s < a.splits; s++) s0 += src[(int64_t)s * DW_PART_FLOATS];
+    for (; s < splits; s++) s0 += src[(int64_t)s * DW_PART_FLOATS];
     sg.dst[(int64_t)row * sg.dst_ld + sg.dst_col0 + col] = (s0 + s1) + (s2 + s3);
 }
 
-int64_t pad_points(int64_t n) { return (n + DF_PAD - 1) / DF_PAD * DF_PAD; }
+__host__ __device__ int64_t pad_points(int64_t n) { return (n + DF_PAD - 1) / DF_PAD * DF_PAD; }
 
-int dw_splits(int64_t n_pad, int* tiles_per_split)
+__host__ __device__ int dw_splits(int64_t n_pad, int* tiles_per_split)
 {
     const int64_t tiles = n_pad / DF_DW_TILE;
     // 7 heavy jobs per split: 73 splits = 511 workgroups = 2 per CU (measured at 300 k points against 146 / 109 splits:
@@ -2389,6 +2444,21 @@ __global__ __launch_bounds__(256) void k_deform_compact_grads(int64_t k, const i
     else if (gs) gs_c[r * 48 + (c - 3)] = gs[row * 48 + (c - 3)];
 }
 
+// gft_deform_backward_rows: the plan of the launches behind it, from the row count a kernel left on the device
+__global__ void k_deform_plan(const uint32_t* __restrict__ count, int64_t cap, DevPlan* __restrict__ plan, uint32_t* __restrict__ rows_out)
+{
+    int64_t k = (int64_t)*count;
+    if (k > cap) k = cap;
+    if (rows_out) *rows_out = (uint32_t)k;
+    DevPlan p;
+    p.n = k;
+    p.n_ext = pad_points(k);
+    p.tiles_per_split = 1;
+    p.splits = 0;
+    if (k > 0) p.splits = dw_splits(p.n_ext, &p.tiles_per_split);
+    *plan = p;
+}
+
 }  // namespace
 
 
@@ -2448,8 +2518,9 @@ extern "C" int gft_deform_pack(void* hip_stream, int xyz_multires, int t_multire
     return 0;
 }
 
-extern "C" int gft_deform_forward(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const float* xyz, const float* t,
-                                  int64_t t_stride, const void* packed, void* saved, float* d_xyz, float* d_sh)
+// (plan != NULL: n is the capacity -- the launch's size and the buffers' plane stride --, the kernels take the point count from the plan)
+static int deform_forward_impl(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const float* xyz, const float* t,
+                               int64_t t_stride, const void* packed, void* saved, float* d_xyz, float* d_sh, const DevPlan* plan)
 {
     if (n < 0) return gft_fail("gft_deform_forward: n < 0");
     if (arch_inputs(xyz_multires, t_multires) < 0)
@@ -2461,6 +2532,7 @@ extern "C" int gft_deform_forward(void* hip_stream, int xyz_multires, int t_mult
     if (n > ((int64_t)1 << 31) * 16) return gft_fail("gft_deform_forward: n too large");
     GFT_CHECK_HIP(set_attrs());
     FwdArgs a;
+    a.plan = plan;
     a.n = n;
     a.n_pad = pad_points(n);
     a.t_stride = t_stride;
@@ -2502,9 +2574,15 @@ extern "C" int gft_deform_forward(void* hip_stream, int xyz_multires, int t_mult
     return 0;
 }
 
-extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const void* packed,
-                                   const void* saved, const float* g_d_xyz, const float* g_d_sh, void* scratch,
-                                   const gft_deform_grads* g)
+extern "C" int gft_deform_forward(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const float* xyz, const float* t,
+                                  int64_t t_stride, const void* packed, void* saved, float* d_xyz, float* d_sh)
+{
+    return deform_forward_impl(hip_stream, xyz_multires, t_multires, n, xyz, t, t_stride, packed, saved, d_xyz, d_sh, nullptr);
+}
+
+static int deform_backward_impl(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const void* packed,
+                                const void* saved, const float* g_d_xyz, const float* g_d_sh, void* scratch,
+                                const gft_deform_grads* g, const DevPlan* plan)
 {
     if (n < 0) return gft_fail("gft_deform_backward: n < 0");
     const int DF_IN = arch_inputs(xyz_multires, t_multires);
@@ -2548,6 +2626,7 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
     const bool h_planes = bf16_planes() && fp16_backward();
     {
         BwdArgs a;
+        a.plan = plan;
         a.n = n; a.n_pad = n_pad;
         a.packed = (const float*)packed;
         a.signs = reinterpret_cast<const uint32_t*>(acts + n_pad * DF_D * DF_W);
@@ -2567,7 +2646,8 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
     }
     {
         DwArgs a;
-        a.n_pad = n_pad;
+        a.plan = plan;
+        a.n_pad = n_pad; a.n_ext = n_pad;
         a.tiles_per_split = tps;
         a.splits = splits;
         a.emb = emb; a.acts = acts; a.dz = dz; a.dzh = dzh;
@@ -2605,6 +2685,7 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
     }
     {
         ReduceArgs a;
+        a.plan = plan;
         a.part = part;
         a.splits = splits;
         int k = 0;
@@ -2639,6 +2720,13 @@ extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_mul
     return 0;
 }
 
+extern "C" int gft_deform_backward(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const void* packed,
+                                   const void* saved, const float* g_d_xyz, const float* g_d_sh, void* scratch,
+                                   const gft_deform_grads* g)
+{
+    return deform_backward_impl(hip_stream, xyz_multires, t_multires, n, packed, saved, g_d_xyz, g_d_sh, scratch, g, nullptr);
+}
+
 extern "C" int gft_deform_compact(void* hip_stream, int64_t n, int64_t k, const uint8_t* mask, const int32_t* rank, const void* saved,
                                   const float* g_d_xyz, const float* g_d_sh, int32_t* idx, void* saved_c, float* g_d_xyz_c,
                                   float* g_d_sh_c)
@@ -2664,4 +2752,77 @@ extern "C" int gft_deform_compact(void* hip_stream, int64_t n, int64_t k, const 
         hipLaunchKernelGGL(k_deform_compact_grads, dim3((unsigned)((k * 51 + 255) / 256)), dim3(256), 0, s, k, idx, g_d_xyz, g_d_sh, g_d_xyz_c, g_d_sh_c);
     GFT_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+// ---- backward over the rows with an upstream gradient, counted on the device (nothing is read back: capturable) ----------
+namespace {
+struct RowsWork {      // byte offsets into the caller's work buffer (all multiples of 256)
+    size_t plan, count, rank_scratch, mask, rank, xs, ts, gx, gs, dx, ds, saved, scratch, total;
+};
+RowsWork rows_work(int64_t n)
+{
+    RowsWork w;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+    w.plan = take(sizeof(DevPlan));
+    w.count = take(sizeof(uint32_t));
+    w.rank_scratch = take(gft_rows_rank_scratch_bytes(n));
+    w.mask = take((size_t)n);
+    w.rank = take((size_t)n * 4);
+    w.xs = take((size_t)n * 12);
+    w.ts = take((size_t)n * 4);
+    w.gx = take((size_t)n * 12);
+    w.gs = take((size_t)n * 192);
+    w.dx = take((size_t)n * 12);
+    w.ds = take((size_t)n * 192);
+    w.saved = take(gft_deform_saved_bytes(n));
+    w.scratch = take(gft_deform_scratch_bytes(n));
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t gft_deform_rows_work_bytes(int64_t n) { return n <= 0 ? 0 : rows_work(n).total; }
+
+extern "C" int gft_deform_backward_rows(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const void* packed,
+                                        const float* xyz, const float* t, int64_t t_stride, const float* g_d_xyz,
+                                        const float* g_d_sh, void* work, const gft_deform_grads* g, uint32_t* rows_out)
+{
+    if (n < 0) return gft_fail("gft_deform_backward_rows: n < 0");
+    if (n == 0 || (!g_d_xyz && !g_d_sh)) {      // no row has a gradient: the dense entry's zero fill
+        if (rows_out) GFT_CHECK_HIP(gft_zero_async(rows_out, sizeof(uint32_t), (hipStream_t)hip_stream));
+        return deform_backward_impl(hip_stream, xyz_multires, t_multires, 0, packed, nullptr, nullptr, nullptr, nullptr, g, nullptr);
+    }
+    if (n > 0x7fffffffll) return gft_fail("gft_deform_backward_rows: n too large");
+    if (!packed || !xyz || !t || !work) return gft_fail("gft_deform_backward_rows: NULL argument");
+    if (t_stride != 0 && t_stride != 1) return gft_fail("gft_deform_backward_rows: t_stride must be 0 or 1");
+    if (((uintptr_t)work & 255) != 0) return gft_fail("gft_deform_backward_rows: work must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)hip_stream;
+    const RowsWork w = rows_work(n);
+    char* base = (char*)work;
+    DevPlan* plan = reinterpret_cast<DevPlan*>(base + w.plan);
+    uint32_t* count = reinterpret_cast<uint32_t*>(base + w.count);
+    uint8_t* mask = reinterpret_cast<uint8_t*>(base + w.mask);
+    int32_t* rank = reinterpret_cast<int32_t*>(base + w.rank);
+    float* xs = reinterpret_cast<float*>(base + w.xs);
+    float* ts = reinterpret_cast<float*>(base + w.ts);
+    float* gx = reinterpret_cast<float*>(base + w.gx);
+    float* gs = reinterpret_cast<float*>(base + w.gs);
+    // which rows, their output rows, how many (on the device), the plan of everything behind
+    if (gft_rows_any_nonzero(s, n, g_d_xyz ? 3 : 0, g_d_xyz, g_d_sh ? 48 : 0, g_d_sh, mask)) return 1;
+    if (gft_rows_rank_dev(s, n, mask, rank, base + w.rank_scratch, count)) return 1;
+    hipLaunchKernelGGL(k_deform_plan, dim3(1), dim3(1), 0, s, count, n, plan, rows_out);
+    GFT_CHECK_HIP(hipGetLastError());
+    // the selected rows' inputs and upstream gradients, in row order (dst[rank[i]] = src[i])
+    if (gft_rows_gather(s, n, mask, rank, xyz, xs, 12)) return 1;
+    if (t_stride == 1 && gft_rows_gather(s, n, mask, rank, t, ts, 4)) return 1;
+    if (g_d_xyz && gft_rows_gather(s, n, mask, rank, g_d_xyz, gx, 12)) return 1;
+    if (g_d_sh && gft_rows_gather(s, n, mask, rank, g_d_sh, gs, 192)) return 1;
+    // their activations from a saving forward over them alone (a point's activations do not depend on its batch), then the
+    // backward over them; launches of the capacity, extents from the plan
+    if (deform_forward_impl(s, xyz_multires, t_multires, n, xs, t_stride == 1 ? ts : t, t_stride, packed, base + w.saved,
+                            reinterpret_cast<float*>(base + w.dx), reinterpret_cast<float*>(base + w.ds), plan))
+        return 1;
+    return deform_backward_impl(s, xyz_multires, t_multires, n, packed, base + w.saved, g_d_xyz ? gx : nullptr, g_d_sh ? gs : nullptr,
+                                base + w.scratch, g, plan);
 }

@@ -154,6 +154,23 @@ extern "C" size_t gft_rows_rank_scratch_bytes(int64_t P)
     return (size_t)(blocks + 64) * sizeof(uint32_t);
 }
 
+// the three launches of a ranking; the count stays on the device (*total_dev; NULL: behind the block sums in scratch)
+static int rows_rank_launch(hipStream_t s, int64_t P, const uint8_t* mask, int32_t* rank, void* scratch, uint32_t* total_dev,
+                            uint32_t** total_at)
+{
+    const int blocks = (int)((P + RK_ROWS - 1) / RK_ROWS);
+    RankArgs a;
+    a.P = P; a.mask = mask; a.rank = rank;
+    a.block_sum = (uint32_t*)scratch;
+    a.total = total_dev ? total_dev : a.block_sum + blocks;
+    hipLaunchKernelGGL(k_rows_count, dim3(blocks), dim3(DN_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, s, a.block_sum, blocks, a.total);
+    hipLaunchKernelGGL(k_rows_rank, dim3(blocks), dim3(DN_BLOCK), 0, s, a);
+    GFT_CHECK_HIP(hipGetLastError());
+    if (total_at) *total_at = a.total;
+    return 0;
+}
+
 extern "C" int gft_rows_rank(void* hip_stream, int64_t P, const uint8_t* mask, int32_t* rank, void* scratch, int64_t* count)
 {
     if (!count) return gft_fail("gft_rows_rank: count is NULL");
@@ -162,20 +179,21 @@ extern "C" int gft_rows_rank(void* hip_stream, int64_t P, const uint8_t* mask, i
     if (P == 0) return 0;
     if (!mask || !rank || !scratch) return gft_fail("gft_rows_rank: NULL argument");
     hipStream_t s = (hipStream_t)hip_stream;
-    const int blocks = (int)((P + RK_ROWS - 1) / RK_ROWS);
-    RankArgs a;
-    a.P = P; a.mask = mask; a.rank = rank;
-    a.block_sum = (uint32_t*)scratch;
-    a.total = a.block_sum + blocks;
-    hipLaunchKernelGGL(k_rows_count, dim3(blocks), dim3(DN_BLOCK), 0, s, a);
-    hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, s, a.block_sum, blocks, a.total);
-    hipLaunchKernelGGL(k_rows_rank, dim3(blocks), dim3(DN_BLOCK), 0, s, a);
-    GFT_CHECK_HIP(hipGetLastError());
+    uint32_t* total = nullptr;
+    if (rows_rank_launch(s, P, mask, rank, scratch, nullptr, &total)) return 1;
     uint32_t host = 0;
-    GFT_CHECK_HIP(hipMemcpyAsync(&host, a.total, sizeof(host), hipMemcpyDeviceToHost, s));
+    GFT_CHECK_HIP(hipMemcpyAsync(&host, total, sizeof(host), hipMemcpyDeviceToHost, s));
     GFT_CHECK_HIP(hipStreamSynchronize(s));
     *count = host;
     return 0;
+}
+
+extern "C" int gft_rows_rank_dev(void* hip_stream, int64_t P, const uint8_t* mask, int32_t* rank, void* scratch, uint32_t* count_dev)
+{
+    if (!count_dev) return gft_fail("gft_rows_rank_dev: count_dev is NULL");
+    if (P <= 0 || P > 0x7fffffffll) return gft_fail("gft_rows_rank_dev: bad row count");
+    if (!mask || !rank || !scratch) return gft_fail("gft_rows_rank_dev: NULL argument");
+    return rows_rank_launch((hipStream_t)hip_stream, P, mask, rank, scratch, count_dev, nullptr);
 }
 
 // mask[i] = 1 if row i of `a` ([P, ra] floats) or of `b` ([P, rb] floats) holds a value that is not zero (NaN counts,

@@ -52,6 +52,16 @@ import os as _os
 lazy_save = _os.environ.get("GFT_DEFORM_LAZY_SAVE", "1") != "0"
 _LAZY_MAX_FRACTION = 0.25        # recomputing that share of the rows costs less than saving all of them
 
+# Rows counted on the device.  The row selection above reads a count back (one blocking read, as the reference's `t[mask]`
+# has), which a stream that is being captured into a HIP graph cannot do.  ``gft_deform_backward_rows`` keeps the count on the
+# device: the forward keeps nothing, the backward marks, ranks and counts the rows with a gradient by kernels, gathers their
+# inputs, recomputes their activations and runs over them -- launches of the capacity whose surplus workgroups return at
+# once.  A captured iteration replayed on other gradients adapts to THEIR rows (the C3 loop from a graph: the backward
+# follows the share of Gaussians a pixel blends, 58 % -> 23 % over the run, instead of staying dense).  Gradients are those of
+# the blocking selection bit for bit (tests/test_deform.py).  "capture" (default): under capture only; True: always (no
+# blocking read in the eager loop either); False: never (a captured call saves its activations and runs dense).
+device_row_count = {"0": False, "1": True}.get(_os.environ.get("GFT_DEFORM_DEVICE_ROWS", ""), "capture")
+
 
 def _param_list(mod):
     ps = []
@@ -109,8 +119,10 @@ class _DeformFn(torch.autograd.Function):
         # reads a row count, so a captured call saves its activations and runs the dense backward -- the same gradients up
         # to summation order)
         capturing = torch.cuda.is_current_stream_capturing()
+        dev_rows = bool(need_bw and sparse_backward and n >= _SPARSE_MIN_POINTS
+                        and (device_row_count is True or (device_row_count == "capture" and capturing)))
         lazy = bool(need_bw and lazy_save and sparse_backward and n >= _SPARSE_MIN_POINTS and state is not None
-                    and state.get("fraction") is not None and state["fraction"] <= _LAZY_MAX_FRACTION and not capturing)
+                    and state.get("fraction") is not None and state["fraction"] <= _LAZY_MAX_FRACTION and not capturing) or dev_rows
         f32 = dict(device=dev, dtype=torch.float32)
         packed = torch.empty((lib.gft_deform_packed_bytes() // 4,), **f32)
         d_xyz = torch.empty((n, 3), **f32)
@@ -127,6 +139,7 @@ class _DeformFn(torch.autograd.Function):
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.state = state
         ctx.lazy = lazy
+        ctx.dev_rows = dev_rows
         if lazy:
             ctx.t_stride = t_stride
             ctx.save_for_backward(packed, x_c, t_c)
@@ -161,6 +174,17 @@ class _DeformFn(torch.autograd.Function):
         gs = g_dsh.float().contiguous() if g_dsh is not None else None
         last_backward_stats.update(points=n, points_processed=n, recomputed=ctx.lazy)
         n_all = n
+        if ctx.dev_rows:
+            # rows counted on the device: one call, nothing read back (capturable)
+            work = torch.empty((lib.gft_deform_rows_work_bytes(n) // 4,), **f32)
+            rows = torch.empty((1,), device=dev, dtype=torch.int32)
+            ptr = lambda t_: t_.data_ptr() if t_ is not None else None
+            with _lib.on_device(dev):
+                _lib.check(lib.gft_deform_backward_rows(_lib.raw_stream(dev), ctx.arch[0], ctx.arch[1], n, packed.data_ptr(), x_c.data_ptr(),
+                                                        t_c.data_ptr(), ctx.t_stride, ptr(gx), ptr(gs), work.data_ptr(),
+                                                        C.byref(_fill(_lib.DeformParams(), grads)), rows.data_ptr()))
+            last_backward_stats.update(points_processed=None, rows_on_device=rows)
+            return (None, None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[5:]))
         if ctx.lazy:
             n, saved, gx, gs = _recompute_rows(lib, ctx, n, packed, x_c, t_c, gx, gs)
             last_backward_stats["points_processed"] = n

@@ -123,6 +123,22 @@ int gft_deform_compact(void* hip_stream, int64_t n, int64_t k, const uint8_t* ma
                        const float* g_d_xyz, const float* g_d_sh, int32_t* idx, void* saved_c, float* g_d_xyz_c,
                        float* g_d_sh_c);
 
+/* The backward over the rows that count with NOTHING read back from the device: the rows whose upstream gradient row
+ * (g_d_xyz, g_d_sh) holds a value != 0 are marked, ranked and counted by kernels, their inputs and gradients gathered
+ * in row order, their activations computed by a saving forward over them alone (a point's activations do not depend on
+ * the batch it is in) and the backward run over them -- every launch sized for n, the capacity, with the extents taken from
+ * a plan a one-thread kernel writes from the count (surplus workgroups return at once).  The call neither blocks nor
+ * allocates, so it can be captured in a HIP graph and replayed on other gradients: the replay adapts to THEIR rows.
+ * For a forward that kept nothing (gft_deform_forward with saved = NULL): xyz [n,3], t and t_stride as the forward had
+ * them.  Gradients equal gft_deform_compact + gft_deform_backward over the same rows bit for bit (the same kernels on
+ * the same compacted rows; only the buffers' plane stride differs), i.e. the dense backward's up to summation order.
+ * work: gft_deform_rows_work_bytes(n) bytes, 256-byte aligned, contents irrelevant before and after.
+ * rows_out: device uint32 that receives the number of rows processed (may be NULL). */
+size_t gft_deform_rows_work_bytes(int64_t n);
+int gft_deform_backward_rows(void* hip_stream, int xyz_multires, int t_multires, int64_t n, const void* packed,
+                             const float* xyz, const float* t, int64_t t_stride, const float* g_d_xyz, const float* g_d_sh,
+                             void* work, const gft_deform_grads* grads, uint32_t* rows_out);
+
 #ifdef __cplusplus
 }
 #endif

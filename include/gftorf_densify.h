@@ -44,6 +44,9 @@ int gft_densify_stats(void* hip_stream, int64_t P, const float* viewspace_grad, 
  * scratch: gft_rows_rank_scratch_bytes(P) bytes. */
 size_t gft_rows_rank_scratch_bytes(int64_t P);
 int gft_rows_rank(void* hip_stream, int64_t P, const uint8_t* mask, int32_t* rank, void* scratch, int64_t* count);
+/* The same ranking with the count left on the device (*count_dev, a uint32) and nothing read back: the call does not
+ * block and can be captured in a HIP graph.  P > 0. */
+int gft_rows_rank_dev(void* hip_stream, int64_t P, const uint8_t* mask, int32_t* rank, void* scratch, uint32_t* count_dev);
 
 /* mask[i] = 1 if row i of a ([P, row_floats_a]) or of b ([P, row_floats_b]) holds a value != 0 (a NaN counts, -0 does
  * not), else 0; either tensor may be NULL.  The rows of a backward that have an upstream gradient -- what

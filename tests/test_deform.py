@@ -557,3 +557,104 @@ def test_activations_on_demand_give_the_saved_forwards_gradients():
         assert not st4["recomputed"]
     finally:
         D.lazy_save = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frac,n,shared_t", [(0.07, 20_000, True), (0.5, 12_345, False), (0.0, 9_000, True), (1.0, 10_000, True)])
+def test_rows_counted_on_the_device_give_the_blocking_selections_gradients(frac, n, shared_t):
+    """gft_deform_backward_rows: the rows with a gradient marked, ranked and counted by kernels, nothing read back, every
+    launch sized for the capacity with its extents from the plan a kernel writes.  Same kernels on the same compacted rows
+    as the blocking selection (gft_rows_rank's count on the host, then buffers of exactly that size): bit-identical
+    gradients, for few / half / no / all rows, one time for all points or one per point."""
+    from gftorf_amd import deform as D
+    dev = torch.device("cuda:0")
+    x, t = _inputs(n, 8, shared_t=shared_t)
+    xt, tt = torch.tensor(x, device=dev), torch.tensor(t, device=dev)
+    if shared_t:
+        tt = tt[:1].expand(n, -1)                                 # one time for all points (stride 0), as gaussian_model.py:171 expands it
+    g = torch.Generator().manual_seed(5)
+    keep = (torch.rand((n,), generator=g) < frac).to(dev)
+    g_dxyz = torch.randn((n, 3), generator=g).to(dev) * keep[:, None]
+    g_dsh = torch.randn((n, 16, 3), generator=g).to(dev) * keep[:, None, None]
+    if 0 < frac < 1:
+        g_dsh[torch.nonzero(keep)[:5, 0]] = 0                     # rows with a gradient in one of the two outputs only
+
+    def step(net):
+        net.zero_grad(set_to_none=True)
+        d_xyz, _, d_sh, _ = net(xt, tt)
+        torch.autograd.backward([d_xyz, d_sh], [g_dxyz, g_dsh])
+        return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, dict(D.last_backward_stats)
+
+    old = (D.device_row_count, D.lazy_save, D._SPARSE_MAX_FRACTION)
+    try:
+        # the blocking path on exactly the rows with a gradient: a forward that keeps nothing, rows recomputed
+        D.device_row_count, D.lazy_save, D._SPARSE_MAX_FRACTION = False, True, 2.0
+        ref_net, _ = _net(12, dev)
+        ref_net._save_state = {"fraction": 0.0}
+        ref, st = step(ref_net)
+        assert st["recomputed"] and st["points_processed"] == int(keep.sum())
+        D.device_row_count = True
+        net, _ = _net(12, dev)
+        got, st = step(net)
+        assert st["recomputed"] and int(st["rows_on_device"].item()) == int(keep.sum())
+        assert len(got) == len(ref) == 24
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+            if frac == 0.0:
+                assert not got[k].any(), k
+    finally:
+        D.device_row_count, D.lazy_save, D._SPARSE_MAX_FRACTION = old
+
+
+@pytest.mark.gpu
+def test_a_captured_backward_follows_the_rows_of_every_replay():
+    """Forward + backward captured in a HIP graph once (the row count stays on the device), replayed on upstream gradients
+    with other rows set: every replay's gradients are those of an eager call on the same gradients, bit for bit, and the
+    row count it leaves is that replay's."""
+    from gftorf_amd import deform as D
+    dev = torch.device("cuda:0")
+    n = 16_000
+    x, t = _inputs(n, 8, shared_t=True)
+    xt, tt = torch.tensor(x, device=dev), torch.tensor(t, device=dev)
+    g = torch.Generator().manual_seed(11)
+    full_xyz, full_sh = torch.randn((n, 3), generator=g).to(dev), torch.randn((n, 16, 3), generator=g).to(dev)
+    masks = [(torch.rand((n,), generator=g) < f).to(dev) for f in (0.3, 0.05, 0.0, 0.8)]
+    s_xyz, s_sh = torch.zeros_like(full_xyz), torch.zeros_like(full_sh)
+    assert D.device_row_count == "capture"
+    net, _ = _net(12, dev)
+    params = [p for p in net.parameters()]
+
+    def run():
+        d_xyz, _, d_sh, _ = net(xt, tt)
+        return torch.autograd.grad([d_xyz, d_sh], [p for p in params if p.requires_grad], [s_xyz, s_sh], allow_unused=True)
+
+    def set_mask(m):
+        s_xyz.copy_(full_xyz * m[:, None])
+        s_sh.copy_(full_sh * m[:, None, None])
+    set_mask(masks[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()                                                     # (warm-up outside the capture: allocations, LDS opt-ins)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = run()
+        rows = D.last_backward_stats["rows_on_device"]
+    old = D.device_row_count
+    try:
+        for m in masks + [masks[0]]:
+            set_mask(m)
+            graph.replay()
+            got = [None if c is None else c.clone() for c in captured]
+            assert int(rows.item()) == int(m.sum())
+            D.device_row_count = True
+            ref = run()
+            D.device_row_count = old
+            for a, b in zip(got, ref):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert torch.equal(a, b)
+    finally:
+        D.device_row_count = old
