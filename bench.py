@@ -758,7 +758,7 @@ def train_iteration_extra(dev, scene, steps=10, warmup=3, only_fused=False):
 
     from gftorf_amd import deform as deform_mod
     hip_ms = timed(build(True), steps, warmup)
-    net_rows = dict(deform_mod.last_backward_stats)
+    net_rows = deform_mod.backward_stats()
     if only_fused:          # (profiles/train_workload.py: the iteration of this package alone, for rocprofv3)
         return {"hip_ms": hip_ms, "network_backward_fraction": net_rows["points_processed"] / max(net_rows["points"], 1)}
     torch.cuda.empty_cache()

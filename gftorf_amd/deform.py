@@ -37,6 +37,16 @@ _SPARSE_MIN_POINTS = 8192        # below this the dense backward is launch-bound
 _SPARSE_MAX_FRACTION = 0.6       # above this the compaction costs more than it saves
 last_backward_stats = {"points": 0, "points_processed": 0, "recomputed": False}
 
+
+def backward_stats():
+    """``last_backward_stats`` with the row count as a number: a backward that counted its rows on the device
+    (``device_row_count``) leaves the count there (``rows_on_device``); this reads it (one blocking read)."""
+    st = dict(last_backward_stats)
+    rows = st.pop("rows_on_device", None)
+    if st.get("points_processed") is None:
+        st["points_processed"] = int(rows.item()) if rows is not None else 0
+    return st
+
 # Activations on demand.  A saving forward writes 8.4 KB per point for the backward (2.5 GB at 300 k points, a sixth of the
 # forward's time -- and of its energy: that kernel runs at the board's power limit).  When the last backward used few of
 # the rows (the usual training iteration: only Gaussians that a pixel blended carry a gradient), the next forward keeps
@@ -58,9 +68,39 @@ _LAZY_MAX_FRACTION = 0.25        # recomputing that share of the rows costs less
 # inputs, recomputes their activations and runs over them -- launches of the capacity whose surplus workgroups return at
 # once.  A captured iteration replayed on other gradients adapts to THEIR rows (the C3 loop from a graph: the backward
 # follows the share of Gaussians a pixel blends, 58 % -> 23 % over the run, instead of staying dense).  Gradients are those of
-# the blocking selection bit for bit (tests/test_deform.py).  "capture" (default): under capture only; True: always (no
-# blocking read in the eager loop either); False: never (a captured call saves its activations and runs dense).
-device_row_count = {"0": False, "1": True}.get(_os.environ.get("GFT_DEFORM_DEVICE_ROWS", ""), "capture")
+# the blocking selection bit for bit (tests/test_deform.py).
+#   "auto" (default): under capture always; eagerly whenever the work buffer (sized for ALL queried points: 17 KB each) stays
+#       below ``_DEVICE_ROWS_MAX_BYTES`` -- the share of rows with a gradient is then learnt WITHOUT a blocking read: every
+#       backward leaves its count in pinned memory and the next forward looks at whatever has arrived.  While that share is
+#       unknown or above ``_DEVICE_ROWS_MAX_FRACTION`` the forward saves its activations and the backward runs dense (and
+#       counts); below it the forward keeps nothing and the backward recomputes the rows that count.  No host read anywhere.
+#   "capture": under capture only (eagerly the blocking selection above);  True: always;  False: never (a captured call
+#       then saves its activations and runs dense).
+# ``GFT_DEFORM_DEVICE_ROWS`` = auto | capture | 1 | 0.
+device_row_count = {"0": False, "1": True, "capture": "capture", "auto": "auto"}.get(_os.environ.get("GFT_DEFORM_DEVICE_ROWS", ""), "auto")
+_DEVICE_ROWS_MAX_FRACTION = 0.6
+_DEVICE_ROWS_MAX_BYTES = 32 << 30
+
+
+def _peek_fraction(state):
+    """The share of rows the last counted backward used, if its count has reached the host by now (never waits)."""
+    pend = state.get("pending") if state is not None else None
+    if pend is not None and pend[1].query():
+        state["fraction"] = int(pend[0].item()) / float(max(pend[2], 1))
+        state["pending"] = None
+
+
+def _post_count(state, rows, n_all):
+    """Queues the device count's way to the host (pinned memory, no wait): the next forward's `_peek_fraction` reads it."""
+    if state is None or torch.cuda.is_current_stream_capturing():
+        return
+    pin = state.get("pin")
+    if pin is None:
+        pin = state["pin"] = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    pin.copy_(rows, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    state["pending"] = (pin, ev, n_all)
 
 
 def _param_list(mod):
@@ -119,9 +159,19 @@ class _DeformFn(torch.autograd.Function):
         # reads a row count, so a captured call saves its activations and runs the dense backward -- the same gradients up
         # to summation order)
         capturing = torch.cuda.is_current_stream_capturing()
-        dev_rows = bool(need_bw and sparse_backward and n >= _SPARSE_MIN_POINTS
-                        and (device_row_count is True or (device_row_count == "capture" and capturing)))
-        lazy = bool(need_bw and lazy_save and sparse_backward and n >= _SPARSE_MIN_POINTS and state is not None
+        sparse_ok = bool(need_bw and sparse_backward and n >= _SPARSE_MIN_POINTS)
+        # rows counted on the device (see device_row_count): "rows" = the forward keeps nothing, the backward recomputes the rows
+        # that count; "count" = the forward saves, the backward runs dense and only counts (the share is unknown or large)
+        dev_mode = None
+        if sparse_ok and device_row_count is not False:
+            if device_row_count is True or (capturing and device_row_count in ("capture", "auto")):
+                dev_mode = "rows"
+            elif device_row_count == "auto" and state is not None and lib.gft_deform_rows_work_bytes(n) <= _DEVICE_ROWS_MAX_BYTES:
+                _peek_fraction(state)
+                frac = state.get("fraction")
+                dev_mode = "rows" if (frac is not None and frac <= _DEVICE_ROWS_MAX_FRACTION and lazy_save) else "count"
+        dev_rows = dev_mode == "rows"
+        lazy = bool(sparse_ok and lazy_save and state is not None and dev_mode is None
                     and state.get("fraction") is not None and state["fraction"] <= _LAZY_MAX_FRACTION and not capturing) or dev_rows
         f32 = dict(device=dev, dtype=torch.float32)
         packed = torch.empty((lib.gft_deform_packed_bytes() // 4,), **f32)
@@ -140,6 +190,7 @@ class _DeformFn(torch.autograd.Function):
         ctx.state = state
         ctx.lazy = lazy
         ctx.dev_rows = dev_rows
+        ctx.dev_count = dev_mode == "count"
         if lazy:
             ctx.t_stride = t_stride
             ctx.save_for_backward(packed, x_c, t_c)
@@ -184,15 +235,22 @@ class _DeformFn(torch.autograd.Function):
                                                         t_c.data_ptr(), ctx.t_stride, ptr(gx), ptr(gs), work.data_ptr(),
                                                         C.byref(_fill(_lib.DeformParams(), grads)), rows.data_ptr()))
             last_backward_stats.update(points_processed=None, rows_on_device=rows)
+            _post_count(ctx.state, rows, n_all)
             return (None, None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[5:]))
+        if ctx.dev_count and (gx is not None or gs is not None):
+            # dense backward over the saved activations; the rows with a gradient are only counted (three small launches, the
+            # count on its way to pinned memory): the next forward decides by it
+            rows = _count_rows_on_device(lib, n, gx, gs, dev)
+            _post_count(ctx.state, rows, n_all)
+            last_backward_stats.pop("rows_on_device", None)
         if ctx.lazy:
             n, saved, gx, gs = _recompute_rows(lib, ctx, n, packed, x_c, t_c, gx, gs)
             last_backward_stats["points_processed"] = n
-        elif (sparse_backward and n >= _SPARSE_MIN_POINTS and (gx is not None or gs is not None)
+        elif (sparse_backward and n >= _SPARSE_MIN_POINTS and (gx is not None or gs is not None) and not ctx.dev_count
               and not torch.cuda.is_current_stream_capturing()):
             n, saved, gx, gs = _compact_rows(lib, n, saved, gx, gs)
             last_backward_stats["points_processed"] = n
-        if ctx.state is not None and n_all >= _SPARSE_MIN_POINTS and not torch.cuda.is_current_stream_capturing():
+        if ctx.state is not None and n_all >= _SPARSE_MIN_POINTS and not ctx.dev_count and not torch.cuda.is_current_stream_capturing():
             ctx.state["fraction"] = n / float(n_all)
         scratch = torch.empty((lib.gft_deform_scratch_bytes(n) // 4,), **f32)
         stream = _lib.raw_stream(dev)
@@ -203,6 +261,21 @@ class _DeformFn(torch.autograd.Function):
                                                scratch.data_ptr() if n else None,
                                                C.byref(_fill(_lib.DeformParams(), grads))))
         return (None, None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[5:]))
+
+
+def _count_rows_on_device(lib, n, gx, gs, dev):
+    """int32 [1] on the device: the number of rows whose upstream gradient holds a value != 0; nothing read back."""
+    mask = torch.empty((n,), device=dev, dtype=torch.uint8)
+    rank = torch.empty((n,), device=dev, dtype=torch.int32)
+    scratch = torch.empty((lib.gft_rows_rank_scratch_bytes(n),), device=dev, dtype=torch.uint8)
+    rows = torch.empty((1,), device=dev, dtype=torch.int32)
+    ptr0 = lambda t: t.data_ptr() if t is not None else None
+    with _lib.on_device(dev):
+        stream = _lib.raw_stream(dev)
+        _lib.check(lib.gft_rows_any_nonzero(stream, n, 3 if gx is not None else 0, ptr0(gx), 48 if gs is not None else 0, ptr0(gs),
+                                            mask.data_ptr()))
+        _lib.check(lib.gft_rows_rank_dev(stream, n, mask.data_ptr(), rank.data_ptr(), scratch.data_ptr(), rows.data_ptr()))
+    return rows
 
 
 def _rows_with_gradient(lib, n, gx, gs, dev):
@@ -323,7 +396,7 @@ class DeformNetwork(nn.Module):
         tensors of zeros -- what train.py:164 passes for a static scene, and what the renderer's additions and
         ``assemble_inputs`` take as well: no 128 bytes per point filled, read and given a gradient for nothing."""
         if not hasattr(self, "_save_state"):
-            self._save_state = {"fraction": None}      # share of the rows the last backward used (lazy_save)
+            self._save_state = {"fraction": None, "pending": None, "pin": None}      # share of the rows the last backward used
         d_xyz, d_sh = _DeformFn.apply(self.xyz_multires, self.t_multires, self._save_state, x, t, *_param_list(self))
         if zeros_as_scalars:
             return d_xyz, 0.0, d_sh, 0.0

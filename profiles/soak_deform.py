@@ -68,7 +68,7 @@ while time.time() - t0 < budget:
         e = max(rel(d_xyz.detach().cpu().numpy(), ref[0]), rel(d_sh.detach().cpu().numpy(), ref[2]))
         worst["forward_extreme" if out_of_range else "forward"] = max(worst.get("forward_extreme" if out_of_range else "forward", 0.0), e)
         torch.autograd.backward([d_xyz, d_sh], [torch.tensor(g_dxyz, device=dev), torch.tensor(g_dsh, device=dev)])
-        st = D.last_backward_stats
+        st = D.backward_stats()
         cases["recomputed" if st["recomputed"] else "saved"] += 1
         cases["dense"] += int(st["points_processed"] == n)
         gref = deform_ref.backward(params, x.astype(np.float64), t.astype(np.float64), g_dxyz, g_dsh, dtype=np.float64)

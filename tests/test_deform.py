@@ -416,14 +416,16 @@ def test_backward_over_rows_with_a_gradient_only(frac, n):
         g_dsh[only_xyz] = 0
 
     def grads(sparse):
-        D.sparse_backward = sparse
+        # (the blocking selection: rows counted by a host read; the rows counted on the device have their own tests below)
+        D.sparse_backward, old = sparse, D.device_row_count
+        D.device_row_count = False
         try:
             net.zero_grad(set_to_none=True)
             d_xyz, _, d_sh, _ = net(x, t)
             torch.autograd.backward([d_xyz, d_sh], [g_dxyz, g_dsh])
             return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, dict(D.last_backward_stats)
         finally:
-            D.sparse_backward = True
+            D.sparse_backward, D.device_row_count = True, old
     dense, st_d = grads(False)
     sparse, st_s = grads(True)
     assert st_d == {"points": n, "points_processed": n, "recomputed": False}
@@ -534,8 +536,9 @@ def test_activations_on_demand_give_the_saved_forwards_gradients():
         torch.autograd.backward([d_xyz, d_sh], list(up))
         return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, dict(D.last_backward_stats)
 
-    old = D.lazy_save
+    old, old_dev = D.lazy_save, D.device_row_count
     try:
+        D.device_row_count = "capture"                       # (eagerly the blocking selection: this test's subject)
         D.lazy_save = False
         ref_net, _ = _net(12, dev)
         ref_sparse, st = step(ref_net, sparse)
@@ -556,7 +559,7 @@ def test_activations_on_demand_give_the_saved_forwards_gradients():
         _, st4 = step(net, (g_dxyz, g_dsh))                  # ... and the next forward saves
         assert not st4["recomputed"]
     finally:
-        D.lazy_save = old
+        D.lazy_save, D.device_row_count = old, old_dev
 
 
 @pytest.mark.gpu
@@ -597,6 +600,7 @@ def test_rows_counted_on_the_device_give_the_blocking_selections_gradients(frac,
         net, _ = _net(12, dev)
         got, st = step(net)
         assert st["recomputed"] and int(st["rows_on_device"].item()) == int(keep.sum())
+        assert D.backward_stats()["points_processed"] == int(keep.sum())
         assert len(got) == len(ref) == 24
         for k in ref:
             assert torch.equal(got[k], ref[k]), k
@@ -620,7 +624,7 @@ def test_a_captured_backward_follows_the_rows_of_every_replay():
     full_xyz, full_sh = torch.randn((n, 3), generator=g).to(dev), torch.randn((n, 16, 3), generator=g).to(dev)
     masks = [(torch.rand((n,), generator=g) < f).to(dev) for f in (0.3, 0.05, 0.0, 0.8)]
     s_xyz, s_sh = torch.zeros_like(full_xyz), torch.zeros_like(full_sh)
-    assert D.device_row_count == "capture"
+    assert D.device_row_count == "auto"
     net, _ = _net(12, dev)
     params = [p for p in net.parameters()]
 
@@ -658,3 +662,59 @@ def test_a_captured_backward_follows_the_rows_of_every_replay():
                     assert torch.equal(a, b)
     finally:
         D.device_row_count = old
+
+
+@pytest.mark.gpu
+def test_the_eager_loop_learns_the_share_of_rows_without_a_host_read():
+    """device_row_count = "auto" (the default): the first forward saves and its backward runs dense and only counts; once a
+    count has reached pinned memory and says few rows carry a gradient the forward keeps nothing and the backward recomputes
+    those rows; when the gradients turn dense again the next forward (after the count arrived) saves again.  Gradients
+    equal the blocking selection's in every phase (dense phase: the dense backward's, bit for bit)."""
+    from gftorf_amd import deform as D
+    dev = torch.device("cuda:0")
+    n = 20_000
+    x, t = _inputs(n, 8, shared_t=True)
+    xt, tt = torch.tensor(x, device=dev), torch.tensor(t, device=dev)
+    g = torch.Generator().manual_seed(3)
+    g_dxyz = torch.randn((n, 3), generator=g).to(dev)
+    g_dsh = torch.randn((n, 16, 3), generator=g).to(dev)
+    few = (torch.rand((n,), generator=g) < 0.1).to(dev)
+    sparse = (g_dxyz * few[:, None], g_dsh * few[:, None, None])
+    dense = (g_dxyz, g_dsh)
+
+    def step(net, up):
+        net.zero_grad(set_to_none=True)
+        d_xyz, _, d_sh, _ = net(xt, tt)
+        torch.autograd.backward([d_xyz, d_sh], list(up))
+        torch.cuda.synchronize()                              # (so that the count HAS arrived when the next forward looks)
+        return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, D.backward_stats()
+
+    assert D.device_row_count == "auto"
+    old = D.device_row_count
+    try:
+        D.device_row_count = False
+        ref_net, _ = _net(12, dev)
+        D.sparse_backward = False
+        ref_sparse_dense, _ = step(ref_net, sparse)           # dense backward on the sparse gradients
+        ref_dense, _ = step(ref_net, dense)
+        D.sparse_backward = True
+        D.device_row_count = True
+        ref_rows, _ = step(ref_net, sparse)                   # rows counted on the device (equal to the blocking selection: test above)
+        D.device_row_count = "auto"
+        net, _ = _net(12, dev)
+        a, st = step(net, sparse)                             # share unknown: saves, dense, counts
+        assert not st["recomputed"] and st["points_processed"] == n
+        assert net._save_state["pending"] is not None         # (the count is on its way; the next forward reads it)
+        b, st = step(net, sparse)                             # few rows: keeps nothing, recomputes them
+        assert st["recomputed"] and st["points_processed"] == int(few.sum())
+        c, st = step(net, dense)                              # lazy forward, dense gradients: all rows recomputed
+        assert st["recomputed"] and st["points_processed"] == n
+        d, st = step(net, dense)                              # the count said "all": saves again
+        assert not st["recomputed"] and st["points_processed"] == n
+        for k in ref_dense:
+            assert torch.equal(a[k], ref_sparse_dense[k]), k
+            assert torch.equal(b[k], ref_rows[k]), k
+            assert torch.equal(d[k], ref_dense[k]), k
+            assert float((c[k] - ref_dense[k]).abs().max()) <= 2e-5 * float(ref_dense[k].abs().max()) + 1e-30, k
+    finally:
+        D.device_row_count, D.sparse_backward = old, True
