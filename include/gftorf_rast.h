@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GFT_ABI_VERSION 13
+#define GFT_ABI_VERSION 14
 
 /* compile-time constants of the reference (RAST/cuda_rasterizer/config.h:15-23) */
 #define GFT_NUM_CHANNELS 3
