@@ -1075,6 +1075,32 @@ def fog_extra(dev, steps=50, warmup=15):
             "path_roofline": {"algorithmic_bytes_per_step": whole, "frac": gbs(whole, ms) / HBM_PEAK_GBS}}
 
 
+def c3_loop_extra(dev, iterations=7000):
+    """BASELINE.json config 3 beside the headline: the torf `copier`-shaped optimisation loop of bench_loop.py (what
+    `--workload C3 [--graph]` times on its own), all 7000 iterations, eagerly and with the iteration's device work replayed
+    from a HIP graph per (SH degree, network on / off)."""
+    import torch
+    import bench_loop
+    out = {"what": "C3: " + bench_loop.C3["label"] + "; %d iterations, it/s of the whole loop" % iterations}
+    for key, graph in (("eager", False), ("graph", True)):
+        def region(step_fn, n):
+            for _ in range(20):
+                step_fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step_fn()
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0
+        secs, rep, info = bench_loop.run(dev, iterations, lambda: torch.cuda.synchronize(dev), region, graph=graph)
+        out[key + "_it_per_s"] = iterations / secs
+        out[key + "_ms_per_iteration"] = secs / iterations * 1e3
+        out[key + "_loss_first_last"] = [rep["loss_trace"][0][1], rep["loss_trace"][-1][1]]
+        del info
+        torch.cuda.empty_cache()
+    return out
+
+
 def graph_pair_extra(dev, steps=200, warmup=30):
     """The two rasterizer calls of a C3-shaped iteration (100 k Gaussians at 320 x 240, opacity 0.1, two cameras on the same
     Gaussians) with their backward: eagerly through the blocking flow (the reference's call pattern: at this size the host --
@@ -1299,7 +1325,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements beside the headline step")
-    ap.add_argument("--extras", default="all", help="comma list of extras to run (render_pair, varying_views, assemble_inputs, knn, "
+    ap.add_argument("--extras", default="all", help="comma list of extras to run (render_pair, varying_views, c3_loop, assemble_inputs, knn, "
                                                     "adam, deform_network, densify, train_iteration) or `all`")
     ap.add_argument("--spin-up", type=float, default=0.3, help="seconds of untimed steps before the warm-up")
     ap.add_argument("--torch-loss", action="store_true", help="--workload C3: the loss's SSIM and L2 terms as stock torch (eight "
@@ -1613,7 +1639,7 @@ def main():
             del state, step
             torch.cuda.empty_cache()
             table = [("train_iteration", lambda: train_iteration_extra(dev, scene)), ("render_pair", lambda: pair_extra(dev, scene)),
-                     ("varying_views", lambda: views_extra(dev, scene)), ("fog", lambda: fog_extra(dev)), ("graph_pair", lambda: graph_pair_extra(dev)), ("grads_kept", lambda: grads_kept_extra(dev, scene)), ("assemble_inputs", lambda: assemble_extra(dev)),
+                     ("varying_views", lambda: views_extra(dev, scene)), ("fog", lambda: fog_extra(dev)), ("graph_pair", lambda: graph_pair_extra(dev)), ("c3_loop", lambda: c3_loop_extra(dev)), ("grads_kept", lambda: grads_kept_extra(dev, scene)), ("assemble_inputs", lambda: assemble_extra(dev)),
                      ("knn", lambda: knn_extra(dev)), ("adam", lambda: adam_extra(dev)), ("deform_network", lambda: deform_extra(dev)),
                      ("densify", lambda: densify_extra(dev))]
             want = None if args.extras == "all" else set(args.extras.split(","))
@@ -1638,6 +1664,9 @@ def main():
             if "graph_pair" in ex:
                 out["c3_pair_eager_ms"] = ex["graph_pair"]["eager_blocking_ms"]
                 out["c3_pair_graph_replay_ms"] = ex["graph_pair"]["graph_replay_ms"]
+            if "c3_loop" in ex:
+                out["c3_loop_it_per_s"] = ex["c3_loop"]["eager_it_per_s"]                # BASELINE config 3 (bench.py --workload C3)
+                out["c3_loop_graph_it_per_s"] = ex["c3_loop"]["graph_it_per_s"]          # ... --graph
             if "fog" in ex:
                 out["fog_it_per_s"] = ex["fog"]["it_per_s"]
                 out["fog_ms_per_step"] = ex["fog"]["ms_per_step"]                        # (median of three legs)
