@@ -1492,7 +1492,7 @@ def main():
                                       "avg_launch_ms": phase.get("network_forward"),
                                       "note": "peak = 2500 TFLOP/s of fp16 MFMA at 2.4 GHz over the multiplies per fp32 product; the "
                                               "kernel runs at the board's power limit (1372-1376 W of 1400, engine clock 1.5-2.1 GHz "
-                                              "while it runs: profiles/r04_power_clock_samples.txt, DESIGN 10.1) -- the gap to the peak "
+                                              "while it runs: profiles/r04/r04_power_clock_samples.txt, DESIGN 10.1) -- the gap to the peak "
                                               "is energy per point, not issue slots; avg_launch_ms is the phase between two events "
                                               "(the walk plus the three pack kernels of the call)"}}
         exchange = {"in_the_timed_step": True, "collectives_per_step": fs.exchanges / max(state["it"], 1),
