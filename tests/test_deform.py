@@ -718,3 +718,53 @@ def test_the_eager_loop_learns_the_share_of_rows_without_a_host_read():
             assert float((c[k] - ref_dense[k]).abs().max()) <= 2e-5 * float(ref_dense[k].abs().max()) + 1e-30, k
     finally:
         D.device_row_count, D.sparse_backward = old, True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["xyz_only", "sh_only", "one_row", "all_but_one"])
+def test_rows_counted_on_the_device_edge_cases(which):
+    """One of the two outputs without an upstream gradient (NULL in the C call), a single row, all rows but one: the rows
+    counted on the device against the blocking selection, bit for bit."""
+    from gftorf_amd import deform as D
+    dev = torch.device("cuda:0")
+    n = 8_195                                                     # (not a multiple of any tile)
+    x, t = _inputs(n, 4, shared_t=False)
+    xt, tt = torch.tensor(x, device=dev), torch.tensor(t, device=dev)
+    g = torch.Generator().manual_seed(17)
+    keep = torch.rand((n,), generator=g) < 0.3
+    if which == "one_row":
+        keep = torch.zeros((n,), dtype=torch.bool)
+        keep[n - 2] = True
+    elif which == "all_but_one":
+        keep = torch.ones((n,), dtype=torch.bool)
+        keep[77] = False
+    keep = keep.to(dev)
+    g_dxyz = torch.randn((n, 3), generator=g).to(dev) * keep[:, None]
+    g_dsh = torch.randn((n, 16, 3), generator=g).to(dev) * keep[:, None, None]
+
+    def step(net):
+        net.zero_grad(set_to_none=True)
+        d_xyz, _, d_sh, _ = net(xt, tt)
+        if which == "xyz_only":
+            torch.autograd.backward([d_xyz], [g_dxyz])
+        elif which == "sh_only":
+            torch.autograd.backward([d_sh], [g_dsh])
+        else:
+            torch.autograd.backward([d_xyz, d_sh], [g_dxyz, g_dsh])
+        return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, D.backward_stats()
+
+    old = (D.device_row_count, D.lazy_save, D._SPARSE_MAX_FRACTION)
+    try:
+        D.device_row_count, D.lazy_save, D._SPARSE_MAX_FRACTION = False, True, 2.0
+        ref_net, _ = _net(12, dev)
+        ref_net._save_state = {"fraction": 0.0}
+        ref, st_ref = step(ref_net)
+        D.device_row_count = True
+        net, _ = _net(12, dev)
+        got, st = step(net)
+        assert st["points_processed"] == st_ref["points_processed"] == int(keep.sum())
+        assert set(got) == set(ref)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+    finally:
+        D.device_row_count, D.lazy_save, D._SPARSE_MAX_FRACTION = old
