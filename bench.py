@@ -1646,7 +1646,12 @@ def main():
             out["extras"] = {}
             for name, fn in table:
                 if want is None or name in want:
-                    out["extras"][name] = fn()
+                    # (a measurement beside the headline that fails says so in its place: the headline line still prints)
+                    try:
+                        out["extras"][name] = fn()
+                    except Exception as e:
+                        print("bench.py: extra `%s` failed: %s: %s" % (name, type(e).__name__, e), file=sys.stderr)
+                        out.setdefault("extras_failed", {})[name] = "%s: %s" % (type(e).__name__, str(e)[:300])
                     torch.cuda.empty_cache()
             # the training-representative figures beside the repeated-frame headline, at the top level of the line: shuffled
             # views (every frame another camera), a caller that keeps its gradients (dense gradient writes), the frame in
