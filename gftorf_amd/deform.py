@@ -155,9 +155,9 @@ class _DeformFn(torch.autograd.Function):
                 raise RuntimeError("DeformNetwork parameters must be float32 on %s" % (dev,))
             ps.append(p.detach().contiguous())
         need_bw = any(ctx.needs_input_grad[5:])      # all False under torch.no_grad()
-        # (while the stream is being captured into a graph nothing may be read from the device: the backward's row selection
-        # reads a row count, so a captured call saves its activations and runs the dense backward -- the same gradients up
-        # to summation order)
+        # (while the stream is being captured into a graph nothing may be read from the device: the blocking row selection
+        # reads a row count, so a captured call either counts its rows on the device -- below -- or, with
+        # device_row_count = False, saves its activations and runs the dense backward: the same gradients up to summation order)
         capturing = torch.cuda.is_current_stream_capturing()
         sparse_ok = bool(need_bw and sparse_backward and n >= _SPARSE_MIN_POINTS)
         # rows counted on the device (see device_row_count): "rows" = the forward keeps nothing, the backward recomputes the rows
