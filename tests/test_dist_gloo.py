@@ -12,6 +12,14 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A port the OS says is free right now (a fixed one derived from the pid met a port in use once in a while)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -39,7 +47,7 @@ def test_two_rank_frame_sharding_and_timing():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -108,7 +116,7 @@ def test_two_rank_allreduce_in_the_gradients_own_buffer():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker_deform_views, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -130,7 +138,7 @@ def test_two_rank_deform_gradient_allreduce():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker_deform, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -268,7 +276,7 @@ def test_two_rank_composed_frame_step():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker_frame_step, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
