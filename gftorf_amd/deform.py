@@ -224,6 +224,7 @@ class _DeformFn(torch.autograd.Function):
         gx = g_dxyz.float().contiguous() if g_dxyz is not None else None
         gs = g_dsh.float().contiguous() if g_dsh is not None else None
         last_backward_stats.update(points=n, points_processed=n, recomputed=ctx.lazy)
+        last_backward_stats.pop("rows_on_device", None)       # (a count an earlier backward left on the device)
         n_all = n
         if ctx.dev_rows:
             # rows counted on the device: one call, nothing read back (capturable)

@@ -624,7 +624,8 @@ def test_a_captured_backward_follows_the_rows_of_every_replay():
     full_xyz, full_sh = torch.randn((n, 3), generator=g).to(dev), torch.randn((n, 16, 3), generator=g).to(dev)
     masks = [(torch.rand((n,), generator=g) < f).to(dev) for f in (0.3, 0.05, 0.0, 0.8)]
     s_xyz, s_sh = torch.zeros_like(full_xyz), torch.zeros_like(full_sh)
-    assert D.device_row_count == "auto"
+    if os.environ.get("GFT_DEFORM_DEVICE_ROWS", "") in ("", "auto"):
+        assert D.device_row_count == "auto"                       # (the default: under capture always)
     net, _ = _net(12, dev)
     params = [p for p in net.parameters()]
 
@@ -689,7 +690,6 @@ def test_the_eager_loop_learns_the_share_of_rows_without_a_host_read():
         torch.cuda.synchronize()                              # (so that the count HAS arrived when the next forward looks)
         return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, D.backward_stats()
 
-    assert D.device_row_count == "auto"
     old = D.device_row_count
     try:
         D.device_row_count = False
